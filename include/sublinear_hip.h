@@ -1,0 +1,247 @@
+/*
+ * sublinear_hip.h — C ABI of the MI355X-native push / Neumann-series solver.
+ *
+ * This is the drop-in boundary for ONE hot path of ruvnet/sublinear-time-solver:
+ * the CSR residual-push SpMV + per-row diagonal normalisation + frontier
+ * compaction that sits under the crate's `solve()` / `estimateEntry()` surface.
+ * A Rust (cgo / ctypes / N-API ...) binding needs only this header; there are no
+ * C++ or torch types in any signature.  INTEGRATION.md shows the Rust shim.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the reference root, @ 2025-09-19).
+ *
+ * Conventions
+ *   - every function returns sl_status (0 = OK); nothing throws or aborts across
+ *     the ABI; sl_last_error_message() gives the detail text of the calling
+ *     thread's last failure.
+ *   - pointers are HOST pointers unless the parameter is documented as device
+ *     memory or the call takes an `sl_mem` selector.
+ *   - sl_matrix owns its device copies (uploaded/converted once at create) and is
+ *     immutable afterwards: it may be shared by concurrent solves.
+ *   - all arithmetic is IEEE binary64, indices are uint32 (types.rs:19-22:
+ *     Precision = f64, IndexType = u32).
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     returns SL_DEVICE_ERROR.
+ */
+#ifndef SUBLINEAR_HIP_H
+#define SUBLINEAR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SL_ABI_VERSION 1
+
+/* ---- status codes: 1:1 with SolverError variants (src/error.rs:16-140) ---------- */
+typedef enum {
+    SL_OK = 0,
+    SL_NOT_DIAGONALLY_DOMINANT = 1, /* MatrixNotDiagonallyDominant  error.rs:18 */
+    SL_NUMERICAL_INSTABILITY = 2,   /* NumericalInstability         error.rs:28 */
+    SL_CONVERGENCE_FAILURE = 3,     /* ConvergenceFailure           error.rs:38 */
+    SL_INVALID_INPUT = 4,           /* InvalidInput                 error.rs:50 */
+    SL_DIMENSION_MISMATCH = 5,      /* DimensionMismatch            error.rs:58 */
+    SL_UNSUPPORTED_FORMAT = 6,      /* UnsupportedMatrixFormat      error.rs:68 */
+    SL_ALLOCATION = 7,              /* MemoryAllocationError        error.rs:78 */
+    SL_INDEX_OUT_OF_BOUNDS = 8,     /* IndexOutOfBounds             error.rs:86 */
+    SL_INVALID_SPARSE_MATRIX = 9,   /* InvalidSparseMatrix          error.rs:96 */
+    SL_ALGORITHM_ERROR = 10,        /* AlgorithmError               error.rs:104 */
+    SL_DEVICE_ERROR = 11            /* new: HIP / RCCL runtime failure */
+} sl_status;
+
+typedef enum { SL_MEM_HOST = 0, SL_MEM_DEVICE = 1 } sl_mem;
+
+/* summation order of one row's dot product */
+typedef enum {
+    SL_ORDER_CSR_SEQUENTIAL = 0, /* CSRStorage::multiply_vector, matrix/sparse.rs:187-203 */
+    SL_ORDER_SIMD4 = 1           /* simd_ops::matrix_vector_multiply_simd, simd_ops.rs:20-88 */
+} sl_order;
+
+typedef enum {
+    SL_START_ZERO = 0,              /* SolverOptions.initial_guess = Some(zeros): exact series  */
+    SL_START_REFERENCE_DEFAULT = 1, /* initial_guess = None: x0 = D^-1 b (neumann.rs:197-208)   */
+    SL_START_INITIAL_GUESS = 2      /* caller-provided warm start                               */
+} sl_start;
+
+typedef enum {
+    SL_RESIDUAL_TRUE = 0,            /* ||A x - b||_2                                            */
+    SL_RESIDUAL_REFERENCE_SCALED = 1 /* ||A x - D^-1 b||_2, the quirk of neumann.rs:302-318      */
+} sl_residual;
+
+typedef struct sl_matrix sl_matrix; /* opaque, device resident */
+
+/* matrix create flags */
+#define SL_MATRIX_DEFAULT 0u
+#define SL_MATRIX_WITH_TRANSPOSE 1u /* also build the column-structure needed by push / estimateEntry */
+#define SL_MATRIX_KEEP_CSR 2u       /* keep the raw CSR arrays on the device next to the slice layout */
+
+/* ---- library ------------------------------------------------------------------- */
+int sl_abi_version(void);
+const char *sl_last_error_message(void);
+const char *sl_status_string(sl_status s);
+sl_status sl_device_count(int *count);
+sl_status sl_set_device(int device);
+/* all launches of the calling thread go to `hip_stream` (a hipStream_t); NULL = default stream */
+sl_status sl_set_stream(void *hip_stream);
+sl_status sl_synchronize(void);
+
+/* ---- a1 / a3: matrices ---------------------------------------------------------
+ * replaces SparseMatrix::from_triplets (matrix/mod.rs:160-199) + COOStorage::from_triplets
+ * (sparse.rs:530-548) + CSRStorage::from_coo (sparse.rs:80-132): bounds / finiteness
+ * validation in input order, exact zeros dropped, STABLE sort by (row, col),
+ * duplicates kept as separate entries. */
+sl_status sl_matrix_create_from_triplets(uint64_t n_triplets, const uint64_t *rows, const uint64_t *cols,
+                                         const double *values, uint64_t n_rows, uint64_t n_cols,
+                                         uint32_t flags, sl_matrix **out);
+/* adopts an existing CSRStorage {values, col_indices, row_ptr} (sparse.rs:16-23) —
+ * what `SparseMatrix::as_csr` hands out.  `row_offset` > 0 makes this the row slice
+ * [row_offset, row_offset + n_rows) of a larger square system (multi-GPU row-range
+ * partition; column ids stay global, n_cols = global dimension). */
+sl_status sl_matrix_create_csr(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, const uint32_t *row_ptr,
+                               const uint32_t *col_idx, const double *values, sl_mem where,
+                               uint64_t row_offset, uint32_t flags, sl_matrix **out);
+void sl_matrix_destroy(sl_matrix *m);
+
+typedef struct {
+    uint64_t n_rows, n_cols, nnz, row_offset;
+    uint64_t padded_nnz;      /* entries stored in the slice layout (>= nnz) */
+    uint64_t n_slices;        /* 64-row slices */
+    uint64_t device_bytes;    /* HBM held by this matrix */
+    uint32_t max_row_nnz, min_row_nnz;
+    uint32_t uniform_width;   /* != 0: every row has exactly this many entries */
+    uint32_t has_transpose;
+} sl_matrix_info;
+sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info);
+/* download the CSR arrays back to the host (needs SL_MATRIX_KEEP_CSR); for tests / ingest */
+sl_status sl_matrix_download_csr(const sl_matrix *m, uint32_t *row_ptr, uint32_t *col_idx, double *values);
+
+/* a6: SparseMatrix::is_diagonally_dominant (matrix/mod.rs:467-485), weak ROW dominance */
+sl_status sl_matrix_is_diagonally_dominant(const sl_matrix *m, int *is_dd);
+/* a7 (first half): D^-1 with the reference's rejection rules (neumann.rs:172-188):
+ * missing diagonal or |d| < 1e-14 -> SL_INVALID_SPARSE_MATRIX.  dinv: n_rows doubles. */
+sl_status sl_matrix_diagonal_inverse(const sl_matrix *m, double *dinv, sl_mem where);
+
+/* ---- a2 / a3 / a5: primitives ----------------------------------------------------
+ * y = A x — Matrix::multiply_vector (matrix/mod.rs:415-439) in either summation order. */
+sl_status sl_spmv(const sl_matrix *m, const double *x, double *y, sl_order order, sl_mem where);
+/* simd_ops::dot_product_simd / axpy_simd (simd_ops.rs:116-189), solver::utils::l2_norm
+ * (solver/mod.rs:369-371).  Device reductions use a fixed tree: run-to-run
+ * deterministic, equal to the sequential CPU sum to rounding (not bitwise). */
+sl_status sl_dot(uint64_t n, const double *x, const double *y, double *out, sl_mem where);
+sl_status sl_axpy(uint64_t n, double alpha, const double *x, double *y, sl_mem where);
+sl_status sl_l2_norm(uint64_t n, const double *x, double *out, sl_mem where);
+
+/* ---- a8 / a9: the fused Neumann step (device pointers only) -------------------------
+ * One pass of NeumannState::apply_iteration_matrix (neumann.rs:280-299) +
+ * `solution += term` and the term norm of compute_next_term (:264-274):
+ *     t_out_i = t_in[i0+i] - dinv_i * (A t_in)_i ;  x_i += t_out_i ;  *norm2 = sum t_out_i^2
+ * t_in has n_cols entries (global), t_out / x / dinv have n_rows entries (local slice;
+ * i0 = row_offset).  Per-row arithmetic is bit-identical to the reference's scalar
+ * loops (product rounded, then added, column order).  norm2 is a device double. */
+sl_status sl_neumann_step(const sl_matrix *m, const double *dinv, const double *t_in, double *t_out,
+                          double *x, double *norm2, sl_order order);
+/* same launch sequence repeated `steps` times with ping-pong buffers t_a -> t_b -> t_a ...
+ * bracketed by HIP events on the launch stream; *elapsed_ms is the device time.
+ * After the call the newest term is in t_a when `steps` is even, t_b when odd. */
+sl_status sl_neumann_run_steps(const sl_matrix *m, const double *dinv, double *t_a, double *t_b, double *x,
+                               double *norm2, sl_order order, uint64_t steps, float *elapsed_ms);
+
+/* ---- a7..a12: NeumannSolver::solve (neumann.rs:469-555) --------------------------- */
+typedef struct {
+    double tolerance;        /* SolverOptions.tolerance        solver/mod.rs:47-62  (1e-6)  */
+    uint64_t max_iterations; /* SolverOptions.max_iterations                         (1000) */
+    uint64_t max_terms;      /* NeumannSolver.max_terms        neumann.rs:58-60      (50)   */
+    double series_tolerance; /* NeumannSolver.series_tolerance                       (1e-8) */
+    int32_t order;           /* sl_order    */
+    int32_t start;           /* sl_start    */
+    int32_t residual;        /* sl_residual */
+    int32_t mem;             /* sl_mem of b / initial_guess / x_out */
+    int32_t collect_stats;   /* SolverOptions.collect_stats */
+    int32_t compute_error_bounds; /* SolverOptions.compute_error_bounds (neumann.rs:321-347) */
+} sl_neumann_options;
+void sl_neumann_options_default(sl_neumann_options *o);
+
+typedef struct {
+    uint64_t iterations;     /* SolverResult.iterations */
+    uint64_t terms_computed;
+    uint64_t matvec_count;   /* SolverStats.matvec_count */
+    double residual_norm;    /* SolverResult.residual_norm */
+    double last_term_norm;
+    double error_bound;      /* ErrorBounds::upper_bound_only, < 0 when not computed */
+    double total_time_ms;    /* SolverStats.total_time_ms (host wall) */
+    double device_time_ms;   /* HIP-event time of the iteration loop */
+    uint64_t bytes_moved;    /* algorithmic HBM bytes of the loop */
+    int32_t converged;       /* SolverResult.converged */
+    int32_t series_converged;
+} sl_neumann_result;
+
+/* x_out (n_rows) is always written, also on SL_CONVERGENCE_FAILURE (the reference drops
+ * it, neumann.rs:523-530).  term_norms may be NULL, else receives one l2 norm per term
+ * (capacity max_terms).  initial_guess is read only for SL_START_INITIAL_GUESS. */
+sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *initial_guess,
+                           const sl_neumann_options *opts, double *x_out, double *term_norms,
+                           sl_neumann_result *result);
+
+/* ---- (a-P) / a13 / a14: synchronous thresholded residual push ------------------------
+ * The data-parallel member of the reference's push family — ForwardPushSolver::push_node
+ * (solver/forward_push.rs:179-216) and TS solveForwardPush (src/core/solver.ts:437-522):
+ * invariant r = b - A x; every round pushes all rows with |r_i * dinv_i| >= theta
+ * (frontier in ascending index order, built by wavefront ballot / prefix scan):
+ *     delta_i = r_i * dinv_i ;  x_i += delta_i ;  r -= A delta  (row-wise, column order)
+ * Needs SL_MATRIX_WITH_TRANSPOSE (candidate-row expansion walks columns of A). */
+typedef struct {
+    double theta;            /* frontier threshold                                  */
+    uint64_t max_rounds;     /* ForwardPushConfig.max_pushes analogue, per round    */
+    int32_t order;           /* sl_order */
+    int32_t mem;             /* sl_mem of b / x / r */
+    double dense_switch;     /* frontier fraction above which a round runs the dense kernel (default 1/16) */
+    int32_t sparse_rhs;      /* != 0: b is given as (b_idx, b_val) pairs — see sl_push_solve_sparse */
+    int32_t reserved;
+} sl_push_options;
+void sl_push_options_default(sl_push_options *o);
+
+typedef struct {
+    uint64_t rounds;
+    uint64_t pushes;         /* sum of |F| */
+    uint64_t rows_touched;   /* sum of |candidate rows| */
+    uint64_t dense_rounds;
+    double residual_norm;    /* l2(r) at exit */
+    double device_time_ms;
+    int32_t converged;       /* frontier became empty */
+    int32_t reserved;
+} sl_push_result;
+
+/* x: in = x0 / out = solution; r_out: residual at exit (may be NULL).
+ * frontier_log (may be NULL): per round, |F| followed by the ascending indices, up to
+ * frontier_cap words; *frontier_words = words written. */
+sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_options *opts, double *x,
+                        double *r_out, uint32_t *frontier_log, uint64_t frontier_cap,
+                        uint64_t *frontier_words, sl_push_result *result);
+
+/* ---- estimateEntry (src/core/solver.ts:550-659; Rust analogue
+ * ForwardPushSolver::query_single_entry, forward_push.rs:224-231) -------------------------
+ * x_row = e_row^T A^-1 b by local push on A^T from e_row: y ~ A^-T e_row, estimate = y.b,
+ * |x_row - estimate| <= ||r_y||_1 * ||x||_inf.  `m` must be created WITH_TRANSPOSE.
+ * Work is proportional to the rows the push touches, not to n. */
+typedef struct {
+    double estimate;
+    double residual_l1;      /* ||r_y||_1 : multiply by a bound on ||x||_inf for the error bound */
+    uint64_t rounds, pushes, rows_touched;
+    double device_time_ms;
+    int32_t converged;
+    int32_t reserved;
+} sl_estimate_result;
+sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, uint64_t row,
+                            double theta, uint64_t max_rounds, sl_estimate_result *result);
+
+/* ---- synthetic inputs, generated in HBM (bench / tests) -------------------
+ * S-DD(n, k, seed, w): rows [row_lo, row_hi) of the seeded diagonally dominant system;
+ * writes device arrays: row_ptr (rows+1), col_idx / values (rows*k), b (rows). */
+sl_status sl_synth_sdd_device(uint64_t n, uint32_t k, uint64_t seed, uint64_t half_bandwidth,
+                              uint64_t row_lo, uint64_t row_hi, uint32_t *row_ptr, uint32_t *col_idx,
+                              double *values, double *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBLINEAR_HIP_H */

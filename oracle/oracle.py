@@ -1,0 +1,291 @@
+"""ctypes wrapper of the CPU oracle (oracle/sl_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never by the product package (sublinear_time_solver_amd/).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+u64, u32, i32, f64 = C.c_uint64, C.c_uint32, C.c_int32, C.c_double
+vp = C.c_void_p
+
+STATUS = {0: "OK", 1: "MatrixNotDiagonallyDominant", 2: "NumericalInstability", 3: "ConvergenceFailure",
+          4: "InvalidInput", 5: "DimensionMismatch", 6: "UnsupportedMatrixFormat", 7: "MemoryAllocationError",
+          8: "IndexOutOfBounds", 9: "InvalidSparseMatrix", 10: "AlgorithmError"}
+ORDER_SEQ, ORDER_SIMD4 = 0, 1
+START_ZERO, START_REFERENCE_DEFAULT, START_INITIAL_GUESS = 0, 1, 2
+RESIDUAL_TRUE, RESIDUAL_REFERENCE_SCALED = 0, 1
+
+
+class NeumannOpts(C.Structure):
+    _fields_ = [("tolerance", f64), ("max_iterations", u64), ("max_terms", u64), ("series_tolerance", f64),
+                ("order", i32), ("start", i32), ("residual", i32), ("threads", i32)]
+
+
+class NeumannResult(C.Structure):
+    _fields_ = [("iterations", u64), ("terms_computed", u64), ("matvec_count", u64), ("residual_norm", f64),
+                ("converged", i32), ("series_converged", i32)]
+
+
+class PushOpts(C.Structure):
+    _fields_ = [("theta", f64), ("max_rounds", u64), ("order", i32), ("pad", i32)]
+
+
+class PushResult(C.Structure):
+    _fields_ = [("rounds", u64), ("pushes", u64), ("rows_touched", u64), ("residual_norm", f64),
+                ("converged", i32), ("pad", i32)]
+
+
+class AclOpts(C.Structure):
+    _fields_ = [("alpha", f64), ("epsilon", f64), ("max_pushes", u64), ("queue_threshold", f64),
+                ("adaptive_threshold", i32), ("pad", i32)]
+
+
+class AclResult(C.Structure):
+    _fields_ = [("push_count", u64), ("nodes_visited", u64), ("residual_norm", f64)]
+
+
+class TsPushResult(C.Structure):
+    _fields_ = [("iterations", u64), ("residual", f64), ("converged", i32), ("pad", i32)]
+
+
+_libs = {}
+
+
+def build(fast: bool = False) -> Path:
+    target = "liboracle_fast.so" if fast else "liboracle.so"
+    subprocess.run(["make", "-C", str(_DIR), target], check=True, capture_output=True)
+    return _DIR / target
+
+
+def lib(fast: bool = False) -> C.CDLL:
+    key = bool(fast)
+    if key not in _libs:
+        path = _DIR / ("liboracle_fast.so" if fast else "liboracle.so")
+        src_mtime = max((_DIR / "sl_oracle.c").stat().st_mtime, (_DIR / "sl_oracle.h").stat().st_mtime)
+        if not path.exists() or path.stat().st_mtime < src_mtime:
+            build(fast)
+        l = C.CDLL(str(path))
+        l.orc_dot_simd4.restype = f64
+        l.orc_dot_sequential.restype = f64
+        l.orc_l2_norm.restype = f64
+        l.orc_l1_norm.restype = f64
+        l.orc_linf_norm.restype = f64
+        _libs[key] = l
+    return _libs[key]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+class OracleError(RuntimeError):
+    def __init__(self, status):
+        self.status = status
+        self.kind = STATUS.get(status, "Unknown")
+        super().__init__(self.kind)
+
+
+def csr_from_triplets(rows_idx, cols_idx, vals, rows, cols):
+    r = np.ascontiguousarray(rows_idx, dtype=np.uint64)
+    c = np.ascontiguousarray(cols_idx, dtype=np.uint64)
+    v = _f(vals)
+    n = v.size
+    rp = np.zeros(rows + 1, dtype=np.uint32)
+    ci = np.zeros(max(n, 1), dtype=np.uint32)
+    va = np.zeros(max(n, 1), dtype=np.float64)
+    nnz = u64(0)
+    st = lib().orc_csr_from_triplets(u64(n), _p(r), _p(c), _p(v), u64(rows), u64(cols), _p(rp), _p(ci), _p(va), C.byref(nnz))
+    if st:
+        raise OracleError(st)
+    return rp, ci[: nnz.value].copy(), va[: nnz.value].copy()
+
+
+def csr_get(rp, ci, va, r, c):
+    out = f64(0)
+    rows = len(rp) - 1
+    ok = lib().orc_csr_get(_p(_u32(rp)), _p(_u32(ci)), _p(_f(va)), u64(rows), u64(r), u64(c), C.byref(out))
+    return out.value if ok else None
+
+
+def spmv(rp, ci, va, x, order=ORDER_SEQ, threads=1, fast=False):
+    rp, ci, va, x = _u32(rp), _u32(ci), _f(va), _f(x)
+    rows = rp.size - 1
+    y = np.empty(rows, dtype=np.float64)
+    l = lib(fast)
+    if order == ORDER_SIMD4:
+        l.orc_spmv_simd4(u64(rows), _p(rp), _p(ci), _p(va), _p(x), _p(y))
+    elif threads > 1:
+        l.orc_spmv_parallel(u64(rows), _p(rp), _p(ci), _p(va), _p(x), _p(y), C.c_int(threads))
+    else:
+        l.orc_spmv_csr_sequential(u64(rows), _p(rp), _p(ci), _p(va), _p(x), _p(y))
+    return y
+
+
+def dot_simd4(x, y):
+    x, y = _f(x), _f(y)
+    return lib().orc_dot_simd4(u64(x.size), _p(x), _p(y))
+
+
+def dot_sequential(x, y):
+    x, y = _f(x), _f(y)
+    return lib().orc_dot_sequential(u64(x.size), _p(x), _p(y))
+
+
+def axpy(alpha, x, y):
+    x = _f(x)
+    y = _f(y).copy()
+    lib().orc_axpy(u64(x.size), f64(alpha), _p(x), _p(y))
+    return y
+
+
+def l2_norm(v):
+    v = _f(v)
+    return lib().orc_l2_norm(u64(v.size), _p(v))
+
+
+def l1_norm(v):
+    v = _f(v)
+    return lib().orc_l1_norm(u64(v.size), _p(v))
+
+
+def linf_norm(v):
+    v = _f(v)
+    return lib().orc_linf_norm(u64(v.size), _p(v))
+
+
+def is_diagonally_dominant(rp, ci, va):
+    rp, ci, va = _u32(rp), _u32(ci), _f(va)
+    return bool(lib().orc_is_diagonally_dominant(u64(rp.size - 1), _p(rp), _p(ci), _p(va)))
+
+
+def neumann_init(rp, ci, va, b, cols=None):
+    rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
+    rows = rp.size - 1
+    cols = rows if cols is None else cols
+    dinv = np.zeros(rows)
+    rhs = np.zeros(rows)
+    st = lib().orc_neumann_init(u64(rows), u64(cols), _p(rp), _p(ci), _p(va), u64(b.size), _p(b), _p(dinv), _p(rhs))
+    if st:
+        raise OracleError(st)
+    return dinv, rhs
+
+
+def neumann_solve(rp, ci, va, b, *, tolerance=1e-6, max_iterations=1000, max_terms=50, series_tolerance=1e-8,
+                  order=ORDER_SEQ, start=START_ZERO, residual=RESIDUAL_TRUE, threads=1, initial_guess=None,
+                  cols=None, fast=False, raise_on_error=True):
+    rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
+    rows = rp.size - 1
+    cols = rows if cols is None else cols
+    o = NeumannOpts(tolerance, max_iterations, max_terms, series_tolerance, order, start, residual, threads)
+    x = np.zeros(rows)
+    term = np.zeros(rows)
+    tn = np.zeros(max(max_terms, 1))
+    res = NeumannResult()
+    g = None
+    if initial_guess is not None:
+        g = _f(initial_guess)
+        o.start = START_INITIAL_GUESS
+    st = lib(fast).orc_neumann_solve(u64(rows), u64(cols), _p(rp), _p(ci), _p(va), u64(b.size), _p(b), _p(g), C.byref(o),
+                                     _p(x), _p(term), _p(tn), C.byref(res))
+    out = {"status": st, "kind": STATUS.get(st), "x": x, "term": term, "term_norms": tn[: res.terms_computed].copy(),
+           "iterations": res.iterations, "terms": res.terms_computed, "matvec_count": res.matvec_count,
+           "residual_norm": res.residual_norm, "converged": bool(res.converged),
+           "series_converged": bool(res.series_converged)}
+    if st and raise_on_error and st != 3:
+        raise OracleError(st)
+    return out
+
+
+def push_sync_solve(rp, ci, va, b, theta, max_rounds=100000, order=ORDER_SEQ, x0=None, log_cap=0):
+    rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
+    n = rp.size - 1
+    x = np.zeros(n) if x0 is None else _f(x0).copy()
+    r = np.zeros(n)
+    o = PushOpts(theta, max_rounds, order, 0)
+    res = PushResult()
+    log = np.zeros(max(log_cap, 1), dtype=np.uint32)
+    words = u64(0)
+    st = lib().orc_push_sync_solve(u64(n), _p(rp), _p(ci), _p(va), _p(b), C.byref(o), _p(x), _p(r),
+                                   _p(log) if log_cap else None, u64(log_cap), C.byref(words), C.byref(res))
+    if st:
+        raise OracleError(st)
+    return {"x": x, "r": r, "rounds": res.rounds, "pushes": res.pushes, "rows_touched": res.rows_touched,
+            "residual_norm": res.residual_norm, "converged": bool(res.converged),
+            "frontier_log": log[: words.value].copy()}
+
+
+def acl_push(rp, ci, w, sources, *, alpha=0.15, epsilon=1e-6, max_pushes=1_000_000, queue_threshold=1e-8,
+             adaptive_threshold=True, backward=False):
+    rp, ci, w = _u32(rp), _u32(ci), _f(w)
+    n = rp.size - 1
+    src = np.ascontiguousarray(sources, dtype=np.uint64)
+    est = np.zeros(max(n, 1))
+    res = np.zeros(max(n, 1))
+    o = AclOpts(alpha, epsilon, max_pushes, queue_threshold, int(adaptive_threshold), 0)
+    out = AclResult()
+    fn = lib().orc_acl_backward_push if backward else lib().orc_acl_forward_push
+    st = fn(u64(n), _p(rp), _p(ci), _p(w), u64(src.size), _p(src), C.byref(o), _p(est), _p(res), C.byref(out))
+    if st:
+        raise OracleError(st)
+    return {"estimate": est[:n], "residual": res[:n], "push_count": out.push_count,
+            "nodes_visited": out.nodes_visited, "residual_norm": out.residual_norm}
+
+
+def csr_transpose(rp, ci, va, ncols=None):
+    rp, ci, va = _u32(rp), _u32(ci), _f(va)
+    nrows = rp.size - 1
+    ncols = nrows if ncols is None else ncols
+    trp = np.zeros(ncols + 1, dtype=np.uint32)
+    tci = np.zeros(max(va.size, 1), dtype=np.uint32)
+    tv = np.zeros(max(va.size, 1))
+    lib().orc_csr_transpose(u64(nrows), u64(ncols), _p(rp), _p(ci), _p(va), _p(trp), _p(tci), _p(tv))
+    return trp, tci[: va.size], tv[: va.size]
+
+
+def ts_forward_push(rp, ci, va, b, epsilon, max_iterations):
+    rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
+    n = rp.size - 1
+    x = np.zeros(n)
+    r = np.zeros(n)
+    res = TsPushResult()
+    st = lib().orc_ts_forward_push(u64(n), _p(rp), _p(ci), _p(va), _p(b), f64(epsilon), u64(max_iterations), _p(x), _p(r), C.byref(res))
+    return {"status": st, "x": x, "r": r, "iterations": res.iterations, "residual": res.residual, "converged": bool(res.converged)}
+
+
+def ts_lcg(seed, count):
+    out = np.zeros(count)
+    lib().orc_ts_lcg(u32(seed), u64(count), _p(out))
+    return out
+
+
+def ts_random_walk_estimate(rp, ci, va, b, row, epsilon, seed):
+    rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
+    n = rp.size - 1
+    mean, var, ns = f64(0), f64(0), u64(0)
+    st = lib().orc_ts_random_walk_estimate(u64(n), _p(rp), _p(ci), _p(va), _p(b), u64(row), f64(epsilon), u32(seed),
+                                           C.byref(mean), C.byref(var), C.byref(ns))
+    if st:
+        raise OracleError(st)
+    return mean.value, var.value, ns.value
+
+
+def dense_to_csr(A):
+    """SparseMatrix::from_dense semantics (matrix/mod.rs:204-223) via the triplet path."""
+    A = np.asarray(A, dtype=np.float64)
+    rr, cc = np.nonzero(A)
+    return csr_from_triplets(rr, cc, A[rr, cc], A.shape[0], A.shape[1])

@@ -1,0 +1,673 @@
+/*
+ * sl_oracle.c — CPU restatement of the reference's push / Neumann hot path.
+ * TEST INFRASTRUCTURE ONLY — see sl_oracle.h.  Build: make -C oracle
+ * (gcc -O2 -ffp-contract=off -fno-fast-math; no FMA contraction, no reassociation).
+ *
+ * Reference = ruvnet/sublinear-time-solver @ 2025-09-19; citations are paths
+ * relative to the reference root.
+ */
+#include "sl_oracle.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ a1 -- */
+
+typedef struct { uint64_t r; uint32_t c; double v; } trip_t;
+
+/* stable merge sort by (row, col): Vec::sort_by is a stable sort, sparse.rs:96 */
+static void trip_msort(trip_t *a, trip_t *tmp, uint64_t n)
+{
+    if (n < 2) return;
+    uint64_t h = n / 2;
+    trip_msort(a, tmp, h);
+    trip_msort(a + h, tmp, n - h);
+    uint64_t i = 0, j = h, k = 0;
+    while (i < h && j < n) {
+        /* take right only if strictly smaller => stable */
+        int right_less = (a[j].r < a[i].r) || (a[j].r == a[i].r && a[j].c < a[i].c);
+        tmp[k++] = right_less ? a[j++] : a[i++];
+    }
+    while (i < h) tmp[k++] = a[i++];
+    while (j < n) tmp[k++] = a[j++];
+    memcpy(a, tmp, n * sizeof(trip_t));
+}
+
+/* SparseMatrix::from_triplets (matrix/mod.rs:160-199): validate every triplet in
+ * input order (row bound, col bound, finiteness); COOStorage::from_triplets
+ * (sparse.rs:530-548) drops v == 0.0; CSRStorage::from_coo (sparse.rs:80-132)
+ * stable-sorts by (row, col) and emits; duplicates stay separate entries. */
+int orc_csr_from_triplets(uint64_t ntrip, const uint64_t *tr, const uint64_t *tc, const double *tv,
+                          uint64_t rows, uint64_t cols,
+                          uint32_t *row_ptr, uint32_t *col_idx, double *values, uint64_t *nnz_out)
+{
+    for (uint64_t k = 0; k < ntrip; ++k) {
+        if (tr[k] >= rows) return ORC_INDEX_OUT_OF_BOUNDS;
+        if (tc[k] >= cols) return ORC_INDEX_OUT_OF_BOUNDS;
+        if (!isfinite(tv[k])) return ORC_INVALID_INPUT;
+    }
+    trip_t *a = (trip_t *)malloc((ntrip ? ntrip : 1) * sizeof(trip_t));
+    trip_t *tmp = (trip_t *)malloc((ntrip ? ntrip : 1) * sizeof(trip_t));
+    if (!a || !tmp) { free(a); free(tmp); return ORC_ALLOCATION; }
+    uint64_t m = 0;
+    for (uint64_t k = 0; k < ntrip; ++k) {
+        if (tv[k] != 0.0) { a[m].r = tr[k]; a[m].c = (uint32_t)tc[k]; a[m].v = tv[k]; ++m; }
+    }
+    trip_msort(a, tmp, m);
+    for (uint64_t i = 0; i <= rows; ++i) row_ptr[i] = 0;
+    uint64_t cur = 0, cnt = 0;
+    for (uint64_t k = 0; k < m; ++k) {
+        while (cur < a[k].r) { ++cur; row_ptr[cur] = (uint32_t)cnt; }
+        values[cnt] = a[k].v;
+        col_idx[cnt] = a[k].c;
+        ++cnt;
+    }
+    while (cur < rows) { ++cur; row_ptr[cur] = (uint32_t)cnt; }
+    *nnz_out = cnt;
+    free(a); free(tmp);
+    return ORC_OK;
+}
+
+/* CSRStorage::get, sparse.rs:142-155 — binary search of the row's column slice.
+ * (With duplicate columns the reference returns whichever entry the search
+ * lands on; so does this.) */
+int orc_csr_get(const uint32_t *row_ptr, const uint32_t *col_idx, const double *values,
+                uint64_t rows, uint64_t r, uint64_t c, double *out)
+{
+    if (r >= rows) return 0;
+    uint64_t lo = row_ptr[r], hi = row_ptr[r + 1];
+    while (lo < hi) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        if (col_idx[mid] == c) { *out = values[mid]; return 1; }
+        if (col_idx[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------- a2/a3/a4 -- */
+
+/* CSRStorage::multiply_vector (sparse.rs:187-203): result.fill(0.0) then
+ * `*row_sum += values[i] * x[col]` left to right. */
+void orc_spmv_csr_sequential(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
+                             const double *values, const double *x, double *y)
+{
+    for (uint64_t i = 0; i < rows; ++i) {
+        double s = 0.0;
+        for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+            double p = values[k] * x[col_idx[k]];
+            s = s + p;
+        }
+        y[i] = s;
+    }
+}
+
+/* simd_ops::matrix_vector_multiply_simd with feature "simd" (simd_ops.rs:20-88):
+ * rows with nnz >= 8 use four lane accumulators over chunks of 4 (wide::f64x4 mul
+ * then add, lane-wise IEEE), horizontal ((l0+l1)+l2)+l3, tail sequential;
+ * shorter rows accumulate sequentially from 0.0. */
+static inline double row_simd4(const double *v, const uint32_t *c, uint64_t nnz, const double *x)
+{
+    if (nnz >= 8) {
+        uint64_t chunks = nnz / 4;
+        double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+        for (uint64_t q = 0; q < chunks; ++q) {
+            uint64_t i = q * 4;
+            double p0 = v[i] * x[c[i]], p1 = v[i + 1] * x[c[i + 1]];
+            double p2 = v[i + 2] * x[c[i + 2]], p3 = v[i + 3] * x[c[i + 3]];
+            l0 = l0 + p0; l1 = l1 + p1; l2 = l2 + p2; l3 = l3 + p3;
+        }
+        double y = l0 + l1; y = y + l2; y = y + l3;
+        for (uint64_t i = chunks * 4; i < nnz; ++i) { double p = v[i] * x[c[i]]; y = y + p; }
+        return y;
+    }
+    double s = 0.0;
+    for (uint64_t i = 0; i < nnz; ++i) { double p = v[i] * x[c[i]]; s = s + p; }
+    return s;
+}
+
+void orc_spmv_simd4(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
+                    const double *values, const double *x, double *y)
+{
+    for (uint64_t i = 0; i < rows; ++i) {
+        uint64_t s = row_ptr[i], e = row_ptr[i + 1];
+        y[i] = (e <= s) ? 0.0 : row_simd4(values + s, col_idx + s, e - s, x);
+    }
+}
+
+/* simd_ops::parallel_matrix_vector_multiply (simd_ops.rs:201-239):
+ * chunk_size = ceil(rows / num_threads); each chunk sequential rows, scalar sums. */
+typedef struct {
+    uint64_t lo, hi; const uint32_t *rp, *ci; const double *v, *x; double *y;
+} par_arg;
+static void *par_worker(void *p)
+{
+    par_arg *a = (par_arg *)p;
+    for (uint64_t i = a->lo; i < a->hi; ++i) {
+        double s = 0.0;
+        for (uint64_t k = a->rp[i]; k < a->rp[i + 1]; ++k) { double q = a->v[k] * a->x[a->ci[k]]; s = s + q; }
+        a->y[i] = s;
+    }
+    return 0;
+}
+void orc_spmv_parallel(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
+                       const double *values, const double *x, double *y, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    uint64_t chunk = (rows + (uint64_t)threads - 1) / (uint64_t)threads;
+    pthread_t tid[256]; par_arg args[256]; int started = 0;
+    for (int t = 0; t < threads; ++t) {
+        uint64_t lo = (uint64_t)t * chunk, hi = lo + chunk;
+        if (lo >= rows) break;
+        if (hi > rows) hi = rows;
+        args[t] = (par_arg){lo, hi, row_ptr, col_idx, values, x, y};
+        if (t == threads - 1 || hi == rows) { par_worker(&args[t]); break; }
+        pthread_create(&tid[t], 0, par_worker, &args[t]); ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(tid[t], 0);
+}
+
+/* ------------------------------------------------------------------ a5 -- */
+
+/* simd_ops::dot_product_simd, simd_ops.rs:116-147 */
+double orc_dot_simd4(uint64_t n, const double *x, const double *y)
+{
+    uint64_t chunks = n / 4;
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+    for (uint64_t q = 0; q < chunks; ++q) {
+        uint64_t i = q * 4;
+        double p0 = x[i] * y[i], p1 = x[i + 1] * y[i + 1], p2 = x[i + 2] * y[i + 2], p3 = x[i + 3] * y[i + 3];
+        l0 = l0 + p0; l1 = l1 + p1; l2 = l2 + p2; l3 = l3 + p3;
+    }
+    double r = l0 + l1; r = r + l2; r = r + l3;
+    for (uint64_t i = chunks * 4; i < n; ++i) { double p = x[i] * y[i]; r = r + p; }
+    return r;
+}
+/* fallback dot (simd_ops.rs:150-154) and fast_solver.rs:182-203's scalar twin */
+double orc_dot_sequential(uint64_t n, const double *x, const double *y)
+{
+    double s = 0.0;
+    for (uint64_t i = 0; i < n; ++i) { double p = x[i] * y[i]; s = s + p; }
+    return s;
+}
+/* simd_ops::axpy_simd, simd_ops.rs:158-189: y = (alpha*x) + y */
+void orc_axpy(uint64_t n, double alpha, const double *x, double *y)
+{
+    for (uint64_t i = 0; i < n; ++i) { double p = alpha * x[i]; y[i] = p + y[i]; }
+}
+/* solver::utils::{l2,l1,linf}_norm, solver/mod.rs:369-381 */
+double orc_l2_norm(uint64_t n, const double *v)
+{
+    double s = 0.0;
+    for (uint64_t i = 0; i < n; ++i) { double p = v[i] * v[i]; s = s + p; }
+    return sqrt(s);
+}
+double orc_l1_norm(uint64_t n, const double *v)
+{
+    double s = 0.0;
+    for (uint64_t i = 0; i < n; ++i) s = s + fabs(v[i]);
+    return s;
+}
+double orc_linf_norm(uint64_t n, const double *v)
+{
+    double m = 0.0;                      /* fold(0.0, f64::max): max ignores NaN, as fmax does */
+    for (uint64_t i = 0; i < n; ++i) m = fmax(m, fabs(v[i]));
+    return m;
+}
+
+/* ------------------------------------------------------------------ a6 -- */
+
+/* SparseMatrix::is_diagonally_dominant, matrix/mod.rs:467-485 */
+int orc_is_diagonally_dominant(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
+                               const double *values)
+{
+    for (uint64_t i = 0; i < rows; ++i) {
+        double diag = 0.0, off = 0.0;
+        for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+            if ((uint64_t)col_idx[k] == i) diag = fabs(values[k]);
+            else off = off + fabs(values[k]);
+        }
+        if (diag < off) return 0;
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------- a7..a11 -- */
+
+/* NeumannState::new, neumann.rs:139-249 — order of checks preserved */
+int orc_neumann_init(uint64_t rows, uint64_t cols, const uint32_t *row_ptr, const uint32_t *col_idx,
+                     const double *values, uint64_t b_len, const double *b,
+                     double *dinv, double *rhs)
+{
+    if (rows != cols) return ORC_INVALID_INPUT;                       /* :147-152 */
+    if (b_len != rows) return ORC_DIMENSION_MISMATCH;                 /* :154-160 */
+    if (!orc_is_diagonally_dominant(rows, row_ptr, col_idx, values))  /* :163-169 */
+        return ORC_NOT_DIAGONALLY_DOMINANT;
+    for (uint64_t i = 0; i < rows; ++i) {                             /* :172-188 */
+        double d;
+        if (!orc_csr_get(row_ptr, col_idx, values, rows, i, i, &d)) return ORC_INVALID_SPARSE_MATRIX;
+        if (fabs(d) < 1e-14) return ORC_INVALID_SPARSE_MATRIX;
+        dinv[i] = 1.0 / d;
+    }
+    for (uint64_t i = 0; i < rows; ++i) rhs[i] = b[i] * dinv[i];      /* :191-194 */
+    return ORC_OK;
+}
+
+static void spmv_by_opts(const orc_neumann_opts *o, uint64_t rows, const uint32_t *rp, const uint32_t *ci,
+                         const double *v, const double *x, double *y)
+{
+    if (o->order == ORC_ORDER_SIMD4) orc_spmv_simd4(rows, rp, ci, v, x, y);
+    else if (o->threads > 1) orc_spmv_parallel(rows, rp, ci, v, x, y, o->threads);
+    else orc_spmv_csr_sequential(rows, rp, ci, v, x, y);
+}
+
+/* NeumannSolver::solve (neumann.rs:469-555) over compute_next_term (:252-277),
+ * apply_iteration_matrix (:280-299), update_residual (:302-318), is_converged
+ * (:422-430).  On CONVERGENCE_FAILURE the outputs are still filled (the
+ * reference drops them, :523-530). */
+int orc_neumann_solve(uint64_t rows, uint64_t cols, const uint32_t *row_ptr, const uint32_t *col_idx,
+                      const double *values, uint64_t b_len, const double *b,
+                      const double *initial_guess, const orc_neumann_opts *o,
+                      double *x, double *term_out, double *term_norms, orc_neumann_result *res)
+{
+    memset(res, 0, sizeof(*res));
+    res->residual_norm = INFINITY;
+    uint64_t n = rows;
+    double *dinv = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *rhs = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *term = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *tmp = (double *)malloc((n ? n : 1) * sizeof(double));
+    if (!dinv || !rhs || !term || !tmp) { free(dinv); free(rhs); free(term); free(tmp); return ORC_ALLOCATION; }
+    int st = orc_neumann_init(rows, cols, row_ptr, col_idx, values, b_len, b, dinv, rhs);
+    if (st != ORC_OK) goto done;
+
+    if (o->start == ORC_START_INITIAL_GUESS && initial_guess) memcpy(x, initial_guess, n * sizeof(double));
+    else if (o->start == ORC_START_REFERENCE_DEFAULT) memcpy(x, rhs, n * sizeof(double));   /* :197-208 */
+    else memset(x, 0, n * sizeof(double));
+    memcpy(term, rhs, n * sizeof(double));                                                    /* :211 */
+
+    double resn = INFINITY;
+    int series_conv = 0;
+    uint64_t terms = 0, it = 0, matvec = 0;
+    const double *res_rhs = (o->residual == ORC_RESIDUAL_REFERENCE_SCALED) ? rhs : b;
+
+#define IS_CONVERGED() ((resn <= o->tolerance) || (series_conv && !(terms >= o->max_terms)))
+#define UPDATE_RESIDUAL() do { \
+        spmv_by_opts(o, n, row_ptr, col_idx, values, x, tmp); ++matvec; \
+        for (uint64_t i_ = 0; i_ < n; ++i_) tmp[i_] = tmp[i_] - res_rhs[i_]; \
+        resn = orc_l2_norm(n, tmp); } while (0)
+
+    while (!IS_CONVERGED() && it < o->max_iterations) {
+        if (terms < o->max_terms) {                                   /* compute_next_term :253-255 */
+            if (terms > 0) {                                          /* apply_iteration_matrix */
+                spmv_by_opts(o, n, row_ptr, col_idx, values, term, tmp); ++matvec;
+                for (uint64_t i = 0; i < n; ++i) tmp[i] = tmp[i] * dinv[i];
+                for (uint64_t i = 0; i < n; ++i) term[i] = term[i] - tmp[i];
+            }
+            for (uint64_t i = 0; i < n; ++i) x[i] = x[i] + term[i];   /* :264-266 */
+            double tn = orc_l2_norm(n, term);
+            if (term_norms) term_norms[terms] = tn;
+            ++terms;
+            if (tn < o->series_tolerance) series_conv = 1;            /* :270-274 */
+        }
+        if (it % 5 == 0) UPDATE_RESIDUAL();                           /* :489-491 */
+        ++it;
+        if (!isfinite(resn)) { st = ORC_NUMERICAL_INSTABILITY; goto fill; } /* :501-507 */
+        if (series_conv) break;                                       /* :510-512 */
+    }
+    UPDATE_RESIDUAL();                                                /* :516 */
+    {
+        int conv = IS_CONVERGED();
+        res->converged = conv;
+        if (!conv && it >= o->max_iterations) st = ORC_CONVERGENCE_FAILURE; /* :523-530 */
+    }
+fill:
+    res->iterations = it; res->terms_computed = terms; res->matvec_count = matvec;
+    res->residual_norm = resn; res->series_converged = series_conv;
+    if (term_out) memcpy(term_out, term, n * sizeof(double));
+done:
+    free(dinv); free(rhs); free(term); free(tmp);
+    return st;
+#undef IS_CONVERGED
+#undef UPDATE_RESIDUAL
+}
+
+/* ------------------------------------------------------------------ a-P -- */
+
+/* Synchronous thresholded push, SURVEY.md §8 (a-P): the data-parallel member of
+ * the family {NeumannState::apply_iteration_matrix (neumann.rs:280-299),
+ * ForwardPushSolver::push_node (forward_push.rs:179-216), TS solveForwardPush
+ * (core/solver.ts:437-522)} — invariant r = b - A x, every round pushes ALL
+ * rows whose scaled residual |r_i * dinv_i| >= theta (ascending index order):
+ *     delta_i = r_i * dinv_i (i in F, else 0);  x_i += delta_i;
+ *     r_i -= sum_k a_ik * delta_{c_k}   (row-wise, column order, product rounded
+ *                                        then added — same order as a2)
+ * over the candidate rows {i : exists k, c_k in F}.  With |F| = 1 = argmax this is
+ * one step of a14. */
+int orc_push_sync_solve(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx,
+                        const double *values, const double *b, const orc_push_opts *o,
+                        double *x, double *r,
+                        uint32_t *flog, uint64_t fcap, uint64_t *fwords, orc_push_result *res)
+{
+    memset(res, 0, sizeof(*res));
+    if (fwords) *fwords = 0;
+    double *dinv = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *delta = (double *)calloc((n ? n : 1), sizeof(double));
+    double *ax = (double *)malloc((n ? n : 1) * sizeof(double));
+    uint8_t *inF = (uint8_t *)calloc((n ? n : 1), 1);
+    if (!dinv || !delta || !ax || !inF) { free(dinv); free(delta); free(ax); free(inF); return ORC_ALLOCATION; }
+    /* D^-1 with the rejection rules of neumann.rs:172-188 (missing / near-zero diagonal); no
+     * row-dominance requirement: the push family never checks it (forward_push.rs:67-122) and
+     * PageRank systems (solver.ts:664-722) are column- not row-dominant. */
+    int st = ORC_OK;
+    for (uint64_t i = 0; i < n; ++i) {
+        double d;
+        if (!orc_csr_get(row_ptr, col_idx, values, n, i, i, &d) || fabs(d) < 1e-14) { st = ORC_INVALID_SPARSE_MATRIX; goto done; }
+        dinv[i] = 1.0 / d;
+    }
+    /* r = b - A x0 */
+    if (o->order == ORC_ORDER_SIMD4) orc_spmv_simd4(n, row_ptr, col_idx, values, x, ax);
+    else orc_spmv_csr_sequential(n, row_ptr, col_idx, values, x, ax);
+    for (uint64_t i = 0; i < n; ++i) r[i] = b[i] - ax[i];
+
+    uint64_t w = 0;
+    while (res->rounds < o->max_rounds) {
+        uint64_t nf = 0;
+        uint64_t hdr = w;
+        if (flog && w < fcap) ++w;
+        for (uint64_t i = 0; i < n; ++i) {
+            double p = r[i] * dinv[i];
+            if (fabs(p) >= o->theta) {
+                inF[i] = 1; delta[i] = p; ++nf;
+                if (flog && w < fcap) flog[w++] = (uint32_t)i;
+            } else { inF[i] = 0; delta[i] = 0.0; }
+        }
+        if (flog && hdr < fcap) flog[hdr] = (uint32_t)nf;
+        if (nf == 0) { res->converged = 1; break; }
+        for (uint64_t i = 0; i < n; ++i) if (inF[i]) x[i] = x[i] + delta[i];
+        uint64_t touched = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            uint64_t s = row_ptr[i], e = row_ptr[i + 1];
+            int cand = 0;
+            for (uint64_t k = s; k < e; ++k) if (inF[col_idx[k]]) { cand = 1; break; }
+            if (!cand) continue;
+            ++touched;
+            double acc;
+            if (o->order == ORC_ORDER_SIMD4) acc = row_simd4(values + s, col_idx + s, e - s, delta);
+            else { acc = 0.0; for (uint64_t k = s; k < e; ++k) { double p = values[k] * delta[col_idx[k]]; acc = acc + p; } }
+            r[i] = r[i] - acc;
+        }
+        res->rounds += 1; res->pushes += nf; res->rows_touched += touched;
+    }
+    res->residual_norm = orc_l2_norm(n, r);
+    if (fwords) *fwords = w;
+done:
+    free(dinv); free(delta); free(ax); free(inF);
+    return st;
+}
+
+/* ------------------------------------------------------------------ a13 -- */
+
+/* CompressedSparseRow::transpose, graph/mod.rs:92-130 (counting sort; entries of
+ * each transposed row end up in increasing original-row order). */
+void orc_csr_transpose(uint64_t nrows, uint64_t ncols, const uint32_t *row_ptr, const uint32_t *col_idx,
+                       const double *values, uint32_t *t_row_ptr, uint32_t *t_col_idx, double *t_values)
+{
+    uint64_t nnz = row_ptr[nrows];
+    for (uint64_t j = 0; j <= ncols; ++j) t_row_ptr[j] = 0;
+    for (uint64_t k = 0; k < nnz; ++k) t_row_ptr[col_idx[k] + 1] += 1;
+    for (uint64_t j = 0; j < ncols; ++j) t_row_ptr[j + 1] += t_row_ptr[j];
+    uint32_t *pos = (uint32_t *)malloc((ncols ? ncols : 1) * sizeof(uint32_t));
+    memcpy(pos, t_row_ptr, ncols * sizeof(uint32_t));
+    for (uint64_t i = 0; i < nrows; ++i)
+        for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+            uint32_t p = pos[col_idx[k]]++;
+            t_col_idx[p] = (uint32_t)i; t_values[p] = values[k];
+        }
+    free(pos);
+}
+
+/* WorkQueue (graph/mod.rs:132-213): BinaryHeap<WorkItem> where WorkItem derives
+ * PartialOrd over (priority, node_id) — lexicographic, max-heap — plus an
+ * in-queue BitSet.  Items are distinct (a node is queued at most once), so the
+ * pop sequence of any correct max-heap is the same. */
+typedef struct { double pr; uint64_t node; } witem;
+typedef struct { witem *h; uint64_t len, cap; uint8_t *inq; double threshold; } wqueue;
+static int wless(const witem *a, const witem *b)
+{
+    if (a->pr < b->pr) return 1;
+    if (a->pr > b->pr) return 0;
+    return a->node < b->node;
+}
+static void wq_push_if_threshold(wqueue *q, uint64_t node, double residual, double degree)
+{
+    double pr = (degree > 0.0) ? residual / degree : residual;          /* graph/mod.rs:172 */
+    if (pr >= q->threshold && !q->inq[node]) {
+        if (q->len == q->cap) { q->cap = q->cap ? q->cap * 2 : 64; q->h = (witem *)realloc(q->h, q->cap * sizeof(witem)); }
+        uint64_t i = q->len++;
+        q->h[i].pr = pr; q->h[i].node = node;
+        while (i > 0) {
+            uint64_t p = (i - 1) / 2;
+            if (!wless(&q->h[p], &q->h[i])) break;
+            witem t = q->h[p]; q->h[p] = q->h[i]; q->h[i] = t; i = p;
+        }
+        q->inq[node] = 1;
+    }
+}
+static int wq_pop(wqueue *q, uint64_t *node)
+{
+    if (!q->len) return 0;
+    *node = q->h[0].node;
+    q->inq[*node] = 0;
+    q->h[0] = q->h[--q->len];
+    uint64_t i = 0;
+    for (;;) {
+        uint64_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < q->len && wless(&q->h[m], &q->h[l])) m = l;
+        if (r < q->len && wless(&q->h[m], &q->h[r])) m = r;
+        if (m == i) break;
+        witem t = q->h[m]; q->h[m] = q->h[i]; q->h[i] = t; i = m;
+    }
+    return 1;
+}
+static void wq_adaptive(wqueue *q, uint64_t maxq, uint64_t minq)              /* graph/mod.rs:204-212 */
+{
+    if (q->len > maxq) q->threshold *= 1.1;
+    else if (q->len < minq && q->threshold > 1e-12) q->threshold *= 0.9;
+}
+
+static void row_sums(uint64_t n, const uint32_t *rp, const double *w, double *out)  /* graph/mod.rs:81-89 */
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (uint64_t k = rp[i]; k < rp[i + 1]; ++k) s = s + w[k];
+        out[i] = s;
+    }
+}
+
+/* direction 0 = forward (forward_push.rs:67-216), 1 = backward (backward_push.rs:67-220) */
+static int acl_push(uint64_t n, const uint32_t *rp, const uint32_t *ci, const double *w,
+                    uint64_t nsrc, const uint64_t *src, const orc_acl_opts *o,
+                    double *est, double *res, orc_acl_result *out, int backward)
+{
+    memset(out, 0, sizeof(*out));
+    for (uint64_t i = 0; i < n; ++i) { est[i] = 0.0; res[i] = 0.0; }
+    if (nsrc == 1 && src[0] >= n) return ORC_OK;                       /* forward_push.rs:75-83 */
+    uint64_t nnz = n ? rp[n] : 0;
+    double *outdeg = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *indeg = 0;
+    uint32_t *trp = 0, *tci = 0; double *tw = 0;
+    uint8_t *visited = (uint8_t *)calloc((n ? n : 1), 1);
+    wqueue q = {0, 0, 0, (uint8_t *)calloc((n ? n : 1), 1), o->queue_threshold};
+    row_sums(n, rp, w, outdeg);
+    const uint32_t *arp = rp, *aci = ci; const double *aw = w; const double *qdeg = outdeg;
+    if (backward) {
+        trp = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));
+        tci = (uint32_t *)malloc((nnz ? nnz : 1) * sizeof(uint32_t));
+        tw = (double *)malloc((nnz ? nnz : 1) * sizeof(double));
+        indeg = (double *)malloc((n ? n : 1) * sizeof(double));
+        orc_csr_transpose(n, n, rp, ci, w, trp, tci, tw);
+        row_sums(n, trp, tw, indeg);                                   /* adjacency.rs:212-224 */
+        arp = trp; aci = tci; aw = tw; qdeg = indeg;
+    }
+    double mass = 1.0 / (double)nsrc;                                  /* forward_push.rs:131 */
+    if (nsrc == 1) res[src[0]] = 1.0;
+    else for (uint64_t s = 0; s < nsrc; ++s) if (src[s] < n) res[src[s]] += mass;
+    for (uint64_t s = 0; s < nsrc; ++s)
+        if (src[s] < n) wq_push_if_threshold(&q, src[s], res[src[s]], fmax(qdeg[src[s]], 1.0));
+
+    uint64_t pushes = 0, nvis = 0, u;
+    while (q.len && pushes < o->max_pushes) {
+        if (!wq_pop(&q, &u)) break;
+        double du = fmax(qdeg[u], 1.0);
+        if (res[u] < o->epsilon * du) continue;                        /* :96-99 */
+        /* push_node :179-216 / backward_push_node :179-220 */
+        if (!(res[u] <= 0.0)) {
+            double push_amount = o->alpha * res[u];
+            est[u] = est[u] + push_amount;
+            double remaining = (1.0 - o->alpha) * res[u];
+            res[u] = 0.0;
+            double deg = qdeg[u];
+            if (deg > 0.0) {
+                for (uint64_t k = arp[u]; k < arp[u + 1]; ++k) {
+                    uint64_t v = aci[k];
+                    double m;
+                    if (!backward) m = remaining * aw[k] / deg;        /* (rem*w)/deg */
+                    else { double tp = aw[k] / fmax(outdeg[v], 1.0); m = remaining * tp; }
+                    res[v] = res[v] + m;
+                    wq_push_if_threshold(&q, v, res[v], fmax(qdeg[v], 1.0));
+                }
+            } else {
+                res[u] = res[u] + remaining;
+                wq_push_if_threshold(&q, u, res[u], 1.0);
+            }
+        }
+        if (!visited[u]) { visited[u] = 1; ++nvis; }
+        ++pushes;
+        if (o->adaptive_threshold && pushes % 1000 == 0) wq_adaptive(&q, 10000, 100);
+    }
+    out->push_count = pushes; out->nodes_visited = nvis; out->residual_norm = orc_l2_norm(n, res);
+    free(outdeg); free(indeg); free(trp); free(tci); free(tw); free(visited); free(q.h); free(q.inq);
+    return ORC_OK;
+}
+
+int orc_acl_forward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx,
+                         const double *weights, uint64_t nsrc, const uint64_t *sources,
+                         const orc_acl_opts *opts, double *estimate, double *residual, orc_acl_result *res)
+{
+    return acl_push(n, row_ptr, col_idx, weights, nsrc, sources, opts, estimate, residual, res, 0);
+}
+int orc_acl_backward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx,
+                          const double *weights, uint64_t ntgt, const uint64_t *targets,
+                          const orc_acl_opts *opts, double *estimate, double *residual, orc_acl_result *res)
+{
+    return acl_push(n, row_ptr, col_idx, weights, ntgt, targets, opts, estimate, residual, res, 1);
+}
+
+/* ------------------------------------------------------------------ a14 -- */
+
+/* TS solveForwardPush (src/core/solver.ts:437-522), Gauss-Southwell on r = b - A x.
+ * The dense column sweep `r_j -= A[j][i] * p` for every j != i only changes r_j
+ * where A[j][i] != 0 (r - (+-0) == r), so the sweep runs over column i of A
+ * (row i of the transpose). */
+int orc_ts_forward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx,
+                        const double *values, const double *b, double epsilon, uint64_t max_iterations,
+                        double *x, double *r, orc_ts_push_result *res)
+{
+    memset(res, 0, sizeof(*res));
+    res->residual = INFINITY;
+    uint64_t nnz = n ? row_ptr[n] : 0;
+    uint32_t *trp = (uint32_t *)malloc((n + 1) * sizeof(uint32_t));
+    uint32_t *tci = (uint32_t *)malloc((nnz ? nnz : 1) * sizeof(uint32_t));
+    double *tv = (double *)malloc((nnz ? nnz : 1) * sizeof(double));
+    orc_csr_transpose(n, n, row_ptr, col_idx, values, trp, tci, tv);
+    for (uint64_t i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; }
+    int st = ORC_OK;
+    for (uint64_t iter = 0; iter < max_iterations; ++iter) {
+        double maxr = 0.0; int64_t node = -1;
+        for (uint64_t i = 0; i < n; ++i) if (fabs(r[i]) > maxr) { maxr = fabs(r[i]); node = (int64_t)i; }
+        if (maxr < epsilon) { res->converged = 1; break; }
+        double d = 0.0;
+        orc_csr_get(row_ptr, col_idx, values, n, (uint64_t)node, (uint64_t)node, &d);
+        if (fabs(d) < 1e-15) { st = ORC_NUMERICAL_INSTABILITY; break; }
+        double p = r[node] / d;
+        x[node] = x[node] + p;
+        r[node] = 0.0;
+        for (uint64_t k = trp[node]; k < trp[node + 1]; ++k) {
+            uint64_t j = tci[k];
+            if (j != (uint64_t)node) { double q = tv[k] * p; r[j] = r[j] - q; }
+        }
+        res->iterations = iter + 1;
+        res->residual = orc_l2_norm(n, r);
+    }
+    if (st == ORC_OK && !res->converged) st = ORC_CONVERGENCE_FAILURE;
+    free(trp); free(tci); free(tv);
+    return st;
+}
+
+/* ------------------------------------------------------------------ a15 -- */
+
+/* createSeededRandom, src/core/utils.ts:161-168.  state*1664525 < 2^53, so the JS
+ * double arithmetic is exact integer arithmetic mod 2^32. */
+static inline double lcg_next(uint64_t *state)
+{
+    *state = (*state * 1664525ull + 1013904223ull) % 0x100000000ull;
+    return (double)*state / 4294967296.0;
+}
+void orc_ts_lcg(uint32_t seed, uint64_t count, double *out)
+{
+    uint64_t s = seed;
+    for (uint64_t i = 0; i < count; ++i) out[i] = lcg_next(&s);
+}
+
+/* estimateEntry random-walk branch (solver.ts:585-601,630-648) over
+ * createTransitionMatrix (:359-385) and performRandomWalk (:390-432).  The dense
+ * cumulative scan over j = 0..n-1 only grows at stored off-diagonal entries, so it
+ * is walked over the CSR row; `rand <= cum[j]` picks the first j, which is j = 0
+ * when rand == 0. */
+int orc_ts_random_walk_estimate(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx,
+                                const double *values, const double *b, uint64_t start_row,
+                                double epsilon, uint32_t seed, double *mean, double *variance,
+                                uint64_t *num_samples)
+{
+    double *absorb = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *diag = (double *)malloc((n ? n : 1) * sizeof(double));
+    for (uint64_t i = 0; i < n; ++i) {
+        double d = 0.0;
+        orc_csr_get(row_ptr, col_idx, values, n, i, i, &d);
+        if (fabs(d) < 1e-15) { free(absorb); free(diag); return ORC_NUMERICAL_INSTABILITY; }
+        diag[i] = d; absorb[i] = 1.0 / d;
+    }
+    double ns = ceil(1.0 / (epsilon * epsilon));
+    uint64_t N = (ns > 100.0) ? (uint64_t)ns : 100;
+    double *est = (double *)malloc(N * sizeof(double));
+    uint64_t state = seed;
+    for (uint64_t s = 0; s < N; ++s) {
+        uint64_t cur = start_row; double value = 0.0;
+        for (int step = 0; step < 1000; ++step) {
+            if (lcg_next(&state) < fabs(absorb[cur])) { value = value + b[cur] * absorb[cur]; break; }
+            double sum = 0.0;
+            for (uint64_t k = row_ptr[cur]; k < row_ptr[cur + 1]; ++k)
+                if (col_idx[k] != cur) sum = sum + fabs(-values[k] / diag[cur]);
+            if (sum == 0.0) { value = value + b[cur] * absorb[cur]; break; }
+            double rnd = lcg_next(&state) * sum;
+            if (rnd <= 0.0) { cur = 0; continue; }
+            double cum = 0.0;
+            for (uint64_t k = row_ptr[cur]; k < row_ptr[cur + 1]; ++k) {
+                if (col_idx[k] == cur) continue;
+                cum = cum + fabs(-values[k] / diag[cur]);
+                if (rnd <= cum) { cur = col_idx[k]; break; }
+            }
+        }
+        est[s] = value;
+    }
+    double m = 0.0;
+    for (uint64_t s = 0; s < N; ++s) m = m + est[s];
+    m = m / (double)N;
+    double var = 0.0;
+    if (N > 1) { for (uint64_t s = 0; s < N; ++s) { double d = est[s] - m; var = var + d * d; } var = var / (double)(N - 1); }
+    *mean = m; *variance = var; *num_samples = N;
+    free(absorb); free(diag); free(est);
+    return ORC_OK;
+}

@@ -1,0 +1,140 @@
+"""ctypes binding of libsublinear_hip.so (the C ABI of include/sublinear_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at
+import-of-symbols time, and every compute call returns SL_DEVICE_ERROR without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libsublinear_hip.so"
+
+SL_OK = 0
+STATUS_NAMES = {
+    0: "OK", 1: "MatrixNotDiagonallyDominant", 2: "NumericalInstability", 3: "ConvergenceFailure",
+    4: "InvalidInput", 5: "DimensionMismatch", 6: "UnsupportedMatrixFormat", 7: "MemoryAllocationError",
+    8: "IndexOutOfBounds", 9: "InvalidSparseMatrix", 10: "AlgorithmError", 11: "DeviceError",
+}
+SL_MEM_HOST, SL_MEM_DEVICE = 0, 1
+SL_ORDER_CSR_SEQUENTIAL, SL_ORDER_SIMD4 = 0, 1
+SL_START_ZERO, SL_START_REFERENCE_DEFAULT, SL_START_INITIAL_GUESS = 0, 1, 2
+SL_RESIDUAL_TRUE, SL_RESIDUAL_REFERENCE_SCALED = 0, 1
+SL_MATRIX_WITH_TRANSPOSE, SL_MATRIX_KEEP_CSR = 1, 2
+
+u64, u32, i32, f64 = C.c_uint64, C.c_uint32, C.c_int32, C.c_double
+vp = C.c_void_p
+
+
+class MatrixInfo(C.Structure):
+    _fields_ = [("n_rows", u64), ("n_cols", u64), ("nnz", u64), ("row_offset", u64), ("padded_nnz", u64),
+                ("n_slices", u64), ("device_bytes", u64), ("max_row_nnz", u32), ("min_row_nnz", u32),
+                ("uniform_width", u32), ("has_transpose", u32)]
+
+
+class NeumannOptions(C.Structure):
+    _fields_ = [("tolerance", f64), ("max_iterations", u64), ("max_terms", u64), ("series_tolerance", f64),
+                ("order", i32), ("start", i32), ("residual", i32), ("mem", i32), ("collect_stats", i32),
+                ("compute_error_bounds", i32)]
+
+
+class NeumannResult(C.Structure):
+    _fields_ = [("iterations", u64), ("terms_computed", u64), ("matvec_count", u64), ("residual_norm", f64),
+                ("last_term_norm", f64), ("error_bound", f64), ("total_time_ms", f64), ("device_time_ms", f64),
+                ("bytes_moved", u64), ("converged", i32), ("series_converged", i32)]
+
+
+class PushOptions(C.Structure):
+    _fields_ = [("theta", f64), ("max_rounds", u64), ("order", i32), ("mem", i32), ("dense_switch", f64),
+                ("sparse_rhs", i32), ("reserved", i32)]
+
+
+class PushResult(C.Structure):
+    _fields_ = [("rounds", u64), ("pushes", u64), ("rows_touched", u64), ("dense_rounds", u64),
+                ("residual_norm", f64), ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
+
+
+class EstimateResult(C.Structure):
+    _fields_ = [("estimate", f64), ("residual_l1", f64), ("rounds", u64), ("pushes", u64), ("rows_touched", u64),
+                ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
+
+
+# every symbol include/sublinear_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "sl_abi_version": (C.c_int, []),
+    "sl_last_error_message": (C.c_char_p, []),
+    "sl_status_string": (C.c_char_p, [C.c_int]),
+    "sl_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sl_set_device": (C.c_int, [C.c_int]),
+    "sl_set_stream": (C.c_int, [vp]),
+    "sl_synchronize": (C.c_int, []),
+    "sl_matrix_create_from_triplets": (C.c_int, [u64, vp, vp, vp, u64, u64, u32, C.POINTER(vp)]),
+    "sl_matrix_create_csr": (C.c_int, [u64, u64, u64, vp, vp, vp, C.c_int, u64, u32, C.POINTER(vp)]),
+    "sl_matrix_destroy": (None, [vp]),
+    "sl_matrix_get_info": (C.c_int, [vp, C.POINTER(MatrixInfo)]),
+    "sl_matrix_download_csr": (C.c_int, [vp, vp, vp, vp]),
+    "sl_matrix_is_diagonally_dominant": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "sl_matrix_diagonal_inverse": (C.c_int, [vp, vp, C.c_int]),
+    "sl_spmv": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+    "sl_dot": (C.c_int, [u64, vp, vp, C.POINTER(f64), C.c_int]),
+    "sl_axpy": (C.c_int, [u64, f64, vp, vp, C.c_int]),
+    "sl_l2_norm": (C.c_int, [u64, vp, C.POINTER(f64), C.c_int]),
+    "sl_neumann_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int]),
+    "sl_neumann_run_steps": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, u64, C.POINTER(C.c_float)]),
+    "sl_neumann_options_default": (None, [C.POINTER(NeumannOptions)]),
+    "sl_neumann_solve": (C.c_int, [vp, vp, vp, C.POINTER(NeumannOptions), vp, vp, C.POINTER(NeumannResult)]),
+    "sl_push_options_default": (None, [C.POINTER(PushOptions)]),
+    "sl_push_solve": (C.c_int, [vp, vp, C.POINTER(PushOptions), vp, vp, vp, u64, C.POINTER(u64),
+                                C.POINTER(PushResult)]),
+    "sl_estimate_entry": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
+    "sl_synth_sdd_device": (C.c_int, [u64, u32, u64, u64, u64, u64, vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class SolverError(RuntimeError):
+    """Mirror of the reference's SolverError enum (src/error.rs:16-140): `.kind` is the variant name."""
+
+    def __init__(self, status: int, message: str):
+        self.status = status
+        self.kind = STATUS_NAMES.get(status, "Unknown")
+        super().__init__(f"{self.kind}: {message}")
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise loudly when it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.environ.get("SUBLINEAR_HIP_LIB", str(LIB_PATH))
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `make -C sublinear_time_solver_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sl_abi_version() != 1:
+        raise ImportError("libsublinear_hip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != SL_OK:
+        msg = load().sl_last_error_message()
+        raise SolverError(status, msg.decode() if msg else "")
+
+
+def ptr(a) -> int:
+    """Raw address of a numpy array (host) or torch tensor (device)."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a.ctypes.data

@@ -1,0 +1,532 @@
+// sl_api.hip — the C ABI of include/sublinear_hip.h: context, matrix lifetime, primitives,
+// and the host-side iteration control of NeumannSolver::solve (neumann.rs:469-555).
+// Host control only decides WHEN kernels run; all arithmetic on vectors happens on the device.
+#include "sl_internal.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+// ---- context ---------------------------------------------------------------------------------
+sl_ctx &sl_context()
+{
+    static thread_local sl_ctx ctx;
+    return ctx;
+}
+sl_status sl_fail(sl_status s, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    sl_context().last_error = buf;
+    return s;
+}
+void *sl_scratch(size_t bytes)
+{
+    sl_ctx &c = sl_context();
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (c.scratch && c.scratch_device == dev && c.scratch_bytes >= bytes) return c.scratch;
+    if (c.scratch) { hipFree(c.scratch); c.scratch = nullptr; c.scratch_bytes = 0; }
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    if (hipMalloc(&c.scratch, want) != hipSuccess) return nullptr;
+    c.scratch_bytes = want;
+    c.scratch_device = dev;
+    return c.scratch;
+}
+
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    sl_status alloc(size_t bytes)
+    {
+        if (p) { hipFree(p); p = nullptr; }
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        if (e != hipSuccess) return sl_fail(SL_ALLOCATION, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return SL_OK;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+#define SL_TRY(expr) do { sl_status s_ = (expr); if (s_ != SL_OK) return s_; } while (0)
+
+sl_status require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return sl_fail(SL_DEVICE_ERROR, "no HIP device available (%s); libsublinear_hip has no CPU fallback",
+                       e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return SL_OK;
+}
+
+// bring a vector to the device if it lives on the host; returns the device pointer
+sl_status stage_in(const double *src, uint64_t n, sl_mem where, DevBuf &tmp, const double **dev)
+{
+    if (where == SL_MEM_DEVICE) { *dev = src; return SL_OK; }
+    SL_TRY(tmp.alloc(n * sizeof(double)));
+    SL_HIP(hipMemcpyAsync(tmp.p, src, n * sizeof(double), hipMemcpyHostToDevice, sl_context().stream));
+    *dev = tmp.as<double>();
+    return SL_OK;
+}
+sl_status read_scalars(const double *d, double *h, int count)
+{
+    hipStream_t st = sl_context().stream;
+    SL_HIP(hipMemcpyAsync(h, d, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    return SL_OK;
+}
+sl_row_args row_args(const sl_matrix *m)
+{
+    sl_row_args a;
+    memset(&a, 0, sizeof(a));
+    a.slice_ptr = m->d_slice_ptr; a.row_len = m->d_row_len; a.cols = m->d_cols; a.vals = m->d_vals;
+    a.n_rows = m->n_rows; a.n_slices = m->n_slices; a.row_offset = m->row_offset;
+    a.uniform_width = m->uniform_width;
+    return a;
+}
+size_t partial_bytes(const sl_matrix *m) { return ((size_t)sl_row_grid(m->n_slices) * 2 + 4096) * sizeof(double); }
+} // namespace
+
+// ---- library -----------------------------------------------------------------------------------
+extern "C" {
+
+int sl_abi_version(void) { return SL_ABI_VERSION; }
+const char *sl_last_error_message(void) { return sl_context().last_error.c_str(); }
+const char *sl_status_string(sl_status s)
+{
+    switch (s) {
+    case SL_OK: return "OK";
+    case SL_NOT_DIAGONALLY_DOMINANT: return "MatrixNotDiagonallyDominant";
+    case SL_NUMERICAL_INSTABILITY: return "NumericalInstability";
+    case SL_CONVERGENCE_FAILURE: return "ConvergenceFailure";
+    case SL_INVALID_INPUT: return "InvalidInput";
+    case SL_DIMENSION_MISMATCH: return "DimensionMismatch";
+    case SL_UNSUPPORTED_FORMAT: return "UnsupportedMatrixFormat";
+    case SL_ALLOCATION: return "MemoryAllocationError";
+    case SL_INDEX_OUT_OF_BOUNDS: return "IndexOutOfBounds";
+    case SL_INVALID_SPARSE_MATRIX: return "InvalidSparseMatrix";
+    case SL_ALGORITHM_ERROR: return "AlgorithmError";
+    case SL_DEVICE_ERROR: return "DeviceError";
+    }
+    return "Unknown";
+}
+sl_status sl_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return SL_OK;
+}
+sl_status sl_set_device(int device)
+{
+    SL_TRY(require_device());
+    SL_HIP(hipSetDevice(device));
+    return SL_OK;
+}
+sl_status sl_set_stream(void *hip_stream)
+{
+    sl_context().stream = static_cast<hipStream_t>(hip_stream);
+    return SL_OK;
+}
+sl_status sl_synchronize(void)
+{
+    SL_TRY(require_device());
+    SL_HIP(hipStreamSynchronize(sl_context().stream));
+    return SL_OK;
+}
+
+// ---- matrices ------------------------------------------------------------------------------------
+void sl_matrix_destroy(sl_matrix *m)
+{
+    if (!m) return;
+    hipFree(m->d_slice_ptr); hipFree(m->d_row_len); hipFree(m->d_cols); hipFree(m->d_vals);
+    hipFree(m->d_row_ptr); hipFree(m->d_col_idx); hipFree(m->d_values);
+    hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval);
+    delete m;
+}
+
+sl_status sl_matrix_create_csr(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, const uint32_t *row_ptr,
+                               const uint32_t *col_idx, const double *values, sl_mem where,
+                               uint64_t row_offset, uint32_t flags, sl_matrix **out)
+{
+    if (!out) return sl_fail(SL_INVALID_INPUT, "out is null");
+    *out = nullptr;
+    if (!row_ptr || (nnz && (!col_idx || !values))) return sl_fail(SL_INVALID_INPUT, "null CSR array");
+    if (n_rows > 0xffffffffull || n_cols > 0xffffffffull || nnz > 0xffffffffull)
+        return sl_fail(SL_INVALID_INPUT, "dimensions exceed IndexType = u32 (types.rs:22)");
+    if (row_offset + n_rows > n_cols && row_offset != 0)
+        return sl_fail(SL_DIMENSION_MISMATCH, "row slice [%llu, %llu) exceeds the global dimension %llu",
+                       (unsigned long long)row_offset, (unsigned long long)(row_offset + n_rows), (unsigned long long)n_cols);
+    SL_TRY(require_device());
+    sl_matrix *m = new sl_matrix();
+    m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz; m->row_offset = row_offset; m->flags = flags;
+    hipGetDevice(&m->device);
+    const bool keep = (flags & (SL_MATRIX_KEEP_CSR | SL_MATRIX_WITH_TRANSPOSE)) != 0;
+    sl_status st;
+    if (where == SL_MEM_HOST) {
+        DevBuf rp, ci, va;
+        hipStream_t s = sl_context().stream;
+        st = rp.alloc((n_rows + 1) * sizeof(uint32_t));
+        if (st == SL_OK) st = ci.alloc(nnz * sizeof(uint32_t));
+        if (st == SL_OK) st = va.alloc(nnz * sizeof(double));
+        if (st == SL_OK) {
+            hipError_t e = hipMemcpyAsync(rp.p, row_ptr, (n_rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess && nnz) e = hipMemcpyAsync(ci.p, col_idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess && nnz) e = hipMemcpyAsync(va.p, values, nnz * sizeof(double), hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) st = sl_fail(SL_DEVICE_ERROR, "CSR upload failed: %s", hipGetErrorString(e));
+        }
+        if (st == SL_OK) {
+            if (keep) { // hand the uploaded buffers over instead of copying them again
+                st = sl_build_from_device_csr(m, rp.as<uint32_t>(), ci.as<uint32_t>(), va.as<double>(), false);
+                if (st == SL_OK) {
+                    m->d_row_ptr = rp.as<uint32_t>(); m->d_col_idx = ci.as<uint32_t>(); m->d_values = va.as<double>();
+                    rp.p = ci.p = va.p = nullptr;
+                    m->device_bytes += (n_rows + 1) * sizeof(uint32_t) + nnz * 12;
+                }
+            } else {
+                st = sl_build_from_device_csr(m, rp.as<uint32_t>(), ci.as<uint32_t>(), va.as<double>(), false);
+            }
+        }
+    } else {
+        st = sl_build_from_device_csr(m, row_ptr, col_idx, values, keep);
+    }
+    if (st != SL_OK) { sl_matrix_destroy(m); return st; }
+    *out = m;
+    return SL_OK;
+}
+
+sl_status sl_matrix_create_from_triplets(uint64_t n_triplets, const uint64_t *rows, const uint64_t *cols,
+                                         const double *values, uint64_t n_rows, uint64_t n_cols,
+                                         uint32_t flags, sl_matrix **out)
+{
+    if (!out) return sl_fail(SL_INVALID_INPUT, "out is null");
+    *out = nullptr;
+    // matrix/mod.rs:165-187: validation in input order
+    for (uint64_t k = 0; k < n_triplets; ++k) {
+        if (rows[k] >= n_rows)
+            return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "row index %llu in triplet %llu (max %llu)", (unsigned long long)rows[k],
+                           (unsigned long long)k, (unsigned long long)(n_rows ? n_rows - 1 : 0));
+        if (cols[k] >= n_cols)
+            return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "column index %llu in triplet %llu (max %llu)", (unsigned long long)cols[k],
+                           (unsigned long long)k, (unsigned long long)(n_cols ? n_cols - 1 : 0));
+        if (!std::isfinite(values[k]))
+            return sl_fail(SL_INVALID_INPUT, "Non-finite value at (%llu, %llu)", (unsigned long long)rows[k], (unsigned long long)cols[k]);
+    }
+    // sparse.rs:536-542 drop exact zeros; sparse.rs:91-96 stable sort by (row, col)
+    std::vector<uint64_t> idx;
+    idx.reserve(n_triplets);
+    for (uint64_t k = 0; k < n_triplets; ++k) if (values[k] != 0.0) idx.push_back(k);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) {
+        if (rows[a] != rows[b]) return rows[a] < rows[b];
+        return cols[a] < cols[b];
+    });
+    const uint64_t nnz = idx.size();
+    std::vector<uint32_t> rp(n_rows + 1, 0), ci(nnz);
+    std::vector<double> va(nnz);
+    for (uint64_t k = 0; k < nnz; ++k) { rp[rows[idx[k]] + 1] += 1; ci[k] = (uint32_t)cols[idx[k]]; va[k] = values[idx[k]]; }
+    for (uint64_t i = 0; i < n_rows; ++i) rp[i + 1] += rp[i];
+    return sl_matrix_create_csr(n_rows, n_cols, nnz, rp.data(), ci.data(), va.data(), SL_MEM_HOST, 0, flags, out);
+}
+
+sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info)
+{
+    if (!m || !info) return sl_fail(SL_INVALID_INPUT, "null argument");
+    info->n_rows = m->n_rows; info->n_cols = m->n_cols; info->nnz = m->nnz; info->row_offset = m->row_offset;
+    info->padded_nnz = m->padded_nnz; info->n_slices = m->n_slices; info->device_bytes = m->device_bytes;
+    info->max_row_nnz = m->max_row_nnz; info->min_row_nnz = m->min_row_nnz; info->uniform_width = m->uniform_width;
+    info->has_transpose = m->d_tptr != nullptr;
+    return SL_OK;
+}
+
+sl_status sl_matrix_download_csr(const sl_matrix *m, uint32_t *row_ptr, uint32_t *col_idx, double *values)
+{
+    if (!m) return sl_fail(SL_INVALID_INPUT, "null matrix");
+    if (!m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "matrix was created without SL_MATRIX_KEEP_CSR");
+    hipStream_t s = sl_context().stream;
+    SL_HIP(hipMemcpyAsync(row_ptr, m->d_row_ptr, (m->n_rows + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (m->nnz) {
+        SL_HIP(hipMemcpyAsync(col_idx, m->d_col_idx, m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        SL_HIP(hipMemcpyAsync(values, m->d_values, m->nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    SL_HIP(hipStreamSynchronize(s));
+    return SL_OK;
+}
+
+sl_status sl_matrix_is_diagonally_dominant(const sl_matrix *m, int *is_dd)
+{
+    if (!m || !is_dd) return sl_fail(SL_INVALID_INPUT, "null argument");
+    unsigned long long hs[4];
+    SL_TRY(sl_matrix_diag_pass(m, nullptr, hs));
+    *is_dd = (hs[0] & 1ull) ? 0 : 1;
+    return SL_OK;
+}
+
+sl_status sl_matrix_diagonal_inverse(const sl_matrix *m, double *dinv, sl_mem where)
+{
+    if (!m || !dinv) return sl_fail(SL_INVALID_INPUT, "null argument");
+    DevBuf tmp;
+    double *d = dinv;
+    if (where == SL_MEM_HOST) { SL_TRY(tmp.alloc(m->n_rows * sizeof(double))); d = tmp.as<double>(); }
+    unsigned long long hs[4];
+    SL_TRY(sl_matrix_diag_pass(m, d, hs));
+    if (hs[0] & 2ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2]);
+    if (hs[0] & 4ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3]);
+    if (where == SL_MEM_HOST) {
+        SL_HIP(hipMemcpyAsync(dinv, d, m->n_rows * sizeof(double), hipMemcpyDeviceToHost, sl_context().stream));
+        SL_HIP(hipStreamSynchronize(sl_context().stream));
+    }
+    return SL_OK;
+}
+
+// ---- primitives ------------------------------------------------------------------------------------
+sl_status sl_spmv(const sl_matrix *m, const double *x, double *y, sl_order order, sl_mem where)
+{
+    if (!m || !x || !y) return sl_fail(SL_INVALID_INPUT, "null argument");
+    hipStream_t s = sl_context().stream;
+    DevBuf xin, yout;
+    const double *dx;
+    SL_TRY(stage_in(x, m->n_cols, where, xin, &dx));
+    double *dy = y;
+    if (where == SL_MEM_HOST) { SL_TRY(yout.alloc(m->n_rows * sizeof(double))); dy = yout.as<double>(); }
+    sl_row_args a = row_args(m);
+    a.gather = dx; a.out = dy;
+    SL_TRY(sl_launch_rows(a, order, SL_EPI_SPMV, s));
+    if (where == SL_MEM_HOST) SL_HIP(hipMemcpyAsync(y, dy, m->n_rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    return SL_OK;
+}
+
+static sl_status reduce_common(int mode, uint64_t n, const double *x, const double *y, double *out, sl_mem where)
+{
+    if (!x || !out || (mode == 1 && !y)) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_TRY(require_device());
+    hipStream_t s = sl_context().stream;
+    DevBuf xin, yin;
+    const double *dx, *dy = nullptr;
+    SL_TRY(stage_in(x, n, where, xin, &dx));
+    if (mode == 1) SL_TRY(stage_in(y, n, where, yin, &dy));
+    double *scr = static_cast<double *>(sl_scratch(4096 * sizeof(double)));
+    if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
+    double *res = scr + 4000;
+    if (mode == 0) SL_TRY(sl_launch_sumsq(n, dx, scr, res, s));
+    else if (mode == 1) SL_TRY(sl_launch_dot(n, dx, dy, scr, res, s));
+    else SL_TRY(sl_launch_abs_sum(n, dx, scr, res, s));
+    double h;
+    SL_TRY(read_scalars(res, &h, 1));
+    *out = (mode == 0) ? std::sqrt(h) : h;
+    return SL_OK;
+}
+sl_status sl_dot(uint64_t n, const double *x, const double *y, double *out, sl_mem where) { return reduce_common(1, n, x, y, out, where); }
+sl_status sl_l2_norm(uint64_t n, const double *x, double *out, sl_mem where) { return reduce_common(0, n, x, nullptr, out, where); }
+
+sl_status sl_axpy(uint64_t n, double alpha, const double *x, double *y, sl_mem where)
+{
+    if (!x || !y) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_TRY(require_device());
+    hipStream_t s = sl_context().stream;
+    DevBuf xin, yio;
+    const double *dx;
+    SL_TRY(stage_in(x, n, where, xin, &dx));
+    double *dy = y;
+    if (where == SL_MEM_HOST) {
+        SL_TRY(yio.alloc(n * sizeof(double)));
+        dy = yio.as<double>();
+        SL_HIP(hipMemcpyAsync(dy, y, n * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    SL_TRY(sl_launch_axpy(n, alpha, dx, dy, s));
+    if (where == SL_MEM_HOST) SL_HIP(hipMemcpyAsync(y, dy, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    return SL_OK;
+}
+
+// ---- fused Neumann step ------------------------------------------------------------------------------
+sl_status sl_neumann_step(const sl_matrix *m, const double *dinv, const double *t_in, double *t_out,
+                          double *x, double *norm2, sl_order order)
+{
+    if (!m || !dinv || !t_in || !t_out || !x) return sl_fail(SL_INVALID_INPUT, "null argument");
+    double *scr = static_cast<double *>(sl_scratch(partial_bytes(m)));
+    if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
+    sl_row_args a = row_args(m);
+    a.gather = t_in; a.dinv = dinv; a.out = t_out; a.x = x; a.partials = scr; a.result = norm2;
+    return sl_launch_rows(a, order, SL_EPI_NEUMANN, sl_context().stream);
+}
+
+sl_status sl_neumann_run_steps(const sl_matrix *m, const double *dinv, double *t_a, double *t_b, double *x,
+                               double *norm2, sl_order order, uint64_t steps, float *elapsed_ms)
+{
+    if (!m || !dinv || !t_a || !t_b || !x) return sl_fail(SL_INVALID_INPUT, "null argument");
+    hipStream_t s = sl_context().stream;
+    hipEvent_t e0, e1;
+    SL_HIP(hipEventCreate(&e0));
+    SL_HIP(hipEventCreate(&e1));
+    SL_HIP(hipEventRecord(e0, s));
+    sl_status st = SL_OK;
+    for (uint64_t k = 0; k < steps && st == SL_OK; ++k)
+        st = sl_neumann_step(m, dinv, (k & 1) ? t_b : t_a, (k & 1) ? t_a : t_b, x, norm2, order);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (elapsed_ms) *elapsed_ms = ms;
+    return st;
+}
+
+// ---- NeumannSolver::solve ---------------------------------------------------------------------------
+void sl_neumann_options_default(sl_neumann_options *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->tolerance = 1e-6;          // solver/mod.rs:47-62
+    o->max_iterations = 1000;
+    o->max_terms = 50;            // neumann.rs:58-60
+    o->series_tolerance = 1e-8;
+    o->order = SL_ORDER_CSR_SEQUENTIAL;
+    o->start = SL_START_ZERO;
+    o->residual = SL_RESIDUAL_TRUE;
+    o->mem = SL_MEM_HOST;
+}
+
+sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *initial_guess,
+                           const sl_neumann_options *o, double *x_out, double *term_norms,
+                           sl_neumann_result *res)
+{
+    if (!m || !b || !o || !x_out || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
+    memset(res, 0, sizeof(*res));
+    res->residual_norm = INFINITY;
+    res->error_bound = -1.0;
+    const auto wall0 = std::chrono::steady_clock::now();
+    // NeumannState::new, neumann.rs:139-249 — order of checks preserved
+    if (m->row_offset == 0 && m->n_rows != m->n_cols)
+        return sl_fail(SL_INVALID_INPUT, "Matrix must be square for Neumann series");
+    if (m->row_offset != 0 || m->n_rows != m->n_cols)
+        return sl_fail(SL_UNSUPPORTED_FORMAT, "sl_neumann_solve needs the whole matrix; drive row slices with sl_neumann_step");
+    const uint64_t n = m->n_rows;
+    const sl_mem where = (sl_mem)o->mem;
+    const sl_order order = (sl_order)o->order;
+    hipStream_t s = sl_context().stream;
+
+    DevBuf bbuf, dinv, rhs, x, ta, tb, scal;
+    const double *db;
+    SL_TRY(stage_in(b, n, where, bbuf, &db));
+    SL_TRY(dinv.alloc(n * 8)); SL_TRY(rhs.alloc(n * 8)); SL_TRY(x.alloc(n * 8));
+    SL_TRY(ta.alloc(n * 8)); SL_TRY(tb.alloc(n * 8)); SL_TRY(scal.alloc(64));
+    double *scr = static_cast<double *>(sl_scratch(partial_bytes(m)));
+    if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
+    double *d_res = scal.as<double>();
+
+    unsigned long long hs[4];
+    SL_TRY(sl_matrix_diag_pass(m, dinv.as<double>(), hs));
+    if (hs[0] & 1ull) return sl_fail(SL_NOT_DIAGONALLY_DOMINANT, "matrix is not row diagonally dominant (first failing row %llu)", hs[1]);
+    if (hs[0] & 2ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2]);
+    if (hs[0] & 4ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3]);
+    SL_TRY(sl_launch_scale_rows(n, db, dinv.as<double>(), rhs.as<double>(), s));        // rhs = b * dinv  (:191-194)
+    if (o->start == SL_START_INITIAL_GUESS) {
+        if (!initial_guess) return sl_fail(SL_INVALID_INPUT, "initial_guess is null");
+        SL_HIP(hipMemcpyAsync(x.p, initial_guess, n * 8, where == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    } else if (o->start == SL_START_REFERENCE_DEFAULT) {
+        SL_HIP(hipMemcpyAsync(x.p, rhs.p, n * 8, hipMemcpyDeviceToDevice, s));           // :197-208
+    } else {
+        SL_HIP(hipMemsetAsync(x.p, 0, n * 8, s));
+    }
+    SL_HIP(hipMemcpyAsync(ta.p, rhs.p, n * 8, hipMemcpyDeviceToDevice, s));              // current_term = rhs (:211)
+
+    double *t_cur = ta.as<double>(), *t_nxt = tb.as<double>();
+    const double *res_rhs = (o->residual == SL_RESIDUAL_REFERENCE_SCALED) ? rhs.as<double>() : db;
+    double resn = INFINITY, tn = 0.0;
+    bool series_conv = false;
+    uint64_t terms = 0, it = 0, matvec = 0, step_launches = 0, resid_launches = 0;
+    sl_status status = SL_OK;
+
+    auto is_converged = [&]() { return (resn <= o->tolerance) || (series_conv && !(terms >= o->max_terms)); };
+    auto update_residual = [&]() -> sl_status {                                         // neumann.rs:302-318
+        sl_row_args a = row_args(m);
+        a.gather = x.as<double>(); a.aux = res_rhs; a.out = nullptr; a.partials = scr; a.result = d_res;
+        SL_TRY(sl_launch_rows(a, order, SL_EPI_RESIDUAL, s));
+        double h;
+        SL_TRY(read_scalars(d_res, &h, 1));
+        resn = std::sqrt(h);
+        ++matvec; ++resid_launches;
+        return SL_OK;
+    };
+
+    hipEvent_t e0, e1;
+    SL_HIP(hipEventCreate(&e0));
+    SL_HIP(hipEventCreate(&e1));
+    SL_HIP(hipEventRecord(e0, s));
+    while (!is_converged() && it < o->max_iterations) {
+        if (terms < o->max_terms) {                                                      // compute_next_term :252-277
+            double h;
+            if (terms > 0) {
+                sl_row_args a = row_args(m);
+                a.gather = t_cur; a.dinv = dinv.as<double>(); a.out = t_nxt; a.x = x.as<double>();
+                a.partials = scr; a.result = d_res;
+                status = sl_launch_rows(a, order, SL_EPI_NEUMANN, s);
+                if (status != SL_OK) break;
+                std::swap(t_cur, t_nxt);
+                ++matvec; ++step_launches;
+            } else {
+                status = sl_launch_axpy(n, 1.0, t_cur, x.as<double>(), s);               // x += term (k = 0)
+                if (status == SL_OK) status = sl_launch_sumsq(n, t_cur, scr, d_res, s);
+                if (status != SL_OK) break;
+            }
+            status = read_scalars(d_res, &h, 1);
+            if (status != SL_OK) break;
+            tn = std::sqrt(h);
+            if (term_norms) term_norms[terms] = tn;
+            ++terms;
+            if (tn < o->series_tolerance) series_conv = true;                            // :270-274
+        }
+        if (it % 5 == 0) { status = update_residual(); if (status != SL_OK) break; }     // :489-491
+        ++it;
+        if (!std::isfinite(resn)) {                                                      // :501-507
+            status = sl_fail(SL_NUMERICAL_INSTABILITY, "Non-finite residual norm at iteration %llu", (unsigned long long)it);
+            break;
+        }
+        if (series_conv) break;                                                          // :510-512
+    }
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float loop_ms = 0.f;
+    hipEventElapsedTime(&loop_ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+
+    if (status == SL_OK) {
+        status = update_residual();                                                      // :516
+        if (status == SL_OK) {
+            res->converged = is_converged() ? 1 : 0;
+            if (!res->converged && it >= o->max_iterations)                              // :523-530
+                status = sl_fail(SL_CONVERGENCE_FAILURE, "neumann: %llu iterations, residual %.6e > tolerance %.6e",
+                                 (unsigned long long)it, resn, o->tolerance);
+        }
+    }
+    // estimate_error_bounds, neumann.rs:321-347
+    if (o->compute_error_bounds && series_conv && terms > 1 && status == SL_OK) {
+        double h;
+        if (sl_launch_sumsq(n, rhs.as<double>(), scr, d_res, s) == SL_OK && read_scalars(d_res, &h, 1) == SL_OK) {
+            const double rhs_norm = std::sqrt(h);
+            const double ratio = tn / rhs_norm;
+            const double est = std::pow(ratio, 1.0 / (double)(terms - 1));
+            if (est < 1.0) res->error_bound = std::pow(est, (double)(int)terms) / (1.0 - est) * rhs_norm;
+        }
+    }
+    res->iterations = it; res->terms_computed = terms; res->matvec_count = matvec;
+    res->residual_norm = resn; res->last_term_norm = tn; res->series_converged = series_conv ? 1 : 0;
+    res->device_time_ms = loop_ms;
+    res->bytes_moved = (step_launches + resid_launches) * (12ull * m->nnz + 4ull * (n + 1)) + step_launches * 40ull * n
+                       + resid_launches * 16ull * n;
+    hipError_t ce = hipMemcpyAsync(x_out, x.p, n * 8, where == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(s);
+    if (ce != hipSuccess && status == SL_OK) status = sl_fail(SL_DEVICE_ERROR, "result download failed: %s", hipGetErrorString(ce));
+    res->total_time_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return status;
+}
+
+} // extern "C"

@@ -1,0 +1,100 @@
+// sl_internal.hpp — internal structures of libsublinear_hip (not part of the ABI).
+//
+// HBM layout of a matrix ("row-slice" layout): rows are grouped in
+// slices of 64 consecutive rows = one wavefront, lane l owns row 64*s + l.  A slice
+// of width W (max row length in the slice, rounded up to 4) is stored as W/4 "quads";
+// quad q holds entries 4q..4q+3 of all 64 rows:
+//     cols : [quad][lane 0..63][4]      u32   -> one 16-B load per lane, 1 KiB per wave
+//     vals : [quad][half 0..1][lane][2] f64   -> two 16-B loads per lane, 2 x 1 KiB per wave
+// so every matrix byte is fetched by fully coalesced dwordx4 loads while each lane still
+// walks ITS row left to right — the reference's summation order (sparse.rs:187-203)
+// is kept bit for bit with no cross-lane reduction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include "../../include/sublinear_hip.h"
+
+#define SL_SLICE 64
+#define SL_BLOCK 256
+#define SL_WAVES_PER_BLOCK (SL_BLOCK / SL_SLICE)
+
+struct sl_matrix {
+    uint64_t n_rows = 0, n_cols = 0, nnz = 0, row_offset = 0;
+    uint32_t flags = 0;
+    int device = 0;
+    // row-slice layout
+    uint64_t n_slices = 0, padded_nnz = 0;
+    uint32_t *d_slice_ptr = nullptr; // [n_slices+1] in quads
+    uint32_t *d_row_len = nullptr;   // [n_slices*64]
+    uint32_t *d_cols = nullptr;      // [padded_nnz]
+    double *d_vals = nullptr;        // [padded_nnz]
+    uint32_t max_row_nnz = 0, min_row_nnz = 0, uniform_width = 0;
+    // raw CSR (SL_MATRIX_KEEP_CSR or needed by the sparse-frontier kernels)
+    uint32_t *d_row_ptr = nullptr, *d_col_idx = nullptr;
+    double *d_values = nullptr;
+    // transpose as CSR of A^T (SL_MATRIX_WITH_TRANSPOSE): rows of each column ascending
+    uint32_t *d_tptr = nullptr; // [n_cols+1]
+    uint32_t *d_trow = nullptr; // [nnz]
+    double *d_tval = nullptr;   // [nnz]
+    uint64_t device_bytes = 0;
+};
+
+// thread-local launch context
+struct sl_ctx {
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // grow-only device scratch for reductions (per thread, per device)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int scratch_device = -1;
+};
+sl_ctx &sl_context();
+sl_status sl_fail(sl_status s, const char *fmt, ...);
+void *sl_scratch(size_t bytes); // nullptr on failure
+
+#define SL_HIP(call)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return sl_fail(SL_DEVICE_ERROR, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// ---- kernel launchers (sl_kernels.hip) -------------------------------------------------
+enum sl_epilogue { SL_EPI_SPMV = 0, SL_EPI_NEUMANN = 1, SL_EPI_RESIDUAL = 2, SL_EPI_PUSH = 3 };
+
+struct sl_row_args {
+    // matrix
+    const uint32_t *slice_ptr, *row_len, *cols;
+    const double *vals;
+    uint64_t n_rows, n_slices, row_offset;
+    uint32_t uniform_width;
+    // vectors
+    const double *gather; // gathered vector (n_cols)
+    const double *dinv;   // n_rows
+    const double *aux;    // RESIDUAL: rhs (n_rows); PUSH: unused
+    double *out;          // SPMV: y; NEUMANN: t_out; RESIDUAL: r (may be null); PUSH: delta_out
+    double *x;            // NEUMANN / PUSH: x in/out
+    double *r;            // PUSH: r in/out
+    double theta;         // PUSH
+    double *partials;     // per-block partial sums (norm^2); PUSH: also counts at partials + nblocks (as u64)
+    double *result;       // device scalar(s): [0] = sum of squares, PUSH: [1] = frontier count (as double bits u64)
+};
+sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s);
+uint32_t sl_row_grid(uint64_t n_slices);
+
+sl_status sl_launch_sumsq(uint64_t n, const double *x, double *partials, double *result, hipStream_t s);
+sl_status sl_launch_dot(uint64_t n, const double *x, const double *y, double *partials, double *result, hipStream_t s);
+sl_status sl_launch_axpy(uint64_t n, double alpha, const double *x, double *y, hipStream_t s);
+sl_status sl_launch_scale_rows(uint64_t n, const double *a, const double *b, double *out, hipStream_t s); // out = a*b
+sl_status sl_launch_sub(uint64_t n, const double *a, const double *b, double *out, hipStream_t s);        // out = a-b
+sl_status sl_launch_abs_sum(uint64_t n, const double *x, double *partials, double *result, hipStream_t s);
+
+// matrix build (sl_matrix.hip)
+sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx,
+                                   const double *d_values, bool keep_csr_copy);
+// a6 + a7 pass: h_status[0] bits 1 = not dominant, 2 = missing diagonal, 4 = near-zero diagonal;
+// h_status[1..3] = first offending row of each class.  d_dinv may be null.
+sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long long h_status[4]);

@@ -1,0 +1,280 @@
+// sl_matrix.hip — device-side matrix ingest: CSR validation, CSR -> row-slice layout,
+// diagonal-dominance check, D^-1 extraction, column structure (pattern of A^T).
+// One-off work per matrix (not in the per-iteration metric).
+#include "sl_internal.hpp"
+#include <vector>
+
+// ---- validation ---------------------------------------------------------------------------
+// err[0]: bit0 row_ptr not monotone / bad ends, bit1 column out of bounds
+__global__ void sl_validate_csr_kernel(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, const uint32_t *row_ptr,
+                                       const uint32_t *col_idx, uint32_t *err)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += stride)
+        if (row_ptr[i] > row_ptr[i + 1]) atomicOr(err, 1u);
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride)
+        if ((uint64_t)col_idx[k] >= n_cols) atomicOr(err, 2u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (row_ptr[0] != 0u) atomicOr(err, 1u);
+        if ((uint64_t)row_ptr[n_rows] != nnz) atomicOr(err, 1u);
+    }
+}
+
+// row lengths + slice widths (in quads) + min/max row length
+__global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64_t n_slices, const uint32_t *row_ptr,
+                                                         uint32_t *row_len, uint32_t *slice_w, uint32_t *minmax)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t s = i >> 6;
+    if (s >= n_slices) return;
+    uint32_t len = 0;
+    if (i < n_rows) {
+        len = row_ptr[i + 1] - row_ptr[i];
+        atomicMin(&minmax[0], len);
+        atomicMax(&minmax[1], len);
+    }
+    row_len[i] = len;
+    uint32_t mx = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = __shfl_xor(mx, o);
+        mx = other > mx ? other : mx;
+    }
+    if ((threadIdx.x & 63) == 0) slice_w[s] = (mx + 3u) >> 2;
+}
+
+// CSR -> row-slice layout.  One wave per slice, lane = row.  Padding entries carry
+// value 0.0 and a valid column (the row's own index when it exists); the kernels never
+// add them (guarded by row_len), they only keep every gather in bounds.
+__global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, uint64_t n_cols, uint64_t n_slices,
+                                                             uint64_t row_offset, const uint32_t *row_ptr,
+                                                             const uint32_t *col_idx, const double *values,
+                                                             const uint32_t *slice_ptr, uint32_t *cols, double *vals)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const uint64_t i = s * 64 + lane;
+    const uint32_t q0 = slice_ptr[s], q1 = slice_ptr[s + 1];
+    uint32_t start = 0, len = 0;
+    uint32_t padcol = 0;
+    if (i < n_rows) {
+        start = row_ptr[i];
+        len = row_ptr[i + 1] - start;
+        const uint64_t gi = row_offset + i;
+        padcol = gi < n_cols ? (uint32_t)gi : 0u;
+    }
+    for (uint32_t q = q0; q < q1; ++q) {
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t k = (q - q0) * 4 + e;
+            const bool in = k < len;
+            const uint32_t c = in ? col_idx[start + k] : padcol;
+            const double v = in ? values[start + k] : 0.0;
+            cols[((uint64_t)q * 64 + lane) * 4 + e] = c;
+            vals[(((uint64_t)q * 2 + (e >> 1)) * 64 + lane) * 2 + (e & 1u)] = v;
+        }
+    }
+}
+
+// a6 + a7: one pass over the slice layout.  Per row, in stored order:
+//   diag = |a_ii| of the LAST diagonal entry seen (0 if none), off += |a_ij|   (matrix/mod.rs:467-485)
+//   d    = that diagonal entry; missing or |d| < 1e-14 is an error            (neumann.rs:172-188)
+// status[0] bits: 1 = some row not dominant, 2 = missing diagonal, 4 = near-zero diagonal
+// status[1..3] = smallest offending row index per class (for the message).
+__global__ __launch_bounds__(256) void sl_diag_kernel(uint64_t n_rows, uint64_t n_slices, uint64_t row_offset,
+                                                      const uint32_t *slice_ptr, const uint32_t *row_len,
+                                                      const uint32_t *cols, const double *vals, double *dinv,
+                                                      unsigned long long *status)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const uint64_t i = s * 64 + lane;
+    const uint32_t q0 = slice_ptr[s], q1 = slice_ptr[s + 1];
+    const uint32_t len = row_len[i];
+    const uint32_t gi = (uint32_t)(row_offset + i);
+    double diag_abs = 0.0, off = 0.0, d = 0.0;
+    bool found = false;
+    for (uint32_t q = q0; q < q1; ++q) {
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t k = (q - q0) * 4 + e;
+            if (k < len) {
+                const uint32_t c = cols[((uint64_t)q * 64 + lane) * 4 + e];
+                const double v = vals[(((uint64_t)q * 2 + (e >> 1)) * 64 + lane) * 2 + (e & 1u)];
+                if (c == gi) { diag_abs = fabs(v); d = v; found = true; }
+                else off = __dadd_rn(off, fabs(v));
+            }
+        }
+    }
+    if (i >= n_rows) return;
+    if (diag_abs < off) { atomicOr(&status[0], 1ull); atomicMin(&status[1], (unsigned long long)i); }
+    if (!found) { atomicOr(&status[0], 2ull); atomicMin(&status[2], (unsigned long long)i); }
+    else if (fabs(d) < 1e-14) { atomicOr(&status[0], 4ull); atomicMin(&status[3], (unsigned long long)i); }
+    if (dinv) dinv[i] = (found && fabs(d) >= 1e-14) ? 1.0 / d : 0.0;
+}
+
+// transpose (CSR of A^T, values included, rows of each column ascending): histogram of
+// columns -> tptr; stable radix sort of (col, entry id) pairs -> entry order; gather.
+__global__ void sl_col_count_kernel(uint64_t nnz, const uint32_t *col_idx, uint32_t *count)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += stride)
+        atomicAdd(&count[col_idx[k] + 1], 1u);
+}
+__global__ void sl_iota_kernel(uint64_t n, uint32_t *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) out[k] = (uint32_t)k;
+}
+__global__ void sl_transpose_gather_kernel(uint64_t nnz, uint64_t n_rows, const uint32_t *row_ptr, const double *values,
+                                           const uint32_t *entry, uint32_t *trow, double *tval)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) {
+        const uint32_t k = entry[p];
+        // row of entry k: largest i with row_ptr[i] <= k
+        uint64_t lo = 0, hi = n_rows;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (row_ptr[mid] <= k) lo = mid; else hi = mid;
+        }
+        trow[p] = (uint32_t)lo;
+        tval[p] = values[k];
+    }
+}
+
+sl_status sl_sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
+                            uint64_t n, int end_bit, hipStream_t s);
+
+static uint32_t grid_for(uint64_t n, uint32_t block)
+{
+    uint64_t g = (n + block - 1) / block;
+    if (g > 65535 * 16) g = 65535 * 16;
+    if (g == 0) g = 1;
+    return (uint32_t)g;
+}
+
+sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx,
+                                   const double *d_values, bool keep_csr_copy)
+{
+    hipStream_t st = sl_context().stream;
+    const uint64_t n = m->n_rows, nnz = m->nnz;
+    m->n_slices = (n + SL_SLICE - 1) / SL_SLICE;
+
+    // 1. validate
+    uint32_t *d_err = nullptr;
+    SL_HIP(hipMalloc(&d_err, 4 * sizeof(uint32_t)));
+    SL_HIP(hipMemsetAsync(d_err, 0, 4 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(sl_validate_csr_kernel, dim3(grid_for(nnz > n ? nnz : n, 256) > 4096 ? 4096 : grid_for(nnz > n ? nnz : n, 256)),
+                       dim3(256), 0, st, n, m->n_cols, nnz, d_row_ptr, d_col_idx, d_err);
+    uint32_t h_err = 0;
+    SL_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    if (h_err & 1u) { hipFree(d_err); return sl_fail(SL_INVALID_SPARSE_MATRIX, "row_ptr is not a monotone 0..nnz prefix array"); }
+    if (h_err & 2u) { hipFree(d_err); return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "column index >= n_cols (%llu)", (unsigned long long)m->n_cols); }
+
+    // 2. row lengths, slice widths
+    const uint64_t padded_rows = m->n_slices * SL_SLICE;
+    uint32_t *d_slice_w = nullptr;
+    SL_HIP(hipMalloc(&m->d_row_len, (padded_rows ? padded_rows : 1) * sizeof(uint32_t)));
+    SL_HIP(hipMalloc(&d_slice_w, (m->n_slices ? m->n_slices : 1) * sizeof(uint32_t)));
+    const uint32_t mm_init[2] = {0xffffffffu, 0u};
+    SL_HIP(hipMemcpyAsync(d_err, mm_init, sizeof(mm_init), hipMemcpyHostToDevice, st));
+    if (m->n_slices)
+        hipLaunchKernelGGL(sl_row_len_kernel, dim3((uint32_t)((padded_rows + 255) / 256)), dim3(256), 0, st, n, m->n_slices,
+                           d_row_ptr, m->d_row_len, d_slice_w, d_err);
+    std::vector<uint32_t> slice_w(m->n_slices), slice_ptr(m->n_slices + 1);
+    uint32_t mm[2];
+    SL_HIP(hipMemcpyAsync(mm, d_err, sizeof(mm), hipMemcpyDeviceToHost, st));
+    if (m->n_slices)
+        SL_HIP(hipMemcpyAsync(slice_w.data(), d_slice_w, m->n_slices * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    hipFree(d_slice_w);
+    hipFree(d_err);
+    m->min_row_nnz = n ? mm[0] : 0;
+    m->max_row_nnz = n ? mm[1] : 0;
+    uint64_t acc = 0;
+    for (uint64_t s = 0; s < m->n_slices; ++s) { slice_ptr[s] = (uint32_t)acc; acc += slice_w[s]; }
+    if (acc > 0xffffffffull) return sl_fail(SL_ALLOCATION, "matrix too large for 32-bit slice pointers");
+    slice_ptr[m->n_slices] = (uint32_t)acc;
+    m->padded_nnz = acc * 4 * SL_SLICE;
+    m->uniform_width = (n && m->min_row_nnz == m->max_row_nnz && (m->max_row_nnz % 4u) == 0u) ? m->max_row_nnz : 0u;
+
+    SL_HIP(hipMalloc(&m->d_slice_ptr, (m->n_slices + 1) * sizeof(uint32_t)));
+    SL_HIP(hipMemcpyAsync(m->d_slice_ptr, slice_ptr.data(), (m->n_slices + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    SL_HIP(hipMalloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
+    SL_HIP(hipMalloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
+    if (m->n_slices)
+        hipLaunchKernelGGL(sl_fill_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_cols,
+                           m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_cols, m->d_vals);
+    SL_HIP(hipGetLastError());
+    m->device_bytes = (m->n_slices + 1 + padded_rows) * sizeof(uint32_t) + m->padded_nnz * 12;
+
+    // 3. transpose
+    if (m->flags & SL_MATRIX_WITH_TRANSPOSE) {
+        SL_HIP(hipMalloc(&m->d_tptr, (m->n_cols + 1) * sizeof(uint32_t)));
+        SL_HIP(hipMalloc(&m->d_trow, (nnz ? nnz : 1) * sizeof(uint32_t)));
+        SL_HIP(hipMalloc(&m->d_tval, (nnz ? nnz : 1) * sizeof(double)));
+        SL_HIP(hipMemsetAsync(m->d_tptr, 0, (m->n_cols + 1) * sizeof(uint32_t), st));
+        const uint32_t g = grid_for(nnz, 256) > 8192 ? 8192 : grid_for(nnz, 256);
+        if (nnz) hipLaunchKernelGGL(sl_col_count_kernel, dim3(g), dim3(256), 0, st, nnz, d_col_idx, m->d_tptr);
+        std::vector<uint32_t> tptr(m->n_cols + 1);
+        SL_HIP(hipMemcpyAsync(tptr.data(), m->d_tptr, (m->n_cols + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        SL_HIP(hipStreamSynchronize(st));
+        uint64_t run = 0;
+        for (uint64_t j = 0; j <= m->n_cols; ++j) { run += tptr[j]; tptr[j] = (uint32_t)run; }
+        SL_HIP(hipMemcpyAsync(m->d_tptr, tptr.data(), (m->n_cols + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        if (nnz) {
+            uint32_t *d_keys = nullptr, *d_ent_in = nullptr, *d_ent = nullptr;
+            SL_HIP(hipMalloc(&d_keys, nnz * sizeof(uint32_t)));
+            SL_HIP(hipMalloc(&d_ent_in, nnz * sizeof(uint32_t)));
+            SL_HIP(hipMalloc(&d_ent, nnz * sizeof(uint32_t)));
+            hipLaunchKernelGGL(sl_iota_kernel, dim3(g), dim3(256), 0, st, nnz, d_ent_in);
+            int bits = 1;
+            while (bits < 32 && (1ull << bits) < m->n_cols) ++bits;
+            sl_status ss = sl_sort_pairs_u32(d_col_idx, d_keys, d_ent_in, d_ent, nnz, bits, st);
+            if (ss == SL_OK) {
+                hipLaunchKernelGGL(sl_transpose_gather_kernel, dim3(g), dim3(256), 0, st, nnz, n, d_row_ptr, d_values, d_ent,
+                                   m->d_trow, m->d_tval);
+                hipStreamSynchronize(st);
+            }
+            hipFree(d_keys); hipFree(d_ent_in); hipFree(d_ent);
+            if (ss != SL_OK) return ss;
+        }
+        m->device_bytes += (m->n_cols + 1) * sizeof(uint32_t) + nnz * 12;
+    }
+
+    // 4. raw CSR copy
+    if (keep_csr_copy) {
+        SL_HIP(hipMalloc(&m->d_row_ptr, (n + 1) * sizeof(uint32_t)));
+        SL_HIP(hipMalloc(&m->d_col_idx, (nnz ? nnz : 1) * sizeof(uint32_t)));
+        SL_HIP(hipMalloc(&m->d_values, (nnz ? nnz : 1) * sizeof(double)));
+        SL_HIP(hipMemcpyAsync(m->d_row_ptr, d_row_ptr, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        if (nnz) {
+            SL_HIP(hipMemcpyAsync(m->d_col_idx, d_col_idx, nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            SL_HIP(hipMemcpyAsync(m->d_values, d_values, nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        m->device_bytes += (n + 1) * sizeof(uint32_t) + nnz * 12;
+    }
+    SL_HIP(hipStreamSynchronize(st));
+    return SL_OK;
+}
+
+// run the a6/a7 pass; dinv may be null (dominance check only)
+sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long long h_status[4])
+{
+    hipStream_t st = sl_context().stream;
+    unsigned long long *d_status = nullptr;
+    SL_HIP(hipMalloc(&d_status, 4 * sizeof(unsigned long long)));
+    const unsigned long long init[4] = {0ull, ~0ull, ~0ull, ~0ull};
+    SL_HIP(hipMemcpyAsync(d_status, init, sizeof(init), hipMemcpyHostToDevice, st));
+    if (m->n_slices)
+        hipLaunchKernelGGL(sl_diag_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, m->n_rows, m->n_slices,
+                           m->row_offset, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_dinv, d_status);
+    SL_HIP(hipMemcpyAsync(h_status, d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    hipFree(d_status);
+    return SL_OK;
+}

@@ -1,0 +1,169 @@
+"""Seeded synthetic inputs.  numpy twins of csrc/sl_synth.hip — bit-identical.
+
+Recipes follow the reference's own benchmark generators (cited per function); they are
+counter-based so any row range can be produced independently on any rank.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_G = np.uint64(0x9E3779B97F4A7C15)
+_K = np.uint64(0xD1B54A32D192ED03)
+
+
+def _mix64(z: np.ndarray) -> np.ndarray:
+    z = z.copy()
+    z ^= z >> np.uint64(30)
+    z *= _M1
+    z ^= z >> np.uint64(27)
+    z *= _M2
+    z ^= z >> np.uint64(31)
+    return z
+
+
+def sdd_rows(n: int, k: int, seed: int, half_bandwidth: int = 0, row_lo: int = 0, row_hi: int | None = None):
+    """S-DD(n, k, seed, w): rows [row_lo, row_hi) as CSR (row_ptr u32, col_idx u32, values f64) + b.
+
+    After src/ultra_fast.rs:221-248 / benches/performance_benchmarks.rs:12-43 (LCG columns, diagonal
+    10 + 0.01 i, b = 1 + 0.001 i) but duplicate-free, self-excluding, exactly k entries per row
+    (diagonal included), strictly row diagonally dominant (sum|offdiag| <= d/2), asymmetric,
+    columns ascending.  half_bandwidth w > 0 draws columns from the band [i-w, i+w].
+    """
+    if row_hi is None:
+        row_hi = n
+    if not (2 <= k <= 64):
+        raise ValueError("k must be in [2, 64]")
+    m = k - 1
+    span = n
+    if half_bandwidth and 2 * half_bandwidth + 1 < n:
+        span = 2 * half_bandwidth + 1
+    sw = span // m
+    if sw < 2:
+        raise ValueError("column window too narrow for k-1 distinct off-diagonals")
+    with np.errstate(over="ignore"):
+        i = np.arange(row_lo, row_hi, dtype=np.uint64)
+        rows = i.size
+        if span == n:
+            lo = np.zeros(rows, dtype=np.uint64)
+        else:
+            w = np.uint64(half_bandwidth)
+            lo = np.where(i > w, i - w, np.uint64(0))
+            lo = np.minimum(lo, np.uint64(n - span))
+        j = np.arange(m, dtype=np.uint64)
+        key = np.uint64(seed) * _G + (i[:, None] * np.uint64(64) + j[None, :] + np.uint64(1)) * _K
+        h1 = _mix64(key)
+        h2 = _mix64(h1 + _G)
+        off = h1 % np.uint64(sw)
+        c = lo[:, None] + j[None, :] * np.uint64(sw) + off
+        hit = c == i[:, None]
+        c = np.where(hit, np.where(off + np.uint64(1) < np.uint64(sw), c + np.uint64(1), c - np.uint64(1)), c)
+    d = 10.0 + 0.01 * (i % np.uint64(1000)).astype(np.float64)
+    scale = d / float(2 * m)
+    u = (h2 >> np.uint64(11)).astype(np.float64) * 1.1102230246251565e-16
+    v = (2.0 * u - 1.0) * scale[:, None]
+    v = np.where(v == 0.0, scale[:, None], v)
+    # insert the diagonal at its sorted position
+    p = (c < i[:, None]).sum(axis=1)
+    col = np.empty((rows, k), dtype=np.uint32)
+    val = np.empty((rows, k), dtype=np.float64)
+    slot = np.arange(k)[None, :]
+    before = slot < p[:, None]
+    at = slot == p[:, None]
+    src = np.clip(np.where(before, slot, slot - 1), 0, m - 1)
+    col[:] = np.take_along_axis(c, src, axis=1).astype(np.uint32)
+    val[:] = np.take_along_axis(v, src, axis=1)
+    col[at] = i.astype(np.uint32)
+    val[at] = d
+    row_ptr = (np.arange(rows + 1, dtype=np.uint64) * np.uint64(k)).astype(np.uint32)
+    b = 1.0 + 0.001 * (i % np.uint64(1000)).astype(np.float64)
+    return row_ptr, col.reshape(-1), val.reshape(-1), b
+
+
+def ts_lcg(seed: int):
+    """createSeededRandom, src/core/utils.ts:161-168."""
+    state = seed
+
+    def nxt() -> float:
+        nonlocal state
+        state = (state * 1664525 + 1013904223) % 0x100000000
+        return state / 0x100000000
+
+    return nxt
+
+
+def gen1000_dense(size: int = 1000, strength: float = 2.0, seed: int = 42, density: float = 0.3):
+    """S-GEN1000: `generate -t diagonally-dominant -s 1000` (src/cli/index.ts:308-352,
+    src/mcp/tools/matrix.ts:297-322: each off-diagonal kept w.p. 0.3, U(-1,1), a_ii = strength*sum|off| + 1)
+    with Math.random replaced by the TS LCG (core/utils.ts:161-168) so it is reproducible.
+    Returns CSR (row_ptr, col_idx, values) and b = ones."""
+    rnd = ts_lcg(seed)
+    rp = [0]
+    ci: list[int] = []
+    va: list[float] = []
+    for i in range(size):
+        row_c: list[int] = []
+        row_v: list[float] = []
+        s = 0.0
+        for j in range(size):
+            if j == i:
+                row_c.append(j)
+                row_v.append(0.0)
+                continue
+            if rnd() < density:
+                v = (rnd() - 0.5) * 2.0
+                if v != 0.0:
+                    row_c.append(j)
+                    row_v.append(v)
+                    s += abs(v)
+        di = row_c.index(i)
+        row_v[di] = strength * s + 1.0
+        ci.extend(row_c)
+        va.extend(row_v)
+        rp.append(len(ci))
+    return (np.asarray(rp, dtype=np.uint32), np.asarray(ci, dtype=np.uint32), np.asarray(va, dtype=np.float64),
+            np.ones(size, dtype=np.float64))
+
+
+def pagerank_graph(n: int, seed: int, mean_degree: int = 16, zipf_s: float = 2.1, max_degree: int = 10_000):
+    """S-PR(n, seed): directed power-law graph as a weighted adjacency CSR (unit weights).
+    Out-degree ~ Zipf(s) capped, targets drawn with a mild preferential bias; deterministic."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    deg = rng.zipf(zipf_s, size=n).astype(np.int64)
+    deg = np.minimum(deg * max(1, mean_degree // 4), max_degree)
+    deg = np.minimum(deg, n - 1)
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    nnz = int(rp[-1])
+    # preferential targets: square of a uniform pushes mass toward low ids
+    u = rng.random(nnz)
+    tgt = np.minimum((u * u * n).astype(np.int64), n - 1)
+    src = np.repeat(np.arange(n, dtype=np.int64), deg)
+    tgt = np.where(tgt == src, (tgt + 1) % n, tgt)
+    # sort + unique per row
+    order = np.lexsort((tgt, src))
+    src, tgt = src[order], tgt[order]
+    keep = np.ones(nnz, dtype=bool)
+    keep[1:] = (src[1:] != src[:-1]) | (tgt[1:] != tgt[:-1])
+    src, tgt = src[keep], tgt[keep]
+    rp2 = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rp2, src + 1, 1)
+    np.cumsum(rp2, out=rp2)
+    return rp2.astype(np.uint32), tgt.astype(np.uint32), np.ones(tgt.size, dtype=np.float64)
+
+
+def pagerank_system(n: int, adj_rp, adj_ci, adj_w, damping: float = 0.85):
+    """A = I - d * P^T in CSR with P_ij = w_ij / out_i (computePageRank, src/core/solver.ts:664-722:
+    S[i][j] -= d * adj[j][i] / out[j]; dangling columns stay identity), rhs = (1-d)/n."""
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix((adj_w, adj_ci.astype(np.int64), adj_rp.astype(np.int64)), shape=(n, n))
+    out = np.asarray(A.sum(axis=1)).ravel()
+    inv = np.where(out > 0, 1.0 / np.where(out > 0, out, 1.0), 0.0)
+    P = sp.diags(inv) @ A
+    S = (sp.identity(n, format="csr") - damping * P.T).tocsr()
+    S.sort_indices()
+    S.eliminate_zeros()
+    return (S.indptr.astype(np.uint32), S.indices.astype(np.uint32), S.data.astype(np.float64),
+            np.full(n, (1.0 - damping) / n))

@@ -1,0 +1,358 @@
+"""Host-side mirror of the reference's solver interfaces over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference:
+  * Rust crate surface: SparseMatrix::from_triplets (src/matrix/mod.rs:160-199), Matrix trait
+    methods (matrix/mod.rs:25-104), SolverOptions / SolverResult (src/solver/mod.rs:20-195),
+    NeumannSolver (src/solver/neumann.rs:24-92, solve :469-555), ForwardPushSolver /
+    query_single_entry (src/solver/forward_push.rs:67-231); errors are SolverError variants
+    (src/error.rs:16-140) carried by `SolverError.kind`.
+  * shipped TypeScript surface: SublinearSolver(config).solve / .estimateEntry
+    (src/core/solver.ts:36-111, 550-659) with the same result field names.
+
+All compute happens in libsublinear_hip.so; this file only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import SolverError
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+@dataclass
+class SolverOptions:
+    """src/solver/mod.rs:20-62 (defaults :47-62)."""
+    tolerance: float = 1e-6
+    max_iterations: int = 1000
+    initial_guess: Optional[Sequence[float]] = None
+    collect_stats: bool = False
+    compute_error_bounds: bool = False
+
+    @staticmethod
+    def high_precision() -> "SolverOptions":   # solver/mod.rs:66-76
+        return SolverOptions(tolerance=1e-12, max_iterations=5000, collect_stats=True, compute_error_bounds=True)
+
+    @staticmethod
+    def fast() -> "SolverOptions":             # solver/mod.rs:79-89
+        return SolverOptions(tolerance=1e-3, max_iterations=100)
+
+
+@dataclass
+class SolverResult:
+    """src/solver/mod.rs:118-195."""
+    solution: np.ndarray
+    residual_norm: float
+    iterations: int
+    converged: bool
+    error_bounds: Optional[float] = None
+    stats: Optional[dict] = None
+    term_norms: Optional[np.ndarray] = None
+
+
+class SparseMatrix:
+    """Device-resident sparse matrix (CSR in, row-slice layout in HBM)."""
+
+    def __init__(self, handle: int, rows: int, cols: int):
+        self._h = handle
+        self._rows, self._cols = rows, cols
+
+    # -- constructors -------------------------------------------------------------------
+    @classmethod
+    def from_triplets(cls, triplets, rows: int, cols: int, with_transpose: bool = False, keep_csr: bool = False):
+        """SparseMatrix::from_triplets, matrix/mod.rs:160-199 (validation, zero dropping, stable sort)."""
+        lib = L.load()
+        t = list(triplets)
+        r = np.asarray([x[0] for x in t], dtype=np.int64)
+        c = np.asarray([x[1] for x in t], dtype=np.int64)
+        v = _f64([x[2] for x in t])
+        if (r < 0).any() or (c < 0).any():
+            raise SolverError(8, "negative index in triplet")
+        r = r.astype(np.uint64)
+        c = c.astype(np.uint64)
+        h = L.vp()
+        flags = (L.SL_MATRIX_WITH_TRANSPOSE if with_transpose else 0) | (L.SL_MATRIX_KEEP_CSR if keep_csr else 0)
+        L.check(lib.sl_matrix_create_from_triplets(len(t), L.ptr(r), L.ptr(c), L.ptr(v), rows, cols, flags, C.byref(h)))
+        return cls(h.value, rows, cols)
+
+    @classmethod
+    def from_csr(cls, row_ptr, col_idx, values, rows: int, cols: int, row_offset: int = 0,
+                 with_transpose: bool = False, keep_csr: bool = False, device: bool = False):
+        """Adopt CSRStorage arrays (matrix/sparse.rs:16-23); device=True: torch CUDA tensors."""
+        lib = L.load()
+        if not device:
+            row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+            col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
+            values = _f64(values)
+            nnz = int(values.size)
+        else:
+            nnz = int(values.numel())
+        h = L.vp()
+        flags = (L.SL_MATRIX_WITH_TRANSPOSE if with_transpose else 0) | (L.SL_MATRIX_KEEP_CSR if keep_csr else 0)
+        L.check(lib.sl_matrix_create_csr(rows, cols, nnz, L.ptr(row_ptr), L.ptr(col_idx), L.ptr(values),
+                                         L.SL_MEM_DEVICE if device else L.SL_MEM_HOST, row_offset, flags, C.byref(h)))
+        return cls(h.value, rows, cols)
+
+    @classmethod
+    def from_dense(cls, data, **kw):
+        """SparseMatrix::from_dense, matrix/mod.rs:204-223: zeros filtered out."""
+        a = np.asarray(data, dtype=np.float64)
+        rows, cols = a.shape
+        rr, cc = np.nonzero(a)
+        return cls.from_triplets(zip(rr.tolist(), cc.tolist(), a[rr, cc].tolist()), rows, cols, **kw)
+
+    @classmethod
+    def from_scipy(cls, A, **kw):
+        A = A.tocsr()
+        A.sort_indices()
+        return cls.from_csr(A.indptr, A.indices, A.data, A.shape[0], A.shape[1], **kw)
+
+    # -- Matrix trait (matrix/mod.rs:25-104) ----------------------------------------------
+    def rows(self) -> int:
+        return self._rows
+
+    def cols(self) -> int:
+        return self._cols
+
+    def is_square(self) -> bool:
+        return self._rows == self._cols
+
+    def info(self) -> L.MatrixInfo:
+        i = L.MatrixInfo()
+        L.check(L.load().sl_matrix_get_info(self._h, C.byref(i)))
+        return i
+
+    def nnz(self) -> int:
+        return int(self.info().nnz)
+
+    def is_diagonally_dominant(self) -> bool:
+        f = C.c_int(0)
+        L.check(L.load().sl_matrix_is_diagonally_dominant(self._h, C.byref(f)))
+        return bool(f.value)
+
+    def diagonal_inverse(self) -> np.ndarray:
+        d = np.empty(self._rows, dtype=np.float64)
+        L.check(L.load().sl_matrix_diagonal_inverse(self._h, L.ptr(d), L.SL_MEM_HOST))
+        return d
+
+    def multiply_vector(self, x, order: int = L.SL_ORDER_CSR_SEQUENTIAL) -> np.ndarray:
+        """Matrix::multiply_vector, matrix/mod.rs:415-439 (DimensionMismatch on bad lengths)."""
+        x = _f64(x)
+        if x.size != self._cols:
+            raise SolverError(5, f"expected {self._cols}, actual {x.size} in matrix_vector_multiply")
+        y = np.empty(self._rows, dtype=np.float64)
+        L.check(L.load().sl_spmv(self._h, L.ptr(x), L.ptr(y), order, L.SL_MEM_HOST))
+        return y
+
+    def to_csr(self):
+        i = self.info()
+        rp = np.empty(i.n_rows + 1, dtype=np.uint32)
+        ci = np.empty(i.nnz, dtype=np.uint32)
+        va = np.empty(i.nnz, dtype=np.float64)
+        L.check(L.load().sl_matrix_download_csr(self._h, L.ptr(rp), L.ptr(ci), L.ptr(va)))
+        return rp, ci, va
+
+    def close(self):
+        if self._h:
+            L.load().sl_matrix_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class NeumannSolver:
+    """src/solver/neumann.rs:24-92.  `start` / `residual` select the reference-compat quirks
+    (SURVEY.md §0.3): defaults are the mathematically exact series."""
+    max_terms: int = 50
+    series_tolerance: float = 1e-8
+    adaptive_truncation: bool = True
+    order: int = L.SL_ORDER_CSR_SEQUENTIAL
+    start: int = L.SL_START_ZERO
+    residual: int = L.SL_RESIDUAL_TRUE
+
+    @staticmethod
+    def high_precision() -> "NeumannSolver":   # neumann.rs:63-65
+        return NeumannSolver(100, 1e-12)
+
+    @staticmethod
+    def fast() -> "NeumannSolver":             # neumann.rs:68-70
+        return NeumannSolver(20, 1e-6)
+
+    def algorithm_name(self) -> str:
+        return "neumann"
+
+    def solve(self, matrix: SparseMatrix, b, options: Optional[SolverOptions] = None) -> SolverResult:
+        options = options or SolverOptions()
+        lib = L.load()
+        b = _f64(b)
+        if matrix.is_square() and b.size != matrix.rows():           # neumann.rs:154-160
+            raise SolverError(5, f"expected {matrix.rows()}, actual {b.size} in neumann_initialization")
+        o = L.NeumannOptions()
+        lib.sl_neumann_options_default(C.byref(o))
+        o.tolerance, o.max_iterations = options.tolerance, options.max_iterations
+        o.max_terms, o.series_tolerance = self.max_terms, self.series_tolerance
+        o.order, o.start, o.residual, o.mem = self.order, self.start, self.residual, L.SL_MEM_HOST
+        o.collect_stats = int(options.collect_stats)
+        o.compute_error_bounds = int(options.compute_error_bounds and self.adaptive_truncation)
+        guess = None
+        if options.initial_guess is not None:
+            guess = _f64(options.initial_guess)
+            if guess.size != matrix.rows():                          # neumann.rs:198-204
+                raise SolverError(5, f"expected {matrix.rows()}, actual {guess.size} in initial_guess")
+            o.start = L.SL_START_INITIAL_GUESS
+        x = np.empty(matrix.rows(), dtype=np.float64)
+        tn = np.zeros(max(self.max_terms, 1), dtype=np.float64)
+        r = L.NeumannResult()
+        st = lib.sl_neumann_solve(matrix._h, L.ptr(b), L.ptr(guess), C.byref(o), L.ptr(x), L.ptr(tn), C.byref(r))
+        if st != L.SL_OK:
+            msg = lib.sl_last_error_message().decode()
+            err = SolverError(st, msg)
+            if st == 3:  # ConvergenceFailure still carries the partial result (the reference drops it)
+                err.result = SolverResult(x, r.residual_norm, int(r.iterations), False)
+            raise err
+        stats = None
+        if options.collect_stats:
+            stats = {"total_time_ms": r.total_time_ms, "matvec_count": int(r.matvec_count),
+                     "device_time_ms": r.device_time_ms, "bytes_moved": int(r.bytes_moved)}
+        return SolverResult(x, r.residual_norm, int(r.iterations), bool(r.converged),
+                            r.error_bound if r.error_bound >= 0 else None, stats, tn[: int(r.terms_computed)].copy())
+
+
+@dataclass
+class PushSolver:
+    """Synchronous thresholded residual push: the data-parallel member of
+    ForwardPushSolver::push_node (forward_push.rs:179-216) / TS solveForwardPush (solver.ts:437-522)."""
+    theta: float = 1e-6
+    max_rounds: int = 10_000
+    order: int = L.SL_ORDER_CSR_SEQUENTIAL
+    dense_switch: float = 1.0 / 16.0
+
+    def solve(self, matrix: SparseMatrix, b, x0=None, log_frontier: int = 0):
+        lib = L.load()
+        b = _f64(b)
+        n = matrix.rows()
+        if b.size != n:
+            raise SolverError(5, f"expected {n}, actual {b.size}")
+        o = L.PushOptions()
+        lib.sl_push_options_default(C.byref(o))
+        o.theta, o.max_rounds, o.order, o.mem, o.dense_switch = self.theta, self.max_rounds, self.order, L.SL_MEM_HOST, self.dense_switch
+        x = np.zeros(n, dtype=np.float64) if x0 is None else _f64(x0).copy()
+        r = np.empty(n, dtype=np.float64)
+        log = np.zeros(max(log_frontier, 1), dtype=np.uint32)
+        words = L.u64(0)
+        res = L.PushResult()
+        L.check(lib.sl_push_solve(matrix._h, L.ptr(b), C.byref(o), L.ptr(x), L.ptr(r),
+                                  L.ptr(log) if log_frontier else None, log_frontier, C.byref(words), C.byref(res)))
+        out = {"solution": x, "residual": r, "rounds": int(res.rounds), "pushes": int(res.pushes),
+               "rows_touched": int(res.rows_touched), "dense_rounds": int(res.dense_rounds),
+               "residual_norm": res.residual_norm, "converged": bool(res.converged),
+               "device_time_ms": res.device_time_ms}
+        if log_frontier:
+            out["frontier_log"] = log[: int(words.value)].copy()
+        return out
+
+
+def estimate_entry(matrix: SparseMatrix, b, row: int, theta: float = 1e-8, max_rounds: int = 100_000):
+    """x_row = e_row^T A^-1 b by local push on A^T (sl_estimate_entry)."""
+    lib = L.load()
+    b = _f64(b)
+    if not (0 <= row < matrix.rows()):
+        raise SolverError(4, f"Row index {row} out of bounds. Matrix has {matrix.rows()} rows")
+    res = L.EstimateResult()
+    L.check(lib.sl_estimate_entry(matrix._h, L.ptr(b), L.SL_MEM_HOST, row, theta, max_rounds, C.byref(res)))
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+# Shipped TypeScript surface (src/core/solver.ts)
+# ------------------------------------------------------------------------------------------------
+def _matrix_from_json(matrix, **kw) -> SparseMatrix:
+    """core/types.ts:6-22: {rows, cols, format:'dense', data:number[][]} or
+    {rows, cols, format:'coo', values, rowIndices, colIndices} (CJS CLI nests COO under `data`,
+    bin/cli.js:484-490); also accepts scipy sparse matrices and SparseMatrix."""
+    if isinstance(matrix, SparseMatrix):
+        return matrix
+    if hasattr(matrix, "tocsr"):
+        return SparseMatrix.from_scipy(matrix, **kw)
+    fmt = matrix.get("format")
+    rows, cols = int(matrix["rows"]), int(matrix["cols"])
+    if fmt == "dense":
+        data = np.asarray(matrix["data"], dtype=np.float64)
+        if data.shape != (rows, cols):
+            raise SolverError(5, f"dense data shape {data.shape} != ({rows}, {cols})")
+        return SparseMatrix.from_dense(data, **kw)
+    if fmt == "coo":
+        src = matrix["data"] if isinstance(matrix.get("data"), dict) else matrix
+        v, r, c = src["values"], src["rowIndices"], src["colIndices"]
+        if not (len(v) == len(r) == len(c)):
+            raise SolverError(4, "COO arrays differ in length")
+        return SparseMatrix.from_triplets(zip(r, c, v), rows, cols, **kw)
+    raise SolverError(6, f"Unsupported matrix format: {fmt}")
+
+
+class SublinearSolver:
+    """new SublinearSolver({method, epsilon, maxIterations, timeout?, seed?}) — core/solver.ts:36-58.
+
+    `neumann` runs the exact series (the TS sign bug of solver.ts:157-163 is NOT reproduced,
+    SURVEY.md §0.3); `forward-push` / `backward-push` / `bidirectional` (aliases in the reference,
+    solver.ts:527-545) run the thresholded push with theta = epsilon."""
+
+    def __init__(self, method: str = "neumann", epsilon: float = 1e-6, max_iterations: int = 1000,
+                 timeout: Optional[float] = None, seed: Optional[int] = None):
+        if method not in ("neumann", "random-walk", "forward-push", "backward-push", "bidirectional"):
+            raise SolverError(4, f"Unknown method: {method}")
+        if not (epsilon > 0):
+            raise SolverError(4, "epsilon must be positive")
+        self.method, self.epsilon, self.max_iterations, self.timeout, self.seed = method, epsilon, max_iterations, timeout, seed
+
+    def solve(self, matrix, vector) -> dict:
+        import time
+        t0 = time.perf_counter()
+        push = self.method in ("forward-push", "backward-push", "bidirectional")
+        m = _matrix_from_json(matrix, with_transpose=push)
+        b = _f64(vector)
+        if b.size != m.rows():
+            raise SolverError(5, f"Vector length {b.size} does not match matrix rows {m.rows()}")
+        if self.method == "random-walk":
+            raise SolverError(10, "random-walk full solve is out of scope for the GPU path (DESIGN.md §8)")
+        if not push:
+            ns = NeumannSolver(max_terms=self.max_iterations, series_tolerance=self.epsilon)
+            r = ns.solve(m, b, SolverOptions(tolerance=self.epsilon, max_iterations=self.max_iterations))
+            sol, it, res, conv = r.solution, r.iterations, r.residual_norm, r.converged
+        else:
+            pr = PushSolver(theta=self.epsilon, max_rounds=self.max_iterations).solve(m, b)
+            if not pr["converged"]:
+                raise SolverError(3, f"Forward push failed to converge after {self.max_iterations} iterations")
+            sol, it, res, conv = pr["solution"], pr["rounds"], pr["residual_norm"], True
+        return {"solution": sol, "iterations": it, "residual": res, "converged": conv, "method": self.method,
+                "computeTime": (time.perf_counter() - t0) * 1e3, "memoryUsed": int(m.info().device_bytes)}
+
+    def estimate_entry(self, matrix, vector, row: int, column: int = 0, epsilon: Optional[float] = None,
+                       confidence: float = 0.95, method: str = "neumann") -> dict:
+        """estimateEntry(matrix, vector, {row, column, epsilon, confidence, method}) -> {estimate,
+        variance, confidence} (solver.ts:550-554).  Returns x_row = (A^-1 vector)_row."""
+        m = _matrix_from_json(matrix, with_transpose=True)
+        if not (0 <= row < m.rows()):
+            raise SolverError(4, f"Row index {row} out of bounds. Matrix has {m.rows()} rows (valid range: 0-{m.rows() - 1})")
+        if not (0 <= column < m.cols()):
+            raise SolverError(4, f"Column index {column} out of bounds. Matrix has {m.cols()} columns")
+        b = _f64(vector)
+        if b.size != m.rows():
+            raise SolverError(5, f"Vector length {b.size} does not match matrix rows {m.rows()}")
+        eps = epsilon if epsilon is not None else self.epsilon
+        r = estimate_entry(m, b, row, theta=eps * 1e-2, max_rounds=self.max_iterations * 100)
+        return {"estimate": r.estimate, "variance": 0.0, "confidence": 1.0 if r.converged else 0.5,
+                "residual_l1": r.residual_l1}

@@ -1,0 +1,274 @@
+"""Pin the CPU oracle (oracle/sl_oracle.c) against the reference's own known answers and against
+outputs captured from the reference's runnable Python / JS solvers.
+CPU only — runs in the build container and on the GPU box alike (nothing reads /root/reference)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+GOLD = np.load(Path(__file__).parent / "golden" / "reference_jacobi.npz")
+CASES = [str(c) for c in GOLD["__cases"]]
+
+
+def _mat(case):
+    key = case.rsplit("__", 1)[0]
+    return GOLD[f"{key}__row_ptr"], GOLD[f"{key}__col_idx"], GOLD[f"{key}__values"]
+
+
+# ---- G1: Python Jacobi iterates == Neumann partial sums --------------------------------------
+@pytest.mark.parametrize("case", CASES)
+def test_g1_partial_sums_match_python_jacobi(case):
+    rp, ci, va = _mat(case)
+    b = GOLD[f"{case}__b"]
+    for k in (1, 2, 5, 10):
+        r = O.neumann_solve(rp, ci, va, b, max_terms=k, series_tolerance=0.0, max_iterations=k, tolerance=0.0)
+        assert r["terms"] == k
+        np.testing.assert_allclose(r["x"], GOLD[f"{case}__x_k{k}"], rtol=0, atol=1e-13)
+    r = O.neumann_solve(rp, ci, va, b, max_terms=2000, series_tolerance=1e-15, max_iterations=2000, tolerance=1e-12)
+    assert r["converged"]
+    np.testing.assert_allclose(r["x"], GOLD[f"{case}__x_final"], rtol=0, atol=1e-11)
+
+
+# ---- G2: JS Jacobi final solution ---------------------------------------------------------------
+@pytest.mark.parametrize("case", CASES)
+def test_g2_matches_js_jacobi(case):
+    rp, ci, va = _mat(case)
+    b = GOLD[f"{case}__b"]
+    r = O.neumann_solve(rp, ci, va, b, max_terms=2000, series_tolerance=1e-15, max_iterations=2000, tolerance=1e-13)
+    xj = GOLD[f"{case}__js_x"]
+    assert np.max(np.abs(r["x"] - xj)) <= 1e-9 * max(1.0, np.max(np.abs(xj)))
+    # JS stops on ||b - Ax|| / ||b|| < 1e-10 (convergence-detector.js:64-72,165-172)
+    res = np.linalg.norm(b - O.spmv(rp, ci, va, xj)) / np.linalg.norm(b)
+    assert res < 1e-9
+
+
+def test_negative_fixture_is_not_diagonally_dominant():
+    rp, ci, va = GOLD["neg_n_100_sparse_dd__row_ptr"], GOLD["neg_n_100_sparse_dd__col_idx"], GOLD["neg_n_100_sparse_dd__values"]
+    assert not O.is_diagonally_dominant(rp, ci, va)
+    with pytest.raises(O.OracleError) as e:
+        O.neumann_solve(rp, ci, va, np.ones(100))
+    assert e.value.kind == "MatrixNotDiagonallyDominant"       # neumann.rs:163-169
+
+
+# ---- G3: primitives from the reference's unit tests (exact) ------------------------------------
+def test_g3_spmv_kats():
+    # sparse.rs:923-933 / simd_ops.rs:259-268
+    rp, ci, va = O.csr_from_triplets([0, 0, 1, 1], [0, 1, 0, 1], [2.0, 1.0, 1.0, 3.0], 2, 2)
+    for order in (O.ORDER_SEQ, O.ORDER_SIMD4):
+        assert O.spmv(rp, ci, va, [1.0, 2.0], order).tolist() == [4.0, 7.0]
+    assert O.spmv(rp, ci, va, [1.0, 2.0], threads=2).tolist() == [4.0, 7.0]
+    # fast_solver.rs:260-272
+    rp, ci, va = O.csr_from_triplets([0, 0, 1, 1], [0, 1, 0, 1], [4.0, 1.0, 2.0, 3.0], 2, 2)
+    assert O.spmv(rp, ci, va, [1.0, 2.0]).tolist() == [6.0, 8.0]
+    # optimized_solver.rs:389-396
+    rp, ci, va = O.csr_from_triplets([0, 0, 1, 1], [0, 1, 0, 1], [4.0, 1.0, 1.0, 3.0], 2, 2)
+    assert O.spmv(rp, ci, va, [1.0, 2.0]).tolist() == [6.0, 7.0]
+
+
+def test_g3_dot_axpy_norms():
+    assert O.dot_simd4([1, 2, 3, 4], [5, 6, 7, 8]) == 70.0                       # simd_ops.rs:270-276
+    assert O.dot_sequential([1, 2, 3, 4], [5, 6, 7, 8]) == 70.0
+    assert O.axpy(2.0, [1, 2, 3, 4], [1, 1, 1, 1]).tolist() == [3.0, 5.0, 7.0, 9.0]  # simd_ops.rs:278-286
+    v = [3.0, 4.0]                                                                # solver/mod.rs:588-595
+    assert O.l1_norm(v) == 7.0 and O.l2_norm(v) == 5.0 and O.linf_norm(v) == 4.0
+
+
+def test_g3_neumann_state_creation():
+    # neumann.rs:634-648: A = [[2,1],[1,3]]... dinv = [0.5, 1/3], rhs = b * dinv = [2, 2] for b = [4, 6]
+    rp, ci, va = O.csr_from_triplets([0, 0, 1, 1], [0, 1, 0, 1], [2.0, 1.0, 1.0, 3.0], 2, 2)
+    dinv, rhs = O.neumann_init(rp, ci, va, [4.0, 6.0])
+    assert dinv.tolist() == [0.5, 1.0 / 3.0]
+    assert rhs.tolist() == [2.0, 6.0 * (1.0 / 3.0)]
+
+
+def test_g3_dd_and_get():
+    # matrix/mod.rs:603-613
+    rp, ci, va = O.csr_from_triplets([0, 0, 1, 1], [0, 1, 0, 1], [5.0, 1.0, 2.0, 7.0], 2, 2)
+    assert O.is_diagonally_dominant(rp, ci, va)
+    rp2, ci2, va2 = O.csr_from_triplets([0, 0, 1, 1], [0, 1, 0, 1], [1.0, 5.0, 2.0, 1.0], 2, 2)
+    assert not O.is_diagonally_dominant(rp2, ci2, va2)
+    # sparse.rs:910-920: get hits / misses
+    rp3, ci3, va3 = O.csr_from_triplets([0, 0, 1, 2, 2], [0, 2, 1, 0, 2], [1.0, 2.0, 3.0, 4.0, 5.0], 3, 3)
+    assert O.csr_get(rp3, ci3, va3, 0, 0) == 1.0 and O.csr_get(rp3, ci3, va3, 0, 2) == 2.0
+    assert O.csr_get(rp3, ci3, va3, 0, 1) is None and O.csr_get(rp3, ci3, va3, 1, 1) == 3.0
+
+
+def test_a1_triplet_rules():
+    # zeros dropped, stable sort by (row, col), duplicates kept separately (sparse.rs:80-132,530-548)
+    rp, ci, va = O.csr_from_triplets([1, 0, 0, 1, 0], [1, 1, 0, 1, 1], [5.0, 2.0, 0.0, 6.0, 3.0], 2, 2)
+    assert rp.tolist() == [0, 2, 4] and ci.tolist() == [1, 1, 1, 1] and va.tolist() == [2.0, 3.0, 5.0, 6.0]
+    with pytest.raises(O.OracleError) as e:
+        O.csr_from_triplets([2], [0], [1.0], 2, 2)
+    assert e.value.kind == "IndexOutOfBounds"
+    with pytest.raises(O.OracleError) as e:
+        O.csr_from_triplets([0], [0], [float("nan")], 2, 2)
+    assert e.value.kind == "InvalidInput"
+    rp, ci, va = O.csr_from_triplets([], [], [], 3, 3)          # empty
+    assert rp.tolist() == [0, 0, 0, 0] and ci.size == 0
+
+
+def test_simd4_order_differs_from_sequential_only_in_rounding():
+    rng = np.random.default_rng(7)
+    n, k = 50, 13
+    cols = np.stack([np.sort(rng.choice(n, k, replace=False)) for _ in range(n)])
+    vals = rng.standard_normal((n, k))
+    rp = np.arange(n + 1, dtype=np.uint32) * k
+    x = rng.standard_normal(n)
+    y0 = O.spmv(rp, cols.ravel(), vals.ravel(), x, O.ORDER_SEQ)
+    y1 = O.spmv(rp, cols.ravel(), vals.ravel(), x, O.ORDER_SIMD4)
+    np.testing.assert_allclose(y0, y1, rtol=1e-13, atol=1e-13)
+    # hand restatement of simd_ops.rs:41-77 for one row
+    v, c = vals[3], cols[3]
+    lanes = [0.0] * 4
+    for q in range(k // 4):
+        for j in range(4):
+            lanes[j] = lanes[j] + v[4 * q + j] * x[c[4 * q + j]]
+    y = ((lanes[0] + lanes[1]) + lanes[2]) + lanes[3]
+    for t in range(4 * (k // 4), k):
+        y = y + v[t] * x[c[t]]
+    assert y1[3] == y
+
+
+# ---- G4: Rust-Neumann restatement KATs ------------------------------------
+def test_g4_rust_neumann_quirks():
+    rp, ci, va = O.csr_from_triplets([0, 0, 1, 1], [0, 1, 0, 1], [4.0, 1.0, 1.0, 3.0], 2, 2)
+    b = [5.0, 4.0]
+    # reference behaviour (scaled residual never passes, series criterion stops at 17 terms)
+    r = O.neumann_solve(rp, ci, va, b, max_terms=20, series_tolerance=1e-8, start=O.START_ZERO,
+                        residual=O.RESIDUAL_REFERENCE_SCALED)
+    np.testing.assert_allclose(r["x"], [1.0, 1.0], atol=1e-7)
+    assert r["iterations"] == 17 and r["converged"]
+    # with the TRUE residual the every-5th-iteration check (neumann.rs:489-491) fires one term earlier
+    t = O.neumann_solve(rp, ci, va, b, max_terms=20, series_tolerance=1e-8, start=O.START_ZERO)
+    np.testing.assert_allclose(t["x"], [1.0, 1.0], atol=1e-7)
+    assert t["iterations"] == 16 and t["converged"] and t["residual_norm"] < 1e-6
+    q = O.neumann_solve(rp, ci, va, b, max_terms=20, series_tolerance=1e-8, start=O.START_REFERENCE_DEFAULT,
+                        residual=O.RESIDUAL_REFERENCE_SCALED)
+    np.testing.assert_allclose(q["x"], [2.25, 2.0 + 1.0 / 3.0], atol=1e-7)    # x_true + D^-1 b
+    assert abs(q["residual_norm"] - 12.8198) < 1e-3
+    z = O.neumann_solve(rp, ci, va, b, max_terms=20, series_tolerance=1e-8, start=O.START_ZERO,
+                        residual=O.RESIDUAL_REFERENCE_SCALED)
+    assert abs(z["residual_norm"] - 4.6015) < 1e-3
+
+
+def test_neumann_error_order_and_failure():
+    rp, ci, va = O.csr_from_triplets([0, 1], [0, 1], [2.0, 3.0], 2, 2)
+    with pytest.raises(O.OracleError) as e:
+        O.neumann_solve(rp, ci, va, [1.0, 2.0], cols=3)
+    assert e.value.kind == "InvalidInput"                        # not square first (:147-152)
+    with pytest.raises(O.OracleError) as e:
+        O.neumann_solve(rp, ci, va, [1.0, 2.0, 3.0])
+    assert e.value.kind == "DimensionMismatch"
+    rp, ci, va = O.csr_from_triplets([0, 1], [0, 0], [2.0, 0.0], 2, 2)  # row 1 empty -> passes DD, fails diag
+    with pytest.raises(O.OracleError) as e:
+        O.neumann_solve(rp, ci, va, [1.0, 2.0])
+    assert e.value.kind == "InvalidSparseMatrix"
+    rp, ci, va = O.csr_from_triplets([0, 0, 1, 1], [0, 1, 0, 1], [4.0, 3.9, 3.9, 4.0], 2, 2)
+    r = O.neumann_solve(rp, ci, va, [1.0, 1.0], max_iterations=10, max_terms=50, tolerance=1e-12, series_tolerance=1e-14)
+    assert r["kind"] == "ConvergenceFailure" and r["iterations"] == 10
+
+
+# ---- G5: push properties (tests/rust/push_tests.rs) ------------------------------------------------
+def _four_node():
+    # create_simple_graph, tests/rust/push_tests.rs:15-22
+    return (np.array([0, 2, 4, 6, 7], np.uint32), np.array([1, 2, 0, 3, 0, 3, 1], np.uint32),
+            np.array([0.5, 0.5, 0.8, 0.2, 0.6, 0.4, 1.0]))
+
+
+def test_g5_acl_forward_push_fixture():
+    rp, ci, w = _four_node()
+    r = O.acl_push(rp, ci, w, [0], alpha=0.15, epsilon=1e-6)
+    est, res = r["estimate"], r["residual"]
+    assert (est >= 0).all() and (res >= 0).all()                                  # push_tests.rs:77-104
+    assert abs(est.sum() + res.sum() - 1.0) < 1e-12                               # mass conservation :107-129
+    # exact PPR: pi = alpha e_s^T (I - (1-alpha) P)^-1
+    P = np.zeros((4, 4))
+    for i in range(4):
+        for k in range(rp[i], rp[i + 1]):
+            P[i, ci[k]] = w[k]          # every row of the fixture already sums to 1
+    pi = 0.15 * np.linalg.solve((np.eye(4) - 0.85 * P).T, np.eye(4)[0])
+    np.testing.assert_allclose(est, pi, atol=2e-6)
+    np.testing.assert_allclose(est, [0.431272, 0.276168, 0.183291, 0.109267], atol=2e-6)
+    assert r["push_count"] == 200
+
+
+def test_g5_monotone_and_edge_cases():
+    rp, ci, w = _four_node()
+    pushes = [O.acl_push(rp, ci, w, [0], epsilon=e)["push_count"] for e in (1e-2, 1e-4, 1e-6)]
+    assert pushes[0] <= pushes[1] <= pushes[2]                                    # push_tests.rs:132-162
+    r = O.acl_push(rp, ci, w, [0], alpha=0.99)
+    assert r["estimate"][0] > 0.5                                                 # :520-537
+    r = O.acl_push(rp, ci, w, [10])                                               # out of bounds source :433-495
+    assert r["push_count"] == 0 and r["estimate"].sum() == 0.0
+    # path graph, disconnected node keeps zero
+    prp, pci, pw = O.csr_from_triplets([0, 1, 2], [1, 2, 3], [1.0, 1.0, 1.0], 5, 5)
+    r = O.acl_push(prp, pci, pw, [0])
+    assert r["estimate"][4] == 0.0 and r["estimate"][0] > 0
+    b = O.acl_push(rp, ci, w, [3], backward=True)
+    assert (b["estimate"] >= 0).all() and b["estimate"][3] > 0
+
+
+# ---- G6: TS forward push (tests/mcp/mcp-tool-tests.js:27-52) ---------------------------------------
+def _tridiag10():
+    tr, tc, tv = [], [], []
+    for i in range(10):
+        for j, v in ((i - 1, -1.0), (i, 10.0), (i + 1, -1.0)):
+            if 0 <= j < 10:
+                tr.append(i), tc.append(j), tv.append(v)
+    return O.csr_from_triplets(tr, tc, tv, 10, 10)
+
+
+def test_g6_ts_forward_push():
+    rp, ci, va = _tridiag10()
+    b = np.zeros(10)
+    b[0] = b[9] = 1.0
+    r = O.ts_forward_push(rp, ci, va, b, 1e-3, 1000)
+    assert r["status"] == 0 and r["converged"] and r["iterations"] == 12
+    assert abs(r["residual"] - 5.2915e-4) < 1e-7
+    np.testing.assert_allclose(b - O.spmv(rp, ci, va, r["x"]), r["r"], atol=1e-15)   # invariant r = b - A x
+
+
+def test_sync_push_invariants_and_limit():
+    rp, ci, va = _tridiag10()
+    b = np.zeros(10)
+    b[0] = b[9] = 1.0
+    r = O.push_sync_solve(rp, ci, va, b, theta=1e-8, log_cap=4096)
+    assert r["converged"]
+    np.testing.assert_allclose(b - O.spmv(rp, ci, va, r["x"]), r["r"], atol=1e-14)
+    np.testing.assert_allclose(r["x"], np.linalg.solve(_dense(rp, ci, va), b), atol=1e-8)
+    log = r["frontier_log"]
+    assert log[0] == 2 and log[1:3].tolist() == [0, 9]      # first frontier: the two loaded rows, ascending
+    # theta larger than every scaled residual: nothing to push
+    z = O.push_sync_solve(rp, ci, va, b, theta=1.0)
+    assert z["rounds"] == 0 and z["converged"] and z["x"].sum() == 0.0
+
+
+def _dense(rp, ci, va):
+    n = len(rp) - 1
+    A = np.zeros((n, n))
+    for i in range(n):
+        for k in range(rp[i], rp[i + 1]):
+            A[i, ci[k]] += va[k]
+    return A
+
+
+# ---- G7: TS LCG stream (core/utils.ts:161-168) -----------------------------------------------------
+def test_g7_lcg_streams():
+    for seed in (1, 42, 12345):
+        s = seed
+        exp = []
+        for _ in range(8):
+            s = (s * 1664525 + 1013904223) % 2 ** 32
+            exp.append(s / 2 ** 32)
+        assert O.ts_lcg(seed, 8).tolist() == exp
+    assert O.ts_lcg(1, 1)[0] == 1015568748 / 2 ** 32
+
+
+def test_random_walk_estimate_runs_and_is_seeded():
+    rp, ci, va = _tridiag10()
+    b = np.ones(10)
+    m1 = O.ts_random_walk_estimate(rp, ci, va, b, 0, 0.1, 42)
+    m2 = O.ts_random_walk_estimate(rp, ci, va, b, 0, 0.1, 42)
+    assert m1 == m2 and m1[2] == 100
