@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: fused push/Neumann iterations on S-DD(n = 10M per GPU, 16 nnz/row).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over the whole (synthetic) system: the fused kernel
+    t' = t - dinv .* (A t);  x += t';  ||t'||^2
+(NeumannState::apply_iteration_matrix + compute_next_term, src/solver/neumann.rs:252-299), inputs
+resident in HBM before the timed region.  value = nnz * K * N / max-over-ranks time.
+Weak scaling: every rank owns `--n` rows of an N*n-row system (row-range partition, one exchange of
+the term vector per step: all-gather for uniform columns, neighbour halo for banded ones).
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+
+def algorithmic_bytes(n_rows: int, nnz: int) -> int:
+    """DESIGN.md §4 / SURVEY.md §8(d): 12 B per entry + 4 B row descriptor + 40 B of vectors per row."""
+    return 12 * nnz + 4 * (n_rows + 1) + 40 * n_rows
+
+
+def cpu_baseline(n_global: int, k: int, seed: int, w: int, threads_all: int):
+    """The reference's CPU hot loop (oracle restatement of simd_ops.rs SpMV variants inside the Neumann
+    step) on a bounded sample: rows [0, n_s) of the SAME system, gathered vector of full length."""
+    import numpy as np
+    from oracle import oracle as O
+    from sublinear_time_solver_amd import generators as G
+
+    O.build(fast=True)
+    n_s = min(n_global, 1_000_000)
+    rp, ci, va, b = G.sdd_rows(n_global, k, seed, w, 0, n_s)
+    dinv = 1.0 / (10.0 + 0.01 * (np.arange(n_s) % 1000))
+    out = {}
+    for label, order, threads, steps in (("simd4_1t", O.ORDER_SIMD4, 1, 6), ("rowchunk_all", O.ORDER_SEQ, threads_all, 20)):
+        t = 1.0 + 0.001 * (np.arange(n_global) % 1000)
+        t[:n_s] *= dinv
+        x = t[:n_s].copy()
+        O.neumann_steps(rp, ci, va, dinv, t, x, 1, order, threads, fast=True)          # warm
+        t0 = time.perf_counter()
+        O.neumann_steps(rp, ci, va, dinv, t, x, steps, order, threads, fast=True)
+        dt = time.perf_counter() - t0
+        out[label] = n_s * k * steps / dt
+    best = max(out, key=out.get)
+    return {"value": out[best], "unit": "nnz*iter/s", "cores": threads_all if best == "rowchunk_all" else 1,
+            "kind": "port",
+            "sample": f"rows [0,{n_s}) of the same S-DD system (gathered vector full length {n_global}), "
+                      f"a8+a9 steps; simd_ops.rs 4-lane SpMV 1 thread = {out['simd4_1t']:.3e}, "
+                      f"row-chunk threads x{threads_all} = {out['rowchunk_all']:.3e} nnz*iter/s",
+            "single_thread_simd4": out["simd4_1t"], "all_threads_rowchunk": out["rowchunk_all"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--k", type=int, default=16, help="entries per row (diagonal included)")
+    ap.add_argument("--bandwidth", type=int, default=-1, help="half bandwidth w of the column window; 0 = uniform columns; -1 = default")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--order", type=int, default=0, help="0 = CSR sequential (sparse.rs), 1 = simd4 (simd_ops.rs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sublinear_time_solver_amd import _lib as L
+    from sublinear_time_solver_amd import distributed as D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    lib = L.load()
+    L.check(lib.sl_set_device(local_rank))
+    stream = torch.cuda.current_stream(dev)
+    L.check(lib.sl_set_stream(C.c_void_p(stream.cuda_stream)))
+
+    n_local, k = args.n, args.k
+    n_global = n_local * world
+    w = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
+    part = D.RowPartition(n_global, world, rank)
+    assert part.n_local == n_local
+
+    # ---- synthesize this rank's rows directly in HBM, build the row-slice layout ---------------------
+    rp = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
+    ci = torch.empty(n_local * k, dtype=torch.int32, device=dev)
+    va = torch.empty(n_local * k, dtype=torch.float64, device=dev)
+    b = torch.empty(n_local, dtype=torch.float64, device=dev)
+    L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, part.lo, part.hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), b.data_ptr()))
+    h = C.c_void_p()
+    L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(),
+                                     L.SL_MEM_DEVICE, part.lo, 0, C.byref(h)))
+    del rp, ci, va
+    torch.cuda.empty_cache()
+    info = L.MatrixInfo()
+    L.check(lib.sl_matrix_get_info(h, C.byref(info)))
+    dinv = torch.empty(n_local, dtype=torch.float64, device=dev)
+    L.check(lib.sl_matrix_diagonal_inverse(h, dinv.data_ptr(), L.SL_MEM_DEVICE))
+
+    # t0 = D^-1 b on every rank (b is a closed form of the row index, so no exchange is needed to start)
+    idx = torch.arange(n_global, device=dev, dtype=torch.float64)
+    t0 = torch.zeros(part.n_padded, dtype=torch.float64, device=dev)
+    t0[:n_global] = (1.0 + 0.001 * torch.remainder(idx, 1000.0)) * (1.0 / (10.0 + 0.01 * torch.remainder(idx, 1000.0)))
+    del idx
+    x = t0[part.lo:part.hi].clone()
+    exchange = D.AllGatherExchange(part) if w == 0 else D.HaloExchange(part, w)
+    drv = D.PartitionedNeumann(part, D.hip_local_step(h, dinv, args.order), exchange, t0, x)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        drv.step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # library launches go to THIS stream
+    t_start = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        drv.step()
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    dev_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed, dev_ms = float(tmax[0]), float(tmax[1])
+    term_norm = drv.term_norm()
+
+    # kernel-only duration on one GPU: the same launches through the library's own HIP-event bracket
+    kern_ms = None
+    if world == 1:
+        ta, tb = drv.t[drv.cur], drv.t[1 - drv.cur]
+        ms = C.c_float(0)
+        L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), drv.norm2.data_ptr(),
+                                         args.order, args.steps, C.byref(ms)))
+        kern_ms = ms.value / args.steps
+
+    if rank == 0:
+        nnz_total = n_global * k
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = nnz_total * args.steps / elapsed
+        per_launch_bytes = algorithmic_bytes(n_local, n_local * k)
+        launch_ms = kern_ms if kern_ms is not None else dev_ms / args.steps
+        achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "pmc_traffic.json"
+        if tf.exists():
+            try:
+                rec = json.loads(tf.read_text())
+                if rec.get("n") == n_local and rec.get("k") == k and rec.get("bandwidth") == w:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "push_iterations_x_nnz_per_sec", "value": value, "unit": "nnz*iter/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"S-DD(n={n_local} rows/GPU, nnz/row={k}, seed={args.seed}, "
+                                   f"{'uniform columns' if w == 0 else f'band half-width {w}'}) fused Neumann/push step, fp64, "
+                                   "1xMI355X HBM roofline run (BASELINE configs[2])",
+                       "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w,
+                       "order": "csr_sequential" if args.order == 0 else "simd4",
+                       "exchange": exchange.name if world > 1 else "none", "partition": f"rows{world}",
+                       "rows_iter_per_s": value / k, "last_term_norm": term_norm},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": launch_ms,
+                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n_global, k, args.seed, w, os.cpu_count() or 1)
+            except Exception as e:  # the baseline is reported context; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "nnz*iter/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    lib.sl_matrix_destroy(h)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# default column structure of the headline run: see DESIGN.md §6 (0 = uniform over all columns)
+DEFAULT_BANDWIDTH = 0
+
+if __name__ == "__main__":
+    main()

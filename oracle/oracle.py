@@ -211,6 +211,16 @@ def neumann_solve(rp, ci, va, b, *, tolerance=1e-6, max_iterations=1000, max_ter
     return out
 
 
+def neumann_steps(rp, ci, va, dinv, t, x, steps, order=ORDER_SEQ, threads=1, fast=False):
+    """In-place: `steps` passes of a8 + a9 on rows [0, len(rp)-1); t may be longer than the row block."""
+    rows = rp.size - 1
+    tmp = np.empty(rows)
+    l = lib(fast)
+    l.orc_neumann_steps.restype = f64
+    return l.orc_neumann_steps(u64(rows), _p(rp), _p(ci), _p(va), _p(dinv), _p(t), _p(x), _p(tmp), u64(steps),
+                               C.c_int(order), C.c_int(threads))
+
+
 def push_sync_solve(rp, ci, va, b, theta, max_rounds=100000, order=ORDER_SEQ, x0=None, log_cap=0):
     rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
     n = rp.size - 1

@@ -333,6 +333,27 @@ done:
 #undef UPDATE_RESIDUAL
 }
 
+/* cpu_baseline leg of bench.py: exactly `steps` passes of a8 + a9 (apply_iteration_matrix,
+ * solution += term, l2 norm of the term) on a row block [0, rows) of a larger system whose
+ * gathered vector has n_cols entries — the reference's CPU hot loop with its own SpMV
+ * variants: order SIMD4 = simd_ops.rs:20-88 (1 thread), threads > 1 = simd_ops.rs:201-239.
+ * t (n_cols) in/out: rows beyond `rows` are left untouched.  Returns the last term norm. */
+double orc_neumann_steps(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values,
+                         const double *dinv, double *t, double *x, double *tmp, uint64_t steps, int order, int threads)
+{
+    orc_neumann_opts o; memset(&o, 0, sizeof(o));
+    o.order = order; o.threads = threads;
+    double tn = 0.0;
+    for (uint64_t s = 0; s < steps; ++s) {
+        spmv_by_opts(&o, rows, row_ptr, col_idx, values, t, tmp);
+        for (uint64_t i = 0; i < rows; ++i) tmp[i] = tmp[i] * dinv[i];
+        for (uint64_t i = 0; i < rows; ++i) t[i] = t[i] - tmp[i];
+        for (uint64_t i = 0; i < rows; ++i) x[i] = x[i] + t[i];
+        tn = orc_l2_norm(rows, t);
+    }
+    return tn;
+}
+
 /* ------------------------------------------------------------------ a-P -- */
 
 /* Synchronous thresholded push, SURVEY.md §8 (a-P): the data-parallel member of

@@ -108,6 +108,10 @@ int orc_neumann_solve(uint64_t rows, uint64_t cols, const uint32_t *row_ptr, con
                       double *x_out, double *term_out, double *term_norms /* [max_terms] or NULL */,
                       orc_neumann_result *res);
 
+/* bench.py cpu_baseline: `steps` passes of a8 + a9 on rows [0, rows) with a gathered vector of any length */
+double orc_neumann_steps(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values,
+                         const double *dinv, double *t, double *x, double *tmp, uint64_t steps, int order, int threads);
+
 /* ---- (a-P) synchronous thresholded push, SURVEY.md §8 (a-P) ---- */
 typedef struct {
     double theta;            /* frontier threshold on |r_i * dinv_i| */

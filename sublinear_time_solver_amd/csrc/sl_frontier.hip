@@ -210,19 +210,6 @@ __global__ __launch_bounds__(256) void sl_dense_csr_round_kernel(uint64_t n, op_
     delta_new[i] = (fabs(p) >= theta) ? p : 0.0;
 }
 
-// diag of a CSR operator (A^T has the same diagonal as A; used when only CSR arrays exist)
-__global__ __launch_bounds__(256) void sl_csr_dinv_kernel(uint64_t n, const uint32_t *ptr, const uint32_t *idx, const double *val,
-                                                          double *dinv, unsigned long long *status)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    bool found = false; double d = 0.0;
-    for (uint32_t k = ptr[i]; k < ptr[i + 1]; ++k) if (idx[k] == (uint32_t)i) { d = val[k]; found = true; }
-    if (!found) { atomicOr(&status[0], 2ull); atomicMin(&status[2], (unsigned long long)i); }
-    else if (fabs(d) < 1e-14) { atomicOr(&status[0], 4ull); atomicMin(&status[3], (unsigned long long)i); }
-    dinv[i] = (found && fabs(d) >= 1e-14) ? 1.0 / d : 0.0;
-}
-
 namespace {
 
 struct push_state {
@@ -466,18 +453,12 @@ sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, u
     const uint64_t n = m->n_rows;
     hipStream_t s = sl_context().stream;
     push_state ps;
-    DevBuf bufs[12], bbuf, status;
+    DevBuf bufs[12], bbuf;
     SL_TRY(alloc_state(ps, n, bufs));
     // operator B = A^T: rows of B = columns of A (sorted transpose), columns of B = rows of A
     ps.op = op_view{m->d_tptr, m->d_trow, m->d_tval, m->d_row_ptr, m->d_col_idx};
-    SL_TRY(status.alloc(32));
-    const unsigned long long init[4] = {0ull, ~0ull, ~0ull, ~0ull};
-    SL_HIP(hipMemcpyAsync(status.p, init, 32, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(sl_csr_dinv_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, n, m->d_tptr, m->d_trow, m->d_tval, ps.dinv,
-                       status.as<unsigned long long>());
     unsigned long long hs[4];
-    SL_HIP(hipMemcpyAsync(hs, status.p, 32, hipMemcpyDeviceToHost, s));
-    SL_HIP(hipStreamSynchronize(s));
+    SL_TRY(sl_csr_diag_pass(n, m->d_tptr, m->d_trow, m->d_tval, ps.dinv, hs));
     if (hs[0] & 2ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2]);
     if (hs[0] & 4ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3]);
     // y0 = 0, r = e_row

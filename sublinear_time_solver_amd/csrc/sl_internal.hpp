@@ -98,3 +98,6 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
 // a6 + a7 pass: h_status[0] bits 1 = not dominant, 2 = missing diagonal, 4 = near-zero diagonal;
 // h_status[1..3] = first offending row of each class.  d_dinv may be null.
 sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long long h_status[4]);
+// same rules over a plain CSR operator (used for A^T, which has no row-slice layout)
+sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx, const double *val, double *d_dinv,
+                           unsigned long long h_status[4]);

@@ -278,3 +278,32 @@ sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long 
     hipFree(d_status);
     return SL_OK;
 }
+
+// diag of a CSR operator (A^T has the same diagonal as A; used when only CSR arrays exist)
+__global__ __launch_bounds__(256) void sl_csr_dinv_kernel(uint64_t n, const uint32_t *ptr, const uint32_t *idx, const double *val,
+                                                          double *dinv, unsigned long long *status)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool found = false; double d = 0.0;
+    for (uint32_t k = ptr[i]; k < ptr[i + 1]; ++k) if (idx[k] == (uint32_t)i) { d = val[k]; found = true; }
+    if (!found) { atomicOr(&status[0], 2ull); atomicMin(&status[2], (unsigned long long)i); }
+    else if (fabs(d) < 1e-14) { atomicOr(&status[0], 4ull); atomicMin(&status[3], (unsigned long long)i); }
+    dinv[i] = (found && fabs(d) >= 1e-14) ? 1.0 / d : 0.0;
+}
+
+
+sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx, const double *val, double *d_dinv,
+                           unsigned long long h_status[4])
+{
+    hipStream_t st = sl_context().stream;
+    unsigned long long *d_status = nullptr;
+    SL_HIP(hipMalloc(&d_status, 4 * sizeof(unsigned long long)));
+    const unsigned long long init[4] = {0ull, ~0ull, ~0ull, ~0ull};
+    SL_HIP(hipMemcpyAsync(d_status, init, sizeof(init), hipMemcpyHostToDevice, st));
+    if (n) hipLaunchKernelGGL(sl_csr_dinv_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, ptr, idx, val, d_dinv, d_status);
+    SL_HIP(hipMemcpyAsync(h_status, d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    hipFree(d_status);
+    return SL_OK;
+}

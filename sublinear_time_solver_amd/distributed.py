@@ -1,0 +1,139 @@
+"""Row-range partition of the Neumann iteration across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI, "gloo" in the CPU tests).
+Rank p owns the contiguous rows [lo_p, hi_p) of A (column ids stay global) and the matching
+slices of dinv / x / t.  Per iteration there is exactly one exchange step — the freshly computed
+slice of the term vector t has to reach every rank that gathers from it — plus a 16-byte
+all-reduce of the squared term norm:
+
+  * AllGather     uniform column structure: every rank needs all of t  ->  all_gather_into_tensor
+  * Halo          banded structure (|i - j| <= w): only the w entries either side of a slice
+                  boundary are exchanged, point to point with the two neighbours.
+
+Precedent for the partition itself: simd_ops::parallel_matrix_vector_multiply row chunks
+(src/simd_ops.rs:201-239).  The exchange is a copy, so every rank sees bit-identical t and the
+partitioned iteration reproduces the single-GPU one bit for bit.
+
+The local step is a callable so that the CPU tests can drive the same host logic with a stand-in;
+the product wiring (`hip_local_step`) calls sl_neumann_step on device memory.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class RowPartition:
+    n_global: int
+    world: int
+    rank: int
+
+    def __post_init__(self):
+        self.rows_per_rank = -(-self.n_global // self.world)          # ceil
+        self.n_padded = self.rows_per_rank * self.world
+        self.lo = min(self.rank * self.rows_per_rank, self.n_global)
+        self.hi = min(self.lo + self.rows_per_rank, self.n_global)
+
+    @property
+    def n_local(self) -> int:
+        return self.hi - self.lo
+
+    def bounds(self, r: int):
+        lo = min(r * self.rows_per_rank, self.n_global)
+        return lo, min(lo + self.rows_per_rank, self.n_global)
+
+
+class AllGatherExchange:
+    """Every rank contributes its slice; result is the full (padded) vector on every rank."""
+    name = "allgather"
+
+    def __init__(self, part: RowPartition, group=None):
+        self.part, self.group = part, group
+
+    def __call__(self, t_full: torch.Tensor) -> None:
+        p = self.part
+        if p.world == 1:
+            return
+        mine = t_full[p.rank * p.rows_per_rank:(p.rank + 1) * p.rows_per_rank]
+        dist.all_gather_into_tensor(t_full, mine, group=self.group)
+
+    def bytes_sent_per_step(self) -> int:
+        return 8 * self.part.rows_per_rank * (self.part.world - 1)
+
+
+class HaloExchange:
+    """Banded systems: only w entries on each side of every slice boundary travel (neighbours only)."""
+    name = "halo"
+
+    def __init__(self, part: RowPartition, half_bandwidth: int, group=None):
+        if part.world > 1 and part.rows_per_rank < 2 * half_bandwidth + 1:
+            raise ValueError("halo exchange needs rows_per_rank >= 2 w + 1")
+        self.part, self.w, self.group = part, int(half_bandwidth), group
+
+    def __call__(self, t_full: torch.Tensor) -> None:
+        p, w = self.part, self.w
+        if p.world == 1 or w == 0:
+            return
+        ops = []
+        if p.rank > 0:                       # left neighbour: send my first w, receive its last w
+            ops.append(dist.P2POp(dist.isend, t_full[p.lo:p.lo + w], p.rank - 1, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, t_full[p.lo - w:p.lo], p.rank - 1, group=self.group))
+        if p.rank < p.world - 1 and p.hi < p.n_global:
+            ops.append(dist.P2POp(dist.isend, t_full[p.hi - w:p.hi], p.rank + 1, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, t_full[p.hi:p.hi + w], p.rank + 1, group=self.group))
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+
+    def bytes_sent_per_step(self) -> int:
+        inner = (1 if self.part.rank > 0 else 0) + (1 if self.part.rank < self.part.world - 1 else 0)
+        return 8 * self.w * inner
+
+
+# local_step(t_in_full, t_out_local, x_local, norm2_out) -> None : one fused Neumann step on the local rows
+LocalStep = Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor], None]
+
+
+class PartitionedNeumann:
+    """Ping-pong driver of the partitioned iteration: local fused step -> exchange -> norm all-reduce."""
+
+    def __init__(self, part: RowPartition, local_step: LocalStep, exchange, t0_full: torch.Tensor,
+                 x_local: torch.Tensor, group=None):
+        self.part, self.local_step, self.exchange, self.group = part, local_step, exchange, group
+        self.t = [t0_full, torch.zeros_like(t0_full)]
+        self.x = x_local
+        self.cur = 0
+        self.norm2 = torch.zeros(2, dtype=torch.float64, device=t0_full.device)
+        self.steps_done = 0
+
+    def step(self, reduce_norm: bool = True) -> None:
+        p = self.part
+        t_in, t_out = self.t[self.cur], self.t[1 - self.cur]
+        self.local_step(t_in, t_out[p.lo:p.hi], self.x, self.norm2)
+        self.exchange(t_out)
+        if reduce_norm and p.world > 1:
+            dist.all_reduce(self.norm2[:1], op=dist.ReduceOp.SUM, group=self.group)
+        self.cur = 1 - self.cur
+        self.steps_done += 1
+
+    @property
+    def term(self) -> torch.Tensor:
+        return self.t[self.cur]
+
+    def term_norm(self) -> float:
+        return float(self.norm2[0].item()) ** 0.5
+
+
+def hip_local_step(matrix_handle: int, dinv_local: torch.Tensor, order: int = 0) -> LocalStep:
+    """Product wiring: the local step is sl_neumann_step on this rank's row slice (device pointers)."""
+    from . import _lib as L
+    lib = L.load()
+
+    def step(t_in_full, t_out_local, x_local, norm2):
+        L.check(lib.sl_neumann_step(matrix_handle, dinv_local.data_ptr(), t_in_full.data_ptr(), t_out_local.data_ptr(),
+                                    x_local.data_ptr(), norm2.data_ptr(), order))
+
+    return step

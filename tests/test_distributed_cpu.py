@@ -1,0 +1,91 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the row-partitioned driver (sublinear_time_solver_amd.distributed).
+The device kernel is replaced by a stand-in local step (the oracle's row loop on this rank's slice) — this
+tests the HOST logic: partition bounds, all-gather / halo exchange, norm all-reduce, ping-pong buffers;
+the partitioned iteration must reproduce the single-process one bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sublinear_time_solver_amd import distributed as D
+from sublinear_time_solver_amd import generators as G
+from oracle import oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_local_step(rp, ci, va, dinv, lo):
+    """stand-in for sl_neumann_step on rows [lo, lo+rows): same arithmetic, via the oracle."""
+    def step(t_in_full, t_out_local, x_local, norm2):
+        t = t_in_full.numpy()
+        y = O.spmv(rp, ci, va, t)
+        tmp = y * dinv
+        tn = t[lo:lo + tmp.size] - tmp
+        t_out_local.copy_(torch.from_numpy(tn))
+        x_local.add_(torch.from_numpy(tn))
+        norm2[0] = float(np.dot(tn, tn))
+    return step
+
+
+def _worker(rank, world, port, n, k, w, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        part = D.RowPartition(n, world, rank)
+        rp, ci, va, b = G.sdd_rows(n, k, 3, w, part.lo, part.hi)
+        d = np.array([va[i * k:(i + 1) * k][ci[i * k:(i + 1) * k] == part.lo + i][0] for i in range(part.n_local)])
+        dinv = 1.0 / d
+        _, _, _, b_all = G.sdd_rows(n, k, 3, w)
+        d_all = 10.0 + 0.01 * (np.arange(n) % 1000)
+        t0 = np.zeros(part.n_padded)
+        t0[:n] = b_all * (1.0 / d_all)
+        t0 = torch.from_numpy(t0)
+        x = t0[part.lo:part.hi].clone()
+        ex = D.AllGatherExchange(part) if w == 0 else D.HaloExchange(part, w)
+        drv = D.PartitionedNeumann(part, _oracle_local_step(rp, ci, va, dinv, part.lo), ex, t0, x)
+        norms = []
+        for _ in range(steps):
+            drv.step()
+            norms.append(drv.term_norm())
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x.numpy(), t=drv.term.numpy()[part.lo:part.hi],
+                 norms=np.asarray(norms), lo=part.lo, hi=part.hi, sent=ex.bytes_sent_per_step())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k,w", [(4000, 8, 0), (4001, 8, 0), (6000, 12, 300)])
+def test_partitioned_iteration_matches_single_process(tmp_path, n, k, w):
+    world, steps = 2, 4
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, k, w, steps, str(tmp_path)), nprocs=world, join=True)
+    rp, ci, va, b = G.sdd_rows(n, k, 3, w)
+    o = O.neumann_solve(rp, ci, va, b, max_terms=steps + 1, series_tolerance=0.0, max_iterations=steps + 1, tolerance=0.0)
+    xs, ts = np.zeros(n), np.zeros(n)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        xs[int(z["lo"]):int(z["hi"])] = z["x"]
+        ts[int(z["lo"]):int(z["hi"])] = z["t"]
+        np.testing.assert_allclose(z["norms"], o["term_norms"][1:], rtol=1e-12)
+        if w:
+            assert int(z["sent"]) == 8 * w          # one neighbour each at world = 2
+    assert (xs.view(np.uint64) == o["x"].view(np.uint64)).all()
+    assert (ts.view(np.uint64) == o["term"].view(np.uint64)).all()
+
+
+def test_row_partition_bounds():
+    p = [D.RowPartition(10, 4, r) for r in range(4)]
+    assert [(q.lo, q.hi) for q in p] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert p[0].n_padded == 12
+    with pytest.raises(ValueError):
+        D.HaloExchange(D.RowPartition(100, 4, 1), 20)

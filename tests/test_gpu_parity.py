@@ -1,0 +1,436 @@
+"""GPU parity tests (pytest -m gpu): the HIP path behind the C ABI vs the CPU oracle on identical inputs.
+Bar: bit-exact per-row arithmetic (x, t, r, frontier index lists); reductions (norms) to 1e-12 relative.
+Nothing here reads /root/reference."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import _lib as L
+from sublinear_time_solver_amd import generators as G
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(Path(__file__).parent / "golden" / "reference_jacobi.npz")
+CASES = [str(c) for c in GOLD["__cases"]]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bitwise(a, b, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    bad = np.nonzero(bits(a) != bits(b))[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} entries differ, first at {bad[:5]}: {a[bad[:5]]} vs {b[bad[:5]]}"
+
+
+def _mat(case):
+    key = case.rsplit("__", 1)[0]
+    return GOLD[f"{key}__row_ptr"], GOLD[f"{key}__col_idx"], GOLD[f"{key}__values"]
+
+
+# ---- primitives (G3) -------------------------------------------------------------------------
+def test_g3_primitives_through_the_abi(gpu):
+    m = S.SparseMatrix.from_triplets([(0, 0, 2.0), (0, 1, 1.0), (1, 0, 1.0), (1, 1, 3.0)], 2, 2)
+    assert m.multiply_vector([1.0, 2.0]).tolist() == [4.0, 7.0]                    # sparse.rs:923-933
+    assert m.multiply_vector([1.0, 2.0], L.SL_ORDER_SIMD4).tolist() == [4.0, 7.0]  # simd_ops.rs:259-268
+    assert m.diagonal_inverse().tolist() == [0.5, 1.0 / 3.0]                       # neumann.rs:634-648
+    assert m.is_diagonally_dominant() and m.nnz() == 4
+    m2 = S.SparseMatrix.from_triplets([(0, 0, 1.0), (0, 1, 5.0), (1, 0, 2.0), (1, 1, 1.0)], 2, 2)
+    assert not m2.is_diagonally_dominant()                                         # matrix/mod.rs:603-613
+    lib = L.load()
+    x = np.array([1.0, 2, 3, 4]); y = np.array([5.0, 6, 7, 8]); out = C.c_double(0)
+    L.check(lib.sl_dot(4, L.ptr(x), L.ptr(y), C.byref(out), 0)); assert out.value == 70.0
+    L.check(lib.sl_l2_norm(2, L.ptr(np.array([3.0, 4.0])), C.byref(out), 0)); assert out.value == 5.0
+    yy = np.ones(4); L.check(lib.sl_axpy(4, 2.0, L.ptr(x), L.ptr(yy), 0)); assert yy.tolist() == [3.0, 5.0, 7.0, 9.0]
+
+
+def test_triplet_rules_match_oracle(gpu):
+    tr = [1, 0, 0, 1, 0, 2]; tc = [1, 1, 0, 1, 1, 2]; tv = [5.0, 2.0, 0.0, 6.0, 3.0, -0.0]
+    m = S.SparseMatrix.from_triplets(zip(tr, tc, tv), 3, 3, keep_csr=True)
+    rp, ci, va = m.to_csr()
+    orp, oci, ova = O.csr_from_triplets(tr, tc, tv, 3, 3)
+    assert rp.tolist() == orp.tolist() and ci.tolist() == oci.tolist() and va.tolist() == ova.tolist()
+    e = S.SparseMatrix.from_triplets([], 3, 3)                                     # empty matrix
+    assert e.nnz() == 0 and e.multiply_vector([1.0, 2.0, 3.0]).tolist() == [0.0, 0.0, 0.0]
+
+
+# ---- golden fixtures ---------------------------------------------------------------------------
+@pytest.mark.parametrize("case", CASES)
+def test_golden_fixture_neumann_bitwise_vs_oracle(gpu, case):
+    rp, ci, va = _mat(case)
+    b = GOLD[f"{case}__b"]
+    n = b.size
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+    for order, oorder in ((L.SL_ORDER_CSR_SEQUENTIAL, O.ORDER_SEQ), (L.SL_ORDER_SIMD4, O.ORDER_SIMD4)):
+        assert_bitwise(m.multiply_vector(b, order), O.spmv(rp, ci, va, b, oorder), "spmv")
+        g = S.NeumannSolver(max_terms=200, series_tolerance=1e-12, order=order).solve(m, b, S.SolverOptions(tolerance=1e-10))
+        o = O.neumann_solve(rp, ci, va, b, max_terms=200, series_tolerance=1e-12, tolerance=1e-10, order=oorder)
+        assert g.iterations == o["iterations"] and g.converged == o["converged"]
+        assert_bitwise(g.solution, o["x"], "x")
+        np.testing.assert_allclose(g.term_norms, o["term_norms"], rtol=1e-12)
+        np.testing.assert_allclose(g.residual_norm, o["residual_norm"], rtol=1e-9, atol=1e-300)
+    # captured reference (Python Jacobi) iterates
+    for k in (1, 2, 5, 10):
+        with pytest.raises(S.SolverError) as e:
+            S.NeumannSolver(max_terms=k, series_tolerance=0.0).solve(m, b, S.SolverOptions(tolerance=0.0, max_iterations=k))
+        assert e.value.kind == "ConvergenceFailure"
+        np.testing.assert_allclose(e.value.result.solution, GOLD[f"{case}__x_k{k}"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(g.solution, GOLD[f"{case}__x_final"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(g.solution, GOLD[f"{case}__js_x"], rtol=0, atol=1e-8)
+
+
+def test_reference_quirk_modes_g4(gpu):
+    m = S.SparseMatrix.from_triplets([(0, 0, 4.0), (0, 1, 1.0), (1, 0, 1.0), (1, 1, 3.0)], 2, 2)
+    b = [5.0, 4.0]
+    r = S.NeumannSolver(20, 1e-8, residual=L.SL_RESIDUAL_REFERENCE_SCALED).solve(m, b)
+    np.testing.assert_allclose(r.solution, [1.0, 1.0], atol=1e-7)
+    assert r.iterations == 17 and abs(r.residual_norm - 4.6015) < 1e-3
+    q = S.NeumannSolver(20, 1e-8, start=L.SL_START_REFERENCE_DEFAULT, residual=L.SL_RESIDUAL_REFERENCE_SCALED).solve(m, b)
+    np.testing.assert_allclose(q.solution, [2.25, 2.0 + 1.0 / 3.0], atol=1e-7)
+    assert abs(q.residual_norm - 12.8198) < 1e-3
+    t = S.NeumannSolver(20, 1e-8).solve(m, b)
+    assert t.iterations == 16 and t.converged
+
+
+def test_error_paths(gpu):
+    neg = (GOLD["neg_n_100_sparse_dd__row_ptr"], GOLD["neg_n_100_sparse_dd__col_idx"], GOLD["neg_n_100_sparse_dd__values"])
+    m = S.SparseMatrix.from_csr(*neg, 100, 100)
+    with pytest.raises(S.SolverError) as e:
+        S.NeumannSolver().solve(m, np.ones(100))
+    assert e.value.kind == "MatrixNotDiagonallyDominant"
+    m = S.SparseMatrix.from_triplets([(0, 0, 2.0)], 2, 2)          # row 1 empty: passes DD, fails on the diagonal
+    with pytest.raises(S.SolverError) as e:
+        S.NeumannSolver().solve(m, [1.0, 1.0])
+    assert e.value.kind == "InvalidSparseMatrix" and "position 1" in str(e.value)
+    m = S.SparseMatrix.from_triplets([(0, 0, 2.0), (1, 1, 1e-15)], 2, 2)
+    with pytest.raises(S.SolverError) as e:
+        S.NeumannSolver().solve(m, [1.0, 1.0])
+    assert e.value.kind == "InvalidSparseMatrix" and "near-zero" in str(e.value)
+    m = S.SparseMatrix.from_triplets([(0, 0, 2.0), (1, 1, 1.0)], 2, 3)
+    with pytest.raises(S.SolverError) as e:
+        S.NeumannSolver().solve(m, [1.0, 1.0])
+    assert e.value.kind == "InvalidInput"
+    m = S.SparseMatrix.from_triplets([(0, 0, 2.0), (1, 1, 1.0)], 2, 2)
+    with pytest.raises(S.SolverError) as e:
+        S.NeumannSolver().solve(m, [1.0, 1.0, 1.0])
+    assert e.value.kind == "DimensionMismatch"
+    with pytest.raises(S.SolverError) as e:
+        m.multiply_vector([1.0])
+    assert e.value.kind == "DimensionMismatch"
+    with pytest.raises(S.SolverError) as e:
+        S.SparseMatrix.from_csr([0, 1, 2], [0, 7], [1.0, 1.0], 2, 2)
+    assert e.value.kind == "IndexOutOfBounds"
+    with pytest.raises(S.SolverError) as e:
+        S.SparseMatrix.from_csr([0, 2, 1], [0, 1], [1.0, 1.0], 2, 2)
+    assert e.value.kind == "InvalidSparseMatrix"
+
+
+# ---- synthetic systems: uniform rows (fast path) and ragged rows (generic path) ---------------------
+@pytest.mark.parametrize("n,k,w", [(20000, 16, 0), (20000, 16, 300), (5000, 8, 0), (3001, 12, 0), (777, 5, 50)])
+def test_sdd_bitwise_parity(gpu, n, k, w):
+    rp, ci, va, b = G.sdd_rows(n, k, seed=1, half_bandwidth=w)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+    info = m.info()
+    assert info.nnz == n * k and info.uniform_width == (k if k % 4 == 0 else 0)
+    for order, oorder in ((L.SL_ORDER_CSR_SEQUENTIAL, O.ORDER_SEQ), (L.SL_ORDER_SIMD4, O.ORDER_SIMD4)):
+        assert_bitwise(m.multiply_vector(b, order), O.spmv(rp, ci, va, b, oorder), "spmv")
+        g = S.NeumannSolver(order=order).solve(m, b, S.SolverOptions(tolerance=1e-10, collect_stats=True))
+        o = O.neumann_solve(rp, ci, va, b, tolerance=1e-10, order=oorder)
+        assert g.iterations == o["iterations"] and g.converged and o["converged"]
+        assert g.stats["matvec_count"] == o["matvec_count"]
+        assert_bitwise(g.solution, o["x"], "x")
+        np.testing.assert_allclose(g.term_norms, o["term_norms"], rtol=1e-12)
+    res = np.linalg.norm(O.spmv(rp, ci, va, g.solution) - b)
+    assert res <= 1e-8 * np.linalg.norm(b)
+    # run-to-run determinism (stands in for a race detector): identical bits on a second run
+    g2 = S.NeumannSolver(order=L.SL_ORDER_SIMD4).solve(m, b, S.SolverOptions(tolerance=1e-10))
+    assert_bitwise(g.solution, g2.solution, "rerun")
+    assert (g.term_norms == g2.term_norms).all()
+
+
+def test_ragged_rows_and_gen1000(gpu):
+    rp, ci, va, b = G.gen1000_dense(size=400, seed=42)          # C1 recipe at a size the test can afford; ~120 nnz/row, ragged
+    m = S.SparseMatrix.from_csr(rp, ci, va, 400, 400)
+    assert m.info().uniform_width == 0
+    for order, oorder in ((L.SL_ORDER_CSR_SEQUENTIAL, O.ORDER_SEQ), (L.SL_ORDER_SIMD4, O.ORDER_SIMD4)):
+        g = S.NeumannSolver(order=order).solve(m, b)
+        o = O.neumann_solve(rp, ci, va, b, order=oorder)
+        assert g.iterations == o["iterations"]
+        assert_bitwise(g.solution, o["x"], "x")
+    # rows with 0..9 entries incl. empty off-diagonals and a slice boundary (n = 130)
+    rng = np.random.default_rng(3)
+    tr, tc, tv = [], [], []
+    n = 130
+    for i in range(n):
+        tr.append(i); tc.append(i); tv.append(20.0 + i)
+        for j in rng.choice(n, size=rng.integers(0, 9), replace=False):
+            if j != i:
+                tr.append(i); tc.append(int(j)); tv.append(float(rng.uniform(-1, 1)))
+    m = S.SparseMatrix.from_triplets(zip(tr, tc, tv), n, n)
+    orp, oci, ova = O.csr_from_triplets(tr, tc, tv, n, n)
+    x = rng.standard_normal(n)
+    for order, oorder in ((0, 0), (1, 1)):
+        assert_bitwise(m.multiply_vector(x, order), O.spmv(orp, oci, ova, x, oorder), "ragged spmv")
+        g = S.NeumannSolver(order=order).solve(m, np.ones(n))
+        o = O.neumann_solve(orp, oci, ova, np.ones(n), order=oorder)
+        assert_bitwise(g.solution, o["x"], "ragged x")
+
+
+def test_c1_generate_1000(gpu):
+    """BASELINE config 0: n = 1000 `generate -t diagonally-dominant` system, full x solve."""
+    rp, ci, va, b = G.gen1000_dense(size=1000, seed=42)
+    m = S.SparseMatrix.from_csr(rp, ci, va, 1000, 1000)
+    g = S.NeumannSolver().solve(m, b)
+    o = O.neumann_solve(rp, ci, va, b)
+    assert g.converged and g.iterations == o["iterations"]
+    assert_bitwise(g.solution, o["x"], "C1 x")
+    assert np.max(np.abs(g.solution - o["x"])) / np.max(np.abs(o["x"])) <= 1e-10
+
+
+def test_c2_full_solve_1m(gpu):
+    """BASELINE config 1: n = 1M, 8 nnz/row, fp64 full solve to a true residual of 1e-8."""
+    n, k = 1_000_000, 8
+    rp, ci, va, b = G.sdd_rows(n, k, seed=1)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+    g = S.NeumannSolver(max_terms=200, series_tolerance=1e-14).solve(m, b, S.SolverOptions(tolerance=1e-8, collect_stats=True))
+    o = O.neumann_solve(rp, ci, va, b, max_terms=200, series_tolerance=1e-14, tolerance=1e-8, threads=8)
+    assert g.converged and g.iterations == o["iterations"]
+    assert_bitwise(g.solution, o["x"], "C2 x")
+    assert g.residual_norm <= 1e-8
+    assert np.linalg.norm(O.spmv(rp, ci, va, g.solution, threads=8) - b) <= 1e-8
+
+
+def test_device_generator_matches_numpy(gpu):
+    import torch
+    lib = L.load()
+    n, k = 100_000, 16
+    for w, lo, hi in ((0, 0, n), (500, 1000, 60_000)):
+        rows = hi - lo
+        rp = torch.empty(rows + 1, dtype=torch.int32, device="cuda")
+        ci = torch.empty(rows * k, dtype=torch.int32, device="cuda")
+        va = torch.empty(rows * k, dtype=torch.float64, device="cuda")
+        bb = torch.empty(rows, dtype=torch.float64, device="cuda")
+        L.check(lib.sl_synth_sdd_device(n, k, 7, w, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), bb.data_ptr()))
+        L.check(lib.sl_synchronize())
+        nrp, nci, nva, nb = G.sdd_rows(n, k, 7, w, lo, hi)
+        assert (rp.cpu().numpy().view(np.uint32) == nrp).all()
+        assert (ci.cpu().numpy().view(np.uint32) == nci).all()
+        assert_bitwise(va.cpu().numpy(), nva, "values")
+        assert_bitwise(bb.cpu().numpy(), nb, "b")
+
+
+def test_fused_step_on_device_buffers_and_row_slices(gpu):
+    """sl_neumann_step on torch-owned HBM, whole matrix vs two row slices (the multi-GPU partition)."""
+    import torch
+    lib = L.load()
+    n, k = 8192 + 77, 16
+    rp, ci, va, b = G.sdd_rows(n, k, seed=5)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+    dinv = m.diagonal_inverse()
+    t0 = b * dinv
+    o = O.neumann_solve(rp, ci, va, b, max_terms=3, series_tolerance=0.0, max_iterations=3, tolerance=0.0)
+
+    def run(mats, bounds):
+        t_in = torch.tensor(t0, device="cuda")
+        x = torch.tensor(t0, device="cuda")              # x after the k = 0 term
+        dv = torch.tensor(dinv, device="cuda")
+        norm2 = torch.zeros(2, dtype=torch.float64, device="cuda")
+        for _ in range(2):
+            t_out = torch.empty_like(t_in)
+            for mm, (lo, hi) in zip(mats, bounds):
+                L.check(lib.sl_neumann_step(mm._h, dv[lo:hi].data_ptr(), t_in.data_ptr(), t_out[lo:hi].data_ptr(),
+                                            x[lo:hi].data_ptr(), norm2.data_ptr(), 0))
+            L.check(lib.sl_synchronize())
+            t_in = t_out
+        return x.cpu().numpy(), t_in.cpu().numpy()
+
+    x1, t1 = run([m], [(0, n)])
+    assert_bitwise(x1, o["x"], "x after 3 terms")
+    assert_bitwise(t1, o["term"], "term")
+    h = 4100                                              # not a multiple of 64
+    lo_rp = rp[: h + 1]
+    hi_rp = (rp[h:] - rp[h]).astype(np.uint32)
+    m_lo = S.SparseMatrix.from_csr(lo_rp, ci[: rp[h]], va[: rp[h]], h, n, row_offset=0)
+    m_hi = S.SparseMatrix.from_csr(hi_rp, ci[rp[h]:], va[rp[h]:], n - h, n, row_offset=h)
+    x2, t2 = run([m_lo, m_hi], [(0, h), (h, n)])
+    assert_bitwise(x2, o["x"], "sliced x")
+    assert_bitwise(t2, o["term"], "sliced term")
+
+
+# ---- push / frontier --------------------------------------------------------------------------------
+def _tridiag10():
+    tr, tc, tv = [], [], []
+    for i in range(10):
+        for j, v in ((i - 1, -1.0), (i, 10.0), (i + 1, -1.0)):
+            if 0 <= j < 10:
+                tr.append(i), tc.append(j), tv.append(v)
+    return tr, tc, tv
+
+
+@pytest.mark.parametrize("dense_switch", [2.0, 1.0 / 16.0, 1e-9])
+def test_push_frontier_bit_exact_small(gpu, dense_switch):
+    tr, tc, tv = _tridiag10()
+    m = S.SparseMatrix.from_triplets(zip(tr, tc, tv), 10, 10, with_transpose=True)
+    rp, ci, va = O.csr_from_triplets(tr, tc, tv, 10, 10)
+    b = np.zeros(10); b[0] = b[9] = 1.0
+    g = S.PushSolver(theta=1e-8, dense_switch=dense_switch).solve(m, b, log_frontier=4096)
+    o = O.push_sync_solve(rp, ci, va, b, theta=1e-8, log_cap=4096)
+    assert g["converged"] and g["rounds"] == o["rounds"] and g["pushes"] == o["pushes"]
+    assert g["frontier_log"].tolist() == o["frontier_log"].tolist()
+    assert_bitwise(g["solution"], o["x"], "x")
+    assert_bitwise(g["residual"], o["r"], "r")
+
+
+@pytest.mark.parametrize("n,k,w,theta,dense_switch", [
+    (5000, 8, 0, 1e-7, 2.0), (5000, 8, 0, 1e-7, 1.0 / 16.0), (5000, 8, 0, 1e-7, 1e-9),
+    (20000, 16, 200, 1e-9, 1.0 / 16.0), (3001, 12, 0, 1e-6, 0.3)])
+def test_push_frontier_bit_exact_sdd(gpu, n, k, w, theta, dense_switch):
+    rp, ci, va, b = G.sdd_rows(n, k, seed=2, half_bandwidth=w)
+    b = b * (np.arange(n) % 7 == 0)                     # sparse right-hand side: the frontier starts small and grows
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    for order in (0, 1):
+        g = S.PushSolver(theta=theta, dense_switch=dense_switch, order=order).solve(m, b, log_frontier=2_000_000)
+        o = O.push_sync_solve(rp, ci, va, b, theta=theta, order=order, log_cap=2_000_000)
+        assert g["converged"] and o["converged"]
+        assert g["rounds"] == o["rounds"] and g["pushes"] == o["pushes"]
+        assert g["frontier_log"].size == o["frontier_log"].size
+        assert (g["frontier_log"] == o["frontier_log"]).all(), "active-index frontier must be bit-exact"
+        assert_bitwise(g["solution"], o["x"], "x")
+        assert_bitwise(g["residual"], o["r"], "r")
+        if dense_switch >= 2.0:
+            assert g["rows_touched"] == o["rows_touched"] and g["dense_rounds"] == 0
+    # invariant r = b - A x and agreement with the Neumann solution
+    np.testing.assert_allclose(b - O.spmv(rp, ci, va, g["solution"]), g["residual"], atol=1e-12)
+    ns = O.neumann_solve(rp, ci, va, b, tolerance=1e-12, max_terms=200, series_tolerance=1e-15)
+    np.testing.assert_allclose(g["solution"], ns["x"], atol=1e-5)
+
+
+def test_push_max_rounds_and_warm_start(gpu):
+    n, k = 4000, 8
+    rp, ci, va, b = G.sdd_rows(n, k, seed=4)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    g = S.PushSolver(theta=1e-9, max_rounds=3).solve(m, b)
+    o = O.push_sync_solve(rp, ci, va, b, theta=1e-9, max_rounds=3)
+    assert not g["converged"] and g["rounds"] == 3
+    assert_bitwise(g["solution"], o["x"], "x at the round limit")
+    assert_bitwise(g["residual"], o["r"], "r at the round limit")
+    g2 = S.PushSolver(theta=1e-9).solve(m, b, x0=g["solution"])
+    o2 = O.push_sync_solve(rp, ci, va, b, theta=1e-9, x0=o["x"])
+    assert g2["converged"] and g2["rounds"] == o2["rounds"]
+    assert_bitwise(g2["solution"], o2["x"], "warm start")
+
+
+def test_transposed_structure(gpu):
+    n, k = 3000, 8
+    rp, ci, va, _ = G.sdd_rows(n, k, seed=9)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True, keep_csr=True)
+    rp2, ci2, va2 = m.to_csr()
+    assert (rp2 == rp).all() and (ci2 == ci).all() and (va2 == va).all()
+    assert m.info().has_transpose == 1
+
+
+def test_estimate_entry_matches_full_solve(gpu):
+    n, k = 20000, 8
+    rp, ci, va, b = G.sdd_rows(n, k, seed=6, half_bandwidth=0)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    x = O.neumann_solve(rp, ci, va, b, tolerance=1e-13, max_terms=300, series_tolerance=1e-16)["x"]
+    for row in (0, 777, n - 1):
+        r = S.estimate_entry(m, b, row, theta=1e-12)
+        assert r.converged
+        assert abs(r.estimate - x[row]) <= r.residual_l1 * np.max(np.abs(x)) + 1e-12
+        assert abs(r.estimate - x[row]) <= 1e-8
+        assert r.rows_touched < 40 * n                   # work follows the touched set, not rounds * n
+    # TS surface: same field names as src/core/solver.ts:550-554
+    ts = S.SublinearSolver(method="forward-push", epsilon=1e-10, max_iterations=5000)
+    e = ts.estimate_entry(m, b, row=5)
+    assert set(e) >= {"estimate", "variance", "confidence"} and abs(e["estimate"] - x[5]) < 1e-7
+
+
+def test_pagerank_system_push_and_estimate(gpu):
+    """Column-dominant (not row-dominant) PageRank system I - 0.85 P^T (core/solver.ts:664-722)."""
+    n = 3000
+    arp, aci, aw = G.pagerank_graph(n, seed=3)
+    rp, ci, va, b = G.pagerank_system(n, arp, aci, aw)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    g = S.PushSolver(theta=1e-12).solve(m, b, log_frontier=0)
+    o = O.push_sync_solve(rp, ci, va, b, theta=1e-12)
+    assert g["converged"] and g["rounds"] == o["rounds"]
+    assert_bitwise(g["solution"], o["x"], "pagerank x")
+    import scipy.sparse as sp, scipy.sparse.linalg as spl
+    A = sp.csr_matrix((va, ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n))
+    xs = spl.spsolve(A.tocsc(), b)
+    np.testing.assert_allclose(g["solution"], xs, atol=1e-9)
+    top = int(np.argmax(xs))
+    r = S.estimate_entry(m, b, top, theta=1e-13)
+    assert abs(r.estimate - xs[top]) <= 1e-9
+
+
+def test_ts_surface_solve(gpu):
+    """SublinearSolver.solve with the reference's JSON matrix layouts (core/types.ts:6-22)."""
+    dense = {"rows": 3, "cols": 3, "format": "dense", "data": [[4, -1, 0], [-1, 4, -1], [0, -1, 3]]}
+    r = S.SublinearSolver(method="neumann", epsilon=1e-10, max_iterations=500).solve(dense, [1, 2, 1])
+    # the mathematically correct answer, NOT the sign-bugged [0.1463, 0.4146, 0.1951]
+    np.testing.assert_allclose(r["solution"], [0.4390243902, 0.7560975610, 0.5853658537], atol=1e-8)
+    assert r["converged"] and r["method"] == "neumann" and set(r) >= {"iterations", "residual", "computeTime", "memoryUsed"}
+    coo = {"rows": 3, "cols": 3, "format": "coo", "values": [4, -1, -1, 4, -1, -1, 3],
+           "rowIndices": [0, 0, 1, 1, 1, 2, 2], "colIndices": [0, 1, 0, 1, 2, 1, 2]}
+    r2 = S.SublinearSolver(method="forward-push", epsilon=1e-10, max_iterations=500).solve(coo, [1, 2, 1])
+    np.testing.assert_allclose(r2["solution"], r["solution"], atol=1e-8)
+    nested = {"rows": 3, "cols": 3, "format": "coo", "data": {k: coo[k] for k in ("values", "rowIndices", "colIndices")}}
+    r3 = S.SublinearSolver(method="bidirectional", epsilon=1e-10).solve(nested, [1, 2, 1])
+    np.testing.assert_allclose(r3["solution"], r["solution"], atol=1e-8)
+    with pytest.raises(S.SolverError):
+        S.SublinearSolver(method="nope")
+
+
+# ---- full size: size-independent properties at the BASELINE roofline configuration ------------------
+def test_c3_full_size_properties(gpu):
+    """n = 10M, 16 nnz/row generated in HBM: (i) sampled row blocks of one fused step equal the oracle
+    bit for bit (rows regenerated on the CPU from the counter-based generator), (ii) the solve reaches a
+    true residual <= 1e-8, (iii) rerun determinism."""
+    import torch
+    lib = L.load()
+    n, k, seed = 10_000_000, 16, 1
+    rp = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    ci = torch.empty(n * k, dtype=torch.int32, device="cuda")
+    va = torch.empty(n * k, dtype=torch.float64, device="cuda")
+    b = torch.empty(n, dtype=torch.float64, device="cuda")
+    L.check(lib.sl_synth_sdd_device(n, k, seed, 0, 0, n, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), b.data_ptr()))
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, device=True)
+    del rp, ci, va
+    torch.cuda.empty_cache()
+    dinv = torch.empty(n, dtype=torch.float64, device="cuda")
+    L.check(lib.sl_matrix_diagonal_inverse(m._h, dinv.data_ptr(), 1))
+    t0 = b * dinv
+    x = t0.clone()
+    t1 = torch.empty_like(t0)
+    norm2 = torch.zeros(2, dtype=torch.float64, device="cuda")
+    L.check(lib.sl_neumann_step(m._h, dinv.data_ptr(), t0.data_ptr(), t1.data_ptr(), x.data_ptr(), norm2.data_ptr(), 0))
+    L.check(lib.sl_synchronize())
+    t0h, t1h, xh = t0.cpu().numpy(), t1.cpu().numpy(), x.cpu().numpy()
+    for lo in (0, 4_999_937, n - 4096):
+        hi = lo + 4096
+        rrp, rci, rva, rb = G.sdd_rows(n, k, seed, 0, lo, hi)
+        y = O.spmv(rrp, rci, rva, t0h)                                  # rows lo..hi of A t0
+        d = np.array([rva[i * k:(i + 1) * k][rci[i * k:(i + 1) * k] == lo + i][0] for i in range(hi - lo)])
+        tn = t0h[lo:hi] - y * (1.0 / d)
+        assert_bitwise(t1h[lo:hi], tn, f"fused step rows {lo}..{hi}")
+        assert_bitwise(xh[lo:hi], t0h[lo:hi] + tn, "x")
+    assert abs(float(norm2[0]) - float(np.dot(t1h, t1h))) <= 1e-10 * float(norm2[0])
+    o = L.NeumannOptions(); lib.sl_neumann_options_default(C.byref(o))
+    o.tolerance, o.mem, o.max_terms, o.series_tolerance = 1e-8, 1, 200, 1e-14
+    xs = torch.empty(n, dtype=torch.float64, device="cuda")
+    res = L.NeumannResult()
+    L.check(lib.sl_neumann_solve(m._h, b.data_ptr(), None, C.byref(o), xs.data_ptr(), None, C.byref(res)))
+    assert res.converged and res.residual_norm <= 1e-8
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    L.check(lib.sl_spmv(m._h, xs.data_ptr(), y.data_ptr(), 0, 1))
+    assert float(torch.linalg.vector_norm(y - b)) <= 1.0000001e-8
+    xs2 = torch.empty_like(xs)
+    L.check(lib.sl_neumann_solve(m._h, b.data_ptr(), None, C.byref(o), xs2.data_ptr(), None, C.byref(res)))
+    assert torch.equal(xs, xs2)
