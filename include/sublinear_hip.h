@@ -107,6 +107,7 @@ typedef struct {
     uint64_t padded_nnz;      /* entries stored in the slice layout (>= nnz) */
     uint64_t n_slices;        /* 64-row slices */
     uint64_t device_bytes;    /* HBM held by this matrix */
+    uint64_t bandwidth;       /* max |col - row| over stored entries: selects the LDS band kernel */
     uint32_t max_row_nnz, min_row_nnz;
     uint32_t uniform_width;   /* != 0: every row has exactly this many entries */
     uint32_t has_transpose;

@@ -30,7 +30,7 @@ vp = C.c_void_p
 
 class MatrixInfo(C.Structure):
     _fields_ = [("n_rows", u64), ("n_cols", u64), ("nnz", u64), ("row_offset", u64), ("padded_nnz", u64),
-                ("n_slices", u64), ("device_bytes", u64), ("max_row_nnz", u32), ("min_row_nnz", u32),
+                ("n_slices", u64), ("device_bytes", u64), ("bandwidth", u64), ("max_row_nnz", u32), ("min_row_nnz", u32),
                 ("uniform_width", u32), ("has_transpose", u32)]
 
 
@@ -104,6 +104,31 @@ class SolverError(RuntimeError):
         super().__init__(f"{self.kind}: {message}")
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (same SONAME as /opt/rocm's); if this library pulled in /opt/rocm's copy first, a later
+    `import torch` would load a second runtime and find no GPU.  When torch is installed but not
+    yet imported, map its copy first so both sides resolve to the same runtime (torch itself is NOT
+    imported here: it is plumbing for callers that want it, not a dependency)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Load the HIP library; raise loudly when it has not been built (no fallback path exists)."""
     global _lib
@@ -114,6 +139,7 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{path} not found: build it with `make -C sublinear_time_solver_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing

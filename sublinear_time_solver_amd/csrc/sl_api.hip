@@ -81,17 +81,19 @@ sl_status read_scalars(const double *d, double *h, int count)
     SL_HIP(hipStreamSynchronize(st));
     return SL_OK;
 }
-sl_row_args row_args(const sl_matrix *m)
+sl_row_args row_args(const sl_matrix *m) { return sl_matrix_row_args(m); }
+size_t partial_bytes(const sl_matrix *m) { return ((size_t)sl_row_grid(m->n_slices) * 2 + 4096) * sizeof(double); }
+} // namespace
+
+sl_row_args sl_matrix_row_args(const sl_matrix *m)
 {
     sl_row_args a;
     memset(&a, 0, sizeof(a));
     a.slice_ptr = m->d_slice_ptr; a.row_len = m->d_row_len; a.cols = m->d_cols; a.vals = m->d_vals;
-    a.n_rows = m->n_rows; a.n_slices = m->n_slices; a.row_offset = m->row_offset;
-    a.uniform_width = m->uniform_width;
+    a.n_rows = m->n_rows; a.n_cols = m->n_cols; a.n_slices = m->n_slices; a.row_offset = m->row_offset;
+    a.bandwidth = m->bandwidth; a.uniform_width = m->uniform_width;
     return a;
 }
-size_t partial_bytes(const sl_matrix *m) { return ((size_t)sl_row_grid(m->n_slices) * 2 + 4096) * sizeof(double); }
-} // namespace
 
 // ---- library -----------------------------------------------------------------------------------
 extern "C" {
@@ -238,7 +240,7 @@ sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info)
 {
     if (!m || !info) return sl_fail(SL_INVALID_INPUT, "null argument");
     info->n_rows = m->n_rows; info->n_cols = m->n_cols; info->nnz = m->nnz; info->row_offset = m->row_offset;
-    info->padded_nnz = m->padded_nnz; info->n_slices = m->n_slices; info->device_bytes = m->device_bytes;
+    info->padded_nnz = m->padded_nnz; info->n_slices = m->n_slices; info->device_bytes = m->device_bytes; info->bandwidth = m->bandwidth;
     info->max_row_nnz = m->max_row_nnz; info->min_row_nnz = m->min_row_nnz; info->uniform_width = m->uniform_width;
     info->has_transpose = m->d_tptr != nullptr;
     return SL_OK;

@@ -296,10 +296,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
         if (dense) {
             uint32_t nf_next = 0;
             if (m) {
-                sl_row_args a;
-                memset(&a, 0, sizeof(a));
-                a.slice_ptr = m->d_slice_ptr; a.row_len = m->d_row_len; a.cols = m->d_cols; a.vals = m->d_vals;
-                a.n_rows = m->n_rows; a.n_slices = m->n_slices; a.row_offset = 0; a.uniform_width = m->uniform_width;
+                sl_row_args a = sl_matrix_row_args(m);
                 a.gather = ps.delta[cur]; a.dinv = ps.dinv; a.out = ps.delta[1 - cur]; a.x = ps.x; a.r = ps.r; a.theta = theta;
                 a.partials = scr; a.result = resbuf.as<double>();
                 st = sl_launch_rows(a, (sl_order)order, SL_EPI_PUSH, s);
@@ -413,10 +410,7 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
     // r = b - A x0
     SL_TRY(ax.alloc(n * 8));
     {
-        sl_row_args a;
-        memset(&a, 0, sizeof(a));
-        a.slice_ptr = m->d_slice_ptr; a.row_len = m->d_row_len; a.cols = m->d_cols; a.vals = m->d_vals;
-        a.n_rows = n; a.n_slices = m->n_slices; a.uniform_width = m->uniform_width;
+        sl_row_args a = sl_matrix_row_args(m);
         a.gather = ps.x; a.out = ax.as<double>();
         SL_TRY(sl_launch_rows(a, (sl_order)o->order, SL_EPI_SPMV, s));
         SL_TRY(sl_launch_sub(n, bbuf.as<double>(), ax.as<double>(), ps.r, s));

@@ -31,6 +31,7 @@ struct sl_matrix {
     uint32_t *d_cols = nullptr;      // [padded_nnz]
     double *d_vals = nullptr;        // [padded_nnz]
     uint32_t max_row_nnz = 0, min_row_nnz = 0, uniform_width = 0;
+    uint64_t bandwidth = 0;          // max |col - (row_offset + row)| over stored entries
     // raw CSR (SL_MATRIX_KEEP_CSR or needed by the sparse-frontier kernels)
     uint32_t *d_row_ptr = nullptr, *d_col_idx = nullptr;
     double *d_values = nullptr;
@@ -69,7 +70,8 @@ struct sl_row_args {
     // matrix
     const uint32_t *slice_ptr, *row_len, *cols;
     const double *vals;
-    uint64_t n_rows, n_slices, row_offset;
+    uint64_t n_rows, n_cols, n_slices, row_offset;
+    uint64_t bandwidth;   // ~0 = unknown / do not use the LDS band kernel
     uint32_t uniform_width;
     // vectors
     const double *gather; // gathered vector (n_cols)
@@ -83,6 +85,7 @@ struct sl_row_args {
     double *result;       // device scalar(s): [0] = sum of squares, PUSH: [1] = frontier count (as double bits u64)
 };
 sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s);
+sl_row_args sl_matrix_row_args(const sl_matrix *m);   // matrix part filled, vectors null
 uint32_t sl_row_grid(uint64_t n_slices);
 
 sl_status sl_launch_sumsq(uint64_t n, const double *x, double *partials, double *result, hipStream_t s);

@@ -11,6 +11,7 @@
 // CSRStorage::multiply_vector (matrix/sparse.rs:187-203) resp. the 4-lane order of
 // simd_ops::matrix_vector_multiply_simd (simd_ops.rs:20-88).
 #include "sl_internal.hpp"
+#include <cstdlib>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -26,9 +27,149 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// One wave = one 64-row slice; lane = row.  ORDER 0: sequential, 1: simd4 lanes.
-// UW > 0: every row of the matrix has exactly UW entries (UW % 4 == 0): no slice_ptr /
-// row_len reads, fully unrolled, all loads issued before the dependent add chain.
+// ---- shared pieces of the row kernels ----------------------------------------------------------
+// Row walk: lane = row of slice s.  GATHER(c) returns the gathered-vector entry of column c —
+// from HBM/L2 (global variant) or from the LDS-staged window (band variant).
+// ORDER 0: sequential, 1: simd4 lanes.  UW > 0: every row has exactly UW entries (UW % 4 == 0):
+// no slice_ptr / row_len reads, fully unrolled, all loads issued before the dependent add chain.
+template <int ORDER, int UW, class GATHER>
+__device__ __forceinline__ double sl_row_walk(const sl_row_args &a, uint64_t s, uint32_t lane, uint64_t i, GATHER gather)
+{
+    const u32x4 *__restrict__ cq = reinterpret_cast<const u32x4 *>(a.cols);
+    const f64x2 *__restrict__ vq = reinterpret_cast<const f64x2 *>(a.vals);
+    double sum = 0.0;
+    if constexpr (UW > 0) {
+        constexpr int NQ = UW / 4;
+        const uint64_t qb = s * NQ;
+        u32x4 c[NQ];
+        f64x2 va[NQ], vb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            c[q] = __builtin_nontemporal_load(&cq[(qb + q) * 64 + lane]);
+            va[q] = __builtin_nontemporal_load(&vq[((qb + q) * 2) * 64 + lane]);
+            vb[q] = __builtin_nontemporal_load(&vq[((qb + q) * 2 + 1) * 64 + lane]);
+        }
+        double t[UW];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            t[4 * q + 0] = gather(c[q].x);
+            t[4 * q + 1] = gather(c[q].y);
+            t[4 * q + 2] = gather(c[q].z);
+            t[4 * q + 3] = gather(c[q].w);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            sum = DADD(sum, DMUL(va[q].x, t[4 * q + 0]));
+            sum = DADD(sum, DMUL(va[q].y, t[4 * q + 1]));
+            sum = DADD(sum, DMUL(vb[q].x, t[4 * q + 2]));
+            sum = DADD(sum, DMUL(vb[q].y, t[4 * q + 3]));
+        }
+    } else {
+        const uint32_t q0 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s]);
+        const uint32_t q1 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s + 1]);
+        const uint32_t len = a.row_len[i];
+        if constexpr (ORDER == 0) {
+            for (uint32_t q = q0; q < q1; ++q) {
+                const u32x4 c = __builtin_nontemporal_load(&cq[(uint64_t)q * 64 + lane]);
+                const f64x2 va = __builtin_nontemporal_load(&vq[((uint64_t)q * 2) * 64 + lane]);
+                const f64x2 vb = __builtin_nontemporal_load(&vq[((uint64_t)q * 2 + 1) * 64 + lane]);
+                const double t0 = gather(c.x), t1 = gather(c.y), t2 = gather(c.z), t3 = gather(c.w);
+                const uint32_t k = (q - q0) * 4;
+                const double s0 = DADD(sum, DMUL(va.x, t0));
+                sum = (k < len) ? s0 : sum;
+                const double s1 = DADD(sum, DMUL(va.y, t1));
+                sum = (k + 1 < len) ? s1 : sum;
+                const double s2 = DADD(sum, DMUL(vb.x, t2));
+                sum = (k + 2 < len) ? s2 : sum;
+                const double s3 = DADD(sum, DMUL(vb.y, t3));
+                sum = (k + 3 < len) ? s3 : sum;
+            }
+        } else {
+            // simd_ops.rs:41-77: rows with >= 8 entries: four lane sums over the full
+            // chunks of 4, then ((l0+l1)+l2)+l3, then the tail sequentially; shorter
+            // rows: sequential from 0.0 (chunks_eff = 0, the horizontal sum of zeros is 0.0).
+            const uint32_t chunks = (len >= 8u) ? (len >> 2) : 0u;
+            double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+            bool merged = false;
+            for (uint32_t q = q0; q < q1; ++q) {
+                const u32x4 c = __builtin_nontemporal_load(&cq[(uint64_t)q * 64 + lane]);
+                const f64x2 va = __builtin_nontemporal_load(&vq[((uint64_t)q * 2) * 64 + lane]);
+                const f64x2 vb = __builtin_nontemporal_load(&vq[((uint64_t)q * 2 + 1) * 64 + lane]);
+                const double p0 = DMUL(va.x, gather(c.x)), p1 = DMUL(va.y, gather(c.y));
+                const double p2 = DMUL(vb.x, gather(c.z)), p3 = DMUL(vb.y, gather(c.w));
+                const uint32_t qi = q - q0;
+                if (qi < chunks) {
+                    l0 = DADD(l0, p0); l1 = DADD(l1, p1); l2 = DADD(l2, p2); l3 = DADD(l3, p3);
+                } else {
+                    if (!merged) { sum = DADD(DADD(DADD(l0, l1), l2), l3); merged = true; }
+                    const uint32_t k = qi * 4;
+                    if (k < len) sum = DADD(sum, p0);
+                    if (k + 1 < len) sum = DADD(sum, p1);
+                    if (k + 2 < len) sum = DADD(sum, p2);
+                    if (k + 3 < len) sum = DADD(sum, p3);
+                }
+            }
+            if (!merged) sum = DADD(DADD(DADD(l0, l1), l2), l3);
+        }
+    }
+    return sum;
+}
+
+// Epilogue of a live row.  e_t / e_d / e_x were fetched before the row walk; dself = the gathered
+// vector's own entry (PUSH only).
+template <int EPI>
+__device__ __forceinline__ void sl_row_epilogue(const sl_row_args &a, uint64_t i, double sum, double e_t, double e_d,
+                                                double e_x, double dself, double &part0, double &part1)
+{
+    if constexpr (EPI == SL_EPI_SPMV) {
+        a.out[i] = sum;
+    } else if constexpr (EPI == SL_EPI_NEUMANN) {
+        // neumann.rs:289-296: tmp *= dinv ; term -= tmp ; :264-266: solution += term
+        const double tmp = DMUL(sum, e_d);
+        const double tn = DSUB(e_t, tmp);
+        a.out[i] = tn;
+        a.x[i] = DADD(e_x, tn);
+        part0 = DADD(part0, DMUL(tn, tn));
+    } else if constexpr (EPI == SL_EPI_RESIDUAL) {
+        // neumann.rs:303-309: residual = A x - rhs
+        const double rr = DSUB(sum, e_t);
+        if (a.out) a.out[i] = rr;
+        part0 = DADD(part0, DMUL(rr, rr));
+    } else { // SL_EPI_PUSH (dense round of the thresholded push):
+        // x_i += delta_i (the frontier being consumed); r -= A delta; next frontier value
+        // delta'_i = r_i * dinv_i where |.| >= theta, else 0.
+        if (dself != 0.0) a.x[i] = DADD(e_x, dself);
+        const double rn = DSUB(e_t, sum);
+        a.r[i] = rn;
+        const double p = DMUL(rn, e_d);
+        const bool f = fabs(p) >= a.theta;
+        a.out[i] = f ? p : 0.0;
+        part0 = DADD(part0, DMUL(rn, rn));
+        part1 += f ? 1.0 : 0.0;
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void sl_block_partials(const sl_row_args &a, double *red, uint32_t lane, uint32_t wave, uint32_t lb,
+                                                  uint32_t nparts, double part0, double part1)
+{
+    if constexpr (EPI != SL_EPI_SPMV) {
+        part0 = wave_sum(part0);
+        if constexpr (EPI == SL_EPI_PUSH) part1 = wave_sum(part1);
+        if (lane == 0) { red[wave] = part0; red[SL_WAVES_PER_BLOCK + wave] = part1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double p0 = red[0], p1 = red[SL_WAVES_PER_BLOCK];
+#pragma unroll
+            for (int w = 1; w < SL_WAVES_PER_BLOCK; ++w) { p0 += red[w]; p1 += red[SL_WAVES_PER_BLOCK + w]; }
+            a.partials[lb] = p0;
+            if constexpr (EPI == SL_EPI_PUSH) a.partials[(uint64_t)nparts + lb] = p1;
+        }
+    }
+}
+
+// ---- general kernel: gathers served by L1/L2/Infinity Cache/HBM --------------------------------
+// One wave = one 64-row slice; lane = row.
 template <int ORDER, int EPI, int UW>
 __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32_t nb8)
 {
@@ -44,138 +185,69 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32
     const bool live_slice = s < a.n_slices;
     const bool live = live_slice && i < a.n_rows;
     const double *__restrict__ g = a.gather;
-    const u32x4 *__restrict__ cq = reinterpret_cast<const u32x4 *>(a.cols);
-    const f64x2 *__restrict__ vq = reinterpret_cast<const f64x2 *>(a.vals);
 
     // epilogue operands are fetched up front so their latency hides under the row walk
-    double e_t = 0.0, e_d = 0.0, e_x = 0.0;
+    double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
     if (live) {
         if constexpr (EPI == SL_EPI_NEUMANN) { e_t = g[a.row_offset + i]; e_d = a.dinv[i]; e_x = a.x[i]; }
         else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
-        else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; }
+        else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = g[a.row_offset + i]; }
     }
-
     double sum = 0.0;
-    if (live_slice) {
-        if constexpr (UW > 0) {
-            constexpr int NQ = UW / 4;
-            const uint64_t qb = s * NQ;
-            u32x4 c[NQ];
-            f64x2 va[NQ], vb[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                c[q] = __builtin_nontemporal_load(&cq[(qb + q) * 64 + lane]);
-                va[q] = __builtin_nontemporal_load(&vq[((qb + q) * 2) * 64 + lane]);
-                vb[q] = __builtin_nontemporal_load(&vq[((qb + q) * 2 + 1) * 64 + lane]);
-            }
-            double t[UW];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                t[4 * q + 0] = g[c[q].x];
-                t[4 * q + 1] = g[c[q].y];
-                t[4 * q + 2] = g[c[q].z];
-                t[4 * q + 3] = g[c[q].w];
-            }
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                sum = DADD(sum, DMUL(va[q].x, t[4 * q + 0]));
-                sum = DADD(sum, DMUL(va[q].y, t[4 * q + 1]));
-                sum = DADD(sum, DMUL(vb[q].x, t[4 * q + 2]));
-                sum = DADD(sum, DMUL(vb[q].y, t[4 * q + 3]));
-            }
-        } else {
-            const uint32_t q0 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s]);
-            const uint32_t q1 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s + 1]);
-            const uint32_t len = a.row_len[i];
-            if constexpr (ORDER == 0) {
-                for (uint32_t q = q0; q < q1; ++q) {
-                    const u32x4 c = __builtin_nontemporal_load(&cq[(uint64_t)q * 64 + lane]);
-                    const f64x2 va = __builtin_nontemporal_load(&vq[((uint64_t)q * 2) * 64 + lane]);
-                    const f64x2 vb = __builtin_nontemporal_load(&vq[((uint64_t)q * 2 + 1) * 64 + lane]);
-                    const double t0 = g[c.x], t1 = g[c.y], t2 = g[c.z], t3 = g[c.w];
-                    const uint32_t k = (q - q0) * 4;
-                    const double s0 = DADD(sum, DMUL(va.x, t0));
-                    sum = (k < len) ? s0 : sum;
-                    const double s1 = DADD(sum, DMUL(va.y, t1));
-                    sum = (k + 1 < len) ? s1 : sum;
-                    const double s2 = DADD(sum, DMUL(vb.x, t2));
-                    sum = (k + 2 < len) ? s2 : sum;
-                    const double s3 = DADD(sum, DMUL(vb.y, t3));
-                    sum = (k + 3 < len) ? s3 : sum;
-                }
-            } else {
-                // simd_ops.rs:41-77: rows with >= 8 entries: four lane sums over the full
-                // chunks of 4, then ((l0+l1)+l2)+l3, then the tail sequentially; shorter
-                // rows: sequential from 0.0 (chunks_eff = 0, the horizontal sum of zeros is 0.0).
-                const uint32_t chunks = (len >= 8u) ? (len >> 2) : 0u;
-                double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
-                bool merged = false;
-                for (uint32_t q = q0; q < q1; ++q) {
-                    const u32x4 c = __builtin_nontemporal_load(&cq[(uint64_t)q * 64 + lane]);
-                    const f64x2 va = __builtin_nontemporal_load(&vq[((uint64_t)q * 2) * 64 + lane]);
-                    const f64x2 vb = __builtin_nontemporal_load(&vq[((uint64_t)q * 2 + 1) * 64 + lane]);
-                    const double p0 = DMUL(va.x, g[c.x]), p1 = DMUL(va.y, g[c.y]);
-                    const double p2 = DMUL(vb.x, g[c.z]), p3 = DMUL(vb.y, g[c.w]);
-                    const uint32_t qi = q - q0;
-                    if (qi < chunks) {
-                        l0 = DADD(l0, p0); l1 = DADD(l1, p1); l2 = DADD(l2, p2); l3 = DADD(l3, p3);
-                    } else {
-                        if (!merged) { sum = DADD(DADD(DADD(l0, l1), l2), l3); merged = true; }
-                        const uint32_t k = qi * 4;
-                        if (k < len) sum = DADD(sum, p0);
-                        if (k + 1 < len) sum = DADD(sum, p1);
-                        if (k + 2 < len) sum = DADD(sum, p2);
-                        if (k + 3 < len) sum = DADD(sum, p3);
-                    }
-                }
-                if (!merged) sum = DADD(DADD(DADD(l0, l1), l2), l3);
-            }
-        }
-    }
-
+    if (live_slice) sum = sl_row_walk<ORDER, UW>(a, s, lane, i, [g](uint32_t c) { return g[c]; });
     double part0 = 0.0, part1 = 0.0;
-    if (live) {
-        if constexpr (EPI == SL_EPI_SPMV) {
-            a.out[i] = sum;
-        } else if constexpr (EPI == SL_EPI_NEUMANN) {
-            // neumann.rs:289-296: tmp *= dinv ; term -= tmp ; :264-266: solution += term
-            const double tmp = DMUL(sum, e_d);
-            const double tn = DSUB(e_t, tmp);
-            a.out[i] = tn;
-            a.x[i] = DADD(e_x, tn);
-            part0 = DMUL(tn, tn);
-        } else if constexpr (EPI == SL_EPI_RESIDUAL) {
-            // neumann.rs:303-309: residual = A x - rhs
-            const double rr = DSUB(sum, e_t);
-            if (a.out) a.out[i] = rr;
-            part0 = DMUL(rr, rr);
-        } else { // SL_EPI_PUSH (dense round of the thresholded push):
-            // x_i += delta_i (the frontier being consumed); r -= A delta; next frontier value
-            // delta'_i = r_i * dinv_i where |.| >= theta, else 0.
-            const double dself = g[a.row_offset + i];
-            if (dself != 0.0) a.x[i] = DADD(e_x, dself);
-            const double rn = DSUB(e_t, sum);
-            a.r[i] = rn;
-            const double p = DMUL(rn, e_d);
-            const bool f = fabs(p) >= a.theta;
-            a.out[i] = f ? p : 0.0;
-            part0 = DMUL(rn, rn);
-            part1 = f ? 1.0 : 0.0;
-        }
-    }
-    if constexpr (EPI != SL_EPI_SPMV) {
-        part0 = wave_sum(part0);
-        if constexpr (EPI == SL_EPI_PUSH) part1 = wave_sum(part1);
-        if (lane == 0) { red[wave] = part0; red[SL_WAVES_PER_BLOCK + wave] = part1; }
+    if (live) sl_row_epilogue<EPI>(a, i, sum, e_t, e_d, e_x, dself, part0, part1);
+    sl_block_partials<EPI>(a, red, lane, wave, lb, nb8 * 8, part0, part1);
+}
+
+// ---- band kernel: gathers served by an LDS-staged window of the gathered vector -----------------
+// For matrices whose entries all satisfy |col - row| <= w (measured at create time).  A block owns
+// R = 4 * spw * 64 consecutive rows; every entry those rows can touch lies in the window
+// [r0 - w, r0 + R + w) of the gathered vector, which is staged ONCE into LDS with coalesced 16-B
+// loads.  The 16 irregular gathers per row then become ds_read_b64 (a few LDS cycles per wave)
+// instead of 64 serialized L1 tag lookups each, and the kernel is a pure HBM stream.
+template <int ORDER, int EPI, int UW>
+__global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32_t nb8, uint32_t spw, uint32_t w)
+{
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    __shared__ double red[2 * SL_WAVES_PER_BLOCK];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
+    const uint64_t R = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE;
+    const uint64_t r0 = (uint64_t)lb * R;                       // first local row of the block
+    double part0 = 0.0, part1 = 0.0;
+    if (r0 < a.n_rows) {                                        // block-uniform
+        const uint64_t g0 = a.row_offset + r0;                  // global index of that row
+        const uint64_t win_lo = (g0 > w ? g0 - w : 0) & ~1ull;  // even => 16-B aligned staging loads
+        uint64_t win_hi = g0 + R + w;
+        if (win_hi > a.n_cols) win_hi = a.n_cols;
+        const uint32_t len = (uint32_t)(win_hi - win_lo);
+        const double *__restrict__ src = a.gather + win_lo;
+        const f64x2 *__restrict__ src2 = reinterpret_cast<const f64x2 *>(src);
+        f64x2 *win2 = reinterpret_cast<f64x2 *>(win);
+        const uint32_t pairs = len >> 1;
+        for (uint32_t p = threadIdx.x; p < pairs; p += SL_BLOCK) win2[p] = src2[p];
+        if ((len & 1u) && threadIdx.x == 0) win[len - 1] = src[len - 1];
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double p0 = red[0], p1 = red[SL_WAVES_PER_BLOCK];
-#pragma unroll
-            for (int w = 1; w < SL_WAVES_PER_BLOCK; ++w) { p0 += red[w]; p1 += red[SL_WAVES_PER_BLOCK + w]; }
-            a.partials[lb] = p0;
-            if constexpr (EPI == SL_EPI_PUSH) a.partials[(uint64_t)nb8 * 8 + lb] = p1;
+        const double *lw = win;
+        const uint32_t base = (uint32_t)win_lo;
+        for (uint32_t j = 0; j < spw; ++j) {
+            const uint64_t s = ((uint64_t)lb * spw + j) * SL_WAVES_PER_BLOCK + wave;   // waves interleave over slices
+            if (s >= a.n_slices) break;
+            const uint64_t i = s * SL_SLICE + lane;
+            const bool live = i < a.n_rows;
+            double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
+            if (live) {
+                if constexpr (EPI == SL_EPI_NEUMANN) { e_t = lw[(uint32_t)(a.row_offset + i) - base]; e_d = a.dinv[i]; e_x = a.x[i]; }
+                else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
+                else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = lw[(uint32_t)(a.row_offset + i) - base]; }
+            }
+            const double sum = sl_row_walk<ORDER, UW>(a, s, lane, i, [lw, base](uint32_t c) { return lw[c - base]; });
+            if (live) sl_row_epilogue<EPI>(a, i, sum, e_t, e_d, e_x, dself, part0, part1);
         }
     }
+    sl_block_partials<EPI>(a, red, lane, wave, lb, nb8 * 8, part0, part1);
 }
 
 // fixed-order final reduction of per-block partials: thread j sums partials j, j+1024, ...
@@ -208,16 +280,58 @@ uint32_t sl_row_grid(uint64_t n_slices)
     return (uint32_t)(nb8 * 8);
 }
 
-template <int ORDER, int EPI>
-static void launch_by_width(const sl_row_args &a, uint32_t grid, hipStream_t s)
+// band-kernel geometry: slices per wave and dynamic LDS bytes for half bandwidth w; 0 = not eligible
+#define SL_BAND_MAX_LDS (80u * 1024u)      // two blocks per CU (160 KiB LDS)
+static uint32_t band_spw(const sl_row_args &a, uint32_t *lds_bytes)
 {
-    const uint32_t nb8 = grid / 8;
-    if (ORDER == 0 && a.uniform_width == 16)
-        hipLaunchKernelGGL((sl_rows_kernel<0, EPI, 16>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
-    else if (ORDER == 0 && a.uniform_width == 8)
-        hipLaunchKernelGGL((sl_rows_kernel<0, EPI, 8>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
-    else
-        hipLaunchKernelGGL((sl_rows_kernel<ORDER, EPI, 0>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
+    static int disabled = -1, forced_spw = -1;
+    if (disabled < 0) {
+        const char *e = getenv("SL_BAND_DISABLE");
+        disabled = (e && e[0] == '1') ? 1 : 0;
+        const char *f = getenv("SL_BAND_SPW");
+        forced_spw = f ? atoi(f) : 0;
+    }
+    if (disabled || a.bandwidth == ~0ull || a.n_cols > 0xffffffffull) return 0;
+    uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : 4u;
+    const uint64_t entries = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE + 2 * a.bandwidth + 2;
+    if (entries * 8 > SL_BAND_MAX_LDS) return 0;
+    *lds_bytes = (uint32_t)(entries * 8);
+    return spw;
+}
+
+template <int ORDER, int EPI>
+static sl_status launch_rows_t(const sl_row_args &a, hipStream_t s, uint32_t *nparts)
+{
+    uint32_t lds = 0;
+    const uint32_t spw = band_spw(a, &lds);
+    if (spw) {
+        const uint64_t nb = (a.n_slices + (uint64_t)SL_WAVES_PER_BLOCK * spw - 1) / ((uint64_t)SL_WAVES_PER_BLOCK * spw);
+        const uint32_t nb8 = (uint32_t)((nb + 7) / 8);
+        const uint32_t grid = nb8 * 8, w = (uint32_t)a.bandwidth;
+        *nparts = grid;
+#define SL_BAND_LAUNCH(UWV)                                                                                          \
+    do {                                                                                                             \
+        auto kfn = sl_band_kernel<(UWV) ? 0 : ORDER, EPI, UWV>;                                                      \
+        static bool attr_done = false;                                                                               \
+        if (!attr_done) { SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SL_BAND_MAX_LDS)); attr_done = true; } \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(SL_BLOCK), lds, s, a, nb8, spw, w);                                  \
+    } while (0)
+        if (ORDER == 0 && a.uniform_width == 16) SL_BAND_LAUNCH(16);
+        else if (ORDER == 0 && a.uniform_width == 8) SL_BAND_LAUNCH(8);
+        else SL_BAND_LAUNCH(0);
+#undef SL_BAND_LAUNCH
+    } else {
+        const uint32_t grid = sl_row_grid(a.n_slices), nb8 = grid / 8;
+        *nparts = grid;
+        if (ORDER == 0 && a.uniform_width == 16)
+            hipLaunchKernelGGL((sl_rows_kernel<0, EPI, 16>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
+        else if (ORDER == 0 && a.uniform_width == 8)
+            hipLaunchKernelGGL((sl_rows_kernel<0, EPI, 8>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
+        else
+            hipLaunchKernelGGL((sl_rows_kernel<ORDER, EPI, 0>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
+    }
+    SL_HIP(hipGetLastError());
+    return SL_OK;
 }
 
 sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s)
@@ -226,25 +340,18 @@ sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, 
         if (epi != SL_EPI_SPMV && a.result) SL_HIP(hipMemsetAsync(a.result, 0, 2 * sizeof(double), s));
         return SL_OK;
     }
-    const uint32_t grid = sl_row_grid(a.n_slices);
     const bool simd4 = (order == SL_ORDER_SIMD4);
+    uint32_t nparts = 0;
+    sl_status st = SL_OK;
     switch (epi) {
-    case SL_EPI_SPMV:
-        simd4 ? launch_by_width<1, SL_EPI_SPMV>(a, grid, s) : launch_by_width<0, SL_EPI_SPMV>(a, grid, s);
-        break;
-    case SL_EPI_NEUMANN:
-        simd4 ? launch_by_width<1, SL_EPI_NEUMANN>(a, grid, s) : launch_by_width<0, SL_EPI_NEUMANN>(a, grid, s);
-        break;
-    case SL_EPI_RESIDUAL:
-        simd4 ? launch_by_width<1, SL_EPI_RESIDUAL>(a, grid, s) : launch_by_width<0, SL_EPI_RESIDUAL>(a, grid, s);
-        break;
-    case SL_EPI_PUSH:
-        simd4 ? launch_by_width<1, SL_EPI_PUSH>(a, grid, s) : launch_by_width<0, SL_EPI_PUSH>(a, grid, s);
-        break;
+    case SL_EPI_SPMV: st = simd4 ? launch_rows_t<1, SL_EPI_SPMV>(a, s, &nparts) : launch_rows_t<0, SL_EPI_SPMV>(a, s, &nparts); break;
+    case SL_EPI_NEUMANN: st = simd4 ? launch_rows_t<1, SL_EPI_NEUMANN>(a, s, &nparts) : launch_rows_t<0, SL_EPI_NEUMANN>(a, s, &nparts); break;
+    case SL_EPI_RESIDUAL: st = simd4 ? launch_rows_t<1, SL_EPI_RESIDUAL>(a, s, &nparts) : launch_rows_t<0, SL_EPI_RESIDUAL>(a, s, &nparts); break;
+    case SL_EPI_PUSH: st = simd4 ? launch_rows_t<1, SL_EPI_PUSH>(a, s, &nparts) : launch_rows_t<0, SL_EPI_PUSH>(a, s, &nparts); break;
     }
-    SL_HIP(hipGetLastError());
+    if (st != SL_OK) return st;
     if (epi != SL_EPI_SPMV && a.result) {
-        hipLaunchKernelGGL(sl_final_reduce_kernel, dim3(1), dim3(1024), 0, s, a.partials, grid, a.result,
+        hipLaunchKernelGGL(sl_final_reduce_kernel, dim3(1), dim3(1024), 0, s, a.partials, nparts, a.result,
                            epi == SL_EPI_PUSH ? 2 : 1);
         SL_HIP(hipGetLastError());
     }

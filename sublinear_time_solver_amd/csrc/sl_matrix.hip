@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64
 __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, uint64_t n_cols, uint64_t n_slices,
                                                              uint64_t row_offset, const uint32_t *row_ptr,
                                                              const uint32_t *col_idx, const double *values,
-                                                             const uint32_t *slice_ptr, uint32_t *cols, double *vals)
+                                                             const uint32_t *slice_ptr, uint32_t *cols, double *vals,
+                                                             unsigned long long *band)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -57,13 +58,15 @@ __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, ui
     const uint64_t i = s * 64 + lane;
     const uint32_t q0 = slice_ptr[s], q1 = slice_ptr[s + 1];
     uint32_t start = 0, len = 0;
-    uint32_t padcol = 0;
+    // padding column: the row's own index; dead lanes of the last slice use the slice's first row
+    // (always a live row) so that every padded gather stays inside the band window of its block
+    uint64_t gi = row_offset + (i < n_rows ? i : s * 64);
+    uint32_t padcol = gi < n_cols ? (uint32_t)gi : 0u;
     if (i < n_rows) {
         start = row_ptr[i];
         len = row_ptr[i + 1] - start;
-        const uint64_t gi = row_offset + i;
-        padcol = gi < n_cols ? (uint32_t)gi : 0u;
     }
+    unsigned long long bw = 0;
     for (uint32_t q = q0; q < q1; ++q) {
 #pragma unroll
         for (uint32_t e = 0; e < 4; ++e) {
@@ -71,10 +74,12 @@ __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, ui
             const bool in = k < len;
             const uint32_t c = in ? col_idx[start + k] : padcol;
             const double v = in ? values[start + k] : 0.0;
+            if (in) { const unsigned long long d = c > gi ? c - gi : gi - c; bw = d > bw ? d : bw; }
             cols[((uint64_t)q * 64 + lane) * 4 + e] = c;
             vals[(((uint64_t)q * 2 + (e >> 1)) * 64 + lane) * 2 + (e & 1u)] = v;
         }
     }
+    if (bw) atomicMax(band, bw);
 }
 
 // a6 + a7: one pass over the slice layout.  Per row, in stored order:
@@ -206,10 +211,18 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     SL_HIP(hipMemcpyAsync(m->d_slice_ptr, slice_ptr.data(), (m->n_slices + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     SL_HIP(hipMalloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
     SL_HIP(hipMalloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
+    unsigned long long *d_band = nullptr;
+    SL_HIP(hipMalloc(&d_band, sizeof(unsigned long long)));
+    SL_HIP(hipMemsetAsync(d_band, 0, sizeof(unsigned long long), st));
     if (m->n_slices)
         hipLaunchKernelGGL(sl_fill_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_cols,
-                           m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_cols, m->d_vals);
+                           m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_cols, m->d_vals, d_band);
     SL_HIP(hipGetLastError());
+    unsigned long long h_band = 0;
+    SL_HIP(hipMemcpyAsync(&h_band, d_band, sizeof(h_band), hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    hipFree(d_band);
+    m->bandwidth = h_band;
     m->device_bytes = (m->n_slices + 1 + padded_rows) * sizeof(uint32_t) + m->padded_nnz * 12;
 
     // 3. transpose

@@ -7,7 +7,7 @@
 // counter-based (splitmix64 of (seed, row, slot)) so that any row range can be produced
 // independently on any rank, duplicate-free and self-excluding so nnz/row is exact:
 //   row i: diagonal d_i = 10 + 0.01 (i mod 1000); k-1 off-diagonals, one per stratum of the
-//   column window [lo, lo+span) (whole matrix when w = 0, else the band i-w .. i+w clamped),
+//   column window [lo, lo+span) (whole matrix when w = 0, else the band i-w .. i+w clipped at the edges),
 //   value U(-1,1) * d_i / (2 (k-1))  =>  sum |offdiag| <= d_i / 2  (strictly row dominant,
 //   asymmetric);  columns ascending;  b_i = 1 + 0.001 (i mod 1000).
 #include "sl_internal.hpp"
@@ -32,10 +32,10 @@ __global__ __launch_bounds__(256) void sl_synth_sdd_kernel(uint64_t n, uint32_t 
     const uint64_t i = row_lo + li;
     const uint32_t m = k - 1;
     uint64_t lo = 0, span = n;
-    if (w != 0 && 2 * w + 1 < n) {
-        span = 2 * w + 1;
+    if (w != 0 && 2 * w + 1 < n) {            // band: columns in [i-w, i+w], clipped at the matrix edge
         lo = i > w ? i - w : 0;
-        if (lo > n - span) lo = n - span;
+        const uint64_t hi = i + w + 1 < n ? i + w + 1 : n;
+        span = hi - lo;
     }
     const uint64_t sw = span / m;
     const double d = __dadd_rn(10.0, __dmul_rn(0.01, (double)(i % 1000)));
@@ -68,7 +68,7 @@ extern "C" sl_status sl_synth_sdd_device(uint64_t n, uint32_t k, uint64_t seed, 
     if (k < 2 || k > 64) return sl_fail(SL_INVALID_INPUT, "k must be in [2, 64]");
     if (row_hi > n || row_lo > row_hi) return sl_fail(SL_INVALID_INPUT, "bad row range");
     uint64_t span = n;
-    if (half_bandwidth != 0 && 2 * half_bandwidth + 1 < n) span = 2 * half_bandwidth + 1;
+    if (half_bandwidth != 0 && 2 * half_bandwidth + 1 < n) span = half_bandwidth + 1;   // narrowest (edge) window
     if (span / (k - 1) < 2) return sl_fail(SL_INVALID_INPUT, "column window too narrow for k-1 distinct off-diagonals");
     if ((row_hi - row_lo) * (uint64_t)k > 0xffffffffull) return sl_fail(SL_INVALID_INPUT, "slice nnz exceeds u32");
     const uint64_t rows = row_hi - row_lo;

@@ -70,8 +70,8 @@ class HaloExchange:
     name = "halo"
 
     def __init__(self, part: RowPartition, half_bandwidth: int, group=None):
-        if part.world > 1 and part.rows_per_rank < 2 * half_bandwidth + 1:
-            raise ValueError("halo exchange needs rows_per_rank >= 2 w + 1")
+        if part.world > 1 and part.rows_per_rank < half_bandwidth:
+            raise ValueError("halo exchange needs rows_per_rank >= w")
         self.part, self.w, self.group = part, int(half_bandwidth), group
 
     def __call__(self, t_full: torch.Tensor) -> None:

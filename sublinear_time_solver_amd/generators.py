@@ -36,29 +36,29 @@ def sdd_rows(n: int, k: int, seed: int, half_bandwidth: int = 0, row_lo: int = 0
     if not (2 <= k <= 64):
         raise ValueError("k must be in [2, 64]")
     m = k - 1
-    span = n
-    if half_bandwidth and 2 * half_bandwidth + 1 < n:
-        span = 2 * half_bandwidth + 1
-    sw = span // m
-    if sw < 2:
+    banded = bool(half_bandwidth) and 2 * half_bandwidth + 1 < n
+    if ((half_bandwidth + 1) if banded else n) // m < 2:
         raise ValueError("column window too narrow for k-1 distinct off-diagonals")
     with np.errstate(over="ignore"):
         i = np.arange(row_lo, row_hi, dtype=np.uint64)
         rows = i.size
-        if span == n:
+        if not banded:
             lo = np.zeros(rows, dtype=np.uint64)
-        else:
+            sw = np.full(rows, n // m, dtype=np.uint64)
+        else:                                   # band: columns in [i-w, i+w], clipped at the matrix edge
             w = np.uint64(half_bandwidth)
             lo = np.where(i > w, i - w, np.uint64(0))
-            lo = np.minimum(lo, np.uint64(n - span))
+            hi = np.minimum(i + w + np.uint64(1), np.uint64(n))
+            sw = (hi - lo) // np.uint64(m)
+        sw = sw[:, None]
         j = np.arange(m, dtype=np.uint64)
         key = np.uint64(seed) * _G + (i[:, None] * np.uint64(64) + j[None, :] + np.uint64(1)) * _K
         h1 = _mix64(key)
         h2 = _mix64(h1 + _G)
-        off = h1 % np.uint64(sw)
-        c = lo[:, None] + j[None, :] * np.uint64(sw) + off
+        off = h1 % sw
+        c = lo[:, None] + j[None, :] * sw + off
         hit = c == i[:, None]
-        c = np.where(hit, np.where(off + np.uint64(1) < np.uint64(sw), c + np.uint64(1), c - np.uint64(1)), c)
+        c = np.where(hit, np.where(off + np.uint64(1) < sw, c + np.uint64(1), c - np.uint64(1)), c)
     d = 10.0 + 0.01 * (i % np.uint64(1000)).astype(np.float64)
     scale = d / float(2 * m)
     u = (h2 >> np.uint64(11)).astype(np.float64) * 1.1102230246251565e-16

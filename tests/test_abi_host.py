@@ -71,7 +71,7 @@ def test_sdd_generator_properties():
         off = np.abs(np.where(isdiag, 0.0, V)).sum(axis=1)
         assert (off <= d / 2 + 1e-12).all(), "strictly row dominant with margin 2"
         if w:
-            assert (np.abs(C - rows) <= 2 * w + 1).all()
+            assert (np.abs(C - rows) <= w).all()
         assert not np.allclose(V[1, 1], V[1, 2])
     # any row range reproduces the same rows
     a = G.sdd_rows(n, k, 3, 0, 100, 200)

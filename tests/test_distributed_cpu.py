@@ -88,4 +88,4 @@ def test_row_partition_bounds():
     assert [(q.lo, q.hi) for q in p] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert p[0].n_padded == 12
     with pytest.raises(ValueError):
-        D.HaloExchange(D.RowPartition(100, 4, 1), 20)
+        D.HaloExchange(D.RowPartition(100, 4, 1), 30)

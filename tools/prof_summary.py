@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (rocpd sqlite) outputs of tools/profile.sh into profiles/<tag>_*.txt/json.
+
+usage: python tools/prof_summary.py gpurun_out/prof_<tag> <tag> [n k bandwidth]
+  stats/stats_results.db      -> profiles/<tag>_kernel_stats.txt   (top_kernels view = `--stats`)
+  pmc_fetch/, pmc_write/      -> profiles/<tag>_pmc.txt and profiles/pmc_traffic.json
+FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE tallies the 128-B requests
+of a wide coalesced read stream at 64 B, i.e. exactly half the bytes (MI355X_MICROARCH.md §HBM), so the
+corrected HBM read bytes are 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken as reported.
+"""
+import json
+import sqlite3
+import sys
+from pathlib import Path
+
+
+def q(db, sql):
+    return sqlite3.connect(db).execute(sql).fetchall()
+
+
+def main():
+    src, tag = Path(sys.argv[1]), sys.argv[2]
+    cfg = [int(v) for v in sys.argv[3:6]] if len(sys.argv) >= 6 else None
+    out = Path(__file__).resolve().parent.parent / "profiles"
+    out.mkdir(exist_ok=True)
+    lines = [f"# rocprofv3 --kernel-trace --stats : {src}/stats  (top_kernels view)", ""]
+    rows = q(src / "stats" / "stats_results.db", "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc")
+    lines.append(f"{'kernel':<92} {'calls':>6} {'total_ms':>10} {'avg_us':>10} {'pct':>7}")
+    for name, calls, tot, avg, pct in rows:          # the view reports microseconds
+        lines.append(f"{name[:92]:<92} {calls:>6} {tot / 1e3:>10.3f} {avg:>10.2f} {pct:>7.2f}")
+    # steady-state average of the dominant kernel: drop the first launches (cold caches / clocks)
+    k = q(src / "stats" / "stats_results.db",
+          "select name, duration from kernels where name like '%sl_band_kernel%' or name like '%sl_rows_kernel%' order by start")
+    by = {}
+    for name, d in k:
+        by.setdefault(name, []).append(d)
+    lines.append("")
+    for name, ds in by.items():
+        tail = ds[len(ds) // 4:]
+        lines.append(f"steady-state {name[:80]}: n={len(tail)} avg={sum(tail) / len(tail) / 1e3:.2f} us min={min(tail) / 1e3:.2f} us max={max(tail) / 1e3:.2f} us")
+    (out / f"{tag}_kernel_stats.txt").write_text("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+    pm = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) : {src}", ""]
+    rec = {}
+    for sub, db, cname in (("pmc_fetch", "fetch_results.db", "FETCH_SIZE"), ("pmc_write", "write_results.db", "WRITE_SIZE")):
+        p = src / sub / db
+        if not p.exists():
+            continue
+        cols = [r[1] for r in q(p, "pragma table_info('counters_collection')")]
+        pm.append(f"{cname}: columns of counters_collection = {cols}")
+        namecol = "kernel_name" if "kernel_name" in cols else "name"
+        rows = q(p, f"select {namecol}, counter_name, avg(value), count(*) from counters_collection "
+                    f"where counter_name='{cname}' group by {namecol} order by avg(value) desc limit 6")
+        for kn, cn, avg, n in rows:
+            pm.append(f"  {kn[:90]:<90} {cn} avg={avg:.1f} KiB over {n} dispatches")
+            if ("sl_band_kernel" in kn or "sl_rows_kernel" in kn) and cn not in rec:
+                rec[cn] = avg
+    if "FETCH_SIZE" in rec or "WRITE_SIZE" in rec:
+        rd = 2.0 * rec.get("FETCH_SIZE", 0.0) * 1024.0
+        wr = rec.get("WRITE_SIZE", 0.0) * 1024.0
+        pm += ["", f"dominant kernel per launch: FETCH_SIZE {rec.get('FETCH_SIZE', 0):.0f} KiB -> corrected read bytes {rd:.4e} (x2, gfx950)",
+               f"                            WRITE_SIZE {rec.get('WRITE_SIZE', 0):.0f} KiB -> write bytes {wr:.4e}",
+               f"                            HBM traffic per launch = {rd + wr:.4e} B"]
+        if cfg:
+            n, kk, w = cfg
+            alg = 12 * n * kk + 4 * (n + 1) + 40 * n
+            pm.append(f"                            algorithmic bytes per launch = {alg:.4e} B  (traffic / algorithmic = {(rd + wr) / alg:.3f})")
+            (out / "pmc_traffic.json").write_text(json.dumps({"tag": tag, "n": n, "k": kk, "bandwidth": w, "fetch_size_kib": rec.get("FETCH_SIZE"),
+                                                              "write_size_kib": rec.get("WRITE_SIZE"), "hbm_bytes_per_launch": rd + wr,
+                                                              "algorithmic_bytes_per_launch": alg}) + "\n")
+    (out / f"{tag}_pmc.txt").write_text("\n".join(pm) + "\n")
+    print("\n".join(pm))
+
+
+if __name__ == "__main__":
+    main()
