@@ -1,0 +1,202 @@
+// sublinear_solver.hpp — header-only C++ host mirror of the reference crate's solver interface over
+// the C ABI (sublinear_hip.h).  The reference is compiled code (Rust) and no Rust toolchain exists in
+// the build image, so the host side above the ABI is C++ with the crate's names, argument meaning and
+// error behaviour (Result<T, SolverError> becomes a thrown SolverError carrying the variant).
+//
+//   reference                                         here
+//   SparseMatrix::from_triplets  matrix/mod.rs:160    sublinear::SparseMatrix::from_triplets
+//   Matrix::{rows,cols,nnz,is_diagonally_dominant,
+//            multiply_vector}    matrix/mod.rs:25-104 same names
+//   SolverOptions (+presets)     solver/mod.rs:20-116 sublinear::SolverOptions
+//   SolverResult / SolverStats   solver/mod.rs:118-195, types.rs:88-109
+//   NeumannSolver::{new,default,high_precision,fast,solve}  solver/neumann.rs:24-92,469-555
+//   ForwardPushSolver::query_single_entry analogue    solver/forward_push.rs:224-231 -> estimate_entry
+//   SolverError variants         error.rs:16-140      sublinear::SolverError::kind
+#pragma once
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "sublinear_hip.h"
+
+namespace sublinear {
+
+using Precision = double;      // types.rs:19
+using IndexType = uint32_t;    // types.rs:22
+
+class SolverError : public std::runtime_error {
+public:
+    SolverError(sl_status k, const std::string &msg) : std::runtime_error(std::string(sl_status_string(k)) + ": " + msg), kind(k) {}
+    sl_status kind;
+    // error.rs:147-160: which failures a caller may retry with different settings
+    bool is_recoverable() const
+    {
+        return kind == SL_CONVERGENCE_FAILURE || kind == SL_NUMERICAL_INSTABILITY || kind == SL_NOT_DIAGONALLY_DOMINANT;
+    }
+};
+
+inline void check(sl_status s)
+{
+    if (s != SL_OK) throw SolverError(s, sl_last_error_message());
+}
+
+struct SolverOptions {                       // solver/mod.rs:20-62
+    Precision tolerance = 1e-6;
+    size_t max_iterations = 1000;
+    std::optional<std::vector<Precision>> initial_guess;
+    bool collect_stats = false;
+    bool compute_error_bounds = false;
+    static SolverOptions high_precision() { SolverOptions o; o.tolerance = 1e-12; o.max_iterations = 5000; o.collect_stats = true; o.compute_error_bounds = true; return o; }
+    static SolverOptions fast() { SolverOptions o; o.tolerance = 1e-3; o.max_iterations = 100; return o; }
+};
+
+struct SolverStats {                         // types.rs:88-109 (fields the path fills) + device additions
+    double total_time_ms = 0, device_time_ms = 0;
+    size_t matvec_count = 0;
+    uint64_t bytes_moved = 0;
+};
+
+struct SolverResult {                        // solver/mod.rs:118-195
+    std::vector<Precision> solution;
+    Precision residual_norm = 0;
+    size_t iterations = 0;
+    bool converged = false;
+    std::optional<Precision> error_bound;
+    std::optional<SolverStats> stats;
+};
+
+class SparseMatrix {
+public:
+    using Triplet = std::tuple<size_t, size_t, Precision>;
+    SparseMatrix(const SparseMatrix &) = delete;
+    SparseMatrix &operator=(const SparseMatrix &) = delete;
+    SparseMatrix(SparseMatrix &&o) noexcept : h_(o.h_), rows_(o.rows_), cols_(o.cols_) { o.h_ = nullptr; }
+    ~SparseMatrix() { if (h_) sl_matrix_destroy(h_); }
+
+    static SparseMatrix from_triplets(const std::vector<Triplet> &t, size_t rows, size_t cols, bool with_transpose = false)
+    {
+        std::vector<uint64_t> r(t.size()), c(t.size());
+        std::vector<double> v(t.size());
+        for (size_t k = 0; k < t.size(); ++k) { r[k] = std::get<0>(t[k]); c[k] = std::get<1>(t[k]); v[k] = std::get<2>(t[k]); }
+        sl_matrix *h = nullptr;
+        check(sl_matrix_create_from_triplets(t.size(), r.data(), c.data(), v.data(), rows, cols,
+                                             with_transpose ? SL_MATRIX_WITH_TRANSPOSE : SL_MATRIX_DEFAULT, &h));
+        return SparseMatrix(h, rows, cols);
+    }
+    // adopt CSRStorage arrays (sparse.rs:16-23)
+    static SparseMatrix from_csr(const std::vector<IndexType> &row_ptr, const std::vector<IndexType> &col_indices,
+                                 const std::vector<Precision> &values, size_t rows, size_t cols, bool with_transpose = false)
+    {
+        sl_matrix *h = nullptr;
+        check(sl_matrix_create_csr(rows, cols, values.size(), row_ptr.data(), col_indices.data(), values.data(), SL_MEM_HOST, 0,
+                                   with_transpose ? SL_MATRIX_WITH_TRANSPOSE : SL_MATRIX_DEFAULT, &h));
+        return SparseMatrix(h, rows, cols);
+    }
+    size_t rows() const { return rows_; }
+    size_t cols() const { return cols_; }
+    bool is_square() const { return rows_ == cols_; }
+    size_t nnz() const { sl_matrix_info i; check(sl_matrix_get_info(h_, &i)); return i.nnz; }
+    bool is_diagonally_dominant() const { int f = 0; check(sl_matrix_is_diagonally_dominant(h_, &f)); return f != 0; }
+    // Matrix::multiply_vector (matrix/mod.rs:415-439): DimensionMismatch on wrong lengths
+    void multiply_vector(const std::vector<Precision> &x, std::vector<Precision> &result, sl_order order = SL_ORDER_CSR_SEQUENTIAL) const
+    {
+        if (x.size() != cols_) throw SolverError(SL_DIMENSION_MISMATCH, "matrix_vector_multiply: x");
+        if (result.size() != rows_) throw SolverError(SL_DIMENSION_MISMATCH, "matrix_vector_multiply: result");
+        check(sl_spmv(h_, x.data(), result.data(), order, SL_MEM_HOST));
+    }
+    const sl_matrix *handle() const { return h_; }
+
+private:
+    SparseMatrix(sl_matrix *h, size_t r, size_t c) : h_(h), rows_(r), cols_(c) {}
+    sl_matrix *h_;
+    size_t rows_, cols_;
+};
+
+class NeumannSolver {                        // neumann.rs:24-92
+public:
+    NeumannSolver(size_t max_terms, Precision series_tolerance) : max_terms_(max_terms), series_tolerance_(series_tolerance) {}
+    NeumannSolver() : NeumannSolver(50, 1e-8) {}                                         // Default, :58-60
+    static NeumannSolver high_precision() { return NeumannSolver(100, 1e-12); }          // :63-65
+    static NeumannSolver fast() { return NeumannSolver(20, 1e-6); }                      // :68-70
+    NeumannSolver &with_order(sl_order o) { order_ = o; return *this; }
+    // reference-compat quirks; the defaults are the exact series
+    NeumannSolver &with_reference_quirks(bool on) { start_ = on ? SL_START_REFERENCE_DEFAULT : SL_START_ZERO; residual_ = on ? SL_RESIDUAL_REFERENCE_SCALED : SL_RESIDUAL_TRUE; return *this; }
+    const char *algorithm_name() const { return "neumann"; }
+
+    SolverResult solve(const SparseMatrix &matrix, const std::vector<Precision> &b, const SolverOptions &options = SolverOptions()) const
+    {
+        if (matrix.is_square() && b.size() != matrix.rows()) throw SolverError(SL_DIMENSION_MISMATCH, "neumann_initialization");   // :154-160
+        sl_neumann_options o;
+        sl_neumann_options_default(&o);
+        o.tolerance = options.tolerance; o.max_iterations = options.max_iterations;
+        o.max_terms = max_terms_; o.series_tolerance = series_tolerance_;
+        o.order = order_; o.start = start_; o.residual = residual_; o.mem = SL_MEM_HOST;
+        o.collect_stats = options.collect_stats; o.compute_error_bounds = options.compute_error_bounds;
+        const double *guess = nullptr;
+        if (options.initial_guess) {
+            if (options.initial_guess->size() != matrix.rows()) throw SolverError(SL_DIMENSION_MISMATCH, "initial_guess");        // :198-204
+            guess = options.initial_guess->data();
+            o.start = SL_START_INITIAL_GUESS;
+        }
+        SolverResult out;
+        out.solution.resize(matrix.rows());
+        sl_neumann_result r;
+        check(sl_neumann_solve(matrix.handle(), b.data(), guess, &o, out.solution.data(), nullptr, &r));
+        out.residual_norm = r.residual_norm; out.iterations = r.iterations; out.converged = r.converged != 0;
+        if (r.error_bound >= 0) out.error_bound = r.error_bound;
+        if (options.collect_stats) { SolverStats s; s.total_time_ms = r.total_time_ms; s.device_time_ms = r.device_time_ms; s.matvec_count = r.matvec_count; s.bytes_moved = r.bytes_moved; out.stats = s; }
+        return out;
+    }
+
+private:
+    size_t max_terms_;
+    Precision series_tolerance_;
+    sl_order order_ = SL_ORDER_CSR_SEQUENTIAL;
+    sl_start start_ = SL_START_ZERO;
+    sl_residual residual_ = SL_RESIDUAL_TRUE;
+};
+
+struct PushResult {
+    std::vector<Precision> solution, residual;
+    size_t rounds = 0, pushes = 0;
+    Precision residual_norm = 0;
+    bool converged = false;
+};
+
+// thresholded residual push (ForwardPushConfig.epsilon -> theta, max_pushes -> max_rounds; forward_push.rs:26-49)
+class PushSolver {
+public:
+    explicit PushSolver(Precision theta = 1e-6, size_t max_rounds = 1000000) : theta_(theta), max_rounds_(max_rounds) {}
+    PushResult solve(const SparseMatrix &matrix, const std::vector<Precision> &b) const
+    {
+        if (b.size() != matrix.rows()) throw SolverError(SL_DIMENSION_MISMATCH, "push");
+        sl_push_options o;
+        sl_push_options_default(&o);
+        o.theta = theta_; o.max_rounds = max_rounds_;
+        PushResult out;
+        out.solution.assign(matrix.rows(), 0.0);
+        out.residual.resize(matrix.rows());
+        sl_push_result r;
+        check(sl_push_solve(matrix.handle(), b.data(), &o, out.solution.data(), out.residual.data(), nullptr, 0, nullptr, &r));
+        out.rounds = r.rounds; out.pushes = r.pushes; out.residual_norm = r.residual_norm; out.converged = r.converged != 0;
+        return out;
+    }
+    // ForwardPushSolver::query_single_entry (forward_push.rs:224-231) / TS estimateEntry (solver.ts:550-659)
+    Precision query_single_entry(const SparseMatrix &matrix, const std::vector<Precision> &b, size_t row, Precision *error_l1 = nullptr) const
+    {
+        sl_estimate_result r;
+        check(sl_estimate_entry(matrix.handle(), b.data(), SL_MEM_HOST, row, theta_, max_rounds_, &r));
+        if (error_l1) *error_l1 = r.residual_l1;
+        return r.estimate;
+    }
+
+private:
+    Precision theta_;
+    size_t max_rounds_;
+};
+
+} // namespace sublinear

@@ -1,0 +1,46 @@
+// C++ host-mirror test: reads like the reference's own unit tests (neumann.rs:558-649, sparse.rs:905-963).
+// Built with g++ against libsublinear_hip.so and run by tests/test_gpu_parity.py::test_cpp_host_mirror.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "sublinear_solver.hpp"
+
+using namespace sublinear;
+
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); std::exit(1); } } while (0)
+
+int main()
+{
+    // sparse.rs:923-933
+    auto m = SparseMatrix::from_triplets({{0, 0, 2.0}, {0, 1, 1.0}, {1, 0, 1.0}, {1, 1, 3.0}}, 2, 2);
+    std::vector<double> y(2);
+    m.multiply_vector({1.0, 2.0}, y);
+    EXPECT(y[0] == 4.0 && y[1] == 7.0);
+    EXPECT(m.nnz() == 4 && m.is_diagonally_dominant());
+
+    // neumann.rs:572-590 (test_neumann_solver_simple): diagonally dominant 2x2
+    auto a = SparseMatrix::from_triplets({{0, 0, 4.0}, {0, 1, 1.0}, {1, 0, 1.0}, {1, 1, 3.0}}, 2, 2, true);
+    auto r = NeumannSolver(20, 1e-8).solve(a, {5.0, 4.0}, SolverOptions());
+    EXPECT(r.converged && r.iterations == 16);
+    EXPECT(std::fabs(r.solution[0] - 1.0) < 1e-7 && std::fabs(r.solution[1] - 1.0) < 1e-7);
+    auto q = NeumannSolver(20, 1e-8).with_reference_quirks(true).solve(a, {5.0, 4.0});
+    EXPECT(std::fabs(q.solution[0] - 2.25) < 1e-7);          // reference default start: x_true + D^-1 b
+
+    // error mapping: Result::Err(SolverError::...) -> thrown SolverError{kind}
+    auto nd = SparseMatrix::from_triplets({{0, 0, 1.0}, {0, 1, 5.0}, {1, 0, 2.0}, {1, 1, 1.0}}, 2, 2);
+    try { NeumannSolver().solve(nd, {1.0, 1.0}); EXPECT(false); } catch (const SolverError &e) { EXPECT(e.kind == SL_NOT_DIAGONALLY_DOMINANT && e.is_recoverable()); }
+    try { SparseMatrix::from_triplets({{2, 0, 1.0}}, 2, 2); EXPECT(false); } catch (const SolverError &e) { EXPECT(e.kind == SL_INDEX_OUT_OF_BOUNDS); }
+    try { NeumannSolver().solve(a, {1.0}); EXPECT(false); } catch (const SolverError &e) { EXPECT(e.kind == SL_DIMENSION_MISMATCH); }
+    SolverOptions tight; tight.tolerance = 1e-14; tight.max_iterations = 3;
+    try { NeumannSolver(50, 1e-16).solve(a, {5.0, 4.0}, tight); EXPECT(false); } catch (const SolverError &e) { EXPECT(e.kind == SL_CONVERGENCE_FAILURE); }
+
+    // push + single-entry query
+    auto p = PushSolver(1e-10).solve(a, {5.0, 4.0});
+    EXPECT(p.converged && std::fabs(p.solution[0] - 1.0) < 1e-8 && std::fabs(p.solution[1] - 1.0) < 1e-8);
+    double err = 0;
+    const double e1 = PushSolver(1e-12).query_single_entry(a, {5.0, 4.0}, 1, &err);
+    EXPECT(std::fabs(e1 - 1.0) < 1e-9);
+    std::printf("cpp host mirror ok\n");
+    return 0;
+}

@@ -434,3 +434,17 @@ def test_c3_full_size_properties(gpu):
     xs2 = torch.empty_like(xs)
     L.check(lib.sl_neumann_solve(m._h, b.data_ptr(), None, C.byref(o), xs2.data_ptr(), None, C.byref(res)))
     assert torch.equal(xs, xs2)
+
+
+def test_cpp_host_mirror(gpu, tmp_path):
+    """include/sublinear_solver.hpp (the C++ mirror of the crate's interface) over the C ABI, in its own process."""
+    import subprocess
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "host_mirror"
+    libdir = root / "sublinear_time_solver_amd"
+    r = subprocess.run(["g++", "-std=c++17", "-O2", f"-I{root / 'include'}", str(root / "tests" / "cpp" / "test_host_mirror.cpp"),
+                        "-o", str(exe), f"-L{libdir}", "-lsublinear_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "cpp host mirror ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
