@@ -8,6 +8,7 @@
  */
 #include "sl_oracle.h"
 #include <math.h>
+#define _GNU_SOURCE
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -150,22 +151,60 @@ static void *par_worker(void *p)
     }
     return 0;
 }
+/* persistent worker pool — rayon keeps its threads too (simd_ops.rs:227 par_chunks_mut); the pool is
+ * rebuilt only when the requested thread count changes.  The calling thread runs chunk 0. */
+static struct {
+    int n;                       /* workers besides the caller */
+    int quit;
+    pthread_barrier_t start, done;
+    pthread_t tid[256];
+    par_arg args[257];
+    int has_work[257];
+} g_pool;
+static void *pool_worker(void *p)
+{
+    const int id = (int)(intptr_t)p;
+    for (;;) {
+        pthread_barrier_wait(&g_pool.start);
+        if (g_pool.quit) break;
+        if (g_pool.has_work[id]) par_worker(&g_pool.args[id]);
+        pthread_barrier_wait(&g_pool.done);
+    }
+    return 0;
+}
+static void pool_resize(int workers)
+{
+    if (g_pool.n == workers) return;
+    if (g_pool.n > 0) {
+        g_pool.quit = 1;
+        pthread_barrier_wait(&g_pool.start);
+        for (int t = 0; t < g_pool.n; ++t) pthread_join(g_pool.tid[t], 0);
+        pthread_barrier_destroy(&g_pool.start); pthread_barrier_destroy(&g_pool.done);
+        g_pool.quit = 0;
+    }
+    g_pool.n = workers;
+    if (workers > 0) {
+        pthread_barrier_init(&g_pool.start, 0, (unsigned)workers + 1);
+        pthread_barrier_init(&g_pool.done, 0, (unsigned)workers + 1);
+        for (int t = 0; t < workers; ++t) pthread_create(&g_pool.tid[t], 0, pool_worker, (void *)(intptr_t)(t + 1));
+    }
+}
 void orc_spmv_parallel(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
                        const double *values, const double *x, double *y, int threads)
 {
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
-    uint64_t chunk = (rows + (uint64_t)threads - 1) / (uint64_t)threads;
-    pthread_t tid[256]; par_arg args[256]; int started = 0;
+    const uint64_t chunk = (rows + (uint64_t)threads - 1) / (uint64_t)threads;   /* simd_ops.rs:219 */
+    pool_resize(threads - 1);
     for (int t = 0; t < threads; ++t) {
         uint64_t lo = (uint64_t)t * chunk, hi = lo + chunk;
-        if (lo >= rows) break;
         if (hi > rows) hi = rows;
-        args[t] = (par_arg){lo, hi, row_ptr, col_idx, values, x, y};
-        if (t == threads - 1 || hi == rows) { par_worker(&args[t]); break; }
-        pthread_create(&tid[t], 0, par_worker, &args[t]); ++started;
+        g_pool.has_work[t] = lo < rows;
+        g_pool.args[t] = (par_arg){lo, hi, row_ptr, col_idx, values, x, y};
     }
-    for (int t = 0; t < started; ++t) pthread_join(tid[t], 0);
+    if (threads > 1) pthread_barrier_wait(&g_pool.start);
+    if (g_pool.has_work[0]) par_worker(&g_pool.args[0]);
+    if (threads > 1) pthread_barrier_wait(&g_pool.done);
 }
 
 /* ------------------------------------------------------------------ a5 -- */

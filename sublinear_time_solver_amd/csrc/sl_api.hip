@@ -89,7 +89,7 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
 {
     sl_row_args a;
     memset(&a, 0, sizeof(a));
-    a.slice_ptr = m->d_slice_ptr; a.row_len = m->d_row_len; a.cols = m->d_cols; a.vals = m->d_vals;
+    a.slice_ptr = m->d_slice_ptr; a.row_len = m->d_row_len; a.cols = m->d_cols; a.cols16 = m->d_cols16; a.vals = m->d_vals;
     a.n_rows = m->n_rows; a.n_cols = m->n_cols; a.n_slices = m->n_slices; a.row_offset = m->row_offset;
     a.bandwidth = m->bandwidth; a.uniform_width = m->uniform_width;
     return a;
@@ -147,7 +147,7 @@ sl_status sl_synchronize(void)
 void sl_matrix_destroy(sl_matrix *m)
 {
     if (!m) return;
-    hipFree(m->d_slice_ptr); hipFree(m->d_row_len); hipFree(m->d_cols); hipFree(m->d_vals);
+    hipFree(m->d_slice_ptr); hipFree(m->d_row_len); hipFree(m->d_cols); hipFree(m->d_cols16); hipFree(m->d_vals);
     hipFree(m->d_row_ptr); hipFree(m->d_col_idx); hipFree(m->d_values);
     hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval);
     delete m;

@@ -29,6 +29,7 @@ struct sl_matrix {
     uint32_t *d_slice_ptr = nullptr; // [n_slices+1] in quads
     uint32_t *d_row_len = nullptr;   // [n_slices*64]
     uint32_t *d_cols = nullptr;      // [padded_nnz]
+    uint16_t *d_cols16 = nullptr;    // [padded_nnz] col - row as int16 (uniform-width band matrices only)
     double *d_vals = nullptr;        // [padded_nnz]
     uint32_t max_row_nnz = 0, min_row_nnz = 0, uniform_width = 0;
     uint64_t bandwidth = 0;          // max |col - (row_offset + row)| over stored entries
@@ -69,6 +70,7 @@ enum sl_epilogue { SL_EPI_SPMV = 0, SL_EPI_NEUMANN = 1, SL_EPI_RESIDUAL = 2, SL_
 struct sl_row_args {
     // matrix
     const uint32_t *slice_ptr, *row_len, *cols;
+    const uint16_t *cols16;   // null unless the matrix carries 16-bit column offsets
     const double *vals;
     uint64_t n_rows, n_cols, n_slices, row_offset;
     uint64_t bandwidth;   // ~0 = unknown / do not use the LDS band kernel

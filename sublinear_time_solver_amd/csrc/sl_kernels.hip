@@ -201,24 +201,118 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32
 }
 
 // ---- band kernel: gathers served by an LDS-staged window of the gathered vector -----------------
-// For matrices whose entries all satisfy |col - row| <= w (measured at create time).  A block owns
-// R = 4 * spw * 64 consecutive rows; every entry those rows can touch lies in the window
+// For matrices whose entries all satisfy |col - row| <= w (measured at create time).  A block of
+// 4 waves owns R = 4 * spw * 64 consecutive rows; every entry those rows can touch lies in the window
 // [r0 - w, r0 + R + w) of the gathered vector, which is staged ONCE into LDS with coalesced 16-B
 // loads.  The 16 irregular gathers per row then become ds_read_b64 (a few LDS cycles per wave)
 // instead of 64 serialized L1 tag lookups each, and the kernel is a pure HBM stream.
-template <int ORDER, int EPI, int UW>
+// Uniform-width matrices (UW = 8 / 16):
+//   PIPE : software pipelining — the matrix bytes of slice j+1 (and of slice 0 before the window
+//          barrier) are in flight while slice j is reduced (pays when the LDS window limits occupancy);
+//   C16  : column indices are read as 16-bit offsets col - row (stored next to the u32 columns when
+//          w < 32768): 10 instead of 12 bytes per entry cross the HBM interface.
+template <int UW, bool C16>
+struct sl_slice_regs {
+    u32x4 c[UW > 0 ? (C16 ? UW / 8 : UW / 4) : 1];
+    f64x2 va[UW > 0 ? UW / 4 : 1], vb[UW > 0 ? UW / 4 : 1];
+    double e_d, e_x, e_aux;
+};
+
+template <int EPI, int UW, bool C16>
+__device__ __forceinline__ void sl_slice_load(const sl_row_args &a, uint64_t s, uint32_t lane, sl_slice_regs<UW, C16> &r)
+{
+    const f64x2 *__restrict__ vq = reinterpret_cast<const f64x2 *>(a.vals);
+    constexpr int NQ = UW / 4;
+    const uint64_t qb = s * NQ;
+    if constexpr (C16) {
+        const u32x4 *__restrict__ c16 = reinterpret_cast<const u32x4 *>(a.cols16);
+#pragma unroll
+        for (int o = 0; o < UW / 8; ++o) r.c[o] = __builtin_nontemporal_load(&c16[(s * (UW / 8) + o) * 64 + lane]);
+    } else {
+        const u32x4 *__restrict__ cq = reinterpret_cast<const u32x4 *>(a.cols);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) r.c[q] = __builtin_nontemporal_load(&cq[(qb + q) * 64 + lane]);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        r.va[q] = __builtin_nontemporal_load(&vq[((qb + q) * 2) * 64 + lane]);
+        r.vb[q] = __builtin_nontemporal_load(&vq[((qb + q) * 2 + 1) * 64 + lane]);
+    }
+    const uint64_t i = s * SL_SLICE + lane;
+    r.e_d = 0.0; r.e_x = 0.0; r.e_aux = 0.0;
+    if (i < a.n_rows) {
+        if constexpr (EPI == SL_EPI_NEUMANN) { r.e_d = a.dinv[i]; r.e_x = a.x[i]; }
+        else if constexpr (EPI == SL_EPI_RESIDUAL) { r.e_aux = a.aux[i]; }
+        else if constexpr (EPI == SL_EPI_PUSH) { r.e_aux = a.r[i]; r.e_d = a.dinv[i]; r.e_x = a.x[i]; }
+    }
+}
+
+// LDS index of entry e (0..3) of quad q: window position of the column
+template <int UW, bool C16>
+__device__ __forceinline__ uint32_t sl_lds_index(const sl_slice_regs<UW, C16> &r, int q, int e, uint32_t base, uint32_t rowpos)
+{
+    if constexpr (C16) {
+        const u32x4 v = r.c[q >> 1];
+        const uint32_t word = (q & 1) ? (e < 2 ? v.z : v.w) : (e < 2 ? v.x : v.y);
+        const int delta = (e & 1) ? ((int)word >> 16) : (int)(short)(word & 0xffffu);
+        return (uint32_t)((int)rowpos + delta);
+    } else {
+        const u32x4 v = r.c[q];
+        const uint32_t c = e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+        return c - base;
+    }
+}
+
+template <int EPI, int UW, bool C16>
+__device__ __forceinline__ void sl_slice_finish(const sl_row_args &a, uint64_t s, uint32_t lane, const sl_slice_regs<UW, C16> &r,
+                                                const double *lw, uint32_t base, double &part0, double &part1)
+{
+    constexpr int NQ = UW / 4;
+    const uint64_t i = s * SL_SLICE + lane;
+    const uint32_t rowpos = (uint32_t)(a.row_offset + i) - base;       // window position of this lane's own row
+    // LDS gathers are cheap and short-latency: fetch one quad ahead of the dependent add chain
+    double sum = 0.0;
+    double t0 = lw[sl_lds_index<UW, C16>(r, 0, 0, base, rowpos)], t1 = lw[sl_lds_index<UW, C16>(r, 0, 1, base, rowpos)];
+    double t2 = lw[sl_lds_index<UW, C16>(r, 0, 2, base, rowpos)], t3 = lw[sl_lds_index<UW, C16>(r, 0, 3, base, rowpos)];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+        if (q + 1 < NQ) {
+            n0 = lw[sl_lds_index<UW, C16>(r, q + 1, 0, base, rowpos)]; n1 = lw[sl_lds_index<UW, C16>(r, q + 1, 1, base, rowpos)];
+            n2 = lw[sl_lds_index<UW, C16>(r, q + 1, 2, base, rowpos)]; n3 = lw[sl_lds_index<UW, C16>(r, q + 1, 3, base, rowpos)];
+        }
+        sum = DADD(sum, DMUL(r.va[q].x, t0));
+        sum = DADD(sum, DMUL(r.va[q].y, t1));
+        sum = DADD(sum, DMUL(r.vb[q].x, t2));
+        sum = DADD(sum, DMUL(r.vb[q].y, t3));
+        t0 = n0; t1 = n1; t2 = n2; t3 = n3;
+    }
+    if (i < a.n_rows) {
+        const double own = lw[rowpos];                                   // the gathered vector's own entry
+        if constexpr (EPI == SL_EPI_NEUMANN) sl_row_epilogue<EPI>(a, i, sum, own, r.e_d, r.e_x, 0.0, part0, part1);
+        else if constexpr (EPI == SL_EPI_PUSH) sl_row_epilogue<EPI>(a, i, sum, r.e_aux, r.e_d, r.e_x, own, part0, part1);
+        else sl_row_epilogue<EPI>(a, i, sum, r.e_aux, 0.0, 0.0, 0.0, part0, part1);
+    }
+}
+
+template <int ORDER, int EPI, int UW, bool PIPE, bool C16>
 __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32_t nb8, uint32_t spw, uint32_t w)
 {
+    constexpr int NW = SL_WAVES_PER_BLOCK;
     extern __shared__ __attribute__((aligned(16))) double win[];
-    __shared__ double red[2 * SL_WAVES_PER_BLOCK];
+    __shared__ double red[2 * NW];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
-    const uint64_t R = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE;
+    const uint64_t R = (uint64_t)NW * spw * SL_SLICE;
     const uint64_t r0 = (uint64_t)lb * R;                       // first local row of the block
     double part0 = 0.0, part1 = 0.0;
     if (r0 < a.n_rows) {                                        // block-uniform
-        const uint64_t g0 = a.row_offset + r0;                  // global index of that row
+        const uint64_t s0 = (uint64_t)lb * spw * NW + wave;     // this wave's slices: s0, s0 + NW, ...
+        [[maybe_unused]] sl_slice_regs<UW, C16> ra, rb;
+        if constexpr (UW > 0 && PIPE) { if (s0 < a.n_slices) sl_slice_load<EPI, UW, C16>(a, s0, lane, ra); }
+
+        const uint64_t g0 = a.row_offset + r0;                  // global index of the block's first row
         const uint64_t win_lo = (g0 > w ? g0 - w : 0) & ~1ull;  // even => 16-B aligned staging loads
         uint64_t win_hi = g0 + R + w;
         if (win_hi > a.n_cols) win_hi = a.n_cols;
@@ -232,19 +326,41 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
         __syncthreads();
         const double *lw = win;
         const uint32_t base = (uint32_t)win_lo;
-        for (uint32_t j = 0; j < spw; ++j) {
-            const uint64_t s = ((uint64_t)lb * spw + j) * SL_WAVES_PER_BLOCK + wave;   // waves interleave over slices
-            if (s >= a.n_slices) break;
-            const uint64_t i = s * SL_SLICE + lane;
-            const bool live = i < a.n_rows;
-            double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
-            if (live) {
-                if constexpr (EPI == SL_EPI_NEUMANN) { e_t = lw[(uint32_t)(a.row_offset + i) - base]; e_d = a.dinv[i]; e_x = a.x[i]; }
-                else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
-                else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = lw[(uint32_t)(a.row_offset + i) - base]; }
+
+        if constexpr (UW > 0 && PIPE) {
+            for (uint32_t j = 0; j < spw; j += 2) {
+                const uint64_t sa = s0 + (uint64_t)j * NW, sb = sa + NW;
+                if (sa >= a.n_slices) break;
+                const bool has_b = (j + 1 < spw) && sb < a.n_slices;
+                if (has_b) sl_slice_load<EPI, UW, C16>(a, sb, lane, rb);
+                sl_slice_finish<EPI, UW, C16>(a, sa, lane, ra, lw, base, part0, part1);
+                if (!has_b) break;
+                const uint64_t sc = sb + NW;
+                if (j + 2 < spw && sc < a.n_slices) sl_slice_load<EPI, UW, C16>(a, sc, lane, ra);
+                sl_slice_finish<EPI, UW, C16>(a, sb, lane, rb, lw, base, part0, part1);
             }
-            const double sum = sl_row_walk<ORDER, UW>(a, s, lane, i, [lw, base](uint32_t c) { return lw[c - base]; });
-            if (live) sl_row_epilogue<EPI>(a, i, sum, e_t, e_d, e_x, dself, part0, part1);
+        } else if constexpr (UW > 0) {
+            for (uint32_t j = 0; j < spw; ++j) {
+                const uint64_t s = s0 + (uint64_t)j * NW;
+                if (s >= a.n_slices) break;
+                sl_slice_load<EPI, UW, C16>(a, s, lane, ra);
+                sl_slice_finish<EPI, UW, C16>(a, s, lane, ra, lw, base, part0, part1);
+            }
+        } else {
+            for (uint32_t j = 0; j < spw; ++j) {
+                const uint64_t s = s0 + (uint64_t)j * NW;
+                if (s >= a.n_slices) break;
+                const uint64_t i = s * SL_SLICE + lane;
+                const bool live = i < a.n_rows;
+                double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
+                if (live) {
+                    if constexpr (EPI == SL_EPI_NEUMANN) { e_t = lw[(uint32_t)(a.row_offset + i) - base]; e_d = a.dinv[i]; e_x = a.x[i]; }
+                    else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
+                    else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = lw[(uint32_t)(a.row_offset + i) - base]; }
+                }
+                const double sum = sl_row_walk<ORDER, 0>(a, s, lane, i, [lw, base](uint32_t c) { return lw[c - base]; });
+                if (live) sl_row_epilogue<EPI>(a, i, sum, e_t, e_d, e_x, dself, part0, part1);
+            }
         }
     }
     sl_block_partials<EPI>(a, red, lane, wave, lb, nb8 * 8, part0, part1);
@@ -280,46 +396,74 @@ uint32_t sl_row_grid(uint64_t n_slices)
     return (uint32_t)(nb8 * 8);
 }
 
-// band-kernel geometry: slices per wave and dynamic LDS bytes for half bandwidth w; 0 = not eligible
+// band-kernel geometry for half bandwidth w: slices per wave, dynamic LDS bytes, pipelining; spw = 0: not eligible
 #define SL_BAND_MAX_LDS (80u * 1024u)      // two blocks per CU (160 KiB LDS)
-static uint32_t band_spw(const sl_row_args &a, uint32_t *lds_bytes)
+struct band_geom { uint32_t spw, lds; bool pipe, c16; };
+static band_geom band_geometry(const sl_row_args &a)
 {
-    static int disabled = -1, forced_spw = -1;
+    static int disabled = -1, forced_spw = 0, forced_pipe = -1, c16_off = 0;
     if (disabled < 0) {
         const char *e = getenv("SL_BAND_DISABLE");
         disabled = (e && e[0] == '1') ? 1 : 0;
         const char *f = getenv("SL_BAND_SPW");
         forced_spw = f ? atoi(f) : 0;
+        const char *g = getenv("SL_BAND_PIPE");
+        forced_pipe = g ? atoi(g) : -1;
+        const char *h = getenv("SL_BAND_C16");
+        c16_off = (h && h[0] == '0') ? 1 : 0;
     }
-    if (disabled || a.bandwidth == ~0ull || a.n_cols > 0xffffffffull) return 0;
-    uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : 4u;
-    const uint64_t entries = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE + 2 * a.bandwidth + 2;
-    if (entries * 8 > SL_BAND_MAX_LDS) return 0;
-    *lds_bytes = (uint32_t)(entries * 8);
-    return spw;
+    band_geom out{0, 0, false, false};
+    if (disabled || a.bandwidth == ~0ull || a.n_cols > 0xffffffffull) return out;
+    // measured (gpurun_out/sweep4.txt): narrow windows like 2 slices per wave (more, smaller blocks), wide
+    // windows 4 (the window is re-staged 4 * spw * 64 rows at a time); pipelining never hurts
+    uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : (a.bandwidth <= 1024 ? 2u : 4u);
+    uint64_t entries = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE + 2 * a.bandwidth + 2;
+    if (entries * 8 > SL_BAND_MAX_LDS && forced_spw <= 0) {       // last resort: a shorter block still fits
+        spw = 2;
+        entries = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE + 2 * a.bandwidth + 2;
+    }
+    if (entries * 8 > SL_BAND_MAX_LDS) return out;
+    out.spw = spw; out.lds = (uint32_t)(entries * 8);
+    out.pipe = forced_pipe >= 0 ? forced_pipe != 0 : true;
+    out.c16 = a.cols16 != nullptr && !c16_off;
+    return out;
+}
+
+template <int ORDER, int EPI, int UWV, bool PIPE, bool C16>
+static sl_status launch_band(const sl_row_args &a, const band_geom &g, uint32_t grid, uint32_t nb8, hipStream_t s)
+{
+    auto kfn = sl_band_kernel<(UWV) ? 0 : ORDER, EPI, UWV, PIPE, C16>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SL_BAND_MAX_LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SL_BLOCK), g.lds, s, a, nb8, g.spw, (uint32_t)a.bandwidth);
+    return SL_OK;
+}
+
+template <int ORDER, int EPI, int UWV>
+static sl_status launch_band_u(const sl_row_args &a, const band_geom &g, uint32_t grid, uint32_t nb8, hipStream_t s)
+{
+    if (g.pipe) return g.c16 ? launch_band<ORDER, EPI, UWV, true, true>(a, g, grid, nb8, s) : launch_band<ORDER, EPI, UWV, true, false>(a, g, grid, nb8, s);
+    return g.c16 ? launch_band<ORDER, EPI, UWV, false, true>(a, g, grid, nb8, s) : launch_band<ORDER, EPI, UWV, false, false>(a, g, grid, nb8, s);
 }
 
 template <int ORDER, int EPI>
 static sl_status launch_rows_t(const sl_row_args &a, hipStream_t s, uint32_t *nparts)
 {
-    uint32_t lds = 0;
-    const uint32_t spw = band_spw(a, &lds);
-    if (spw) {
-        const uint64_t nb = (a.n_slices + (uint64_t)SL_WAVES_PER_BLOCK * spw - 1) / ((uint64_t)SL_WAVES_PER_BLOCK * spw);
+    const band_geom g = band_geometry(a);
+    if (g.spw) {
+        const uint64_t per_block = (uint64_t)SL_WAVES_PER_BLOCK * g.spw;
+        const uint64_t nb = (a.n_slices + per_block - 1) / per_block;
         const uint32_t nb8 = (uint32_t)((nb + 7) / 8);
-        const uint32_t grid = nb8 * 8, w = (uint32_t)a.bandwidth;
+        const uint32_t grid = nb8 * 8;
         *nparts = grid;
-#define SL_BAND_LAUNCH(UWV)                                                                                          \
-    do {                                                                                                             \
-        auto kfn = sl_band_kernel<(UWV) ? 0 : ORDER, EPI, UWV>;                                                      \
-        static bool attr_done = false;                                                                               \
-        if (!attr_done) { SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SL_BAND_MAX_LDS)); attr_done = true; } \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(SL_BLOCK), lds, s, a, nb8, spw, w);                                  \
-    } while (0)
-        if (ORDER == 0 && a.uniform_width == 16) SL_BAND_LAUNCH(16);
-        else if (ORDER == 0 && a.uniform_width == 8) SL_BAND_LAUNCH(8);
-        else SL_BAND_LAUNCH(0);
-#undef SL_BAND_LAUNCH
+        sl_status st;
+        if (ORDER == 0 && a.uniform_width == 16) st = launch_band_u<ORDER, EPI, 16>(a, g, grid, nb8, s);
+        else if (ORDER == 0 && a.uniform_width == 8) st = launch_band_u<ORDER, EPI, 8>(a, g, grid, nb8, s);
+        else st = launch_band<ORDER, EPI, 0, false, false>(a, g, grid, nb8, s);
+        if (st != SL_OK) return st;
     } else {
         const uint32_t grid = sl_row_grid(a.n_slices), nb8 = grid / 8;
         *nparts = grid;

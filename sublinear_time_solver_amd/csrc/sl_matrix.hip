@@ -82,6 +82,26 @@ __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, ui
     if (bw) atomicMax(band, bw);
 }
 
+// 16-bit column offsets for uniform-width band matrices: [slice][octet][lane][8] int16 = col - row,
+// one 16-B load per lane per 8 entries.  Padding entries and dead lanes carry offset 0.
+__global__ __launch_bounds__(256) void sl_fill_cols16_kernel(uint64_t n_rows, uint64_t n_slices, uint64_t row_offset, uint32_t uw,
+                                                             const uint32_t *cols, uint16_t *cols16)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const uint64_t i = s * 64 + lane;
+    const uint64_t gi = row_offset + i;
+    const uint32_t nq = uw / 4;
+    for (uint32_t q = 0; q < nq; ++q)
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t c = cols[((s * nq + q) * 64 + lane) * 4 + e];
+            const int delta = (i < n_rows) ? (int)((long long)c - (long long)gi) : 0;
+            const uint32_t k = q * 4 + e;
+            cols16[((s * (uw / 8) + (k >> 3)) * 64 + lane) * 8 + (k & 7u)] = (uint16_t)(int16_t)delta;
+        }
+}
+
 // a6 + a7: one pass over the slice layout.  Per row, in stored order:
 //   diag = |a_ii| of the LAST diagonal entry seen (0 if none), off += |a_ij|   (matrix/mod.rs:467-485)
 //   d    = that diagonal entry; missing or |d| < 1e-14 is an error            (neumann.rs:172-188)
@@ -223,7 +243,13 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     SL_HIP(hipStreamSynchronize(st));
     hipFree(d_band);
     m->bandwidth = h_band;
-    m->device_bytes = (m->n_slices + 1 + padded_rows) * sizeof(uint32_t) + m->padded_nnz * 12;
+    if ((m->uniform_width == 8 || m->uniform_width == 16) && m->bandwidth < 32768 && m->n_slices) {
+        SL_HIP(hipMalloc(&m->d_cols16, m->padded_nnz * sizeof(uint16_t)));
+        hipLaunchKernelGGL(sl_fill_cols16_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_slices, m->row_offset,
+                           m->uniform_width, m->d_cols, m->d_cols16);
+        SL_HIP(hipGetLastError());
+    }
+    m->device_bytes = (m->n_slices + 1 + padded_rows) * sizeof(uint32_t) + m->padded_nnz * 12 + (m->d_cols16 ? m->padded_nnz * 2 : 0);
 
     // 3. transpose
     if (m->flags & SL_MATRIX_WITH_TRANSPOSE) {
