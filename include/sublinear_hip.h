@@ -234,6 +234,14 @@ typedef struct {
 } sl_estimate_result;
 sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, uint64_t row,
                             double theta, uint64_t max_rounds, sl_estimate_result *result);
+/* same query when the caller already holds A^T as `mt` (e.g. the row-stochastic side I - alpha P of a
+ * PageRank system whose solve matrix is I - alpha P^T, src/core/solver.ts:664-722; PushGraph keeps both
+ * orientations, src/graph/adjacency.rs:199-224): the push runs on mt's own rows and may use its dense kernel. */
+sl_status sl_estimate_entry_transposed(const sl_matrix *mt, const double *b, sl_mem where, uint64_t row,
+                                       double theta, uint64_t max_rounds, sl_estimate_result *result);
+/* A^T as a matrix of its own (CompressedSparseRow::transpose, src/graph/mod.rs:92-130; PushGraph::from_matrix
+ * adjacency.rs:212-224).  `m` must have been created WITH_TRANSPOSE. */
+sl_status sl_matrix_transpose(const sl_matrix *m, uint32_t flags, sl_matrix **out);
 
 /* ---- synthetic inputs, generated in HBM (bench / tests) -------------------
  * S-DD(n, k, seed, w): rows [row_lo, row_hi) of the seeded diagonally dominant system;
@@ -241,6 +249,12 @@ sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, u
 sl_status sl_synth_sdd_device(uint64_t n, uint32_t k, uint64_t seed, uint64_t half_bandwidth,
                               uint64_t row_lo, uint64_t row_hi, uint32_t *row_ptr, uint32_t *col_idx,
                               double *values, double *b);
+/* S-PR(n, seed, alpha): power-law digraph (out-degree dmin * 2^g, g geometric so that P(d >= x) ~ x^-1.1,
+ * capped at dmax; targets floor(n u^2): preferential to low ids) as the ROW-dominant matrix
+ * M = I - alpha P (P row-stochastic), whose transpose is the PageRank system of core/solver.ts:664-722.
+ * Two calls: with col_idx == NULL only row_ptr (n+1) is written and *nnz returned; then with arrays of *nnz. */
+sl_status sl_synth_pagerank_device(uint64_t n, uint64_t seed, double alpha, uint32_t dmin, uint32_t dmax,
+                                   uint32_t *row_ptr, uint32_t *col_idx, double *values, uint64_t *nnz);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,9 @@ SIGNATURES = {
                                 C.POINTER(PushResult)]),
     "sl_estimate_entry": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
     "sl_synth_sdd_device": (C.c_int, [u64, u32, u64, u64, u64, u64, vp, vp, vp, vp]),
+    "sl_estimate_entry_transposed": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
+    "sl_matrix_transpose": (C.c_int, [vp, u32, C.POINTER(vp)]),
+    "sl_synth_pagerank_device": (C.c_int, [u64, u64, f64, u32, u32, vp, vp, vp, C.POINTER(u64)]),
 }
 
 _lib = None

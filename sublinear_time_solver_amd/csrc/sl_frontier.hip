@@ -436,8 +436,9 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
     return SL_OK;
 }
 
-sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double theta,
-                            uint64_t max_rounds, sl_estimate_result *res)
+// shared body: `given_is_transpose` = the matrix holds A^T (its rows are the operator of the push)
+static sl_status estimate_entry_impl(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double theta,
+                                     uint64_t max_rounds, bool given_is_transpose, sl_estimate_result *res)
 {
     if (!m || !b || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
     memset(res, 0, sizeof(*res));
@@ -449,10 +450,16 @@ sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, u
     push_state ps;
     DevBuf bufs[12], bbuf;
     SL_TRY(alloc_state(ps, n, bufs));
-    // operator B = A^T: rows of B = columns of A (sorted transpose), columns of B = rows of A
-    ps.op = op_view{m->d_tptr, m->d_trow, m->d_tval, m->d_row_ptr, m->d_col_idx};
     unsigned long long hs[4];
-    SL_TRY(sl_csr_diag_pass(n, m->d_tptr, m->d_trow, m->d_tval, ps.dinv, hs));
+    if (given_is_transpose) {
+        // operator B = the matrix itself (= A^T); its dense rounds can use the row-slice kernels
+        ps.op = op_view{m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_trow};
+        SL_TRY(sl_matrix_diag_pass(m, ps.dinv, hs));
+    } else {
+        // operator B = A^T: rows of B = columns of A (sorted transpose), columns of B = rows of A
+        ps.op = op_view{m->d_tptr, m->d_trow, m->d_tval, m->d_row_ptr, m->d_col_idx};
+        SL_TRY(sl_csr_diag_pass(n, m->d_tptr, m->d_trow, m->d_tval, ps.dinv, hs));
+    }
     if (hs[0] & 2ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2]);
     if (hs[0] & 4ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3]);
     // y0 = 0, r = e_row
@@ -463,7 +470,7 @@ sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, u
     push_log plog;
     round_stats rs;
     float ms = 0.f;
-    SL_TRY(run_push(ps, nullptr, theta, max_rounds, SL_ORDER_CSR_SEQUENTIAL, 0.25, plog, rs, &ms));
+    SL_TRY(run_push(ps, given_is_transpose ? m : nullptr, theta, max_rounds, SL_ORDER_CSR_SEQUENTIAL, given_is_transpose ? 1.0 / 16.0 : 0.25, plog, rs, &ms));
     // estimate = y . b ; residual_l1 = ||r_y||_1
     const double *db = b;
     if (where == SL_MEM_HOST) { SL_TRY(bbuf.alloc(n * 8)); SL_HIP(hipMemcpyAsync(bbuf.p, b, n * 8, hipMemcpyHostToDevice, s)); db = bbuf.as<double>(); }
@@ -480,6 +487,26 @@ sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, u
     res->rounds = rs.rounds; res->pushes = rs.pushes; res->rows_touched = rs.rows_touched;
     res->device_time_ms = ms; res->converged = rs.converged ? 1 : 0;
     return SL_OK;
+}
+
+sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double theta,
+                            uint64_t max_rounds, sl_estimate_result *res)
+{
+    return estimate_entry_impl(m, b, where, row, theta, max_rounds, false, res);
+}
+
+sl_status sl_estimate_entry_transposed(const sl_matrix *mt, const double *b, sl_mem where, uint64_t row, double theta,
+                                       uint64_t max_rounds, sl_estimate_result *res)
+{
+    return estimate_entry_impl(mt, b, where, row, theta, max_rounds, true, res);
+}
+
+sl_status sl_matrix_transpose(const sl_matrix *m, uint32_t flags, sl_matrix **out)
+{
+    if (!m || !out) return sl_fail(SL_INVALID_INPUT, "null argument");
+    if (!m->d_tptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "sl_matrix_transpose needs a matrix created with SL_MATRIX_WITH_TRANSPOSE");
+    if (m->row_offset != 0) return sl_fail(SL_UNSUPPORTED_FORMAT, "cannot transpose a row slice");
+    return sl_matrix_create_csr(m->n_cols, m->n_rows, m->nnz, m->d_tptr, m->d_trow, m->d_tval, SL_MEM_DEVICE, 0, flags, out);
 }
 
 } // extern "C"

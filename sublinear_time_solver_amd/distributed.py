@@ -98,7 +98,11 @@ LocalStep = Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor], N
 
 
 class PartitionedNeumann:
-    """Ping-pong driver of the partitioned iteration: local fused step -> exchange -> norm all-reduce."""
+    """Ping-pong driver of the partitioned iteration: local fused step -> exchange -> norm all-reduce.
+
+    The 8-byte all-reduce of ||t||^2 is issued asynchronously into one of two result slots, so it
+    overlaps the next step's kernel; it is only waited for when the norm is read (term_norm) or when
+    its slot is about to be reused two steps later."""
 
     def __init__(self, part: RowPartition, local_step: LocalStep, exchange, t0_full: torch.Tensor,
                  x_local: torch.Tensor, group=None):
@@ -106,16 +110,28 @@ class PartitionedNeumann:
         self.t = [t0_full, torch.zeros_like(t0_full)]
         self.x = x_local
         self.cur = 0
-        self.norm2 = torch.zeros(2, dtype=torch.float64, device=t0_full.device)
+        self._norm = [torch.zeros(2, dtype=torch.float64, device=t0_full.device) for _ in range(2)]
+        self._pending = [None, None]
+        self._slot = 0
         self.steps_done = 0
+
+    @property
+    def norm2(self) -> torch.Tensor:
+        """result slot of the most recent step (valid after term_norm() / a wait)"""
+        return self._norm[self._slot]
 
     def step(self, reduce_norm: bool = True) -> None:
         p = self.part
+        slot = 1 - self._slot
+        if self._pending[slot] is not None:            # the all-reduce that last used this slot must be done
+            self._pending[slot].wait()
+            self._pending[slot] = None
         t_in, t_out = self.t[self.cur], self.t[1 - self.cur]
-        self.local_step(t_in, t_out[p.lo:p.hi], self.x, self.norm2)
+        self.local_step(t_in, t_out[p.lo:p.hi], self.x, self._norm[slot])
         self.exchange(t_out)
         if reduce_norm and p.world > 1:
-            dist.all_reduce(self.norm2[:1], op=dist.ReduceOp.SUM, group=self.group)
+            self._pending[slot] = dist.all_reduce(self._norm[slot][:1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._slot = slot
         self.cur = 1 - self.cur
         self.steps_done += 1
 
@@ -124,7 +140,10 @@ class PartitionedNeumann:
         return self.t[self.cur]
 
     def term_norm(self) -> float:
-        return float(self.norm2[0].item()) ** 0.5
+        if self._pending[self._slot] is not None:
+            self._pending[self._slot].wait()
+            self._pending[self._slot] = None
+        return float(self._norm[self._slot][0].item()) ** 0.5
 
 
 def hip_local_step(matrix_handle: int, dinv_local: torch.Tensor, order: int = 0) -> LocalStep:

@@ -160,6 +160,13 @@ class SparseMatrix:
         L.check(L.load().sl_matrix_download_csr(self._h, L.ptr(rp), L.ptr(ci), L.ptr(va)))
         return rp, ci, va
 
+    def transpose(self, with_transpose: bool = False, keep_csr: bool = False) -> "SparseMatrix":
+        """A^T as its own matrix (CompressedSparseRow::transpose, src/graph/mod.rs:92-130); needs with_transpose at create."""
+        h = L.vp()
+        flags = (L.SL_MATRIX_WITH_TRANSPOSE if with_transpose else 0) | (L.SL_MATRIX_KEEP_CSR if keep_csr else 0)
+        L.check(L.load().sl_matrix_transpose(self._h, flags, C.byref(h)))
+        return SparseMatrix(h.value, self._cols, self._rows)
+
     def close(self):
         if self._h:
             L.load().sl_matrix_destroy(self._h)
@@ -265,14 +272,18 @@ class PushSolver:
         return out
 
 
-def estimate_entry(matrix: SparseMatrix, b, row: int, theta: float = 1e-8, max_rounds: int = 100_000):
-    """x_row = e_row^T A^-1 b by local push on A^T (sl_estimate_entry)."""
+def estimate_entry(matrix: SparseMatrix, b, row: int, theta: float = 1e-8, max_rounds: int = 100_000,
+                   matrix_is_transpose: bool = False, device: bool = False):
+    """x_row = e_row^T A^-1 b by local push on A^T (sl_estimate_entry); matrix_is_transpose: `matrix` already
+    holds A^T (sl_estimate_entry_transposed).  device=True: b is a torch CUDA tensor."""
     lib = L.load()
-    b = _f64(b)
+    if not device:
+        b = _f64(b)
     if not (0 <= row < matrix.rows()):
         raise SolverError(4, f"Row index {row} out of bounds. Matrix has {matrix.rows()} rows")
     res = L.EstimateResult()
-    L.check(lib.sl_estimate_entry(matrix._h, L.ptr(b), L.SL_MEM_HOST, row, theta, max_rounds, C.byref(res)))
+    fn = lib.sl_estimate_entry_transposed if matrix_is_transpose else lib.sl_estimate_entry
+    L.check(fn(matrix._h, L.ptr(b), L.SL_MEM_DEVICE if device else L.SL_MEM_HOST, row, theta, max_rounds, C.byref(res)))
     return res
 
 

@@ -1,0 +1,87 @@
+"""GPU tests for the PageRank / estimateEntry side of the path (BASELINE config 4 at test size) and for the
+uniform-width band-kernel variants (16-bit column offsets, pipelining)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import _lib as L
+from sublinear_time_solver_amd import generators as G
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits_equal(a, b):
+    return (np.ascontiguousarray(a).view(np.uint64) == np.ascontiguousarray(b).view(np.uint64)).all()
+
+
+def _spr(n, seed=1, alpha=0.85):
+    import torch
+    lib = L.load()
+    rp = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    nnz = C.c_uint64(0)
+    L.check(lib.sl_synth_pagerank_device(n, seed, alpha, 2, 8192, rp.data_ptr(), None, None, C.byref(nnz)))
+    ci = torch.empty(nnz.value, dtype=torch.int32, device="cuda")
+    va = torch.empty(nnz.value, dtype=torch.float64, device="cuda")
+    L.check(lib.sl_synth_pagerank_device(n, seed, alpha, 2, 8192, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), C.byref(nnz)))
+    L.check(lib.sl_synchronize())
+    return rp, ci, va
+
+
+def test_spr_generator_and_transposed_query(gpu):
+    n, alpha = 50_000, 0.85
+    rp, ci, va = _spr(n)
+    M = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True, keep_csr=True, device=True)
+    hrp, hci, hva = M.to_csr()
+    deg = np.diff(hrp.astype(np.int64)) - 1
+    assert deg.min() >= 2 and deg.max() <= 8192 and 8 < deg.mean() < 30           # power-law out-degrees, mean ~16
+    assert (hci[hrp[:-1]] == np.arange(n)).all() and (hva[hrp[:-1]] == 1.0).all()  # diagonal first, = 1
+    rows = np.repeat(np.arange(n), deg + 1)
+    offd = hci != rows
+    assert np.allclose(np.add.reduceat(np.where(offd, -hva, 0.0), hrp[:-1]), alpha)  # rows of P sum to 1
+    assert M.is_diagonally_dominant()                                               # M = I - alpha P is ROW dominant
+    # A = M^T is the PageRank solve matrix (column dominant): the transpose object equals the oracle's transpose
+    A = M.transpose(with_transpose=True, keep_csr=True)
+    arp, aci, ava = A.to_csr()
+    trp, tci, tva = O.csr_transpose(hrp, hci, hva, n)
+    assert (arp == trp).all() and (aci == tci).all() and _bits_equal(ava, tva)
+    b = np.full(n, (1.0 - alpha) / n)
+    # full solve of A x = b: GPU push vs oracle push, bit for bit (dense + sparse rounds, ragged power-law rows)
+    g = S.PushSolver(theta=1e-11 / n).solve(A, b)
+    o = O.push_sync_solve(arp, aci, ava, b, theta=1e-11 / n)
+    assert g["converged"] and g["rounds"] == o["rounds"] and g["pushes"] == o["pushes"]
+    assert _bits_equal(g["solution"], o["x"])
+    x = g["solution"]
+    assert abs(x.sum() - 1.0) < 1e-6                                                # PageRank mass
+    # single-entry queries: push on A^T = M (given directly) and on A (transpose taken inside) agree with x
+    for row in (0, 1, n // 2, n - 1):
+        e1 = S.estimate_entry(M, b, row, theta=1e-12, matrix_is_transpose=True)
+        e2 = S.estimate_entry(A, b, row, theta=1e-12)
+        for e in (e1, e2):
+            assert e.converged and abs(e.estimate - x[row]) <= e.residual_l1 * np.abs(x).max() + 1e-15
+        assert e1.estimate == e2.estimate and e1.pushes == e2.pushes               # same arithmetic either way
+    # reference semantics of the push family on this graph (forward_push.rs:67-216): ACL estimate from node 0
+    # solves the same system with b = alpha' e_0 on the row-stochastic side; mass is conserved
+    acl = O.acl_push(hrp, hci, np.where(offd, -hva / alpha, 0.0), [0], alpha=0.15, epsilon=1e-7)
+    assert abs(acl["estimate"].sum() + acl["residual"].sum() - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("n,k,w", [(40_000, 16, 500), (40_000, 16, 4096), (30_011, 8, 100), (30_011, 8, 3000)])
+def test_band_kernel_variants_bitwise(gpu, n, k, w):
+    """uniform-width band matrices: 16-bit column offsets + pipelined slices, both epilogue families"""
+    rp, ci, va, b = G.sdd_rows(n, k, seed=3, half_bandwidth=w)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    info = m.info()
+    assert info.uniform_width == k and info.bandwidth <= w
+    x = np.cos(np.arange(n))
+    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
+    g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-11))
+    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-11)
+    assert g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
+    bs = b * (np.arange(n) % 3 == 0)
+    p = S.PushSolver(theta=1e-9, dense_switch=1e-9).solve(m, bs, log_frontier=4_000_000)      # dense rounds only
+    q = O.push_sync_solve(rp, ci, va, bs, theta=1e-9, log_cap=4_000_000)
+    assert p["rounds"] == q["rounds"] and (p["frontier_log"] == q["frontier_log"]).all()
+    assert _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])

@@ -52,10 +52,12 @@ def main():
         namecol = "kernel_name" if "kernel_name" in cols else "name"
         rows = q(p, f"select {namecol}, counter_name, avg(value), count(*) from counters_collection "
                     f"where counter_name='{cname}' group by {namecol} order by avg(value) desc limit 6")
+        best_n = 0
         for kn, cn, avg, n in rows:
             pm.append(f"  {kn[:90]:<90} {cn} avg={avg:.1f} KiB over {n} dispatches")
-            if ("sl_band_kernel" in kn or "sl_rows_kernel" in kn) and cn not in rec:
+            if ("sl_band_kernel" in kn or "sl_rows_kernel" in kn) and n > best_n:   # the step kernel = most dispatches
                 rec[cn] = avg
+                best_n = n
     if "FETCH_SIZE" in rec or "WRITE_SIZE" in rec:
         rd = 2.0 * rec.get("FETCH_SIZE", 0.0) * 1024.0
         wr = rec.get("WRITE_SIZE", 0.0) * 1024.0
