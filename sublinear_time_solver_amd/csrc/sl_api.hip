@@ -82,7 +82,7 @@ sl_status read_scalars(const double *d, double *h, int count)
     return SL_OK;
 }
 sl_row_args row_args(const sl_matrix *m) { return sl_matrix_row_args(m); }
-size_t partial_bytes(const sl_matrix *m) { return ((size_t)sl_row_grid(m->n_slices) * 2 + 4096) * sizeof(double); }
+size_t partial_bytes(const sl_matrix *m) { return (((size_t)sl_row_grid(m->n_slices) + m->n_long) * 2 + 4096) * sizeof(double); }
 } // namespace
 
 sl_row_args sl_matrix_row_args(const sl_matrix *m)
@@ -92,6 +92,8 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
     a.slice_ptr = m->d_slice_ptr; a.row_len = m->d_row_len; a.cols = m->d_cols; a.cols16 = m->d_cols16; a.vals = m->d_vals;
     a.n_rows = m->n_rows; a.n_cols = m->n_cols; a.n_slices = m->n_slices; a.row_offset = m->row_offset;
     a.bandwidth = m->bandwidth; a.uniform_width = m->uniform_width;
+    a.csr_ptr = m->d_row_ptr; a.csr_idx = m->d_col_idx; a.csr_val = m->d_values;
+    a.long_rows = m->d_long_rows; a.n_long = (uint32_t)m->n_long;
     return a;
 }
 
@@ -149,7 +151,7 @@ void sl_matrix_destroy(sl_matrix *m)
     if (!m) return;
     hipFree(m->d_slice_ptr); hipFree(m->d_row_len); hipFree(m->d_cols); hipFree(m->d_cols16); hipFree(m->d_vals);
     hipFree(m->d_row_ptr); hipFree(m->d_col_idx); hipFree(m->d_values);
-    hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval);
+    hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval); hipFree(m->d_long_rows);
     delete m;
 }
 
@@ -186,7 +188,7 @@ sl_status sl_matrix_create_csr(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, c
         if (st == SL_OK) {
             if (keep) { // hand the uploaded buffers over instead of copying them again
                 st = sl_build_from_device_csr(m, rp.as<uint32_t>(), ci.as<uint32_t>(), va.as<double>(), false);
-                if (st == SL_OK) {
+                if (st == SL_OK && !m->d_row_ptr) {      // (long rows make the build keep its own copy already)
                     m->d_row_ptr = rp.as<uint32_t>(); m->d_col_idx = ci.as<uint32_t>(); m->d_values = va.as<double>();
                     rp.p = ci.p = va.p = nullptr;
                     m->device_bytes += (n_rows + 1) * sizeof(uint32_t) + nnz * 12;

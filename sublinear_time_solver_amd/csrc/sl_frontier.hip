@@ -135,11 +135,15 @@ __global__ __launch_bounds__(256) void sl_select_kernel(uint64_t n, const double
 __global__ __launch_bounds__(256) void sl_expand_kernel(uint32_t nf, const uint32_t *frontier, op_view op, const double *delta,
                                                         double *x, uint32_t *cand_flag, uint32_t *cand, uint32_t *cand_count)
 {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    // one WAVE per frontier column: hub columns (power-law in-degree, 10^4..10^5 entries) are walked by 64
+    // lanes with coalesced index loads instead of serialising one thread for milliseconds
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
     if (t >= nf) return;
     const uint32_t j = frontier[t];
-    x[j] = DADD(x[j], delta[j]);
-    for (uint32_t k = op.tptr[j]; k < op.tptr[j + 1]; ++k) {
+    if (lane == 0) x[j] = DADD(x[j], delta[j]);
+    const uint32_t k1 = op.tptr[j + 1];
+    for (uint32_t k = op.tptr[j] + lane; k < k1; k += 64) {
         const uint32_t i = op.tidx[k];
         if (atomicExch(&cand_flag[i], 1u) == 0u) cand[atomicAdd(cand_count, 1u)] = i;
     }
@@ -169,21 +173,70 @@ __device__ __forceinline__ double sl_csr_row_dot(const op_view &op, uint32_t i, 
 }
 
 // (2) pull update of candidate rows: r_i -= (B delta_old)_i ; next frontier from |r_i dinv_i| >= theta
-__global__ __launch_bounds__(256) void sl_pull_kernel(uint32_t nc, const uint32_t *cand, op_view op, const double *delta_old,
-                                                      const double *dinv, double theta, int order, double *r,
-                                                      double *delta_new, uint32_t *cand_flag, uint32_t *next, uint32_t *next_count)
+__device__ __forceinline__ void sl_pull_finish(uint32_t i, double acc, const double *dinv, double theta, double *r, double *delta_new,
+                                               uint32_t *next, uint32_t *next_count)
 {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= nc) return;
-    const uint32_t i = cand[t];
-    cand_flag[i] = 0u;
-    const double acc = sl_csr_row_dot(op, i, delta_old, order);
     const double rn = DSUB(r[i], acc);
     r[i] = rn;
     const double p = DMUL(rn, dinv[i]);
     if (fabs(p) >= theta) {
         delta_new[i] = p;
         next[atomicAdd(next_count, 1u)] = i;
+    }
+}
+
+// thread per candidate row; rows with more than SL_LONG_ROW entries are deferred to sl_pull_long_kernel
+// (cand is reused as the deferred list: slot indices [0, *long_count) are overwritten only after being read)
+__global__ __launch_bounds__(256) void sl_pull_kernel(uint32_t nc, const uint32_t *cand, op_view op, const double *delta_old,
+                                                      const double *dinv, double theta, int order, double *r,
+                                                      double *delta_new, uint32_t *cand_flag, uint32_t *next, uint32_t *next_count,
+                                                      uint32_t *long_list, uint32_t *long_count)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nc) return;
+    const uint32_t i = cand[t];
+    cand_flag[i] = 0u;
+    if (op.ptr[i + 1] - op.ptr[i] > SL_LONG_ROW) { long_list[atomicAdd(long_count, 1u)] = i; return; }
+    sl_pull_finish(i, sl_csr_row_dot(op, i, delta_old, order), dinv, theta, r, delta_new, next, next_count);
+}
+
+// one wave per deferred long row (persistent: waves stride over the list).  Lanes form the products of 64
+// consecutive entries in parallel; only the NON-ZERO products are then added, in entry order — skipping an
+// exactly-zero product cannot change the running sum (s + (+-0) == s, and s is never -0), so the value equals
+// the sequential reference sum bit for bit while the cost follows the (small) number of frontier columns hit.
+__global__ __launch_bounds__(256) void sl_pull_long_kernel(const uint32_t *long_list, const uint32_t *long_count, op_view op,
+                                                           const double *delta_old, const double *dinv, double theta, int order,
+                                                           double *r, double *delta_new, uint32_t *next, uint32_t *next_count)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const uint32_t n_long = *long_count;
+    for (uint32_t t = wave; t < n_long; t += nwaves) {
+        const uint32_t i = long_list[t];
+        const uint32_t s = op.ptr[i], e = op.ptr[i + 1], len = e - s;
+        const uint32_t chunks4 = (order == SL_ORDER_SIMD4) ? ((len >> 2) << 2) : 0u;
+        double sum = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+        bool merged = false;
+        for (uint32_t base = s; base < e; base += 64) {
+            const uint32_t k = base + lane;
+            const double p = k < e ? DMUL(op.val[k], delta_old[op.idx[k]]) : 0.0;
+            unsigned long long mask = __ballot(p != 0.0);
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const double pv = __shfl(p, l);
+                const uint32_t q = base - s + (uint32_t)l;
+                if (q < chunks4) {
+                    const uint32_t ln = q & 3u;
+                    if (ln == 0) l0 = DADD(l0, pv); else if (ln == 1) l1 = DADD(l1, pv); else if (ln == 2) l2 = DADD(l2, pv); else l3 = DADD(l3, pv);
+                } else {
+                    if (order == SL_ORDER_SIMD4 && !merged) { sum = DADD(DADD(DADD(l0, l1), l2), l3); merged = true; }
+                    sum = DADD(sum, pv);
+                }
+            }
+        }
+        if (order == SL_ORDER_SIMD4 && !merged) sum = DADD(DADD(DADD(l0, l1), l2), l3);
+        if (lane == 0) sl_pull_finish(i, sum, dinv, theta, r, delta_new, next, next_count);
     }
 }
 
@@ -219,7 +272,8 @@ struct push_state {
     double *delta[2] = {nullptr, nullptr};
     uint32_t *frontier[2] = {nullptr, nullptr}; // cur / next
     uint32_t *cand = nullptr, *cand_flag = nullptr;
-    uint32_t *counters = nullptr;               // [0] cand_count, [1] next_count, [2] compaction total
+    uint32_t *counters = nullptr;               // [0] cand_count, [1] next_count, [2] compaction total, [3] deferred long rows
+    uint32_t *long_list = nullptr;
     uint32_t *block_count = nullptr, *block_off = nullptr;
     uint32_t nblocks = 0;
 };
@@ -284,7 +338,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s));
     bool list_valid = true, list_sorted = true;
     double *scr = nullptr;
-    if (m) { scr = static_cast<double *>(sl_scratch(((size_t)sl_row_grid(m->n_slices) * 2 + 4096) * sizeof(double))); if (!scr) return sl_fail(SL_ALLOCATION, "scratch"); }
+    if (m) { scr = static_cast<double *>(sl_scratch((((size_t)sl_row_grid(m->n_slices) + m->n_long) * 2 + 4096) * sizeof(double))); if (!scr) return sl_fail(SL_ALLOCATION, "scratch"); }
     DevBuf resbuf;
     SL_TRY(resbuf.alloc(64));
 
@@ -320,13 +374,18 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
             if (!list_valid) { SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s)); list_valid = true; list_sorted = true;
                                SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s)); }
             SL_HIP(hipMemsetAsync(ps.counters, 0, 2 * sizeof(uint32_t), s));
-            hipLaunchKernelGGL(sl_expand_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, nf, ps.frontier[0], ps.op, ps.delta[cur], ps.x,
+            SL_HIP(hipMemsetAsync(ps.counters + 3, 0, sizeof(uint32_t), s));
+            hipLaunchKernelGGL(sl_expand_kernel, dim3((nf + 3) / 4), dim3(256), 0, s, nf, ps.frontier[0], ps.op, ps.delta[cur], ps.x,
                                ps.cand_flag, ps.cand, ps.counters);
             uint32_t nc = 0;
             SL_HIP(hipMemcpyAsync(&nc, ps.counters, 4, hipMemcpyDeviceToHost, s));
             SL_HIP(hipStreamSynchronize(s));
-            if (nc) hipLaunchKernelGGL(sl_pull_kernel, dim3((nc + 255) / 256), dim3(256), 0, s, nc, ps.cand, ps.op, ps.delta[cur], ps.dinv,
-                                       theta, order, ps.r, ps.delta[1 - cur], ps.cand_flag, ps.frontier[1], ps.counters + 1);
+            if (nc) {
+                hipLaunchKernelGGL(sl_pull_kernel, dim3((nc + 255) / 256), dim3(256), 0, s, nc, ps.cand, ps.op, ps.delta[cur], ps.dinv,
+                                   theta, order, ps.r, ps.delta[1 - cur], ps.cand_flag, ps.frontier[1], ps.counters + 1, ps.long_list, ps.counters + 3);
+                hipLaunchKernelGGL(sl_pull_long_kernel, dim3(nc < 4096u ? (nc + 3) / 4 : 1024u), dim3(256), 0, s, ps.long_list, ps.counters + 3, ps.op,
+                                   ps.delta[cur], ps.dinv, theta, order, ps.r, ps.delta[1 - cur], ps.frontier[1], ps.counters + 1);
+            }
             hipLaunchKernelGGL(sl_clear_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, nf, ps.frontier[0], ps.delta[cur]);
             uint32_t nn = 0;
             SL_HIP(hipMemcpyAsync(&nn, ps.counters + 1, 4, hipMemcpyDeviceToHost, s));
@@ -346,7 +405,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     return st;
 }
 
-sl_status alloc_state(push_state &ps, uint64_t n, DevBuf bufs[12])
+sl_status alloc_state(push_state &ps, uint64_t n, DevBuf bufs[16])
 {
     ps.n = n;
     ps.nblocks = (uint32_t)((n + SL_CTILE - 1) / SL_CTILE);
@@ -361,6 +420,7 @@ sl_status alloc_state(push_state &ps, uint64_t n, DevBuf bufs[12])
     SL_TRY(bufs[k].alloc(n * 4)); ps.frontier[1] = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.cand = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.cand_flag = bufs[k++].as<uint32_t>();
+    SL_TRY(bufs[k].alloc(n * 4)); ps.long_list = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(64)); ps.counters = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc((size_t)ps.nblocks * 4)); ps.block_count = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc((size_t)ps.nblocks * 4)); ps.block_off = bufs[k++].as<uint32_t>();
@@ -397,7 +457,7 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
     const hipMemcpyKind out_kind = o->mem == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
 
     push_state ps;
-    DevBuf bufs[12], bbuf, ax;
+    DevBuf bufs[16], bbuf, ax;
     SL_TRY(alloc_state(ps, n, bufs));
     ps.op = op_view{m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_trow};
     SL_TRY(bbuf.alloc(n * 8));
@@ -448,7 +508,7 @@ static sl_status estimate_entry_impl(const sl_matrix *m, const double *b, sl_mem
     const uint64_t n = m->n_rows;
     hipStream_t s = sl_context().stream;
     push_state ps;
-    DevBuf bufs[12], bbuf;
+    DevBuf bufs[16], bbuf;
     SL_TRY(alloc_state(ps, n, bufs));
     unsigned long long hs[4];
     if (given_is_transpose) {

@@ -19,6 +19,10 @@
 #define SL_SLICE 64
 #define SL_BLOCK 256
 #define SL_WAVES_PER_BLOCK (SL_BLOCK / SL_SLICE)
+// rows longer than this leave the slice layout (one hub row would stretch its whole 64-row slice): they are
+// reduced by the long-row kernel, one block per row, products in parallel, additions in the reference order
+#define SL_LONG_ROW 256u
+#define SL_LONG_SENTINEL 0xffffffffu   // row_len[] value of such a row
 
 struct sl_matrix {
     uint64_t n_rows = 0, n_cols = 0, nnz = 0, row_offset = 0;
@@ -39,6 +43,8 @@ struct sl_matrix {
     // transpose as CSR of A^T (SL_MATRIX_WITH_TRANSPOSE): rows of each column ascending
     uint32_t *d_tptr = nullptr; // [n_cols+1]
     uint32_t *d_trow = nullptr; // [nnz]
+    uint32_t *d_long_rows = nullptr; // ascending local ids of the rows with more than SL_LONG_ROW entries
+    uint64_t n_long = 0;
     double *d_tval = nullptr;   // [nnz]
     uint64_t device_bytes = 0;
 };
@@ -71,6 +77,11 @@ struct sl_row_args {
     // matrix
     const uint32_t *slice_ptr, *row_len, *cols;
     const uint16_t *cols16;   // null unless the matrix carries 16-bit column offsets
+    const uint32_t *csr_ptr, *csr_idx;   // raw CSR (long rows only)
+    const double *csr_val;
+    const uint32_t *long_rows;
+    uint32_t n_long;
+    uint32_t part_stride;     // partial slots per set (set by the launcher): main grid + n_long
     const double *vals;
     uint64_t n_rows, n_cols, n_slices, row_offset;
     uint64_t bandwidth;   // ~0 = unknown / do not use the LDS band kernel

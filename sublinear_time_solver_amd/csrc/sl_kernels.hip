@@ -67,8 +67,10 @@ __device__ __forceinline__ double sl_row_walk(const sl_row_args &a, uint64_t s, 
     } else {
         const uint32_t q0 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s]);
         const uint32_t q1 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s + 1]);
-        const uint32_t len = a.row_len[i];
+        const uint32_t len_raw = a.row_len[i];
+        const uint32_t len = len_raw == SL_LONG_SENTINEL ? 0u : len_raw;     // long rows: sl_long_rows_kernel
         if constexpr (ORDER == 0) {
+#pragma unroll 2
             for (uint32_t q = q0; q < q1; ++q) {
                 const u32x4 c = __builtin_nontemporal_load(&cq[(uint64_t)q * 64 + lane]);
                 const f64x2 va = __builtin_nontemporal_load(&vq[((uint64_t)q * 2) * 64 + lane]);
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32
     const uint64_t s = (uint64_t)lb * SL_WAVES_PER_BLOCK + wave;
     const uint64_t i = s * SL_SLICE + lane;
     const bool live_slice = s < a.n_slices;
-    const bool live = live_slice && i < a.n_rows;
+    bool live = live_slice && i < a.n_rows;
+    if constexpr (UW == 0) { if (live && a.n_long && a.row_len[i] == SL_LONG_SENTINEL) live = false; }
     const double *__restrict__ g = a.gather;
 
     // epilogue operands are fetched up front so their latency hides under the row walk
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32
     if (live_slice) sum = sl_row_walk<ORDER, UW>(a, s, lane, i, [g](uint32_t c) { return g[c]; });
     double part0 = 0.0, part1 = 0.0;
     if (live) sl_row_epilogue<EPI>(a, i, sum, e_t, e_d, e_x, dself, part0, part1);
-    sl_block_partials<EPI>(a, red, lane, wave, lb, nb8 * 8, part0, part1);
+    sl_block_partials<EPI>(a, red, lane, wave, lb, a.part_stride, part0, part1);
 }
 
 // ---- band kernel: gathers served by an LDS-staged window of the gathered vector -----------------
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
                 const uint64_t s = s0 + (uint64_t)j * NW;
                 if (s >= a.n_slices) break;
                 const uint64_t i = s * SL_SLICE + lane;
-                const bool live = i < a.n_rows;
+                bool live = i < a.n_rows;
+                if (live && a.n_long && a.row_len[i] == SL_LONG_SENTINEL) live = false;
                 double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
                 if (live) {
                     if constexpr (EPI == SL_EPI_NEUMANN) { e_t = lw[(uint32_t)(a.row_offset + i) - base]; e_d = a.dinv[i]; e_x = a.x[i]; }
@@ -363,7 +367,60 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
             }
         }
     }
-    sl_block_partials<EPI>(a, red, lane, wave, lb, nb8 * 8, part0, part1);
+    sl_block_partials<EPI>(a, red, lane, wave, lb, a.part_stride, part0, part1);
+}
+
+// ---- long rows: one block per row ------------------------------------------------------------------
+// Rows with more than SL_LONG_ROW entries (hubs of power-law graphs).  The 256 threads fetch the raw CSR
+// entries coalesced and form the products in parallel; the additions stay sequential in the reference's
+// order (thread 0 walks the products through LDS), so the result is bit-identical to the slice path.
+template <int ORDER, int EPI>
+__global__ __launch_bounds__(SL_BLOCK) void sl_long_rows_kernel(sl_row_args a, uint32_t slot0)
+{
+    __shared__ double prod[SL_BLOCK];
+    const uint32_t i = a.long_rows[blockIdx.x];
+    const double *__restrict__ g = a.gather;
+    const uint32_t s = a.csr_ptr[i], e = a.csr_ptr[i + 1], len = e - s;
+    const uint32_t chunks4 = (ORDER == 1) ? ((len >> 2) << 2) : 0u;     // entries covered by full simd chunks (len >= 8 here)
+    double sum = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+    bool merged = false;
+    for (uint32_t base = s; base < e; base += SL_BLOCK) {
+        const uint32_t k = base + threadIdx.x;
+        prod[threadIdx.x] = k < e ? DMUL(a.csr_val[k], g[a.csr_idx[k]]) : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t cnt = (e - base) < SL_BLOCK ? (e - base) : SL_BLOCK;
+            if constexpr (ORDER == 0) {
+#pragma unroll 8
+                for (uint32_t j = 0; j < cnt; ++j) sum = DADD(sum, prod[j]);
+            } else {
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint32_t q = base - s + j;
+                    const double p = prod[j];
+                    if (q < chunks4) {
+                        const uint32_t ln = q & 3u;
+                        if (ln == 0) l0 = DADD(l0, p); else if (ln == 1) l1 = DADD(l1, p); else if (ln == 2) l2 = DADD(l2, p); else l3 = DADD(l3, p);
+                    } else {
+                        if (!merged) { sum = DADD(DADD(DADD(l0, l1), l2), l3); merged = true; }
+                        sum = DADD(sum, p);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if constexpr (ORDER == 1) { if (!merged) sum = DADD(DADD(DADD(l0, l1), l2), l3); }
+        double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0, part0 = 0.0, part1 = 0.0;
+        if constexpr (EPI == SL_EPI_NEUMANN) { e_t = g[a.row_offset + i]; e_d = a.dinv[i]; e_x = a.x[i]; }
+        else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
+        else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = g[a.row_offset + i]; }
+        sl_row_epilogue<EPI>(a, i, sum, e_t, e_d, e_x, dself, part0, part1);
+        if constexpr (EPI != SL_EPI_SPMV) {
+            a.partials[slot0 + blockIdx.x] = part0;
+            if constexpr (EPI == SL_EPI_PUSH) a.partials[(uint64_t)a.part_stride + slot0 + blockIdx.x] = part1;
+        }
+    }
 }
 
 // fixed-order final reduction of per-block partials: thread j sums partials j, j+1024, ...
@@ -450,15 +507,17 @@ static sl_status launch_band_u(const sl_row_args &a, const band_geom &g, uint32_
 }
 
 template <int ORDER, int EPI>
-static sl_status launch_rows_t(const sl_row_args &a, hipStream_t s, uint32_t *nparts)
+static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t *nparts)
 {
+    sl_row_args a = a_in;
     const band_geom g = band_geometry(a);
     if (g.spw) {
         const uint64_t per_block = (uint64_t)SL_WAVES_PER_BLOCK * g.spw;
         const uint64_t nb = (a.n_slices + per_block - 1) / per_block;
         const uint32_t nb8 = (uint32_t)((nb + 7) / 8);
         const uint32_t grid = nb8 * 8;
-        *nparts = grid;
+        *nparts = grid + a.n_long;
+        a.part_stride = *nparts;
         sl_status st;
         if (ORDER == 0 && a.uniform_width == 16) st = launch_band_u<ORDER, EPI, 16>(a, g, grid, nb8, s);
         else if (ORDER == 0 && a.uniform_width == 8) st = launch_band_u<ORDER, EPI, 8>(a, g, grid, nb8, s);
@@ -466,7 +525,8 @@ static sl_status launch_rows_t(const sl_row_args &a, hipStream_t s, uint32_t *np
         if (st != SL_OK) return st;
     } else {
         const uint32_t grid = sl_row_grid(a.n_slices), nb8 = grid / 8;
-        *nparts = grid;
+        *nparts = grid + a.n_long;
+        a.part_stride = *nparts;
         if (ORDER == 0 && a.uniform_width == 16)
             hipLaunchKernelGGL((sl_rows_kernel<0, EPI, 16>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
         else if (ORDER == 0 && a.uniform_width == 8)
@@ -474,6 +534,8 @@ static sl_status launch_rows_t(const sl_row_args &a, hipStream_t s, uint32_t *np
         else
             hipLaunchKernelGGL((sl_rows_kernel<ORDER, EPI, 0>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
     }
+    if (a.n_long)
+        hipLaunchKernelGGL((sl_long_rows_kernel<ORDER, EPI>), dim3(a.n_long), dim3(SL_BLOCK), 0, s, a, *nparts - a.n_long);
     SL_HIP(hipGetLastError());
     return SL_OK;
 }

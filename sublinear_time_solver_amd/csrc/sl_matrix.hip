@@ -32,9 +32,11 @@ __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64
         len = row_ptr[i + 1] - row_ptr[i];
         atomicMin(&minmax[0], len);
         atomicMax(&minmax[1], len);
+        if (len > SL_LONG_ROW) atomicAdd(&minmax[2], 1u);
     }
-    row_len[i] = len;
-    uint32_t mx = len;
+    const bool is_long = len > SL_LONG_ROW;          // leaves the slice layout (sl_long_rows_kernel owns it)
+    row_len[i] = is_long ? SL_LONG_SENTINEL : len;
+    uint32_t mx = is_long ? 0u : len;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t other = __shfl_xor(mx, o);
@@ -49,8 +51,8 @@ __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64
 __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, uint64_t n_cols, uint64_t n_slices,
                                                              uint64_t row_offset, const uint32_t *row_ptr,
                                                              const uint32_t *col_idx, const double *values,
-                                                             const uint32_t *slice_ptr, uint32_t *cols, double *vals,
-                                                             unsigned long long *band)
+                                                             const uint32_t *slice_ptr, const uint32_t *row_len, uint32_t *cols,
+                                                             double *vals, unsigned long long *band)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, ui
     uint32_t padcol = gi < n_cols ? (uint32_t)gi : 0u;
     if (i < n_rows) {
         start = row_ptr[i];
-        len = row_ptr[i + 1] - start;
+        len = row_len[i] == SL_LONG_SENTINEL ? 0u : row_len[i];
     }
     unsigned long long bw = 0;
     for (uint32_t q = q0; q < q1; ++q) {
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256) void sl_diag_kernel(uint64_t n_rows, uint64_t 
     if (s >= n_slices) return;
     const uint64_t i = s * 64 + lane;
     const uint32_t q0 = slice_ptr[s], q1 = slice_ptr[s + 1];
+    if (row_len[i] == SL_LONG_SENTINEL) return;     // sl_long_diag_kernel handles it
     const uint32_t len = row_len[i];
     const uint32_t gi = (uint32_t)(row_offset + i);
     double diag_abs = 0.0, off = 0.0, d = 0.0;
@@ -139,6 +142,34 @@ __global__ __launch_bounds__(256) void sl_diag_kernel(uint64_t n_rows, uint64_t 
     else if (fabs(d) < 1e-14) { atomicOr(&status[0], 4ull); atomicMin(&status[3], (unsigned long long)i); }
     if (dinv) dinv[i] = (found && fabs(d) >= 1e-14) ? 1.0 / d : 0.0;
 }
+
+// the same a6 + a7 rules for the long rows, over their raw CSR entries (thread per row; one-off)
+__global__ void sl_long_diag_kernel(uint32_t n_long, const uint32_t *long_rows, uint64_t row_offset, const uint32_t *row_ptr,
+                                    const uint32_t *col_idx, const double *values, double *dinv, unsigned long long *status)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_long) return;
+    const uint32_t i = long_rows[t];
+    const uint32_t gi = (uint32_t)(row_offset + i);
+    double diag_abs = 0.0, off = 0.0, d = 0.0;
+    bool found = false;
+    for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+        const double v = values[k];
+        if (col_idx[k] == gi) { diag_abs = fabs(v); d = v; found = true; }
+        else off = __dadd_rn(off, fabs(v));
+    }
+    if (diag_abs < off) { atomicOr(&status[0], 1ull); atomicMin(&status[1], (unsigned long long)i); }
+    if (!found) { atomicOr(&status[0], 2ull); atomicMin(&status[2], (unsigned long long)i); }
+    else if (fabs(d) < 1e-14) { atomicOr(&status[0], 4ull); atomicMin(&status[3], (unsigned long long)i); }
+    if (dinv) dinv[i] = (found && fabs(d) >= 1e-14) ? 1.0 / d : 0.0;
+}
+__global__ void sl_long_collect_kernel(uint64_t n_rows, const uint32_t *row_len, uint32_t *list, uint32_t *count)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += stride)
+        if (row_len[i] == SL_LONG_SENTINEL) list[atomicAdd(count, 1u)] = (uint32_t)i;
+}
+sl_status sl_sort_keys_u32(const uint32_t *keys_in, uint32_t *keys_out, uint64_t n, hipStream_t s);
 
 // transpose (CSR of A^T, values included, rows of each column ascending): histogram of
 // columns -> tptr; stable radix sort of (col, entry id) pairs -> entry order; gather.
@@ -205,21 +236,32 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     uint32_t *d_slice_w = nullptr;
     SL_HIP(hipMalloc(&m->d_row_len, (padded_rows ? padded_rows : 1) * sizeof(uint32_t)));
     SL_HIP(hipMalloc(&d_slice_w, (m->n_slices ? m->n_slices : 1) * sizeof(uint32_t)));
-    const uint32_t mm_init[2] = {0xffffffffu, 0u};
+    const uint32_t mm_init[4] = {0xffffffffu, 0u, 0u, 0u};
     SL_HIP(hipMemcpyAsync(d_err, mm_init, sizeof(mm_init), hipMemcpyHostToDevice, st));
     if (m->n_slices)
         hipLaunchKernelGGL(sl_row_len_kernel, dim3((uint32_t)((padded_rows + 255) / 256)), dim3(256), 0, st, n, m->n_slices,
                            d_row_ptr, m->d_row_len, d_slice_w, d_err);
     std::vector<uint32_t> slice_w(m->n_slices), slice_ptr(m->n_slices + 1);
-    uint32_t mm[2];
+    uint32_t mm[4];
     SL_HIP(hipMemcpyAsync(mm, d_err, sizeof(mm), hipMemcpyDeviceToHost, st));
     if (m->n_slices)
         SL_HIP(hipMemcpyAsync(slice_w.data(), d_slice_w, m->n_slices * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
     hipFree(d_slice_w);
-    hipFree(d_err);
     m->min_row_nnz = n ? mm[0] : 0;
     m->max_row_nnz = n ? mm[1] : 0;
+    m->n_long = n ? mm[2] : 0;
+    if (m->n_long) {                                 // ascending list of the long rows (deterministic partial slots)
+        uint32_t *d_tmp = nullptr;
+        SL_HIP(hipMalloc(&d_tmp, m->n_long * sizeof(uint32_t)));
+        SL_HIP(hipMalloc(&m->d_long_rows, m->n_long * sizeof(uint32_t)));
+        SL_HIP(hipMemsetAsync(d_err, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(sl_long_collect_kernel, dim3(1024), dim3(256), 0, st, n, m->d_row_len, d_tmp, d_err);
+        sl_status ss = sl_sort_keys_u32(d_tmp, m->d_long_rows, m->n_long, st);
+        hipFree(d_tmp);
+        if (ss != SL_OK) { hipFree(d_err); return ss; }
+    }
+    hipFree(d_err);
     uint64_t acc = 0;
     for (uint64_t s = 0; s < m->n_slices; ++s) { slice_ptr[s] = (uint32_t)acc; acc += slice_w[s]; }
     if (acc > 0xffffffffull) return sl_fail(SL_ALLOCATION, "matrix too large for 32-bit slice pointers");
@@ -236,7 +278,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     SL_HIP(hipMemsetAsync(d_band, 0, sizeof(unsigned long long), st));
     if (m->n_slices)
         hipLaunchKernelGGL(sl_fill_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_cols,
-                           m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_cols, m->d_vals, d_band);
+                           m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_band);
     SL_HIP(hipGetLastError());
     unsigned long long h_band = 0;
     SL_HIP(hipMemcpyAsync(&h_band, d_band, sizeof(h_band), hipMemcpyDeviceToHost, st));
@@ -285,8 +327,8 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         m->device_bytes += (m->n_cols + 1) * sizeof(uint32_t) + nnz * 12;
     }
 
-    // 4. raw CSR copy
-    if (keep_csr_copy) {
+    // 4. raw CSR copy (also needed by the long-row kernel)
+    if (keep_csr_copy || (m->n_long && !m->d_row_ptr)) {
         SL_HIP(hipMalloc(&m->d_row_ptr, (n + 1) * sizeof(uint32_t)));
         SL_HIP(hipMalloc(&m->d_col_idx, (nnz ? nnz : 1) * sizeof(uint32_t)));
         SL_HIP(hipMalloc(&m->d_values, (nnz ? nnz : 1) * sizeof(double)));
@@ -312,6 +354,9 @@ sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long 
     if (m->n_slices)
         hipLaunchKernelGGL(sl_diag_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, m->n_rows, m->n_slices,
                            m->row_offset, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_dinv, d_status);
+    if (m->n_long)
+        hipLaunchKernelGGL(sl_long_diag_kernel, dim3((uint32_t)((m->n_long + 63) / 64)), dim3(64), 0, st, (uint32_t)m->n_long, m->d_long_rows,
+                           m->row_offset, m->d_row_ptr, m->d_col_idx, m->d_values, d_dinv, d_status);
     SL_HIP(hipMemcpyAsync(h_status, d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
     hipFree(d_status);

@@ -1,0 +1,85 @@
+"""Rows longer than SL_LONG_ROW (hubs of power-law graphs) leave the slice layout and are reduced by the
+long-row kernels; their results must stay bit-identical to the sequential reference order."""
+import numpy as np
+import pytest
+
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import _lib as L
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits_equal(a, b):
+    return (np.ascontiguousarray(a).view(np.uint64) == np.ascontiguousarray(b).view(np.uint64)).all()
+
+
+def _hub_system(n=3000, seed=5):
+    """row dominant, ragged: most rows 3..12 entries, every 97th row 300..1500, one row almost dense"""
+    rng = np.random.default_rng(seed)
+    tr, tc, tv = [], [], []
+    for i in range(n):
+        m = int(rng.integers(3, 13))
+        if i % 97 == 0:
+            m = int(rng.integers(300, 1500))
+        if i == 1234:
+            m = n - 7
+        cols = np.sort(rng.choice(n, size=min(m, n - 1), replace=False))
+        cols = cols[cols != i]
+        vals = rng.uniform(-1.0, 1.0, size=cols.size)
+        d = 2.0 * np.abs(vals).sum() + 1.0
+        pos = int(np.searchsorted(cols, i))
+        cols = np.insert(cols, pos, i)
+        vals = np.insert(vals, pos, d)
+        tr += [i] * cols.size
+        tc += cols.tolist()
+        tv += vals.tolist()
+    return O.csr_from_triplets(tr, tc, tv, n, n)
+
+
+def test_long_rows_spmv_neumann_both_orders(gpu):
+    rp, ci, va = _hub_system()
+    n = rp.size - 1
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    assert m.info().max_row_nnz > 256 and m.is_diagonally_dominant()
+    x = np.sin(np.arange(n) * 0.37) + 0.1
+    b = 1.0 + (np.arange(n) % 13) * 0.25
+    dinv, _ = O.neumann_init(rp, ci, va, b)
+    assert _bits_equal(m.diagonal_inverse(), dinv)
+    for order, oorder in ((L.SL_ORDER_CSR_SEQUENTIAL, O.ORDER_SEQ), (L.SL_ORDER_SIMD4, O.ORDER_SIMD4)):
+        assert _bits_equal(m.multiply_vector(x, order), O.spmv(rp, ci, va, x, oorder))
+        g = S.NeumannSolver(order=order).solve(m, b, S.SolverOptions(tolerance=1e-11))
+        o = O.neumann_solve(rp, ci, va, b, tolerance=1e-11, order=oorder)
+        assert g.iterations == o["iterations"] and g.converged
+        assert _bits_equal(g.solution, o["x"])
+        np.testing.assert_allclose(g.term_norms, o["term_norms"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("dense_switch", [2.0, 1.0 / 16.0, 1e-9])
+def test_long_rows_push_bitwise(gpu, dense_switch):
+    rp, ci, va = _hub_system(seed=9)
+    n = rp.size - 1
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    b = np.zeros(n)
+    b[[0, 97, 1234, 2999]] = [1.0, -2.0, 0.5, 3.0]            # frontier starts at hub rows and spreads
+    for order in (0, 1):
+        g = S.PushSolver(theta=1e-10, dense_switch=dense_switch, order=order).solve(m, b, log_frontier=3_000_000)
+        o = O.push_sync_solve(rp, ci, va, b, theta=1e-10, order=order, log_cap=3_000_000)
+        assert g["converged"] and g["rounds"] == o["rounds"] and g["pushes"] == o["pushes"]
+        assert (g["frontier_log"] == o["frontier_log"]).all()
+        assert _bits_equal(g["solution"], o["x"]) and _bits_equal(g["residual"], o["r"])
+    # estimateEntry through both orientations
+    xs = np.linalg.solve(_dense(rp, ci, va), b)
+    mt = m.transpose(with_transpose=True)
+    for row in (0, 1234, 5):
+        e1 = S.estimate_entry(m, b, row, theta=1e-13)
+        e2 = S.estimate_entry(mt, b, row, theta=1e-13, matrix_is_transpose=True)
+        assert abs(e1.estimate - xs[row]) < 1e-9 and e1.estimate == e2.estimate
+
+
+def _dense(rp, ci, va):
+    n = rp.size - 1
+    A = np.zeros((n, n))
+    for i in range(n):
+        A[i, ci[rp[i]:rp[i + 1]]] = va[rp[i]:rp[i + 1]]
+    return A

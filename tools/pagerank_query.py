@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--n", type=int, default=10_000_000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--alpha", type=float, default=0.85)
-    ap.add_argument("--theta", type=float, default=1e-9)
+    ap.add_argument("--thetas", type=str, default="1e-5,1e-7,1e-9")
     ap.add_argument("--no-full-solve", action="store_true")
     args = ap.parse_args()
     import torch
@@ -60,10 +60,10 @@ def main():
                              "device_ms": res.device_time_ms, "wall_s": time.perf_counter() - t1, "sum_x": float(x.sum()),
                              "padded_over_nnz": A.info().padded_nnz / A.info().nnz}
     xinf = float(x.abs().max()) if x is not None else None
-    for row in rows:
+    for row, theta in [(r, float(t)) for r in rows for t in args.thetas.split(",")]:
         t2 = time.perf_counter()
-        e = S.estimate_entry(M, b, row, theta=args.theta, max_rounds=100000, matrix_is_transpose=True, device=True)
-        q = {"row": row, "estimate": e.estimate, "residual_l1": e.residual_l1, "rounds": int(e.rounds), "pushes": int(e.pushes),
+        e = S.estimate_entry(M, b, row, theta=theta, max_rounds=100000, matrix_is_transpose=True, device=True)
+        q = {"row": row, "theta": theta, "estimate": e.estimate, "residual_l1": e.residual_l1, "rounds": int(e.rounds), "pushes": int(e.pushes),
              "rows_touched": int(e.rows_touched), "touched_per_round_over_n": e.rows_touched / max(1, e.rounds) / n,
              "device_ms": e.device_time_ms, "wall_ms": (time.perf_counter() - t2) * 1e3, "converged": bool(e.converged)}
         if x is not None:
