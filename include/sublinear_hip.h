@@ -243,6 +243,26 @@ sl_status sl_estimate_entry_transposed(const sl_matrix *mt, const double *b, sl_
  * adjacency.rs:212-224).  `m` must have been created WITH_TRANSPOSE. */
 sl_status sl_matrix_transpose(const sl_matrix *m, uint32_t flags, sl_matrix **out);
 
+/* ---- conjugate gradient behind the same SpMV ------------------------------------------
+ * OptimizedConjugateGradientSolver::solve (src/optimized_solver.rs:182-295) == FastConjugateGradient::solve
+ * (src/fast_solver.rs:126-178): x0 = 0, r = p = b, stop at r.r <= tolerance^2, break when |p.Ap| < 1e-16. */
+typedef struct {
+    double tolerance;        /* OptimizedSolverConfig.tolerance (1e-6), optimized_solver.rs:119-127 */
+    uint64_t max_iterations; /* OptimizedSolverConfig.max_iterations (1000) */
+    int32_t order;           /* sl_order of the SpMV */
+    int32_t mem;             /* sl_mem of b / x_out */
+} sl_cg_options;
+void sl_cg_options_default(sl_cg_options *o);
+typedef struct {
+    uint64_t iterations;     /* OptimizedSolverResult.iterations */
+    uint64_t matvec_count;   /* OptimizedSolverStats.matvec_count */
+    double residual_norm;    /* sqrt(r.r) */
+    double total_time_ms, device_time_ms;
+    int32_t converged;
+    int32_t reserved;
+} sl_cg_result;
+sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *opts, double *x_out, sl_cg_result *result);
+
 /* ---- synthetic inputs, generated in HBM (bench / tests) -------------------
  * S-DD(n, k, seed, w): rows [row_lo, row_hi) of the seeded diagonally dominant system;
  * writes device arrays: row_ptr (rows+1), col_idx / values (rows*k), b (rows). */

@@ -299,3 +299,17 @@ def dense_to_csr(A):
     A = np.asarray(A, dtype=np.float64)
     rr, cc = np.nonzero(A)
     return csr_from_triplets(rr, cc, A[rr, cc], A.shape[0], A.shape[1])
+
+
+def cg_solve(rp, ci, va, b, tolerance=1e-6, max_iterations=1000, order=ORDER_SEQ):
+    """OptimizedConjugateGradientSolver::solve (optimized_solver.rs:182-295) restatement."""
+    rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
+    n = rp.size - 1
+    x = np.zeros(n)
+    it, mv = u64(0), u64(0)
+    res, conv = f64(0), C.c_int(0)
+    st = lib().orc_cg_solve(u64(n), _p(rp), _p(ci), _p(va), _p(b), f64(tolerance), u64(max_iterations), C.c_int(order), _p(x),
+                            C.byref(it), C.byref(res), C.byref(conv), C.byref(mv))
+    if st:
+        raise OracleError(st)
+    return {"x": x, "iterations": it.value, "residual_norm": res.value, "converged": bool(conv.value), "matvec_count": mv.value}

@@ -731,3 +731,45 @@ int orc_ts_random_walk_estimate(uint64_t n, const uint32_t *row_ptr, const uint3
     free(absorb); free(diag); free(est);
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------ (f-1) CG -- */
+
+/* OptimizedConjugateGradientSolver::solve (src/optimized_solver.rs:182-295) == FastConjugateGradient::solve
+ * (src/fast_solver.rs:126-178): x0 = 0, r = p = b, sequential dot products, stop when rsold <= tol^2,
+ * break when |p.Ap| < 1e-16.  order selects the SpMV (simd feature on: simd_ops.rs:20-88). */
+int orc_cg_solve(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, const double *b,
+                 double tolerance, uint64_t max_iterations, int order, double *x, uint64_t *iterations,
+                 double *residual_norm, int *converged, uint64_t *matvec_count)
+{
+    double *r = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *p = (double *)malloc((n ? n : 1) * sizeof(double));
+    double *ap = (double *)malloc((n ? n : 1) * sizeof(double));
+    if (!r || !p || !ap) { free(r); free(p); free(ap); return ORC_ALLOCATION; }
+    for (uint64_t i = 0; i < n; ++i) { x[i] = 0.0; r[i] = b[i]; p[i] = b[i]; }
+    const double tol_sq = tolerance * tolerance;
+    double rsold = 0.0;
+    for (uint64_t i = 0; i < n; ++i) { double q = r[i] * r[i]; rsold = rsold + q; }
+    uint64_t it = 0, mv = 0;
+    int conv = 0;
+    while (it < max_iterations) {
+        if (rsold <= tol_sq) { conv = 1; break; }
+        if (order == ORC_ORDER_SIMD4) orc_spmv_simd4(n, row_ptr, col_idx, values, p, ap);
+        else orc_spmv_csr_sequential(n, row_ptr, col_idx, values, p, ap);
+        ++mv;
+        double pap = 0.0;
+        for (uint64_t i = 0; i < n; ++i) { double q = p[i] * ap[i]; pap = pap + q; }
+        if (fabs(pap) < 1e-16) break;
+        const double alpha = rsold / pap;
+        for (uint64_t i = 0; i < n; ++i) { double q = alpha * p[i]; x[i] = x[i] + q; }
+        for (uint64_t i = 0; i < n; ++i) { double q = alpha * ap[i]; r[i] = r[i] - q; }
+        double rsnew = 0.0;
+        for (uint64_t i = 0; i < n; ++i) { double q = r[i] * r[i]; rsnew = rsnew + q; }
+        const double beta = rsnew / rsold;
+        for (uint64_t i = 0; i < n; ++i) { double q = beta * p[i]; p[i] = r[i] + q; }
+        rsold = rsnew;
+        ++it;
+    }
+    *iterations = it; *residual_norm = sqrt(rsold); *converged = conv; *matvec_count = mv;
+    free(r); free(p); free(ap);
+    return ORC_OK;
+}

@@ -61,6 +61,15 @@ class EstimateResult(C.Structure):
                 ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
 
 
+class CgOptions(C.Structure):
+    _fields_ = [("tolerance", f64), ("max_iterations", u64), ("order", i32), ("mem", i32)]
+
+
+class CgResult(C.Structure):
+    _fields_ = [("iterations", u64), ("matvec_count", u64), ("residual_norm", f64), ("total_time_ms", f64),
+                ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
+
+
 # every symbol include/sublinear_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "sl_abi_version": (C.c_int, []),
@@ -90,6 +99,8 @@ SIGNATURES = {
                                 C.POINTER(PushResult)]),
     "sl_estimate_entry": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
     "sl_synth_sdd_device": (C.c_int, [u64, u32, u64, u64, u64, u64, vp, vp, vp, vp]),
+    "sl_cg_options_default": (None, [C.POINTER(CgOptions)]),
+    "sl_cg_solve": (C.c_int, [vp, vp, C.POINTER(CgOptions), vp, C.POINTER(CgResult)]),
     "sl_estimate_entry_transposed": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
     "sl_matrix_transpose": (C.c_int, [vp, u32, C.POINTER(vp)]),
     "sl_synth_pagerank_device": (C.c_int, [u64, u64, f64, u32, u32, vp, vp, vp, C.POINTER(u64)]),

@@ -239,6 +239,31 @@ class NeumannSolver:
 
 
 @dataclass
+class ConjugateGradientSolver:
+    """OptimizedConjugateGradientSolver (src/optimized_solver.rs:167-295; config defaults :119-127) and
+    FastConjugateGradient (src/fast_solver.rs:110-178) over sl_cg_solve."""
+    max_iterations: int = 1000
+    tolerance: float = 1e-6
+    order: int = L.SL_ORDER_CSR_SEQUENTIAL
+
+    def solve(self, matrix: SparseMatrix, b) -> SolverResult:
+        lib = L.load()
+        b = _f64(b)
+        if not matrix.is_square():
+            raise SolverError(4, "Matrix must be square")                                    # optimized_solver.rs:187-190
+        if b.size != matrix.rows():
+            raise SolverError(5, "Right-hand side vector length must match matrix size")     # :191-193
+        o = L.CgOptions()
+        lib.sl_cg_options_default(C.byref(o))
+        o.tolerance, o.max_iterations, o.order, o.mem = self.tolerance, self.max_iterations, self.order, L.SL_MEM_HOST
+        x = np.empty(matrix.rows(), dtype=np.float64)
+        r = L.CgResult()
+        L.check(lib.sl_cg_solve(matrix._h, L.ptr(b), C.byref(o), L.ptr(x), C.byref(r)))
+        return SolverResult(x, r.residual_norm, int(r.iterations), bool(r.converged), None,
+                            {"matvec_count": int(r.matvec_count), "total_time_ms": r.total_time_ms, "device_time_ms": r.device_time_ms})
+
+
+@dataclass
 class PushSolver:
     """Synchronous thresholded residual push: the data-parallel member of
     ForwardPushSolver::push_node (forward_push.rs:179-216) / TS solveForwardPush (solver.ts:437-522)."""
