@@ -120,3 +120,18 @@ def test_product_package_never_imports_the_oracle():
         if f.suffix in (".py", ".hip", ".hpp", ".cpp", ".h") and f.is_file():
             t = f.read_text()
             assert "oracle" not in t.lower() or f.name == "README.md", f"{f} mentions the oracle"
+
+
+def test_index_width_limits_are_enforced_before_any_device_work():
+    """IndexType = u32 (types.rs:22): dimensions / nnz beyond 2^32-1 are InvalidInput, not a crash."""
+    import ctypes as C
+    lib = L.load()
+    rp = np.zeros(4, dtype=np.uint32)
+    ci = np.zeros(1, dtype=np.uint32)
+    va = np.zeros(1, dtype=np.float64)
+    h = L.vp()
+    for rows, cols, nnz in ((3, 3, 2 ** 32), (2 ** 32 + 1, 3, 1), (3, 2 ** 33, 1)):
+        st = lib.sl_matrix_create_csr(rows, cols, nnz, L.ptr(rp), L.ptr(ci), L.ptr(va), L.SL_MEM_HOST, 0, 0, C.byref(h))
+        assert st == 4 and b"u32" in lib.sl_last_error_message()
+    st = lib.sl_matrix_create_csr(3, 3, 1, None, L.ptr(ci), L.ptr(va), L.SL_MEM_HOST, 0, 0, C.byref(h))
+    assert st == 4

@@ -83,3 +83,26 @@ def _dense(rp, ci, va):
     for i in range(n):
         A[i, ci[rp[i]:rp[i + 1]]] = va[rp[i]:rp[i + 1]]
     return A
+
+
+def test_duplicate_entries_are_kept_and_summed_in_order(gpu):
+    """CSRStorage::from_coo keeps duplicate (row, col) entries as separate consecutive entries (sparse.rs:80-132);
+    SpMV adds them in stored order.  (Off-diagonal duplicates: which duplicate `get(i, i)` returns depends on the
+    Rust binary_search implementation and is left unpinned.)"""
+    tr = [0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 2]
+    tc = [0, 1, 1, 2, 0, 1, 0, 2, 1, 1, 1]
+    tv = [9.0, 0.5, 0.25, -1.0, 0.125, 7.0, -0.5, 5.0, 1e-3, 1.0, -1.0]
+    m = S.SparseMatrix.from_triplets(zip(tr, tc, tv), 3, 3, keep_csr=True, with_transpose=True)
+    rp, ci, va = m.to_csr()
+    orp, oci, ova = O.csr_from_triplets(tr, tc, tv, 3, 3)
+    assert rp.tolist() == orp.tolist() == [0, 4, 7, 11] and ci.tolist() == oci.tolist() and va.tolist() == ova.tolist()
+    x = np.array([0.1, 0.7, -0.3])
+    for order in (0, 1):
+        assert _bits_equal(m.multiply_vector(x, order), O.spmv(orp, oci, ova, x, order))
+    b = np.array([1.0, 2.0, 3.0])
+    g = S.NeumannSolver().solve(m, b)
+    o = O.neumann_solve(orp, oci, ova, b)
+    assert g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
+    p = S.PushSolver(theta=1e-12).solve(m, b)
+    q = O.push_sync_solve(orp, oci, ova, b, theta=1e-12)
+    assert p["rounds"] == q["rounds"] and _bits_equal(p["solution"], q["x"])
