@@ -243,6 +243,21 @@ sl_status sl_estimate_entry_transposed(const sl_matrix *mt, const double *b, sl_
  * adjacency.rs:212-224).  `m` must have been created WITH_TRANSPOSE. */
 sl_status sl_matrix_transpose(const sl_matrix *m, uint32_t flags, sl_matrix **out);
 
+/* ---- Monte-Carlo branch of estimateEntry ---------------------------------------------
+ * TS estimateEntry with method 'random-walk' (src/core/solver.ts:585-601,630-648; walk rule :390-432):
+ * numSamples = max(100, ceil(1/epsilon^2)) absorbing walks from `row`, one lane per walk, walk s drawing from
+ * its own TS LCG stream createSeededRandom(seed + s) (core/utils.ts:161-168).  num_samples = 0 derives the
+ * count from epsilon.  walk_values (may be NULL) receives the per-walk estimates.  Needs the raw CSR
+ * (SL_MATRIX_KEEP_CSR or SL_MATRIX_WITH_TRANSPOSE). */
+typedef struct {
+    double estimate;         /* mean of the walk values            (solver.ts:630)  */
+    double variance;         /* sample variance, N - 1 denominator (solver.ts:631-633) */
+    uint64_t num_samples;
+    double device_time_ms;
+} sl_walk_result;
+sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double epsilon,
+                                        uint32_t seed, uint64_t num_samples, double *walk_values, sl_walk_result *result);
+
 /* ---- conjugate gradient behind the same SpMV ------------------------------------------
  * OptimizedConjugateGradientSolver::solve (src/optimized_solver.rs:182-295) == FastConjugateGradient::solve
  * (src/fast_solver.rs:126-178): x0 = 0, r = p = b, stop at r.r <= tolerance^2, break when |p.Ap| < 1e-16. */

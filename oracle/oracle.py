@@ -313,3 +313,16 @@ def cg_solve(rp, ci, va, b, tolerance=1e-6, max_iterations=1000, order=ORDER_SEQ
     if st:
         raise OracleError(st)
     return {"x": x, "iterations": it.value, "residual_norm": res.value, "converged": bool(conv.value), "matvec_count": mv.value}
+
+
+def ts_random_walk_streams(rp, ci, va, b, row, num_samples, seed):
+    """per-walk-stream form of the TS random-walk estimateEntry (see sl_oracle.c)."""
+    rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
+    n = rp.size - 1
+    vals = np.zeros(num_samples)
+    mean, var = f64(0), f64(0)
+    st = lib().orc_ts_random_walk_streams(u64(n), _p(rp), _p(ci), _p(va), _p(b), u64(row), u64(num_samples), u32(seed),
+                                          _p(vals), C.byref(mean), C.byref(var))
+    if st:
+        raise OracleError(st)
+    return vals, mean.value, var.value

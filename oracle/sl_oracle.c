@@ -773,3 +773,52 @@ int orc_cg_solve(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, c
     free(r); free(p); free(ap);
     return ORC_OK;
 }
+
+/* ---------------------------------------------- (f-3) per-walk-stream MC -- */
+
+/* The data-parallel form of estimateEntry's random-walk branch (src/core/solver.ts:585-601,630-648 over
+ * performRandomWalk :390-432): identical walk rule and estimator, but walk s draws from its OWN TS LCG
+ * stream createSeededRandom(seed + s) (core/utils.ts:161-168) instead of one stream shared by all walks —
+ * a shared stream makes walk s+1 depend on how many numbers walk s consumed, i.e. is inherently serial.
+ * values[] (num_samples) receives the per-walk estimates; mean / variance as in the reference (:630-634). */
+int orc_ts_random_walk_streams(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values_a,
+                               const double *b, uint64_t start_row, uint64_t num_samples, uint32_t seed,
+                               double *values, double *mean, double *variance)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        double d = 0.0;
+        orc_csr_get(row_ptr, col_idx, values_a, n, i, i, &d);
+        if (fabs(d) < 1e-15) return ORC_NUMERICAL_INSTABILITY;
+    }
+    for (uint64_t s = 0; s < num_samples; ++s) {
+        uint64_t state = (uint32_t)(seed + (uint32_t)s);
+        uint64_t cur = start_row; double value = 0.0;
+        for (int step = 0; step < 1000; ++step) {
+            double d = 0.0;
+            for (uint64_t k = row_ptr[cur]; k < row_ptr[cur + 1]; ++k) if (col_idx[k] == cur) d = values_a[k];
+            const double absorb = 1.0 / d;
+            if (lcg_next(&state) < fabs(absorb)) { value = value + b[cur] * absorb; break; }
+            double sum = 0.0;
+            for (uint64_t k = row_ptr[cur]; k < row_ptr[cur + 1]; ++k)
+                if (col_idx[k] != cur) sum = sum + fabs(-values_a[k] / d);
+            if (sum == 0.0) { value = value + b[cur] * absorb; break; }
+            const double rnd = lcg_next(&state) * sum;
+            if (rnd <= 0.0) { cur = 0; continue; }
+            double cum = 0.0;
+            const uint64_t row = cur;
+            for (uint64_t k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
+                if (col_idx[k] == row) continue;
+                cum = cum + fabs(-values_a[k] / d);
+                if (rnd <= cum) { cur = col_idx[k]; break; }
+            }
+        }
+        values[s] = value;
+    }
+    double m = 0.0;
+    for (uint64_t s = 0; s < num_samples; ++s) m = m + values[s];
+    m = m / (double)num_samples;
+    double var = 0.0;
+    if (num_samples > 1) { for (uint64_t s = 0; s < num_samples; ++s) { double q = values[s] - m; var = var + q * q; } var = var / (double)(num_samples - 1); }
+    *mean = m; *variance = var;
+    return ORC_OK;
+}

@@ -61,6 +61,10 @@ class EstimateResult(C.Structure):
                 ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
 
 
+class WalkResult(C.Structure):
+    _fields_ = [("estimate", f64), ("variance", f64), ("num_samples", u64), ("device_time_ms", f64)]
+
+
 class CgOptions(C.Structure):
     _fields_ = [("tolerance", f64), ("max_iterations", u64), ("order", i32), ("mem", i32)]
 
@@ -99,6 +103,7 @@ SIGNATURES = {
                                 C.POINTER(PushResult)]),
     "sl_estimate_entry": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
     "sl_synth_sdd_device": (C.c_int, [u64, u32, u64, u64, u64, u64, vp, vp, vp, vp]),
+    "sl_estimate_entry_random_walk": (C.c_int, [vp, vp, C.c_int, u64, f64, u32, u64, vp, C.POINTER(WalkResult)]),
     "sl_cg_options_default": (None, [C.POINTER(CgOptions)]),
     "sl_cg_solve": (C.c_int, [vp, vp, C.POINTER(CgOptions), vp, C.POINTER(CgResult)]),
     "sl_estimate_entry_transposed": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),

@@ -389,6 +389,11 @@ class SublinearSolver:
         if b.size != m.rows():
             raise SolverError(5, f"Vector length {b.size} does not match matrix rows {m.rows()}")
         eps = epsilon if epsilon is not None else self.epsilon
+        if method == "random-walk":                                      # solver.ts:585-601, 630-648
+            res = L.WalkResult()
+            seed = (self.seed if self.seed is not None else 0) & 0xFFFFFFFF
+            L.check(L.load().sl_estimate_entry_random_walk(m._h, L.ptr(b), L.SL_MEM_HOST, row, eps, seed, 0, None, C.byref(res)))
+            return {"estimate": res.estimate, "variance": res.variance, "confidence": confidence, "numSamples": int(res.num_samples)}
         r = estimate_entry(m, b, row, theta=eps * 1e-2, max_rounds=self.max_iterations * 100)
         return {"estimate": r.estimate, "variance": 0.0, "confidence": 1.0 if r.converged else 0.5,
                 "residual_l1": r.residual_l1}
