@@ -129,8 +129,9 @@ __device__ __forceinline__ void sl_row_epilogue(const sl_row_args &a, uint64_t i
         // neumann.rs:289-296: tmp *= dinv ; term -= tmp ; :264-266: solution += term
         const double tmp = DMUL(sum, e_d);
         const double tn = DSUB(e_t, tmp);
-        a.out[i] = tn;
-        a.x[i] = DADD(e_x, tn);
+        // streamed once per iteration: keep them out of the way of the LDS-window / gather lines in L2
+        __builtin_nontemporal_store(tn, &a.out[i]);
+        __builtin_nontemporal_store(DADD(e_x, tn), &a.x[i]);
         part0 = DADD(part0, DMUL(tn, tn));
     } else if constexpr (EPI == SL_EPI_RESIDUAL) {
         // neumann.rs:303-309: residual = A x - rhs
@@ -471,12 +472,12 @@ static band_geom band_geometry(const sl_row_args &a)
     }
     band_geom out{0, 0, false, false};
     if (disabled || a.bandwidth == ~0ull || a.n_cols > 0xffffffffull) return out;
-    // measured (gpurun_out/sweep4.txt): narrow windows like 2 slices per wave (more, smaller blocks), wide
-    // windows 4 (the window is re-staged 4 * spw * 64 rows at a time); pipelining never hurts
-    uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : (a.bandwidth <= 1024 ? 2u : 4u);
+    // measured (gpurun_out/sweep4.txt, sweep5.txt; +-5 % DVFS noise between repetitions): 4 slices per wave for
+    // narrow windows, 6 for wide ones (the window is re-staged 4 * spw * 64 rows at a time); pipelining never hurts
+    uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : (a.bandwidth <= 1024 ? 4u : 6u);
     uint64_t entries = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE + 2 * a.bandwidth + 2;
-    if (entries * 8 > SL_BAND_MAX_LDS && forced_spw <= 0) {       // last resort: a shorter block still fits
-        spw = 2;
+    while (entries * 8 > SL_BAND_MAX_LDS && forced_spw <= 0 && spw > 1) {   // a shorter block may still fit
+        spw >>= 1;
         entries = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE + 2 * a.bandwidth + 2;
     }
     if (entries * 8 > SL_BAND_MAX_LDS) return out;
