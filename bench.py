@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--order", type=int, default=0, help="0 = CSR sequential (sparse.rs), 1 = simd4 (simd_ops.rs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary column-structure measurements")
+    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: do not split boundary / interior rows")
+    ap.add_argument("--force-split", action="store_true", help="testing: use the boundary / interior split even on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -139,20 +141,39 @@ def main():
     assert part.n_local == n_local
 
     # ---- synthesize this rank's rows directly in HBM, build the row-slice layout ---------------------
-    rp = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
-    ci = torch.empty(n_local * k, dtype=torch.int32, device=dev)
-    va = torch.empty(n_local * k, dtype=torch.float64, device=dev)
-    b = torch.empty(n_local, dtype=torch.float64, device=dev)
-    L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, part.lo, part.hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), b.data_ptr()))
-    h = C.c_void_p()
-    L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(),
-                                     L.SL_MEM_DEVICE, part.lo, 0, C.byref(h)))
-    del rp, ci, va
+    def build_piece(lo_l, hi_l):
+        """rows [part.lo + lo_l, part.lo + hi_l) as their own device matrix (row slice, global column ids)"""
+        rows = hi_l - lo_l
+        rp = torch.empty(rows + 1, dtype=torch.int32, device=dev)
+        ci = torch.empty(rows * k, dtype=torch.int32, device=dev)
+        va = torch.empty(rows * k, dtype=torch.float64, device=dev)
+        bb = torch.empty(rows, dtype=torch.float64, device=dev)
+        L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, part.lo + lo_l, part.lo + hi_l, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), bb.data_ptr()))
+        hh = C.c_void_p()
+        L.check(lib.sl_matrix_create_csr(rows, n_global, rows * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(),
+                                         L.SL_MEM_DEVICE, part.lo + lo_l, 0, C.byref(hh)))
+        del rp, ci, va, bb
+        L.check(lib.sl_matrix_diagonal_inverse(hh, dinv[lo_l:hi_l].data_ptr(), L.SL_MEM_DEVICE))
+        return hh
+
+    dinv = torch.empty(n_local, dtype=torch.float64, device=dev)
+    overlap = (world > 1 or args.force_split) and w > 0 and not args.no_overlap and n_local >= 4 * w
+    handles = []
+    if overlap:   # boundary rows first, halo transfer in flight under the interior rows (DESIGN.md §7)
+        bnd, inter = D.split_bounds(n_local, w, rank > 0 or args.force_split, rank < world - 1 or args.force_split)
+        pieces_b = [(lo_l, hi_l, build_piece(lo_l, hi_l)) for lo_l, hi_l in bnd if hi_l > lo_l]
+        pieces_i = [(lo_l, hi_l, build_piece(lo_l, hi_l)) for lo_l, hi_l in inter if hi_l > lo_l]
+        handles = [hh for _, _, hh in pieces_b + pieces_i]
+        h = pieces_i[0][2]
+        local_step = D.SplitStep([(lo_l, hi_l, D.hip_local_step(hh, dinv[lo_l:hi_l], args.order)) for lo_l, hi_l, hh in pieces_b],
+                                 [(lo_l, hi_l, D.hip_local_step(hh, dinv[lo_l:hi_l], args.order)) for lo_l, hi_l, hh in pieces_i], dev)
+    else:
+        h = build_piece(0, n_local)
+        handles = [h]
+        local_step = D.hip_local_step(h, dinv, args.order)
     torch.cuda.empty_cache()
     info = L.MatrixInfo()
     L.check(lib.sl_matrix_get_info(h, C.byref(info)))
-    dinv = torch.empty(n_local, dtype=torch.float64, device=dev)
-    L.check(lib.sl_matrix_diagonal_inverse(h, dinv.data_ptr(), L.SL_MEM_DEVICE))
 
     # t0 = D^-1 b on every rank (b is a closed form of the row index, so no exchange is needed to start)
     idx = torch.arange(n_global, device=dev, dtype=torch.float64)
@@ -161,7 +182,7 @@ def main():
     del idx
     x = t0[part.lo:part.hi].clone()
     exchange = D.AllGatherExchange(part) if w == 0 else D.HaloExchange(part, w)
-    drv = D.PartitionedNeumann(part, D.hip_local_step(h, dinv, args.order), exchange, t0, x)
+    drv = D.PartitionedNeumann(part, local_step, exchange, t0, x)
 
     def barrier():
         if world > 1:
@@ -220,7 +241,7 @@ def main():
                                    "1xMI355X HBM roofline run (BASELINE configs[2])",
                        "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w,
                        "order": "csr_sequential" if args.order == 0 else "simd4",
-                       "exchange": exchange.name if world > 1 else "none", "partition": f"rows{world}",
+                       "exchange": (exchange.name + ("+overlap" if overlap else "")) if (world > 1 or overlap) else "none", "partition": f"rows{world}",
                        "rows_iter_per_s": value / k, "last_term_norm": term_norm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -236,7 +257,8 @@ def main():
             except Exception as e:  # the baseline is reported context; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "nnz*iter/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
-    lib.sl_matrix_destroy(h)
+    for hh in handles:
+        lib.sl_matrix_destroy(hh)
     if world > 1:
         dist.destroy_process_group()
 

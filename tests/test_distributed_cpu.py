@@ -37,7 +37,7 @@ def _oracle_local_step(rp, ci, va, dinv, lo):
     return step
 
 
-def _worker(rank, world, port, n, k, w, steps, out_dir):
+def _worker(rank, world, port, n, k, w, steps, out_dir, split=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -53,7 +53,14 @@ def _worker(rank, world, port, n, k, w, steps, out_dir):
         t0 = torch.from_numpy(t0)
         x = t0[part.lo:part.hi].clone()
         ex = D.AllGatherExchange(part) if w == 0 else D.HaloExchange(part, w)
-        drv = D.PartitionedNeumann(part, _oracle_local_step(rp, ci, va, dinv, part.lo), ex, t0, x)
+        local = _oracle_local_step(rp, ci, va, dinv, part.lo)
+        if split:      # boundary rows first, exchange in flight under the interior rows
+            def piece(lo_l, hi_l):
+                prp = (rp[lo_l:hi_l + 1] - rp[lo_l]).astype(np.uint32)
+                return (lo_l, hi_l, _oracle_local_step(prp, ci[rp[lo_l]:rp[hi_l]], va[rp[lo_l]:rp[hi_l]], dinv[lo_l:hi_l], part.lo + lo_l))
+            bnd, inter = D.split_bounds(part.n_local, max(w, 64), rank > 0, rank < world - 1)
+            local = D.SplitStep([piece(a, b) for a, b in bnd if b > a], [piece(a, b) for a, b in inter if b > a], torch.device("cpu"))
+        drv = D.PartitionedNeumann(part, local, ex, t0, x)
         norms = []
         for _ in range(steps):
             drv.step()
@@ -64,11 +71,11 @@ def _worker(rank, world, port, n, k, w, steps, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,k,w", [(4000, 8, 0), (4001, 8, 0), (6000, 12, 300)])
-def test_partitioned_iteration_matches_single_process(tmp_path, n, k, w):
+@pytest.mark.parametrize("n,k,w,split", [(4000, 8, 0, False), (4001, 8, 0, True), (6000, 12, 300, False), (6000, 12, 300, True)])
+def test_partitioned_iteration_matches_single_process(tmp_path, n, k, w, split):
     world, steps = 2, 4
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, k, w, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, k, w, steps, str(tmp_path), split), nprocs=world, join=True)
     rp, ci, va, b = G.sdd_rows(n, k, 3, w)
     o = O.neumann_solve(rp, ci, va, b, max_terms=steps + 1, series_tolerance=0.0, max_iterations=steps + 1, tolerance=0.0)
     xs, ts = np.zeros(n), np.zeros(n)
@@ -81,6 +88,13 @@ def test_partitioned_iteration_matches_single_process(tmp_path, n, k, w):
             assert int(z["sent"]) == 8 * w          # one neighbour each at world = 2
     assert (xs.view(np.uint64) == o["x"].view(np.uint64)).all()
     assert (ts.view(np.uint64) == o["term"].view(np.uint64)).all()
+
+
+def test_split_bounds():
+    assert D.split_bounds(1000, 100, True, True) == ([(0, 100), (900, 1000)], [(100, 900)])
+    assert D.split_bounds(1000, 100, False, True) == ([(0, 0), (900, 1000)], [(0, 900)])
+    assert D.split_bounds(1000, 100, True, False) == ([(0, 100), (1000, 1000)], [(100, 1000)])
+    assert D.split_bounds(150, 100, True, True) == ([(0, 100), (100, 150)], [(100, 100)])
 
 
 def test_row_partition_bounds():
