@@ -45,17 +45,18 @@ def cpu_baseline(n_global: int, k: int, seed: int, w: int, threads_all: int):
     dinv = 1.0 / (10.0 + 0.01 * (np.arange(n_s) % 1000))
     out = {}
     for label, order, threads in (("simd4_1t", O.ORDER_SIMD4, 1), ("rowchunk_all", O.ORDER_SEQ, threads_all)):
-        t = 1.0 + 0.001 * (np.arange(n_global) % 1000)
-        t[:n_s] *= dinv
-        x = t[:n_s].copy()
+        t_init = 1.0 + 0.001 * (np.arange(n_global) % 1000)
+        t_init[:n_s] *= dinv
+        t, x = t_init.copy(), t_init[:n_s].copy()
         O.neumann_steps(rp, ci, va, dinv, t, x, 2, order, threads, fast=True)          # warm (page faults, thread pool)
-        done, dt, steps = 0, 0.0, 8
-        while dt < 4.0 and done < 4096:                                                # ~4 s of CPU work per leg
+        done, dt, steps = 0, 0.0, 32
+        while dt < 4.0 and done < 8192:                                                # ~4 s of CPU work per leg
+            t[:] = t_init                                                              # restart the series: no denormal tail
+            x[:] = t_init[:n_s]
             t0 = time.perf_counter()
             O.neumann_steps(rp, ci, va, dinv, t, x, steps, order, threads, fast=True)
             dt += time.perf_counter() - t0
             done += steps
-            steps *= 2
         out[label] = n_s * k * done / dt
     best = max(out, key=out.get)
     return {"value": out[best], "unit": "nnz*iter/s", "cores": threads_all if best == "rowchunk_all" else 1,
