@@ -299,6 +299,129 @@ __device__ __forceinline__ void sl_slice_finish(const sl_row_args &a, uint64_t s
     }
 }
 
+// ---- ragged rows in the band kernel: quad-granular batches, software pipelined ---------------------------
+// A slice of width W is consumed in batches of up to 4 quads (16 entries per lane); the loads of the next
+// batch — of the same slice or the first one of the wave's next slice, together with that slice's epilogue
+// operands — are in flight while the current batch is reduced.  Everything that steers the loop (slice
+// pointers, quad counts) is wave-uniform.  C16: columns come as 16-bit offsets col - row, layout
+// [quad][lane][4] (8 B per lane per quad).
+struct sl_batch { uint64_t s; uint32_t q, nq, kbase; bool first, last, valid; };
+struct sl_batch_regs {
+    u32x4 c[4];
+    f64x2 va[4], vb[4];
+    double e_d, e_x, e_aux;
+    uint32_t len;
+};
+struct sl_batch_cursor { uint64_t s0, s; uint32_t j, spw, q, q0, q1; bool in_slice; };
+struct sl_row_state { double sum, l0, l1, l2, l3, e_d, e_x, e_aux; uint32_t len, chunks; bool merged, live; };
+
+__device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch_cursor &c)
+{
+    sl_batch b{0, 0, 0, 0, false, false, false};
+    if (!c.in_slice) {
+        if (c.j >= c.spw) return b;
+        c.s = c.s0 + (uint64_t)c.j * SL_WAVES_PER_BLOCK;
+        if (c.s >= a.n_slices) return b;
+        c.q0 = __builtin_amdgcn_readfirstlane(a.slice_ptr[c.s]);
+        c.q1 = __builtin_amdgcn_readfirstlane(a.slice_ptr[c.s + 1]);
+        c.q = c.q0;
+        c.in_slice = true;
+    }
+    uint32_t nq = c.q1 - c.q;
+    nq = nq > 4u ? 4u : nq;
+    b.s = c.s; b.q = c.q; b.nq = nq; b.kbase = (c.q - c.q0) * 4u;
+    b.first = c.q == c.q0; b.last = c.q + nq == c.q1; b.valid = true;
+    c.q += nq;
+    if (c.q == c.q1) { c.in_slice = false; ++c.j; }
+    return b;
+}
+
+template <int EPI, bool C16>
+__device__ __forceinline__ void sl_batch_load(const sl_row_args &a, const sl_batch &b, uint32_t lane, sl_batch_regs &r)
+{
+    const f64x2 *__restrict__ vq = reinterpret_cast<const f64x2 *>(a.vals);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        if ((uint32_t)qq < b.nq) {
+            const uint64_t q = (uint64_t)b.q + qq;
+            if constexpr (C16) {
+                const unsigned long long w2 = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(a.cols16) + q * 64 + lane);
+                r.c[qq].x = (uint32_t)w2; r.c[qq].y = (uint32_t)(w2 >> 32);
+            } else {
+                r.c[qq] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.cols) + q * 64 + lane);
+            }
+            r.va[qq] = __builtin_nontemporal_load(&vq[(q * 2) * 64 + lane]);
+            r.vb[qq] = __builtin_nontemporal_load(&vq[(q * 2 + 1) * 64 + lane]);
+        }
+    }
+    if (b.first) {
+        const uint64_t i = b.s * SL_SLICE + lane;
+        r.len = a.row_len[i];
+        r.e_d = 0.0; r.e_x = 0.0; r.e_aux = 0.0;
+        if (i < a.n_rows && r.len != SL_LONG_SENTINEL) {
+            if constexpr (EPI == SL_EPI_NEUMANN) { r.e_d = a.dinv[i]; r.e_x = a.x[i]; }
+            else if constexpr (EPI == SL_EPI_RESIDUAL) { r.e_aux = a.aux[i]; }
+            else if constexpr (EPI == SL_EPI_PUSH) { r.e_aux = a.r[i]; r.e_d = a.dinv[i]; r.e_x = a.x[i]; }
+        }
+    }
+}
+
+template <int ORDER, int EPI, bool C16>
+__device__ __forceinline__ void sl_batch_finish(const sl_row_args &a, const sl_batch &b, uint32_t lane, const sl_batch_regs &r,
+                                                sl_row_state &st, const double *lw, uint32_t base, double &part0, double &part1)
+{
+    const uint64_t i = b.s * SL_SLICE + lane;
+    const uint32_t rowpos = (uint32_t)(a.row_offset + i) - base;
+    if (b.first) {
+        st.sum = 0.0; st.l0 = st.l1 = st.l2 = st.l3 = 0.0; st.merged = false;
+        st.live = i < a.n_rows && r.len != SL_LONG_SENTINEL;
+        st.len = r.len == SL_LONG_SENTINEL ? 0u : r.len;
+        st.chunks = (st.len >= 8u) ? (st.len >> 2) : 0u;
+        st.e_d = r.e_d; st.e_x = r.e_x; st.e_aux = r.e_aux;
+    }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+        if ((uint32_t)qq < b.nq) {
+            uint32_t i0, i1, i2, i3;
+            if constexpr (C16) {
+                const uint32_t w0 = r.c[qq].x, w1 = r.c[qq].y;
+                i0 = (uint32_t)((int)rowpos + (int)(short)(w0 & 0xffffu)); i1 = (uint32_t)((int)rowpos + ((int)w0 >> 16));
+                i2 = (uint32_t)((int)rowpos + (int)(short)(w1 & 0xffffu)); i3 = (uint32_t)((int)rowpos + ((int)w1 >> 16));
+            } else {
+                i0 = r.c[qq].x - base; i1 = r.c[qq].y - base; i2 = r.c[qq].z - base; i3 = r.c[qq].w - base;
+            }
+            const double p0 = DMUL(r.va[qq].x, lw[i0]), p1 = DMUL(r.va[qq].y, lw[i1]);
+            const double p2 = DMUL(r.vb[qq].x, lw[i2]), p3 = DMUL(r.vb[qq].y, lw[i3]);
+            const uint32_t k = b.kbase + 4u * qq;
+            if constexpr (ORDER == 0) {
+                const double s0 = DADD(st.sum, p0); st.sum = (k < st.len) ? s0 : st.sum;
+                const double s1 = DADD(st.sum, p1); st.sum = (k + 1 < st.len) ? s1 : st.sum;
+                const double s2 = DADD(st.sum, p2); st.sum = (k + 2 < st.len) ? s2 : st.sum;
+                const double s3 = DADD(st.sum, p3); st.sum = (k + 3 < st.len) ? s3 : st.sum;
+            } else {
+                if ((k >> 2) < st.chunks) {
+                    st.l0 = DADD(st.l0, p0); st.l1 = DADD(st.l1, p1); st.l2 = DADD(st.l2, p2); st.l3 = DADD(st.l3, p3);
+                } else {
+                    if (!st.merged) { st.sum = DADD(DADD(DADD(st.l0, st.l1), st.l2), st.l3); st.merged = true; }
+                    if (k < st.len) st.sum = DADD(st.sum, p0);
+                    if (k + 1 < st.len) st.sum = DADD(st.sum, p1);
+                    if (k + 2 < st.len) st.sum = DADD(st.sum, p2);
+                    if (k + 3 < st.len) st.sum = DADD(st.sum, p3);
+                }
+            }
+        }
+    }
+    if (b.last) {
+        if constexpr (ORDER == 1) { if (!st.merged) st.sum = DADD(DADD(DADD(st.l0, st.l1), st.l2), st.l3); }
+        if (st.live) {
+            const double own = lw[rowpos];
+            if constexpr (EPI == SL_EPI_NEUMANN) sl_row_epilogue<EPI>(a, i, st.sum, own, st.e_d, st.e_x, 0.0, part0, part1);
+            else if constexpr (EPI == SL_EPI_PUSH) sl_row_epilogue<EPI>(a, i, st.sum, st.e_aux, st.e_d, st.e_x, own, part0, part1);
+            else sl_row_epilogue<EPI>(a, i, st.sum, st.e_aux, 0.0, 0.0, 0.0, part0, part1);
+        }
+    }
+}
+
 template <int ORDER, int EPI, int UW, bool PIPE, bool C16>
 __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32_t nb8, uint32_t spw, uint32_t w)
 {
@@ -349,6 +472,21 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
                 if (s >= a.n_slices) break;
                 sl_slice_load<EPI, UW, C16>(a, s, lane, ra);
                 sl_slice_finish<EPI, UW, C16>(a, s, lane, ra, lw, base, part0, part1);
+            }
+        } else if constexpr (PIPE) {
+            sl_batch_cursor cur{s0, 0, 0, spw, 0, 0, 0, false};
+            sl_batch_regs ga, gb;
+            sl_row_state st{};
+            sl_batch ba = sl_next_batch(a, cur);
+            if (ba.valid) sl_batch_load<EPI, C16>(a, ba, lane, ga);
+            while (ba.valid) {
+                const sl_batch bb = sl_next_batch(a, cur);
+                if (bb.valid) sl_batch_load<EPI, C16>(a, bb, lane, gb);
+                sl_batch_finish<ORDER, EPI, C16>(a, ba, lane, ga, st, lw, base, part0, part1);
+                if (!bb.valid) break;
+                ba = sl_next_batch(a, cur);
+                if (ba.valid) sl_batch_load<EPI, C16>(a, ba, lane, ga);
+                sl_batch_finish<ORDER, EPI, C16>(a, bb, lane, gb, st, lw, base, part0, part1);
             }
         } else {
             for (uint32_t j = 0; j < spw; ++j) {
@@ -522,7 +660,13 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
         sl_status st;
         if (ORDER == 0 && a.uniform_width == 16) st = launch_band_u<ORDER, EPI, 16>(a, g, grid, nb8, s);
         else if (ORDER == 0 && a.uniform_width == 8) st = launch_band_u<ORDER, EPI, 8>(a, g, grid, nb8, s);
-        else st = launch_band<ORDER, EPI, 0, false, false>(a, g, grid, nb8, s);
+        else {
+            // the batched ragged path reads 16-bit offsets in the QUAD layout; a uniform-width matrix that ends up
+            // here (simd4 order) carries them in the octet layout of the unrolled path: use its u32 columns instead
+            band_geom gg = g;
+            if (a.uniform_width == 8 || a.uniform_width == 16) gg.c16 = false;
+            st = launch_band_u<ORDER, EPI, 0>(a, gg, grid, nb8, s);
+        }
         if (st != SL_OK) return st;
     } else {
         const uint32_t grid = sl_row_grid(a.n_slices), nb8 = grid / 8;

@@ -104,6 +104,28 @@ __global__ __launch_bounds__(256) void sl_fill_cols16_kernel(uint64_t n_rows, ui
         }
 }
 
+// 16-bit column offsets for ragged band matrices: [quad][lane][4] int16 (8 B per lane per quad)
+__global__ __launch_bounds__(256) void sl_fill_cols16_quads_kernel(uint64_t n_rows, uint64_t n_slices, uint64_t row_offset,
+                                                                   const uint32_t *slice_ptr, const uint32_t *row_len,
+                                                                   const uint32_t *cols, uint16_t *cols16)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const uint64_t i = s * 64 + lane;
+    const uint64_t gi = row_offset + i;
+    uint32_t len = i < n_rows ? row_len[i] : 0u;
+    if (len == SL_LONG_SENTINEL) len = 0u;
+    const uint32_t q0 = slice_ptr[s], q1 = slice_ptr[s + 1];
+    for (uint32_t q = q0; q < q1; ++q)
+        for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t k = (q - q0) * 4 + e;
+            const uint64_t at = ((uint64_t)q * 64 + lane) * 4 + e;
+            const int delta = k < len ? (int)((long long)cols[at] - (long long)gi) : 0;
+            cols16[at] = (uint16_t)(int16_t)delta;
+        }
+}
+
 // a6 + a7: one pass over the slice layout.  Per row, in stored order:
 //   diag = |a_ii| of the LAST diagonal entry seen (0 if none), off += |a_ij|   (matrix/mod.rs:467-485)
 //   d    = that diagonal entry; missing or |d| < 1e-14 is an error            (neumann.rs:172-188)
@@ -285,10 +307,14 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     SL_HIP(hipStreamSynchronize(st));
     hipFree(d_band);
     m->bandwidth = h_band;
-    if ((m->uniform_width == 8 || m->uniform_width == 16) && m->bandwidth < 32768 && m->n_slices) {
+    if (m->bandwidth < 32768 && m->n_slices && m->padded_nnz) {
         SL_HIP(hipMalloc(&m->d_cols16, m->padded_nnz * sizeof(uint16_t)));
-        hipLaunchKernelGGL(sl_fill_cols16_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_slices, m->row_offset,
-                           m->uniform_width, m->d_cols, m->d_cols16);
+        if (m->uniform_width == 8 || m->uniform_width == 16)      // octet layout of the unrolled uniform path
+            hipLaunchKernelGGL(sl_fill_cols16_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_slices, m->row_offset,
+                               m->uniform_width, m->d_cols, m->d_cols16);
+        else                                                      // quad layout of the batched ragged path
+            hipLaunchKernelGGL(sl_fill_cols16_quads_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_slices,
+                               m->row_offset, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_cols16);
         SL_HIP(hipGetLastError());
     }
     m->device_bytes = (m->n_slices + 1 + padded_rows) * sizeof(uint32_t) + m->padded_nnz * 12 + (m->d_cols16 ? m->padded_nnz * 2 : 0);

@@ -68,20 +68,23 @@ def test_spr_generator_and_transposed_query(gpu):
     assert abs(acl["estimate"].sum() + acl["residual"].sum() - 1.0) < 1e-9
 
 
-@pytest.mark.parametrize("n,k,w", [(40_000, 16, 500), (40_000, 16, 4096), (30_011, 8, 100), (30_011, 8, 3000)])
+@pytest.mark.parametrize("n,k,w", [(40_000, 16, 500), (40_000, 16, 4096), (30_011, 8, 100), (30_011, 8, 3000),
+                                   (30_011, 13, 700), (30_011, 5, 60), (30_011, 12, 2000), (9_000, 37, 900)])
 def test_band_kernel_variants_bitwise(gpu, n, k, w):
-    """uniform-width band matrices: 16-bit column offsets + pipelined slices, both epilogue families"""
+    """band matrices, uniform width (unrolled path, octet 16-bit offsets) and other widths (batched ragged path, quad
+    16-bit offsets), both summation orders, both epilogue families"""
     rp, ci, va, b = G.sdd_rows(n, k, seed=3, half_bandwidth=w)
     m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
     info = m.info()
-    assert info.uniform_width == k and info.bandwidth <= w
+    assert info.uniform_width == (k if k % 4 == 0 else 0) and info.bandwidth <= w
     x = np.cos(np.arange(n))
-    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
-    g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-11))
-    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-11)
-    assert g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
     bs = b * (np.arange(n) % 3 == 0)
-    p = S.PushSolver(theta=1e-9, dense_switch=1e-9).solve(m, bs, log_frontier=4_000_000)      # dense rounds only
-    q = O.push_sync_solve(rp, ci, va, bs, theta=1e-9, log_cap=4_000_000)
-    assert p["rounds"] == q["rounds"] and (p["frontier_log"] == q["frontier_log"]).all()
-    assert _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])
+    for order in (0, 1):
+        assert _bits_equal(m.multiply_vector(x, order), O.spmv(rp, ci, va, x, order))
+        g = S.NeumannSolver(order=order).solve(m, b, S.SolverOptions(tolerance=1e-11))
+        o = O.neumann_solve(rp, ci, va, b, tolerance=1e-11, order=order)
+        assert g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
+        p = S.PushSolver(theta=1e-9, dense_switch=1e-9, order=order).solve(m, bs, log_frontier=4_000_000)      # dense rounds only
+        q = O.push_sync_solve(rp, ci, va, bs, theta=1e-9, order=order, log_cap=4_000_000)
+        assert p["rounds"] == q["rounds"] and (p["frontier_log"] == q["frontier_log"]).all()
+        assert _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])
