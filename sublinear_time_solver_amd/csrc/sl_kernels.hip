@@ -312,7 +312,7 @@ struct sl_batch_regs {
     double e_d, e_x, e_aux;
     uint32_t len;
 };
-struct sl_batch_cursor { uint64_t s0, s; uint32_t j, spw, q, q0, q1; bool in_slice; };
+struct sl_batch_cursor { uint64_t s0, s; uint32_t j, spw, q, q0, q1; bool in_slice; uint32_t lane_q0, lane_q1; };   // lane_q*: slice pointers of slice j held by lane j
 struct sl_row_state { double sum, l0, l1, l2, l3, e_d, e_x, e_aux; uint32_t len, chunks; bool merged, live; };
 
 __device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch_cursor &c)
@@ -322,8 +322,8 @@ __device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch
         if (c.j >= c.spw) return b;
         c.s = c.s0 + (uint64_t)c.j * SL_WAVES_PER_BLOCK;
         if (c.s >= a.n_slices) return b;
-        c.q0 = __builtin_amdgcn_readfirstlane(a.slice_ptr[c.s]);
-        c.q1 = __builtin_amdgcn_readfirstlane(a.slice_ptr[c.s + 1]);
+        c.q0 = __builtin_amdgcn_readlane(c.lane_q0, c.j);      // fetched for all of the wave's slices up front
+        c.q1 = __builtin_amdgcn_readlane(c.lane_q1, c.j);
         c.q = c.q0;
         c.in_slice = true;
     }
@@ -438,6 +438,11 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
         const uint64_t s0 = (uint64_t)lb * spw * NW + wave;     // this wave's slices: s0, s0 + NW, ...
         [[maybe_unused]] sl_slice_regs<UW, C16> ra, rb;
         if constexpr (UW > 0 && PIPE) { if (s0 < a.n_slices) sl_slice_load<EPI, UW, C16>(a, s0, lane, ra); }
+        [[maybe_unused]] uint32_t pre_q0 = 0, pre_q1 = 0;        // ragged path: lane j prefetches the pointers of slice j
+        if constexpr (UW == 0 && PIPE) {
+            const uint64_t sj = s0 + (uint64_t)lane * NW;
+            if (lane < spw && sj < a.n_slices) { pre_q0 = a.slice_ptr[sj]; pre_q1 = a.slice_ptr[sj + 1]; }
+        }
 
         const uint64_t g0 = a.row_offset + r0;                  // global index of the block's first row
         const uint64_t win_lo = (g0 > w ? g0 - w : 0) & ~1ull;  // even => 16-B aligned staging loads
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
                 sl_slice_finish<EPI, UW, C16>(a, s, lane, ra, lw, base, part0, part1);
             }
         } else if constexpr (PIPE) {
-            sl_batch_cursor cur{s0, 0, 0, spw, 0, 0, 0, false};
+            sl_batch_cursor cur{s0, 0, 0, spw, 0, 0, 0, false, pre_q0, pre_q1};
             sl_batch_regs ga, gb;
             sl_row_state st{};
             sl_batch ba = sl_next_batch(a, cur);
