@@ -141,6 +141,11 @@ sl_status sl_l2_norm(uint64_t n, const double *x, double *out, sl_mem where);
  * loops (product rounded, then added, column order).  norm2 is a device double. */
 sl_status sl_neumann_step(const sl_matrix *m, const double *dinv, const double *t_in, double *t_out,
                           double *x, double *norm2, sl_order order);
+/* a10 on device pointers (row slices included): r = A x - rhs over the local rows, *norm2 = sum r_i^2
+ * (NeumannState::update_residual, neumann.rs:302-318; rhs = b for the true residual, D^-1 b for the
+ * reference's scaled one).  x_full has n_cols entries, rhs / r_out n_rows; r_out may be NULL. */
+sl_status sl_residual_norm2(const sl_matrix *m, const double *x_full, const double *rhs, double *r_out, double *norm2,
+                            sl_order order);
 /* same launch sequence repeated `steps` times with ping-pong buffers t_a -> t_b -> t_a ...
  * bracketed by HIP events on the launch stream; *elapsed_ms is the device time.
  * After the call the newest term is in t_a when `steps` is even, t_b when odd. */

@@ -95,6 +95,7 @@ SIGNATURES = {
     "sl_axpy": (C.c_int, [u64, f64, vp, vp, C.c_int]),
     "sl_l2_norm": (C.c_int, [u64, vp, C.POINTER(f64), C.c_int]),
     "sl_neumann_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int]),
+    "sl_residual_norm2": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
     "sl_neumann_run_steps": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, u64, C.POINTER(C.c_float)]),
     "sl_neumann_options_default": (None, [C.POINTER(NeumannOptions)]),
     "sl_neumann_solve": (C.c_int, [vp, vp, vp, C.POINTER(NeumannOptions), vp, vp, C.POINTER(NeumannResult)]),

@@ -361,6 +361,16 @@ sl_status sl_neumann_step(const sl_matrix *m, const double *dinv, const double *
     return sl_launch_rows(a, order, SL_EPI_NEUMANN, sl_context().stream);
 }
 
+sl_status sl_residual_norm2(const sl_matrix *m, const double *x_full, const double *rhs, double *r_out, double *norm2, sl_order order)
+{
+    if (!m || !x_full || !rhs || !norm2) return sl_fail(SL_INVALID_INPUT, "null argument");
+    double *scr = static_cast<double *>(sl_scratch(partial_bytes(m)));
+    if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
+    sl_row_args a = row_args(m);
+    a.gather = x_full; a.aux = rhs; a.out = r_out; a.partials = scr; a.result = norm2;
+    return sl_launch_rows(a, order, SL_EPI_RESIDUAL, sl_context().stream);
+}
+
 sl_status sl_neumann_run_steps(const sl_matrix *m, const double *dinv, double *t_a, double *t_b, double *x,
                                double *norm2, sl_order order, uint64_t steps, float *elapsed_ms)
 {

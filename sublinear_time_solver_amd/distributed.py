@@ -216,3 +216,123 @@ def split_bounds(n_local: int, w: int, has_left: bool, has_right: bool) -> Tuple
     top = (0, min(w, n_local)) if has_left else (0, 0)
     bot = (max(n_local - w, top[1]), n_local) if has_right else (n_local, n_local)
     return [top, bot], [(top[1], bot[0])]
+
+
+# ------------------------------------------------------------------------------------------------------
+# Partitioned NeumannSolver::solve: the control flow of neumann.rs:469-555 with the vectors split by rows
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class LocalOps:
+    """what one rank must be able to do on its row slice; `hip_local_ops` wires these to the C ABI, the CPU
+    tests provide stand-ins.  All tensors live on the rank's device."""
+    step: LocalStep                                                    # fused a8 + a9 on the local rows
+    residual_norm2: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], None]   # (x_full, rhs_local, norm2_out): a10
+    axpy: Callable[[float, torch.Tensor, torch.Tensor], None]           # y += alpha * x (local vectors)
+    sumsq: Callable[[torch.Tensor, torch.Tensor], None]                 # (v_local, out[0]) = sum v_i^2
+
+
+@dataclass
+class PartitionedResult:
+    solution_local: torch.Tensor
+    residual_norm: float
+    iterations: int
+    converged: bool
+    terms_computed: int
+    term_norms: List[float]
+
+
+class PartitionedNeumannSolver:
+    """NeumannSolver::solve (src/solver/neumann.rs:469-555) over a row partition: same loop, same stop rules;
+    every norm is the all-reduced sum of the ranks' partial sums, every gathered vector (the term each iteration,
+    the solution every 5th iteration for update_residual) goes through the exchange.  Per-row values are the same
+    bits as on one GPU; norms agree to rounding (partial sums are combined in rank order)."""
+
+    def __init__(self, part: RowPartition, ops: LocalOps, exchange, max_terms: int = 50, series_tolerance: float = 1e-8,
+                 reference_scaled_residual: bool = False, group=None):
+        self.part, self.ops, self.exchange, self.group = part, ops, exchange, group
+        self.max_terms, self.series_tolerance = max_terms, series_tolerance
+        self.scaled = reference_scaled_residual
+
+    def _allsum(self, scalar: torch.Tensor) -> float:
+        if self.part.world > 1:
+            dist.all_reduce(scalar, op=dist.ReduceOp.SUM, group=self.group)
+        return float(scalar[0].item())
+
+    def solve(self, b_local: torch.Tensor, dinv_local: torch.Tensor, tolerance: float = 1e-6, max_iterations: int = 1000,
+              initial_guess_local: Optional[torch.Tensor] = None, reference_default_start: bool = False) -> PartitionedResult:
+        p = self.part
+        dev, dt = b_local.device, torch.float64
+        rhs = b_local * dinv_local                                       # neumann.rs:191-194
+        t = [torch.zeros(p.n_padded, dtype=dt, device=dev), torch.zeros(p.n_padded, dtype=dt, device=dev)]
+        t[0][p.lo:p.hi] = rhs                                            # current_term = rhs (:211)
+        self.exchange(t[0])
+        if initial_guess_local is not None:
+            x = initial_guess_local.clone()
+        elif reference_default_start:
+            x = rhs.clone()                                              # :197-208
+        else:
+            x = torch.zeros_like(rhs)
+        x_full = torch.zeros(p.n_padded, dtype=dt, device=dev)
+        res_rhs = rhs if self.scaled else b_local
+        scal = torch.zeros(2, dtype=dt, device=dev)
+        cur, terms, it = 0, 0, 0
+        resn, series_conv = float("inf"), False
+        norms: List[float] = []
+
+        def is_converged():
+            return resn <= tolerance or (series_conv and not terms >= self.max_terms)
+
+        def update_residual():                                           # :302-318
+            x_full[p.lo:p.hi] = x
+            self.exchange(x_full)
+            self.ops.residual_norm2(x_full, res_rhs, scal)
+            return self._allsum(scal[:1]) ** 0.5
+
+        while not is_converged() and it < max_iterations:
+            if terms < self.max_terms:                                   # compute_next_term :252-277
+                if terms > 0:
+                    self.ops.step(t[cur], t[1 - cur][p.lo:p.hi], x, scal)
+                    self.exchange(t[1 - cur])
+                    cur = 1 - cur
+                else:
+                    self.ops.axpy(1.0, t[cur][p.lo:p.hi], x)             # x += term (k = 0)
+                    self.ops.sumsq(t[cur][p.lo:p.hi], scal)
+                tn = self._allsum(scal[:1]) ** 0.5
+                norms.append(tn)
+                terms += 1
+                if tn < self.series_tolerance:
+                    series_conv = True
+            if it % 5 == 0:
+                resn = update_residual()
+            it += 1
+            if resn != resn or resn in (float("inf"), float("-inf")):
+                raise FloatingPointError(f"Non-finite residual norm at iteration {it}")     # NumericalInstability :501-507
+            if series_conv:
+                break
+        resn = update_residual()                                         # :516
+        return PartitionedResult(x, resn, it, is_converged(), terms, norms)
+
+
+def hip_local_ops(matrix_handle: int, dinv_local: torch.Tensor, order: int = 0) -> LocalOps:
+    """Product wiring of LocalOps: every operation is a launch of libsublinear_hip on device pointers."""
+    import ctypes as C
+
+    from . import _lib as L
+    lib = L.load()
+    if dinv_local.is_cuda:       # torch's copies / RCCL calls and the library's launches must share one stream
+        L.check(lib.sl_set_device(dinv_local.device.index))
+        L.check(lib.sl_set_stream(C.c_void_p(torch.cuda.current_stream(dinv_local.device).cuda_stream)))
+    step = hip_local_step(matrix_handle, dinv_local, order)
+
+    def residual_norm2(x_full, rhs_local, norm2):
+        L.check(lib.sl_residual_norm2(matrix_handle, x_full.data_ptr(), rhs_local.data_ptr(), None, norm2.data_ptr(), order))
+
+    def axpy(alpha, xv, yv):
+        L.check(lib.sl_axpy(xv.numel(), alpha, xv.data_ptr(), yv.data_ptr(), L.SL_MEM_DEVICE))
+
+    def sumsq(v, out):
+        h = C.c_double(0)
+        L.check(lib.sl_dot(v.numel(), v.data_ptr(), v.data_ptr(), C.byref(h), L.SL_MEM_DEVICE))
+        out[0] = h.value
+
+    return LocalOps(step, residual_norm2, axpy, sumsq)

@@ -90,6 +90,53 @@ def test_partitioned_iteration_matches_single_process(tmp_path, n, k, w, split):
     assert (ts.view(np.uint64) == o["term"].view(np.uint64)).all()
 
 
+def _solve_worker(rank, world, port, n, k, w, tol, scaled, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        part = D.RowPartition(n, world, rank)
+        rp, ci, va, b = G.sdd_rows(n, k, 3, w, part.lo, part.hi)
+        d = np.array([va[i * k:(i + 1) * k][ci[i * k:(i + 1) * k] == part.lo + i][0] for i in range(part.n_local)])
+        dinv = 1.0 / d
+
+        def residual_norm2(x_full, rhs_local, out):
+            r = rhs_local.numpy() - O.spmv(rp, ci, va, x_full.numpy())     # rhs_local is b, or D^-1 b for the reference's scaled form
+            out[0] = float(np.dot(r, r))
+
+        def axpy(alpha, xv, yv):
+            yv.add_(xv, alpha=alpha)
+
+        def sumsq(v, out):
+            out[0] = float(np.dot(v.numpy(), v.numpy()))
+
+        ops = D.LocalOps(_oracle_local_step(rp, ci, va, dinv, part.lo), residual_norm2, axpy, sumsq)
+        ex = D.AllGatherExchange(part) if w == 0 else D.HaloExchange(part, w)
+        s = D.PartitionedNeumannSolver(part, ops, ex, reference_scaled_residual=scaled)
+        r = s.solve(torch.from_numpy(b), torch.from_numpy(dinv), tolerance=tol)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=r.solution_local.numpy(), lo=part.lo, hi=part.hi, it=r.iterations,
+                 terms=r.terms_computed, conv=r.converged, resn=r.residual_norm, norms=np.asarray(r.term_norms))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,k,w,tol,scaled", [(4000, 8, 0, 1e-10, False), (6000, 12, 300, 1e-6, False), (6000, 12, 300, 1e-12, True)])
+def test_partitioned_solve_matches_single_process(tmp_path, n, k, w, tol, scaled):
+    """the whole NeumannSolver::solve loop over 2 ranks: same iteration count, stop reason and bits as one process"""
+    world = 2
+    mp.spawn(_solve_worker, args=(world, _free_port(), n, k, w, tol, scaled, str(tmp_path)), nprocs=world, join=True)
+    rp, ci, va, b = G.sdd_rows(n, k, 3, w)
+    o = O.neumann_solve(rp, ci, va, b, tolerance=tol, residual=1 if scaled else 0)
+    xs = np.zeros(n)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        xs[int(z["lo"]):int(z["hi"])] = z["x"]
+        assert int(z["it"]) == o["iterations"] and int(z["terms"]) == o["terms"] and bool(z["conv"]) == o["converged"]
+        np.testing.assert_allclose(z["norms"], o["term_norms"][:int(z["terms"])], rtol=1e-12)
+        assert abs(float(z["resn"]) - o["residual_norm"]) <= 1e-12 * max(1.0, o["residual_norm"])
+    assert (xs.view(np.uint64) == o["x"].view(np.uint64)).all()
+
+
 def test_split_bounds():
     assert D.split_bounds(1000, 100, True, True) == ([(0, 100), (900, 1000)], [(100, 900)])
     assert D.split_bounds(1000, 100, False, True) == ([(0, 0), (900, 1000)], [(0, 900)])
