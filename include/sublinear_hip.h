@@ -84,6 +84,10 @@ sl_status sl_set_device(int device);
 /* all launches of the calling thread go to `hip_stream` (a hipStream_t); NULL = default stream */
 sl_status sl_set_stream(void *hip_stream);
 sl_status sl_synchronize(void);
+/* Solve calls take their device workspace (term vectors, frontier lists) from a per-thread cache instead of
+ * allocating per call; this returns the cached buffers of the calling thread to the driver.  Cache size limit:
+ * env SL_WORKSPACE_CACHE_MB (default 16384). */
+void sl_release_workspace(void);
 
 /* ---- a1 / a3: matrices ---------------------------------------------------------
  * replaces SparseMatrix::from_triplets (matrix/mod.rs:160-199) + COOStorage::from_triplets
@@ -244,6 +248,18 @@ sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, u
  * orientations, src/graph/adjacency.rs:199-224): the push runs on mt's own rows and may use its dense kernel. */
 sl_status sl_estimate_entry_transposed(const sl_matrix *mt, const double *b, sl_mem where, uint64_t row,
                                        double theta, uint64_t max_rounds, sl_estimate_result *result);
+/* Query sessions — the object form of the same query (ForwardPushSolver::new + query after query,
+ * forward_push.rs:52-66, 224-231): D^-1, the state vectors and the device copy of b are set up once; each
+ * query then costs only the rows its push touches (seed one row, device-driven sparse rounds, sums and reset over
+ * the touched rows).  matrix_is_transpose = 1: `m` already holds A^T (as for sl_estimate_entry_transposed).
+ * `m` (and b, when where = SL_MEM_DEVICE) must outlive the session.  One session serves one thread at a time. */
+typedef struct sl_query_session sl_query_session;
+sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, const double *b, sl_mem where,
+                                  sl_query_session **out);
+sl_status sl_query_session_estimate(sl_query_session *q, uint64_t row, double theta, uint64_t max_rounds,
+                                    sl_estimate_result *result);
+void sl_query_session_destroy(sl_query_session *q);
+
 /* A^T as a matrix of its own (CompressedSparseRow::transpose, src/graph/mod.rs:92-130; PushGraph::from_matrix
  * adjacency.rs:212-224).  `m` must have been created WITH_TRANSPOSE. */
 sl_status sl_matrix_transpose(const sl_matrix *m, uint32_t flags, sl_matrix **out);

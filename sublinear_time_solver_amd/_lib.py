@@ -83,6 +83,7 @@ SIGNATURES = {
     "sl_set_device": (C.c_int, [C.c_int]),
     "sl_set_stream": (C.c_int, [vp]),
     "sl_synchronize": (C.c_int, []),
+    "sl_release_workspace": (None, []),
     "sl_matrix_create_from_triplets": (C.c_int, [u64, vp, vp, vp, u64, u64, u32, C.POINTER(vp)]),
     "sl_matrix_create_csr": (C.c_int, [u64, u64, u64, vp, vp, vp, C.c_int, u64, u32, C.POINTER(vp)]),
     "sl_matrix_destroy": (None, [vp]),
@@ -108,6 +109,9 @@ SIGNATURES = {
     "sl_cg_options_default": (None, [C.POINTER(CgOptions)]),
     "sl_cg_solve": (C.c_int, [vp, vp, C.POINTER(CgOptions), vp, C.POINTER(CgResult)]),
     "sl_estimate_entry_transposed": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
+    "sl_query_session_create": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(vp)]),
+    "sl_query_session_estimate": (C.c_int, [vp, u64, f64, u64, C.POINTER(EstimateResult)]),
+    "sl_query_session_destroy": (None, [vp]),
     "sl_matrix_transpose": (C.c_int, [vp, u32, C.POINTER(vp)]),
     "sl_synth_pagerank_device": (C.c_int, [u64, u64, f64, u32, u32, vp, vp, vp, C.POINTER(u64)]),
 }

@@ -40,20 +40,57 @@ void *sl_scratch(size_t bytes)
     return c.scratch;
 }
 
-namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    sl_status alloc(size_t bytes)
-    {
-        if (p) { hipFree(p); p = nullptr; }
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
-        if (e != hipSuccess) return sl_fail(SL_ALLOCATION, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        return SL_OK;
+// ---- workspace pool --------------------------------------------------------------------------
+static size_t ws_cache_limit()
+{
+    static size_t lim = 0;
+    if (!lim) { const char *e = getenv("SL_WORKSPACE_CACHE_MB"); lim = (size_t)(e ? atoll(e) : 16384) << 20; if (!lim) lim = 1; }
+    return lim;
+}
+void *sl_ws_alloc(size_t bytes)
+{
+    sl_ctx &c = sl_context();
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (size_t i = 0; i < c.ws.size(); ++i) {        // smallest cached block that fits and is not grossly oversized
+        const auto &b = c.ws[i];
+        if (b.in_use || b.device != dev || b.bytes < bytes || b.bytes > 4 * bytes + (1u << 20)) continue;
+        if (best < 0 || b.bytes < c.ws[best].bytes) best = (int)i;
     }
-    template <class T> T *as() const { return static_cast<T *>(p); }
-};
-#define SL_TRY(expr) do { sl_status s_ = (expr); if (s_ != SL_OK) return s_; } while (0)
+    if (best >= 0) { c.ws[best].in_use = true; return c.ws[best].p; }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        sl_release_workspace();                        // give the cache back and try once more
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    }
+    c.ws.push_back({p, bytes, dev, true});
+    return p;
+}
+void sl_ws_free(void *p)
+{
+    sl_ctx &c = sl_context();
+    size_t cached = 0;
+    for (const auto &b : c.ws) if (!b.in_use) cached += b.bytes;
+    for (size_t i = 0; i < c.ws.size(); ++i) {
+        if (c.ws[i].p != p) continue;
+        if (cached + c.ws[i].bytes > ws_cache_limit()) { hipFree(p); c.ws.erase(c.ws.begin() + i); }
+        else c.ws[i].in_use = false;
+        return;
+    }
+    hipFree(p);                                        // not ours (allocated by another thread): plain free
+}
+extern "C" void sl_release_workspace(void)
+{
+    sl_ctx &c = sl_context();
+    for (size_t i = 0; i < c.ws.size();) {
+        if (!c.ws[i].in_use) { hipFree(c.ws[i].p); c.ws.erase(c.ws.begin() + i); }
+        else ++i;
+    }
+}
+
+namespace {
 
 sl_status require_device()
 {
@@ -82,6 +119,27 @@ sl_status read_scalars(const double *d, double *h, int count)
     return SL_OK;
 }
 sl_row_args row_args(const sl_matrix *m) { return sl_matrix_row_args(m); }
+// squared-norm thresholds for the device-side stop rules: for every h >= 0
+//   (sqrt(h) <  tol) == (h <  sq_threshold_lt(tol))      and      (sqrt(h) <= tol) == (h <= sq_threshold_le(tol))
+// (sqrt is monotone and correctly rounded; the loops move a few ulps at most)
+double sq_threshold_lt(double tol)
+{
+    if (tol != tol) return tol;                     // NaN: never true on either side
+    if (!(tol > 0.0)) return 0.0;                   // sqrt(h) < tol never holds; h < 0 never holds
+    double t = tol * tol;
+    while (t > 0.0 && std::sqrt(t) >= tol) t = std::nextafter(t, 0.0);
+    while (std::sqrt(t) < tol) t = std::nextafter(t, INFINITY);      // smallest t with sqrt(t) >= tol
+    return t;
+}
+double sq_threshold_le(double tol)
+{
+    if (tol != tol) return tol;
+    if (tol < 0.0) return -1.0;
+    double t = tol * tol;
+    while (std::sqrt(t) <= tol && t < INFINITY) t = std::nextafter(t, INFINITY);
+    while (t > 0.0 && std::sqrt(t) > tol) t = std::nextafter(t, 0.0);  // largest t with sqrt(t) <= tol
+    return t;
+}
 size_t partial_bytes(const sl_matrix *m) { return (((size_t)sl_row_grid(m->n_slices) + m->n_long) * 2 + 4096) * sizeof(double); }
 } // namespace
 
@@ -176,9 +234,9 @@ sl_status sl_matrix_create_csr(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, c
     if (where == SL_MEM_HOST) {
         DevBuf rp, ci, va;
         hipStream_t s = sl_context().stream;
-        st = rp.alloc((n_rows + 1) * sizeof(uint32_t));
-        if (st == SL_OK) st = ci.alloc(nnz * sizeof(uint32_t));
-        if (st == SL_OK) st = va.alloc(nnz * sizeof(double));
+        st = rp.alloc_owned((n_rows + 1) * sizeof(uint32_t));
+        if (st == SL_OK) st = ci.alloc_owned(nnz * sizeof(uint32_t));
+        if (st == SL_OK) st = va.alloc_owned(nnz * sizeof(double));
         if (st == SL_OK) {
             hipError_t e = hipMemcpyAsync(rp.p, row_ptr, (n_rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s);
             if (e == hipSuccess && nnz) e = hipMemcpyAsync(ci.p, col_idx, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, s);
@@ -189,8 +247,8 @@ sl_status sl_matrix_create_csr(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, c
             if (keep) { // hand the uploaded buffers over instead of copying them again
                 st = sl_build_from_device_csr(m, rp.as<uint32_t>(), ci.as<uint32_t>(), va.as<double>(), false);
                 if (st == SL_OK && !m->d_row_ptr) {      // (long rows make the build keep its own copy already)
-                    m->d_row_ptr = rp.as<uint32_t>(); m->d_col_idx = ci.as<uint32_t>(); m->d_values = va.as<double>();
-                    rp.p = ci.p = va.p = nullptr;
+                    m->d_row_ptr = static_cast<uint32_t *>(rp.release()); m->d_col_idx = static_cast<uint32_t *>(ci.release());
+                    m->d_values = static_cast<double *>(va.release());
                     m->device_bytes += (n_rows + 1) * sizeof(uint32_t) + nnz * 12;
                 }
             } else {
@@ -470,40 +528,103 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
         return SL_OK;
     };
 
+    // The loop is enqueued speculatively, `batch` iterations at a time (sl_solve_ctl, sl_internal.hpp): nothing is
+    // read back inside a batch, the reducing launches apply the stop rules on the device and later launches gate
+    // themselves off; the host then replays the reference's control flow over the logged sums.  Same decisions and
+    // bits as an iteration-by-iteration loop, one host round trip per batch instead of one or two per iteration.
+    static int batch_env = -1;
+    if (batch_env < 0) { const char *e = getenv("SL_SOLVE_BATCH"); batch_env = e ? atoi(e) : 10; if (batch_env < 1) batch_env = 1; if (batch_env > 25) batch_env = 25; }
+    DevBuf ctlbuf;
+    SL_TRY(ctlbuf.alloc(sizeof(sl_solve_ctl)));
+    sl_solve_ctl *d_ctl = ctlbuf.as<sl_solve_ctl>();
+    const double thr_series = sq_threshold_lt(o->series_tolerance), thr_tol = sq_threshold_le(o->tolerance);
+    struct planned { int kind; double *t_after; };      // kind 0: term k = 0, 1: fused step, 2: residual
+    std::vector<planned> plan;
+
     hipEvent_t e0, e1;
     SL_HIP(hipEventCreate(&e0));
     SL_HIP(hipEventCreate(&e1));
     SL_HIP(hipEventRecord(e0, s));
-    while (!is_converged() && it < o->max_iterations) {
-        if (terms < o->max_terms) {                                                      // compute_next_term :252-277
-            double h;
-            if (terms > 0) {
-                sl_row_args a = row_args(m);
-                a.gather = t_cur; a.dinv = dinv.as<double>(); a.out = t_nxt; a.x = x.as<double>();
-                a.partials = scr; a.result = d_res;
-                status = sl_launch_rows(a, order, SL_EPI_NEUMANN, s);
-                if (status != SL_OK) break;
-                std::swap(t_cur, t_nxt);
-                ++matvec; ++step_launches;
-            } else {
-                status = sl_launch_axpy(n, 1.0, t_cur, x.as<double>(), s);               // x += term (k = 0)
-                if (status == SL_OK) status = sl_launch_sumsq(n, t_cur, scr, d_res, s);
-                if (status != SL_OK) break;
+    bool done = false;
+    while (!done && !is_converged() && it < o->max_iterations) {
+        // ---- enqueue iterations [it, it_end) as if no stop rule fired ----
+        const uint64_t it_end = std::min<uint64_t>(it + (uint64_t)batch_env, o->max_iterations);
+        plan.clear();
+        status = sl_launch_ctl_reset(d_ctl, s);
+        uint64_t p_terms = terms;
+        double *p_cur = t_cur, *p_nxt = t_nxt;
+        for (uint64_t pit = it; pit < it_end && status == SL_OK; ++pit) {
+            const uint32_t rel = (uint32_t)(pit - it);
+            if (p_terms < o->max_terms) {                                                // compute_next_term :252-277
+                if (p_terms > 0) {
+                    sl_row_args a = row_args(m);
+                    a.gather = p_cur; a.dinv = dinv.as<double>(); a.out = p_nxt; a.x = x.as<double>();
+                    a.partials = scr; a.result = nullptr;
+                    a.ctl = d_ctl; a.gate_it = rel; a.ctl_slot = (uint32_t)plan.size(); a.ctl_mode = SL_JUDGE_LT; a.ctl_threshold = thr_series;
+                    status = sl_launch_rows(a, order, SL_EPI_NEUMANN, s);
+                    std::swap(p_cur, p_nxt);
+                    plan.push_back({1, p_cur});
+                } else {
+                    status = sl_launch_axpy(n, 1.0, p_cur, x.as<double>(), s);           // x += term (k = 0)
+                    if (status == SL_OK)
+                        status = sl_launch_sumsq_judged(n, p_cur, scr, d_ctl, rel, (uint32_t)plan.size(), SL_JUDGE_LT, thr_series, s);
+                    plan.push_back({0, p_cur});
+                }
+                ++p_terms;
             }
-            status = read_scalars(d_res, &h, 1);
-            if (status != SL_OK) break;
-            tn = std::sqrt(h);
-            if (term_norms) term_norms[terms] = tn;
-            ++terms;
-            if (tn < o->series_tolerance) series_conv = true;                            // :270-274
+            if (pit % 5 == 0 && status == SL_OK) {                                       // update_residual :302-318, :489-491
+                sl_row_args a = row_args(m);
+                a.gather = x.as<double>(); a.aux = res_rhs; a.out = nullptr; a.partials = scr; a.result = nullptr;
+                a.ctl = d_ctl; a.gate_it = rel; a.ctl_slot = (uint32_t)plan.size(); a.ctl_mode = SL_JUDGE_LE_OR_NONFINITE; a.ctl_threshold = thr_tol;
+                status = sl_launch_rows(a, order, SL_EPI_RESIDUAL, s);
+                plan.push_back({2, nullptr});
+            }
         }
-        if (it % 5 == 0) { status = update_residual(); if (status != SL_OK) break; }     // :489-491
-        ++it;
-        if (!std::isfinite(resn)) {                                                      // :501-507
-            status = sl_fail(SL_NUMERICAL_INSTABILITY, "Non-finite residual norm at iteration %llu", (unsigned long long)it);
+        if (status != SL_OK) break;
+        sl_solve_ctl h_ctl;
+        if (hipMemcpyAsync(&h_ctl, d_ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            status = sl_fail(SL_DEVICE_ERROR, "solve-loop readback failed");
             break;
         }
-        if (series_conv) break;                                                          // :510-512
+        // ---- replay neumann.rs:477-513 over the log ----
+        size_t used = 0;
+        auto next_logged = [&](double *h) -> bool {
+            if (used >= h_ctl.n_done || used >= plan.size()) return false;
+            *h = h_ctl.log[used++];
+            return true;
+        };
+        bool in_sync = true;
+        while (!is_converged() && it < it_end) {
+            if (terms < o->max_terms) {
+                double h;
+                if (!(in_sync = next_logged(&h))) break;
+                const planned &pl = plan[used - 1];
+                if (pl.kind == 1) { t_cur = pl.t_after; ++matvec; ++step_launches; }
+                tn = std::sqrt(h);
+                if (term_norms) term_norms[terms] = tn;
+                ++terms;
+                if (tn < o->series_tolerance) series_conv = true;                        // :270-274
+            }
+            if (it % 5 == 0) {
+                double h;
+                if (!(in_sync = next_logged(&h))) break;
+                resn = std::sqrt(h);
+                ++matvec; ++resid_launches;
+            }
+            ++it;
+            if (!std::isfinite(resn)) {                                                  // :501-507
+                status = sl_fail(SL_NUMERICAL_INSTABILITY, "Non-finite residual norm at iteration %llu", (unsigned long long)it);
+                done = true;
+                break;
+            }
+            if (series_conv) { done = true; break; }                                     // :510-512
+        }
+        t_nxt = (t_cur == ta.as<double>()) ? tb.as<double>() : ta.as<double>();
+        if (!in_sync || used != h_ctl.n_done) {
+            status = sl_fail(SL_DEVICE_ERROR, "speculative solve loop out of step with the device (%zu of %u reductions consumed)",
+                             used, h_ctl.n_done);
+            break;
+        }
     }
     hipEventRecord(e1, s);
     hipEventSynchronize(e1);

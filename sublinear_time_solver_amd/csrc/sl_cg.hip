@@ -62,18 +62,6 @@ __global__ __launch_bounds__(1024) void sl_cg_final_reduce_kernel(const double *
 }
 
 namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    sl_status alloc(size_t bytes)
-    {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
-        if (e != hipSuccess) return sl_fail(SL_ALLOCATION, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        return SL_OK;
-    }
-    template <class T> T *as() const { return static_cast<T *>(p); }
-};
-#define SL_TRY(expr) do { sl_status s_ = (expr); if (s_ != SL_OK) return s_; } while (0)
 } // namespace
 
 extern "C" {

@@ -22,19 +22,6 @@ sl_status sl_sort_keys_u32(const uint32_t *keys_in, uint32_t *keys_out, uint64_t
 #define DSUB(a, b) __dsub_rn((a), (b))
 
 namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    sl_status alloc(size_t bytes)
-    {
-        if (p) { hipFree(p); p = nullptr; }
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
-        if (e != hipSuccess) return sl_fail(SL_ALLOCATION, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-        return SL_OK;
-    }
-    template <class T> T *as() const { return static_cast<T *>(p); }
-};
-#define SL_TRY(expr) do { sl_status s_ = (expr); if (s_ != SL_OK) return s_; } while (0)
 
 // operator view: CSR rows of the operator B, and CSR rows of B^T (= columns of B)
 struct op_view {
@@ -130,22 +117,113 @@ __global__ __launch_bounds__(256) void sl_select_kernel(uint64_t n, const double
 }
 
 // ---- sparse round ------------------------------------------------------------------------------
-// (1) per frontier column j: x_j += delta_j, and every row i with B_ij != 0 becomes a candidate
-//     (atomicExch de-duplicates; the candidate LIST is unordered, its use is order-free).
-__global__ __launch_bounds__(256) void sl_expand_kernel(uint32_t nf, const uint32_t *frontier, op_view op, const double *delta,
-                                                        double *x, uint32_t *cand_flag, uint32_t *cand, uint32_t *cand_count)
+// Sparse rounds are DEVICE-DRIVEN: the list sizes live in a control block in HBM, every kernel of a round reads
+// them there and strides over its list with a fixed grid, and a one-thread kernel closes the round (statistics,
+// list swap, stop rule).  The host enqueues several rounds back to back and reads the block once per batch; rounds
+// enqueued past the stop are empty launches.  A local query of a dozen rounds costs two host round trips.
+struct sl_push_ctl {
+    uint32_t nf, nn, n_long_cols, pad0;   // |frontier|, next frontier, deferred hub columns of the running round
+    uint32_t nc[4];                       // candidate rows of the running round by length class (short, mid, long)
+    uint32_t n_touched;                   // rows whose x / r may be non-zero (query sessions; not reset per batch)
+    uint32_t stop;                        // 0 running, 1 frontier empty (converged), 2 frontier above the dense switch
+    uint32_t rounds, pad1;                // rounds executed in this batch
+    unsigned long long pushes, rows_touched;
+};
+#define SL_FLAG_CAND 1u               // row is in this round's candidate lists
+#define SL_FLAG_TOUCHED 2u            // row is in the session's touched list
+// candidate rows are pulled by a thread (fewer than 8 entries), a 16-lane group (up to 64) or a whole wave
+#define SL_SHORT_ROW 8u
+#define SL_MID_ROW 64u
+
+struct sl_cand_lists { uint32_t *list[3]; };
+
+__global__ void sl_push_ctl_reset_kernel(sl_push_ctl *c, uint32_t nf)
 {
-    // one WAVE per frontier column: hub columns (power-law in-degree, 10^4..10^5 entries) are walked by 64
-    // lanes with coalesced index loads instead of serialising one thread for milliseconds
-    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    c->nf = nf; c->nn = 0; c->n_long_cols = 0; c->nc[0] = c->nc[1] = c->nc[2] = 0; c->stop = 0; c->rounds = 0; c->pushes = 0; c->rows_touched = 0;
+}
+
+// (1) per frontier column j: x_j += delta_j, and every row i with B_ij != 0 becomes a candidate
+//     (the atomic flag de-duplicates; the candidate LISTS are unordered, their use is order-free).
+//     One WAVE per frontier column, 4 x 64 entries in flight per step.  A fresh candidate is classified by its row
+//     length into one of three lists; the wave reserves the slots of all its fresh candidates with one atomic
+//     instruction (ballot + popcount, the three class leaders issue together).  Hub columns (power-law in-degree,
+//     10^4..10^5 entries) are deferred to sl_expand_long_kernel, where the whole grid walks each of them.
+#define SL_LONG_COL 1024u
+
+__device__ __forceinline__ void sl_mark_candidates(uint32_t i, bool valid, uint32_t lane, const uint32_t *row_ptr, uint32_t *flag,
+                                                   const sl_cand_lists &cl, uint32_t *touched, sl_push_ctl *c)
+{
+    uint32_t old = SL_FLAG_CAND | SL_FLAG_TOUCHED;
+    if (valid) old = atomicOr(&flag[i], touched ? (SL_FLAG_CAND | SL_FLAG_TOUCHED) : SL_FLAG_CAND);
+    const bool fresh = valid && !(old & SL_FLAG_CAND);
+    if (!__ballot(fresh)) return;                                              // wave-uniform
+    uint32_t cls = 3;
+    if (fresh) {
+        const uint32_t len = row_ptr[i + 1] - row_ptr[i];
+        cls = len < SL_SHORT_ROW ? 0u : (len <= SL_MID_ROW ? 1u : 2u);
+    }
+    const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
+    const unsigned long long mine = cls == 0u ? m0 : (cls == 1u ? m1 : m2);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t base = 0;
+    if (fresh && !(mine & below)) base = atomicAdd(&c->nc[cls], (uint32_t)__popcll(mine));   // the first lane of each class
+    const uint32_t b0 = __shfl(base, m0 ? __builtin_ctzll(m0) : 0), b1 = __shfl(base, m1 ? __builtin_ctzll(m1) : 0),
+                   b2 = __shfl(base, m2 ? __builtin_ctzll(m2) : 0);
+    if (fresh) cl.list[cls][(cls == 0u ? b0 : (cls == 1u ? b1 : b2)) + (uint32_t)__popcll(mine & below)] = i;
+    if (touched) {                                                             // query session: first time this row is reached
+        const bool first = fresh && !(old & SL_FLAG_TOUCHED);
+        const unsigned long long mt = __ballot(first);
+        if (mt) {
+            uint32_t tb = 0;
+            const int leader = __builtin_ctzll(mt);
+            if ((int)lane == leader) tb = atomicAdd(&c->n_touched, (uint32_t)__popcll(mt));
+            tb = __shfl(tb, leader);
+            if (first) touched[tb + (uint32_t)__popcll(mt & below)] = i;
+        }
+    }
+}
+
+__device__ __forceinline__ void sl_expand_piece(uint32_t k, uint32_t k1, uint32_t lane, const op_view &op, uint32_t *flag, const sl_cand_lists &cl,
+                                                uint32_t *touched, sl_push_ctl *c)
+{
+    const bool va = k < k1, vb = k + 64 < k1, vc = k + 128 < k1, vd = k + 192 < k1;
+    const uint32_t ia = va ? op.tidx[k] : 0u, ib = vb ? op.tidx[k + 64] : 0u, ic = vc ? op.tidx[k + 128] : 0u, id = vd ? op.tidx[k + 192] : 0u;
+    sl_mark_candidates(ia, va, lane, op.ptr, flag, cl, touched, c);
+    sl_mark_candidates(ib, vb, lane, op.ptr, flag, cl, touched, c);
+    sl_mark_candidates(ic, vc, lane, op.ptr, flag, cl, touched, c);
+    sl_mark_candidates(id, vd, lane, op.ptr, flag, cl, touched, c);
+}
+
+__global__ __launch_bounds__(256) void sl_expand_kernel(sl_push_ctl *c, const uint32_t *frontier, op_view op, const double *delta,
+                                                        double *x, uint32_t *flag, sl_cand_lists cl, uint32_t *long_cols, uint32_t *touched)
+{
+    if (c->stop) return;
+    const uint32_t nf = c->nf;
     const uint32_t lane = threadIdx.x & 63u;
-    if (t >= nf) return;
-    const uint32_t j = frontier[t];
-    if (lane == 0) x[j] = DADD(x[j], delta[j]);
-    const uint32_t k1 = op.tptr[j + 1];
-    for (uint32_t k = op.tptr[j] + lane; k < k1; k += 64) {
-        const uint32_t i = op.tidx[k];
-        if (atomicExch(&cand_flag[i], 1u) == 0u) cand[atomicAdd(cand_count, 1u)] = i;
+    const uint32_t nwaves = gridDim.x * 4;
+    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < nf; t += nwaves) {
+        const uint32_t j = frontier[t];
+        if (lane == 0) x[j] = DADD(x[j], delta[j]);
+        const uint32_t k0 = op.tptr[j], k1 = op.tptr[j + 1];
+        if (k1 - k0 > SL_LONG_COL) { if (lane == 0) long_cols[atomicAdd(&c->n_long_cols, 1u)] = j; continue; }
+        const uint32_t steps = (k1 - k0 + 255u) / 256u;                        // wave-uniform trip count (ballots inside)
+        for (uint32_t q = 0; q < steps; ++q) sl_expand_piece(k0 + q * 256u + lane, k1, lane, op, flag, cl, touched, c);
+    }
+}
+
+// hub columns: every wave of the grid takes 256-entry pieces of each deferred column
+__global__ __launch_bounds__(256) void sl_expand_long_kernel(sl_push_ctl *c, const uint32_t *long_cols, op_view op, uint32_t *flag,
+                                                             sl_cand_lists cl, uint32_t *touched)
+{
+    if (c->stop) return;
+    const uint32_t n_long = c->n_long_cols;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (uint32_t t = 0; t < n_long; ++t) {
+        const uint32_t j = long_cols[t];
+        const uint32_t k0 = op.tptr[j], k1 = op.tptr[j + 1];
+        const uint32_t pieces = (k1 - k0 + 255u) / 256u;
+        for (uint32_t q = wave; q < pieces; q += nwaves) sl_expand_piece(k0 + q * 256u + lane, k1, lane, op, flag, cl, touched, c);
     }
 }
 
@@ -173,78 +251,162 @@ __device__ __forceinline__ double sl_csr_row_dot(const op_view &op, uint32_t i, 
 }
 
 // (2) pull update of candidate rows: r_i -= (B delta_old)_i ; next frontier from |r_i dinv_i| >= theta
-__device__ __forceinline__ void sl_pull_finish(uint32_t i, double acc, const double *dinv, double theta, double *r, double *delta_new,
+__device__ __forceinline__ void sl_pull_finish(uint32_t i, double acc, double r_old, double dinv_i, double theta, double *r, double *delta_new,
                                                uint32_t *next, uint32_t *next_count)
 {
-    const double rn = DSUB(r[i], acc);
+    const double rn = DSUB(r_old, acc);
     r[i] = rn;
-    const double p = DMUL(rn, dinv[i]);
+    const double p = DMUL(rn, dinv_i);
     if (fabs(p) >= theta) {
         delta_new[i] = p;
         next[atomicAdd(next_count, 1u)] = i;
     }
 }
 
-// thread per candidate row; rows with more than SL_LONG_ROW entries are deferred to sl_pull_long_kernel
-// (cand is reused as the deferred list: slot indices [0, *long_count) are overwritten only after being read)
-__global__ __launch_bounds__(256) void sl_pull_kernel(uint32_t nc, const uint32_t *cand, op_view op, const double *delta_old,
-                                                      const double *dinv, double theta, int order, double *r,
-                                                      double *delta_new, uint32_t *cand_flag, uint32_t *next, uint32_t *next_count,
-                                                      uint32_t *long_list, uint32_t *long_count)
+// Ordered accumulation of the products a group of G lanes holds for one row: only the NON-ZERO products are added,
+// in entry order — skipping an exactly-zero product cannot change the running sum (s + (+-0) == s, and s is never
+// -0), so the value equals the sequential reference sum bit for bit while the cost follows the (small) number of
+// frontier columns the row hits.  `acc` carries the reference's two summation orders (sparse.rs:194-202 and the
+// 4-lane order of simd_ops.rs:41-77).
+struct sl_row_acc {
+    double sum = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+    uint32_t chunks4 = 0;
+    bool lanes4 = false, merged = false;
+    __device__ __forceinline__ void init(uint32_t len, int order)
+    {
+        lanes4 = (order == SL_ORDER_SIMD4 && len >= 8u);
+        chunks4 = lanes4 ? ((len >> 2) << 2) : 0u;
+    }
+    __device__ __forceinline__ void add(uint32_t q, double pv)              // q = position of the entry in its row
+    {
+        if (q < chunks4) {
+            const uint32_t ln = q & 3u;
+            if (ln == 0) l0 = DADD(l0, pv); else if (ln == 1) l1 = DADD(l1, pv); else if (ln == 2) l2 = DADD(l2, pv); else l3 = DADD(l3, pv);
+        } else {
+            if (lanes4 && !merged) { sum = DADD(DADD(DADD(l0, l1), l2), l3); merged = true; }
+            sum = DADD(sum, pv);
+        }
+    }
+    __device__ __forceinline__ double finish()
+    {
+        if (lanes4 && !merged) sum = DADD(DADD(DADD(l0, l1), l2), l3);
+        return sum;
+    }
+};
+
+// products p (one per lane) of entries at row positions q0 + (lane within group): add the non-zero ones of MY group in order
+template <int G>
+__device__ __forceinline__ void sl_group_accumulate(sl_row_acc &acc, double p, uint32_t q0, uint32_t lane)
 {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= nc) return;
-    const uint32_t i = cand[t];
-    cand_flag[i] = 0u;
-    if (op.ptr[i + 1] - op.ptr[i] > SL_LONG_ROW) { long_list[atomicAdd(long_count, 1u)] = i; return; }
-    sl_pull_finish(i, sl_csr_row_dot(op, i, delta_old, order), dinv, theta, r, delta_new, next, next_count);
+    const unsigned long long all = __ballot(p != 0.0);
+    const uint32_t g0 = lane & ~(uint32_t)(G - 1);                            // first lane of my group
+    unsigned long long seg = (G == 64) ? all : ((all >> g0) & ((1ull << G) - 1ull));
+    while (seg) {                                                             // groups iterate independently (sources are in-group)
+        const int l = __builtin_ctzll(seg);
+        seg &= seg - 1;
+        acc.add(q0 + (uint32_t)l, __shfl(p, (int)g0 + l));
+    }
 }
 
-// one wave per deferred long row (persistent: waves stride over the list).  Lanes form the products of 64
-// consecutive entries in parallel; only the NON-ZERO products are then added, in entry order — skipping an
-// exactly-zero product cannot change the running sum (s + (+-0) == s, and s is never -0), so the value equals
-// the sequential reference sum bit for bit while the cost follows the (small) number of frontier columns hit.
-__global__ __launch_bounds__(256) void sl_pull_long_kernel(const uint32_t *long_list, const uint32_t *long_count, op_view op,
-                                                           const double *delta_old, const double *dinv, double theta, int order,
-                                                           double *r, double *delta_new, uint32_t *next, uint32_t *next_count)
+// One launch, three roles by block range — the candidate lists of a round are independent of each other:
+//   blocks [0, nb0)         short rows, one THREAD per row: all entries are fetched at once (two memory latencies);
+//   blocks [nb0, nb0+nb1)   rows of 8..64 entries, a 16-lane group per row, 4 entries per lane in flight;
+//   the rest                longer rows, one WAVE per row, 1024 entries (16 per lane) in flight per step.
+// A row's cost is a handful of memory latencies whatever its length, instead of two per entry.
+__global__ __launch_bounds__(256) void sl_pull_kernel(sl_push_ctl *c, sl_cand_lists cl, uint32_t nb0, uint32_t nb1, op_view op,
+                                                      const double *delta_old, const double *dinv, double theta, int order, double *r,
+                                                      double *delta_new, uint32_t *flag, uint32_t *next, uint32_t keep_flag)
 {
+    if (c->stop) return;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    const uint32_t n_long = *long_count;
-    for (uint32_t t = wave; t < n_long; t += nwaves) {
-        const uint32_t i = long_list[t];
-        const uint32_t s = op.ptr[i], e = op.ptr[i + 1], len = e - s;
-        const uint32_t chunks4 = (order == SL_ORDER_SIMD4) ? ((len >> 2) << 2) : 0u;
-        double sum = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
-        bool merged = false;
-        for (uint32_t base = s; base < e; base += 64) {
-            const uint32_t k = base + lane;
-            const double p = k < e ? DMUL(op.val[k], delta_old[op.idx[k]]) : 0.0;
-            unsigned long long mask = __ballot(p != 0.0);
-            while (mask) {
-                const int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const double pv = __shfl(p, l);
-                const uint32_t q = base - s + (uint32_t)l;
-                if (q < chunks4) {
-                    const uint32_t ln = q & 3u;
-                    if (ln == 0) l0 = DADD(l0, pv); else if (ln == 1) l1 = DADD(l1, pv); else if (ln == 2) l2 = DADD(l2, pv); else l3 = DADD(l3, pv);
-                } else {
-                    if (order == SL_ORDER_SIMD4 && !merged) { sum = DADD(DADD(DADD(l0, l1), l2), l3); merged = true; }
-                    sum = DADD(sum, pv);
-                }
-            }
+    if (blockIdx.x < nb0) {
+        const uint32_t nc = c->nc[0];
+        const uint32_t stride = nb0 * 256;
+        for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nc; t += stride) {
+            const uint32_t i = cl.list[0][t];
+            const uint32_t s = op.ptr[i], len = op.ptr[i + 1] - s;             // len < 8: both orders are the plain left-to-right sum
+            const double r_old = r[i], dv = dinv[i];
+            flag[i] = keep_flag;
+            uint32_t ci[7]; double va[7], dl[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) { const bool ok = (uint32_t)u < len; ci[u] = ok ? op.idx[s + u] : 0u; va[u] = ok ? op.val[s + u] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) dl[u] = (uint32_t)u < len ? delta_old[ci[u]] : 0.0;
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 7; ++u) if ((uint32_t)u < len) acc = DADD(acc, DMUL(va[u], dl[u]));
+            sl_pull_finish(i, acc, r_old, dv, theta, r, delta_new, next, &c->nn);
         }
-        if (order == SL_ORDER_SIMD4 && !merged) sum = DADD(DADD(DADD(l0, l1), l2), l3);
-        if (lane == 0) sl_pull_finish(i, sum, dinv, theta, r, delta_new, next, next_count);
+    } else if (blockIdx.x < nb0 + nb1) {
+        const uint32_t nc = c->nc[1];
+        const uint32_t lig = lane & 15u;
+        const uint32_t group = (blockIdx.x - nb0) * 16 + (threadIdx.x >> 4), ngroups = nb1 * 16;
+        const uint32_t trips = (nc + ngroups - 1) / ngroups;                   // same trip count for the whole wave (ballots inside)
+        for (uint32_t it = 0; it < trips; ++it) {
+            const uint32_t t = group + it * ngroups;
+            const bool live = t < nc;
+            const uint32_t i = live ? cl.list[1][t] : 0u;
+            const uint32_t s = live ? op.ptr[i] : 0u, len = live ? op.ptr[i + 1] - s : 0u;
+            double r_old = 0.0, dv = 0.0;
+            if (live && lig == 0) { r_old = r[i]; dv = dinv[i]; flag[i] = keep_flag; }
+            double pr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t q = (uint32_t)u * 16u + lig;
+                pr[u] = q < len ? DMUL(op.val[s + q], delta_old[op.idx[s + q]]) : 0.0;
+            }
+            sl_row_acc acc;
+            acc.init(len, order);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sl_group_accumulate<16>(acc, pr[u], (uint32_t)u * 16u, lane);
+            const double sum = acc.finish();
+            if (live && lig == 0) sl_pull_finish(i, sum, r_old, dv, theta, r, delta_new, next, &c->nn);
+        }
+    } else {
+        const uint32_t nc = c->nc[2];
+        const uint32_t nb2 = gridDim.x - nb0 - nb1;
+        const uint32_t wave = (blockIdx.x - nb0 - nb1) * 4 + (threadIdx.x >> 6), nwaves = nb2 * 4;
+        for (uint32_t t = wave; t < nc; t += nwaves) {
+            const uint32_t i = cl.list[2][t];
+            const uint32_t s = op.ptr[i], len = op.ptr[i + 1] - s;
+            double r_old = 0.0, dv = 0.0;
+            if (lane == 0) { r_old = r[i]; dv = dinv[i]; flag[i] = keep_flag; }
+            sl_row_acc acc;
+            acc.init(len, order);
+            for (uint32_t base = 0; base < len; base += 1024u) {
+                double pr[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t q = base + (uint32_t)u * 64u + lane;
+                    pr[u] = q < len ? DMUL(op.val[s + q], delta_old[op.idx[s + q]]) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sl_group_accumulate<64>(acc, pr[u], base + (uint32_t)u * 64u, lane);
+            }
+            const double sum = acc.finish();
+            if (lane == 0) sl_pull_finish(i, sum, r_old, dv, theta, r, delta_new, next, &c->nn);
+        }
     }
 }
 
 // (3) delta_old[j] = 0 for the frontier just consumed (keeps the buffer all-zero outside a frontier)
-__global__ __launch_bounds__(256) void sl_clear_kernel(uint32_t nf, const uint32_t *frontier, double *delta)
+__global__ __launch_bounds__(256) void sl_clear_kernel(sl_push_ctl *c, const uint32_t *frontier, double *delta)
 {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < nf) delta[frontier[t]] = 0.0;
+    if (c->stop) return;
+    const uint32_t nf = c->nf;
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nf; t += stride) delta[frontier[t]] = 0.0;
+}
+
+// (4) close the round: statistics, next frontier becomes the frontier, stop rule
+__global__ void sl_round_end_kernel(sl_push_ctl *c, uint32_t dense_threshold)
+{
+    if (c->stop) return;
+    c->rounds += 1; c->pushes += c->nf; c->rows_touched += (unsigned long long)c->nc[0] + c->nc[1] + c->nc[2];
+    const uint32_t nf = c->nn;
+    c->nf = nf; c->nc[0] = c->nc[1] = c->nc[2] = 0; c->nn = 0; c->n_long_cols = 0;
+    if (nf == 0) c->stop = 1u;
+    else if (nf > dense_threshold) c->stop = 2u;
 }
 
 // generic (any operator given as CSR) dense round, one thread per row — used by estimate_entry
@@ -271,9 +433,12 @@ struct push_state {
     double *x = nullptr, *r = nullptr, *dinv = nullptr;
     double *delta[2] = {nullptr, nullptr};
     uint32_t *frontier[2] = {nullptr, nullptr}; // cur / next
-    uint32_t *cand = nullptr, *cand_flag = nullptr;
-    uint32_t *counters = nullptr;               // [0] cand_count, [1] next_count, [2] compaction total, [3] deferred long rows
+    uint32_t *cand = nullptr, *cand_mid = nullptr, *cand_long = nullptr, *cand_flag = nullptr;   // candidate rows by length class
+    uint32_t *counters = nullptr;               // [2] compaction total
+    sl_push_ctl *ctl = nullptr;                 // device-driven sparse rounds
     uint32_t *long_list = nullptr;
+    uint32_t *touched = nullptr;                // query sessions: rows whose state must be cleaned up afterwards
+    bool flooded = false;                       // a dense round ran: every row may be touched
     uint32_t *block_count = nullptr, *block_off = nullptr;
     uint32_t nblocks = 0;
 };
@@ -317,11 +482,13 @@ struct push_log {
     }
 };
 
-struct round_stats { uint64_t rounds = 0, pushes = 0, rows_touched = 0, dense_rounds = 0; bool converged = false; };
+struct round_stats { uint64_t rounds = 0, pushes = 0, rows_touched = 0, dense_rounds = 0; uint32_t n_touched = 0; bool converged = false; };
 
 // The round loop.  `m` != null enables the row-slice dense kernel (operator = A itself).
+// preseeded: the caller has already written the round-0 frontier (list in frontier[0], values in delta[0], delta[1]
+// all zero) and passes its size — a query session seeds one row without touching the other n - 1.
 sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t max_rounds, int order, double dense_switch,
-                   push_log &plog, round_stats &rs, float *device_ms)
+                   push_log &plog, round_stats &rs, float *device_ms, bool preseeded = false, uint32_t nf0 = 0)
 {
     hipStream_t s = sl_context().stream;
     const uint64_t n = ps.n;
@@ -332,15 +499,22 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
 
     int cur = 0;                 // delta[cur] holds the frontier values, delta[1-cur] is all zero
     // round 0 frontier from r (dense select), ascending list by compaction
-    hipLaunchKernelGGL(sl_select_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, n, ps.r, ps.dinv, theta, ps.delta[cur]);
-    SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s));
-    uint32_t nf = 0;
-    SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s));
+    uint32_t nf = nf0;
+    if (!preseeded) {
+        hipLaunchKernelGGL(sl_select_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, n, ps.r, ps.dinv, theta, ps.delta[cur]);
+        SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s));
+        SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s));
+    }
     bool list_valid = true, list_sorted = true;
     double *scr = nullptr;
     if (m) { scr = static_cast<double *>(sl_scratch((((size_t)sl_row_grid(m->n_slices) + m->n_long) * 2 + 4096) * sizeof(double))); if (!scr) return sl_fail(SL_ALLOCATION, "scratch"); }
     DevBuf resbuf;
     SL_TRY(resbuf.alloc(64));
+
+    static int sparse_batch = -1;
+    if (sparse_batch < 0) { const char *e = getenv("SL_PUSH_BATCH"); sparse_batch = e ? atoi(e) : 8; if (sparse_batch < 1) sparse_batch = 1; }
+    const double dense_limit = dense_switch * (double)n;               // nf > dense_limit  <=>  nf > floor(dense_limit)
+    const uint32_t dense_threshold = dense_limit >= 4294967295.0 ? 0xffffffffu : (dense_limit > 0.0 ? (uint32_t)dense_limit : 0u);
 
     sl_status st = SL_OK;
     while (rs.rounds < max_rounds) {
@@ -364,6 +538,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
                                    ps.dinv, theta, order, ps.r, ps.x, ps.delta[1 - cur]);
             }
             rs.rounds += 1; rs.pushes += nf; rs.rows_touched += n; rs.dense_rounds += 1;
+            ps.flooded = true;
             cur = 1 - cur;                       // delta[cur] now dense-valid; delta[1-cur] holds stale values
             const bool next_dense_likely = m && (double)nf_next > dense_switch * (double)n && !plog.log;
             if (next_dense_likely) { nf = nf_next; list_valid = false; continue; } // no list needed: the dense kernel overwrites everything
@@ -373,27 +548,29 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
         } else {
             if (!list_valid) { SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s)); list_valid = true; list_sorted = true;
                                SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s)); }
-            SL_HIP(hipMemsetAsync(ps.counters, 0, 2 * sizeof(uint32_t), s));
-            SL_HIP(hipMemsetAsync(ps.counters + 3, 0, sizeof(uint32_t), s));
-            hipLaunchKernelGGL(sl_expand_kernel, dim3((nf + 3) / 4), dim3(256), 0, s, nf, ps.frontier[0], ps.op, ps.delta[cur], ps.x,
-                               ps.cand_flag, ps.cand, ps.counters);
-            uint32_t nc = 0;
-            SL_HIP(hipMemcpyAsync(&nc, ps.counters, 4, hipMemcpyDeviceToHost, s));
-            SL_HIP(hipStreamSynchronize(s));
-            if (nc) {
-                hipLaunchKernelGGL(sl_pull_kernel, dim3((nc + 255) / 256), dim3(256), 0, s, nc, ps.cand, ps.op, ps.delta[cur], ps.dinv,
-                                   theta, order, ps.r, ps.delta[1 - cur], ps.cand_flag, ps.frontier[1], ps.counters + 1, ps.long_list, ps.counters + 3);
-                hipLaunchKernelGGL(sl_pull_long_kernel, dim3(nc < 4096u ? (nc + 3) / 4 : 1024u), dim3(256), 0, s, ps.long_list, ps.counters + 3, ps.op,
-                                   ps.delta[cur], ps.dinv, theta, order, ps.r, ps.delta[1 - cur], ps.frontier[1], ps.counters + 1);
+            // a batch of device-driven sparse rounds (one round when the frontier lists are being logged)
+            uint64_t batch = plog.log ? 1 : (uint64_t)sparse_batch;
+            if (batch > max_rounds - rs.rounds) batch = max_rounds - rs.rounds;
+            hipLaunchKernelGGL(sl_push_ctl_reset_kernel, dim3(1), dim3(1), 0, s, ps.ctl, nf);
+            const sl_cand_lists cl{{ps.cand, ps.cand_mid, ps.cand_long}};
+            for (uint64_t b = 0; b < batch; ++b) {
+                const int c = cur ^ (int)(b & 1);
+                uint32_t *f_in = ps.frontier[b & 1], *f_out = ps.frontier[1 - (b & 1)];
+                hipLaunchKernelGGL(sl_expand_kernel, dim3(1024), dim3(256), 0, s, ps.ctl, f_in, ps.op, ps.delta[c], ps.x, ps.cand_flag, cl, ps.long_list, ps.touched);
+                hipLaunchKernelGGL(sl_expand_long_kernel, dim3(512), dim3(256), 0, s, ps.ctl, ps.long_list, ps.op, ps.cand_flag, cl, ps.touched);
+                hipLaunchKernelGGL(sl_pull_kernel, dim3(512 + 512 + 512), dim3(256), 0, s, ps.ctl, cl, 512u, 512u, ps.op, ps.delta[c], ps.dinv, theta, order,
+                                   ps.r, ps.delta[1 - c], ps.cand_flag, f_out, ps.touched ? SL_FLAG_TOUCHED : 0u);
+                hipLaunchKernelGGL(sl_clear_kernel, dim3(256), dim3(256), 0, s, ps.ctl, f_in, ps.delta[c]);
+                hipLaunchKernelGGL(sl_round_end_kernel, dim3(1), dim3(1), 0, s, ps.ctl, dense_threshold);
             }
-            hipLaunchKernelGGL(sl_clear_kernel, dim3((nf + 255) / 256), dim3(256), 0, s, nf, ps.frontier[0], ps.delta[cur]);
-            uint32_t nn = 0;
-            SL_HIP(hipMemcpyAsync(&nn, ps.counters + 1, 4, hipMemcpyDeviceToHost, s));
+            sl_push_ctl h;
+            SL_HIP(hipMemcpyAsync(&h, ps.ctl, sizeof(h), hipMemcpyDeviceToHost, s));
             SL_HIP(hipStreamSynchronize(s));
-            rs.rounds += 1; rs.pushes += nf; rs.rows_touched += nc;
-            std::swap(ps.frontier[0], ps.frontier[1]);
-            cur = 1 - cur;
-            nf = nn; list_valid = true; list_sorted = false;
+            rs.rounds += h.rounds; rs.pushes += h.pushes; rs.rows_touched += h.rows_touched;
+            if (h.rounds & 1u) { std::swap(ps.frontier[0], ps.frontier[1]); cur = 1 - cur; }
+            nf = h.nf; list_valid = true; list_sorted = false;
+            rs.n_touched = h.n_touched;
+            if (h.rounds == 0 && h.stop == 0) return sl_fail(SL_DEVICE_ERROR, "sparse push batch made no progress");
         }
     }
     hipEventRecord(e1, s);
@@ -405,7 +582,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     return st;
 }
 
-sl_status alloc_state(push_state &ps, uint64_t n, DevBuf bufs[16])
+sl_status alloc_state(push_state &ps, uint64_t n, DevBuf bufs[20])
 {
     ps.n = n;
     ps.nblocks = (uint32_t)((n + SL_CTILE - 1) / SL_CTILE);
@@ -419,9 +596,13 @@ sl_status alloc_state(push_state &ps, uint64_t n, DevBuf bufs[16])
     SL_TRY(bufs[k].alloc(n * 4)); ps.frontier[0] = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.frontier[1] = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.cand = bufs[k++].as<uint32_t>();
+    SL_TRY(bufs[k].alloc(n * 4)); ps.cand_mid = bufs[k++].as<uint32_t>();
+    SL_TRY(bufs[k].alloc(n * 4)); ps.cand_long = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.cand_flag = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.long_list = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(64)); ps.counters = bufs[k++].as<uint32_t>();
+    SL_TRY(bufs[k].alloc(sizeof(sl_push_ctl))); ps.ctl = bufs[k++].as<sl_push_ctl>();
+    SL_HIP(hipMemsetAsync(ps.ctl, 0, sizeof(sl_push_ctl), sl_context().stream));
     SL_TRY(bufs[k].alloc((size_t)ps.nblocks * 4)); ps.block_count = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc((size_t)ps.nblocks * 4)); ps.block_off = bufs[k++].as<uint32_t>();
     SL_HIP(hipMemsetAsync(ps.cand_flag, 0, n * 4, sl_context().stream));
@@ -457,7 +638,7 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
     const hipMemcpyKind out_kind = o->mem == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
 
     push_state ps;
-    DevBuf bufs[16], bbuf, ax;
+    DevBuf bufs[20], bbuf, ax;
     SL_TRY(alloc_state(ps, n, bufs));
     ps.op = op_view{m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_trow};
     SL_TRY(bbuf.alloc(n * 8));
@@ -496,7 +677,198 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
     return SL_OK;
 }
 
-// shared body: `given_is_transpose` = the matrix holds A^T (its rows are the operator of the push)
+// ---- query sessions: single-entry queries whose cost follows the rows the push touches ----------------------
+// ForwardPushSolver holds its graph and answers query after query (forward_push.rs:52-66, 224-231).  The session
+// is that object: state vectors, D^-1, the device copy of b and the transpose live across queries and stay all-zero
+// between them; a query seeds one row, runs device-driven sparse rounds, sums over the rows it touched and zeroes
+// exactly those again.  Nothing in a query is O(n) unless its frontier floods past the dense switch.
+} // extern "C"
+
+struct sl_query_session {
+    const sl_matrix *m = nullptr;
+    bool given_is_transpose = false;
+    uint64_t n = 0;
+    push_state ps;
+    DevBuf bufs[20], bbuf, touched, sums;
+    const double *db = nullptr;
+    std::vector<double> h_dinv;           // host copy: the seed's threshold test needs dinv[row] only
+    double dense_switch = 0.25;
+};
+
+// r[row] = 1 and, if it passes the threshold, the one-entry frontier {row}
+__global__ void sl_seed_kernel(uint32_t row, double p, int in_frontier, double *r, double *delta, uint32_t *frontier, uint32_t *flag,
+                               uint32_t *touched, sl_push_ctl *c)
+{
+    r[row] = 1.0;
+    if (in_frontier) { delta[row] = p; frontier[0] = row; }
+    flag[row] = SL_FLAG_TOUCHED;
+    touched[0] = row;
+    c->n_touched = 1;
+}
+
+// estimate = sum x_i b_i and ||r||_1 over the ASCENDING touched list: 1024-entry tiles, fixed tree inside a tile
+__global__ __launch_bounds__(256) void sl_touched_sums_kernel(uint32_t nt, const uint32_t *sorted, const double *x, const double *b,
+                                                              const double *r, double *partials, uint32_t nblocks)
+{
+    __shared__ double red[8];
+    double e = 0.0, l = 0.0;
+    const uint32_t base = blockIdx.x * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t = base + k * 256 + threadIdx.x;
+        if (t < nt) { const uint32_t i = sorted[t]; e = DADD(e, DMUL(x[i], b[i])); l = DADD(l, fabs(r[i])); }
+    }
+    for (int off = 32; off > 0; off >>= 1) { e = DADD(e, __shfl_xor(e, off)); l = DADD(l, __shfl_xor(l, off)); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = e; red[4 + (threadIdx.x >> 6)] = l; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = DADD(DADD(DADD(red[0], red[1]), red[2]), red[3]);
+        partials[nblocks + blockIdx.x] = DADD(DADD(DADD(red[4], red[5]), red[6]), red[7]);
+    }
+}
+__global__ __launch_bounds__(1024) void sl_touched_final_kernel(uint32_t nblocks, const double *partials, double *out)
+{
+    __shared__ double red[32];
+    double e = 0.0, l = 0.0;
+    for (uint32_t j = threadIdx.x; j < nblocks; j += 1024) { e = DADD(e, partials[j]); l = DADD(l, partials[nblocks + j]); }
+    for (int off = 32; off > 0; off >>= 1) { e = DADD(e, __shfl_xor(e, off)); l = DADD(l, __shfl_xor(l, off)); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = e; red[16 + (threadIdx.x >> 6)] = l; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double te = red[0], tl = red[16];
+        for (int w = 1; w < 16; ++w) { te = DADD(te, red[w]); tl = DADD(tl, red[16 + w]); }
+        out[0] = te; out[1] = tl;
+    }
+}
+__global__ __launch_bounds__(256) void sl_touched_cleanup_kernel(uint32_t nt, const uint32_t *touched, double *x, double *r, double *d0,
+                                                                 double *d1, uint32_t *flag)
+{
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nt; t += stride) {
+        const uint32_t i = touched[t];
+        x[i] = 0.0; r[i] = 0.0; d0[i] = 0.0; d1[i] = 0.0; flag[i] = 0u;
+    }
+}
+
+extern "C" {
+
+sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, const double *b, sl_mem where, sl_query_session **out)
+{
+    if (!out) return sl_fail(SL_INVALID_INPUT, "out is null");
+    *out = nullptr;
+    if (!m || !b) return sl_fail(SL_INVALID_INPUT, "null argument");
+    if (m->n_rows != m->n_cols || m->row_offset != 0) return sl_fail(SL_INVALID_INPUT, "Matrix must be square");
+    if (!m->d_tptr || !m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "estimate_entry needs a matrix created with SL_MATRIX_WITH_TRANSPOSE");
+    const uint64_t n = m->n_rows;
+    hipStream_t s = sl_context().stream;
+    sl_query_session *q = new (std::nothrow) sl_query_session();
+    if (!q) return sl_fail(SL_ALLOCATION, "out of host memory");
+    q->m = m; q->n = n; q->given_is_transpose = matrix_is_transpose != 0;
+    q->dense_switch = q->given_is_transpose ? 1.0 / 16.0 : 0.25;
+    sl_status st = alloc_state(q->ps, n, q->bufs);
+    if (st == SL_OK) st = q->touched.alloc((n ? n : 1) * 4);
+    if (st == SL_OK) st = q->sums.alloc((2 * ((n + 1023) / 1024) + 8) * sizeof(double));
+    unsigned long long hs[4] = {0, 0, 0, 0};
+    if (st == SL_OK) {
+        q->ps.touched = q->touched.as<uint32_t>();
+        if (q->given_is_transpose) {
+            // operator B = the matrix itself (= A^T); its dense rounds can use the row-slice kernels
+            q->ps.op = op_view{m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_trow};
+            st = sl_matrix_diag_pass(m, q->ps.dinv, hs);
+        } else {
+            // operator B = A^T: rows of B = columns of A (sorted transpose), columns of B = rows of A
+            q->ps.op = op_view{m->d_tptr, m->d_trow, m->d_tval, m->d_row_ptr, m->d_col_idx};
+            st = sl_csr_diag_pass(n, m->d_tptr, m->d_trow, m->d_tval, q->ps.dinv, hs);
+        }
+    }
+    if (st == SL_OK && (hs[0] & 2ull)) st = sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2]);
+    if (st == SL_OK && (hs[0] & 4ull)) st = sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3]);
+    if (st == SL_OK) {
+        q->h_dinv.resize(n);
+        hipError_t e = hipMemsetAsync(q->ps.x, 0, n * 8, s);
+        if (e == hipSuccess) e = hipMemsetAsync(q->ps.r, 0, n * 8, s);
+        if (e == hipSuccess) e = hipMemsetAsync(q->ps.delta[0], 0, n * 8, s);
+        if (e == hipSuccess) e = hipMemsetAsync(q->ps.delta[1], 0, n * 8, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(q->h_dinv.data(), q->ps.dinv, n * 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && where == SL_MEM_HOST) {
+            st = q->bbuf.alloc(n * 8);
+            if (st == SL_OK) { e = hipMemcpyAsync(q->bbuf.p, b, n * 8, hipMemcpyHostToDevice, s); q->db = q->bbuf.as<double>(); }
+        } else {
+            q->db = b;                     // device vector owned by the caller; must outlive the session
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess && st == SL_OK) st = sl_fail(SL_DEVICE_ERROR, "session setup failed: %s", hipGetErrorString(e));
+    }
+    if (st != SL_OK) { delete q; return st; }
+    *out = q;
+    return SL_OK;
+}
+
+void sl_query_session_destroy(sl_query_session *q) { delete q; }
+
+sl_status sl_query_session_estimate(sl_query_session *q, uint64_t row, double theta, uint64_t max_rounds, sl_estimate_result *res)
+{
+    if (!q || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
+    memset(res, 0, sizeof(*res));
+    const uint64_t n = q->n;
+    if (row >= n) return sl_fail(SL_INVALID_INPUT, "Row index %llu out of bounds. Matrix has %llu rows", (unsigned long long)row, (unsigned long long)n);
+    hipStream_t s = sl_context().stream;
+    push_state &ps = q->ps;
+    // y0 = 0, r = e_row; round-0 frontier = {row} if |1 * dinv_row| >= theta
+    const double p = q->h_dinv[row];
+    const int in_frontier = std::fabs(p) >= theta ? 1 : 0;
+    ps.flooded = false;
+    hipLaunchKernelGGL(sl_seed_kernel, dim3(1), dim3(1), 0, s, (uint32_t)row, p, in_frontier, ps.r, ps.delta[0], ps.frontier[0], ps.cand_flag,
+                       ps.touched, ps.ctl);
+    push_log plog;
+    round_stats rs;
+    rs.n_touched = 1;
+    float ms = 0.f;
+    sl_status st = run_push(ps, q->given_is_transpose ? q->m : nullptr, theta, max_rounds, SL_ORDER_CSR_SEQUENTIAL, q->dense_switch, plog, rs, &ms,
+                            true, (uint32_t)in_frontier);
+    double h[2] = {0.0, 0.0};
+    if (st == SL_OK && !ps.flooded) {
+        // estimate = y . b ; residual_l1 = ||r_y||_1 over the touched rows, in ascending row order
+        const uint32_t nt = rs.n_touched;
+        DevBuf sorted;
+        st = sorted.alloc((size_t)nt * 4);
+        if (st == SL_OK) st = sl_sort_keys_u32(ps.touched, sorted.as<uint32_t>(), nt, s);
+        if (st == SL_OK) {
+            const uint32_t nb = (nt + 1023) / 1024;
+            double *scr = q->sums.as<double>();
+            hipLaunchKernelGGL(sl_touched_sums_kernel, dim3(nb), dim3(256), 0, s, nt, sorted.as<uint32_t>(), ps.x, q->db, ps.r, scr, nb);
+            hipLaunchKernelGGL(sl_touched_final_kernel, dim3(1), dim3(1024), 0, s, nb, scr, scr + 2 * nb);
+            hipLaunchKernelGGL(sl_touched_cleanup_kernel, dim3((uint32_t)std::min<uint64_t>((nt + 255) / 256, 1024)), dim3(256), 0, s, nt, ps.touched,
+                               ps.x, ps.r, ps.delta[0], ps.delta[1], ps.cand_flag);
+            hipError_t e = hipMemcpyAsync(h, scr + 2 * nb, 16, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) st = sl_fail(SL_DEVICE_ERROR, "query readback failed: %s", hipGetErrorString(e));
+        }
+    } else if (st == SL_OK) {
+        // the frontier flooded the graph: whole-vector sums and a whole-vector reset
+        double *scr = static_cast<double *>(sl_scratch(8192 * sizeof(double)));
+        if (!scr) st = sl_fail(SL_ALLOCATION, "scratch");
+        if (st == SL_OK) st = sl_launch_dot(n, ps.x, q->db, scr, scr + 4000, s);
+        if (st == SL_OK) st = sl_launch_abs_sum(n, ps.r, scr + 4100, scr + 4001, s);
+        if (st == SL_OK) {
+            hipError_t e = hipMemcpyAsync(h, scr + 4000, 16, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) st = sl_fail(SL_DEVICE_ERROR, "query readback failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (st != SL_OK || ps.flooded) {                       // leave the session all-zero whatever happened
+        hipMemsetAsync(ps.x, 0, n * 8, s); hipMemsetAsync(ps.r, 0, n * 8, s);
+        hipMemsetAsync(ps.delta[0], 0, n * 8, s); hipMemsetAsync(ps.delta[1], 0, n * 8, s);
+        hipMemsetAsync(ps.cand_flag, 0, n * 4, s);
+    }
+    if (st != SL_OK) return st;
+    res->estimate = h[0]; res->residual_l1 = h[1];
+    res->rounds = rs.rounds; res->pushes = rs.pushes; res->rows_touched = rs.rows_touched;
+    res->device_time_ms = ms; res->converged = rs.converged ? 1 : 0;
+    return SL_OK;
+}
+
+// one-shot queries: a session for the duration of the call
 static sl_status estimate_entry_impl(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double theta,
                                      uint64_t max_rounds, bool given_is_transpose, sl_estimate_result *res)
 {
@@ -504,49 +876,11 @@ static sl_status estimate_entry_impl(const sl_matrix *m, const double *b, sl_mem
     memset(res, 0, sizeof(*res));
     if (m->n_rows != m->n_cols || m->row_offset != 0) return sl_fail(SL_INVALID_INPUT, "Matrix must be square");
     if (row >= m->n_rows) return sl_fail(SL_INVALID_INPUT, "Row index %llu out of bounds. Matrix has %llu rows", (unsigned long long)row, (unsigned long long)m->n_rows);
-    if (!m->d_tptr || !m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "estimate_entry needs a matrix created with SL_MATRIX_WITH_TRANSPOSE");
-    const uint64_t n = m->n_rows;
-    hipStream_t s = sl_context().stream;
-    push_state ps;
-    DevBuf bufs[16], bbuf;
-    SL_TRY(alloc_state(ps, n, bufs));
-    unsigned long long hs[4];
-    if (given_is_transpose) {
-        // operator B = the matrix itself (= A^T); its dense rounds can use the row-slice kernels
-        ps.op = op_view{m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_trow};
-        SL_TRY(sl_matrix_diag_pass(m, ps.dinv, hs));
-    } else {
-        // operator B = A^T: rows of B = columns of A (sorted transpose), columns of B = rows of A
-        ps.op = op_view{m->d_tptr, m->d_trow, m->d_tval, m->d_row_ptr, m->d_col_idx};
-        SL_TRY(sl_csr_diag_pass(n, m->d_tptr, m->d_trow, m->d_tval, ps.dinv, hs));
-    }
-    if (hs[0] & 2ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2]);
-    if (hs[0] & 4ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3]);
-    // y0 = 0, r = e_row
-    SL_HIP(hipMemsetAsync(ps.x, 0, n * 8, s));
-    SL_HIP(hipMemsetAsync(ps.r, 0, n * 8, s));
-    const double one = 1.0;
-    SL_HIP(hipMemcpyAsync(ps.r + row, &one, 8, hipMemcpyHostToDevice, s));
-    push_log plog;
-    round_stats rs;
-    float ms = 0.f;
-    SL_TRY(run_push(ps, given_is_transpose ? m : nullptr, theta, max_rounds, SL_ORDER_CSR_SEQUENTIAL, given_is_transpose ? 1.0 / 16.0 : 0.25, plog, rs, &ms));
-    // estimate = y . b ; residual_l1 = ||r_y||_1
-    const double *db = b;
-    if (where == SL_MEM_HOST) { SL_TRY(bbuf.alloc(n * 8)); SL_HIP(hipMemcpyAsync(bbuf.p, b, n * 8, hipMemcpyHostToDevice, s)); db = bbuf.as<double>(); }
-    double *scr = static_cast<double *>(sl_scratch(8192 * sizeof(double)));
-    if (!scr) return sl_fail(SL_ALLOCATION, "scratch");
-    double h[2];
-    SL_TRY(sl_launch_dot(n, ps.x, db, scr, scr + 4000, s));
-    SL_HIP(hipMemcpyAsync(&h[0], scr + 4000, 8, hipMemcpyDeviceToHost, s));
-    SL_HIP(hipStreamSynchronize(s));
-    SL_TRY(sl_launch_abs_sum(n, ps.r, scr, scr + 4000, s));
-    SL_HIP(hipMemcpyAsync(&h[1], scr + 4000, 8, hipMemcpyDeviceToHost, s));
-    SL_HIP(hipStreamSynchronize(s));
-    res->estimate = h[0]; res->residual_l1 = h[1];
-    res->rounds = rs.rounds; res->pushes = rs.pushes; res->rows_touched = rs.rows_touched;
-    res->device_time_ms = ms; res->converged = rs.converged ? 1 : 0;
-    return SL_OK;
+    sl_query_session *q = nullptr;
+    SL_TRY(sl_query_session_create(m, given_is_transpose ? 1 : 0, b, where, &q));
+    const sl_status st = sl_query_session_estimate(q, row, theta, max_rounds, res);
+    sl_query_session_destroy(q);
+    return st;
 }
 
 sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double theta,

@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 #include "../../include/sublinear_hip.h"
 
 #define SL_SLICE 64
@@ -57,10 +58,21 @@ struct sl_ctx {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     int scratch_device = -1;
+    // workspace pool (sl_ws_alloc / sl_ws_free)
+    struct ws_block { void *p; size_t bytes; int device; bool in_use; };
+    std::vector<ws_block> ws;
 };
 sl_ctx &sl_context();
 sl_status sl_fail(sl_status s, const char *fmt, ...);
 void *sl_scratch(size_t bytes); // nullptr on failure
+
+// Workspace pool: device buffers of the solve calls (term vectors, frontier lists, logs) are taken from a per-thread
+// cache and returned to it instead of hipMalloc / hipFree on every call — hipFree synchronises the device and both
+// cost 10^2 us, which is what a local push query or a small solve takes in total.  All work of a thread runs on its
+// one in-order stream, so a buffer handed out again is only touched after the previous user's launches.
+// sl_release_workspace() (ABI) returns the cached buffers to the driver.
+void *sl_ws_alloc(size_t bytes);   // nullptr on failure
+void sl_ws_free(void *p);
 
 #define SL_HIP(call)                                                                            \
     do {                                                                                        \
@@ -70,8 +82,50 @@ void *sl_scratch(size_t bytes); // nullptr on failure
                            __FILE__, __LINE__);                                                 \
     } while (0)
 
+struct DevBuf {
+    void *p = nullptr;
+    bool pooled = true;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { reset(); }
+    void reset() { if (p) { if (pooled) sl_ws_free(p); else hipFree(p); p = nullptr; } }
+    sl_status alloc(size_t bytes)
+    {
+        reset();
+        pooled = true;
+        p = sl_ws_alloc(bytes ? bytes : 8);
+        if (!p) return sl_fail(SL_ALLOCATION, "device allocation of %zu bytes failed", bytes);
+        return SL_OK;
+    }
+    // exact-size allocation outside the pool, for buffers whose ownership may move to a longer-lived object
+    sl_status alloc_owned(size_t bytes)
+    {
+        reset();
+        pooled = false;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { p = nullptr; return sl_fail(SL_ALLOCATION, "hipMalloc(%zu) failed", bytes); }
+        return SL_OK;
+    }
+    void *release() { void *q = p; p = nullptr; return q; }   // alloc_owned buffers only
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+#define SL_TRY(expr) do { sl_status s_ = (expr); if (s_ != SL_OK) return s_; } while (0)
+
 // ---- kernel launchers (sl_kernels.hip) -------------------------------------------------
 enum sl_epilogue { SL_EPI_SPMV = 0, SL_EPI_NEUMANN = 1, SL_EPI_RESIDUAL = 2, SL_EPI_PUSH = 3 };
+
+// Control block of a speculatively enqueued solve loop (sl_neumann_solve): the host enqueues several iterations
+// without reading anything back; every reducing launch logs its sum here and closes the gate (stop_after) when the
+// reference's stop rule fires, and every launch of a later iteration then returns at once.  The host replays the
+// reference's control flow over the log afterwards — same decisions, same results, one readback per batch.
+#define SL_CTL_LOG 62
+struct sl_solve_ctl {
+    uint32_t stop_after;   // launches with gate_it > stop_after do nothing
+    uint32_t n_done;       // judged reductions executed so far (a prefix of the enqueued ones)
+    uint32_t pad[2];
+    double log[SL_CTL_LOG];
+};
+enum { SL_JUDGE_NONE = 0, SL_JUDGE_LT = 1, SL_JUDGE_LE_OR_NONFINITE = 2 };
 
 struct sl_row_args {
     // matrix
@@ -96,12 +150,20 @@ struct sl_row_args {
     double theta;         // PUSH
     double *partials;     // per-block partial sums (norm^2); PUSH: also counts at partials + nblocks (as u64)
     double *result;       // device scalar(s): [0] = sum of squares, PUSH: [1] = frontier count (as double bits u64)
+    // speculative solve loop (null ctl = plain launch)
+    sl_solve_ctl *ctl;
+    uint32_t gate_it, ctl_slot;
+    int ctl_mode;         // SL_JUDGE_*: which comparison of the reduced sum against ctl_threshold closes the gate
+    double ctl_threshold;
 };
 sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s);
 sl_row_args sl_matrix_row_args(const sl_matrix *m);   // matrix part filled, vectors null
 uint32_t sl_row_grid(uint64_t n_slices);
 
 sl_status sl_launch_sumsq(uint64_t n, const double *x, double *partials, double *result, hipStream_t s);
+sl_status sl_launch_sumsq_judged(uint64_t n, const double *x, double *partials, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot,
+                                 int mode, double threshold, hipStream_t s);
+sl_status sl_launch_ctl_reset(sl_solve_ctl *ctl, hipStream_t s);
 sl_status sl_launch_dot(uint64_t n, const double *x, const double *y, double *partials, double *result, hipStream_t s);
 sl_status sl_launch_axpy(uint64_t n, double alpha, const double *x, double *y, hipStream_t s);
 sl_status sl_launch_scale_rows(uint64_t n, const double *a, const double *b, double *out, hipStream_t s); // out = a*b

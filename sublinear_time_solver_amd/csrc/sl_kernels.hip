@@ -177,6 +177,7 @@ template <int ORDER, int EPI, int UW>
 __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32_t nb8)
 {
     __shared__ double red[2 * SL_WAVES_PER_BLOCK];
+    if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     // XCD-aware mapping: physical block b is dispatched to XCD b % 8; give every XCD a
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
     constexpr int NW = SL_WAVES_PER_BLOCK;
     extern __shared__ __attribute__((aligned(16))) double win[];
     __shared__ double red[2 * NW];
+    if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
@@ -522,6 +524,7 @@ template <int ORDER, int EPI>
 __global__ __launch_bounds__(SL_BLOCK) void sl_long_rows_kernel(sl_row_args a, uint32_t slot0)
 {
     __shared__ double prod[SL_BLOCK];
+    if (a.ctl && a.gate_it > a.ctl->stop_after) return;
     const uint32_t i = a.long_rows[blockIdx.x];
     const double *__restrict__ g = a.gather;
     const uint32_t s = a.csr_ptr[i], e = a.csr_ptr[i + 1], len = e - s;
@@ -587,6 +590,44 @@ __global__ __launch_bounds__(1024) void sl_final_reduce_kernel(const double *par
         }
         __syncthreads();
     }
+}
+
+// the same reduction inside a speculatively enqueued solve loop: gated, logs the sum, applies the stop rule.
+// The thresholds are squared norms prepared by the host so that (sum < thr) == (sqrt(sum) < tolerance) exactly.
+__global__ __launch_bounds__(1024) void sl_judge_reduce_kernel(const double *partials, uint32_t nparts, double *result,
+                                                               sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot, int mode, double thr)
+{
+    __shared__ double red[16];
+    if (gate_it > ctl->stop_after) return;
+    double acc = 0.0;
+    for (uint32_t j = threadIdx.x; j < nparts; j += 1024) acc += partials[j];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = red[0];
+        for (int w = 1; w < 16; ++w) t += red[w];
+        if (result) result[0] = t;
+        ctl->log[slot] = t;
+        ctl->n_done = slot + 1;
+        bool stop = false;
+        if (mode == SL_JUDGE_LT) stop = t < thr;
+        else if (mode == SL_JUDGE_LE_OR_NONFINITE) stop = (t <= thr) || (t != t) || (fabs(t) == INFINITY);
+        if (stop && gate_it < ctl->stop_after) ctl->stop_after = gate_it;
+    }
+}
+
+__global__ void sl_ctl_reset_kernel(sl_solve_ctl *ctl)
+{
+    ctl->stop_after = 0xffffffffu;
+    ctl->n_done = 0;
+}
+
+sl_status sl_launch_ctl_reset(sl_solve_ctl *ctl, hipStream_t s)
+{
+    hipLaunchKernelGGL(sl_ctl_reset_kernel, dim3(1), dim3(1), 0, s, ctl);
+    SL_HIP(hipGetLastError());
+    return SL_OK;
 }
 
 uint32_t sl_row_grid(uint64_t n_slices)
@@ -693,7 +734,10 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
 sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s)
 {
     if (a.n_slices == 0) {
-        if (epi != SL_EPI_SPMV && a.result) SL_HIP(hipMemsetAsync(a.result, 0, 2 * sizeof(double), s));
+        if (epi != SL_EPI_SPMV && a.ctl)
+            hipLaunchKernelGGL(sl_judge_reduce_kernel, dim3(1), dim3(1024), 0, s, a.partials, 0u, a.result, a.ctl, a.gate_it,
+                               a.ctl_slot, a.ctl_mode, a.ctl_threshold);
+        else if (epi != SL_EPI_SPMV && a.result) SL_HIP(hipMemsetAsync(a.result, 0, 2 * sizeof(double), s));
         return SL_OK;
     }
     const bool simd4 = (order == SL_ORDER_SIMD4);
@@ -706,7 +750,11 @@ sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, 
     case SL_EPI_PUSH: st = simd4 ? launch_rows_t<1, SL_EPI_PUSH>(a, s, &nparts) : launch_rows_t<0, SL_EPI_PUSH>(a, s, &nparts); break;
     }
     if (st != SL_OK) return st;
-    if (epi != SL_EPI_SPMV && a.result) {
+    if (epi != SL_EPI_SPMV && a.ctl) {
+        hipLaunchKernelGGL(sl_judge_reduce_kernel, dim3(1), dim3(1024), 0, s, a.partials, nparts, a.result, a.ctl, a.gate_it,
+                           a.ctl_slot, a.ctl_mode, a.ctl_threshold);
+        SL_HIP(hipGetLastError());
+    } else if (epi != SL_EPI_SPMV && a.result) {
         hipLaunchKernelGGL(sl_final_reduce_kernel, dim3(1), dim3(1024), 0, s, a.partials, nparts, a.result,
                            epi == SL_EPI_PUSH ? 2 : 1);
         SL_HIP(hipGetLastError());
@@ -748,6 +796,15 @@ sl_status sl_launch_sumsq(uint64_t n, const double *x, double *partials, double 
     const uint32_t g = vec_grid(n);
     hipLaunchKernelGGL((sl_reduce_kernel<0>), dim3(g), dim3(256), 0, s, n, x, x, partials);
     hipLaunchKernelGGL(sl_final_reduce_kernel, dim3(1), dim3(1024), 0, s, partials, g, result, 1);
+    SL_HIP(hipGetLastError());
+    return SL_OK;
+}
+sl_status sl_launch_sumsq_judged(uint64_t n, const double *x, double *partials, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot,
+                                 int mode, double threshold, hipStream_t s)
+{
+    const uint32_t g = vec_grid(n);
+    hipLaunchKernelGGL((sl_reduce_kernel<0>), dim3(g), dim3(256), 0, s, n, x, x, partials);
+    hipLaunchKernelGGL(sl_judge_reduce_kernel, dim3(1), dim3(1024), 0, s, partials, g, (double *)nullptr, ctl, gate_it, slot, mode, threshold);
     SL_HIP(hipGetLastError());
     return SL_OK;
 }

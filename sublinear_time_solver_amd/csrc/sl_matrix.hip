@@ -373,8 +373,9 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
 sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long long h_status[4])
 {
     hipStream_t st = sl_context().stream;
-    unsigned long long *d_status = nullptr;
-    SL_HIP(hipMalloc(&d_status, 4 * sizeof(unsigned long long)));
+    DevBuf status_buf;
+    SL_TRY(status_buf.alloc(4 * sizeof(unsigned long long)));
+    unsigned long long *d_status = status_buf.as<unsigned long long>();
     const unsigned long long init[4] = {0ull, ~0ull, ~0ull, ~0ull};
     SL_HIP(hipMemcpyAsync(d_status, init, sizeof(init), hipMemcpyHostToDevice, st));
     if (m->n_slices)
@@ -385,7 +386,6 @@ sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long 
                            m->row_offset, m->d_row_ptr, m->d_col_idx, m->d_values, d_dinv, d_status);
     SL_HIP(hipMemcpyAsync(h_status, d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
-    hipFree(d_status);
     return SL_OK;
 }
 
@@ -407,13 +407,13 @@ sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx,
                            unsigned long long h_status[4])
 {
     hipStream_t st = sl_context().stream;
-    unsigned long long *d_status = nullptr;
-    SL_HIP(hipMalloc(&d_status, 4 * sizeof(unsigned long long)));
+    DevBuf status_buf;
+    SL_TRY(status_buf.alloc(4 * sizeof(unsigned long long)));
+    unsigned long long *d_status = status_buf.as<unsigned long long>();
     const unsigned long long init[4] = {0ull, ~0ull, ~0ull, ~0ull};
     SL_HIP(hipMemcpyAsync(d_status, init, sizeof(init), hipMemcpyHostToDevice, st));
     if (n) hipLaunchKernelGGL(sl_csr_dinv_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, ptr, idx, val, d_dinv, d_status);
     SL_HIP(hipMemcpyAsync(h_status, d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
-    hipFree(d_status);
     return SL_OK;
 }

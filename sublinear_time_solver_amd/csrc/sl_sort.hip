@@ -11,11 +11,11 @@ sl_status sl_sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const u
     if (n > 0x7fffffffull) return sl_fail(SL_ALLOCATION, "sort too large");
     size_t tb = 0;
     SL_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, s));
-    void *tmp = nullptr;
-    SL_HIP(hipMalloc(&tmp, tb ? tb : 8));
+    DevBuf tmpbuf;
+    SL_TRY(tmpbuf.alloc(tb));
+    void *tmp = tmpbuf.p;
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys_in, keys_out, vals_in, vals_out, (int)n, 0, end_bit, s);
     hipError_t e2 = hipStreamSynchronize(s);
-    hipFree(tmp);
     if (e != hipSuccess || e2 != hipSuccess) return sl_fail(SL_DEVICE_ERROR, "radix sort failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return SL_OK;
 }
@@ -26,11 +26,11 @@ sl_status sl_sort_keys_u32(const uint32_t *keys_in, uint32_t *keys_out, uint64_t
     if (n > 0x7fffffffull) return sl_fail(SL_ALLOCATION, "sort too large");
     size_t tb = 0;
     SL_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, keys_in, keys_out, (int)n, 0, 32, s));
-    void *tmp = nullptr;
-    SL_HIP(hipMalloc(&tmp, tb ? tb : 8));
+    DevBuf tmpbuf;
+    SL_TRY(tmpbuf.alloc(tb));
+    void *tmp = tmpbuf.p;
     hipError_t e = hipcub::DeviceRadixSort::SortKeys(tmp, tb, keys_in, keys_out, (int)n, 0, 32, s);
     hipError_t e2 = hipStreamSynchronize(s);
-    hipFree(tmp);
     if (e != hipSuccess || e2 != hipSuccess) return sl_fail(SL_DEVICE_ERROR, "radix sort failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     return SL_OK;
 }

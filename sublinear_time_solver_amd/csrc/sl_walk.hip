@@ -99,15 +99,15 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
         const double ns = std::ceil(1.0 / (epsilon * epsilon));             // solver.ts:586
         num_samples = ns > 100.0 ? (uint64_t)ns : 100;
     }
-    double *d_b = nullptr, *d_vals = nullptr;
+    DevBuf bbuf, vbuf;
     const double *db = b;
     if (where == SL_MEM_HOST) {
-        SL_HIP(hipMalloc(&d_b, n * 8));
-        SL_HIP(hipMemcpyAsync(d_b, b, n * 8, hipMemcpyHostToDevice, s));
-        db = d_b;
+        SL_TRY(bbuf.alloc(n * 8));
+        SL_HIP(hipMemcpyAsync(bbuf.p, b, n * 8, hipMemcpyHostToDevice, s));
+        db = bbuf.as<double>();
     }
-    hipError_t e = hipMalloc(&d_vals, num_samples * 8);
-    if (e != hipSuccess) { hipFree(d_b); return sl_fail(SL_ALLOCATION, "hipMalloc for %llu walk values failed", (unsigned long long)num_samples); }
+    SL_TRY(vbuf.alloc(num_samples * 8));
+    double *d_vals = vbuf.as<double>();
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, s);
@@ -144,7 +144,6 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
         hipStreamSynchronize(s);
     }
     hipError_t le = hipGetLastError();
-    hipFree(d_b); hipFree(d_vals);
     if (st == SL_OK && le != hipSuccess) st = sl_fail(SL_DEVICE_ERROR, "random-walk kernels failed: %s", hipGetErrorString(le));
     return st;
 }

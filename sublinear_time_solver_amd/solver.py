@@ -312,6 +312,47 @@ def estimate_entry(matrix: SparseMatrix, b, row: int, theta: float = 1e-8, max_r
     return res
 
 
+class QuerySession:
+    """Many single-entry queries against one system (ForwardPushSolver::new + query_single_entry,
+    forward_push.rs:52-66, 224-231): setup once, then every query costs only the rows its push touches
+    (sl_query_session_*).  matrix_is_transpose: `matrix` already holds A^T."""
+
+    def __init__(self, matrix: SparseMatrix, b, matrix_is_transpose: bool = False, device: bool = False):
+        lib = L.load()
+        self._matrix, self._b = matrix, (b if device else _f64(b))          # keep both alive for the session's lifetime
+        size = int(self._b.numel()) if device else self._b.size
+        if size != matrix.rows():
+            raise SolverError(5, f"Vector length {size} does not match matrix rows {matrix.rows()}")
+        h = L.vp()
+        L.check(lib.sl_query_session_create(matrix._h, int(matrix_is_transpose), L.ptr(self._b),
+                                            L.SL_MEM_DEVICE if device else L.SL_MEM_HOST, C.byref(h)))
+        self._h = h.value
+
+    def estimate(self, row: int, theta: float = 1e-8, max_rounds: int = 100_000):
+        if not (0 <= row < self._matrix.rows()):
+            raise SolverError(4, f"Row index {row} out of bounds. Matrix has {self._matrix.rows()} rows")
+        res = L.EstimateResult()
+        L.check(L.load().sl_query_session_estimate(self._h, row, theta, max_rounds, C.byref(res)))
+        return res
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.load().sl_query_session_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------------------------------------
 # Shipped TypeScript surface (src/core/solver.ts)
 # ------------------------------------------------------------------------------------------------

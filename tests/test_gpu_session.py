@@ -1,0 +1,67 @@
+"""Query sessions (sl_query_session_*): single-entry queries whose cost follows the touched rows.  Checked against
+the CPU restatement of the push on A^T from e_row (same rounds, same pushes, estimate = y.b to rounding), against
+the one-shot entry points, and for state hygiene: a session answers the same query with the same bits however many
+other queries ran in between, including ones that flood the graph and ones that stop at the round limit."""
+import numpy as np
+import pytest
+
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import generators as G
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_query(rp, ci, va, n, b, row, theta, max_rounds=100_000):
+    trp, tci, tva = O.csr_transpose(rp, ci, va, n)
+    e = np.zeros(n)
+    e[row] = 1.0
+    o = O.push_sync_solve(trp, tci, tva, e, theta=theta, max_rounds=max_rounds)
+    return o, float(np.dot(o["x"], b)), float(np.abs(o["r"]).sum())
+
+
+@pytest.mark.parametrize("n,k,w", [(20_000, 8, 0), (30_011, 13, 700)])
+def test_session_queries_match_cpu_push_and_one_shot(gpu, n, k, w):
+    rp, ci, va, b = G.sdd_rows(n, k, seed=5, half_bandwidth=w)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    with S.QuerySession(m, b) as q:
+        first = {}
+        for rnd in range(2):                                  # second pass: same bits after other queries ran
+            for row, theta in [(0, 1e-4), (n // 3, 1e-6), (n - 1, 1e-9), (17, 1e-2), (n // 2, 10.0)]:
+                e = q.estimate(row, theta=theta)
+                if rnd == 0:
+                    o, est, l1 = _oracle_query(rp, ci, va, n, b, row, theta)
+                    assert e.rounds == o["rounds"] and e.pushes == o["pushes"] and bool(e.converged)
+                    assert abs(e.estimate - est) <= 1e-14 * max(1.0, abs(est)) and abs(e.residual_l1 - l1) <= 1e-14 * max(1.0, l1)
+                    one = S.estimate_entry(m, b, row, theta=theta)
+                    assert (one.rounds, one.pushes, one.rows_touched) == (e.rounds, e.pushes, e.rows_touched)
+                    assert abs(one.estimate - e.estimate) <= 1e-15 * max(1.0, abs(est))
+                    first[(row, theta)] = (e.estimate, e.residual_l1, e.rounds, e.pushes, e.rows_touched)
+                else:
+                    assert first[(row, theta)] == (e.estimate, e.residual_l1, e.rounds, e.pushes, e.rows_touched)
+        # theta above |1/a_ii|: nothing is pushed, the residual is the seed itself
+        e = q.estimate(5, theta=10.0)
+        assert e.rounds == 0 and e.pushes == 0 and e.estimate == 0.0 and e.residual_l1 == 1.0 and bool(e.converged)
+
+
+def test_session_survives_flooding_and_round_limit(gpu):
+    n = 4096
+    rp, ci, va, b = G.sdd_rows(n, 8, seed=2, half_bandwidth=0)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    x = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-13)).solution
+    with S.QuerySession(m, b) as q:
+        ref = q.estimate(100, theta=1e-3)
+        flood = q.estimate(7, theta=1e-14)                     # floods: dense rounds, whole-vector reset afterwards
+        assert bool(flood.converged) and abs(flood.estimate - x[7]) <= 1e-11
+        again = q.estimate(100, theta=1e-3)
+        assert (again.estimate, again.residual_l1, again.rounds, again.pushes) == (ref.estimate, ref.residual_l1, ref.rounds, ref.pushes)
+        cut = q.estimate(9, theta=1e-9, max_rounds=3)          # stops with a live frontier: leftovers must be cleaned up
+        o, est, l1 = _oracle_query(rp, ci, va, n, b, 9, 1e-9, max_rounds=3)
+        assert cut.rounds == 3 and not bool(cut.converged) and cut.pushes == o["pushes"]
+        assert abs(cut.estimate - est) <= 1e-14 and abs(cut.residual_l1 - l1) <= 1e-13
+        again = q.estimate(100, theta=1e-3)
+        assert (again.estimate, again.residual_l1, again.rounds, again.pushes) == (ref.estimate, ref.residual_l1, ref.rounds, ref.pushes)
+    mt = m.transpose(with_transpose=True)
+    with S.QuerySession(mt, b, matrix_is_transpose=True) as qt:  # the caller already holds A^T
+        e = qt.estimate(100, theta=1e-3)
+        assert (e.rounds, e.pushes) == (ref.rounds, ref.pushes) and abs(e.estimate - ref.estimate) <= 1e-15

@@ -60,9 +60,17 @@ def main():
                              "device_ms": res.device_time_ms, "wall_s": time.perf_counter() - t1, "sum_x": float(x.sum()),
                              "padded_over_nnz": A.info().padded_nnz / A.info().nnz}
     xinf = float(x.abs().max()) if x is not None else None
+    # one-shot queries pay the O(n) setup each time; a session pays it once
+    t2 = time.perf_counter()
+    e = S.estimate_entry(M, b, rows[0], theta=1e-5, max_rounds=100000, matrix_is_transpose=True, device=True)
+    out["one_shot_query_wall_ms"] = (time.perf_counter() - t2) * 1e3
+    t2 = time.perf_counter()
+    sess = S.QuerySession(M, b, matrix_is_transpose=True, device=True)
+    out["session_create_ms"] = (time.perf_counter() - t2) * 1e3
+    sess.estimate(rows[1], theta=1e-5)                       # warm-up (first use of the kernels)
     for row, theta in [(r, float(t)) for r in rows for t in args.thetas.split(",")]:
         t2 = time.perf_counter()
-        e = S.estimate_entry(M, b, row, theta=theta, max_rounds=100000, matrix_is_transpose=True, device=True)
+        e = sess.estimate(row, theta=theta, max_rounds=100000)
         q = {"row": row, "theta": theta, "estimate": e.estimate, "residual_l1": e.residual_l1, "rounds": int(e.rounds), "pushes": int(e.pushes),
              "rows_touched": int(e.rows_touched), "touched_per_round_over_n": e.rows_touched / max(1, e.rounds) / n,
              "device_ms": e.device_time_ms, "wall_ms": (time.perf_counter() - t2) * 1e3, "converged": bool(e.converged)}
@@ -72,6 +80,18 @@ def main():
             q["error_bound"] = e.residual_l1 * xinf
             q["within_bound"] = bool(q["abs_error"] <= q["error_bound"] + 1e-18)
         out["queries"].append(q)
+    # throughput of a stream of distinct local queries on one session
+    import random
+    rnd = random.Random(7)
+    qrows = [rnd.randrange(n) for _ in range(200)]
+    t2 = time.perf_counter()
+    touched = 0
+    for row in qrows:
+        touched += sess.estimate(row, theta=1e-5).rows_touched
+    dt = time.perf_counter() - t2
+    out["query_stream"] = {"queries": len(qrows), "theta": 1e-5, "mean_wall_ms": dt / len(qrows) * 1e3, "queries_per_s": len(qrows) / dt,
+                           "mean_rows_touched": touched / len(qrows)}
+    sess.close()
     print(json.dumps(out))
 
 
