@@ -209,7 +209,7 @@ void sl_matrix_destroy(sl_matrix *m)
     if (!m) return;
     hipFree(m->d_slice_ptr); hipFree(m->d_row_len); hipFree(m->d_cols); hipFree(m->d_cols16); hipFree(m->d_vals);
     hipFree(m->d_row_ptr); hipFree(m->d_col_idx); hipFree(m->d_values);
-    hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval); hipFree(m->d_long_rows);
+    hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval); hipFree(m->d_tent); hipFree(m->d_long_rows);
     delete m;
 }
 

@@ -27,6 +27,7 @@ namespace {
 struct op_view {
     const uint32_t *ptr, *idx; const double *val;   // rows of B
     const uint32_t *tptr, *tidx;                    // columns of B (pattern)
+    const uint32_t *tk;                             // for each column entry: index of the same entry in the row arrays
 };
 } // namespace
 
@@ -122,80 +123,106 @@ __global__ __launch_bounds__(256) void sl_select_kernel(uint64_t n, const double
 // list swap, stop rule).  The host enqueues several rounds back to back and reads the block once per batch; rounds
 // enqueued past the stop are empty launches.  A local query of a dozen rounds costs two host round trips.
 struct sl_push_ctl {
-    uint32_t nf, nn, n_long_cols, pad0;   // |frontier|, next frontier, deferred hub columns of the running round
-    uint32_t nc[4];                       // candidate rows of the running round by length class (short, mid, long)
+    uint32_t nf, nn, n_long_cols, nrec;   // |frontier|, next frontier, deferred hub columns, hit records of the running round
+    uint32_t nc, n_heavy;                 // candidate rows of the running round; those with more than SL_MAX_HITS hits
     uint32_t n_touched;                   // rows whose x / r may be non-zero (query sessions; not reset per batch)
-    uint32_t stop;                        // 0 running, 1 frontier empty (converged), 2 frontier above the dense switch
-    uint32_t rounds, pad1;                // rounds executed in this batch
+    uint32_t stop;                        // 0 running, 1 frontier empty (converged), 2 frontier too large for a sparse round
+    uint32_t rounds, done_blocks;         // rounds executed in this batch; block counter of the closing kernel
+    unsigned long long hits, next_hits;   // column entries under the frontier (= records a round writes) and under the next one
     unsigned long long pushes, rows_touched;
 };
-#define SL_FLAG_CAND 1u               // row is in this round's candidate lists
 #define SL_FLAG_TOUCHED 2u            // row is in the session's touched list
-// candidate rows are pulled by a thread (fewer than 8 entries), a 16-lane group (up to 64) or a whole wave
-#define SL_SHORT_ROW 8u
-#define SL_MID_ROW 64u
+#define SL_EMPTY 0xffffffffu          // head[] of a row without hits
+#define SL_MAX_HITS 8                 // rows hit by more frontier columns than this are pulled over their whole length
+#define SL_LONG_COL 1024u             // longer frontier columns are walked by the whole grid
 
-struct sl_cand_lists { uint32_t *list[3]; };
+// one frontier column entry (i, j): the product B_ij * delta_j, the position of the entry in B's row arrays (the order
+// key of the row sum) and the previous hit of the same row (a per-row linked list, newest first)
+struct sl_hit { double prod; uint32_t k, next; };
 
 __global__ void sl_push_ctl_reset_kernel(sl_push_ctl *c, uint32_t nf)
 {
-    c->nf = nf; c->nn = 0; c->n_long_cols = 0; c->nc[0] = c->nc[1] = c->nc[2] = 0; c->stop = 0; c->rounds = 0; c->pushes = 0; c->rows_touched = 0;
+    c->nf = nf; c->nn = 0; c->n_long_cols = 0; c->nrec = 0; c->nc = 0; c->n_heavy = 0; c->stop = 0; c->rounds = 0; c->done_blocks = 0;
+    c->hits = 0; c->next_hits = 0; c->pushes = 0; c->rows_touched = 0;
 }
 
-// (1) per frontier column j: x_j += delta_j, and every row i with B_ij != 0 becomes a candidate
-//     (the atomic flag de-duplicates; the candidate LISTS are unordered, their use is order-free).
-//     One WAVE per frontier column, 4 x 64 entries in flight per step.  A fresh candidate is classified by its row
-//     length into one of three lists; the wave reserves the slots of all its fresh candidates with one atomic
-//     instruction (ballot + popcount, the three class leaders issue together).  Hub columns (power-law in-degree,
-//     10^4..10^5 entries) are deferred to sl_expand_long_kernel, where the whole grid walks each of them.
-#define SL_LONG_COL 1024u
-
-__device__ __forceinline__ void sl_mark_candidates(uint32_t i, bool valid, uint32_t lane, const uint32_t *row_ptr, uint32_t *flag,
-                                                   const sl_cand_lists &cl, uint32_t *touched, sl_push_ctl *c)
+// column entries under the first frontier of a batch (later rounds accumulate the figure as their frontier forms)
+__global__ __launch_bounds__(256) void sl_frontier_hits_kernel(sl_push_ctl *c, const uint32_t *frontier, const uint32_t *tptr)
 {
-    uint32_t old = SL_FLAG_CAND | SL_FLAG_TOUCHED;
-    if (valid) old = atomicOr(&flag[i], touched ? (SL_FLAG_CAND | SL_FLAG_TOUCHED) : SL_FLAG_CAND);
-    const bool fresh = valid && !(old & SL_FLAG_CAND);
-    if (!__ballot(fresh)) return;                                              // wave-uniform
-    uint32_t cls = 3;
-    if (fresh) {
-        const uint32_t len = row_ptr[i + 1] - row_ptr[i];
-        cls = len < SL_SHORT_ROW ? 0u : (len <= SL_MID_ROW ? 1u : 2u);
-    }
-    const unsigned long long m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
-    const unsigned long long mine = cls == 0u ? m0 : (cls == 1u ? m1 : m2);
+    const uint32_t nf = c->nf;
+    unsigned long long acc = 0;
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nf; t += gridDim.x * 256) { const uint32_t j = frontier[t]; acc += tptr[j + 1] - tptr[j]; }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(&c->hits, acc);
+}
+__global__ void sl_hits_gate_kernel(sl_push_ctl *c, unsigned long long hit_limit)
+{
+    if (c->hits > hit_limit) c->stop = 2u;
+}
+
+// (1) expansion.  Sparse rounds are HIT-DRIVEN: a frontier column j reaches row i through the entry B_ij, and only
+//     those entries contribute to (B delta)_i.  One wave per frontier column (hub columns: the whole grid, second
+//     kernel) emits a record per entry and links it into its row's list with one atomicExch; a row whose list was
+//     empty becomes a candidate.  Slots in the record, candidate and touched lists are reserved per wave (ballot +
+//     popcount, one atomic for up to 256 entries).  The work of a round follows the column entries under the
+//     frontier, not the lengths of the rows they touch.
+__device__ __forceinline__ void sl_expand_piece(uint32_t p0, uint32_t p1, double dj, uint32_t lane, const op_view &op, sl_hit *recs,
+                                                uint32_t *head, uint32_t *cand, uint32_t *flag, uint32_t *touched, sl_push_ctl *c)
+{
     const unsigned long long below = (1ull << lane) - 1ull;
+    bool ok[4]; uint32_t row[4], kb[4]; double bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t p = p0 + (uint32_t)u * 64u;
+        ok[u] = p < p1;
+        row[u] = ok[u] ? op.tidx[p] : 0u;
+        kb[u] = ok[u] ? op.tk[p] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bv[u] = ok[u] ? op.val[kb[u]] : 0.0;
+    unsigned long long m[4];
+    uint32_t off[4], total = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { m[u] = __ballot(ok[u]); off[u] = total; total += (uint32_t)__popcll(m[u]); }
     uint32_t base = 0;
-    if (fresh && !(mine & below)) base = atomicAdd(&c->nc[cls], (uint32_t)__popcll(mine));   // the first lane of each class
-    const uint32_t b0 = __shfl(base, m0 ? __builtin_ctzll(m0) : 0), b1 = __shfl(base, m1 ? __builtin_ctzll(m1) : 0),
-                   b2 = __shfl(base, m2 ? __builtin_ctzll(m2) : 0);
-    if (fresh) cl.list[cls][(cls == 0u ? b0 : (cls == 1u ? b1 : b2)) + (uint32_t)__popcll(mine & below)] = i;
-    if (touched) {                                                             // query session: first time this row is reached
-        const bool first = fresh && !(old & SL_FLAG_TOUCHED);
-        const unsigned long long mt = __ballot(first);
-        if (mt) {
-            uint32_t tb = 0;
-            const int leader = __builtin_ctzll(mt);
-            if ((int)lane == leader) tb = atomicAdd(&c->n_touched, (uint32_t)__popcll(mt));
-            tb = __shfl(tb, leader);
-            if (first) touched[tb + (uint32_t)__popcll(mt & below)] = i;
+    if (lane == 0) base = atomicAdd(&c->nrec, total);
+    base = __shfl(base, 0);
+    uint32_t prev[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t rec = base + off[u] + (uint32_t)__popcll(m[u] & below);
+        prev[u] = ok[u] ? atomicExch(&head[row[u]], rec) : 0u;
+        if (ok[u]) recs[rec] = sl_hit{DMUL(bv[u], dj), kb[u], prev[u]};
+    }
+    // rows reached for the first time this round
+    bool fresh[4];
+    total = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { fresh[u] = ok[u] && prev[u] == SL_EMPTY; m[u] = __ballot(fresh[u]); off[u] = total; total += (uint32_t)__popcll(m[u]); }
+    if (total == 0) return;                                                    // wave-uniform
+    if (lane == 0) base = atomicAdd(&c->nc, total);
+    base = __shfl(base, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (fresh[u]) cand[base + off[u] + (uint32_t)__popcll(m[u] & below)] = row[u];
+    if (touched) {                                                             // query session: first time ever (this lane owns the row now)
+        total = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bool first = false;
+            if (fresh[u]) { const uint32_t f = flag[row[u]]; if (!(f & SL_FLAG_TOUCHED)) { flag[row[u]] = f | SL_FLAG_TOUCHED; first = true; } }
+            fresh[u] = first; m[u] = __ballot(first); off[u] = total; total += (uint32_t)__popcll(m[u]);
         }
+        if (total == 0) return;
+        if (lane == 0) base = atomicAdd(&c->n_touched, total);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (fresh[u]) touched[base + off[u] + (uint32_t)__popcll(m[u] & below)] = row[u];
     }
 }
 
-__device__ __forceinline__ void sl_expand_piece(uint32_t k, uint32_t k1, uint32_t lane, const op_view &op, uint32_t *flag, const sl_cand_lists &cl,
-                                                uint32_t *touched, sl_push_ctl *c)
-{
-    const bool va = k < k1, vb = k + 64 < k1, vc = k + 128 < k1, vd = k + 192 < k1;
-    const uint32_t ia = va ? op.tidx[k] : 0u, ib = vb ? op.tidx[k + 64] : 0u, ic = vc ? op.tidx[k + 128] : 0u, id = vd ? op.tidx[k + 192] : 0u;
-    sl_mark_candidates(ia, va, lane, op.ptr, flag, cl, touched, c);
-    sl_mark_candidates(ib, vb, lane, op.ptr, flag, cl, touched, c);
-    sl_mark_candidates(ic, vc, lane, op.ptr, flag, cl, touched, c);
-    sl_mark_candidates(id, vd, lane, op.ptr, flag, cl, touched, c);
-}
-
-__global__ __launch_bounds__(256) void sl_expand_kernel(sl_push_ctl *c, const uint32_t *frontier, op_view op, const double *delta,
-                                                        double *x, uint32_t *flag, sl_cand_lists cl, uint32_t *long_cols, uint32_t *touched)
+__global__ __launch_bounds__(256) void sl_expand_kernel(sl_push_ctl *c, const uint32_t *frontier, op_view op, const double *delta, double *x,
+                                                        sl_hit *recs, uint32_t *head, uint32_t *cand, uint32_t *flag, uint32_t *long_cols,
+                                                        uint32_t *touched)
 {
     if (c->stop) return;
     const uint32_t nf = c->nf;
@@ -203,17 +230,18 @@ __global__ __launch_bounds__(256) void sl_expand_kernel(sl_push_ctl *c, const ui
     const uint32_t nwaves = gridDim.x * 4;
     for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < nf; t += nwaves) {
         const uint32_t j = frontier[t];
-        if (lane == 0) x[j] = DADD(x[j], delta[j]);
-        const uint32_t k0 = op.tptr[j], k1 = op.tptr[j + 1];
-        if (k1 - k0 > SL_LONG_COL) { if (lane == 0) long_cols[atomicAdd(&c->n_long_cols, 1u)] = j; continue; }
-        const uint32_t steps = (k1 - k0 + 255u) / 256u;                        // wave-uniform trip count (ballots inside)
-        for (uint32_t q = 0; q < steps; ++q) sl_expand_piece(k0 + q * 256u + lane, k1, lane, op, flag, cl, touched, c);
+        const double dj = delta[j];
+        if (lane == 0) x[j] = DADD(x[j], dj);
+        const uint32_t p0 = op.tptr[j], p1 = op.tptr[j + 1];
+        if (p1 - p0 > SL_LONG_COL) { if (lane == 0) long_cols[atomicAdd(&c->n_long_cols, 1u)] = j; continue; }
+        const uint32_t steps = (p1 - p0 + 255u) / 256u;                        // wave-uniform trip count (ballots inside)
+        for (uint32_t q = 0; q < steps; ++q) sl_expand_piece(p0 + q * 256u + lane, p1, dj, lane, op, recs, head, cand, flag, touched, c);
     }
 }
 
 // hub columns: every wave of the grid takes 256-entry pieces of each deferred column
-__global__ __launch_bounds__(256) void sl_expand_long_kernel(sl_push_ctl *c, const uint32_t *long_cols, op_view op, uint32_t *flag,
-                                                             sl_cand_lists cl, uint32_t *touched)
+__global__ __launch_bounds__(256) void sl_expand_long_kernel(sl_push_ctl *c, const uint32_t *long_cols, op_view op, const double *delta,
+                                                             sl_hit *recs, uint32_t *head, uint32_t *cand, uint32_t *flag, uint32_t *touched)
 {
     if (c->stop) return;
     const uint32_t n_long = c->n_long_cols;
@@ -221,9 +249,10 @@ __global__ __launch_bounds__(256) void sl_expand_long_kernel(sl_push_ctl *c, con
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     for (uint32_t t = 0; t < n_long; ++t) {
         const uint32_t j = long_cols[t];
-        const uint32_t k0 = op.tptr[j], k1 = op.tptr[j + 1];
-        const uint32_t pieces = (k1 - k0 + 255u) / 256u;
-        for (uint32_t q = wave; q < pieces; q += nwaves) sl_expand_piece(k0 + q * 256u + lane, k1, lane, op, flag, cl, touched, c);
+        const double dj = delta[j];
+        const uint32_t p0 = op.tptr[j], p1 = op.tptr[j + 1];
+        const uint32_t pieces = (p1 - p0 + 255u) / 256u;
+        for (uint32_t q = wave; q < pieces; q += nwaves) sl_expand_piece(p0 + q * 256u + lane, p1, dj, lane, op, recs, head, cand, flag, touched, c);
     }
 }
 
@@ -250,24 +279,10 @@ __device__ __forceinline__ double sl_csr_row_dot(const op_view &op, uint32_t i, 
     return acc;
 }
 
-// (2) pull update of candidate rows: r_i -= (B delta_old)_i ; next frontier from |r_i dinv_i| >= theta
-__device__ __forceinline__ void sl_pull_finish(uint32_t i, double acc, double r_old, double dinv_i, double theta, double *r, double *delta_new,
-                                               uint32_t *next, uint32_t *next_count)
-{
-    const double rn = DSUB(r_old, acc);
-    r[i] = rn;
-    const double p = DMUL(rn, dinv_i);
-    if (fabs(p) >= theta) {
-        delta_new[i] = p;
-        next[atomicAdd(next_count, 1u)] = i;
-    }
-}
-
-// Ordered accumulation of the products a group of G lanes holds for one row: only the NON-ZERO products are added,
-// in entry order — skipping an exactly-zero product cannot change the running sum (s + (+-0) == s, and s is never
-// -0), so the value equals the sequential reference sum bit for bit while the cost follows the (small) number of
-// frontier columns the row hits.  `acc` carries the reference's two summation orders (sparse.rs:194-202 and the
-// 4-lane order of simd_ops.rs:41-77).
+// Ordered accumulation of the non-zero products of one row.  Only NON-ZERO products are added, in entry order —
+// leaving out an exactly-zero product cannot change the running sum (s + (+-0) == s, and s is never -0), so the value
+// equals the sequential reference sum over the whole row bit for bit.  `add` carries the reference's two summation
+// orders (sparse.rs:194-202 and the 4-lane order of simd_ops.rs:41-77); positions must arrive ascending.
 struct sl_row_acc {
     double sum = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
     uint32_t chunks4 = 0;
@@ -294,119 +309,134 @@ struct sl_row_acc {
     }
 };
 
-// products p (one per lane) of entries at row positions q0 + (lane within group): add the non-zero ones of MY group in order
-template <int G>
-__device__ __forceinline__ void sl_group_accumulate(sl_row_acc &acc, double p, uint32_t q0, uint32_t lane)
+// (2) candidate rows: r_i -= (B delta_old)_i ; next frontier from |r_i dinv_i| >= theta.  Appends to the next frontier
+//     (and the count of column entries under it) are reserved per wave.
+__device__ __forceinline__ void sl_pull_finish_wave(bool live, uint32_t i, double acc, double r_old, double dinv_i, double theta, uint32_t lane,
+                                                    const uint32_t *tptr, double *r, double *delta_new, uint32_t *next, sl_push_ctl *c)
 {
-    const unsigned long long all = __ballot(p != 0.0);
-    const uint32_t g0 = lane & ~(uint32_t)(G - 1);                            // first lane of my group
-    unsigned long long seg = (G == 64) ? all : ((all >> g0) & ((1ull << G) - 1ull));
-    while (seg) {                                                             // groups iterate independently (sources are in-group)
-        const int l = __builtin_ctzll(seg);
-        seg &= seg - 1;
-        acc.add(q0 + (uint32_t)l, __shfl(p, (int)g0 + l));
+    double p = 0.0;
+    if (live) {
+        const double rn = DSUB(r_old, acc);
+        r[i] = rn;
+        p = DMUL(rn, dinv_i);
     }
+    const bool pass = live && fabs(p) >= theta;
+    const unsigned long long m = __ballot(pass);
+    if (!m) return;
+    unsigned long long colw = pass ? (unsigned long long)(tptr[i + 1] - tptr[i]) : 0ull;
+    for (int off = 32; off > 0; off >>= 1) colw += __shfl_xor(colw, off);
+    uint32_t base = 0;
+    const int leader = __builtin_ctzll(m);
+    if ((int)lane == leader) { base = atomicAdd(&c->nn, (uint32_t)__popcll(m)); atomicAdd(&c->next_hits, colw); }
+    base = __shfl(base, leader);
+    if (pass) { delta_new[i] = p; next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i; }
 }
 
-// One launch, three roles by block range — the candidate lists of a round are independent of each other:
-//   blocks [0, nb0)         short rows, one THREAD per row: all entries are fetched at once (two memory latencies);
-//   blocks [nb0, nb0+nb1)   rows of 8..64 entries, a 16-lane group per row, 4 entries per lane in flight;
-//   the rest                longer rows, one WAVE per row, 1024 entries (16 per lane) in flight per step.
-// A row's cost is a handful of memory latencies whatever its length, instead of two per entry.
-__global__ __launch_bounds__(256) void sl_pull_kernel(sl_push_ctl *c, sl_cand_lists cl, uint32_t nb0, uint32_t nb1, op_view op,
-                                                      const double *delta_old, const double *dinv, double theta, int order, double *r,
-                                                      double *delta_new, uint32_t *flag, uint32_t *next, uint32_t keep_flag)
+// thread per candidate row: walk the row's hit list (newest first), order the hits by position with a static
+// insertion network, add them up.  Rows hit more than SL_MAX_HITS times go to the heavy list (whole-row pull).
+__global__ __launch_bounds__(256) void sl_pull_hits_kernel(sl_push_ctl *c, const uint32_t *cand, op_view op, const sl_hit *recs, uint32_t *head,
+                                                           const double *dinv, double theta, int order, double *r, double *delta_new,
+                                                           uint32_t *next, uint32_t *heavy)
 {
     if (c->stop) return;
     const uint32_t lane = threadIdx.x & 63u;
-    if (blockIdx.x < nb0) {
-        const uint32_t nc = c->nc[0];
-        const uint32_t stride = nb0 * 256;
-        for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nc; t += stride) {
-            const uint32_t i = cl.list[0][t];
-            const uint32_t s = op.ptr[i], len = op.ptr[i + 1] - s;             // len < 8: both orders are the plain left-to-right sum
-            const double r_old = r[i], dv = dinv[i];
-            flag[i] = keep_flag;
-            uint32_t ci[7]; double va[7], dl[7];
-#pragma unroll
-            for (int u = 0; u < 7; ++u) { const bool ok = (uint32_t)u < len; ci[u] = ok ? op.idx[s + u] : 0u; va[u] = ok ? op.val[s + u] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 7; ++u) dl[u] = (uint32_t)u < len ? delta_old[ci[u]] : 0.0;
-            double acc = 0.0;
-#pragma unroll
-            for (int u = 0; u < 7; ++u) if ((uint32_t)u < len) acc = DADD(acc, DMUL(va[u], dl[u]));
-            sl_pull_finish(i, acc, r_old, dv, theta, r, delta_new, next, &c->nn);
+    const uint32_t nc = c->nc;
+    const uint32_t stride = gridDim.x * 256;
+    const uint32_t trips = (nc + stride - 1) / stride;                         // wave-uniform (ballots in the finish)
+    for (uint32_t it = 0; it < trips; ++it) {
+        const uint32_t t = it * stride + blockIdx.x * 256 + threadIdx.x;
+        bool live = t < nc;
+        const uint32_t i = live ? cand[t] : 0u;
+        uint32_t h = SL_EMPTY;
+        double r_old = 0.0, dv = 0.0;
+        uint32_t s = 0, len = 0;
+        if (live) {
+            h = head[i]; head[i] = SL_EMPTY;
+            r_old = r[i]; dv = dinv[i];
+            if (order == SL_ORDER_SIMD4) { s = op.ptr[i]; len = op.ptr[i + 1] - s; }
         }
-    } else if (blockIdx.x < nb0 + nb1) {
-        const uint32_t nc = c->nc[1];
-        const uint32_t lig = lane & 15u;
-        const uint32_t group = (blockIdx.x - nb0) * 16 + (threadIdx.x >> 4), ngroups = nb1 * 16;
-        const uint32_t trips = (nc + ngroups - 1) / ngroups;                   // same trip count for the whole wave (ballots inside)
-        for (uint32_t it = 0; it < trips; ++it) {
-            const uint32_t t = group + it * ngroups;
-            const bool live = t < nc;
-            const uint32_t i = live ? cl.list[1][t] : 0u;
-            const uint32_t s = live ? op.ptr[i] : 0u, len = live ? op.ptr[i + 1] - s : 0u;
-            double r_old = 0.0, dv = 0.0;
-            if (live && lig == 0) { r_old = r[i]; dv = dinv[i]; flag[i] = keep_flag; }
-            double pr[4];
+        uint32_t hk[SL_MAX_HITS]; double hp[SL_MAX_HITS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t q = (uint32_t)u * 16u + lig;
-                pr[u] = q < len ? DMUL(op.val[s + q], delta_old[op.idx[s + q]]) : 0.0;
-            }
-            sl_row_acc acc;
-            acc.init(len, order);
+        for (int u = 0; u < SL_MAX_HITS; ++u) { hk[u] = SL_EMPTY; hp[u] = 0.0; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sl_group_accumulate<16>(acc, pr[u], (uint32_t)u * 16u, lane);
-            const double sum = acc.finish();
-            if (live && lig == 0) sl_pull_finish(i, sum, r_old, dv, theta, r, delta_new, next, &c->nn);
-        }
-    } else {
-        const uint32_t nc = c->nc[2];
-        const uint32_t nb2 = gridDim.x - nb0 - nb1;
-        const uint32_t wave = (blockIdx.x - nb0 - nb1) * 4 + (threadIdx.x >> 6), nwaves = nb2 * 4;
-        for (uint32_t t = wave; t < nc; t += nwaves) {
-            const uint32_t i = cl.list[2][t];
-            const uint32_t s = op.ptr[i], len = op.ptr[i + 1] - s;
-            double r_old = 0.0, dv = 0.0;
-            if (lane == 0) { r_old = r[i]; dv = dinv[i]; flag[i] = keep_flag; }
-            sl_row_acc acc;
-            acc.init(len, order);
-            for (uint32_t base = 0; base < len; base += 1024u) {
-                double pr[16];
+        for (int hop = 0; hop < SL_MAX_HITS; ++hop) {
+            if (h != SL_EMPTY) {
+                const sl_hit rec = recs[h];
+                h = rec.next;
+                uint32_t nk = rec.k; double np = rec.prod;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const uint32_t q = base + (uint32_t)u * 64u + lane;
-                    pr[u] = q < len ? DMUL(op.val[s + q], delta_old[op.idx[s + q]]) : 0.0;
+                for (int u = 0; u < SL_MAX_HITS; ++u) {                        // keep hk ascending: bubble the new hit into place
+                    if (nk < hk[u]) { const uint32_t tk = hk[u]; const double tp = hp[u]; hk[u] = nk; hp[u] = np; nk = tk; np = tp; }
                 }
-#pragma unroll
-                for (int u = 0; u < 16; ++u) sl_group_accumulate<64>(acc, pr[u], base + (uint32_t)u * 64u, lane);
             }
-            const double sum = acc.finish();
-            if (lane == 0) sl_pull_finish(i, sum, r_old, dv, theta, r, delta_new, next, &c->nn);
         }
+        if (live && h != SL_EMPTY) { heavy[atomicAdd(&c->n_heavy, 1u)] = i; live = false; }   // more hits than the network holds
+        sl_row_acc acc;
+        acc.init(len, order);
+#pragma unroll
+        for (int u = 0; u < SL_MAX_HITS; ++u) if (hk[u] != SL_EMPTY) acc.add(hk[u] - s, hp[u]);
+        sl_pull_finish_wave(live, i, acc.finish(), r_old, dv, theta, lane, op.tptr, r, delta_new, next, c);
     }
 }
 
-// (3) delta_old[j] = 0 for the frontier just consumed (keeps the buffer all-zero outside a frontier)
-__global__ __launch_bounds__(256) void sl_clear_kernel(sl_push_ctl *c, const uint32_t *frontier, double *delta)
+// heavy rows (hit by many frontier columns): one WAVE per row over the whole row, 1024 entries (16 per lane) in flight
+// per step, non-zero products added in entry order
+__global__ __launch_bounds__(256) void sl_pull_heavy_kernel(sl_push_ctl *c, const uint32_t *heavy, op_view op, const double *delta_old,
+                                                            const double *dinv, double theta, int order, double *r, double *delta_new,
+                                                            uint32_t *next)
+{
+    if (c->stop) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nh = c->n_heavy;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (uint32_t t = wave; t < nh; t += nwaves) {
+        const uint32_t i = heavy[t];
+        const uint32_t s = op.ptr[i], len = op.ptr[i + 1] - s;
+        double r_old = 0.0, dv = 0.0;
+        if (lane == 0) { r_old = r[i]; dv = dinv[i]; }
+        sl_row_acc acc;
+        acc.init(len, order);
+        for (uint32_t base = 0; base < len; base += 1024u) {
+            double pr[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t q = base + (uint32_t)u * 64u + lane;
+                pr[u] = q < len ? DMUL(op.val[s + q], delta_old[op.idx[s + q]]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                unsigned long long seg = __ballot(pr[u] != 0.0);
+                while (seg) {
+                    const int l = __builtin_ctzll(seg);
+                    seg &= seg - 1;
+                    acc.add(base + (uint32_t)u * 64u + (uint32_t)l, __shfl(pr[u], l));
+                }
+            }
+        }
+        sl_pull_finish_wave(lane == 0, i, acc.finish(), r_old, dv, theta, lane, op.tptr, r, delta_new, next, c);
+    }
+}
+
+// (3) delta_old[j] = 0 for the frontier just consumed (keeps the buffer all-zero outside a frontier); the block that
+//     finishes last closes the round: statistics, the next frontier becomes the frontier, stop rule
+__global__ __launch_bounds__(256) void sl_clear_kernel(sl_push_ctl *c, const uint32_t *frontier, double *delta, uint32_t dense_threshold,
+                                                       unsigned long long hit_limit)
 {
     if (c->stop) return;
     const uint32_t nf = c->nf;
     const uint32_t stride = gridDim.x * 256;
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nf; t += stride) delta[frontier[t]] = 0.0;
-}
-
-// (4) close the round: statistics, next frontier becomes the frontier, stop rule
-__global__ void sl_round_end_kernel(sl_push_ctl *c, uint32_t dense_threshold)
-{
-    if (c->stop) return;
-    c->rounds += 1; c->pushes += c->nf; c->rows_touched += (unsigned long long)c->nc[0] + c->nc[1] + c->nc[2];
-    const uint32_t nf = c->nn;
-    c->nf = nf; c->nc[0] = c->nc[1] = c->nc[2] = 0; c->nn = 0; c->n_long_cols = 0;
-    if (nf == 0) c->stop = 1u;
-    else if (nf > dense_threshold) c->stop = 2u;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    __threadfence();
+    if (atomicAdd(&c->done_blocks, 1u) != gridDim.x - 1) return;
+    c->done_blocks = 0;
+    c->rounds += 1; c->pushes += nf; c->rows_touched += c->nc;
+    const uint32_t nn = c->nn;
+    const unsigned long long nh = c->next_hits;
+    c->nf = nn; c->nn = 0; c->nc = 0; c->n_heavy = 0; c->n_long_cols = 0; c->nrec = 0; c->hits = nh; c->next_hits = 0;
+    if (nn == 0) c->stop = 1u;
+    else if (nn > dense_threshold || nh > hit_limit) c->stop = 2u;
 }
 
 // generic (any operator given as CSR) dense round, one thread per row — used by estimate_entry
@@ -433,10 +463,14 @@ struct push_state {
     double *x = nullptr, *r = nullptr, *dinv = nullptr;
     double *delta[2] = {nullptr, nullptr};
     uint32_t *frontier[2] = {nullptr, nullptr}; // cur / next
-    uint32_t *cand = nullptr, *cand_mid = nullptr, *cand_long = nullptr, *cand_flag = nullptr;   // candidate rows by length class
+    uint32_t *cand = nullptr, *heavy = nullptr; // candidate rows of a sparse round; those pulled over their whole length
+    uint32_t *head = nullptr;                   // per row: newest hit record of the running round (SL_EMPTY between rounds)
+    uint32_t *cand_flag = nullptr;              // per row: SL_FLAG_TOUCHED (query sessions)
+    sl_hit *recs = nullptr;                     // hit records of the running round
+    uint64_t rec_cap = 0, op_nnz = 0;
     uint32_t *counters = nullptr;               // [2] compaction total
     sl_push_ctl *ctl = nullptr;                 // device-driven sparse rounds
-    uint32_t *long_list = nullptr;
+    uint32_t *long_list = nullptr;              // deferred hub columns
     uint32_t *touched = nullptr;                // query sessions: rows whose state must be cleaned up afterwards
     bool flooded = false;                       // a dense round ran: every row may be touched
     uint32_t *block_count = nullptr, *block_off = nullptr;
@@ -516,11 +550,18 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     const double dense_limit = dense_switch * (double)n;               // nf > dense_limit  <=>  nf > floor(dense_limit)
     const uint32_t dense_threshold = dense_limit >= 4294967295.0 ? 0xffffffffu : (dense_limit > 0.0 ? (uint32_t)dense_limit : 0u);
 
+    // a sparse round costs ~40x a dense round per matrix entry it touches (records, atomics, random sectors)
+    // (dense_switch >= 1: the caller asked for sparse rounds throughout; only the record buffer limits them)
+    const unsigned long long hit_limit = dense_switch >= 1.0 ? ps.rec_cap
+                                         : std::min<unsigned long long>(ps.rec_cap, std::max<unsigned long long>(ps.op_nnz / 32, 4096));
+    bool force_dense = false, need_log = true;
+
     sl_status st = SL_OK;
     while (rs.rounds < max_rounds) {
-        if (list_valid) SL_TRY(plog.append(ps, ps.frontier[0], nf, list_sorted, s));
+        if (list_valid && need_log) { SL_TRY(plog.append(ps, ps.frontier[0], nf, list_sorted, s)); need_log = false; }
         if (nf == 0) { rs.converged = true; break; }
-        const bool dense = (double)nf > dense_switch * (double)n;
+        const bool dense = force_dense || (double)nf > dense_switch * (double)n;
+        force_dense = false;
         if (dense) {
             uint32_t nf_next = 0;
             if (m) {
@@ -544,24 +585,28 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
             if (next_dense_likely) { nf = nf_next; list_valid = false; continue; } // no list needed: the dense kernel overwrites everything
             SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s));
             SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s));
-            list_valid = true; list_sorted = true;
+            list_valid = true; list_sorted = true; need_log = true;
         } else {
-            if (!list_valid) { SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s)); list_valid = true; list_sorted = true;
+            if (!list_valid) { SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s)); list_valid = true; list_sorted = true; need_log = true;
                                SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s)); }
             // a batch of device-driven sparse rounds (one round when the frontier lists are being logged)
             uint64_t batch = plog.log ? 1 : (uint64_t)sparse_batch;
             if (batch > max_rounds - rs.rounds) batch = max_rounds - rs.rounds;
             hipLaunchKernelGGL(sl_push_ctl_reset_kernel, dim3(1), dim3(1), 0, s, ps.ctl, nf);
-            const sl_cand_lists cl{{ps.cand, ps.cand_mid, ps.cand_long}};
+            hipLaunchKernelGGL(sl_frontier_hits_kernel, dim3((uint32_t)std::min<uint64_t>((nf + 255) / 256, 512)), dim3(256), 0, s, ps.ctl, ps.frontier[0], ps.op.tptr);
+            hipLaunchKernelGGL(sl_hits_gate_kernel, dim3(1), dim3(1), 0, s, ps.ctl, (unsigned long long)ps.rec_cap);   // hard limit: the record buffer
             for (uint64_t b = 0; b < batch; ++b) {
                 const int c = cur ^ (int)(b & 1);
                 uint32_t *f_in = ps.frontier[b & 1], *f_out = ps.frontier[1 - (b & 1)];
-                hipLaunchKernelGGL(sl_expand_kernel, dim3(1024), dim3(256), 0, s, ps.ctl, f_in, ps.op, ps.delta[c], ps.x, ps.cand_flag, cl, ps.long_list, ps.touched);
-                hipLaunchKernelGGL(sl_expand_long_kernel, dim3(512), dim3(256), 0, s, ps.ctl, ps.long_list, ps.op, ps.cand_flag, cl, ps.touched);
-                hipLaunchKernelGGL(sl_pull_kernel, dim3(512 + 512 + 512), dim3(256), 0, s, ps.ctl, cl, 512u, 512u, ps.op, ps.delta[c], ps.dinv, theta, order,
-                                   ps.r, ps.delta[1 - c], ps.cand_flag, f_out, ps.touched ? SL_FLAG_TOUCHED : 0u);
-                hipLaunchKernelGGL(sl_clear_kernel, dim3(256), dim3(256), 0, s, ps.ctl, f_in, ps.delta[c]);
-                hipLaunchKernelGGL(sl_round_end_kernel, dim3(1), dim3(1), 0, s, ps.ctl, dense_threshold);
+                hipLaunchKernelGGL(sl_expand_kernel, dim3(1024), dim3(256), 0, s, ps.ctl, f_in, ps.op, ps.delta[c], ps.x, ps.recs, ps.head, ps.cand,
+                                   ps.cand_flag, ps.long_list, ps.touched);
+                hipLaunchKernelGGL(sl_expand_long_kernel, dim3(512), dim3(256), 0, s, ps.ctl, ps.long_list, ps.op, ps.delta[c], ps.recs, ps.head, ps.cand,
+                                   ps.cand_flag, ps.touched);
+                hipLaunchKernelGGL(sl_pull_hits_kernel, dim3(512), dim3(256), 0, s, ps.ctl, ps.cand, ps.op, ps.recs, ps.head, ps.dinv, theta, order, ps.r,
+                                   ps.delta[1 - c], f_out, ps.heavy);
+                hipLaunchKernelGGL(sl_pull_heavy_kernel, dim3(512), dim3(256), 0, s, ps.ctl, ps.heavy, ps.op, ps.delta[c], ps.dinv, theta, order, ps.r,
+                                   ps.delta[1 - c], f_out);
+                hipLaunchKernelGGL(sl_clear_kernel, dim3(128), dim3(256), 0, s, ps.ctl, f_in, ps.delta[c], dense_threshold, hit_limit);
             }
             sl_push_ctl h;
             SL_HIP(hipMemcpyAsync(&h, ps.ctl, sizeof(h), hipMemcpyDeviceToHost, s));
@@ -570,6 +615,8 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
             if (h.rounds & 1u) { std::swap(ps.frontier[0], ps.frontier[1]); cur = 1 - cur; }
             nf = h.nf; list_valid = true; list_sorted = false;
             rs.n_touched = h.n_touched;
+            force_dense = (h.stop == 2u);                              // too many column entries (or rows) for a sparse round
+            need_log = h.rounds != 0;
             if (h.rounds == 0 && h.stop == 0) return sl_fail(SL_DEVICE_ERROR, "sparse push batch made no progress");
         }
     }
@@ -582,11 +629,14 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     return st;
 }
 
-sl_status alloc_state(push_state &ps, uint64_t n, DevBuf bufs[20])
+sl_status alloc_state(push_state &ps, uint64_t n, uint64_t nnz, DevBuf bufs[20])
 {
     ps.n = n;
+    ps.op_nnz = nnz;
+    ps.rec_cap = std::min<uint64_t>(nnz, std::max<uint64_t>(2 * n + nnz / 16, 1u << 22));   // 16 B per record; small systems: every entry
     ps.nblocks = (uint32_t)((n + SL_CTILE - 1) / SL_CTILE);
     if (ps.nblocks == 0) ps.nblocks = 1;
+    hipStream_t s = sl_context().stream;
     size_t k = 0;
     SL_TRY(bufs[k].alloc(n * 8)); ps.x = bufs[k++].as<double>();
     SL_TRY(bufs[k].alloc(n * 8)); ps.r = bufs[k++].as<double>();
@@ -596,17 +646,19 @@ sl_status alloc_state(push_state &ps, uint64_t n, DevBuf bufs[20])
     SL_TRY(bufs[k].alloc(n * 4)); ps.frontier[0] = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.frontier[1] = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.cand = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc(n * 4)); ps.cand_mid = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc(n * 4)); ps.cand_long = bufs[k++].as<uint32_t>();
+    SL_TRY(bufs[k].alloc(n * 4)); ps.heavy = bufs[k++].as<uint32_t>();
+    SL_TRY(bufs[k].alloc(n * 4)); ps.head = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.cand_flag = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(n * 4)); ps.long_list = bufs[k++].as<uint32_t>();
+    SL_TRY(bufs[k].alloc((ps.rec_cap + 256) * sizeof(sl_hit))); ps.recs = bufs[k++].as<sl_hit>();
     SL_TRY(bufs[k].alloc(64)); ps.counters = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc(sizeof(sl_push_ctl))); ps.ctl = bufs[k++].as<sl_push_ctl>();
-    SL_HIP(hipMemsetAsync(ps.ctl, 0, sizeof(sl_push_ctl), sl_context().stream));
     SL_TRY(bufs[k].alloc((size_t)ps.nblocks * 4)); ps.block_count = bufs[k++].as<uint32_t>();
     SL_TRY(bufs[k].alloc((size_t)ps.nblocks * 4)); ps.block_off = bufs[k++].as<uint32_t>();
-    SL_HIP(hipMemsetAsync(ps.cand_flag, 0, n * 4, sl_context().stream));
-    SL_HIP(hipMemsetAsync(ps.counters, 0, 64, sl_context().stream));
+    SL_HIP(hipMemsetAsync(ps.ctl, 0, sizeof(sl_push_ctl), s));
+    SL_HIP(hipMemsetAsync(ps.cand_flag, 0, n * 4, s));
+    SL_HIP(hipMemsetAsync(ps.head, 0xff, n * 4, s));                    // SL_EMPTY
+    SL_HIP(hipMemsetAsync(ps.counters, 0, 64, s));
     return SL_OK;
 }
 
@@ -639,8 +691,8 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
 
     push_state ps;
     DevBuf bufs[20], bbuf, ax;
-    SL_TRY(alloc_state(ps, n, bufs));
-    ps.op = op_view{m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_trow};
+    SL_TRY(alloc_state(ps, n, m->nnz, bufs));
+    ps.op = op_view{m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_trow, m->d_tent};
     SL_TRY(bbuf.alloc(n * 8));
     SL_HIP(hipMemcpyAsync(bbuf.p, b, n * 8, in_kind, s));
     SL_HIP(hipMemcpyAsync(ps.x, x, n * 8, in_kind, s));
@@ -689,11 +741,17 @@ struct sl_query_session {
     bool given_is_transpose = false;
     uint64_t n = 0;
     push_state ps;
-    DevBuf bufs[20], bbuf, touched, sums;
+    DevBuf bufs[20], bbuf, touched, sums, tinv;
     const double *db = nullptr;
     std::vector<double> h_dinv;           // host copy: the seed's threshold test needs dinv[row] only
     double dense_switch = 0.25;
 };
+
+__global__ void sl_invert_perm_kernel(uint64_t nnz, const uint32_t *perm, uint32_t *inv)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < nnz; p += stride) inv[perm[p]] = (uint32_t)p;
+}
 
 // r[row] = 1 and, if it passes the threshold, the one-entry frontier {row}
 __global__ void sl_seed_kernel(uint32_t row, double p, int in_frontier, double *r, double *delta, uint32_t *frontier, uint32_t *flag,
@@ -758,14 +816,14 @@ sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, c
     *out = nullptr;
     if (!m || !b) return sl_fail(SL_INVALID_INPUT, "null argument");
     if (m->n_rows != m->n_cols || m->row_offset != 0) return sl_fail(SL_INVALID_INPUT, "Matrix must be square");
-    if (!m->d_tptr || !m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "estimate_entry needs a matrix created with SL_MATRIX_WITH_TRANSPOSE");
+    if (!m->d_tptr || !m->d_row_ptr || (m->nnz && !m->d_tent)) return sl_fail(SL_UNSUPPORTED_FORMAT, "estimate_entry needs a matrix created with SL_MATRIX_WITH_TRANSPOSE");
     const uint64_t n = m->n_rows;
     hipStream_t s = sl_context().stream;
     sl_query_session *q = new (std::nothrow) sl_query_session();
     if (!q) return sl_fail(SL_ALLOCATION, "out of host memory");
     q->m = m; q->n = n; q->given_is_transpose = matrix_is_transpose != 0;
     q->dense_switch = q->given_is_transpose ? 1.0 / 16.0 : 0.25;
-    sl_status st = alloc_state(q->ps, n, q->bufs);
+    sl_status st = alloc_state(q->ps, n, m->nnz, q->bufs);
     if (st == SL_OK) st = q->touched.alloc((n ? n : 1) * 4);
     if (st == SL_OK) st = q->sums.alloc((2 * ((n + 1023) / 1024) + 8) * sizeof(double));
     unsigned long long hs[4] = {0, 0, 0, 0};
@@ -773,12 +831,17 @@ sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, c
         q->ps.touched = q->touched.as<uint32_t>();
         if (q->given_is_transpose) {
             // operator B = the matrix itself (= A^T); its dense rounds can use the row-slice kernels
-            q->ps.op = op_view{m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_trow};
+            q->ps.op = op_view{m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_trow, m->d_tent};
             st = sl_matrix_diag_pass(m, q->ps.dinv, hs);
         } else {
             // operator B = A^T: rows of B = columns of A (sorted transpose), columns of B = rows of A
-            q->ps.op = op_view{m->d_tptr, m->d_trow, m->d_tval, m->d_row_ptr, m->d_col_idx};
-            st = sl_csr_diag_pass(n, m->d_tptr, m->d_trow, m->d_tval, q->ps.dinv, hs);
+            // the column entries of B are A's CSR entries k; their place in B's row arrays is the inverse of the transpose permutation
+            st = q->tinv.alloc((m->nnz ? m->nnz : 1) * 4);
+            if (st == SL_OK && m->nnz)
+                hipLaunchKernelGGL(sl_invert_perm_kernel, dim3((uint32_t)std::min<uint64_t>((m->nnz + 255) / 256, 65535)), dim3(256), 0, s, m->nnz, m->d_tent,
+                                   q->tinv.as<uint32_t>());
+            q->ps.op = op_view{m->d_tptr, m->d_trow, m->d_tval, m->d_row_ptr, m->d_col_idx, q->tinv.as<uint32_t>()};
+            if (st == SL_OK) st = sl_csr_diag_pass(n, m->d_tptr, m->d_trow, m->d_tval, q->ps.dinv, hs);
         }
     }
     if (st == SL_OK && (hs[0] & 2ull)) st = sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2]);

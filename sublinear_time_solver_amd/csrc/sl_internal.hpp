@@ -47,6 +47,7 @@ struct sl_matrix {
     uint32_t *d_long_rows = nullptr; // ascending local ids of the rows with more than SL_LONG_ROW entries
     uint64_t n_long = 0;
     double *d_tval = nullptr;   // [nnz]
+    uint32_t *d_tent = nullptr; // [nnz] CSR entry index of each transposed entry (the permutation of the transpose)
     uint64_t device_bytes = 0;
 };
 

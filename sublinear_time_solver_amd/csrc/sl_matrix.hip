@@ -347,10 +347,11 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
                                    m->d_trow, m->d_tval);
                 hipStreamSynchronize(st);
             }
-            hipFree(d_keys); hipFree(d_ent_in); hipFree(d_ent);
-            if (ss != SL_OK) return ss;
+            hipFree(d_keys); hipFree(d_ent_in);
+            if (ss != SL_OK) { hipFree(d_ent); return ss; }
+            m->d_tent = d_ent;
         }
-        m->device_bytes += (m->n_cols + 1) * sizeof(uint32_t) + nnz * 12;
+        m->device_bytes += (m->n_cols + 1) * sizeof(uint32_t) + nnz * 16;
     }
 
     // 4. raw CSR copy (also needed by the long-row kernel)

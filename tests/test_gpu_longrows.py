@@ -77,6 +77,25 @@ def test_long_rows_push_bitwise(gpu, dense_switch):
         assert abs(e1.estimate - xs[row]) < 1e-9 and e1.estimate == e2.estimate
 
 
+@pytest.mark.parametrize("order", [0, 1])
+def test_hub_columns_and_batched_sparse_rounds_bitwise(gpu, order):
+    """push on the transpose of the hub system: hub COLUMNS (walked by the whole grid), rows hit by many frontier
+    columns (whole-row pull) and rows hit by few (hit lists), sparse rounds only, no frontier log — so several rounds
+    are enqueued per host round trip"""
+    rp, ci, va = _hub_system(seed=11)
+    n = rp.size - 1
+    trp, tci, tva = O.csr_transpose(rp, ci, va, n)
+    mt = S.SparseMatrix.from_csr(trp, tci, tva, n, n, with_transpose=True)
+    assert np.diff(rp.astype(np.int64)).max() > 1024                       # = the longest column of the transpose
+    b = np.zeros(n)
+    b[[3, 1234, 2500]] = [1.0, -0.75, 2.0]
+    g = S.PushSolver(theta=1e-9, dense_switch=2.0, order=order).solve(mt, b)
+    o = O.push_sync_solve(trp, tci, tva, b, theta=1e-9, order=order)
+    assert g["converged"] and g["dense_rounds"] == 0
+    assert (g["rounds"], g["pushes"], g["rows_touched"]) == (o["rounds"], o["pushes"], o["rows_touched"])
+    assert _bits_equal(g["solution"], o["x"]) and _bits_equal(g["residual"], o["r"])
+
+
 def _dense(rp, ci, va):
     n = rp.size - 1
     A = np.zeros((n, n))
