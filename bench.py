@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=10_000_000,
+                    help="rows per GPU (use --rows under torch.distributed.run: its own parser rejects `--n` as an ambiguous prefix)")
     ap.add_argument("--k", type=int, default=16, help="entries per row (diagonal included)")
     ap.add_argument("--bandwidth", type=int, default=-1, help="half bandwidth w of the column window; 0 = uniform columns; -1 = default")
     ap.add_argument("--seed", type=int, default=1)
@@ -128,11 +129,18 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
+    # SL_BENCH_BACKEND=gloo is a TEST mode: ranks may share a GPU and the exchanges are staged through the host
+    backend = os.environ.get("SL_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     lib = L.load()
     L.check(lib.sl_set_device(local_rank))
@@ -208,7 +216,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        D.all_reduce_scalar(tmax, dist.ReduceOp.MAX)
     elapsed, dev_ms = float(tmax[0]), float(tmax[1])
     term_norm = drv.term_norm()
 

@@ -31,6 +31,21 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(t: torch.Tensor, group=None) -> bool:
+    """gloo moves host memory only: device tensors are staged through the host (test mode — two ranks sharing one
+    GPU exercise the partitioned driver with the real kernels; the production backend is "nccl" = RCCL)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_scalar(t: torch.Tensor, op, group=None, async_op: bool = False):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=op, group=group, async_op=async_op)
+
+
 @dataclass
 class RowPartition:
     n_global: int
@@ -64,6 +79,11 @@ class AllGatherExchange:
         if p.world == 1:
             return None
         mine = t_full[p.rank * p.rows_per_rank:(p.rank + 1) * p.rows_per_rank]
+        if _staged(t_full, self.group):
+            host = torch.empty(t_full.numel(), dtype=t_full.dtype)
+            dist.all_gather_into_tensor(host, mine.cpu(), group=self.group)
+            t_full.copy_(host)
+            return None
         return dist.all_gather_into_tensor(t_full, mine, group=self.group, async_op=True)
 
     def finish(self, handle) -> None:
@@ -91,19 +111,32 @@ class HaloExchange:
         p, w = self.part, self.w
         if p.world == 1 or w == 0:
             return None
-        ops = []
+        staged = _staged(t_full, self.group)
+        ops, landing = [], []
+
+        def pair(send_view, recv_view, peer):
+            if staged:
+                buf = torch.empty(recv_view.numel(), dtype=recv_view.dtype)
+                landing.append((buf, recv_view))
+                send_view, recv_view = send_view.cpu(), buf
+            ops.append(dist.P2POp(dist.isend, send_view, peer, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, recv_view, peer, group=self.group))
+
         if p.rank > 0:                       # left neighbour: send my first w, receive its last w
-            ops.append(dist.P2POp(dist.isend, t_full[p.lo:p.lo + w], p.rank - 1, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, t_full[p.lo - w:p.lo], p.rank - 1, group=self.group))
+            pair(t_full[p.lo:p.lo + w], t_full[p.lo - w:p.lo], p.rank - 1)
         if p.rank < p.world - 1 and p.hi < p.n_global:
-            ops.append(dist.P2POp(dist.isend, t_full[p.hi - w:p.hi], p.rank + 1, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, t_full[p.hi:p.hi + w], p.rank + 1, group=self.group))
-        return dist.batch_isend_irecv(ops) if ops else None
+            pair(t_full[p.hi - w:p.hi], t_full[p.hi:p.hi + w], p.rank + 1)
+        if not ops:
+            return None
+        return dist.batch_isend_irecv(ops), landing
 
     def finish(self, handle) -> None:
         if handle:
-            for r in handle:
+            reqs, landing = handle
+            for r in reqs:
                 r.wait()
+            for buf, view in landing:
+                view.copy_(buf)
 
     def __call__(self, t_full: torch.Tensor) -> None:
         self.finish(self.start(t_full))
@@ -183,7 +216,7 @@ class PartitionedNeumann:
             self.local_step(t_in, t_out_local, self.x, self._norm[slot])
             self.exchange(t_out)
         if reduce_norm and p.world > 1:
-            self._pending[slot] = dist.all_reduce(self._norm[slot][:1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending[slot] = all_reduce_scalar(self._norm[slot][:1], dist.ReduceOp.SUM, self.group, async_op=True)
         self._slot = slot
         self.cur = 1 - self.cur
         self.steps_done += 1
@@ -255,7 +288,7 @@ class PartitionedNeumannSolver:
 
     def _allsum(self, scalar: torch.Tensor) -> float:
         if self.part.world > 1:
-            dist.all_reduce(scalar, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_scalar(scalar, dist.ReduceOp.SUM, self.group)
         return float(scalar[0].item())
 
     def solve(self, b_local: torch.Tensor, dinv_local: torch.Tensor, tolerance: float = 1e-6, max_iterations: int = 1000,

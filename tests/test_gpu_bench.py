@@ -30,3 +30,35 @@ def test_bench_line_contract_and_split_equivalence(gpu):
     assert b["config"]["exchange"] == "halo+overlap"
     na, nb = a["config"]["last_term_norm"], b["config"]["last_term_norm"]
     assert abs(na - nb) <= 1e-12 * na and na > 0
+
+
+def _bench_two_ranks(n_per_rank, w, *extra):
+    """two ranks sharing the one GPU of the test box; exchanges staged through the host over gloo (SL_BENCH_BACKEND)"""
+    import os
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SL_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", "2", "--rows", str(n_per_rank), "--k", "16", "--bandwidth", str(w),
+                        "--steps", "7", "--warmup", "0", "--no-cpu-baseline", "--no-sweep", *extra],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("w,extra,exchange", [(512, (), "halo+overlap"), (512, ("--no-overlap",), "halo"), (0, (), "allgather")])
+def test_bench_two_ranks_reproduce_the_single_rank_iteration(gpu, w, extra, exchange):
+    """bench.py at world size 2 (row slices at a non-zero row offset, halo / all-gather exchange, boundary-first overlap,
+    norm all-reduce) must run the same iteration as one rank owning all rows: same last term norm"""
+    one = subprocess.run([sys.executable, "bench.py", "--n", "300000", "--k", "16", "--bandwidth", str(w), "--steps", "7", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-sweep"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    b = _bench_two_ranks(150000, w, *extra)
+    assert b["n_gpus"] == 2 and b["config"]["n_global"] == 300000 and b["config"]["exchange"] == exchange and b["scaling"] == "weak"
+    na, nb = a["config"]["last_term_norm"], b["config"]["last_term_norm"]
+    assert na > 0 and abs(na - nb) <= 1e-12 * na
+    assert abs(b["value"] - 300000 * 16 * 7 / (b["ms_per_step"] * 7e-3)) <= 1e-6 * b["value"]     # whole-job units / max-over-ranks time
