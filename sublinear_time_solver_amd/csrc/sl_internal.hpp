@@ -18,7 +18,9 @@
 #include "../../include/sublinear_hip.h"
 
 #define SL_SLICE 64
+#ifndef SL_BLOCK
 #define SL_BLOCK 256
+#endif
 #define SL_WAVES_PER_BLOCK (SL_BLOCK / SL_SLICE)
 // rows longer than this leave the slice layout (one hub row would stretch its whole 64-row slice): they are
 // reduced by the long-row kernel, one block per row, products in parallel, additions in the reference order

@@ -152,19 +152,19 @@ __device__ __forceinline__ void sl_row_epilogue(const sl_row_args &a, uint64_t i
     }
 }
 
-template <int EPI>
+template <int EPI, int NWB = SL_WAVES_PER_BLOCK>
 __device__ __forceinline__ void sl_block_partials(const sl_row_args &a, double *red, uint32_t lane, uint32_t wave, uint32_t lb,
                                                   uint32_t nparts, double part0, double part1)
 {
     if constexpr (EPI != SL_EPI_SPMV) {
         part0 = wave_sum(part0);
         if constexpr (EPI == SL_EPI_PUSH) part1 = wave_sum(part1);
-        if (lane == 0) { red[wave] = part0; red[SL_WAVES_PER_BLOCK + wave] = part1; }
+        if (lane == 0) { red[wave] = part0; red[NWB + wave] = part1; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            double p0 = red[0], p1 = red[SL_WAVES_PER_BLOCK];
+            double p0 = red[0], p1 = red[NWB];
 #pragma unroll
-            for (int w = 1; w < SL_WAVES_PER_BLOCK; ++w) { p0 += red[w]; p1 += red[SL_WAVES_PER_BLOCK + w]; }
+            for (int w = 1; w < NWB; ++w) { p0 += red[w]; p1 += red[NWB + w]; }
             a.partials[lb] = p0;
             if constexpr (EPI == SL_EPI_PUSH) a.partials[(uint64_t)nparts + lb] = p1;
         }
@@ -313,7 +313,7 @@ struct sl_batch_regs {
     double e_d, e_x, e_aux;
     uint32_t len;
 };
-struct sl_batch_cursor { uint64_t s0, s; uint32_t j, spw, q, q0, q1; bool in_slice; uint32_t lane_q0, lane_q1; };   // lane_q*: slice pointers of slice j held by lane j
+struct sl_batch_cursor { uint64_t s0, s; uint32_t j, spw, q, q0, q1; bool in_slice; uint32_t lane_q0, lane_q1, nw; };   // lane_q*: slice pointers of slice j held by lane j
 struct sl_row_state { double sum, l0, l1, l2, l3, e_d, e_x, e_aux; uint32_t len, chunks; bool merged, live; };
 
 __device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch_cursor &c)
@@ -321,7 +321,7 @@ __device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch
     sl_batch b{0, 0, 0, 0, false, false, false};
     if (!c.in_slice) {
         if (c.j >= c.spw) return b;
-        c.s = c.s0 + (uint64_t)c.j * SL_WAVES_PER_BLOCK;
+        c.s = c.s0 + (uint64_t)c.j * c.nw;
         if (c.s >= a.n_slices) return b;
         c.q0 = __builtin_amdgcn_readlane(c.lane_q0, c.j);      // fetched for all of the wave's slices up front
         c.q1 = __builtin_amdgcn_readlane(c.lane_q1, c.j);
@@ -423,10 +423,12 @@ __device__ __forceinline__ void sl_batch_finish(const sl_row_args &a, const sl_b
     }
 }
 
-template <int ORDER, int EPI, int UW, bool PIPE, bool C16>
-__global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32_t nb8, uint32_t spw, uint32_t w)
+// NW = waves per block.  4 by default; 8 for wide windows, where the LDS window (not registers) caps the CU at two
+// blocks: 8-wave blocks then double the waves in flight per window (4 per SIMD — the second launch-bounds argument
+// holds the kernel to 128 VGPRs for that).  Measured at w = 4096: +5..6 % (gpurun_out/ab_b512.txt).
+template <int ORDER, int EPI, int UW, bool PIPE, bool C16, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void sl_band_kernel(sl_row_args a, uint32_t nb8, uint32_t spw, uint32_t w)
 {
-    constexpr int NW = SL_WAVES_PER_BLOCK;
     extern __shared__ __attribute__((aligned(16))) double win[];
     __shared__ double red[2 * NW];
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
         const f64x2 *__restrict__ src2 = reinterpret_cast<const f64x2 *>(src);
         f64x2 *win2 = reinterpret_cast<f64x2 *>(win);
         const uint32_t pairs = len >> 1;
-        for (uint32_t p = threadIdx.x; p < pairs; p += SL_BLOCK) win2[p] = src2[p];
+        for (uint32_t p = threadIdx.x; p < pairs; p += NW * 64) win2[p] = src2[p];
         if ((len & 1u) && threadIdx.x == 0) win[len - 1] = src[len - 1];
         __syncthreads();
         const double *lw = win;
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
                 sl_slice_finish<EPI, UW, C16>(a, s, lane, ra, lw, base, part0, part1);
             }
         } else if constexpr (PIPE) {
-            sl_batch_cursor cur{s0, 0, 0, spw, 0, 0, 0, false, pre_q0, pre_q1};
+            sl_batch_cursor cur{s0, 0, 0, spw, 0, 0, 0, false, pre_q0, pre_q1, (uint32_t)NW};
             sl_batch_regs ga, gb;
             sl_row_state st{};
             sl_batch ba = sl_next_batch(a, cur);
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_band_kernel(sl_row_args a, uint32
             }
         }
     }
-    sl_block_partials<EPI>(a, red, lane, wave, lb, a.part_stride, part0, part1);
+    sl_block_partials<EPI, NW>(a, red, lane, wave, lb, a.part_stride, part0, part1);
 }
 
 // ---- long rows: one block per row ------------------------------------------------------------------
@@ -640,10 +642,10 @@ uint32_t sl_row_grid(uint64_t n_slices)
 
 // band-kernel geometry for half bandwidth w: slices per wave, dynamic LDS bytes, pipelining; spw = 0: not eligible
 #define SL_BAND_MAX_LDS (80u * 1024u)      // two blocks per CU (160 KiB LDS)
-struct band_geom { uint32_t spw, lds; bool pipe, c16; };
-static band_geom band_geometry(const sl_row_args &a)
+struct band_geom { uint32_t spw, lds, nw; bool pipe, c16; };
+static band_geom band_geometry(const sl_row_args &a, bool variant_fits_nw8)
 {
-    static int disabled = -1, forced_spw = 0, forced_pipe = -1, c16_off = 0;
+    static int disabled = -1, forced_spw = 0, forced_pipe = -1, c16_off = 0, forced_nw = 0;
     if (disabled < 0) {
         const char *e = getenv("SL_BAND_DISABLE");
         disabled = (e && e[0] == '1') ? 1 : 0;
@@ -653,35 +655,52 @@ static band_geom band_geometry(const sl_row_args &a)
         forced_pipe = g ? atoi(g) : -1;
         const char *h = getenv("SL_BAND_C16");
         c16_off = (h && h[0] == '0') ? 1 : 0;
+        const char *nwe = getenv("SL_BAND_NW");
+        forced_nw = nwe ? atoi(nwe) : 0;
     }
-    band_geom out{0, 0, false, false};
+    band_geom out{0, 0, 4, false, false};
     if (disabled || a.bandwidth == ~0ull || a.n_cols > 0xffffffffull) return out;
-    // measured (gpurun_out/sweep4.txt, sweep5.txt; +-5 % DVFS noise between repetitions): 4 slices per wave for
-    // narrow windows, 6 for wide ones (the window is re-staged 4 * spw * 64 rows at a time); pipelining never hurts
-    uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : (a.bandwidth <= 1024 ? 4u : 6u);
-    uint64_t entries = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE + 2 * a.bandwidth + 2;
+    // measured (gpurun_out/sweep4.txt, sweep5.txt, ab_b512.txt; +-5 % DVFS noise between repetitions): narrow windows
+    // 4 waves x 4 slices per block; wide windows (w > 1024), where the window itself caps the CU at two blocks,
+    // 8 waves x 3 slices (the window is re-staged nw * spw * 64 rows at a time); pipelining never hurts
+    const bool pipe = forced_pipe >= 0 ? forced_pipe != 0 : true;
+    const bool c16 = a.cols16 != nullptr && !c16_off;
+    uint32_t nw = (forced_nw == 4 || forced_nw == 8) ? (uint32_t)forced_nw : (a.bandwidth > 1024 ? 8u : 4u);
+    if (!pipe || !c16 || !variant_fits_nw8) nw = 4;                 // 8-wave blocks exist for the variants that fit 128 VGPRs only
+    uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : (a.bandwidth <= 1024 ? 4u : (nw == 8 ? 3u : 6u));
+    uint64_t entries = (uint64_t)nw * spw * SL_SLICE + 2 * a.bandwidth + 2;
     while (entries * 8 > SL_BAND_MAX_LDS && forced_spw <= 0 && spw > 1) {   // a shorter block may still fit
-        spw >>= 1;
-        entries = (uint64_t)SL_WAVES_PER_BLOCK * spw * SL_SLICE + 2 * a.bandwidth + 2;
+        spw = spw == 3 ? 2 : spw >> 1;
+        entries = (uint64_t)nw * spw * SL_SLICE + 2 * a.bandwidth + 2;
     }
     if (entries * 8 > SL_BAND_MAX_LDS) return out;
-    out.spw = spw; out.lds = (uint32_t)(entries * 8);
-    out.pipe = forced_pipe >= 0 ? forced_pipe != 0 : true;
-    out.c16 = a.cols16 != nullptr && !c16_off;
+    out.spw = spw; out.lds = (uint32_t)(entries * 8); out.nw = nw;
+    out.pipe = pipe;
+    out.c16 = c16;
     return out;
 }
 
-template <int ORDER, int EPI, int UWV, bool PIPE, bool C16>
-static sl_status launch_band(const sl_row_args &a, const band_geom &g, uint32_t grid, uint32_t nb8, hipStream_t s)
+template <int ORDER, int EPI, int UWV, bool PIPE, bool C16, int NW>
+static sl_status launch_band_nw(const sl_row_args &a, const band_geom &g, uint32_t grid, uint32_t nb8, hipStream_t s)
 {
-    auto kfn = sl_band_kernel<(UWV) ? 0 : ORDER, EPI, UWV, PIPE, C16>;
+    auto kfn = sl_band_kernel<(UWV) ? 0 : ORDER, EPI, UWV, PIPE, C16, NW>;
     static bool attr_done = false;
     if (!attr_done) {
         SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SL_BAND_MAX_LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(SL_BLOCK), g.lds, s, a, nb8, g.spw, (uint32_t)a.bandwidth);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), g.lds, s, a, nb8, g.spw, (uint32_t)a.bandwidth);
     return SL_OK;
+}
+template <int ORDER, int EPI, int UWV, bool PIPE, bool C16>
+static sl_status launch_band(const sl_row_args &a, const band_geom &g, uint32_t grid, uint32_t nb8, hipStream_t s)
+{
+    // 8-wave blocks must fit 128 VGPRs: the unrolled uniform-width variants with 16-bit offsets do; the batched ragged
+    // path and the push epilogue at width 16 would spill (kernel-resource-usage remarks), they stay at 4 waves
+    constexpr bool nw8_ok = PIPE && C16 && UWV != 0 && !(EPI == SL_EPI_PUSH && UWV == 16);
+    if constexpr (nw8_ok) { if (g.nw == 8) return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 8>(a, g, grid, nb8, s); }
+    if (g.nw != 4) return sl_fail(SL_DEVICE_ERROR, "band geometry asks for %u waves per block, variant built for 4", g.nw);
+    return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 4>(a, g, grid, nb8, s);
 }
 
 template <int ORDER, int EPI, int UWV>
@@ -695,9 +714,10 @@ template <int ORDER, int EPI>
 static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t *nparts)
 {
     sl_row_args a = a_in;
-    const band_geom g = band_geometry(a);
+    const bool uniform_unrolled = ORDER == 0 && (a.uniform_width == 16 || a.uniform_width == 8);
+    const band_geom g = band_geometry(a, uniform_unrolled && !(EPI == SL_EPI_PUSH && a.uniform_width == 16));
     if (g.spw) {
-        const uint64_t per_block = (uint64_t)SL_WAVES_PER_BLOCK * g.spw;
+        const uint64_t per_block = (uint64_t)g.nw * g.spw;
         const uint64_t nb = (a.n_slices + per_block - 1) / per_block;
         const uint32_t nb8 = (uint32_t)((nb + 7) / 8);
         const uint32_t grid = nb8 * 8;
