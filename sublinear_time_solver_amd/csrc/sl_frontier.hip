@@ -685,6 +685,7 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
     if (m->n_rows != m->n_cols || m->row_offset != 0) return sl_fail(SL_INVALID_INPUT, "Matrix must be square");
     if (!m->d_tptr || !m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "push needs a matrix created with SL_MATRIX_WITH_TRANSPOSE");
     const uint64_t n = m->n_rows;
+    if (n == 0) { res->converged = 1; return SL_OK; }             // nothing to push
     hipStream_t s = sl_context().stream;
     const hipMemcpyKind in_kind = o->mem == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     const hipMemcpyKind out_kind = o->mem == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

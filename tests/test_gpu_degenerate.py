@@ -1,0 +1,78 @@
+"""Degenerate sizes through every entry point of the path: 1 x 1 and 2 x 2 systems, an empty system, empty rows,
+one row far longer than the rest — the launch geometry (grids from counts, batches, speculative loops) must not
+depend on there being work."""
+import numpy as np
+import pytest
+
+import sublinear_time_solver_amd as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_by_one_and_two_by_two(gpu):
+    m = S.SparseMatrix.from_triplets([(0, 0, 4.0)], 1, 1, with_transpose=True)
+    r = S.NeumannSolver().solve(m, [2.0], S.SolverOptions(tolerance=1e-12))
+    assert r.converged and r.solution.tolist() == [0.5]
+    p = S.PushSolver(theta=1e-12).solve(m, [2.0])
+    assert p["converged"] and p["solution"].tolist() == [0.5] and p["rounds"] == 1
+    assert S.estimate_entry(m, [2.0], 0, theta=1e-12).estimate == 0.5
+    with S.QuerySession(m, [2.0]) as q:
+        assert q.estimate(0, theta=1e-12).estimate == 0.5 and q.estimate(0, theta=1e-12).estimate == 0.5
+    tr = [(0, 0, 4.0), (0, 1, 1.0), (1, 0, -1.0), (1, 1, 5.0)]
+    m2 = S.SparseMatrix.from_triplets(tr, 2, 2, with_transpose=True)
+    rp, ci, va = O.csr_from_triplets([t[0] for t in tr], [t[1] for t in tr], [t[2] for t in tr], 2, 2)
+    b = np.array([1.0, -3.0])
+    g = S.NeumannSolver().solve(m2, b, S.SolverOptions(tolerance=1e-13))
+    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-13)
+    assert g.iterations == o["iterations"] and (g.solution.view(np.uint64) == o["x"].view(np.uint64)).all()
+    x = np.linalg.solve(np.array([[4.0, 1.0], [-1.0, 5.0]]), b)
+    for row in (0, 1):
+        assert abs(S.estimate_entry(m2, b, row, theta=1e-14).estimate - x[row]) < 1e-12
+
+
+def test_zero_right_hand_side_and_zero_iterations(gpu):
+    m = S.SparseMatrix.from_triplets([(0, 0, 2.0), (1, 1, 2.0), (0, 1, 0.5)], 2, 2, with_transpose=True)
+    r = S.NeumannSolver().solve(m, [0.0, 0.0])                      # first term norm 0 < series tolerance: stops at once
+    assert r.converged and r.solution.tolist() == [0.0, 0.0] and r.iterations == 1
+    p = S.PushSolver(theta=1e-9).solve(m, [0.0, 0.0])
+    assert p["converged"] and p["rounds"] == 0 and p["pushes"] == 0
+    with pytest.raises(S.SolverError) as e:                          # max_iterations = 0: nothing runs, not converged
+        S.NeumannSolver().solve(m, [1.0, 1.0], S.SolverOptions(max_iterations=0))
+    assert e.value.status == 3
+
+
+def test_one_huge_row_among_tiny_ones(gpu):
+    n = 5000
+    tr, tc, tv = [], [], []
+    for i in range(n):
+        if i == 77:
+            cols = np.arange(n)
+            vals = np.where(cols == i, 3.0 * n, np.where(cols % 2 == 0, 1.0, -1.0))
+        else:
+            cols = np.array(sorted({i, (i * 7 + 1) % n}))
+            vals = np.where(cols == i, 4.0, 1.5)
+        tr += [i] * cols.size
+        tc += cols.tolist()
+        tv += vals.tolist()
+    rp, ci, va = O.csr_from_triplets(tr, tc, tv, n, n)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    b = np.cos(np.arange(n))
+    for order in (0, 1):
+        g = S.NeumannSolver(order=order).solve(m, b, S.SolverOptions(tolerance=1e-12))
+        o = O.neumann_solve(rp, ci, va, b, tolerance=1e-12, order=order)
+        assert g.iterations == o["iterations"] and (g.solution.view(np.uint64) == o["x"].view(np.uint64)).all()
+        p = S.PushSolver(theta=1e-10, dense_switch=2.0, order=order).solve(m, b)      # column 77... row 77 is hit by every column
+        q = O.push_sync_solve(rp, ci, va, b, theta=1e-10, order=order)
+        assert p["rounds"] == q["rounds"] and (p["solution"].view(np.uint64) == q["x"].view(np.uint64)).all()
+    e = S.estimate_entry(m, b, 77, theta=1e-13)                                       # A^T: column 77 of B is the hub
+    assert abs(e.estimate - g.solution[77]) < 1e-10
+
+
+def test_empty_system(gpu):
+    m = S.SparseMatrix.from_csr(np.zeros(1, dtype=np.uint32), np.zeros(0, dtype=np.uint32), np.zeros(0), 0, 0, with_transpose=True)
+    assert m.rows() == 0 and m.multiply_vector(np.zeros(0)).size == 0
+    r = S.NeumannSolver().solve(m, np.zeros(0))
+    assert r.solution.size == 0 and r.converged
+    p = S.PushSolver().solve(m, np.zeros(0))
+    assert p["solution"].size == 0 and p["converged"] and p["rounds"] == 0
