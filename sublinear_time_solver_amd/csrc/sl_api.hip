@@ -434,19 +434,12 @@ sl_status sl_neumann_run_steps(const sl_matrix *m, const double *dinv, double *t
 {
     if (!m || !dinv || !t_a || !t_b || !x) return sl_fail(SL_INVALID_INPUT, "null argument");
     hipStream_t s = sl_context().stream;
-    hipEvent_t e0, e1;
-    SL_HIP(hipEventCreate(&e0));
-    SL_HIP(hipEventCreate(&e1));
-    SL_HIP(hipEventRecord(e0, s));
+    sl_timer timer;
+    SL_TRY(timer.start(s));
     sl_status st = SL_OK;
     for (uint64_t k = 0; k < steps && st == SL_OK; ++k)
         st = sl_neumann_step(m, dinv, (k & 1) ? t_b : t_a, (k & 1) ? t_a : t_b, x, norm2, order);
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    const float ms = timer.stop();
     if (elapsed_ms) *elapsed_ms = ms;
     return st;
 }
@@ -541,10 +534,8 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
     struct planned { int kind; double *t_after; };      // kind 0: term k = 0, 1: fused step, 2: residual
     std::vector<planned> plan;
 
-    hipEvent_t e0, e1;
-    SL_HIP(hipEventCreate(&e0));
-    SL_HIP(hipEventCreate(&e1));
-    SL_HIP(hipEventRecord(e0, s));
+    sl_timer timer;
+    SL_TRY(timer.start(s));
     bool done = false;
     while (!done && !is_converged() && it < o->max_iterations) {
         // ---- enqueue iterations [it, it_end) as if no stop rule fired ----
@@ -626,12 +617,7 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
             break;
         }
     }
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
-    float loop_ms = 0.f;
-    hipEventElapsedTime(&loop_ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    const float loop_ms = timer.stop();
 
     if (status == SL_OK) {
         status = update_residual();                                                      // :516

@@ -106,9 +106,8 @@ sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *
     const double tol_sq = o->tolerance * o->tolerance;
     uint64_t it = 0, mv = 0;
     bool converged = false;
-    hipEvent_t e0, e1;
-    SL_HIP(hipEventCreate(&e0)); SL_HIP(hipEventCreate(&e1));
-    SL_HIP(hipEventRecord(e0, s));
+    sl_timer timer;
+    SL_TRY(timer.start(s));
     sl_status st = SL_OK;
     while (it < o->max_iterations) {
         if (rsold <= tol_sq) { converged = true; break; }                    // :221-224
@@ -135,11 +134,7 @@ sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *
         rsold = rsnew;
         ++it;
     }
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    const float ms = timer.stop();
     res->iterations = it; res->matvec_count = mv; res->residual_norm = std::sqrt(rsold); res->converged = converged ? 1 : 0;
     res->device_time_ms = ms;
     hipError_t ce = hipMemcpyAsync(x_out, x.p, n * 8, out_kind, s);

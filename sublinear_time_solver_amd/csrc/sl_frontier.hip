@@ -526,10 +526,8 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
 {
     hipStream_t s = sl_context().stream;
     const uint64_t n = ps.n;
-    hipEvent_t e0, e1;
-    SL_HIP(hipEventCreate(&e0));
-    SL_HIP(hipEventCreate(&e1));
-    SL_HIP(hipEventRecord(e0, s));
+    sl_timer timer;
+    SL_TRY(timer.start(s));
 
     int cur = 0;                 // delta[cur] holds the frontier values, delta[1-cur] is all zero
     // round 0 frontier from r (dense select), ascending list by compaction
@@ -620,11 +618,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
             if (h.rounds == 0 && h.stop == 0) return sl_fail(SL_DEVICE_ERROR, "sparse push batch made no progress");
         }
     }
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    const float ms = timer.stop();
     if (device_ms) *device_ms = ms;
     return st;
 }

@@ -85,6 +85,31 @@ void sl_ws_free(void *p);
                            __FILE__, __LINE__);                                                 \
     } while (0)
 
+// HIP-event stopwatch on a stream; the events are released on every exit path
+struct sl_timer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t stream = nullptr;
+    sl_timer() = default;
+    sl_timer(const sl_timer &) = delete;
+    sl_timer &operator=(const sl_timer &) = delete;
+    ~sl_timer() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+    sl_status start(hipStream_t s)
+    {
+        stream = s;
+        SL_HIP(hipEventCreate(&e0));
+        SL_HIP(hipEventCreate(&e1));
+        SL_HIP(hipEventRecord(e0, s));
+        return SL_OK;
+    }
+    float stop()                       // milliseconds since start(); waits for the stream to reach this point
+    {
+        float ms = 0.f;
+        if (!e0 || !e1) return ms;
+        if (hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
+        return ms;
+    }
+};
+
 struct DevBuf {
     void *p = nullptr;
     bool pooled = true;

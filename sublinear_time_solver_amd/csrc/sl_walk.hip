@@ -108,9 +108,8 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
     }
     SL_TRY(vbuf.alloc(num_samples * 8));
     double *d_vals = vbuf.as<double>();
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, s);
+    sl_timer timer;
+    SL_TRY(timer.start(s));
     hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((num_samples + 255) / 256)), dim3(256), 0, s, num_samples, seed, (uint32_t)row,
                        m->d_row_ptr, m->d_col_idx, m->d_values, db, d_vals);
     double *scr = static_cast<double *>(sl_scratch(4096 * sizeof(double)));
@@ -133,11 +132,7 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
         res->variance = num_samples > 1 ? h_var / (double)(num_samples - 1) : 0.0;
         res->num_samples = num_samples;
     }
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    const float ms = timer.stop();
     res->device_time_ms = ms;
     if (st == SL_OK && walk_values) {
         hipMemcpyAsync(walk_values, d_vals, num_samples * 8, where == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s);
