@@ -643,7 +643,7 @@ uint32_t sl_row_grid(uint64_t n_slices)
 // band-kernel geometry for half bandwidth w: slices per wave, dynamic LDS bytes, pipelining; spw = 0: not eligible
 #define SL_BAND_MAX_LDS (80u * 1024u)      // two blocks per CU (160 KiB LDS)
 struct band_geom { uint32_t spw, lds, nw; bool pipe, c16; };
-static band_geom band_geometry(const sl_row_args &a, bool variant_fits_nw8)
+static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool nw8_pays)
 {
     static int disabled = -1, forced_spw = 0, forced_pipe = -1, c16_off = 0, forced_nw = 0;
     if (disabled < 0) {
@@ -664,9 +664,9 @@ static band_geom band_geometry(const sl_row_args &a, bool variant_fits_nw8)
     // 4 waves x 4 slices per block; wide windows (w > 1024), where the window itself caps the CU at two blocks,
     // 8 waves x 3 slices (the window is re-staged nw * spw * 64 rows at a time); pipelining never hurts
     const bool pipe = forced_pipe >= 0 ? forced_pipe != 0 : true;
-    const bool c16 = a.cols16 != nullptr && !c16_off;
+    const bool c16 = a.cols16 != nullptr && !c16_off && offsets16_usable;
     uint32_t nw = (forced_nw == 4 || forced_nw == 8) ? (uint32_t)forced_nw : (a.bandwidth > 1024 ? 8u : 4u);
-    if (!pipe || !c16 || !variant_fits_nw8) nw = 4;                 // 8-wave blocks exist for the variants that fit 128 VGPRs only
+    if (!pipe || !c16 || !nw8_pays) nw = 4;                         // 8-wave blocks: pipelined 16-bit-offset variants that gain from them
     uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : (a.bandwidth <= 1024 ? 4u : (nw == 8 ? 3u : 6u));
     uint64_t entries = (uint64_t)nw * spw * SL_SLICE + 2 * a.bandwidth + 2;
     while (entries * 8 > SL_BAND_MAX_LDS && forced_spw <= 0 && spw > 1) {   // a shorter block may still fit
@@ -695,10 +695,8 @@ static sl_status launch_band_nw(const sl_row_args &a, const band_geom &g, uint32
 template <int ORDER, int EPI, int UWV, bool PIPE, bool C16>
 static sl_status launch_band(const sl_row_args &a, const band_geom &g, uint32_t grid, uint32_t nb8, hipStream_t s)
 {
-    // 8-wave blocks must fit 128 VGPRs: the unrolled uniform-width variants with 16-bit offsets do; the batched ragged
-    // path and the push epilogue at width 16 would spill (kernel-resource-usage remarks), they stay at 4 waves
-    constexpr bool nw8_ok = PIPE && C16 && UWV != 0 && !(EPI == SL_EPI_PUSH && UWV == 16);
-    if constexpr (nw8_ok) { if (g.nw == 8) return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 8>(a, g, grid, nb8, s); }
+    constexpr bool nw8_built = PIPE && C16 && ORDER == 0 && !(EPI == SL_EPI_PUSH && UWV != 8);   // = the cases band_geometry picks 8 for
+    if constexpr (nw8_built) { if (g.nw == 8) return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 8>(a, g, grid, nb8, s); }
     if (g.nw != 4) return sl_fail(SL_DEVICE_ERROR, "band geometry asks for %u waves per block, variant built for 4", g.nw);
     return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 4>(a, g, grid, nb8, s);
 }
@@ -715,7 +713,14 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
 {
     sl_row_args a = a_in;
     const bool uniform_unrolled = ORDER == 0 && (a.uniform_width == 16 || a.uniform_width == 8);
-    const band_geom g = band_geometry(a, uniform_unrolled && !(EPI == SL_EPI_PUSH && a.uniform_width == 16));
+    // a uniform-width matrix carries its 16-bit offsets in the OCTET layout of the unrolled path; when it runs through
+    // the batched path instead (simd4 order), that path — which reads the QUAD layout — uses the u32 columns
+    const bool uniform_octets = a.uniform_width == 8 || a.uniform_width == 16;
+    // 8-wave blocks (wide windows) are held to 128 VGPRs: the sequential-order variants gain (+5 % unrolled, 67 -> 80 %
+    // batched, spilling 60 B per lane or less); the 4-lane order and the push epilogue spill 100+ B and lose 5..10 %
+    // (measured, tools/push_dense_bench.py and bench.py --order 1) — they stay at 4 waves
+    const bool nw8_pays = ORDER == 0 && !(EPI == SL_EPI_PUSH && a.uniform_width != 8);
+    const band_geom g = band_geometry(a, uniform_unrolled || !uniform_octets, nw8_pays);
     if (g.spw) {
         const uint64_t per_block = (uint64_t)g.nw * g.spw;
         const uint64_t nb = (a.n_slices + per_block - 1) / per_block;
@@ -727,11 +732,7 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
         if (ORDER == 0 && a.uniform_width == 16) st = launch_band_u<ORDER, EPI, 16>(a, g, grid, nb8, s);
         else if (ORDER == 0 && a.uniform_width == 8) st = launch_band_u<ORDER, EPI, 8>(a, g, grid, nb8, s);
         else {
-            // the batched ragged path reads 16-bit offsets in the QUAD layout; a uniform-width matrix that ends up
-            // here (simd4 order) carries them in the octet layout of the unrolled path: use its u32 columns instead
-            band_geom gg = g;
-            if (a.uniform_width == 8 || a.uniform_width == 16) gg.c16 = false;
-            st = launch_band_u<ORDER, EPI, 0>(a, gg, grid, nb8, s);
+            st = launch_band_u<ORDER, EPI, 0>(a, g, grid, nb8, s);
         }
         if (st != SL_OK) return st;
     } else {
