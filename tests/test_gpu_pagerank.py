@@ -88,3 +88,38 @@ def test_band_kernel_variants_bitwise(gpu, n, k, w):
         q = O.push_sync_solve(rp, ci, va, bs, theta=1e-9, order=order, log_cap=4_000_000)
         assert p["rounds"] == q["rounds"] and (p["frontier_log"] == q["frontier_log"]).all()
         assert _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])
+
+
+def test_c4_full_size_pagerank_queries(gpu):
+    """BASELINE config 4 at its full size (n = 10^7, ~1.1e8 edges): single-entry queries on a session against the full
+    solve of the same system — size-independent properties: PageRank mass 1, every estimate inside its own error
+    bound |x_row - est| <= ||r_y||_1 * ||x||_inf, repeated queries bit-identical, local queries touch a small part of
+    the graph."""
+    import torch
+    n, alpha = 10_000_000, 0.85
+    lib = L.load()
+    rp, ci, va = _spr(n, seed=1, alpha=alpha)
+    M = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True, device=True)
+    del rp, ci, va
+    b = torch.full((n,), (1.0 - alpha) / n, dtype=torch.float64, device="cuda")
+    A = M.transpose(with_transpose=True)
+    o = L.PushOptions()
+    lib.sl_push_options_default(C.byref(o))
+    o.theta, o.max_rounds, o.mem = 1e-13 / n, 10000, L.SL_MEM_DEVICE
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    res = L.PushResult()
+    L.check(lib.sl_push_solve(A._h, b.data_ptr(), C.byref(o), x.data_ptr(), None, None, 0, None, C.byref(res)))
+    assert res.converged and abs(float(x.sum()) - 1.0) < 1e-9
+    xinf = float(x.abs().max())
+    del A
+    torch.cuda.empty_cache()
+    with S.QuerySession(M, b, matrix_is_transpose=True, device=True) as q:
+        for row in (n - 1, n // 2, 123_456, 0):
+            for theta in (1e-5, 1e-7):
+                e = q.estimate(row, theta=theta)
+                xv = float(x[row])
+                assert e.converged and abs(e.estimate - xv) <= e.residual_l1 * xinf + 1e-18, (row, theta)
+                e2 = q.estimate(row, theta=theta)
+                assert (e2.estimate, e2.residual_l1, e2.rounds, e2.pushes) == (e.estimate, e.residual_l1, e.rounds, e.pushes)
+        local = q.estimate(n - 1, theta=1e-5)
+        assert local.rows_touched < n // 50                       # a local query: < 2 % of the rows over all its rounds
