@@ -30,3 +30,27 @@ def gpu():
     if not _has_gpu():
         pytest.fail("no HIP device or libsublinear_hip.so missing: GPU tests have no fallback")
     return True
+
+
+@pytest.fixture
+def c_smoke_exe(tmp_path):
+    """tests/c/abi_smoke.c built as strict C99 against include/sublinear_hip.h and linked to the library"""
+    import subprocess
+    exe = tmp_path / "abi_smoke"
+    pkg = ROOT / "sublinear_time_solver_amd"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c" / "abi_smoke.c"),
+                        "-o", str(exe), f"-L{pkg}", "-lsublinear_hip", "-lm", f"-Wl,-rpath,{pkg}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.fixture
+def node_surface_script():
+    """bindings/node built (N-API addon, gcc); returns the path of the JavaScript surface test, or skips without node"""
+    import shutil
+    import subprocess
+    if not shutil.which("node") or not Path("/usr/include/node/node_api.h").exists():
+        pytest.skip("node / node_api.h not available")
+    r = subprocess.run(["make", "-C", str(ROOT / "bindings" / "node")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return ROOT / "tests" / "js" / "surface_test.js"

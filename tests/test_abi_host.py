@@ -135,3 +135,19 @@ def test_index_width_limits_are_enforced_before_any_device_work():
         assert st == 4 and b"u32" in lib.sl_last_error_message()
     st = lib.sl_matrix_create_csr(3, 3, 1, None, L.ptr(ci), L.ptr(va), L.SL_MEM_HOST, 0, 0, C.byref(h))
     assert st == 4
+
+
+def test_header_is_plain_c99_and_the_library_links_from_c(c_smoke_exe):
+    """include/sublinear_hip.h must be consumable by a C compiler (cgo / bindgen / ctypes generators): strict C99 build of
+    tests/c/abi_smoke.c; without a GPU the program checks the loud SL_DEVICE_ERROR"""
+    import subprocess
+    r = subprocess.run([str(c_smoke_exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_javascript_surface_host_logic(node_surface_script):
+    """bindings/node: the reference's shipped SublinearSolver surface in JavaScript over the N-API addon — config and
+    matrix validation, analyzeMatrix, error codes, and the loud DeviceError without a GPU (tests/js/surface_test.js)"""
+    import subprocess
+    r = subprocess.run(["node", str(node_surface_script)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "host logic ok" in r.stdout, r.stdout + r.stderr

@@ -59,3 +59,18 @@ def test_cli_reports_solver_errors(gpu, tmp_path):
     b.write_text("[1, 1]")
     r = _run("solve", "-m", str(a), "-b", str(b))
     assert r.returncode == 1 and "MatrixNotDiagonallyDominant" in r.stderr and "Warning: Matrix is not diagonally dominant" in r.stderr
+
+
+def test_c_program_solves_through_the_abi(gpu, c_smoke_exe):
+    """a C99 program (gcc, no HIP headers) drives create / solve / estimate_entry through include/sublinear_hip.h"""
+    import subprocess
+    r = subprocess.run([str(c_smoke_exe), "gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
+
+
+def test_javascript_surface_on_gpu(gpu, node_surface_script):
+    """the same surface solving on the GPU: solve (dense / coo / CLI-nested coo, all methods), estimateEntry (push and
+    seeded random walk), computePageRank vs power iteration (tests/js/surface_test.js gpu)"""
+    import subprocess
+    r = subprocess.run(["node", str(node_surface_script), "gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "gpu surface ok" in r.stdout, r.stdout + r.stderr
