@@ -62,3 +62,27 @@ def test_bench_two_ranks_reproduce_the_single_rank_iteration(gpu, w, extra, exch
     na, nb = a["config"]["last_term_norm"], b["config"]["last_term_norm"]
     assert na > 0 and abs(na - nb) <= 1e-12 * na
     assert abs(b["value"] - 300000 * 16 * 7 / (b["ms_per_step"] * 7e-3)) <= 1e-6 * b["value"]     # whole-job units / max-over-ranks time
+
+
+def test_partitioned_solve_script_two_ranks_equals_one(gpu):
+    """tools/solve_partitioned.py (BASELINE config 5 as a full solve): two ranks sharing the GPU run the same iterations to the
+    same residual and solution sums as one rank owning all rows"""
+    import os
+    import socket
+
+    def run(ranks, rows):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "tools/solve_partitioned.py", "--rows", str(rows), "--bandwidth", "700", "--tolerance", "1e-9"]
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, SL_BENCH_BACKEND="gloo"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    one, two = run(1, 200_000), run(2, 100_000)
+    assert one["converged"] and two["converged"] and two["n_gpus"] == 2
+    assert (one["iterations"], one["terms"]) == (two["iterations"], two["terms"])
+    for key in ("residual_norm", "sum_x", "sum_x2", "last_term_norm"):
+        assert abs(one[key] - two[key]) <= 1e-11 * max(1.0, abs(one[key])), key
