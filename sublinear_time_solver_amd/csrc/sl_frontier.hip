@@ -623,8 +623,10 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     return st;
 }
 
-sl_status alloc_state(push_state &ps, uint64_t n, uint64_t nnz, DevBuf bufs[20])
+// owned: plain allocations that may be released by another thread (long-lived sessions); otherwise the calling thread's pool
+sl_status alloc_state(push_state &ps, uint64_t n, uint64_t nnz, DevBuf bufs[20], bool owned = false)
 {
+    auto get = [owned](DevBuf &b, size_t bytes) { return owned ? b.alloc_owned(bytes) : b.alloc(bytes); };
     ps.n = n;
     ps.op_nnz = nnz;
     ps.rec_cap = std::min<uint64_t>(nnz, std::max<uint64_t>(2 * n + nnz / 16, 1u << 22));   // 16 B per record; small systems: every entry
@@ -632,23 +634,23 @@ sl_status alloc_state(push_state &ps, uint64_t n, uint64_t nnz, DevBuf bufs[20])
     if (ps.nblocks == 0) ps.nblocks = 1;
     hipStream_t s = sl_context().stream;
     size_t k = 0;
-    SL_TRY(bufs[k].alloc(n * 8)); ps.x = bufs[k++].as<double>();
-    SL_TRY(bufs[k].alloc(n * 8)); ps.r = bufs[k++].as<double>();
-    SL_TRY(bufs[k].alloc(n * 8)); ps.dinv = bufs[k++].as<double>();
-    SL_TRY(bufs[k].alloc(n * 8)); ps.delta[0] = bufs[k++].as<double>();
-    SL_TRY(bufs[k].alloc(n * 8)); ps.delta[1] = bufs[k++].as<double>();
-    SL_TRY(bufs[k].alloc(n * 4)); ps.frontier[0] = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc(n * 4)); ps.frontier[1] = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc(n * 4)); ps.cand = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc(n * 4)); ps.heavy = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc(n * 4)); ps.head = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc(n * 4)); ps.cand_flag = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc(n * 4)); ps.long_list = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc((ps.rec_cap + 256) * sizeof(sl_hit))); ps.recs = bufs[k++].as<sl_hit>();
-    SL_TRY(bufs[k].alloc(64)); ps.counters = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc(sizeof(sl_push_ctl))); ps.ctl = bufs[k++].as<sl_push_ctl>();
-    SL_TRY(bufs[k].alloc((size_t)ps.nblocks * 4)); ps.block_count = bufs[k++].as<uint32_t>();
-    SL_TRY(bufs[k].alloc((size_t)ps.nblocks * 4)); ps.block_off = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], n * 8)); ps.x = bufs[k++].as<double>();
+    SL_TRY(get(bufs[k], n * 8)); ps.r = bufs[k++].as<double>();
+    SL_TRY(get(bufs[k], n * 8)); ps.dinv = bufs[k++].as<double>();
+    SL_TRY(get(bufs[k], n * 8)); ps.delta[0] = bufs[k++].as<double>();
+    SL_TRY(get(bufs[k], n * 8)); ps.delta[1] = bufs[k++].as<double>();
+    SL_TRY(get(bufs[k], n * 4)); ps.frontier[0] = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], n * 4)); ps.frontier[1] = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], n * 4)); ps.cand = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], n * 4)); ps.heavy = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], n * 4)); ps.head = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], n * 4)); ps.cand_flag = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], n * 4)); ps.long_list = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], (ps.rec_cap + 256) * sizeof(sl_hit))); ps.recs = bufs[k++].as<sl_hit>();
+    SL_TRY(get(bufs[k], 64)); ps.counters = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], sizeof(sl_push_ctl))); ps.ctl = bufs[k++].as<sl_push_ctl>();
+    SL_TRY(get(bufs[k], (size_t)ps.nblocks * 4)); ps.block_count = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], (size_t)ps.nblocks * 4)); ps.block_off = bufs[k++].as<uint32_t>();
     SL_HIP(hipMemsetAsync(ps.ctl, 0, sizeof(sl_push_ctl), s));
     SL_HIP(hipMemsetAsync(ps.cand_flag, 0, n * 4, s));
     SL_HIP(hipMemsetAsync(ps.head, 0xff, n * 4, s));                    // SL_EMPTY
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(256) void sl_touched_cleanup_kernel(uint32_t nt, co
 
 extern "C" {
 
-sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, const double *b, sl_mem where, sl_query_session **out)
+static sl_status session_create(const sl_matrix *m, int matrix_is_transpose, const double *b, sl_mem where, bool owned, sl_query_session **out)
 {
     if (!out) return sl_fail(SL_INVALID_INPUT, "out is null");
     *out = nullptr;
@@ -818,9 +820,10 @@ sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, c
     if (!q) return sl_fail(SL_ALLOCATION, "out of host memory");
     q->m = m; q->n = n; q->given_is_transpose = matrix_is_transpose != 0;
     q->dense_switch = q->given_is_transpose ? 1.0 / 16.0 : 0.25;
-    sl_status st = alloc_state(q->ps, n, m->nnz, q->bufs);
-    if (st == SL_OK) st = q->touched.alloc((n ? n : 1) * 4);
-    if (st == SL_OK) st = q->sums.alloc((2 * ((n + 1023) / 1024) + 8) * sizeof(double));
+    auto get = [owned](DevBuf &buf, size_t bytes) { return owned ? buf.alloc_owned(bytes) : buf.alloc(bytes); };
+    sl_status st = alloc_state(q->ps, n, m->nnz, q->bufs, owned);
+    if (st == SL_OK) st = get(q->touched, (n ? n : 1) * 4);
+    if (st == SL_OK) st = get(q->sums, (2 * ((n + 1023) / 1024) + 8) * sizeof(double));
     unsigned long long hs[4] = {0, 0, 0, 0};
     if (st == SL_OK) {
         q->ps.touched = q->touched.as<uint32_t>();
@@ -831,7 +834,7 @@ sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, c
         } else {
             // operator B = A^T: rows of B = columns of A (sorted transpose), columns of B = rows of A
             // the column entries of B are A's CSR entries k; their place in B's row arrays is the inverse of the transpose permutation
-            st = q->tinv.alloc((m->nnz ? m->nnz : 1) * 4);
+            st = get(q->tinv, (m->nnz ? m->nnz : 1) * 4);
             if (st == SL_OK && m->nnz)
                 hipLaunchKernelGGL(sl_invert_perm_kernel, dim3((uint32_t)std::min<uint64_t>((m->nnz + 255) / 256, 65535)), dim3(256), 0, s, m->nnz, m->d_tent,
                                    q->tinv.as<uint32_t>());
@@ -849,7 +852,7 @@ sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, c
         if (e == hipSuccess) e = hipMemsetAsync(q->ps.delta[1], 0, n * 8, s);
         if (e == hipSuccess) e = hipMemcpyAsync(q->h_dinv.data(), q->ps.dinv, n * 8, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && where == SL_MEM_HOST) {
-            st = q->bbuf.alloc(n * 8);
+            st = get(q->bbuf, n * 8);
             if (st == SL_OK) { e = hipMemcpyAsync(q->bbuf.p, b, n * 8, hipMemcpyHostToDevice, s); q->db = q->bbuf.as<double>(); }
         } else {
             q->db = b;                     // device vector owned by the caller; must outlive the session
@@ -860,6 +863,12 @@ sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, c
     if (st != SL_OK) { delete q; return st; }
     *out = q;
     return SL_OK;
+}
+
+// a session may be handed to and released by another thread: its buffers are plain allocations, not pool blocks
+sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, const double *b, sl_mem where, sl_query_session **out)
+{
+    return session_create(m, matrix_is_transpose, b, where, true, out);
 }
 
 void sl_query_session_destroy(sl_query_session *q) { delete q; }
@@ -935,7 +944,7 @@ static sl_status estimate_entry_impl(const sl_matrix *m, const double *b, sl_mem
     if (m->n_rows != m->n_cols || m->row_offset != 0) return sl_fail(SL_INVALID_INPUT, "Matrix must be square");
     if (row >= m->n_rows) return sl_fail(SL_INVALID_INPUT, "Row index %llu out of bounds. Matrix has %llu rows", (unsigned long long)row, (unsigned long long)m->n_rows);
     sl_query_session *q = nullptr;
-    SL_TRY(sl_query_session_create(m, given_is_transpose ? 1 : 0, b, where, &q));
+    SL_TRY(session_create(m, given_is_transpose ? 1 : 0, b, where, false, &q));   // lives for this call: pool blocks
     const sl_status st = sl_query_session_estimate(q, row, theta, max_rounds, res);
     sl_query_session_destroy(q);
     return st;
