@@ -178,8 +178,7 @@ def main():
         pieces_i = [(lo_l, hi_l, build_piece(lo_l, hi_l)) for lo_l, hi_l in inter if hi_l > lo_l]
         handles = [hh for _, _, hh in pieces_b + pieces_i]
         h = pieces_i[0][2]
-        local_step = D.SplitStep([(lo_l, hi_l, D.hip_local_step(hh, dinv[lo_l:hi_l], args.order)) for lo_l, hi_l, hh in pieces_b],
-                                 [(lo_l, hi_l, D.hip_local_step(hh, dinv[lo_l:hi_l], args.order)) for lo_l, hi_l, hh in pieces_i], dev)
+        local_step = D.HipSplitStep(pieces_b, pieces_i, dinv, args.order)
     else:
         h = build_piece(0, n_local)
         handles = [h]

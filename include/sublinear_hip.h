@@ -150,6 +150,15 @@ sl_status sl_neumann_step(const sl_matrix *m, const double *dinv, const double *
  * reference's scaled one).  x_full has n_cols entries, rhs / r_out n_rows; r_out may be NULL. */
 sl_status sl_residual_norm2(const sl_matrix *m, const double *x_full, const double *rhs, double *r_out, double *norm2,
                             sl_order order);
+/* The fused step for callers that cut one rank's rows into several matrices (multi-GPU: the rows within w of a slice
+ * boundary first, so that their halo travels while the interior rows compute).  Each piece leaves its per-block partial
+ * sums of ||t_out||^2 in `partials` (device; capacity from sl_matrix_partials_capacity) and reports how many it wrote;
+ * one fixed-order sl_reduce_partials over the concatenated pieces closes the step. */
+sl_status sl_matrix_partials_capacity(const sl_matrix *m, uint64_t *count);
+sl_status sl_neumann_step_partials(const sl_matrix *m, const double *dinv, const double *t_in, double *t_out, double *x,
+                                   double *partials, uint32_t *n_partials, sl_order order);
+sl_status sl_reduce_partials(const double *partials, uint32_t n, double *norm2);
+
 /* same launch sequence repeated `steps` times with ping-pong buffers t_a -> t_b -> t_a ...
  * bracketed by HIP events on the launch stream; *elapsed_ms is the device time.
  * After the call the newest term is in t_a when `steps` is even, t_b when odd. */

@@ -96,6 +96,9 @@ SIGNATURES = {
     "sl_axpy": (C.c_int, [u64, f64, vp, vp, C.c_int]),
     "sl_l2_norm": (C.c_int, [u64, vp, C.POINTER(f64), C.c_int]),
     "sl_neumann_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int]),
+    "sl_matrix_partials_capacity": (C.c_int, [vp, C.POINTER(u64)]),
+    "sl_neumann_step_partials": (C.c_int, [vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint32), C.c_int]),
+    "sl_reduce_partials": (C.c_int, [vp, C.c_uint32, vp]),
     "sl_residual_norm2": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
     "sl_neumann_run_steps": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, u64, C.POINTER(C.c_float)]),
     "sl_neumann_options_default": (None, [C.POINTER(NeumannOptions)]),

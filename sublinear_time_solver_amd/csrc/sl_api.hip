@@ -419,6 +419,29 @@ sl_status sl_neumann_step(const sl_matrix *m, const double *dinv, const double *
     return sl_launch_rows(a, order, SL_EPI_NEUMANN, sl_context().stream);
 }
 
+// the same step for callers that cut one rank's rows into several matrices (boundary rows first, so that their halo
+// can travel while the interior computes): every piece leaves its per-block partial sums in the caller's buffer, one
+// fixed-order reduction over all of them closes the step — 3 + 1 launches instead of 3 x 2 plus glue
+sl_status sl_matrix_partials_capacity(const sl_matrix *m, uint64_t *count)
+{
+    if (!m || !count) return sl_fail(SL_INVALID_INPUT, "null argument");
+    *count = (uint64_t)sl_row_grid(m->n_slices) + m->n_long;
+    return SL_OK;
+}
+sl_status sl_neumann_step_partials(const sl_matrix *m, const double *dinv, const double *t_in, double *t_out, double *x,
+                                   double *partials, uint32_t *n_partials, sl_order order)
+{
+    if (!m || !dinv || !t_in || !t_out || !x || !partials || !n_partials) return sl_fail(SL_INVALID_INPUT, "null argument");
+    sl_row_args a = row_args(m);
+    a.gather = t_in; a.dinv = dinv; a.out = t_out; a.x = x; a.partials = partials; a.result = nullptr;
+    return sl_launch_rows(a, order, SL_EPI_NEUMANN, sl_context().stream, n_partials);
+}
+sl_status sl_reduce_partials(const double *partials, uint32_t n, double *norm2)
+{
+    if (!partials || !norm2) return sl_fail(SL_INVALID_INPUT, "null argument");
+    return sl_launch_final_reduce(partials, n, norm2, sl_context().stream);
+}
+
 sl_status sl_residual_norm2(const sl_matrix *m, const double *x_full, const double *rhs, double *r_out, double *norm2, sl_order order)
 {
     if (!m || !x_full || !rhs || !norm2) return sl_fail(SL_INVALID_INPUT, "null argument");

@@ -184,7 +184,8 @@ struct sl_row_args {
     int ctl_mode;         // SL_JUDGE_*: which comparison of the reduced sum against ctl_threshold closes the gate
     double ctl_threshold;
 };
-sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s);
+sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s, uint32_t *n_partials = nullptr);
+sl_status sl_launch_final_reduce(const double *partials, uint32_t n, double *result, hipStream_t s);
 sl_row_args sl_matrix_row_args(const sl_matrix *m);   // matrix part filled, vectors null
 uint32_t sl_row_grid(uint64_t n_slices);
 

@@ -752,8 +752,9 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
     return SL_OK;
 }
 
-sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s)
+sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s, uint32_t *n_partials)
 {
+    if (n_partials) *n_partials = 0;
     if (a.n_slices == 0) {
         if (epi != SL_EPI_SPMV && a.ctl)
             hipLaunchKernelGGL(sl_judge_reduce_kernel, dim3(1), dim3(1024), 0, s, a.partials, 0u, a.result, a.ctl, a.gate_it,
@@ -771,6 +772,7 @@ sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, 
     case SL_EPI_PUSH: st = simd4 ? launch_rows_t<1, SL_EPI_PUSH>(a, s, &nparts) : launch_rows_t<0, SL_EPI_PUSH>(a, s, &nparts); break;
     }
     if (st != SL_OK) return st;
+    if (n_partials) *n_partials = nparts;
     if (epi != SL_EPI_SPMV && a.ctl) {
         hipLaunchKernelGGL(sl_judge_reduce_kernel, dim3(1), dim3(1024), 0, s, a.partials, nparts, a.result, a.ctl, a.gate_it,
                            a.ctl_slot, a.ctl_mode, a.ctl_threshold);
@@ -780,6 +782,13 @@ sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, 
                            epi == SL_EPI_PUSH ? 2 : 1);
         SL_HIP(hipGetLastError());
     }
+    return SL_OK;
+}
+
+sl_status sl_launch_final_reduce(const double *partials, uint32_t n, double *result, hipStream_t s)
+{
+    hipLaunchKernelGGL(sl_final_reduce_kernel, dim3(1), dim3(1024), 0, s, partials, n, result, 1);
+    SL_HIP(hipGetLastError());
     return SL_OK;
 }
 

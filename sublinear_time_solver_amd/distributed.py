@@ -172,6 +172,70 @@ class SplitStep:
         torch.sum(self.parts[:, 0], dim=0, out=norm2_out[0])          # fixed order: pieces in list order
 
 
+class HipSplitStep:
+    """SplitStep on libsublinear_hip: every piece is its own row-slice matrix; the pieces leave their per-block partial sums
+    side by side in one device buffer (sl_neumann_step_partials) and ONE fixed-order reduction closes the step
+    (sl_reduce_partials) — boundary pieces, interior piece, one reduce: four launches per step, no glue kernels."""
+
+    def __init__(self, boundary: Sequence[Tuple[int, int, int]], interior: Sequence[Tuple[int, int, int]], dinv_local: torch.Tensor, order: int = 0):
+        """pieces: (lo, hi, matrix handle) in local row coordinates"""
+        import ctypes as C
+
+        from . import _lib as L
+        self._L, self._lib, self._C = L, L.load(), C
+        self.boundary = [(lo, hi, h) for lo, hi, h in boundary if hi > lo]
+        self.interior = [(lo, hi, h) for lo, hi, h in interior if hi > lo]
+        self.dinv, self.order = dinv_local, order
+        cap = 0
+        for _, _, h in self.boundary + self.interior:
+            c = L.u64(0)
+            L.check(self._lib.sl_matrix_partials_capacity(h, C.byref(c)))
+            cap += int(c.value)
+        self.partials = torch.zeros(max(cap, 1), dtype=torch.float64, device=dinv_local.device)
+        self._used = 0
+        self.concurrent = True                       # boundary pieces on a side stream (run_overlapped)
+
+    def _run(self, pieces, t_in, t_out_local, x_local):
+        L, C = self._L, self._C
+        d0, t0, o0, x0, p0 = self.dinv.data_ptr(), t_in.data_ptr(), t_out_local.data_ptr(), x_local.data_ptr(), self.partials.data_ptr()
+        for lo, hi, h in pieces:                     # raw addresses: no tensor views on the per-step path
+            got = C.c_uint32(0)
+            L.check(self._lib.sl_neumann_step_partials(h, d0 + 8 * lo, t0, o0 + 8 * lo, x0 + 8 * lo, p0 + 8 * self._used, C.byref(got), self.order))
+            self._used += got.value
+
+    def _use_stream(self, stream):
+        self._L.check(self._lib.sl_set_stream(self._C.c_void_p(stream.cuda_stream)))
+
+    def run_boundary(self, t_in, t_out_local, x_local):
+        self._used = 0
+        self._run(self.boundary, t_in, t_out_local, x_local)
+
+    def run_interior(self, t_in, t_out_local, x_local, norm2_out):
+        self._run(self.interior, t_in, t_out_local, x_local)
+        self._L.check(self._lib.sl_reduce_partials(self.partials.data_ptr(), self._used, norm2_out.data_ptr()))
+
+    def run_overlapped(self, t_in, t_out, t_out_local, x_local, norm2_out, exchange):
+        """One step with the boundary pieces on a side stream: they run CONCURRENTLY with the interior piece (both only
+        read t_in), the halo transfer is enqueued behind them, and the main stream joins both before the reduction.
+        Critical path of a step = the interior kernel; the small launches and the transfer hide under it."""
+        main = torch.cuda.current_stream(self.dinv.device)
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=self.dinv.device, priority=-1)
+        side = self.side
+        side.wait_stream(main)                       # t_in complete: the previous step's interior rows and halo are in place
+        with torch.cuda.stream(side):
+            self._use_stream(side)
+            self.run_boundary(t_in, t_out_local, x_local)
+            handle = exchange.start(t_out)           # rides behind the boundary kernels
+        self._use_stream(main)
+        self._run(self.interior, t_in, t_out_local, x_local)
+        main.wait_stream(side)                       # boundary partial sums are final
+        self._L.check(self._lib.sl_reduce_partials(self.partials.data_ptr(), self._used, norm2_out.data_ptr()))
+        exchange.finish(handle)                      # main stream waits for the halo to land
+
+    side = None
+
+
 class PartitionedNeumann:
     """Ping-pong driver of the partitioned iteration: local fused step -> exchange -> norm all-reduce.
 
@@ -204,7 +268,10 @@ class PartitionedNeumann:
             self._pending[slot] = None
         t_in, t_out = self.t[self.cur], self.t[1 - self.cur]
         t_out_local = t_out[p.lo:p.hi]
-        if isinstance(self.local_step, SplitStep):
+        if isinstance(self.local_step, HipSplitStep) and t_in.is_cuda and getattr(self.exchange, "needs_only_boundary", False) \
+                and self.local_step.concurrent:
+            self.local_step.run_overlapped(t_in, t_out, t_out_local, self.x, self._norm[slot], self.exchange)
+        elif isinstance(self.local_step, (SplitStep, HipSplitStep)):
             self.local_step.run_boundary(t_in, t_out_local, self.x)
             early = getattr(self.exchange, "needs_only_boundary", False)
             handle = self.exchange.start(t_out) if early else None   # boundary rows are final: ship them while the interior computes
