@@ -10,9 +10,9 @@ all-reduce of the squared term norm:
   * Halo          banded structure (|i - j| <= w): only the w entries either side of a slice
                   boundary are exchanged, point to point with the two neighbours.
 
-Overlap (banded case): the rows within w of a slice boundary are computed FIRST by two small launches;
-their halo transfer then runs on RCCL's stream while the interior launch (all other rows) computes;
-the step only waits for the transfer at its end.  The norm all-reduce of a step is asynchronous too
+Overlap (banded case): the rows within w of a slice boundary are two small matrices of their own, launched on a
+side stream concurrently with the interior launch (all other rows); their halo transfer is enqueued behind them
+on RCCL's stream; the step only waits for the transfer at its end.  The norm all-reduce of a step is asynchronous too
 and overlaps the next step.
 
 Precedent for the partition itself: simd_ops::parallel_matrix_vector_multiply row chunks
@@ -20,7 +20,7 @@ Precedent for the partition itself: simd_ops::parallel_matrix_vector_multiply ro
 partitioned iteration reproduces the single-GPU one bit for bit.
 
 The local step is a callable so that the CPU tests can drive the same host logic with a stand-in;
-the product wiring (`hip_local_step`, `hip_split_step`) calls sl_neumann_step on device memory.
+the product wiring (`hip_local_step`, `hip_local_ops`, `HipSplitStep`) calls libsublinear_hip on device memory.
 """
 from __future__ import annotations
 
