@@ -92,7 +92,7 @@ struct sl_timer {
     sl_timer() = default;
     sl_timer(const sl_timer &) = delete;
     sl_timer &operator=(const sl_timer &) = delete;
-    ~sl_timer() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); }
+    ~sl_timer() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
     sl_status start(hipStream_t s)
     {
         stream = s;
@@ -105,7 +105,7 @@ struct sl_timer {
     {
         float ms = 0.f;
         if (!e0 || !e1) return ms;
-        if (hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
+        if (hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
         return ms;
     }
 };
@@ -117,7 +117,7 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { reset(); }
-    void reset() { if (p) { if (pooled) sl_ws_free(p); else hipFree(p); p = nullptr; } }
+    void reset() { if (p) { if (pooled) sl_ws_free(p); else (void)hipFree(p); p = nullptr; } }
     sl_status alloc(size_t bytes)
     {
         reset();

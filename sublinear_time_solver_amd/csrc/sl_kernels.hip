@@ -307,15 +307,20 @@ __device__ __forceinline__ void sl_slice_finish(const sl_row_args &a, uint64_t s
 // pointers, quad counts) is wave-uniform.  C16: columns come as 16-bit offsets col - row, layout
 // [quad][lane][4] (8 B per lane per quad).
 struct sl_batch { uint64_t s; uint32_t q, nq, kbase; bool first, last, valid; };
+#ifndef SL_BATCH_QUADS_NW8
+#define SL_BATCH_QUADS_NW8 3      /* measured: 3 quads per batch beat 2 and 4 (4 spills at 128 VGPRs), gpurun 2026-09 A/B in DESIGN.md §5 */
+#endif
+template <int BQ>
 struct sl_batch_regs {
-    u32x4 c[4];
-    f64x2 va[4], vb[4];
+    u32x4 c[BQ];
+    f64x2 va[BQ], vb[BQ];
     double e_d, e_x, e_aux;
     uint32_t len;
 };
 struct sl_batch_cursor { uint64_t s0, s; uint32_t j, spw, q, q0, q1; bool in_slice; uint32_t lane_q0, lane_q1, nw; };   // lane_q*: slice pointers of slice j held by lane j
 struct sl_row_state { double sum, l0, l1, l2, l3, e_d, e_x, e_aux; uint32_t len, chunks; bool merged, live; };
 
+template <int BQ>
 __device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch_cursor &c)
 {
     sl_batch b{0, 0, 0, 0, false, false, false};
@@ -329,7 +334,7 @@ __device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch
         c.in_slice = true;
     }
     uint32_t nq = c.q1 - c.q;
-    nq = nq > 4u ? 4u : nq;
+    nq = nq > (uint32_t)BQ ? (uint32_t)BQ : nq;
     b.s = c.s; b.q = c.q; b.nq = nq; b.kbase = (c.q - c.q0) * 4u;
     b.first = c.q == c.q0; b.last = c.q + nq == c.q1; b.valid = true;
     c.q += nq;
@@ -337,12 +342,12 @@ __device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch
     return b;
 }
 
-template <int EPI, bool C16>
-__device__ __forceinline__ void sl_batch_load(const sl_row_args &a, const sl_batch &b, uint32_t lane, sl_batch_regs &r)
+template <int EPI, bool C16, int BQ>
+__device__ __forceinline__ void sl_batch_load(const sl_row_args &a, const sl_batch &b, uint32_t lane, sl_batch_regs<BQ> &r)
 {
     const f64x2 *__restrict__ vq = reinterpret_cast<const f64x2 *>(a.vals);
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
+    for (int qq = 0; qq < BQ; ++qq) {
         if ((uint32_t)qq < b.nq) {
             const uint64_t q = (uint64_t)b.q + qq;
             if constexpr (C16) {
@@ -367,8 +372,8 @@ __device__ __forceinline__ void sl_batch_load(const sl_row_args &a, const sl_bat
     }
 }
 
-template <int ORDER, int EPI, bool C16>
-__device__ __forceinline__ void sl_batch_finish(const sl_row_args &a, const sl_batch &b, uint32_t lane, const sl_batch_regs &r,
+template <int ORDER, int EPI, bool C16, int BQ>
+__device__ __forceinline__ void sl_batch_finish(const sl_row_args &a, const sl_batch &b, uint32_t lane, const sl_batch_regs<BQ> &r,
                                                 sl_row_state &st, const double *lw, uint32_t base, double &part0, double &part1)
 {
     const uint64_t i = b.s * SL_SLICE + lane;
@@ -381,7 +386,7 @@ __device__ __forceinline__ void sl_batch_finish(const sl_row_args &a, const sl_b
         st.e_d = r.e_d; st.e_x = r.e_x; st.e_aux = r.e_aux;
     }
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
+    for (int qq = 0; qq < BQ; ++qq) {
         if ((uint32_t)qq < b.nq) {
             uint32_t i0, i1, i2, i3;
             if constexpr (C16) {
@@ -484,18 +489,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void sl_band_kernel(sl_ro
             }
         } else if constexpr (PIPE) {
             sl_batch_cursor cur{s0, 0, 0, spw, 0, 0, 0, false, pre_q0, pre_q1, (uint32_t)NW};
-            sl_batch_regs ga, gb;
+            constexpr int BQ = (NW == 8) ? (ORDER == 1 ? 2 : SL_BATCH_QUADS_NW8) : 4;   // 8-wave blocks live in 128 VGPRs: shorter batches, no spills
+            sl_batch_regs<BQ> ga, gb;
             sl_row_state st{};
-            sl_batch ba = sl_next_batch(a, cur);
-            if (ba.valid) sl_batch_load<EPI, C16>(a, ba, lane, ga);
+            sl_batch ba = sl_next_batch<BQ>(a, cur);
+            if (ba.valid) sl_batch_load<EPI, C16, BQ>(a, ba, lane, ga);
             while (ba.valid) {
-                const sl_batch bb = sl_next_batch(a, cur);
-                if (bb.valid) sl_batch_load<EPI, C16>(a, bb, lane, gb);
-                sl_batch_finish<ORDER, EPI, C16>(a, ba, lane, ga, st, lw, base, part0, part1);
+                const sl_batch bb = sl_next_batch<BQ>(a, cur);
+                if (bb.valid) sl_batch_load<EPI, C16, BQ>(a, bb, lane, gb);
+                sl_batch_finish<ORDER, EPI, C16, BQ>(a, ba, lane, ga, st, lw, base, part0, part1);
                 if (!bb.valid) break;
-                ba = sl_next_batch(a, cur);
-                if (ba.valid) sl_batch_load<EPI, C16>(a, ba, lane, ga);
-                sl_batch_finish<ORDER, EPI, C16>(a, bb, lane, gb, st, lw, base, part0, part1);
+                ba = sl_next_batch<BQ>(a, cur);
+                if (ba.valid) sl_batch_load<EPI, C16, BQ>(a, ba, lane, ga);
+                sl_batch_finish<ORDER, EPI, C16, BQ>(a, bb, lane, gb, st, lw, base, part0, part1);
             }
         } else {
             for (uint32_t j = 0; j < spw; ++j) {
@@ -695,7 +701,7 @@ static sl_status launch_band_nw(const sl_row_args &a, const band_geom &g, uint32
 template <int ORDER, int EPI, int UWV, bool PIPE, bool C16>
 static sl_status launch_band(const sl_row_args &a, const band_geom &g, uint32_t grid, uint32_t nb8, hipStream_t s)
 {
-    constexpr bool nw8_built = PIPE && C16 && ORDER == 0 && !(EPI == SL_EPI_PUSH && UWV != 8);   // = the cases band_geometry picks 8 for
+    constexpr bool nw8_built = PIPE && C16 && !(EPI == SL_EPI_PUSH && UWV == 16);   // = the cases band_geometry picks 8 for
     if constexpr (nw8_built) { if (g.nw == 8) return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 8>(a, g, grid, nb8, s); }
     if (g.nw != 4) return sl_fail(SL_DEVICE_ERROR, "band geometry asks for %u waves per block, variant built for 4", g.nw);
     return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 4>(a, g, grid, nb8, s);
@@ -716,10 +722,10 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
     // a uniform-width matrix carries its 16-bit offsets in the OCTET layout of the unrolled path; when it runs through
     // the batched path instead (simd4 order), that path — which reads the QUAD layout — uses the u32 columns
     const bool uniform_octets = a.uniform_width == 8 || a.uniform_width == 16;
-    // 8-wave blocks (wide windows) are held to 128 VGPRs: the sequential-order variants gain (+5 % unrolled, 67 -> 80 %
-    // batched, spilling 60 B per lane or less); the 4-lane order and the push epilogue spill 100+ B and lose 5..10 %
-    // (measured, tools/push_dense_bench.py and bench.py --order 1) — they stay at 4 waves
-    const bool nw8_pays = ORDER == 0 && !(EPI == SL_EPI_PUSH && a.uniform_width != 8);
+    // 8-wave blocks (wide windows) are held to 128 VGPRs.  The unrolled uniform-width variants fit (except the push
+    // epilogue at width 16, which would spill ~100 B per lane and lose 10 %: it stays at 4 waves); the batched path fits
+    // with 3 quads per batch (2 in the 4-lane order) instead of 4
+    const bool nw8_pays = !(EPI == SL_EPI_PUSH && uniform_unrolled && a.uniform_width == 16);
     const band_geom g = band_geometry(a, uniform_unrolled || !uniform_octets, nw8_pays);
     if (g.spw) {
         const uint64_t per_block = (uint64_t)g.nw * g.spw;
