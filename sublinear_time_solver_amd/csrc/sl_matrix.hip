@@ -2,6 +2,7 @@
 // diagonal-dominance check, D^-1 extraction, column structure (pattern of A^T).
 // One-off work per matrix (not in the per-iteration metric).
 #include "sl_internal.hpp"
+#include <cstdlib>
 #include <vector>
 
 // ---- validation ---------------------------------------------------------------------------
@@ -290,6 +291,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     slice_ptr[m->n_slices] = (uint32_t)acc;
     m->padded_nnz = acc * 4 * SL_SLICE;
     m->uniform_width = (n && m->min_row_nnz == m->max_row_nnz && (m->max_row_nnz % 4u) == 0u) ? m->max_row_nnz : 0u;
+    if (getenv("SL_NO_UNROLLED")) m->uniform_width = 0;          // experiments: send uniform-width matrices through the batched path
 
     SL_HIP(hipMalloc(&m->d_slice_ptr, (m->n_slices + 1) * sizeof(uint32_t)));
     SL_HIP(hipMemcpyAsync(m->d_slice_ptr, slice_ptr.data(), (m->n_slices + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
