@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build the library and the oracle checker once."""
+    import subprocess
+    missing = [p for p in (ROOT / "sublinear_time_solver_amd" / "libsublinear_hip.so", ROOT / "oracle" / "liboracle.so",
+                           ROOT / "oracle" / "liboracle_fast.so") if not p.exists()]
+    if missing:
+        jobs = str(max(1, min(8, os.cpu_count() or 1)))
+        subprocess.run(["make", "-C", str(ROOT / "sublinear_time_solver_amd" / "csrc"), "-j", jobs], check=True, capture_output=True)
+        subprocess.run(["make", "-C", str(ROOT / "oracle"), "liboracle.so", "liboracle_fast.so"], check=True, capture_output=True)
+
+
 def _has_gpu() -> bool:
     try:
         import ctypes
