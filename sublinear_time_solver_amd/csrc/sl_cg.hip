@@ -13,6 +13,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+#include <algorithm>
 
 #define DMUL(a, b) __dmul_rn((a), (b))
 #define DADD(a, b) __dadd_rn((a), (b))
@@ -25,11 +27,65 @@ __device__ __forceinline__ double cg_wave_sum(double v)
     return v;
 }
 
-// x += alpha p ; r -= alpha ap ; partial sum of r^2   (optimized_solver.rs:244-257)
-__global__ __launch_bounds__(256) void sl_cg_update_kernel(uint64_t n, double alpha, const double *__restrict__ p,
-                                                           const double *__restrict__ ap, double *x, double *r, double *partials)
+// The loop runs without host round trips (same scheme as sl_neumann_solve, sl_solve_ctl in sl_internal.hpp): alpha, beta and
+// r.r live in device memory, the one-block kernels that finish the two reductions compute them (IEEE division, the same
+// bits as on the host), log the reduced sums and close the gate when a stop rule of optimized_solver.rs:221-263 fires;
+// the host enqueues a batch of iterations and replays the control flow over the log.  Gate index: 2 * iteration for the
+// first half of an iteration (A p, p.Ap), 2 * iteration + 1 for the second (updates, r.r, new direction).
+struct sl_cg_scalars { double rsold, pap, alpha, beta; };
+
+__device__ __forceinline__ bool cg_gated(const sl_solve_ctl *c, uint32_t g) { return g > c->stop_after; }
+
+__global__ void sl_cg_set_rsold_kernel(sl_cg_scalars *sc, double rsold) { sc->rsold = rsold; }
+
+// partial sums of p . ap
+__global__ __launch_bounds__(256) void sl_cg_dot_kernel(const sl_solve_ctl *c, uint32_t g, uint64_t n, const double *__restrict__ p,
+                                                        const double *__restrict__ ap, double *partials)
 {
     __shared__ double red[4];
+    if (cg_gated(c, g)) return;
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) acc = DADD(acc, DMUL(p[i], ap[i]));
+    acc = cg_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__device__ __forceinline__ double cg_block_total(const double *partials, uint32_t nparts, double *red)
+{
+    double acc = 0.0;
+    for (uint32_t j = threadIdx.x; j < nparts; j += 1024) acc += partials[j];
+    acc = cg_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    double t = red[0];
+    for (int w = 1; w < 16; ++w) t += red[w];
+    return t;
+}
+
+// p.Ap -> alpha = rsold / pAp; breakdown rule |pAp| < 1e-16 (optimized_solver.rs:236-238)
+__global__ __launch_bounds__(1024) void sl_cg_pap_kernel(sl_solve_ctl *c, uint32_t g, const double *partials, uint32_t nparts, sl_cg_scalars *sc)
+{
+    __shared__ double red[16];
+    if (cg_gated(c, g)) return;
+    const double pap = cg_block_total(partials, nparts, red);
+    if (threadIdx.x != 0) return;
+    sc->pap = pap;
+    sc->alpha = sc->rsold / pap;
+    c->log[c->n_done] = pap;
+    c->n_done += 1;
+    if (fabs(pap) < 1e-16 && g < c->stop_after) c->stop_after = g;           // the second half of this iteration does not run
+}
+
+// x += alpha p ; r -= alpha ap ; partial sum of r^2   (optimized_solver.rs:244-257)
+__global__ __launch_bounds__(256) void sl_cg_update_kernel(const sl_solve_ctl *c, uint32_t g, uint64_t n, const sl_cg_scalars *sc,
+                                                           const double *__restrict__ p, const double *__restrict__ ap, double *x, double *r,
+                                                           double *partials)
+{
+    __shared__ double red[4];
+    if (cg_gated(c, g)) return;
+    const double alpha = sc->alpha;
     double acc = 0.0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         x[i] = DADD(x[i], DMUL(alpha, p[i]));
@@ -43,22 +99,30 @@ __global__ __launch_bounds__(256) void sl_cg_update_kernel(uint64_t n, double al
     if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
-// p = r + beta p   (optimized_solver.rs:261-263)
-__global__ __launch_bounds__(256) void sl_cg_direction_kernel(uint64_t n, double beta, const double *__restrict__ r, double *p)
-{
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
-        p[i] = DADD(r[i], DMUL(beta, p[i]));
-}
-
-__global__ __launch_bounds__(1024) void sl_cg_final_reduce_kernel(const double *partials, uint32_t nparts, double *result)
+// r.r -> beta = rsnew / rsold, rsold = rsnew; stop rules: non-finite (error, the direction update is skipped), rsnew <= tol^2
+__global__ __launch_bounds__(1024) void sl_cg_rs_kernel(sl_solve_ctl *c, uint32_t g, const double *partials, uint32_t nparts, sl_cg_scalars *sc,
+                                                        double tol_sq)
 {
     __shared__ double red[16];
-    double acc = 0.0;
-    for (uint32_t j = threadIdx.x; j < nparts; j += 1024) acc += partials[j];
-    acc = cg_wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { double t = red[0]; for (int w = 1; w < 16; ++w) t += red[w]; *result = t; }
+    if (cg_gated(c, g)) return;
+    const double rsnew = cg_block_total(partials, nparts, red);
+    if (threadIdx.x != 0) return;
+    c->log[c->n_done] = rsnew;
+    c->n_done += 1;
+    if (rsnew != rsnew || fabs(rsnew) == INFINITY) { if (g - 1 < c->stop_after) c->stop_after = g - 1; return; }
+    sc->beta = rsnew / sc->rsold;
+    sc->rsold = rsnew;
+    if (rsnew <= tol_sq && g < c->stop_after) c->stop_after = g;
+}
+
+// p = r + beta p   (optimized_solver.rs:261-263)
+__global__ __launch_bounds__(256) void sl_cg_direction_kernel(const sl_solve_ctl *c, uint32_t g, uint64_t n, const sl_cg_scalars *sc,
+                                                              const double *__restrict__ r, double *p)
+{
+    if (cg_gated(c, g)) return;
+    const double beta = sc->beta;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        p[i] = DADD(r[i], DMUL(beta, p[i]));
 }
 
 namespace {
@@ -106,33 +170,58 @@ sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *
     const double tol_sq = o->tolerance * o->tolerance;
     uint64_t it = 0, mv = 0;
     bool converged = false;
+    DevBuf ctlbuf, scbuf;
+    SL_TRY(ctlbuf.alloc(sizeof(sl_solve_ctl)));
+    SL_TRY(scbuf.alloc(sizeof(sl_cg_scalars)));
+    sl_solve_ctl *d_ctl = ctlbuf.as<sl_solve_ctl>();
+    sl_cg_scalars *d_sc = scbuf.as<sl_cg_scalars>();
+    hipLaunchKernelGGL(sl_cg_set_rsold_kernel, dim3(1), dim3(1), 0, s, d_sc, rsold);
+    static int batch_env = -1;
+    if (batch_env < 0) { const char *e = getenv("SL_SOLVE_BATCH"); batch_env = e ? atoi(e) : 10; if (batch_env < 1) batch_env = 1; if (batch_env > 25) batch_env = 25; }
     sl_timer timer;
     SL_TRY(timer.start(s));
     sl_status st = SL_OK;
-    while (it < o->max_iterations) {
+    bool done = false;
+    while (!done && it < o->max_iterations) {
         if (rsold <= tol_sq) { converged = true; break; }                    // :221-224
-        sl_row_args a = sl_matrix_row_args(m);
-        a.gather = p.as<double>(); a.out = ap.as<double>();
-        st = sl_launch_rows(a, (sl_order)o->order, SL_EPI_SPMV, s);          // ap = A p  (:227)
+        // ---- enqueue a batch of iterations as if no stop rule fired ----
+        const uint64_t batch = std::min<uint64_t>((uint64_t)batch_env, o->max_iterations - it);
+        st = sl_launch_ctl_reset(d_ctl, s);
+        for (uint64_t k = 0; k < batch && st == SL_OK; ++k) {
+            const uint32_t ga = (uint32_t)(2 * k), gb = ga + 1;
+            sl_row_args a = sl_matrix_row_args(m);
+            a.gather = p.as<double>(); a.out = ap.as<double>();
+            a.ctl = d_ctl; a.gate_it = ga;
+            st = sl_launch_rows(a, (sl_order)o->order, SL_EPI_SPMV, s);      // ap = A p  (:227)
+            if (st != SL_OK) break;
+            hipLaunchKernelGGL(sl_cg_dot_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, ga, n, p.as<double>(), ap.as<double>(), scr);
+            hipLaunchKernelGGL(sl_cg_pap_kernel, dim3(1), dim3(1024), 0, s, d_ctl, ga, scr, vgrid, d_sc);
+            hipLaunchKernelGGL(sl_cg_update_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, gb, n, d_sc, p.as<double>(), ap.as<double>(), x.as<double>(),
+                               r.as<double>(), scr);
+            hipLaunchKernelGGL(sl_cg_rs_kernel, dim3(1), dim3(1024), 0, s, d_ctl, gb, scr, vgrid, d_sc, tol_sq);
+            hipLaunchKernelGGL(sl_cg_direction_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, gb, n, d_sc, r.as<double>(), p.as<double>());
+        }
         if (st != SL_OK) break;
-        ++mv;
-        double pap = 0.0;
-        st = sl_launch_dot(n, p.as<double>(), ap.as<double>(), scr, d_res, s);
-        if (st == SL_OK) st = read(&pap);
-        if (st != SL_OK) break;
-        if (std::fabs(pap) < 1e-16) break;                                   // :236-238
-        const double alpha = rsold / pap;
-        hipLaunchKernelGGL(sl_cg_update_kernel, dim3(vgrid), dim3(256), 0, s, n, alpha, p.as<double>(), ap.as<double>(), x.as<double>(),
-                           r.as<double>(), scr);
-        hipLaunchKernelGGL(sl_cg_final_reduce_kernel, dim3(1), dim3(1024), 0, s, scr, vgrid, d_res);
-        double rsnew = 0.0;
-        st = read(&rsnew);
-        if (st != SL_OK) break;
-        if (!std::isfinite(rsnew)) { st = sl_fail(SL_NUMERICAL_INSTABILITY, "Non-finite residual in CG at iteration %llu", (unsigned long long)it); break; }
-        const double beta = rsnew / rsold;
-        hipLaunchKernelGGL(sl_cg_direction_kernel, dim3(vgrid), dim3(256), 0, s, n, beta, r.as<double>(), p.as<double>());
-        rsold = rsnew;
-        ++it;
+        sl_solve_ctl h_ctl;
+        if (hipMemcpyAsync(&h_ctl, d_ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            st = sl_fail(SL_DEVICE_ERROR, "CG loop readback failed");
+            break;
+        }
+        // ---- replay optimized_solver.rs:221-263 over the log ----
+        uint32_t used = 0;
+        for (uint64_t k = 0; k < batch; ++k) {
+            if (rsold <= tol_sq) { converged = true; done = true; break; }
+            if (used >= h_ctl.n_done) { st = sl_fail(SL_DEVICE_ERROR, "CG loop out of step with the device"); done = true; break; }
+            const double pap = h_ctl.log[used++];
+            ++mv;
+            if (std::fabs(pap) < 1e-16) { done = true; break; }               // :236-238
+            if (used >= h_ctl.n_done) { st = sl_fail(SL_DEVICE_ERROR, "CG loop out of step with the device"); done = true; break; }
+            const double rsnew = h_ctl.log[used++];
+            if (!std::isfinite(rsnew)) { st = sl_fail(SL_NUMERICAL_INSTABILITY, "Non-finite residual in CG at iteration %llu", (unsigned long long)it); done = true; break; }
+            rsold = rsnew;
+            ++it;
+        }
+        if (st == SL_OK && used != h_ctl.n_done) { st = sl_fail(SL_DEVICE_ERROR, "CG loop out of step with the device (%u of %u sums consumed)", used, h_ctl.n_done); break; }
     }
     const float ms = timer.stop();
     res->iterations = it; res->matvec_count = mv; res->residual_norm = std::sqrt(rsold); res->converged = converged ? 1 : 0;
