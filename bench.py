@@ -258,6 +258,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": launch_ms,
+                         "timed_region_device_ms_per_step": dev_ms / args.steps,     # HIP events around the K timed steps, same stream
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         }
         if world == 1 and not args.no_sweep:
