@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void sl_diag_kernel(uint64_t n_rows, uint64_t 
     const uint32_t gi = (uint32_t)(row_offset + i);
     double diag_abs = 0.0, off = 0.0, d = 0.0;
     bool found = false;
+    uint32_t ndiag = 0;
     for (uint32_t q = q0; q < q1; ++q) {
 #pragma unroll
         for (uint32_t e = 0; e < 4; ++e) {
@@ -154,9 +155,18 @@ __global__ __launch_bounds__(256) void sl_diag_kernel(uint64_t n_rows, uint64_t 
             if (k < len) {
                 const uint32_t c = cols[((uint64_t)q * 64 + lane) * 4 + e];
                 const double v = vals[(((uint64_t)q * 2 + (e >> 1)) * 64 + lane) * 2 + (e & 1u)];
-                if (c == gi) { diag_abs = fabs(v); d = v; found = true; }
+                if (c == gi) { diag_abs = fabs(v); d = v; found = true; ++ndiag; }
                 else off = __dadd_rn(off, fabs(v));
             }
+        }
+    }
+    if (ndiag > 1) {        // duplicated diagonal: SparseMatrix::get is a binary search (sparse.rs:142-155) — take the entry IT lands on
+        uint32_t lo = 0, hi = len;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2, q = q0 + mid / 4, e = mid & 3u;
+            const uint32_t c = cols[((uint64_t)q * 64 + lane) * 4 + e];
+            if (c == gi) { d = vals[(((uint64_t)q * 2 + (e >> 1)) * 64 + lane) * 2 + (e & 1u)]; break; }
+            if (c < gi) lo = mid + 1; else hi = mid;
         }
     }
     if (i >= n_rows) return;
@@ -164,6 +174,16 @@ __global__ __launch_bounds__(256) void sl_diag_kernel(uint64_t n_rows, uint64_t 
     if (!found) { atomicOr(&status[0], 2ull); atomicMin(&status[2], (unsigned long long)i); }
     else if (fabs(d) < 1e-14) { atomicOr(&status[0], 4ull); atomicMin(&status[3], (unsigned long long)i); }
     if (dinv) dinv[i] = (found && fabs(d) >= 1e-14) ? 1.0 / d : 0.0;
+}
+
+// duplicated diagonal entries: the value SparseMatrix::get's binary search lands on (sparse.rs:142-155)
+__device__ __forceinline__ void sl_bsearch_diag(uint32_t lo, uint32_t hi, const uint32_t *col_idx, const double *values, uint32_t gi, double *d)
+{
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (col_idx[mid] == gi) { *d = values[mid]; return; }
+        if (col_idx[mid] < gi) lo = mid + 1; else hi = mid;
+    }
 }
 
 // the same a6 + a7 rules for the long rows, over their raw CSR entries (thread per row; one-off)
@@ -176,11 +196,13 @@ __global__ void sl_long_diag_kernel(uint32_t n_long, const uint32_t *long_rows, 
     const uint32_t gi = (uint32_t)(row_offset + i);
     double diag_abs = 0.0, off = 0.0, d = 0.0;
     bool found = false;
+    uint32_t ndiag = 0;
     for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
         const double v = values[k];
-        if (col_idx[k] == gi) { diag_abs = fabs(v); d = v; found = true; }
+        if (col_idx[k] == gi) { diag_abs = fabs(v); d = v; found = true; ++ndiag; }
         else off = __dadd_rn(off, fabs(v));
     }
+    if (ndiag > 1) sl_bsearch_diag(row_ptr[i], row_ptr[i + 1], col_idx, values, gi, &d);
     if (diag_abs < off) { atomicOr(&status[0], 1ull); atomicMin(&status[1], (unsigned long long)i); }
     if (!found) { atomicOr(&status[0], 2ull); atomicMin(&status[2], (unsigned long long)i); }
     else if (fabs(d) < 1e-14) { atomicOr(&status[0], 4ull); atomicMin(&status[3], (unsigned long long)i); }
@@ -399,7 +421,9 @@ __global__ __launch_bounds__(256) void sl_csr_dinv_kernel(uint64_t n, const uint
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     bool found = false; double d = 0.0;
-    for (uint32_t k = ptr[i]; k < ptr[i + 1]; ++k) if (idx[k] == (uint32_t)i) { d = val[k]; found = true; }
+    uint32_t ndiag = 0;
+    for (uint32_t k = ptr[i]; k < ptr[i + 1]; ++k) if (idx[k] == (uint32_t)i) { d = val[k]; found = true; ++ndiag; }
+    if (ndiag > 1) sl_bsearch_diag(ptr[i], ptr[i + 1], idx, val, (uint32_t)i, &d);
     if (!found) { atomicOr(&status[0], 2ull); atomicMin(&status[2], (unsigned long long)i); }
     else if (fabs(d) < 1e-14) { atomicOr(&status[0], 4ull); atomicMin(&status[3], (unsigned long long)i); }
     dinv[i] = (found && fabs(d) >= 1e-14) ? 1.0 / d : 0.0;

@@ -125,3 +125,30 @@ def test_duplicate_entries_are_kept_and_summed_in_order(gpu):
     p = S.PushSolver(theta=1e-12).solve(m, b)
     q = O.push_sync_solve(orp, oci, ova, b, theta=1e-12)
     assert p["rounds"] == q["rounds"] and _bits_equal(p["solution"], q["x"])
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_duplicate_entries_in_hit_driven_sparse_rounds(gpu, order):
+    """duplicate (row, col) entries are separate hits of the same frontier column on the same row: the hit lists must
+    order them by their position in the row, like the reference's row walk"""
+    rng = np.random.default_rng(3)
+    n = 400
+    tr, tc, tv = [], [], []
+    for i in range(n):
+        cols = rng.choice(n, size=9, replace=True)                  # with replacement: duplicates are likely
+        cols = cols[cols != i]
+        vals = rng.uniform(-1.0, 1.0, size=cols.size)
+        tr += [i] * (cols.size + 2)                                 # a duplicated DIAGONAL too: device and oracle follow the same
+        tc += cols.tolist() + [i, i]                                # binary search (which duplicate Rust's lands on stays unpinned)
+        tv += vals.tolist() + [4.0 * np.abs(vals).sum() + 1.0, 0.5]
+    rp, ci, va = O.csr_from_triplets(tr, tc, tv, n, n)
+    assert (np.diff(np.stack([np.repeat(np.arange(n), np.diff(rp.astype(np.int64))), ci.astype(np.int64)]), axis=1) == 0).all(axis=0).any()
+    m = S.SparseMatrix.from_triplets(zip(tr, tc, tv), n, n, with_transpose=True)
+    b = np.zeros(n)
+    b[[5, 77, 300]] = [1.0, -2.0, 0.25]
+    # (the binary search lands on the SMALL duplicate in some rows, so this iteration does not contract: a few rounds only)
+    p = S.PushSolver(theta=1e-11, dense_switch=2.0, order=order, max_rounds=7).solve(m, b, log_frontier=1 << 20)
+    q = O.push_sync_solve(rp, ci, va, b, theta=1e-11, order=order, log_cap=1 << 20, max_rounds=7)
+    assert p["dense_rounds"] == 0 and p["rounds"] == q["rounds"] == 7 and (p["frontier_log"] == q["frontier_log"]).all()
+    assert np.isfinite(q["x"]).all() and _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])
+    assert _bits_equal(m.diagonal_inverse(), np.array([1.0 / O.csr_get(rp, ci, va, i, i) for i in range(n)]))
