@@ -1,0 +1,73 @@
+"""Seeded random systems through the main entry points, bit for bit against the oracle: sizes that do not fill the last
+slice / block, row lengths from 1 to several hundred in one matrix (batched, long-row and heavy-row paths), bandwidths on
+both sides of every kernel-selection threshold (LDS band kernel with 4- and 8-wave blocks, general kernel), both summation
+orders, sparse and dense push rounds, query sessions."""
+import numpy as np
+import pytest
+
+import sublinear_time_solver_amd as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits_equal(a, b):
+    return (np.ascontiguousarray(a).view(np.uint64) == np.ascontiguousarray(b).view(np.uint64)).all()
+
+
+def _random_system(rng, n, w, max_len, long_rows):
+    tr, tc, tv = [], [], []
+    for i in range(n):
+        m = int(rng.integers(0, max_len))
+        if long_rows and rng.random() < 0.01:
+            m = int(rng.integers(260, 700))
+        lo, hi = (0, n) if w == 0 else (max(0, i - w), min(n, i + w + 1))
+        m = min(m, hi - lo - 1)
+        cols = rng.choice(np.arange(lo, hi), size=m, replace=False) if m > 0 else np.zeros(0, dtype=np.int64)
+        cols = cols[cols != i]
+        vals = rng.uniform(-1.0, 1.0, size=cols.size)
+        tr += [i] * (cols.size + 1)
+        tc += cols.tolist() + [i]
+        tv += vals.tolist() + [float(rng.uniform(1.5, 3.0)) * np.abs(vals).sum() + 0.5]
+    return O.csr_from_triplets(tr, tc, tv, n, n)
+
+
+CASES = [(1, 0, 4, False), (63, 0, 9, False), (64, 5, 9, False), (65, 0, 20, False), (257, 40, 12, False), (1000, 0, 30, True),
+         (2049, 300, 17, False), (3001, 1200, 24, True), (4097, 2000, 6, False), (5000, 4000, 40, True), (5003, 0, 3, False),
+         (6000, 5500, 16, False), (700, 699, 60, True)]
+
+
+@pytest.mark.parametrize("n,w,max_len,long_rows", CASES)
+def test_random_systems_bitwise(gpu, n, w, max_len, long_rows):
+    rng = np.random.default_rng(1000 * n + w)
+    rp, ci, va = _random_system(rng, n, w, max_len, long_rows)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    lens = np.diff(rp.astype(np.int64))
+    dist = np.abs(ci.astype(np.int64) - np.repeat(np.arange(n), lens))
+    short = np.repeat(lens <= 256, lens)                             # rows beyond 256 entries live outside the slice layout
+    assert m.info().bandwidth == int(dist[short].max(initial=0))
+    x = rng.standard_normal(n)
+    b = rng.standard_normal(n)
+    bs = b * (rng.random(n) < 0.02)                                   # sparse right-hand side: local pushes
+    if not bs.any():
+        bs[0] = 1.0
+    for order in (0, 1):
+        assert _bits_equal(m.multiply_vector(x, order), O.spmv(rp, ci, va, x, order))
+        g = S.NeumannSolver(order=order).solve(m, b, S.SolverOptions(tolerance=1e-12))
+        o = O.neumann_solve(rp, ci, va, b, tolerance=1e-12, order=order)
+        assert (g.iterations, g.converged) == (o["iterations"], o["converged"]) and _bits_equal(g.solution, o["x"])
+        for ds in (2.0, 1.0 / 16.0, 1e-12):
+            p = S.PushSolver(theta=1e-9, dense_switch=ds, order=order).solve(m, bs)
+            q = O.push_sync_solve(rp, ci, va, bs, theta=1e-9, order=order)
+            assert (p["rounds"], p["pushes"]) == (q["rounds"], q["pushes"]), (order, ds)
+            assert _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"]), (order, ds)
+    trp, tci, tva = O.csr_transpose(rp, ci, va, n)
+    with S.QuerySession(m, b) as sess:
+        for row in {0, n // 2, n - 1}:
+            e = sess.estimate(row, theta=1e-7)
+            unit = np.zeros(n)
+            unit[row] = 1.0
+            q = O.push_sync_solve(trp, tci, tva, unit, theta=1e-7)
+            assert (e.rounds, e.pushes) == (q["rounds"], q["pushes"])
+            est = float(np.dot(q["x"], b))
+            assert abs(e.estimate - est) <= 1e-13 * max(1.0, np.abs(q["x"]).sum() * np.abs(b).max())
