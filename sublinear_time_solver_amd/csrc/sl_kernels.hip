@@ -432,7 +432,7 @@ __device__ __forceinline__ void sl_batch_finish(const sl_row_args &a, const sl_b
 // blocks: 8-wave blocks then double the waves in flight per window (4 per SIMD — the second launch-bounds argument
 // holds the kernel to 128 VGPRs for that).  Measured at w = 4096: +5..6 % (gpurun_out/ab_b512.txt).
 template <int ORDER, int EPI, int UW, bool PIPE, bool C16, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void sl_band_kernel(sl_row_args a, uint32_t nb8, uint32_t spw, uint32_t w)
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_row_args a, uint32_t nb8, uint32_t spw, uint32_t w)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];
     __shared__ double red[2 * NW];
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void sl_band_kernel(sl_ro
             }
         } else if constexpr (PIPE) {
             sl_batch_cursor cur{s0, 0, 0, spw, 0, 0, 0, false, pre_q0, pre_q1, (uint32_t)NW};
-            constexpr int BQ = (NW == 8) ? (ORDER == 1 ? 2 : SL_BATCH_QUADS_NW8) : 4;   // 8-wave blocks live in 128 VGPRs: shorter batches, no spills
+            constexpr int BQ = (NW >= 8) ? (ORDER == 1 ? 2 : SL_BATCH_QUADS_NW8) : 4;   // 8-wave blocks live in 128 VGPRs: shorter batches, no spills
             sl_batch_regs<BQ> ga, gb;
             sl_row_state st{};
             sl_batch ba = sl_next_batch<BQ>(a, cur);
@@ -648,6 +648,7 @@ uint32_t sl_row_grid(uint64_t n_slices)
 
 // band-kernel geometry for half bandwidth w: slices per wave, dynamic LDS bytes, pipelining; spw = 0: not eligible
 #define SL_BAND_MAX_LDS (80u * 1024u)      // two blocks per CU (160 KiB LDS)
+#define SL_BAND_MAX_LDS_ONE (158u * 1024u)  // one 16-wave block per CU: windows up to w ~ 9500 (leaves room for the static arrays)
 struct band_geom { uint32_t spw, lds, nw; bool pipe, c16; };
 static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool nw8_pays)
 {
@@ -679,7 +680,17 @@ static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool
         spw = spw == 3 ? 2 : spw >> 1;
         entries = (uint64_t)nw * spw * SL_SLICE + 2 * a.bandwidth + 2;
     }
-    if (entries * 8 > SL_BAND_MAX_LDS) return out;
+    if (entries * 8 > SL_BAND_MAX_LDS || forced_nw == 16) {
+        // the window does not fit twice per CU: one 16-wave block per CU with (almost) the whole LDS, if that variant exists
+        // (w = 6000..9400: 52-56 % with the general kernel -> 72-82 %)
+        static const bool wide_off = getenv("SL_BAND_NW16") && getenv("SL_BAND_NW16")[0] == '0';
+        if (wide_off || !pipe || !c16 || !nw8_pays || forced_nw == 4 || forced_nw == 8) return out;
+        nw = 16;
+        spw = forced_spw > 0 ? (uint32_t)forced_spw : 4u;
+        entries = (uint64_t)nw * spw * SL_SLICE + 2 * a.bandwidth + 2;
+        while (entries * 8 > SL_BAND_MAX_LDS_ONE && forced_spw <= 0 && spw > 1) { --spw; entries = (uint64_t)nw * spw * SL_SLICE + 2 * a.bandwidth + 2; }
+        if (entries * 8 > SL_BAND_MAX_LDS_ONE) return out;
+    }
     out.spw = spw; out.lds = (uint32_t)(entries * 8); out.nw = nw;
     out.pipe = pipe;
     out.c16 = c16;
@@ -692,7 +703,8 @@ static sl_status launch_band_nw(const sl_row_args &a, const band_geom &g, uint32
     auto kfn = sl_band_kernel<(UWV) ? 0 : ORDER, EPI, UWV, PIPE, C16, NW>;
     static bool attr_done = false;
     if (!attr_done) {
-        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, SL_BAND_MAX_LDS));
+        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   NW == 16 ? SL_BAND_MAX_LDS_ONE : SL_BAND_MAX_LDS));
         attr_done = true;
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), g.lds, s, a, nb8, g.spw, (uint32_t)a.bandwidth);
@@ -702,7 +714,10 @@ template <int ORDER, int EPI, int UWV, bool PIPE, bool C16>
 static sl_status launch_band(const sl_row_args &a, const band_geom &g, uint32_t grid, uint32_t nb8, hipStream_t s)
 {
     constexpr bool nw8_built = PIPE && C16 && !(EPI == SL_EPI_PUSH && UWV == 16);   // = the cases band_geometry picks 8 for
-    if constexpr (nw8_built) { if (g.nw == 8) return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 8>(a, g, grid, nb8, s); }
+    if constexpr (nw8_built) {
+        if (g.nw == 8) return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 8>(a, g, grid, nb8, s);
+        if (g.nw == 16) return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 16>(a, g, grid, nb8, s);
+    }
     if (g.nw != 4) return sl_fail(SL_DEVICE_ERROR, "band geometry asks for %u waves per block, variant built for 4", g.nw);
     return launch_band_nw<ORDER, EPI, UWV, PIPE, C16, 4>(a, g, grid, nb8, s);
 }
