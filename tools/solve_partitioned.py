@@ -18,6 +18,7 @@ import time
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL peer access on this platform needs dmabuf IPC
 
 
 def main():
