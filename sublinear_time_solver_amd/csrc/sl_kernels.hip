@@ -430,7 +430,7 @@ __device__ __forceinline__ void sl_batch_finish(const sl_row_args &a, const sl_b
 
 // NW = waves per block.  4 by default; 8 for wide windows, where the LDS window (not registers) caps the CU at two
 // blocks: 8-wave blocks then double the waves in flight per window (4 per SIMD — the second launch-bounds argument
-// holds the kernel to 128 VGPRs for that).  Measured at w = 4096: +5..6 % (gpurun_out/ab_b512.txt).
+// holds the kernel to 128 VGPRs for that).  Measured at w = 4096: +5..6 % (profiles/r01_ab_wave_blocks.txt).
 template <int ORDER, int EPI, int UW, bool PIPE, bool C16, int NW>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_row_args a, uint32_t nb8, uint32_t spw, uint32_t w)
 {
@@ -667,7 +667,7 @@ static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool
     }
     band_geom out{0, 0, 4, false, false};
     if (disabled || a.bandwidth == ~0ull || a.n_cols > 0xffffffffull) return out;
-    // measured (gpurun_out/sweep4.txt, sweep5.txt, ab_b512.txt; +-5 % DVFS noise between repetitions): narrow windows
+    // measured (profiles/r01_ab_wave_blocks.txt and earlier spw sweeps; +-5 % DVFS noise between repetitions): narrow windows
     // 4 waves x 4 slices per block; wide windows (w > 1024), where the window itself caps the CU at two blocks,
     // 8 waves x 3 slices (the window is re-staged nw * spw * 64 rows at a time); pipelining never hurts
     const bool pipe = forced_pipe >= 0 ? forced_pipe != 0 : true;
