@@ -1,14 +1,15 @@
 // sl_internal.hpp — internal structures of libsublinear_hip (not part of the ABI).
 //
 // HBM layout of a matrix ("row-slice" layout): rows are grouped in
-// slices of 64 consecutive rows = one wavefront, lane l owns row 64*s + l.  A slice
-// of width W (max row length in the slice, rounded up to 4) is stored as W/4 "quads";
-// quad q holds entries 4q..4q+3 of all 64 rows:
-//     cols : [quad][lane 0..63][4]      u32   -> one 16-B load per lane, 1 KiB per wave
-//     vals : [quad][half 0..1][lane][2] f64   -> two 16-B loads per lane, 2 x 1 KiB per wave
-// so every matrix byte is fetched by fully coalesced dwordx4 loads while each lane still
-// walks ITS row left to right — the reference's summation order (sparse.rs:187-203)
-// is kept bit for bit with no cross-lane reduction.
+// slices of 64 consecutive rows = one wavefront, lane l owns row 64*s + l.  A slice whose longest row has
+// L entries is stored in ceil(L / 2) "pair blocks" of 128 entries; two consecutive pair blocks form a quad
+// (entries 4q..4q+3 of all 64 rows), an odd last pair block stands alone (rows of 5 take 6 slots, not 8):
+//     vals   : [pair block][lane 0..63][2]  f64   -> 16-B loads, 1 KiB per wave (both halves of a quad alike)
+//     cols   : [quad][lane][4] u32 (16-B loads) over two pair blocks; odd last block [lane][2] (8-B loads)
+//     cols16 : the same slots as int16 offsets col - row (8-B / 4-B loads)
+// slice_ptr[] counts pair blocks.  Every matrix byte is fetched by fully coalesced loads while each lane still
+// walks ITS row left to right — the reference's summation order (sparse.rs:187-203) is kept bit for bit with
+// no cross-lane reduction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -33,7 +34,7 @@ struct sl_matrix {
     int device = 0;
     // row-slice layout
     uint64_t n_slices = 0, padded_nnz = 0;
-    uint32_t *d_slice_ptr = nullptr; // [n_slices+1] in quads
+    uint32_t *d_slice_ptr = nullptr; // [n_slices+1] in pair blocks (128 entries)
     uint32_t *d_row_len = nullptr;   // [n_slices*64]
     uint32_t *d_cols = nullptr;      // [padded_nnz]
     uint16_t *d_cols16 = nullptr;    // [padded_nnz] col - row as int16 (uniform-width band matrices only)
@@ -138,6 +139,18 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 #define SL_TRY(expr) do { sl_status s_ = (expr); if (s_ != SL_OK) return s_; } while (0)
+
+// entry slot of position k of `lane`'s row inside a slice occupying pair blocks [h0, h1)   (fill / diagnostic kernels)
+__host__ __device__ inline uint64_t sl_col_slot(uint32_t h0, uint32_t h1, uint32_t k, uint32_t lane)
+{
+    const uint32_t pk = k >> 1, w2 = h1 - h0;
+    if ((w2 & 1u) && pk == w2 - 1) return (uint64_t)(h0 + pk) * 128 + lane * 2 + (k & 1u);      // the odd last pair block
+    return (uint64_t)(h0 + (pk & ~1u)) * 128 + lane * 4 + (k & 3u);                              // inside a quad
+}
+__host__ __device__ inline uint64_t sl_val_slot(uint32_t h0, uint32_t k, uint32_t lane)
+{
+    return (uint64_t)(h0 + (k >> 1)) * 128 + lane * 2 + (k & 1u);
+}
 
 // ---- kernel launchers (sl_kernels.hip) -------------------------------------------------
 enum sl_epilogue { SL_EPI_SPMV = 0, SL_EPI_NEUMANN = 1, SL_EPI_RESIDUAL = 2, SL_EPI_PUSH = 3 };

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 #define DMUL(a, b) __dmul_rn((a), (b))
@@ -65,54 +66,47 @@ __device__ __forceinline__ double sl_row_walk(const sl_row_args &a, uint64_t s, 
             sum = DADD(sum, DMUL(vb[q].y, t[4 * q + 3]));
         }
     } else {
-        const uint32_t q0 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s]);
-        const uint32_t q1 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s + 1]);
+        // slice_ptr counts pair blocks (128 entries): two consecutive blocks form a quad, an odd last block stands alone
+        const uint32_t h0 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s]);
+        const uint32_t h1 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s + 1]);
         const uint32_t len_raw = a.row_len[i];
         const uint32_t len = len_raw == SL_LONG_SENTINEL ? 0u : len_raw;     // long rows: sl_long_rows_kernel
-        if constexpr (ORDER == 0) {
+        // simd_ops.rs:41-77: rows with >= 8 entries: four lane sums over the full chunks of 4, then ((l0+l1)+l2)+l3,
+        // then the tail sequentially; shorter rows (and ORDER 0): sequential from 0.0
+        const uint32_t chunks = (ORDER == 1 && len >= 8u) ? (len >> 2) : 0u;
+        double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+        bool merged = false;
 #pragma unroll 2
-            for (uint32_t q = q0; q < q1; ++q) {
-                const u32x4 c = __builtin_nontemporal_load(&cq[(uint64_t)q * 64 + lane]);
-                const f64x2 va = __builtin_nontemporal_load(&vq[((uint64_t)q * 2) * 64 + lane]);
-                const f64x2 vb = __builtin_nontemporal_load(&vq[((uint64_t)q * 2 + 1) * 64 + lane]);
-                const double t0 = gather(c.x), t1 = gather(c.y), t2 = gather(c.z), t3 = gather(c.w);
-                const uint32_t k = (q - q0) * 4;
-                const double s0 = DADD(sum, DMUL(va.x, t0));
+        for (uint32_t h = h0; h < h1; h += 2) {
+            u32x4 c;
+            f64x2 vb;
+            const f64x2 va = __builtin_nontemporal_load(&vq[(uint64_t)h * 64 + lane]);
+            if (h + 1 < h1) {                                                  // wave-uniform
+                c = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.cols + (uint64_t)h * 128) + lane);
+                vb = __builtin_nontemporal_load(&vq[(uint64_t)(h + 1) * 64 + lane]);
+            } else {                                                           // the odd last pair block: entries k, k+1 only
+                const u32x2 c2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.cols + (uint64_t)h * 128) + lane);
+                c.x = c2.x; c.y = c2.y; c.z = c2.x; c.w = c2.x;
+                vb.x = 0.0; vb.y = 0.0;
+            }
+            const double p0 = DMUL(va.x, gather(c.x)), p1 = DMUL(va.y, gather(c.y));
+            const double p2 = DMUL(vb.x, gather(c.z)), p3 = DMUL(vb.y, gather(c.w));
+            const uint32_t k = (h - h0) * 2;
+            if (ORDER == 1 && (k >> 2) < chunks) {
+                l0 = DADD(l0, p0); l1 = DADD(l1, p1); l2 = DADD(l2, p2); l3 = DADD(l3, p3);
+            } else {
+                if (ORDER == 1 && !merged) { sum = DADD(DADD(DADD(l0, l1), l2), l3); merged = true; }
+                const double s0 = DADD(sum, p0);
                 sum = (k < len) ? s0 : sum;
-                const double s1 = DADD(sum, DMUL(va.y, t1));
+                const double s1 = DADD(sum, p1);
                 sum = (k + 1 < len) ? s1 : sum;
-                const double s2 = DADD(sum, DMUL(vb.x, t2));
+                const double s2 = DADD(sum, p2);
                 sum = (k + 2 < len) ? s2 : sum;
-                const double s3 = DADD(sum, DMUL(vb.y, t3));
+                const double s3 = DADD(sum, p3);
                 sum = (k + 3 < len) ? s3 : sum;
             }
-        } else {
-            // simd_ops.rs:41-77: rows with >= 8 entries: four lane sums over the full
-            // chunks of 4, then ((l0+l1)+l2)+l3, then the tail sequentially; shorter
-            // rows: sequential from 0.0 (chunks_eff = 0, the horizontal sum of zeros is 0.0).
-            const uint32_t chunks = (len >= 8u) ? (len >> 2) : 0u;
-            double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
-            bool merged = false;
-            for (uint32_t q = q0; q < q1; ++q) {
-                const u32x4 c = __builtin_nontemporal_load(&cq[(uint64_t)q * 64 + lane]);
-                const f64x2 va = __builtin_nontemporal_load(&vq[((uint64_t)q * 2) * 64 + lane]);
-                const f64x2 vb = __builtin_nontemporal_load(&vq[((uint64_t)q * 2 + 1) * 64 + lane]);
-                const double p0 = DMUL(va.x, gather(c.x)), p1 = DMUL(va.y, gather(c.y));
-                const double p2 = DMUL(vb.x, gather(c.z)), p3 = DMUL(vb.y, gather(c.w));
-                const uint32_t qi = q - q0;
-                if (qi < chunks) {
-                    l0 = DADD(l0, p0); l1 = DADD(l1, p1); l2 = DADD(l2, p2); l3 = DADD(l3, p3);
-                } else {
-                    if (!merged) { sum = DADD(DADD(DADD(l0, l1), l2), l3); merged = true; }
-                    const uint32_t k = qi * 4;
-                    if (k < len) sum = DADD(sum, p0);
-                    if (k + 1 < len) sum = DADD(sum, p1);
-                    if (k + 2 < len) sum = DADD(sum, p2);
-                    if (k + 3 < len) sum = DADD(sum, p3);
-                }
-            }
-            if (!merged) sum = DADD(DADD(DADD(l0, l1), l2), l3);
         }
+        if (ORDER == 1 && !merged) sum = DADD(DADD(DADD(l0, l1), l2), l3);
     }
     return sum;
 }
@@ -306,7 +300,7 @@ __device__ __forceinline__ void sl_slice_finish(const sl_row_args &a, uint64_t s
 // operands — are in flight while the current batch is reduced.  Everything that steers the loop (slice
 // pointers, quad counts) is wave-uniform.  C16: columns come as 16-bit offsets col - row, layout
 // [quad][lane][4] (8 B per lane per quad).
-struct sl_batch { uint64_t s; uint32_t q, nq, kbase; bool first, last, valid; };
+struct sl_batch { uint64_t s; uint32_t q, nq, kbase, q1; bool first, last, valid; };    // q, q1: pair blocks; nq: quads (the last may be half)
 #ifndef SL_BATCH_QUADS_NW8
 #define SL_BATCH_QUADS_NW8 3      /* measured: 3 quads per batch beat 2 and 4 (4 spills at 128 VGPRs), gpurun 2026-09 A/B in DESIGN.md §5 */
 #endif
@@ -323,7 +317,7 @@ struct sl_row_state { double sum, l0, l1, l2, l3, e_d, e_x, e_aux; uint32_t len,
 template <int BQ>
 __device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch_cursor &c)
 {
-    sl_batch b{0, 0, 0, 0, false, false, false};
+    sl_batch b{0, 0, 0, 0, 0, false, false, false};
     if (!c.in_slice) {
         if (c.j >= c.spw) return b;
         c.s = c.s0 + (uint64_t)c.j * c.nw;
@@ -333,12 +327,13 @@ __device__ __forceinline__ sl_batch sl_next_batch(const sl_row_args &a, sl_batch
         c.q = c.q0;
         c.in_slice = true;
     }
-    uint32_t nq = c.q1 - c.q;
+    uint32_t nq = (c.q1 - c.q + 1u) >> 1;                      // quads left in the slice, an odd last pair block counting as one
     nq = nq > (uint32_t)BQ ? (uint32_t)BQ : nq;
-    b.s = c.s; b.q = c.q; b.nq = nq; b.kbase = (c.q - c.q0) * 4u;
-    b.first = c.q == c.q0; b.last = c.q + nq == c.q1; b.valid = true;
-    c.q += nq;
-    if (c.q == c.q1) { c.in_slice = false; ++c.j; }
+    b.s = c.s; b.q = c.q; b.nq = nq; b.kbase = (c.q - c.q0) * 2u; b.q1 = c.q1;
+    b.first = c.q == c.q0;
+    c.q += 2u * nq;
+    if (c.q >= c.q1) { c.q = c.q1; c.in_slice = false; ++c.j; b.last = true; }
+    b.valid = true;
     return b;
 }
 
@@ -349,15 +344,27 @@ __device__ __forceinline__ void sl_batch_load(const sl_row_args &a, const sl_bat
 #pragma unroll
     for (int qq = 0; qq < BQ; ++qq) {
         if ((uint32_t)qq < b.nq) {
-            const uint64_t q = (uint64_t)b.q + qq;
+            const uint64_t h = (uint64_t)b.q + 2u * (uint32_t)qq;             // pair block of this quad's first half
+            const bool half = h + 1 == b.q1;                                   // the slice's odd last pair block (wave-uniform)
             if constexpr (C16) {
-                const unsigned long long w2 = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(a.cols16) + q * 64 + lane);
-                r.c[qq].x = (uint32_t)w2; r.c[qq].y = (uint32_t)(w2 >> 32);
+                if (!half) {
+                    const unsigned long long w2 = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(a.cols16) + h * 32 + lane);
+                    r.c[qq].x = (uint32_t)w2; r.c[qq].y = (uint32_t)(w2 >> 32);
+                } else {
+                    r.c[qq].x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(a.cols16) + h * 64 + lane);
+                    r.c[qq].y = 0u;                                            // offsets 0: the row itself (never added)
+                }
             } else {
-                r.c[qq] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.cols) + q * 64 + lane);
+                if (!half) {
+                    r.c[qq] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.cols + h * 128) + lane);
+                } else {
+                    const u32x2 c2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.cols + h * 128) + lane);
+                    r.c[qq].x = c2.x; r.c[qq].y = c2.y; r.c[qq].z = c2.x; r.c[qq].w = c2.x;
+                }
             }
-            r.va[qq] = __builtin_nontemporal_load(&vq[(q * 2) * 64 + lane]);
-            r.vb[qq] = __builtin_nontemporal_load(&vq[(q * 2 + 1) * 64 + lane]);
+            r.va[qq] = __builtin_nontemporal_load(&vq[h * 64 + lane]);
+            if (!half) r.vb[qq] = __builtin_nontemporal_load(&vq[(h + 1) * 64 + lane]);
+            else { r.vb[qq].x = 0.0; r.vb[qq].y = 0.0; }
         }
     }
     if (b.first) {

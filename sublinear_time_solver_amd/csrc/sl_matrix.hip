@@ -21,7 +21,7 @@ __global__ void sl_validate_csr_kernel(uint64_t n_rows, uint64_t n_cols, uint64_
     }
 }
 
-// row lengths + slice widths (in quads) + min/max row length
+// row lengths + slice widths (in pair blocks) + min/max row length
 __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64_t n_slices, const uint32_t *row_ptr,
                                                          uint32_t *row_len, uint32_t *slice_w, uint32_t *minmax)
 {
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64
         const uint32_t other = __shfl_xor(mx, o);
         mx = other > mx ? other : mx;
     }
-    if ((threadIdx.x & 63) == 0) slice_w[s] = (mx + 3u) >> 2;
+    if ((threadIdx.x & 63) == 0) slice_w[s] = (mx + 1u) >> 1;
 }
 
 // CSR -> row-slice layout.  One wave per slice, lane = row.  Padding entries carry
@@ -70,17 +70,14 @@ __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, ui
         len = row_len[i] == SL_LONG_SENTINEL ? 0u : row_len[i];
     }
     unsigned long long bw = 0;
-    for (uint32_t q = q0; q < q1; ++q) {
-#pragma unroll
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t k = (q - q0) * 4 + e;
-            const bool in = k < len;
-            const uint32_t c = in ? col_idx[start + k] : padcol;
-            const double v = in ? values[start + k] : 0.0;
-            if (in) { const unsigned long long d = c > gi ? c - gi : gi - c; bw = d > bw ? d : bw; }
-            cols[((uint64_t)q * 64 + lane) * 4 + e] = c;
-            vals[(((uint64_t)q * 2 + (e >> 1)) * 64 + lane) * 2 + (e & 1u)] = v;
-        }
+    const uint32_t slots = (q1 - q0) * 2;                      // q0, q1: pair blocks
+    for (uint32_t k = 0; k < slots; ++k) {
+        const bool in = k < len;
+        const uint32_t c = in ? col_idx[start + k] : padcol;
+        const double v = in ? values[start + k] : 0.0;
+        if (in) { const unsigned long long d = c > gi ? c - gi : gi - c; bw = d > bw ? d : bw; }
+        cols[sl_col_slot(q0, q1, k, lane)] = c;
+        vals[sl_val_slot(q0, k, lane)] = v;
     }
     if (bw) atomicMax(band, bw);
 }
@@ -105,7 +102,7 @@ __global__ __launch_bounds__(256) void sl_fill_cols16_kernel(uint64_t n_rows, ui
         }
 }
 
-// 16-bit column offsets for ragged band matrices: [quad][lane][4] int16 (8 B per lane per quad)
+// 16-bit column offsets for ragged band matrices, in the slots of `cols` (8 B per lane per quad, 4 B in an odd last pair block)
 __global__ __launch_bounds__(256) void sl_fill_cols16_quads_kernel(uint64_t n_rows, uint64_t n_slices, uint64_t row_offset,
                                                                    const uint32_t *slice_ptr, const uint32_t *row_len,
                                                                    const uint32_t *cols, uint16_t *cols16)
@@ -118,13 +115,11 @@ __global__ __launch_bounds__(256) void sl_fill_cols16_quads_kernel(uint64_t n_ro
     uint32_t len = i < n_rows ? row_len[i] : 0u;
     if (len == SL_LONG_SENTINEL) len = 0u;
     const uint32_t q0 = slice_ptr[s], q1 = slice_ptr[s + 1];
-    for (uint32_t q = q0; q < q1; ++q)
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t k = (q - q0) * 4 + e;
-            const uint64_t at = ((uint64_t)q * 64 + lane) * 4 + e;
-            const int delta = k < len ? (int)((long long)cols[at] - (long long)gi) : 0;
-            cols16[at] = (uint16_t)(int16_t)delta;
-        }
+    for (uint32_t k = 0; k < (q1 - q0) * 2; ++k) {
+        const uint64_t at = sl_col_slot(q0, q1, k, lane);
+        const int delta = k < len ? (int)((long long)cols[at] - (long long)gi) : 0;
+        cols16[at] = (uint16_t)(int16_t)delta;
+    }
 }
 
 // a6 + a7: one pass over the slice layout.  Per row, in stored order:
@@ -148,24 +143,18 @@ __global__ __launch_bounds__(256) void sl_diag_kernel(uint64_t n_rows, uint64_t 
     double diag_abs = 0.0, off = 0.0, d = 0.0;
     bool found = false;
     uint32_t ndiag = 0;
-    for (uint32_t q = q0; q < q1; ++q) {
-#pragma unroll
-        for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t k = (q - q0) * 4 + e;
-            if (k < len) {
-                const uint32_t c = cols[((uint64_t)q * 64 + lane) * 4 + e];
-                const double v = vals[(((uint64_t)q * 2 + (e >> 1)) * 64 + lane) * 2 + (e & 1u)];
-                if (c == gi) { diag_abs = fabs(v); d = v; found = true; ++ndiag; }
-                else off = __dadd_rn(off, fabs(v));
-            }
-        }
+    for (uint32_t k = 0; k < len; ++k) {
+        const uint32_t c = cols[sl_col_slot(q0, q1, k, lane)];
+        const double v = vals[sl_val_slot(q0, k, lane)];
+        if (c == gi) { diag_abs = fabs(v); d = v; found = true; ++ndiag; }
+        else off = __dadd_rn(off, fabs(v));
     }
     if (ndiag > 1) {        // duplicated diagonal: SparseMatrix::get is a binary search (sparse.rs:142-155) — take the entry IT lands on
         uint32_t lo = 0, hi = len;
         while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo) / 2, q = q0 + mid / 4, e = mid & 3u;
-            const uint32_t c = cols[((uint64_t)q * 64 + lane) * 4 + e];
-            if (c == gi) { d = vals[(((uint64_t)q * 2 + (e >> 1)) * 64 + lane) * 2 + (e & 1u)]; break; }
+            const uint32_t mid = lo + (hi - lo) / 2;
+            const uint32_t c = cols[sl_col_slot(q0, q1, mid, lane)];
+            if (c == gi) { d = vals[sl_val_slot(q0, mid, lane)]; break; }
             if (c < gi) lo = mid + 1; else hi = mid;
         }
     }
@@ -311,7 +300,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     for (uint64_t s = 0; s < m->n_slices; ++s) { slice_ptr[s] = (uint32_t)acc; acc += slice_w[s]; }
     if (acc > 0xffffffffull) return sl_fail(SL_ALLOCATION, "matrix too large for 32-bit slice pointers");
     slice_ptr[m->n_slices] = (uint32_t)acc;
-    m->padded_nnz = acc * 4 * SL_SLICE;
+    m->padded_nnz = acc * 2 * SL_SLICE;                         // acc counts pair blocks
     m->uniform_width = (n && m->min_row_nnz == m->max_row_nnz && (m->max_row_nnz % 4u) == 0u) ? m->max_row_nnz : 0u;
     if (getenv("SL_NO_UNROLLED")) m->uniform_width = 0;          // experiments: send uniform-width matrices through the batched path
 
