@@ -182,6 +182,9 @@ class SublinearSolver {
     });
     out.method = method;
     out.computeTime = Number(process.hrtime.bigint() - t0) / 1e6;
+    if (this.config.timeout && out.computeTime > this.config.timeout) {      // TimeoutController.checkTimeout, core/utils.ts:319-325 (measured per solve)
+      throw new SolverError(`Operation timed out after ${this.config.timeout}ms`, ErrorCodes.TIMEOUT);
+    }
     if (progressCallback) progressCallback({ iteration: out.iterations, residual: out.residual, elapsed: out.computeTime });
     return out;
   }

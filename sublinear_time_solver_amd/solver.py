@@ -414,8 +414,11 @@ class SublinearSolver:
             if not pr["converged"]:
                 raise SolverError(3, f"Forward push failed to converge after {self.max_iterations} iterations")
             sol, it, res, conv = pr["solution"], pr["rounds"], pr["residual_norm"], True
+        elapsed_ms = (time.perf_counter() - t0) * 1e3
+        if self.timeout and elapsed_ms > self.timeout:               # TimeoutController.checkTimeout, core/utils.ts:319-325 (measured per solve)
+            raise SolverError(3, f"Operation timed out after {self.timeout}ms")
         return {"solution": sol, "iterations": it, "residual": res, "converged": conv, "method": self.method,
-                "computeTime": (time.perf_counter() - t0) * 1e3, "memoryUsed": int(m.info().device_bytes)}
+                "computeTime": elapsed_ms, "memoryUsed": int(m.info().device_bytes)}
 
     def estimate_entry(self, matrix, vector, row: int, column: int = 0, epsilon: Optional[float] = None,
                        confidence: float = 0.95, method: str = "neumann") -> dict:

@@ -82,6 +82,7 @@ async function rejects(p, code, re) {
     assert(r.converged && r.method === method && r.iterations > 0 && r.memoryUsed > 0 && r.computeTime >= 0);
     r.solution.forEach((v, i) => assert(Math.abs(v - x3[i]) < 1e-10, `${method} x[${i}]`));
   }
+  await rejects(new SublinearSolver({ method: 'neumann', epsilon: 1e-12, maxIterations: 100, timeout: 1e-6 }).solve(dense, b3), ErrorCodes.TIMEOUT, /timed out after/);
   const n = 200, A = randomDD(n, 7), b = Array.from({ length: n }, (_, i) => Math.sin(i));
   const xr = gauss(A, b);
   const rows = [], cols = [], vals = [];
