@@ -111,10 +111,15 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--order", type=int, default=0, help="0 = CSR sequential (sparse.rs), 1 = simd4 (simd_ops.rs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the cpu_baseline leg
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary column-structure measurements")
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: do not split boundary / interior rows")
     ap.add_argument("--force-split", action="store_true", help="testing: use the boundary / interior split even on one GPU")
     args = ap.parse_args()
+    if args.cpu_baseline_only:      # runs in its own process: a crash of the CPU checker must not take the GPU line with it
+        w0 = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
+        print(json.dumps(cpu_baseline(args.n, args.k, args.seed, w0, os.cpu_count() or 1)), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -266,7 +271,12 @@ def main():
             out["config"]["other_column_structures"] = column_structure_sweep(lib, L, torch, dev, n_local, k, args.seed, args.order, others)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(n_global, k, args.seed, w, os.cpu_count() or 1)
+                import subprocess
+                r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--rows", str(n_global), "--k", str(k),
+                                    "--seed", str(args.seed), "--bandwidth", str(w)], capture_output=True, text=True, timeout=600)
+                if r.returncode != 0:
+                    raise RuntimeError(f"child exited with {r.returncode}: {r.stderr[-300:]}")
+                out["cpu_baseline"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             except Exception as e:  # the baseline is reported context; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "nnz*iter/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
