@@ -151,3 +151,13 @@ def test_javascript_surface_host_logic(node_surface_script):
     import subprocess
     r = subprocess.run(["node", str(node_surface_script)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "host logic ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_every_abi_entry_is_documented_with_its_reference_counterpart():
+    """INTEGRATION.md lists, for every entry point of include/sublinear_hip.h, the reference interface it replaces"""
+    root = Path(__file__).resolve().parent.parent
+    header = (root / "include" / "sublinear_hip.h").read_text()
+    doc = (root / "INTEGRATION.md").read_text()
+    names = set(re.findall(r"\b(sl_[a-z0-9_]+)\s*\(", header))
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
