@@ -140,8 +140,10 @@ def main():
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("SL_BENCH_FORCE_DIST") == "1"        # TEST: initialise the process group even at world size 1
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -202,7 +204,7 @@ def main():
     drv = D.PartitionedNeumann(part, local_step, exchange, t0, x)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -219,7 +221,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     dev_ms = ev0.elapsed_time(ev1)
     tmax = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or force_dist:
         D.all_reduce_scalar(tmax, dist.ReduceOp.MAX)
     elapsed, dev_ms = float(tmax[0]), float(tmax[1])
     term_norm = drv.term_norm()
@@ -282,7 +284,7 @@ def main():
         print(json.dumps(out), flush=True)
     for hh in handles:
         lib.sl_matrix_destroy(hh)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

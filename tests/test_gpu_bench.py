@@ -86,3 +86,15 @@ def test_partitioned_solve_script_two_ranks_equals_one(gpu):
     assert (one["iterations"], one["terms"]) == (two["iterations"], two["terms"])
     for key in ("residual_norm", "sum_x", "sum_x2", "last_term_norm"):
         assert abs(one[key] - two[key]) <= 1e-11 * max(1.0, abs(one[key])), key
+
+
+def test_bench_initialises_rccl_on_this_box(gpu):
+    """world size 1 through the real backend ("nccl" = RCCL): process-group init with device_id, barrier and all-reduce run
+    through RCCL on the GPU box (the halo transfer itself needs a second GPU and is first exercised by the multi-GPU run)"""
+    import os
+    r = subprocess.run([sys.executable, "bench.py", "--rows", "300000", "--k", "16", "--bandwidth", "512", "--steps", "5", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-sweep", "--force-split"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SL_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    a = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert a["n_gpus"] == 1 and a["config"]["exchange"] == "halo+overlap" and a["value"] > 0
