@@ -217,6 +217,7 @@ def main():
     for _ in range(args.steps):
         drv.step()
     ev1.record(stream)
+    enqueue_s = time.perf_counter() - t_start        # host time to enqueue the K steps (no waiting unless the queue is full)
     barrier()
     elapsed = time.perf_counter() - t_start
     dev_ms = ev0.elapsed_time(ev1)
@@ -266,6 +267,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": launch_ms,
                          "timed_region_device_ms_per_step": dev_ms / args.steps,     # HIP events around the K timed steps, same stream
+                         "host_enqueue_ms_per_step": enqueue_s * 1e3 / args.steps,
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
         }
         if world == 1 and not args.no_sweep:
