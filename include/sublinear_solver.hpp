@@ -199,4 +199,56 @@ private:
     size_t max_rounds_;
 };
 
+// Many single-entry queries against one system: ForwardPushSolver::new(graph, config) once, query_single_entry per
+// query (forward_push.rs:52-66, 224-231).  Setup is paid once; a query costs the rows its push touches.  `matrix` and
+// `b` are captured: the matrix must outlive the session.
+class QuerySession {
+public:
+    QuerySession(const SparseMatrix &matrix, const std::vector<Precision> &b, bool matrix_is_transpose = false)
+    {
+        if (b.size() != matrix.rows()) throw SolverError(SL_DIMENSION_MISMATCH, "query session");
+        check(sl_query_session_create(matrix.handle(), matrix_is_transpose ? 1 : 0, b.data(), SL_MEM_HOST, &q_));
+    }
+    QuerySession(const QuerySession &) = delete;
+    QuerySession &operator=(const QuerySession &) = delete;
+    ~QuerySession() { if (q_) sl_query_session_destroy(q_); }
+    // x_row = (A^-1 b)_row; *error_l1 * max|x| bounds the error
+    Precision query_single_entry(size_t row, Precision theta = 1e-8, size_t max_rounds = 100000, Precision *error_l1 = nullptr,
+                                 size_t *rows_touched = nullptr) const
+    {
+        sl_estimate_result r;
+        check(sl_query_session_estimate(q_, row, theta, max_rounds, &r));
+        if (error_l1) *error_l1 = r.residual_l1;
+        if (rows_touched) *rows_touched = r.rows_touched;
+        return r.estimate;
+    }
+
+private:
+    sl_query_session *q_ = nullptr;
+};
+
+// OptimizedConjugateGradientSolver (optimized_solver.rs:167-295; config defaults :119-127) / FastConjugateGradient
+// (fast_solver.rs:110-178) over sl_cg_solve
+class ConjugateGradientSolver {
+public:
+    explicit ConjugateGradientSolver(size_t max_iterations = 1000, Precision tolerance = 1e-6) : max_iterations_(max_iterations), tolerance_(tolerance) {}
+    SolverResult solve(const SparseMatrix &matrix, const std::vector<Precision> &b) const
+    {
+        if (b.size() != matrix.rows()) throw SolverError(SL_DIMENSION_MISMATCH, "Right-hand side vector length must match matrix size");
+        sl_cg_options o;
+        sl_cg_options_default(&o);
+        o.tolerance = tolerance_; o.max_iterations = max_iterations_;
+        SolverResult out;
+        out.solution.resize(matrix.rows());
+        sl_cg_result r;
+        check(sl_cg_solve(matrix.handle(), b.data(), &o, out.solution.data(), &r));
+        out.residual_norm = r.residual_norm; out.iterations = r.iterations; out.converged = r.converged != 0;
+        return out;
+    }
+
+private:
+    size_t max_iterations_;
+    Precision tolerance_;
+};
+
 } // namespace sublinear

@@ -41,6 +41,19 @@ int main()
     double err = 0;
     const double e1 = PushSolver(1e-12).query_single_entry(a, {5.0, 4.0}, 1, &err);
     EXPECT(std::fabs(e1 - 1.0) < 1e-9);
+    // the ForwardPushSolver object: setup once, query after query, same answers as the one-shot call and as the solve
+    {
+        QuerySession session(a, {5.0, 4.0});
+        for (int rep = 0; rep < 3; ++rep) {
+            size_t touched = 0;
+            EXPECT(std::fabs(session.query_single_entry(0, 1e-12, 100000, &err, &touched) - 1.0) < 1e-9 && touched > 0);
+            EXPECT(session.query_single_entry(1, 1e-12) == e1);
+        }
+    }
+    // CG on a symmetric positive definite system (optimized_solver.rs tests: 2x2 SPD)
+    auto spd = SparseMatrix::from_triplets({{0, 0, 4.0}, {0, 1, 1.0}, {1, 0, 1.0}, {1, 1, 3.0}}, 2, 2);
+    auto c = ConjugateGradientSolver(100, 1e-10).solve(spd, {1.0, 2.0});
+    EXPECT(c.converged && std::fabs(c.solution[0] - 1.0 / 11.0) < 1e-9 && std::fabs(c.solution[1] - 7.0 / 11.0) < 1e-9);
     std::printf("cpp host mirror ok\n");
     return 0;
 }
