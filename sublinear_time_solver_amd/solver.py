@@ -14,8 +14,7 @@ All compute happens in libsublinear_hip.so; this file only marshals arguments.
 from __future__ import annotations
 
 import ctypes as C
-import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Sequence
 
 import numpy as np
