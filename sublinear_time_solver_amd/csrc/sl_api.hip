@@ -40,6 +40,20 @@ void *sl_scratch(size_t bytes)
     return c.scratch;
 }
 
+bool sl_side_stream(sl_ctx &c)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (c.side && c.side_device == dev) return true;
+    if (c.side) { (void)hipStreamDestroy(c.side); (void)hipEventDestroy(c.ev_fork); (void)hipEventDestroy(c.ev_join); c.side = nullptr; }
+    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) { c.side = nullptr; return false; }
+    if (hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(c.side); c.side = nullptr; return false;
+    }
+    c.side_device = dev;
+    return true;
+}
+
 // ---- workspace pool --------------------------------------------------------------------------
 static size_t ws_cache_limit()
 {

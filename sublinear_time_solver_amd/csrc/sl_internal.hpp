@@ -65,7 +65,12 @@ struct sl_ctx {
     // workspace pool (sl_ws_alloc / sl_ws_free)
     struct ws_block { void *p; size_t bytes; int device; bool in_use; };
     std::vector<ws_block> ws;
+    // side stream + fork / join events: the long-row kernel of a launch runs beside the slice kernel (sl_kernels.hip)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int side_device = -1;
 };
+bool sl_side_stream(sl_ctx &c);      // lazily creates the side stream / events for the current device; false if that failed
 sl_ctx &sl_context();
 sl_status sl_fail(sl_status s, const char *fmt, ...);
 void *sl_scratch(size_t bytes); // nullptr on failure

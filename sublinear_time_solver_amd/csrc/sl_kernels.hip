@@ -657,6 +657,18 @@ uint32_t sl_row_grid(uint64_t n_slices)
 #define SL_BAND_MAX_LDS (80u * 1024u)      // two blocks per CU (160 KiB LDS)
 #define SL_BAND_MAX_LDS_ONE (158u * 1024u)  // one 16-wave block per CU: windows up to w ~ 9500 (leaves room for the static arrays)
 struct band_geom { uint32_t spw, lds, nw; bool pipe, c16; };
+// matrices with at least this many slices run their long-row kernel beside the slice kernel (env SL_LONG_ROWS_BESIDE_MIN; tests use 0)
+static uint64_t long_rows_beside_min()
+{
+    static long long v = -1;
+    if (v < 0) {
+        const char *e = getenv("SL_LONG_ROWS_BESIDE_MIN");
+        v = e ? atoll(e) : 16384;
+        if (getenv("SL_LONG_ROWS_SERIAL") && getenv("SL_LONG_ROWS_SERIAL")[0] == '1') v = (long long)1 << 62;
+    }
+    return (uint64_t)v;
+}
+
 static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool nw8_pays)
 {
     static int disabled = -1, forced_spw = 0, forced_pipe = -1, c16_off = 0, forced_nw = 0;
@@ -740,6 +752,13 @@ template <int ORDER, int EPI>
 static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t *nparts)
 {
     sl_row_args a = a_in;
+    if (a.n_long && a.n_slices >= long_rows_beside_min()) {          // fork point for the long-row kernel (see the end of this function)
+        sl_ctx &c = sl_context();
+        if (sl_side_stream(c)) {
+            SL_HIP(hipEventRecord(c.ev_fork, s));
+            SL_HIP(hipStreamWaitEvent(c.side, c.ev_fork, 0));
+        }
+    }
     const bool uniform_unrolled = ORDER == 0 && (a.uniform_width == 16 || a.uniform_width == 8);
     // a uniform-width matrix carries its 16-bit offsets in the OCTET layout of the unrolled path; when it runs through
     // the batched path instead (simd4 order), that path — which reads the QUAD layout — uses the u32 columns
@@ -774,8 +793,21 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
         else
             hipLaunchKernelGGL((sl_rows_kernel<ORDER, EPI, 0>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
     }
-    if (a.n_long)
-        hipLaunchKernelGGL((sl_long_rows_kernel<ORDER, EPI>), dim3(a.n_long), dim3(SL_BLOCK), 0, s, a, *nparts - a.n_long);
+    if (a.n_long) {
+        // hub rows: one block per row with a sequential add chain (10^4..10^5 entries: 0.1 ms and more).  On large matrices it
+        // runs BESIDE the slice kernel on a side stream — same inputs, disjoint rows and partial slots; the launches that follow
+        // on `s` (final reduction, next step) are ordered behind both by the join event.
+        sl_ctx &c = sl_context();
+        const bool beside = a.n_slices >= long_rows_beside_min() && sl_side_stream(c);
+        if (beside) {
+            // fork point = everything enqueued on s BEFORE the slice kernel of this launch; it was recorded by the caller below
+            hipLaunchKernelGGL((sl_long_rows_kernel<ORDER, EPI>), dim3(a.n_long), dim3(SL_BLOCK), 0, c.side, a, *nparts - a.n_long);
+            SL_HIP(hipEventRecord(c.ev_join, c.side));
+            SL_HIP(hipStreamWaitEvent(s, c.ev_join, 0));
+        } else {
+            hipLaunchKernelGGL((sl_long_rows_kernel<ORDER, EPI>), dim3(a.n_long), dim3(SL_BLOCK), 0, s, a, *nparts - a.n_long);
+        }
+    }
     SL_HIP(hipGetLastError());
     return SL_OK;
 }

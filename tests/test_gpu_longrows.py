@@ -152,3 +152,17 @@ def test_duplicate_entries_in_hit_driven_sparse_rounds(gpu, order):
     assert p["dense_rounds"] == 0 and p["rounds"] == q["rounds"] == 7 and (p["frontier_log"] == q["frontier_log"]).all()
     assert np.isfinite(q["x"]).all() and _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])
     assert _bits_equal(m.diagonal_inverse(), np.array([1.0 / O.csr_get(rp, ci, va, i, i) for i in range(n)]))
+
+
+def test_long_rows_beside_the_slice_kernel(gpu):
+    """large matrices run their long-row kernel on a side stream beside the slice kernel; here that mode is forced on for the
+    small test systems (SL_LONG_ROWS_BESIDE_MIN=0, read once per process) and the bitwise tests above are repeated"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__)), "-x", "-q", "-k", "both_orders or push_bitwise or hub_columns"],
+                       cwd=root, capture_output=True, text=True, timeout=900, env=dict(os.environ, SL_LONG_ROWS_BESIDE_MIN="0"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
