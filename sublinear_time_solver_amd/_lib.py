@@ -31,7 +31,7 @@ vp = C.c_void_p
 class MatrixInfo(C.Structure):
     _fields_ = [("n_rows", u64), ("n_cols", u64), ("nnz", u64), ("row_offset", u64), ("padded_nnz", u64),
                 ("n_slices", u64), ("device_bytes", u64), ("bandwidth", u64), ("max_row_nnz", u32), ("min_row_nnz", u32),
-                ("uniform_width", u32), ("has_transpose", u32)]
+                ("uniform_width", u32), ("has_transpose", u32), ("long_row_threshold", u32), ("n_long_rows", u32)]
 
 
 class NeumannOptions(C.Structure):

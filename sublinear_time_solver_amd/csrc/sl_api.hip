@@ -317,6 +317,8 @@ sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info)
     info->padded_nnz = m->padded_nnz; info->n_slices = m->n_slices; info->device_bytes = m->device_bytes; info->bandwidth = m->bandwidth;
     info->max_row_nnz = m->max_row_nnz; info->min_row_nnz = m->min_row_nnz; info->uniform_width = m->uniform_width;
     info->has_transpose = m->d_tptr != nullptr;
+    info->long_row_threshold = m->long_row;
+    info->n_long_rows = (uint32_t)m->n_long;
     return SL_OK;
 }
 

@@ -23,9 +23,12 @@
 #define SL_BLOCK 256
 #endif
 #define SL_WAVES_PER_BLOCK (SL_BLOCK / SL_SLICE)
-// rows longer than this leave the slice layout (one hub row would stretch its whole 64-row slice): they are
-// reduced by the long-row kernel, one block per row, products in parallel, additions in the reference order
+// upper limit of the per-matrix long-row threshold (sl_matrix::long_row): longer rows leave the slice layout (one hub row would
+// stretch its whole 64-row slice) and are reduced by the long-row kernel, one block per row, products in parallel, additions in
+// the reference order
+#ifndef SL_LONG_ROW
 #define SL_LONG_ROW 256u
+#endif
 #define SL_LONG_SENTINEL 0xffffffffu   // row_len[] value of such a row
 
 struct sl_matrix {
@@ -40,6 +43,7 @@ struct sl_matrix {
     uint16_t *d_cols16 = nullptr;    // [padded_nnz] col - row as int16 (uniform-width band matrices only)
     double *d_vals = nullptr;        // [padded_nnz]
     uint32_t max_row_nnz = 0, min_row_nnz = 0, uniform_width = 0;
+    uint32_t long_row = SL_LONG_ROW;   // rows with more entries than this are served by the long-row kernel (per matrix: 4 x mean, in [32, 256])
     uint64_t bandwidth = 0;          // max |col - (row_offset + row)| over stored entries
     // raw CSR (SL_MATRIX_KEEP_CSR or needed by the sparse-frontier kernels)
     uint32_t *d_row_ptr = nullptr, *d_col_idx = nullptr;

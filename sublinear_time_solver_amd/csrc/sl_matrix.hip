@@ -22,7 +22,7 @@ __global__ void sl_validate_csr_kernel(uint64_t n_rows, uint64_t n_cols, uint64_
 }
 
 // row lengths + slice widths (in pair blocks) + min/max row length
-__global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64_t n_slices, const uint32_t *row_ptr,
+__global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64_t n_slices, uint32_t long_row, const uint32_t *row_ptr,
                                                          uint32_t *row_len, uint32_t *slice_w, uint32_t *minmax)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -33,9 +33,9 @@ __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64
         len = row_ptr[i + 1] - row_ptr[i];
         atomicMin(&minmax[0], len);
         atomicMax(&minmax[1], len);
-        if (len > SL_LONG_ROW) atomicAdd(&minmax[2], 1u);
+        if (len > long_row) atomicAdd(&minmax[2], 1u);
     }
-    const bool is_long = len > SL_LONG_ROW;          // leaves the slice layout (sl_long_rows_kernel owns it)
+    const bool is_long = len > long_row;             // leaves the slice layout (sl_long_rows_kernel owns it)
     row_len[i] = is_long ? SL_LONG_SENTINEL : len;
     uint32_t mx = is_long ? 0u : len;
 #pragma unroll
@@ -265,6 +265,14 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     if (h_err & 1u) { hipFree(d_err); return sl_fail(SL_INVALID_SPARSE_MATRIX, "row_ptr is not a monotone 0..nnz prefix array"); }
     if (h_err & 2u) { hipFree(d_err); return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "column index >= n_cols (%llu)", (unsigned long long)m->n_cols); }
 
+    // rows far longer than the typical row leave the slice layout (one of them would stretch its whole 64-row slice): 4 x the mean
+    // length, within [32, 256].  Measured on the 10^7-node power-law graph (mean 10.9): threshold 256 -> 32 takes the full PageRank
+    // solve from 0.73 to 0.59 s; 16 is too low (0.76 s: too many one-block rows).  Uniform systems are unaffected.
+    {
+        const uint64_t mean4 = n ? (4 * nnz + n - 1) / n : 0;
+        m->long_row = (uint32_t)(mean4 < 32 ? 32 : (mean4 > SL_LONG_ROW ? SL_LONG_ROW : mean4));
+        if (const char *e = getenv("SL_LONG_ROW_MIN")) m->long_row = (uint32_t)atoi(e);      // experiments
+    }
     // 2. row lengths, slice widths
     const uint64_t padded_rows = m->n_slices * SL_SLICE;
     uint32_t *d_slice_w = nullptr;
@@ -273,7 +281,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     const uint32_t mm_init[4] = {0xffffffffu, 0u, 0u, 0u};
     SL_HIP(hipMemcpyAsync(d_err, mm_init, sizeof(mm_init), hipMemcpyHostToDevice, st));
     if (m->n_slices)
-        hipLaunchKernelGGL(sl_row_len_kernel, dim3((uint32_t)((padded_rows + 255) / 256)), dim3(256), 0, st, n, m->n_slices,
+        hipLaunchKernelGGL(sl_row_len_kernel, dim3((uint32_t)((padded_rows + 255) / 256)), dim3(256), 0, st, n, m->n_slices, m->long_row,
                            d_row_ptr, m->d_row_len, d_slice_w, d_err);
     std::vector<uint32_t> slice_w(m->n_slices), slice_ptr(m->n_slices + 1);
     uint32_t mm[4];

@@ -44,8 +44,10 @@ def test_random_systems_bitwise(gpu, n, w, max_len, long_rows):
     m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
     lens = np.diff(rp.astype(np.int64))
     dist = np.abs(ci.astype(np.int64) - np.repeat(np.arange(n), lens))
-    short = np.repeat(lens <= 256, lens)                             # rows beyond 256 entries live outside the slice layout
-    assert m.info().bandwidth == int(dist[short].max(initial=0))
+    info = m.info()
+    assert 32 <= info.long_row_threshold <= 256 and info.n_long_rows == int((lens > info.long_row_threshold).sum())
+    short = np.repeat(lens <= info.long_row_threshold, lens)        # longer rows live outside the slice layout
+    assert info.bandwidth == int(dist[short].max(initial=0))
     x = rng.standard_normal(n)
     b = rng.standard_normal(n)
     bs = b * (rng.random(n) < 0.02)                                   # sparse right-hand side: local pushes
