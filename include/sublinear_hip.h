@@ -115,7 +115,7 @@ typedef struct {
     uint32_t max_row_nnz, min_row_nnz;
     uint32_t uniform_width;   /* != 0: every row has exactly this many entries */
     uint32_t has_transpose;
-    uint32_t long_row_threshold; /* rows with more entries than this are served by the long-row kernel (4 x mean length, in [32, 256]) */
+    uint32_t long_row_threshold; /* rows with more entries than this are served by the long-row kernel (2.5 x mean length, in [24, 256]) */
     uint32_t n_long_rows;
 } sl_matrix_info;
 sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info);

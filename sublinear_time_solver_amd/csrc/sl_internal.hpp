@@ -43,7 +43,7 @@ struct sl_matrix {
     uint16_t *d_cols16 = nullptr;    // [padded_nnz] col - row as int16 (uniform-width band matrices only)
     double *d_vals = nullptr;        // [padded_nnz]
     uint32_t max_row_nnz = 0, min_row_nnz = 0, uniform_width = 0;
-    uint32_t long_row = SL_LONG_ROW;   // rows with more entries than this are served by the long-row kernel (per matrix: 4 x mean, in [32, 256])
+    uint32_t long_row = SL_LONG_ROW;   // rows with more entries than this are served by the long-row kernel (per matrix: 2.5 x mean, in [24, 256])
     uint64_t bandwidth = 0;          // max |col - (row_offset + row)| over stored entries
     // raw CSR (SL_MATRIX_KEEP_CSR or needed by the sparse-frontier kernels)
     uint32_t *d_row_ptr = nullptr, *d_col_idx = nullptr;

@@ -265,12 +265,12 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     if (h_err & 1u) { hipFree(d_err); return sl_fail(SL_INVALID_SPARSE_MATRIX, "row_ptr is not a monotone 0..nnz prefix array"); }
     if (h_err & 2u) { hipFree(d_err); return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "column index >= n_cols (%llu)", (unsigned long long)m->n_cols); }
 
-    // rows far longer than the typical row leave the slice layout (one of them would stretch its whole 64-row slice): 4 x the mean
-    // length, within [32, 256].  Measured on the 10^7-node power-law graph (mean 10.9): threshold 256 -> 32 takes the full PageRank
-    // solve from 0.73 to 0.59 s; 16 is too low (0.76 s: too many one-block rows).  Uniform systems are unaffected.
+    // rows far longer than the typical row leave the slice layout (one of them would stretch its whole 64-row slice): 2.5 x the
+    // mean length, within [24, 256].  Measured on the 10^7-node power-law graph (mean 10.9) — full PageRank solve by threshold:
+    // 256: 0.73 s, 44: 0.62, 32: 0.59, 28 / 24: 0.58, 16: 0.76 (too many one-block rows).  Uniform systems are unaffected.
     {
-        const uint64_t mean4 = n ? (4 * nnz + n - 1) / n : 0;
-        m->long_row = (uint32_t)(mean4 < 32 ? 32 : (mean4 > SL_LONG_ROW ? SL_LONG_ROW : mean4));
+        const uint64_t scaled = n ? (5 * nnz + 2 * n - 1) / (2 * n) : 0;
+        m->long_row = (uint32_t)(scaled < 24 ? 24 : (scaled > SL_LONG_ROW ? SL_LONG_ROW : scaled));
         if (const char *e = getenv("SL_LONG_ROW_MIN")) m->long_row = (uint32_t)atoi(e);      // experiments
     }
     // 2. row lengths, slice widths

@@ -45,7 +45,7 @@ def test_random_systems_bitwise(gpu, n, w, max_len, long_rows):
     lens = np.diff(rp.astype(np.int64))
     dist = np.abs(ci.astype(np.int64) - np.repeat(np.arange(n), lens))
     info = m.info()
-    assert 32 <= info.long_row_threshold <= 256 and info.n_long_rows == int((lens > info.long_row_threshold).sum())
+    assert 24 <= info.long_row_threshold <= 256 and info.n_long_rows == int((lens > info.long_row_threshold).sum())
     short = np.repeat(lens <= info.long_row_threshold, lens)        # longer rows live outside the slice layout
     assert info.bandwidth == int(dist[short].max(initial=0))
     x = rng.standard_normal(n)
