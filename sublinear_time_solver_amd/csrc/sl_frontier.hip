@@ -553,12 +553,15 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     const unsigned long long hit_limit = dense_switch >= 1.0 ? ps.rec_cap
                                          : std::min<unsigned long long>(ps.rec_cap, std::max<unsigned long long>(ps.op_nnz / 32, 4096));
     bool force_dense = false, need_log = true;
+    const double mean_col = n ? (double)ps.op_nnz / (double)n : 0.0;
 
     sl_status st = SL_OK;
     while (rs.rounds < max_rounds) {
         if (list_valid && need_log) { SL_TRY(plog.append(ps, ps.frontier[0], nf, list_sorted, s)); need_log = false; }
         if (nf == 0) { rs.converged = true; break; }
-        const bool dense = force_dense || (double)nf > dense_switch * (double)n;
+        // dense when the frontier is large — by rows, or by the column entries it is expected to cover (|F| x mean column length
+        // against the limit the device-side gate of a sparse batch would trip on: no point enqueueing that batch)
+        const bool dense = force_dense || (double)nf > dense_switch * (double)n || (dense_switch < 1.0 && (double)nf * mean_col > (double)hit_limit);
         force_dense = false;
         if (dense) {
             uint32_t nf_next = 0;
@@ -579,7 +582,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
             rs.rounds += 1; rs.pushes += nf; rs.rows_touched += n; rs.dense_rounds += 1;
             ps.flooded = true;
             cur = 1 - cur;                       // delta[cur] now dense-valid; delta[1-cur] holds stale values
-            const bool next_dense_likely = m && (double)nf_next > dense_switch * (double)n && !plog.log;
+            const bool next_dense_likely = m && !plog.log && ((double)nf_next > dense_switch * (double)n || (dense_switch < 1.0 && (double)nf_next * mean_col > (double)hit_limit));
             if (next_dense_likely) { nf = nf_next; list_valid = false; continue; } // no list needed: the dense kernel overwrites everything
             SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s));
             SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s));
