@@ -431,7 +431,7 @@ sl_status sl_neumann_step(const sl_matrix *m, const double *dinv, const double *
     double *scr = static_cast<double *>(sl_scratch(partial_bytes(m)));
     if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
     sl_row_args a = row_args(m);
-    a.gather = t_in; a.dinv = dinv; a.out = t_out; a.x = x; a.partials = scr; a.result = norm2;
+    a.gather = t_in; a.dinv = dinv; a.out = t_out; a.x = x; a.partials = scr; a.partials_slack = 4096; a.result = norm2;
     return sl_launch_rows(a, order, SL_EPI_NEUMANN, sl_context().stream);
 }
 
@@ -464,7 +464,7 @@ sl_status sl_residual_norm2(const sl_matrix *m, const double *x_full, const doub
     double *scr = static_cast<double *>(sl_scratch(partial_bytes(m)));
     if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
     sl_row_args a = row_args(m);
-    a.gather = x_full; a.aux = rhs; a.out = r_out; a.partials = scr; a.result = norm2;
+    a.gather = x_full; a.aux = rhs; a.out = r_out; a.partials = scr; a.partials_slack = 4096; a.result = norm2;
     return sl_launch_rows(a, order, SL_EPI_RESIDUAL, sl_context().stream);
 }
 
@@ -551,7 +551,7 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
     auto is_converged = [&]() { return (resn <= o->tolerance) || (series_conv && !(terms >= o->max_terms)); };
     auto update_residual = [&]() -> sl_status {                                         // neumann.rs:302-318
         sl_row_args a = row_args(m);
-        a.gather = x.as<double>(); a.aux = res_rhs; a.out = nullptr; a.partials = scr; a.result = d_res;
+        a.gather = x.as<double>(); a.aux = res_rhs; a.out = nullptr; a.partials = scr; a.partials_slack = 4096; a.result = d_res;
         SL_TRY(sl_launch_rows(a, order, SL_EPI_RESIDUAL, s));
         double h;
         SL_TRY(read_scalars(d_res, &h, 1));
@@ -589,7 +589,7 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
                 if (p_terms > 0) {
                     sl_row_args a = row_args(m);
                     a.gather = p_cur; a.dinv = dinv.as<double>(); a.out = p_nxt; a.x = x.as<double>();
-                    a.partials = scr; a.result = nullptr;
+                    a.partials = scr; a.partials_slack = 4096; a.result = nullptr;
                     a.ctl = d_ctl; a.gate_it = rel; a.ctl_slot = (uint32_t)plan.size(); a.ctl_mode = SL_JUDGE_LT; a.ctl_threshold = thr_series;
                     status = sl_launch_rows(a, order, SL_EPI_NEUMANN, s);
                     std::swap(p_cur, p_nxt);
@@ -604,7 +604,7 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
             }
             if (pit % 5 == 0 && status == SL_OK) {                                       // update_residual :302-318, :489-491
                 sl_row_args a = row_args(m);
-                a.gather = x.as<double>(); a.aux = res_rhs; a.out = nullptr; a.partials = scr; a.result = nullptr;
+                a.gather = x.as<double>(); a.aux = res_rhs; a.out = nullptr; a.partials = scr; a.partials_slack = 4096; a.result = nullptr;
                 a.ctl = d_ctl; a.gate_it = rel; a.ctl_slot = (uint32_t)plan.size(); a.ctl_mode = SL_JUDGE_LE_OR_NONFINITE; a.ctl_threshold = thr_tol;
                 status = sl_launch_rows(a, order, SL_EPI_RESIDUAL, s);
                 plan.push_back({2, nullptr});

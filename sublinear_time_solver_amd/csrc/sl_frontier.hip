@@ -568,7 +568,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
             if (m) {
                 sl_row_args a = sl_matrix_row_args(m);
                 a.gather = ps.delta[cur]; a.dinv = ps.dinv; a.out = ps.delta[1 - cur]; a.x = ps.x; a.r = ps.r; a.theta = theta;
-                a.partials = scr; a.result = resbuf.as<double>();
+                a.partials = scr; a.partials_slack = 4096; a.result = resbuf.as<double>();
                 st = sl_launch_rows(a, (sl_order)order, SL_EPI_PUSH, s);
                 if (st != SL_OK) break;
                 double h[2];

@@ -199,6 +199,7 @@ struct sl_row_args {
     double *r;            // PUSH: r in/out
     double theta;         // PUSH
     double *partials;     // per-block partial sums (norm^2); PUSH: also counts at partials + nblocks (as u64)
+    uint32_t partials_slack; // doubles available behind the two partial sets (>= 512 enables the two-stage reduction of very many partials)
     double *result;       // device scalar(s): [0] = sum of squares, PUSH: [1] = frontier count (as double bits u64)
     // speculative solve loop (null ctl = plain launch)
     sl_solve_ctl *ctl;

@@ -585,6 +585,24 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_long_rows_kernel(sl_row_args a, u
     }
 }
 
+// very many partials (one per long row of a 10^7-node graph: ~10^6): a first stage of SL_PRE_BLOCKS blocks brings each set down to
+// SL_PRE_BLOCKS values (thread t of block b sums partials b*256+t, +SL_PRE_BLOCKS*256, ... in order; fixed butterfly), the
+// one-block kernels below finish.  Same mapping every time: deterministic.
+#define SL_PRE_BLOCKS 128
+#define SL_PRE_THRESHOLD 65536u
+__global__ __launch_bounds__(256) void sl_pre_reduce_kernel(const double *partials, uint32_t nparts, double *out, const sl_solve_ctl *ctl, uint32_t gate_it)
+{
+    __shared__ double red[4];
+    if (ctl && gate_it > ctl->stop_after) return;
+    const double *p = partials + (uint64_t)blockIdx.y * nparts;
+    double acc = 0.0;
+    for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < nparts; j += SL_PRE_BLOCKS * 256) acc += p[j];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.y * SL_PRE_BLOCKS + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 // fixed-order final reduction of per-block partials: thread j sums partials j, j+1024, ...
 // sequentially, then a fixed butterfly.  nsets independent sets laid out back to back.
 __global__ __launch_bounds__(1024) void sl_final_reduce_kernel(const double *partials, uint32_t nparts,
@@ -833,12 +851,20 @@ sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, 
     }
     if (st != SL_OK) return st;
     if (n_partials) *n_partials = nparts;
+    const double *parts = a.partials;
+    if (epi != SL_EPI_SPMV && (a.ctl || a.result) && nparts > SL_PRE_THRESHOLD && a.partials_slack >= 2 * SL_PRE_BLOCKS) {
+        const int nsets = epi == SL_EPI_PUSH ? 2 : 1;
+        double *stage = a.partials + 2 * (uint64_t)nparts;             // the slack behind the partial sets
+        hipLaunchKernelGGL(sl_pre_reduce_kernel, dim3(SL_PRE_BLOCKS, nsets), dim3(256), 0, s, a.partials, nparts, stage, a.ctl, a.gate_it);
+        parts = stage;
+        nparts = SL_PRE_BLOCKS;
+    }
     if (epi != SL_EPI_SPMV && a.ctl) {
-        hipLaunchKernelGGL(sl_judge_reduce_kernel, dim3(1), dim3(1024), 0, s, a.partials, nparts, a.result, a.ctl, a.gate_it,
+        hipLaunchKernelGGL(sl_judge_reduce_kernel, dim3(1), dim3(1024), 0, s, parts, nparts, a.result, a.ctl, a.gate_it,
                            a.ctl_slot, a.ctl_mode, a.ctl_threshold);
         SL_HIP(hipGetLastError());
     } else if (epi != SL_EPI_SPMV && a.result) {
-        hipLaunchKernelGGL(sl_final_reduce_kernel, dim3(1), dim3(1024), 0, s, a.partials, nparts, a.result,
+        hipLaunchKernelGGL(sl_final_reduce_kernel, dim3(1), dim3(1024), 0, s, parts, nparts, a.result,
                            epi == SL_EPI_PUSH ? 2 : 1);
         SL_HIP(hipGetLastError());
     }
