@@ -544,7 +544,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     SL_TRY(resbuf.alloc(64));
 
     static int sparse_batch = -1;
-    if (sparse_batch < 0) { const char *e = getenv("SL_PUSH_BATCH"); sparse_batch = e ? atoi(e) : 8; if (sparse_batch < 1) sparse_batch = 1; }
+    if (sparse_batch < 0) { const char *e = getenv("SL_PUSH_BATCH"); sparse_batch = e ? atoi(e) : 12; if (sparse_batch < 1) sparse_batch = 1; }
     const double dense_limit = dense_switch * (double)n;               // nf > dense_limit  <=>  nf > floor(dense_limit)
     const uint32_t dense_threshold = dense_limit >= 4294967295.0 ? 0xffffffffu : (dense_limit > 0.0 ? (uint32_t)dense_limit : 0u);
 
@@ -553,6 +553,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     const unsigned long long hit_limit = dense_switch >= 1.0 ? ps.rec_cap
                                          : std::min<unsigned long long>(ps.rec_cap, std::max<unsigned long long>(ps.op_nnz / 32, 4096));
     bool force_dense = false, need_log = true;
+    int sparse_batches_done = 0;
     const double mean_col = n ? (double)ps.op_nnz / (double)n : 0.0;
 
     sl_status st = SL_OK;
@@ -591,7 +592,10 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
             if (!list_valid) { SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s)); list_valid = true; list_sorted = true; need_log = true;
                                SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s)); }
             // a batch of device-driven sparse rounds (one round when the frontier lists are being logged)
-            uint64_t batch = plog.log ? 1 : (uint64_t)sparse_batch;
+            // the first batch is the long one; a query that outlives it usually needs a few rounds more, and every round enqueued
+            // past the stop still costs five empty launches
+            uint64_t batch = plog.log ? 1 : (uint64_t)(sparse_batches_done == 0 ? sparse_batch : std::max(sparse_batch / 2, 1));
+            ++sparse_batches_done;
             if (batch > max_rounds - rs.rounds) batch = max_rounds - rs.rounds;
             hipLaunchKernelGGL(sl_push_ctl_reset_kernel, dim3(1), dim3(1), 0, s, ps.ctl, nf);
             hipLaunchKernelGGL(sl_frontier_hits_kernel, dim3((uint32_t)std::min<uint64_t>((nf + 255) / 256, 512)), dim3(256), 0, s, ps.ctl, ps.frontier[0], ps.op.tptr);
