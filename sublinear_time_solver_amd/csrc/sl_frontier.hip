@@ -549,9 +549,11 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     const uint32_t dense_threshold = dense_limit >= 4294967295.0 ? 0xffffffffu : (dense_limit > 0.0 ? (uint32_t)dense_limit : 0u);
 
     // a sparse round costs ~40x a dense round per matrix entry it touches (records, atomics, random sectors)
+    static unsigned long long hit_div = 0;
+    if (!hit_div) { const char *e = getenv("SL_PUSH_HIT_DIV"); hit_div = e ? strtoull(e, nullptr, 10) : 32; if (!hit_div) hit_div = 32; }
     // (dense_switch >= 1: the caller asked for sparse rounds throughout; only the record buffer limits them)
     const unsigned long long hit_limit = dense_switch >= 1.0 ? ps.rec_cap
-                                         : std::min<unsigned long long>(ps.rec_cap, std::max<unsigned long long>(ps.op_nnz / 32, 4096));
+                                         : std::min<unsigned long long>(ps.rec_cap, std::max<unsigned long long>(ps.op_nnz / hit_div, 4096));
     bool force_dense = false, need_log = true;
     int sparse_batches_done = 0;
     const double mean_col = n ? (double)ps.op_nnz / (double)n : 0.0;
