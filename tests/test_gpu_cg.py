@@ -66,3 +66,24 @@ def test_cg_on_sdd_system_agrees_with_neumann(gpu):
     assert c.converged
     nm = S.NeumannSolver(max_terms=500, series_tolerance=1e-14).solve(m, b, S.SolverOptions(tolerance=1e-11))
     np.testing.assert_allclose(c.solution, nm.solution, atol=1e-7)
+
+
+def test_g8_gpu_cg_matches_the_reference_js_twin(gpu):
+    """the GPU CG against the golden vectors of the reference's runnable JS FastConjugateGradient (tests/golden/reference_cg.npz)"""
+    from pathlib import Path
+    z = np.load(Path(__file__).resolve().parent / "golden" / "reference_cg.npz")
+    tol = float(z["__tol"][0])
+    for ck in (str(c) for c in z["__cases"]):
+        key = ck.rsplit("__", 1)[0]
+        rp, ci, va, b = z[f"{key}__row_ptr"], z[f"{key}__col_idx"], z[f"{key}__values"], z[f"{ck}__b"]
+        n = b.size
+        m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+        r = S.ConjugateGradientSolver(max_iterations=1000, tolerance=tol).solve(m, b)
+        xj, pj = z[f"{ck}__js_x"], int(z[f"{ck}__js_products"][0])
+        scale = np.abs(xj).max()
+        if pj < 100:
+            assert abs(int(r.stats["matvec_count"]) - pj) <= 1, (ck, r.stats["matvec_count"], pj)     # tree-reduced dots: +-1 at a threshold
+            assert np.abs(r.solution - xj).max() <= 1e-9 * scale, ck
+        else:
+            assert abs(int(r.stats["matvec_count"]) - pj) <= pj // 20, (ck, r.stats["matvec_count"], pj)
+            assert np.abs(r.solution - xj).max() <= 1e-5 * scale, ck
