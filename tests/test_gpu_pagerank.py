@@ -123,3 +123,21 @@ def test_c4_full_size_pagerank_queries(gpu):
                 assert (e2.estimate, e2.residual_l1, e2.rounds, e2.pushes) == (e.estimate, e.residual_l1, e.rounds, e.pushes)
         local = q.estimate(n - 1, theta=1e-5)
         assert local.rows_touched < n // 50                       # a local query: < 2 % of the rows over all its rounds
+
+
+def test_g9_gpu_pagerank_matches_the_reference_power_iteration(gpu):
+    """the same goldens (reference Python power iteration, tests/golden/reference_pagerank.npz) through the GPU push"""
+    import scipy.sparse as sp
+    from pathlib import Path
+    z = np.load(Path(__file__).resolve().parent / "golden" / "reference_pagerank.npz")
+    for key in (str(c) for c in z["__cases"]):
+        n, d = int(z[f"{key}__n"][0]), float(z[f"{key}__damping"][0])
+        A = sp.csr_matrix((z[f"{key}__vals"], (z[f"{key}__rows"].astype(np.int64), z[f"{key}__cols"].astype(np.int64))), shape=(n, n))
+        rp, ci, va, b = G.pagerank_system(n, A.indptr.astype(np.uint32), A.indices.astype(np.uint32), A.data, d)
+        m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+        g = S.PushSolver(theta=1e-18).solve(m, b)
+        ref = z[f"{key}__pagerank"]
+        assert g["converged"] and np.abs(g["solution"] - ref).max() <= 1e-13, key
+        top = int(np.argmax(ref))
+        e = S.estimate_entry(m, b, top, theta=1e-16)
+        assert abs(e.estimate - ref[top]) <= 1e-12

@@ -272,3 +272,20 @@ def test_random_walk_estimate_runs_and_is_seeded():
     m1 = O.ts_random_walk_estimate(rp, ci, va, b, 0, 0.1, 42)
     m2 = O.ts_random_walk_estimate(rp, ci, va, b, 0, 0.1, 42)
     assert m1 == m2 and m1[2] == 100
+
+
+def test_g9_pagerank_system_matches_the_reference_power_iteration():
+    """G9: the PageRank system of computePageRank (solver.ts:664-722), assembled by generators.pagerank_system and solved by the
+    oracle's thresholded push, against the fixed point of the reference's runnable power iteration
+    (scripts/pagerank/sublinear_pagerank.py:145-166; tests/golden/make_golden_pagerank.py): dangling nodes, self loops, weights, a hub"""
+    import scipy.sparse as sp
+    from pathlib import Path
+    from sublinear_time_solver_amd import generators as G
+    z = np.load(Path(__file__).resolve().parent / "golden" / "reference_pagerank.npz")
+    for key in (str(c) for c in z["__cases"]):
+        n, d = int(z[f"{key}__n"][0]), float(z[f"{key}__damping"][0])
+        A = sp.csr_matrix((z[f"{key}__vals"], (z[f"{key}__rows"].astype(np.int64), z[f"{key}__cols"].astype(np.int64))), shape=(n, n))
+        rp, ci, va, b = G.pagerank_system(n, A.indptr.astype(np.uint32), A.indices.astype(np.uint32), A.data, d)
+        r = O.push_sync_solve(rp, ci, va, b, theta=1e-18)
+        ref = z[f"{key}__pagerank"]
+        assert r["converged"] and np.abs(r["x"] - ref).max() <= 1e-13, (key, np.abs(r["x"] - ref).max())
