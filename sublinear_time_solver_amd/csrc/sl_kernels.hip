@@ -469,7 +469,18 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_ro
         const f64x2 *__restrict__ src2 = reinterpret_cast<const f64x2 *>(src);
         f64x2 *win2 = reinterpret_cast<f64x2 *>(win);
         const uint32_t pairs = len >> 1;
+#ifndef SL_NO_LDS_DMA
+        // the window is staged with direct global -> LDS loads (gfx950: 16 B per lane, no VGPR round trip): each wave moves 64 x 16 B
+        // = 1 KiB per instruction into consecutive LDS; +2 % at w = 4096 over load + ds_write, neutral for narrow windows
+        for (uint32_t p0 = wave * 64u; p0 < pairs; p0 += NW * 64) {
+            if (p0 + lane < pairs)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src2 + p0 + lane),
+                                                 (__attribute__((address_space(3))) void *)(win2 + p0), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         for (uint32_t p = threadIdx.x; p < pairs; p += NW * 64) win2[p] = src2[p];
+#endif
         if ((len & 1u) && threadIdx.x == 0) win[len - 1] = src[len - 1];
         __syncthreads();
         const double *lw = win;
