@@ -145,6 +145,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
+            os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # the small transfer kernels must not queue behind a 20 K-block launch
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -200,8 +201,19 @@ def main():
     t0[:n_global] = (1.0 + 0.001 * torch.remainder(idx, 1000.0)) * (1.0 / (10.0 + 0.01 * torch.remainder(idx, 1000.0)))
     del idx
     x = t0[part.lo:part.hi].clone()
-    exchange = D.AllGatherExchange(part) if w == 0 else D.HaloExchange(part, w)
-    drv = D.PartitionedNeumann(part, local_step, exchange, t0, x)
+    # SL_BENCH_LOOPBACK=1 (with SL_BENCH_FORCE_DIST=1 --force-split): MEASUREMENT mode on one GPU — the rank exchanges both
+    # boundary strips with itself over RCCL and all-reduces the norm, i.e. the full per-step enqueue path of an inner rank
+    loopback = force_dist and world == 1 and os.environ.get("SL_BENCH_LOOPBACK") == "1" and backend == "nccl"
+    exchange = D.AllGatherExchange(part) if w == 0 else D.HaloExchange(part, w, loopback=loopback)
+    # the norm log is all-reduced once per batch of 10 steps (= SL_SOLVE_BATCH of the speculative solve loop); 1 = every step
+    reduce_every = int(os.environ.get("SL_BENCH_REDUCE_EVERY", "10"))
+    drv = D.PartitionedNeumann(part, local_step, exchange, t0, x, reduce_every=reduce_every)
+    drv.reduce_always = loopback and os.environ.get("SL_BENCH_NO_ALLREDUCE") != "1"
+    if overlap and os.environ.get("SL_BENCH_HALO_WAIT") == "main":          # A/B knob: main stream waits for the strips every step
+        local_step.halo_wait_on_side = False
+    if overlap and os.environ.get("SL_BENCH_SERIAL_BOUNDARY") == "1":       # A/B knob: boundary pieces on the main stream, ahead of the interior
+        local_step.concurrent = False
+    reduce_norm = os.environ.get("SL_BENCH_NO_ALLREDUCE") != "1"             # A/B knob (measurement only)
 
     def barrier():
         if world > 1 or force_dist:
@@ -209,13 +221,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        drv.step()
+        drv.step(reduce_norm)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # library launches go to THIS stream
     t_start = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
-        drv.step()
+        drv.step(reduce_norm)
     ev1.record(stream)
     enqueue_s = time.perf_counter() - t_start        # host time to enqueue the K steps (no waiting unless the queue is full)
     barrier()
@@ -261,7 +273,8 @@ def main():
                                    "1xMI355X HBM roofline run (BASELINE configs[2])",
                        "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w,
                        "order": "csr_sequential" if args.order == 0 else "simd4",
-                       "exchange": (exchange.name + ("+overlap" if overlap else "")) if (world > 1 or overlap) else "none", "partition": f"rows{world}",
+                       "exchange": (exchange.name + ("+overlap" if overlap else "") + ("+loopback" if loopback else "")) if (world > 1 or overlap) else "none", "partition": f"rows{world}",
+                       "norm_allreduce_every": reduce_every if (world > 1 or loopback) else None,
                        "rows_iter_per_s": value / k, "last_term_norm": term_norm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -102,14 +102,30 @@ class HaloExchange:
     name = "halo"
     needs_only_boundary = True      # may start as soon as the boundary rows of the new term are written
 
-    def __init__(self, part: RowPartition, half_bandwidth: int, group=None):
+    def __init__(self, part: RowPartition, half_bandwidth: int, group=None, loopback: bool = False):
+        """loopback (MEASUREMENT mode, world size 1 with an initialised RCCL group): the rank sends both boundary strips to
+        ITSELF into scratch strips — same op list, same enqueue cost and same transfer kernels as a rank with two neighbours,
+        so the per-step host and device cost of the exchange can be measured on a one-GPU box."""
         if part.world > 1 and part.rows_per_rank < half_bandwidth:
             raise ValueError("halo exchange needs rows_per_rank >= w")
         self.part, self.w, self.group = part, int(half_bandwidth), group
+        self.loopback = bool(loopback) and part.world == 1
         self._ops = {}
+        self._scratch = None
 
     def start(self, t_full: torch.Tensor):
         p, w = self.part, self.w
+        if self.loopback and w > 0:
+            ops = self._ops.get(t_full.data_ptr())
+            if ops is None:
+                if self._scratch is None:
+                    self._scratch = torch.empty(2, w, dtype=t_full.dtype, device=t_full.device)
+                ops = [dist.P2POp(dist.isend, t_full[p.lo:p.lo + w], p.rank, group=self.group),
+                       dist.P2POp(dist.irecv, self._scratch[0], p.rank, group=self.group),
+                       dist.P2POp(dist.isend, t_full[p.hi - w:p.hi], p.rank, group=self.group),
+                       dist.P2POp(dist.irecv, self._scratch[1], p.rank, group=self.group)]
+                self._ops[t_full.data_ptr()] = ops
+            return dist.batch_isend_irecv(ops), ()
         if p.world == 1 or w == 0:
             return None
         staged = _staged(t_full, self.group)
@@ -234,81 +250,123 @@ class HipSplitStep:
         if self.side is None:
             self.side = torch.cuda.Stream(device=self.dinv.device, priority=-1)
         side = self.side
-        side.wait_stream(main)                       # t_in complete: the previous step's interior rows and halo are in place
+        side.wait_stream(main)                       # t_in complete: the previous step's interior rows are in place
         with torch.cuda.stream(side):
             self._use_stream(side)
+            if self._halo_pending is not None:       # the strips received during the previous step: only boundary rows read them
+                exchange.finish(self._halo_pending)
+                self._halo_pending = None
             self.run_boundary(t_in, t_out_local, x_local)
             handle = exchange.start(t_out)           # rides behind the boundary kernels
         self._use_stream(main)
         self._run(self.interior, t_in, t_out_local, x_local)
-        main.wait_stream(side)                       # boundary partial sums are final
+        main.wait_stream(side)                       # boundary rows and their partial sums are final
         self._L.check(self._lib.sl_reduce_partials(self.partials.data_ptr(), self._used, norm2_out.data_ptr()))
-        exchange.finish(handle)                      # main stream waits for the halo to land
+        if self.halo_wait_on_side:
+            self._halo_pending = handle              # interior rows never read the strips: the main stream does not wait for them
+        else:
+            exchange.finish(handle)
 
+    def flush(self, exchange) -> None:
+        """current stream waits for the strips still in flight (call before anything but the next step reads the term vector)"""
+        if self._halo_pending is not None:
+            exchange.finish(self._halo_pending)
+            self._halo_pending = None
+
+    halo_wait_on_side = True
+    _halo_pending = None
     side = None
 
 
 class PartitionedNeumann:
     """Ping-pong driver of the partitioned iteration: local fused step -> exchange -> norm all-reduce.
 
-    The 8-byte all-reduce of ||t||^2 is issued asynchronously into one of two result slots, so it
-    overlaps the next step's kernel; it is only waited for when the norm is read (term_norm) or when
-    its slot is about to be reused two steps later.  With a SplitStep the term exchange itself
-    overlaps the interior rows."""
+    Every step leaves its local ||t||^2 in the next row of a small device log; the log is all-reduced asynchronously
+    (it overlaps the following kernels) once per `reduce_every` steps — 1 = one 8-byte all-reduce per step, B > 1 = one
+    all-reduce of B rows per B steps, the batch of the speculative solve loop (the convergence replay
+    lags the device by a batch anyway).  A pending all-reduce is only waited for when a norm is read (term_norm) or
+    when its log is about to be reused two batches later.  With a SplitStep the term exchange overlaps the interior rows."""
 
     def __init__(self, part: RowPartition, local_step, exchange, t0_full: torch.Tensor,
-                 x_local: torch.Tensor, group=None):
+                 x_local: torch.Tensor, group=None, reduce_every: int = 1):
         self.part, self.local_step, self.exchange, self.group = part, local_step, exchange, group
         self.t = [t0_full, torch.zeros_like(t0_full)]
         self.x = x_local
         self.cur = 0
-        self._norm = [torch.zeros(2, dtype=torch.float64, device=t0_full.device) for _ in range(2)]
+        self.reduce_every = max(1, int(reduce_every))
+        self._norm = [torch.zeros(self.reduce_every, 2, dtype=torch.float64, device=t0_full.device) for _ in range(2)]
         self._pending = [None, None]
-        self._slot = 0
+        self._log, self._fill = 0, 0                   # log being filled, rows written
+        self._last = (0, 0)                            # (log, row) of the most recent step
         self.steps_done = 0
+        self.reduce_always = False                     # measurement mode: issue the norm all-reduce even at world size 1
 
     @property
     def norm2(self) -> torch.Tensor:
-        """result slot of the most recent step (valid after term_norm() / a wait)"""
-        return self._norm[self._slot]
+        """log row of the most recent step (globally summed after term_norm())"""
+        return self._norm[self._last[0]][self._last[1]]
+
+    def _close_log(self, reduce_norm: bool) -> None:
+        if self._fill == 0:
+            return
+        if reduce_norm and (self.part.world > 1 or self.reduce_always):
+            self._pending[self._log] = all_reduce_scalar(self._norm[self._log][:self._fill], dist.ReduceOp.SUM, self.group, async_op=True)
+        self._log, self._fill = 1 - self._log, 0
 
     def step(self, reduce_norm: bool = True) -> None:
         p = self.part
-        slot = 1 - self._slot
-        if self._pending[slot] is not None:            # the all-reduce that last used this slot must be done
-            self._pending[slot].wait()
-            self._pending[slot] = None
+        if self._fill == 0 and self._pending[self._log] is not None:   # the all-reduce that last used this log must be done
+            self._pending[self._log].wait()
+            self._pending[self._log] = None
+        norm_out = self._norm[self._log][self._fill]
         t_in, t_out = self.t[self.cur], self.t[1 - self.cur]
         t_out_local = t_out[p.lo:p.hi]
         if isinstance(self.local_step, HipSplitStep) and t_in.is_cuda and getattr(self.exchange, "needs_only_boundary", False) \
                 and self.local_step.concurrent:
-            self.local_step.run_overlapped(t_in, t_out, t_out_local, self.x, self._norm[slot], self.exchange)
+            self.local_step.run_overlapped(t_in, t_out, t_out_local, self.x, norm_out, self.exchange)
         elif isinstance(self.local_step, (SplitStep, HipSplitStep)):
             self.local_step.run_boundary(t_in, t_out_local, self.x)
             early = getattr(self.exchange, "needs_only_boundary", False)
             handle = self.exchange.start(t_out) if early else None   # boundary rows are final: ship them while the interior computes
-            self.local_step.run_interior(t_in, t_out_local, self.x, self._norm[slot])
+            self.local_step.run_interior(t_in, t_out_local, self.x, norm_out)
             if not early:
                 handle = self.exchange.start(t_out)                  # an all-gather needs the whole slice
             self.exchange.finish(handle)
         else:
-            self.local_step(t_in, t_out_local, self.x, self._norm[slot])
+            self.local_step(t_in, t_out_local, self.x, norm_out)
             self.exchange(t_out)
-        if reduce_norm and p.world > 1:
-            self._pending[slot] = all_reduce_scalar(self._norm[slot][:1], dist.ReduceOp.SUM, self.group, async_op=True)
-        self._slot = slot
+        self._last = (self._log, self._fill)
+        self._fill += 1
+        if self._fill == self.reduce_every:
+            self._close_log(reduce_norm)
         self.cur = 1 - self.cur
         self.steps_done += 1
 
+    def flush(self) -> None:
+        """strips of the last step that are still in flight (HipSplitStep.run_overlapped) land before the caller reads the term"""
+        if isinstance(self.local_step, HipSplitStep):
+            self.local_step.flush(self.exchange)
+
     @property
     def term(self) -> torch.Tensor:
+        self.flush()
         return self.t[self.cur]
 
     def term_norm(self) -> float:
-        if self._pending[self._slot] is not None:
-            self._pending[self._slot].wait()
-            self._pending[self._slot] = None
-        return float(self._norm[self._slot][0].item()) ** 0.5
+        """global ||t|| of the most recent step (closes a partly filled log, waits for its all-reduce)"""
+        self.flush()
+        self._close_log(True)
+        log, row = self._last
+        if self._pending[log] is not None:
+            self._pending[log].wait()
+            self._pending[log] = None
+        return float(self._norm[log][row][0].item()) ** 0.5
+
+    def term_norms_of_batch(self):
+        """global ||t|| of every step of the batch the most recent step belongs to, oldest first (what the convergence replay reads)"""
+        self.term_norm()
+        log, row = self._last
+        return [float(v) ** 0.5 for v in self._norm[log][:row + 1, 0].tolist()]
 
 
 def hip_local_step(matrix_handle: int, dinv_local: torch.Tensor, order: int = 0) -> LocalStep:

@@ -60,11 +60,15 @@ def _worker(rank, world, port, n, k, w, steps, out_dir, split=False):
                 return (lo_l, hi_l, _oracle_local_step(prp, ci[rp[lo_l]:rp[hi_l]], va[rp[lo_l]:rp[hi_l]], dinv[lo_l:hi_l], part.lo + lo_l))
             bnd, inter = D.split_bounds(part.n_local, max(w, 64), rank > 0, rank < world - 1)
             local = D.SplitStep([piece(a, b) for a, b in bnd if b > a], [piece(a, b) for a, b in inter if b > a], torch.device("cpu"))
-        drv = D.PartitionedNeumann(part, local, ex, t0, x)
+        every = int(os.environ.get("SL_TEST_REDUCE_EVERY", "1"))
+        drv = D.PartitionedNeumann(part, local, ex, t0, x, reduce_every=every)
         norms = []
-        for _ in range(steps):
+        for s in range(steps):
             drv.step()
-            norms.append(drv.term_norm())
+            if every == 1:
+                norms.append(drv.term_norm())
+            elif (s + 1) % every == 0 or s + 1 == steps:       # batched log: one all-reduce per `every` steps (and one for the tail)
+                norms.extend(drv.term_norms_of_batch())
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x.numpy(), t=drv.term.numpy()[part.lo:part.hi],
                  norms=np.asarray(norms), lo=part.lo, hi=part.hi, sent=ex.bytes_sent_per_step())
     finally:
@@ -88,6 +92,19 @@ def test_partitioned_iteration_matches_single_process(tmp_path, n, k, w, split):
             assert int(z["sent"]) == 8 * w          # one neighbour each at world = 2
     assert (xs.view(np.uint64) == o["x"].view(np.uint64)).all()
     assert (ts.view(np.uint64) == o["term"].view(np.uint64)).all()
+
+
+def test_partitioned_iteration_batched_norm_log(tmp_path, monkeypatch):
+    """reduce_every = 4 over 10 steps: two full logs and a tail of two — every step's norm still arrives globally summed"""
+    monkeypatch.setenv("SL_TEST_REDUCE_EVERY", "4")
+    n, k, w, world, steps = 6000, 12, 300, 2, 10
+    mp.spawn(_worker, args=(world, _free_port(), n, k, w, steps, str(tmp_path), True), nprocs=world, join=True)
+    rp, ci, va, b = G.sdd_rows(n, k, 3, w)
+    o = O.neumann_solve(rp, ci, va, b, max_terms=steps + 1, series_tolerance=0.0, max_iterations=steps + 1, tolerance=0.0)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        assert len(z["norms"]) == steps
+        np.testing.assert_allclose(z["norms"], o["term_norms"][1:], rtol=1e-12)
 
 
 def _solve_worker(rank, world, port, n, k, w, tol, scaled, out_dir):
