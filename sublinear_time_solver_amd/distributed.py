@@ -48,11 +48,24 @@ def all_reduce_scalar(t: torch.Tensor, op, group=None, async_op: bool = False):
 
 @dataclass
 class RowPartition:
+    """Contiguous row ranges, one per rank.  Default: equal row counts (the last ranks may be short or empty; vectors are
+    padded to world * rows_per_rank so the all-gather moves equal chunks).  With `bounds` (world + 1 ascending row
+    indices, e.g. from nnz_balanced_bounds) the ranges are arbitrary and vectors have exactly n_global entries."""
     n_global: int
     world: int
     rank: int
+    bounds: Optional[Sequence[int]] = None
 
     def __post_init__(self):
+        if self.bounds is not None:
+            b = [int(v) for v in self.bounds]
+            if len(b) != self.world + 1 or b[0] != 0 or b[-1] != self.n_global or any(b[i] > b[i + 1] for i in range(self.world)):
+                raise ValueError("bounds must be world + 1 ascending row indices from 0 to n_global")
+            self.bounds = b
+            self.rows_per_rank = max(b[i + 1] - b[i] for i in range(self.world))
+            self.n_padded = self.n_global
+            self.lo, self.hi = b[self.rank], b[self.rank + 1]
+            return
         self.rows_per_rank = -(-self.n_global // self.world)          # ceil
         self.n_padded = self.rows_per_rank * self.world
         self.lo = min(self.rank * self.rows_per_rank, self.n_global)
@@ -62,9 +75,41 @@ class RowPartition:
     def n_local(self) -> int:
         return self.hi - self.lo
 
-    def bounds(self, r: int):
+    @property
+    def uniform(self) -> bool:
+        return self.bounds is None
+
+    def range_of(self, r: int):
+        if self.bounds is not None:
+            return self.bounds[r], self.bounds[r + 1]
         lo = min(r * self.rows_per_rank, self.n_global)
         return lo, min(lo + self.rows_per_rank, self.n_global)
+
+
+def nnz_balanced_bounds(row_ptr, world: int):
+    """Row bounds that give every rank about nnz / world stored entries (prefix sum of row_ptr): rank r starts at
+    the first row whose prefix reaches r * nnz / world.  Every rank derives the same bounds from the same global row_ptr."""
+    import numpy as np
+    rp = np.asarray(row_ptr, dtype=np.int64)
+    n, nnz = len(rp) - 1, int(rp[-1])
+    cuts = [int(np.searchsorted(rp, (r * nnz) // world, side="left")) for r in range(1, world)]
+    b = [0] + [min(max(c, 0), n) for c in cuts] + [n]
+    for i in range(1, len(b)):
+        b[i] = max(b[i], b[i - 1])
+    return b
+
+
+class _WorkList:
+    """several outstanding collectives waited for as one (plus host buffers to land in the staged test mode)"""
+
+    def __init__(self, works, landing=()):
+        self.works, self.landing = works, landing
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for buf, view in self.landing:
+            view.copy_(buf)
 
 
 class AllGatherExchange:
@@ -78,6 +123,23 @@ class AllGatherExchange:
         p = self.part
         if p.world == 1:
             return None
+        if not p.uniform:                       # unequal ranges: one broadcast per rank (all_gather needs equal chunks on gloo)
+            staged = _staged(t_full, self.group)
+            works, landing = [], []
+            for r in range(p.world):
+                lo, hi = p.range_of(r)
+                if hi == lo:
+                    continue
+                src = dist.get_global_rank(self.group, r) if self.group is not None else r
+                view = t_full[lo:hi]
+                if staged:
+                    buf = view.cpu() if r == p.rank else torch.empty(hi - lo, dtype=t_full.dtype)
+                    works.append(dist.broadcast(buf, src=src, group=self.group, async_op=True))
+                    if r != p.rank:
+                        landing.append((buf, view))
+                else:
+                    works.append(dist.broadcast(view, src=src, group=self.group, async_op=True))
+            return _WorkList(works, landing)
         mine = t_full[p.rank * p.rows_per_rank:(p.rank + 1) * p.rows_per_rank]
         if _staged(t_full, self.group):
             host = torch.empty(t_full.numel(), dtype=t_full.dtype)
@@ -94,7 +156,7 @@ class AllGatherExchange:
         self.finish(self.start(t_full))
 
     def bytes_sent_per_step(self) -> int:
-        return 8 * self.part.rows_per_rank * (self.part.world - 1)
+        return 8 * (self.part.n_local if not self.part.uniform else self.part.rows_per_rank) * (self.part.world - 1)
 
 
 class HaloExchange:
@@ -106,8 +168,9 @@ class HaloExchange:
         """loopback (MEASUREMENT mode, world size 1 with an initialised RCCL group): the rank sends both boundary strips to
         ITSELF into scratch strips — same op list, same enqueue cost and same transfer kernels as a rank with two neighbours,
         so the per-step host and device cost of the exchange can be measured on a one-GPU box."""
-        if part.world > 1 and part.rows_per_rank < half_bandwidth:
-            raise ValueError("halo exchange needs rows_per_rank >= w")
+        sizes = [part.range_of(r)[1] - part.range_of(r)[0] for r in range(part.world)]
+        if part.world > 1 and min([v for v in sizes if v > 0] or [0]) < half_bandwidth:
+            raise ValueError("halo exchange needs at least w rows on every rank")
         self.part, self.w, self.group = part, int(half_bandwidth), group
         self.loopback = bool(loopback) and part.world == 1
         self._ops = {}

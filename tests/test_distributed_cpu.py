@@ -161,7 +161,67 @@ def test_split_bounds():
     assert D.split_bounds(150, 100, True, True) == ([(0, 100), (100, 150)], [(100, 100)])
 
 
+def _ragged_system(n):
+    """row dominant with power-law row lengths: the transpose of the PageRank system, I - 0.85 P (rows = out-links, Zipf degrees)"""
+    import scipy.sparse as sp
+    rp, ci, va, b = G.pagerank_system(n, *G.pagerank_graph(n, 5))
+    T = sp.csr_matrix((va, ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n)).T.tocsr()
+    T.sort_indices()
+    return T.indptr.astype(np.uint32), T.indices.astype(np.uint32), T.data.astype(np.float64), 1.0 + 0.001 * (np.arange(n) % 1000)
+
+
+def _ragged_worker(rank, world, port, n, steps, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rp, ci, va, b = _ragged_system(n)
+        part = D.RowPartition(n, world, rank, bounds=D.nnz_balanced_bounds(rp, world))
+        lo, hi = part.lo, part.hi
+        prp = (rp[lo:hi + 1].astype(np.int64) - int(rp[lo])).astype(np.uint32)
+        pci, pva = ci[rp[lo]:rp[hi]], va[rp[lo]:rp[hi]]
+        dinv_all = 1.0 / np.array([va[rp[i]:rp[i + 1]][ci[rp[i]:rp[i + 1]] == i][0] for i in range(n)])
+        t0 = torch.from_numpy(b * dinv_all)
+        x = t0[lo:hi].clone()
+        drv = D.PartitionedNeumann(part, _oracle_local_step(prp, pci, pva, dinv_all[lo:hi], lo), D.AllGatherExchange(part), t0, x)
+        norms = []
+        for _ in range(steps):
+            drv.step()
+            norms.append(drv.term_norm())
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x.numpy(), t=drv.term.numpy()[lo:hi], norms=np.asarray(norms), lo=lo, hi=hi,
+                 nnz=int(rp[hi]) - int(rp[lo]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nnz_balanced_partition_of_ragged_rows(tmp_path):
+    """row ranges balanced by stored entries (prefix sum of row_ptr).  Three ranks with unequal row counts,
+    all-gather over unequal chunks; per-row bits equal the single-process iteration."""
+    n, world, steps = 3000, 3, 4
+    mp.spawn(_ragged_worker, args=(world, _free_port(), n, steps, str(tmp_path)), nprocs=world, join=True)
+    rp, ci, va, b = _ragged_system(n)
+    o = O.neumann_solve(rp, ci, va, b, max_terms=steps + 1, series_tolerance=0.0, max_iterations=steps + 1, tolerance=0.0)
+    xs, ts, sizes, nnzs = np.zeros(n), np.zeros(n), [], []
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        xs[int(z["lo"]):int(z["hi"])] = z["x"]
+        ts[int(z["lo"]):int(z["hi"])] = z["t"]
+        sizes.append(int(z["hi"]) - int(z["lo"]))
+        nnzs.append(int(z["nnz"]))
+        np.testing.assert_allclose(z["norms"], o["term_norms"][1:], rtol=1e-12)
+    assert sum(sizes) == n and max(sizes) > 1.1 * min(sizes)             # the row counts really differ ...
+    assert max(nnzs) - min(nnzs) <= 2 * int(np.diff(rp.astype(np.int64)).max())   # ... because the entries are balanced
+    assert (xs.view(np.uint64) == o["x"].view(np.uint64)).all()
+    assert (ts.view(np.uint64) == o["term"].view(np.uint64)).all()
+
+
 def test_row_partition_bounds():
+    b = D.nnz_balanced_bounds([0, 10, 10, 11, 12, 20], 2)
+    assert b == [0, 1, 5]
+    q = D.RowPartition(5, 2, 1, bounds=b)
+    assert (q.lo, q.hi, q.n_padded, q.uniform) == (1, 5, 5, False) and q.range_of(0) == (0, 1)
+    with pytest.raises(ValueError):
+        D.RowPartition(5, 2, 0, bounds=[0, 3, 4])
     p = [D.RowPartition(10, 4, r) for r in range(4)]
     assert [(q.lo, q.hi) for q in p] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert p[0].n_padded == 12

@@ -70,13 +70,15 @@ def test_partitioned_solve_script_two_ranks_equals_one(gpu):
     import os
     import socket
 
-    def run(ranks, rows):
+    def run(ranks, rows, bandwidth=700, bounds=None):
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), "tools/solve_partitioned.py", "--rows", str(rows), "--bandwidth", "700", "--tolerance", "1e-9"]
+               "--master-port", str(port), "tools/solve_partitioned.py", "--rows", str(rows), "--bandwidth", str(bandwidth), "--tolerance", "1e-9"]
+        if bounds:
+            cmd += ["--bounds", bounds]
         r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, SL_BENCH_BACKEND="gloo"))
         assert r.returncode == 0, r.stderr[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -86,6 +88,13 @@ def test_partitioned_solve_script_two_ranks_equals_one(gpu):
     assert (one["iterations"], one["terms"]) == (two["iterations"], two["terms"])
     for key in ("residual_norm", "sum_x", "sum_x2", "last_term_norm"):
         assert abs(one[key] - two[key]) <= 1e-11 * max(1.0, abs(one[key])), key
+    # unequal row ranges (RowPartition with explicit bounds, as nnz_balanced_bounds returns): halo and gather exchanges
+    for bw in (700, 0):
+        ref = one if bw == 700 else run(1, 200_000, bw)
+        skew = run(2, 0, bw, bounds="0,61234,200000")
+        assert skew["converged"] and (ref["iterations"], ref["terms"]) == (skew["iterations"], skew["terms"])
+        for key in ("residual_norm", "sum_x", "sum_x2", "last_term_norm"):
+            assert abs(ref[key] - skew[key]) <= 1e-11 * max(1.0, abs(ref[key])), (bw, key)
 
 
 def test_bench_initialises_rccl_on_this_box(gpu):

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tolerance", type=float, default=1e-8)
     ap.add_argument("--order", type=int, default=0)
+    ap.add_argument("--bounds", type=str, default="", help="explicit row bounds b0,b1,...,bN (N = ranks, b0 = 0, bN = n_global) instead of "
+                    "--rows per rank: unequal row ranges, as nnz-balanced bounds of a ragged system would be")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -53,9 +55,15 @@ def main():
     L.check(lib.sl_set_device(local_rank))
     L.check(lib.sl_set_stream(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
-    n_local, k, w = a.rows, a.k, a.bandwidth
-    n_global = n_local * world
-    part = D.RowPartition(n_global, world, rank)
+    k, w = a.k, a.bandwidth
+    if a.bounds:
+        bounds = [int(v) for v in a.bounds.split(",")]
+        n_global = bounds[-1]
+        part = D.RowPartition(n_global, world, rank, bounds=bounds)
+    else:
+        n_global = a.rows * world
+        part = D.RowPartition(n_global, world, rank)
+    n_local = part.n_local
     rp = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
     ci = torch.empty(n_local * k, dtype=torch.int32, device=dev)
     va = torch.empty(n_local * k, dtype=torch.float64, device=dev)
