@@ -123,41 +123,91 @@ __global__ __launch_bounds__(256) void sl_select_kernel(uint64_t n, const double
 // list swap, stop rule).  The host enqueues several rounds back to back and reads the block once per batch; rounds
 // enqueued past the stop are empty launches.  A local query of a dozen rounds costs two host round trips.
 struct sl_push_ctl {
-    uint32_t nf, nn, n_long_cols, nrec;   // |frontier|, next frontier, deferred hub columns, hit records of the running round
-    uint32_t nc, n_heavy;                 // candidate rows of the running round; those with more than SL_MAX_HITS hits
-    uint32_t n_touched;                   // rows whose x / r may be non-zero (query sessions; not reset per batch)
+    // every wave of a round reserves list slots through these counters: each sits on its own 128-byte line, so the atomics on
+    // different counters do not queue behind one another in one L2 channel
+    alignas(128) uint32_t nrec;           // hit records of the running round
+    alignas(128) uint32_t nc;             // candidate rows of the running round
+    alignas(128) uint32_t n_touched;      // rows whose x / r may be non-zero (query sessions; not reset per batch)
+    alignas(128) uint32_t nn;             // next frontier
+    alignas(128) unsigned long long next_hits;   // column entries under the next frontier
+    alignas(128) uint32_t n_long_cols;    // (column, piece) work items of the running round
+    alignas(128) uint32_t n_heavy;        // candidate rows with more than SL_MAX_HITS hits
+    alignas(128) uint32_t nf;             // |frontier|
     uint32_t stop;                        // 0 running, 1 frontier empty (converged), 2 frontier too large for a sparse round
     uint32_t rounds, done_blocks;         // rounds executed in this batch; block counter of the closing kernel
-    unsigned long long hits, next_hits;   // column entries under the frontier (= records a round writes) and under the next one
+    uint32_t nf_prev;                     // |frontier| of the round before (cleared at the head of the next expansion)
+    unsigned long long hits;              // column entries under the frontier (= records a round writes)
     unsigned long long pushes, rows_touched;
 };
 #define SL_FLAG_TOUCHED 2u            // row is in the session's touched list
 #define SL_EMPTY 0xffffffffu          // head[] of a row without hits
 #define SL_MAX_HITS 8                 // rows hit by more frontier columns than this are pulled over their whole length
-#define SL_LONG_COL 1024u             // longer frontier columns are walked by the whole grid
+#define SL_PIECE 256u                 // column entries one wave expands at a time; longer frontier columns are cut into pieces
 
 // one frontier column entry (i, j): the product B_ij * delta_j, the position of the entry in B's row arrays (the order
 // key of the row sum) and the previous hit of the same row (a per-row linked list, newest first)
 struct sl_hit { double prod; uint32_t k, next; };
 
-__global__ void sl_push_ctl_reset_kernel(sl_push_ctl *c, uint32_t nf)
+// everything a sparse round touches.  Round k of a batch reads frontier[k & 1] / delta[k & 1] and writes the other pair: the
+// parity comes from the round counter in the control block, so the same argument block serves every round of the batch
+struct sl_round_io {
+    sl_push_ctl *c;
+    uint32_t *frontier[2];
+    double *delta[2];
+    op_view op;
+    double *x, *r;
+    const double *dinv;
+    sl_hit *recs;
+    uint32_t *head, *cand, *flag, *touched, *heavy;
+    uint2 *long_cols;                          // (column, piece) work items of the running round
+    double theta;
+    int order;
+    uint32_t dense_threshold, round_limit;     // a batch runs rounds while c->rounds < round_limit
+    unsigned long long hit_limit;
+    uint32_t nf0;                              // |frontier| the batch starts from
+    unsigned long long rec_cap;                // record buffer capacity (hard limit on the entries under a frontier)
+};
+// The argument block of a batch lives in device memory (written by one small kernel per batch): every kernel of the batch takes
+// the same 8-byte pointer instead of ~200 bytes of arguments (launches got 15 % cheaper; a local query is a few dozen launches).
+__global__ void sl_set_io_kernel(sl_round_io io, sl_round_io *dst) { *dst = io; }
+#define SL_PICK(pair, which) ((which) ? (pair)[1] : (pair)[0])      // no dynamic indexing into kernel arguments
+// where a thread sits in the machine: the round phases run as five wide launches or inside one persistent kernel
+struct sl_worker { uint32_t tid, nthreads, wave, nwaves, lane; };
+__device__ __forceinline__ sl_worker sl_worker_here()
 {
-    c->nf = nf; c->nn = 0; c->n_long_cols = 0; c->nrec = 0; c->nc = 0; c->n_heavy = 0; c->stop = 0; c->rounds = 0; c->done_blocks = 0;
-    c->hits = 0; c->next_hits = 0; c->pushes = 0; c->rows_touched = 0;
+    sl_worker w;
+    w.tid = blockIdx.x * blockDim.x + threadIdx.x; w.nthreads = gridDim.x * blockDim.x;
+    w.wave = w.tid >> 6; w.nwaves = w.nthreads >> 6; w.lane = threadIdx.x & 63u;
+    return w;
+}
+template <typename T> __device__ __forceinline__ T sl_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool sl_round_open(const sl_round_io &io, uint32_t &par)
+{
+    if (io.c->stop || io.c->rounds >= io.round_limit) return false;
+    par = io.c->rounds & 1u;
+    return true;
 }
 
-// column entries under the first frontier of a batch (later rounds accumulate the figure as their frontier forms)
-__global__ __launch_bounds__(256) void sl_frontier_hits_kernel(sl_push_ctl *c, const uint32_t *frontier, const uint32_t *tptr)
+__global__ void sl_push_ctl_reset_kernel(const sl_round_io *iop)
 {
-    const uint32_t nf = c->nf;
+    sl_push_ctl *c = iop->c;
+    c->nf = iop->nf0; c->nn = 0; c->n_long_cols = 0; c->nrec = 0; c->nc = 0; c->n_heavy = 0; c->stop = 0; c->rounds = 0; c->done_blocks = 0; c->nf_prev = 0;
+    c->hits = 0; c->next_hits = 0; c->pushes = 0; c->rows_touched = 0;
+}
+// column entries under the first frontier of a batch (later rounds accumulate the figure as their frontier forms)
+__global__ __launch_bounds__(256) void sl_frontier_hits_kernel(const sl_round_io *iop)
+{
+    sl_push_ctl *c = iop->c;
+    const uint32_t *frontier = iop->frontier[0], *tptr = iop->op.tptr;
+    const uint32_t nf = iop->nf0;
     unsigned long long acc = 0;
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nf; t += gridDim.x * 256) { const uint32_t j = frontier[t]; acc += tptr[j + 1] - tptr[j]; }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(&c->hits, acc);
 }
-__global__ void sl_hits_gate_kernel(sl_push_ctl *c, unsigned long long hit_limit)
+__global__ void sl_hits_gate_kernel(const sl_round_io *iop)
 {
-    if (c->hits > hit_limit) c->stop = 2u;
+    if (iop->c->hits > iop->rec_cap) iop->c->stop = 2u;
 }
 
 // (1) expansion.  Sparse rounds are HIT-DRIVEN: a frontier column j reaches row i through the entry B_ij, and only
@@ -166,93 +216,123 @@ __global__ void sl_hits_gate_kernel(sl_push_ctl *c, unsigned long long hit_limit
 //     empty becomes a candidate.  Slots in the record, candidate and touched lists are reserved per wave (ballot +
 //     popcount, one atomic for up to 256 entries).  The work of a round follows the column entries under the
 //     frontier, not the lengths of the rows they touch.
-__device__ __forceinline__ void sl_expand_piece(uint32_t p0, uint32_t p1, double dj, uint32_t lane, const op_view &op, sl_hit *recs,
-                                                uint32_t *head, uint32_t *cand, uint32_t *flag, uint32_t *touched, sl_push_ctl *c)
+// Latency, not bandwidth, bounds a sparse round, so the piece is written as three round trips to memory: (1) the slot
+// reservation (it needs only the entry count) next to the loads of row and position; (2) the list link (needs the row and the
+// slot), the value and the row's session flag together; (3) the candidate / touched reservations, then plain stores.
+// A piece = four segments of up to 64 column entries, each with its own delta: four short columns, or 256 consecutive entries
+// of one long column.  pa[u] + lane < pe[u] selects the lanes of segment u.
+__device__ __forceinline__ void sl_expand_piece(const uint32_t pa[4], const uint32_t pe[4], const double dj[4], uint32_t lane, const op_view &op,
+                                                sl_hit *recs, uint32_t *head, uint32_t *cand, uint32_t *flag, uint32_t *touched, sl_push_ctl *c)
 {
     const unsigned long long below = (1ull << lane) - 1ull;
-    bool ok[4]; uint32_t row[4], kb[4]; double bv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t p = p0 + (uint32_t)u * 64u;
-        ok[u] = p < p1;
-        row[u] = ok[u] ? op.tidx[p] : 0u;
-        kb[u] = ok[u] ? op.tk[p] : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) bv[u] = ok[u] ? op.val[kb[u]] : 0.0;
+    bool ok[4];
     unsigned long long m[4];
     uint32_t off[4], total = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { m[u] = __ballot(ok[u]); off[u] = total; total += (uint32_t)__popcll(m[u]); }
+    for (int u = 0; u < 4; ++u) { ok[u] = pa[u] + lane < pe[u]; m[u] = __ballot(ok[u]); off[u] = total; total += (uint32_t)__popcll(m[u]); }
+    if (total == 0) return;                                                    // wave-uniform
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&c->nrec, total);
-    base = __shfl(base, 0);
-    uint32_t prev[4];
+    uint32_t row[4], kb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const uint32_t rec = base + off[u] + (uint32_t)__popcll(m[u] & below);
-        prev[u] = ok[u] ? atomicExch(&head[row[u]], rec) : 0u;
-        if (ok[u]) recs[rec] = sl_hit{DMUL(bv[u], dj), kb[u], prev[u]};
+        const uint32_t p = pa[u] + lane;
+        row[u] = ok[u] ? op.tidx[p] : 0u;
+        kb[u] = ok[u] ? op.tk[p] : 0u;
     }
-    // rows reached for the first time this round
-    bool fresh[4];
-    total = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { fresh[u] = ok[u] && prev[u] == SL_EMPTY; m[u] = __ballot(fresh[u]); off[u] = total; total += (uint32_t)__popcll(m[u]); }
-    if (total == 0) return;                                                    // wave-uniform
-    if (lane == 0) base = atomicAdd(&c->nc, total);
     base = __shfl(base, 0);
+    uint32_t prev[4], rec[4], fl[4];
+    double bv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (fresh[u]) cand[base + off[u] + (uint32_t)__popcll(m[u] & below)] = row[u];
-    if (touched) {                                                             // query session: first time ever (this lane owns the row now)
-        total = 0;
+    for (int u = 0; u < 4; ++u) {
+        rec[u] = base + off[u] + (uint32_t)__popcll(m[u] & below);
+        prev[u] = ok[u] ? atomicExch(&head[row[u]], rec[u]) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        bv[u] = ok[u] ? op.val[kb[u]] : 0.0;
+        fl[u] = (touched && ok[u]) ? flag[row[u]] : 0u;      // only the lane that links a row first this round may change its flag
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (ok[u]) recs[rec[u]] = sl_hit{DMUL(bv[u], dj[u]), kb[u], prev[u]};
+    // rows reached for the first time this round; among them, rows reached for the first time in this query
+    bool fresh[4], first[4];
+    unsigned long long mf[4], mt[4];
+    uint32_t offf[4], offt[4], nfresh = 0, nfirst = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        fresh[u] = ok[u] && prev[u] == SL_EMPTY;
+        first[u] = fresh[u] && touched && !(fl[u] & SL_FLAG_TOUCHED);
+        mf[u] = __ballot(fresh[u]); offf[u] = nfresh; nfresh += (uint32_t)__popcll(mf[u]);
+        mt[u] = __ballot(first[u]); offt[u] = nfirst; nfirst += (uint32_t)__popcll(mt[u]);
+    }
+    if (nfresh == 0) return;                                                   // wave-uniform
+    uint32_t basec = 0, baset = 0;
+    if (lane == 0) { basec = atomicAdd(&c->nc, nfresh); if (nfirst) baset = atomicAdd(&c->n_touched, nfirst); }
+    basec = __shfl(basec, 0); baset = __shfl(baset, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (fresh[u]) cand[basec + offf[u] + (uint32_t)__popcll(mf[u] & below)] = row[u];
+        if (first[u]) { flag[row[u]] = fl[u] | SL_FLAG_TOUCHED; touched[baset + offt[u] + (uint32_t)__popcll(mt[u] & below)] = row[u]; }
+    }
+}
+
+__device__ __forceinline__ void sl_phase_expand(const sl_round_io &io, uint32_t par, uint32_t nf, const sl_worker &w)
+{
+    const uint32_t *frontier = SL_PICK(io.frontier, par);
+    const double *delta = SL_PICK(io.delta, par);
+    // four frontier columns per wave and step (lanes 0..3 fetch one each): most columns are short, and the slot reservations of a
+    // piece — the only traffic all waves aim at the same few addresses — are shared by four columns
+    for (uint32_t t0 = w.wave * 4u; t0 < nf; t0 += w.nwaves * 4u) {
+        uint32_t j = 0, a = 0, e = 0;
+        double d = 0.0;
+        if (w.lane < 4u && t0 + w.lane < nf) {
+            j = frontier[t0 + w.lane];
+            d = delta[j];
+            io.x[j] = DADD(io.x[j], d);
+            a = io.op.tptr[j]; e = io.op.tptr[j + 1];
+        }
+        const bool is_long = e - a > 64u;                                       // more than one segment: (column, piece) items for the second phase
+        const uint32_t pieces = is_long ? (e - a + SL_PIECE - 1u) / SL_PIECE : 0u;
+        const unsigned long long ml = __ballot(is_long);
+        if (ml) {
+            uint32_t pre = 0, tot = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t pu = __shfl(pieces, u); if ((uint32_t)u < w.lane) pre += pu; tot += pu; }
+            uint32_t base = 0;
+            if (w.lane == 0) base = atomicAdd(&io.c->n_long_cols, tot);
+            base = __shfl(base, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t pu = __shfl(pieces, u), ju = __shfl(j, u), bu = base + __shfl(pre, u);
+                for (uint32_t q = w.lane; q < pu; q += 64u) io.long_cols[bu + q] = uint2{ju, q};
+            }
+        }
+        uint32_t pa[4], pe[4];
+        double dj[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            bool first = false;
-            if (fresh[u]) { const uint32_t f = flag[row[u]]; if (!(f & SL_FLAG_TOUCHED)) { flag[row[u]] = f | SL_FLAG_TOUCHED; first = true; } }
-            fresh[u] = first; m[u] = __ballot(first); off[u] = total; total += (uint32_t)__popcll(m[u]);
+            const bool lu = (ml >> u) & 1ull;
+            pa[u] = lu ? 0u : __shfl(a, u); pe[u] = lu ? 0u : __shfl(e, u); dj[u] = __shfl(d, u);
         }
-        if (total == 0) return;
-        if (lane == 0) base = atomicAdd(&c->n_touched, total);
-        base = __shfl(base, 0);
+        sl_expand_piece(pa, pe, dj, w.lane, io.op, io.recs, io.head, io.cand, io.flag, io.touched, io.c);
+    }
+}
+
+// the pieces of the longer columns, one wave each: a hub column is spread over the machine
+__device__ __forceinline__ void sl_phase_expand_long(const sl_round_io &io, uint32_t par, uint32_t n_items, const sl_worker &w)
+{
+    const double *delta = SL_PICK(io.delta, par);
+    for (uint32_t t = w.wave; t < n_items; t += w.nwaves) {
+        const uint2 item = io.long_cols[t];
+        const uint32_t j = item.x;
+        const double d = delta[j];
+        const uint32_t p0 = io.op.tptr[j] + item.y * SL_PIECE, p1 = io.op.tptr[j + 1];
+        uint32_t pa[4], pe[4];
+        double dj[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (fresh[u]) touched[base + off[u] + (uint32_t)__popcll(m[u] & below)] = row[u];
-    }
-}
-
-__global__ __launch_bounds__(256) void sl_expand_kernel(sl_push_ctl *c, const uint32_t *frontier, op_view op, const double *delta, double *x,
-                                                        sl_hit *recs, uint32_t *head, uint32_t *cand, uint32_t *flag, uint32_t *long_cols,
-                                                        uint32_t *touched)
-{
-    if (c->stop) return;
-    const uint32_t nf = c->nf;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nwaves = gridDim.x * 4;
-    for (uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t < nf; t += nwaves) {
-        const uint32_t j = frontier[t];
-        const double dj = delta[j];
-        if (lane == 0) x[j] = DADD(x[j], dj);
-        const uint32_t p0 = op.tptr[j], p1 = op.tptr[j + 1];
-        if (p1 - p0 > SL_LONG_COL) { if (lane == 0) long_cols[atomicAdd(&c->n_long_cols, 1u)] = j; continue; }
-        const uint32_t steps = (p1 - p0 + 255u) / 256u;                        // wave-uniform trip count (ballots inside)
-        for (uint32_t q = 0; q < steps; ++q) sl_expand_piece(p0 + q * 256u + lane, p1, dj, lane, op, recs, head, cand, flag, touched, c);
-    }
-}
-
-// hub columns: every wave of the grid takes 256-entry pieces of each deferred column
-__global__ __launch_bounds__(256) void sl_expand_long_kernel(sl_push_ctl *c, const uint32_t *long_cols, op_view op, const double *delta,
-                                                             sl_hit *recs, uint32_t *head, uint32_t *cand, uint32_t *flag, uint32_t *touched)
-{
-    if (c->stop) return;
-    const uint32_t n_long = c->n_long_cols;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    for (uint32_t t = 0; t < n_long; ++t) {
-        const uint32_t j = long_cols[t];
-        const double dj = delta[j];
-        const uint32_t p0 = op.tptr[j], p1 = op.tptr[j + 1];
-        const uint32_t pieces = (p1 - p0 + 255u) / 256u;
-        for (uint32_t q = wave; q < pieces; q += nwaves) sl_expand_piece(p0 + q * 256u + lane, p1, dj, lane, op, recs, head, cand, flag, touched, c);
+        for (int u = 0; u < 4; ++u) { pa[u] = p0 + (uint32_t)u * 64u; pe[u] = p1; dj[u] = d; }
+        sl_expand_piece(pa, pe, dj, w.lane, io.op, io.recs, io.head, io.cand, io.flag, io.touched, io.c);
     }
 }
 
@@ -332,27 +412,53 @@ __device__ __forceinline__ void sl_pull_finish_wave(bool live, uint32_t i, doubl
     if (pass) { delta_new[i] = p; next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i; }
 }
 
-// thread per candidate row: walk the row's hit list (newest first), order the hits by position with a static
-// insertion network, add them up.  Rows hit more than SL_MAX_HITS times go to the heavy list (whole-row pull).
-__global__ __launch_bounds__(256) void sl_pull_hits_kernel(sl_push_ctl *c, const uint32_t *cand, op_view op, const sl_hit *recs, uint32_t *head,
-                                                           const double *dinv, double theta, int order, double *r, double *delta_new,
-                                                           uint32_t *next, uint32_t *heavy)
+// whole-row pull of one row by a whole wave (rows hit by more frontier columns than the insertion network holds): 1024 entries
+// (16 per lane) in flight per step, non-zero products added in entry order
+__device__ __forceinline__ double sl_wave_row_pull(const op_view &op, uint32_t i, const double *delta_old, int order, uint32_t lane)
 {
-    if (c->stop) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nc = c->nc;
-    const uint32_t stride = gridDim.x * 256;
-    const uint32_t trips = (nc + stride - 1) / stride;                         // wave-uniform (ballots in the finish)
+    const uint32_t s = op.ptr[i], len = op.ptr[i + 1] - s;
+    sl_row_acc acc;
+    acc.init(len, order);
+    for (uint32_t base = 0; base < len; base += 1024u) {
+        double pr[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t q = base + (uint32_t)u * 64u + lane;
+            pr[u] = q < len ? DMUL(op.val[s + q], delta_old[op.idx[s + q]]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            unsigned long long seg = __ballot(pr[u] != 0.0);
+            while (seg) {
+                const int l = __builtin_ctzll(seg);
+                seg &= seg - 1;
+                acc.add(base + (uint32_t)u * 64u + (uint32_t)l, __shfl(pr[u], l));
+            }
+        }
+    }
+    return acc.finish();
+}
+
+// thread per candidate row: walk the row's hit list (newest first), order the hits by position with a static
+// insertion network, add them up.  Rows hit more than SL_MAX_HITS times go to the heavy list (whole-row pull, next launch:
+// pulling them in place was tried — the waves that find several of them hold the round up, 2x slower on large frontiers).
+__device__ __forceinline__ void sl_phase_pull_hits(const sl_round_io &io, uint32_t par, uint32_t nc, const sl_worker &w)
+{
+    const op_view &op = io.op;
+    double *delta_new = SL_PICK(io.delta, 1u - par);
+    uint32_t *next = SL_PICK(io.frontier, 1u - par);
+    const int order = io.order;
+    const uint32_t trips = (nc + w.nthreads - 1) / w.nthreads;                 // wave-uniform (ballots in the finish)
     for (uint32_t it = 0; it < trips; ++it) {
-        const uint32_t t = it * stride + blockIdx.x * 256 + threadIdx.x;
+        const uint32_t t = it * w.nthreads + w.tid;
         bool live = t < nc;
-        const uint32_t i = live ? cand[t] : 0u;
+        const uint32_t i = live ? io.cand[t] : 0u;
         uint32_t h = SL_EMPTY;
         double r_old = 0.0, dv = 0.0;
         uint32_t s = 0, len = 0;
         if (live) {
-            h = head[i]; head[i] = SL_EMPTY;
-            r_old = r[i]; dv = dinv[i];
+            h = io.head[i]; io.head[i] = SL_EMPTY;
+            r_old = io.r[i]; dv = io.dinv[i];
             if (order == SL_ORDER_SIMD4) { s = op.ptr[i]; len = op.ptr[i + 1] - s; }
         }
         uint32_t hk[SL_MAX_HITS]; double hp[SL_MAX_HITS];
@@ -361,7 +467,7 @@ __global__ __launch_bounds__(256) void sl_pull_hits_kernel(sl_push_ctl *c, const
 #pragma unroll
         for (int hop = 0; hop < SL_MAX_HITS; ++hop) {
             if (h != SL_EMPTY) {
-                const sl_hit rec = recs[h];
+                const sl_hit rec = io.recs[h];
                 h = rec.next;
                 uint32_t nk = rec.k; double np = rec.prod;
 #pragma unroll
@@ -370,73 +476,96 @@ __global__ __launch_bounds__(256) void sl_pull_hits_kernel(sl_push_ctl *c, const
                 }
             }
         }
-        if (live && h != SL_EMPTY) { heavy[atomicAdd(&c->n_heavy, 1u)] = i; live = false; }   // more hits than the network holds
+        if (live && h != SL_EMPTY) { io.heavy[atomicAdd(&io.c->n_heavy, 1u)] = i; live = false; }   // more hits than the network holds
         sl_row_acc acc;
         acc.init(len, order);
 #pragma unroll
         for (int u = 0; u < SL_MAX_HITS; ++u) if (hk[u] != SL_EMPTY) acc.add(hk[u] - s, hp[u]);
-        sl_pull_finish_wave(live, i, acc.finish(), r_old, dv, theta, lane, op.tptr, r, delta_new, next, c);
+        sl_pull_finish_wave(live, i, acc.finish(), r_old, dv, io.theta, w.lane, op.tptr, io.r, delta_new, next, io.c);
     }
 }
 
-// heavy rows (hit by many frontier columns): one WAVE per row over the whole row, 1024 entries (16 per lane) in flight
-// per step, non-zero products added in entry order
-__global__ __launch_bounds__(256) void sl_pull_heavy_kernel(sl_push_ctl *c, const uint32_t *heavy, op_view op, const double *delta_old,
-                                                            const double *dinv, double theta, int order, double *r, double *delta_new,
-                                                            uint32_t *next)
+// heavy rows: one WAVE per row over the whole row
+__device__ __forceinline__ void sl_phase_pull_heavy(const sl_round_io &io, uint32_t par, uint32_t nh, const sl_worker &w)
 {
-    if (c->stop) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nh = c->n_heavy;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-    for (uint32_t t = wave; t < nh; t += nwaves) {
-        const uint32_t i = heavy[t];
-        const uint32_t s = op.ptr[i], len = op.ptr[i + 1] - s;
+    const double *delta_old = SL_PICK(io.delta, par);
+    for (uint32_t t = w.wave; t < nh; t += w.nwaves) {
+        const uint32_t i = io.heavy[t];
         double r_old = 0.0, dv = 0.0;
-        if (lane == 0) { r_old = r[i]; dv = dinv[i]; }
-        sl_row_acc acc;
-        acc.init(len, order);
-        for (uint32_t base = 0; base < len; base += 1024u) {
-            double pr[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t q = base + (uint32_t)u * 64u + lane;
-                pr[u] = q < len ? DMUL(op.val[s + q], delta_old[op.idx[s + q]]) : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                unsigned long long seg = __ballot(pr[u] != 0.0);
-                while (seg) {
-                    const int l = __builtin_ctzll(seg);
-                    seg &= seg - 1;
-                    acc.add(base + (uint32_t)u * 64u + (uint32_t)l, __shfl(pr[u], l));
-                }
-            }
-        }
-        sl_pull_finish_wave(lane == 0, i, acc.finish(), r_old, dv, theta, lane, op.tptr, r, delta_new, next, c);
+        if (w.lane == 0) { r_old = io.r[i]; dv = io.dinv[i]; }
+        const double sum = sl_wave_row_pull(io.op, i, delta_old, io.order, w.lane);
+        sl_pull_finish_wave(w.lane == 0, i, sum, r_old, dv, io.theta, w.lane, io.op.tptr, io.r, SL_PICK(io.delta, 1u - par), SL_PICK(io.frontier, 1u - par), io.c);
     }
 }
 
-// (3) delta_old[j] = 0 for the frontier just consumed (keeps the buffer all-zero outside a frontier); the block that
-//     finishes last closes the round: statistics, the next frontier becomes the frontier, stop rule
-__global__ __launch_bounds__(256) void sl_clear_kernel(sl_push_ctl *c, const uint32_t *frontier, double *delta, uint32_t dense_threshold,
-                                                       unsigned long long hit_limit)
+// delta[j] = 0 over a consumed frontier (keeps the buffer all-zero outside a frontier).  It runs at the head of the NEXT round's
+// expansion — which reads the other buffer, while the list is still intact — and once after the last round of a batch.
+__device__ __forceinline__ void sl_clear_frontier(const uint32_t *frontier, double *delta, uint32_t nf, const sl_worker &w)
 {
-    if (c->stop) return;
+    for (uint32_t t = w.tid; t < nf; t += w.nthreads) delta[frontier[t]] = 0.0;
+}
+// ONE thread closes the round once every pull has finished: statistics, the next frontier becomes the frontier, stop rule
+__device__ __forceinline__ void sl_close_round(const sl_round_io &io, uint32_t nf)
+{
+    sl_push_ctl *c = io.c;
+    const uint32_t nn = sl_ld(&c->nn), nc = sl_ld(&c->nc);
+    const unsigned long long nh = sl_ld(&c->next_hits);
+    c->rounds += 1; c->pushes += nf; c->rows_touched += nc;
+    c->nf_prev = nf;
+    c->nf = nn; c->nn = 0; c->nc = 0; c->n_heavy = 0; c->n_long_cols = 0; c->nrec = 0; c->hits = nh; c->next_hits = 0;
+    if (nn == 0) c->stop = 1u;
+    else if (nn > io.dense_threshold || nh > io.hit_limit) c->stop = 2u;
+}
+
+// A round is four launches: expansion of the short columns (+ clearing the previous frontier), the pieces of the long
+// columns, the pull over hit lists, and the whole-row pull of heavy rows, whose last block closes the round.
+__global__ __launch_bounds__(256) void sl_expand_kernel(const sl_round_io *iop)
+{
+    const sl_round_io io = *iop;
+    uint32_t par;
+    if (!sl_round_open(io, par)) return;
+    const sl_worker w = sl_worker_here();
+    if (io.c->rounds) sl_clear_frontier(SL_PICK(io.frontier, 1u - par), SL_PICK(io.delta, 1u - par), io.c->nf_prev, w);
+    sl_phase_expand(io, par, io.c->nf, w);
+}
+__global__ __launch_bounds__(256) void sl_expand_long_kernel(const sl_round_io *iop)
+{
+    const sl_round_io io = *iop;
+    uint32_t par;
+    if (!sl_round_open(io, par)) return;
+    sl_phase_expand_long(io, par, io.c->n_long_cols, sl_worker_here());
+}
+__global__ __launch_bounds__(256) void sl_pull_hits_kernel(const sl_round_io *iop)
+{
+    const sl_round_io io = *iop;
+    uint32_t par;
+    if (!sl_round_open(io, par)) return;
+    sl_phase_pull_hits(io, par, io.c->nc, sl_worker_here());
+}
+// the block that finishes last closes the round (a small grid: every block pays an agent-scope fence on the way out)
+__global__ __launch_bounds__(256) void sl_pull_heavy_kernel(const sl_round_io *iop)
+{
+    const sl_round_io io = *iop;
+    uint32_t par;
+    if (!sl_round_open(io, par)) return;
+    sl_push_ctl *c = io.c;
     const uint32_t nf = c->nf;
-    const uint32_t stride = gridDim.x * 256;
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nf; t += stride) delta[frontier[t]] = 0.0;
+    sl_phase_pull_heavy(io, par, c->n_heavy, sl_worker_here());
     __syncthreads();
     if (threadIdx.x != 0) return;
     __threadfence();
     if (atomicAdd(&c->done_blocks, 1u) != gridDim.x - 1) return;
     c->done_blocks = 0;
-    c->rounds += 1; c->pushes += nf; c->rows_touched += c->nc;
-    const uint32_t nn = c->nn;
-    const unsigned long long nh = c->next_hits;
-    c->nf = nn; c->nn = 0; c->nc = 0; c->n_heavy = 0; c->n_long_cols = 0; c->nrec = 0; c->hits = nh; c->next_hits = 0;
-    if (nn == 0) c->stop = 1u;
-    else if (nn > dense_threshold || nh > hit_limit) c->stop = 2u;
+    sl_close_round(io, nf);
+}
+// after the last round of a batch: the frontier that round consumed is still marked in its delta buffer
+__global__ __launch_bounds__(256) void sl_batch_end_kernel(const sl_round_io *iop)
+{
+    const sl_round_io io = *iop;
+    const uint32_t rounds = io.c->rounds;
+    if (rounds == 0) return;
+    const uint32_t par = (rounds - 1u) & 1u;                                   // parity of the last round run
+    sl_clear_frontier(SL_PICK(io.frontier, par), SL_PICK(io.delta, par), io.c->nf_prev, sl_worker_here());
 }
 
 // generic (any operator given as CSR) dense round, one thread per row — used by estimate_entry
@@ -470,11 +599,12 @@ struct push_state {
     uint64_t rec_cap = 0, op_nnz = 0;
     uint32_t *counters = nullptr;               // [2] compaction total
     sl_push_ctl *ctl = nullptr;                 // device-driven sparse rounds
-    uint32_t *long_list = nullptr;              // deferred hub columns
+    uint2 *long_list = nullptr;                 // (column, piece) work items of frontier columns longer than one piece
     uint32_t *touched = nullptr;                // query sessions: rows whose state must be cleaned up afterwards
     bool flooded = false;                       // a dense round ran: every row may be touched
     uint32_t *block_count = nullptr, *block_off = nullptr;
     uint32_t nblocks = 0;
+    sl_round_io *io_dev = nullptr;              // argument block of the running batch
 };
 
 sl_status compact(push_state &ps, const double *delta, double theta, uint32_t *list, uint32_t *h_count, hipStream_t s)
@@ -543,8 +673,8 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     DevBuf resbuf;
     SL_TRY(resbuf.alloc(64));
 
-    static int sparse_batch = -1;
-    if (sparse_batch < 0) { const char *e = getenv("SL_PUSH_BATCH"); sparse_batch = e ? atoi(e) : 12; if (sparse_batch < 1) sparse_batch = 1; }
+    static int cfg_batch = -1;
+    if (cfg_batch < 0) { const char *e = getenv("SL_PUSH_BATCH"); cfg_batch = e ? atoi(e) : 12; if (cfg_batch < 1) cfg_batch = 1; }
     const double dense_limit = dense_switch * (double)n;               // nf > dense_limit  <=>  nf > floor(dense_limit)
     const uint32_t dense_threshold = dense_limit >= 4294967295.0 ? 0xffffffffu : (dense_limit > 0.0 ? (uint32_t)dense_limit : 0u);
 
@@ -593,28 +723,32 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
         } else {
             if (!list_valid) { SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s)); list_valid = true; list_sorted = true; need_log = true;
                                SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s)); }
-            // a batch of device-driven sparse rounds (one round when the frontier lists are being logged)
-            // the first batch is the long one; a query that outlives it usually needs a few rounds more, and every round enqueued
-            // past the stop still costs five empty launches
-            uint64_t batch = plog.log ? 1 : (uint64_t)(sparse_batches_done == 0 ? sparse_batch : std::max(sparse_batch / 2, 1));
+            // a batch of device-driven sparse rounds (one round when the frontier lists are being logged); the first batch is the
+            // long one — a query that outlives it usually needs a few rounds more, and every round enqueued past the stop still
+            // costs four empty launches
+            uint64_t batch = plog.log ? 1 : (uint64_t)(sparse_batches_done == 0 ? cfg_batch : std::max(cfg_batch / 2, 1));
             ++sparse_batches_done;
             if (batch > max_rounds - rs.rounds) batch = max_rounds - rs.rounds;
-            hipLaunchKernelGGL(sl_push_ctl_reset_kernel, dim3(1), dim3(1), 0, s, ps.ctl, nf);
-            hipLaunchKernelGGL(sl_frontier_hits_kernel, dim3((uint32_t)std::min<uint64_t>((nf + 255) / 256, 512)), dim3(256), 0, s, ps.ctl, ps.frontier[0], ps.op.tptr);
-            hipLaunchKernelGGL(sl_hits_gate_kernel, dim3(1), dim3(1), 0, s, ps.ctl, (unsigned long long)ps.rec_cap);   // hard limit: the record buffer
+            sl_round_io io{};
+            io.c = ps.ctl;
+            io.frontier[0] = ps.frontier[0]; io.frontier[1] = ps.frontier[1];
+            io.delta[0] = ps.delta[cur]; io.delta[1] = ps.delta[1 - cur];
+            io.op = ps.op; io.x = ps.x; io.r = ps.r; io.dinv = ps.dinv; io.recs = ps.recs; io.head = ps.head; io.cand = ps.cand;
+            io.flag = ps.cand_flag; io.long_cols = ps.long_list; io.touched = ps.touched; io.heavy = ps.heavy;
+            io.theta = theta; io.order = order; io.dense_threshold = dense_threshold; io.round_limit = (uint32_t)batch; io.hit_limit = hit_limit;
+            io.nf0 = nf; io.rec_cap = ps.rec_cap;
+            const sl_round_io *iop = ps.io_dev;
+            hipLaunchKernelGGL(sl_set_io_kernel, dim3(1), dim3(1), 0, s, io, ps.io_dev);
+            hipLaunchKernelGGL(sl_push_ctl_reset_kernel, dim3(1), dim3(1), 0, s, iop);
+            hipLaunchKernelGGL(sl_frontier_hits_kernel, dim3((uint32_t)std::min<uint64_t>((nf + 255) / 256, 512)), dim3(256), 0, s, iop);
+            hipLaunchKernelGGL(sl_hits_gate_kernel, dim3(1), dim3(1), 0, s, iop);              // hard limit: the record buffer
             for (uint64_t b = 0; b < batch; ++b) {
-                const int c = cur ^ (int)(b & 1);
-                uint32_t *f_in = ps.frontier[b & 1], *f_out = ps.frontier[1 - (b & 1)];
-                hipLaunchKernelGGL(sl_expand_kernel, dim3(1024), dim3(256), 0, s, ps.ctl, f_in, ps.op, ps.delta[c], ps.x, ps.recs, ps.head, ps.cand,
-                                   ps.cand_flag, ps.long_list, ps.touched);
-                hipLaunchKernelGGL(sl_expand_long_kernel, dim3(512), dim3(256), 0, s, ps.ctl, ps.long_list, ps.op, ps.delta[c], ps.recs, ps.head, ps.cand,
-                                   ps.cand_flag, ps.touched);
-                hipLaunchKernelGGL(sl_pull_hits_kernel, dim3(512), dim3(256), 0, s, ps.ctl, ps.cand, ps.op, ps.recs, ps.head, ps.dinv, theta, order, ps.r,
-                                   ps.delta[1 - c], f_out, ps.heavy);
-                hipLaunchKernelGGL(sl_pull_heavy_kernel, dim3(512), dim3(256), 0, s, ps.ctl, ps.heavy, ps.op, ps.delta[c], ps.dinv, theta, order, ps.r,
-                                   ps.delta[1 - c], f_out);
-                hipLaunchKernelGGL(sl_clear_kernel, dim3(128), dim3(256), 0, s, ps.ctl, f_in, ps.delta[c], dense_threshold, hit_limit);
+                hipLaunchKernelGGL(sl_expand_kernel, dim3(1024), dim3(256), 0, s, iop);
+                hipLaunchKernelGGL(sl_expand_long_kernel, dim3(512), dim3(256), 0, s, iop);
+                hipLaunchKernelGGL(sl_pull_hits_kernel, dim3(512), dim3(256), 0, s, iop);
+                hipLaunchKernelGGL(sl_pull_heavy_kernel, dim3(128), dim3(256), 0, s, iop);
             }
+            hipLaunchKernelGGL(sl_batch_end_kernel, dim3(128), dim3(256), 0, s, iop);
             sl_push_ctl h;
             SL_HIP(hipMemcpyAsync(&h, ps.ctl, sizeof(h), hipMemcpyDeviceToHost, s));
             SL_HIP(hipStreamSynchronize(s));
@@ -654,10 +788,11 @@ sl_status alloc_state(push_state &ps, uint64_t n, uint64_t nnz, DevBuf bufs[20],
     SL_TRY(get(bufs[k], n * 4)); ps.heavy = bufs[k++].as<uint32_t>();
     SL_TRY(get(bufs[k], n * 4)); ps.head = bufs[k++].as<uint32_t>();
     SL_TRY(get(bufs[k], n * 4)); ps.cand_flag = bufs[k++].as<uint32_t>();
-    SL_TRY(get(bufs[k], n * 4)); ps.long_list = bufs[k++].as<uint32_t>();
+    SL_TRY(get(bufs[k], (ps.rec_cap / SL_PIECE + n + 64) * sizeof(uint2))); ps.long_list = bufs[k++].as<uint2>();   // pieces <= hits / 256 + |frontier|
     SL_TRY(get(bufs[k], (ps.rec_cap + 256) * sizeof(sl_hit))); ps.recs = bufs[k++].as<sl_hit>();
     SL_TRY(get(bufs[k], 64)); ps.counters = bufs[k++].as<uint32_t>();
     SL_TRY(get(bufs[k], sizeof(sl_push_ctl))); ps.ctl = bufs[k++].as<sl_push_ctl>();
+    SL_TRY(get(bufs[k], sizeof(sl_round_io))); ps.io_dev = bufs[k++].as<sl_round_io>();
     SL_TRY(get(bufs[k], (size_t)ps.nblocks * 4)); ps.block_count = bufs[k++].as<uint32_t>();
     SL_TRY(get(bufs[k], (size_t)ps.nblocks * 4)); ps.block_off = bufs[k++].as<uint32_t>();
     SL_HIP(hipMemsetAsync(ps.ctl, 0, sizeof(sl_push_ctl), s));
