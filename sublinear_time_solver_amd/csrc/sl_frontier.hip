@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 sl_status sl_sort_keys_u32(const uint32_t *keys_in, uint32_t *keys_out, uint64_t n, hipStream_t s);
@@ -652,8 +653,12 @@ struct round_stats { uint64_t rounds = 0, pushes = 0, rows_touched = 0, dense_ro
 // preseeded: the caller has already written the round-0 frontier (list in frontier[0], values in delta[0], delta[1]
 // all zero) and passes its size — a query session seeds one row without touching the other n - 1.
 sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t max_rounds, int order, double dense_switch,
-                   push_log &plog, round_stats &rs, float *device_ms, bool preseeded = false, uint32_t nf0 = 0)
+                   push_log &plog, round_stats &rs, float *device_ms, bool preseeded = false, uint32_t nf0 = 0,
+                   const std::function<void(hipStream_t, bool, uint32_t)> *tail = nullptr)
 {
+    // tail (query sessions): work to enqueue behind every sparse batch, BEFORE the host knows how the batch ended — its kernels
+    // check the control block themselves and only act if the batch finished the query (frontier empty, or — second argument —
+    // the round limit the caller set was reached).  A local query that converges inside its first batch is one host round trip.
     hipStream_t s = sl_context().stream;
     const uint64_t n = ps.n;
     sl_timer timer;
@@ -749,6 +754,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
                 hipLaunchKernelGGL(sl_pull_heavy_kernel, dim3(128), dim3(256), 0, s, iop);
             }
             hipLaunchKernelGGL(sl_batch_end_kernel, dim3(128), dim3(256), 0, s, iop);
+            if (tail && !ps.flooded) (*tail)(s, rs.rounds + batch >= max_rounds, (uint32_t)batch);
             sl_push_ctl h;
             SL_HIP(hipMemcpyAsync(&h, ps.ctl, sizeof(h), hipMemcpyDeviceToHost, s));
             SL_HIP(hipStreamSynchronize(s));
@@ -905,43 +911,106 @@ __global__ void sl_seed_kernel(uint32_t row, double p, int in_frontier, double *
     c->n_touched = 1;
 }
 
-// estimate = sum x_i b_i and ||r||_1 over the ASCENDING touched list: 1024-entry tiles, fixed tree inside a tile
-__global__ __launch_bounds__(256) void sl_touched_sums_kernel(uint32_t nt, const uint32_t *sorted, const double *x, const double *b,
-                                                              const double *r, double *partials, uint32_t nblocks)
+// estimate = sum x_i b_i and ||r||_1 over the touched rows.  The list comes in whatever order the rounds appended it, and the
+// answer must not depend on that: a binned (pre-rounded) sum.  Pass 1 takes the largest magnitude M of either set of terms; with
+// 2^E > M every term is cut into SL_BINS slices, slice b a multiple of 2^(E - 20 (b + 1)) below 2^(E - 20 b) — sums of such
+// multiples are EXACT in fp64 for up to 2^32 terms, so any reduction order (shuffles, atomics) gives the same bits — and the
+// host adds the bins smallest first.  80 bits below the largest term; no sort, two launches.
+#define SL_BINS 4
+#define SL_BIN_BITS 20
+#define SL_SUM_STRIDE 16               // accumulators 128 bytes apart: atomics on different values do not share an L2 line
+__device__ __forceinline__ void sl_touched_terms(uint32_t i, const double *x, const double *b, const double *r, double &e, double &l)
 {
-    __shared__ double red[8];
-    double e = 0.0, l = 0.0;
-    const uint32_t base = blockIdx.x * 1024;
+    e = DMUL(x[i], b[i]);
+    l = fabs(r[i]);
+}
+// The three kernels of a query's tail run speculatively behind a batch (run_push): they act only if the batch finished the query.
+// gate: 0 = unconditional (the host already knows), 1 = frontier empty, 2 = frontier empty or round limit reached
+__device__ __forceinline__ bool sl_tail_open(const sl_push_ctl *c, int gate, uint32_t round_limit, uint32_t &nt)
+{
+    nt = c->n_touched;
+    if (gate == 0) return true;
+    return c->stop == 1u || (gate == 2 && c->rounds >= round_limit);
+}
+__global__ __launch_bounds__(256) void sl_touched_max_kernel(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, const double *x,
+                                                             const double *b, const double *r, unsigned long long *mx)
+{
+    uint32_t nt;
+    if (!sl_tail_open(c, gate, round_limit, nt)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) mx[2 * SL_SUM_STRIDE - 1] = 1ull;   // marker: the sums below are those of the finished query
+    unsigned long long me = 0, ml = 0;                     // bit patterns of non-negative doubles order like the doubles
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nt; t += gridDim.x * 256) {
+        double e, l;
+        sl_touched_terms(touched[t], x, b, r, e, l);
+        me = max(me, (unsigned long long)__double_as_longlong(fabs(e)));
+        ml = max(ml, (unsigned long long)__double_as_longlong(l));
+    }
+    for (int off = 32; off > 0; off >>= 1) { me = max(me, __shfl_xor(me, off)); ml = max(ml, __shfl_xor(ml, off)); }
+    __shared__ unsigned long long red[8];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = me; red[4 + (threadIdx.x >> 6)] = ml; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                // one atomic per block and value: they all aim at the same two lines
+        me = max(max(red[0], red[1]), max(red[2], red[3])); ml = max(max(red[4], red[5]), max(red[6], red[7]));
+        if (me) atomicMax(&mx[0], me);
+        if (ml) atomicMax(&mx[SL_SUM_STRIDE], ml);
+    }
+}
+// slices of v against the top exponent E (2^E > every |v|): slice k = v rounded to a multiple of 2^(E - 20 (k + 1)), then removed
+// from v (scaling by a power of two, rounding to an integer and subtracting the slice are all exact)
+__device__ __forceinline__ void sl_bin_slices(double v, int E, double out[SL_BINS])
+{
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t t = base + k * 256 + threadIdx.x;
-        if (t < nt) { const uint32_t i = sorted[t]; e = DADD(e, DMUL(x[i], b[i])); l = DADD(l, fabs(r[i])); }
-    }
-    for (int off = 32; off > 0; off >>= 1) { e = DADD(e, __shfl_xor(e, off)); l = DADD(l, __shfl_xor(l, off)); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = e; red[4 + (threadIdx.x >> 6)] = l; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        partials[blockIdx.x] = DADD(DADD(DADD(red[0], red[1]), red[2]), red[3]);
-        partials[nblocks + blockIdx.x] = DADD(DADD(DADD(red[4], red[5]), red[6]), red[7]);
+    for (int k = 0; k < SL_BINS; ++k) {
+        const int eq = E - SL_BIN_BITS * (k + 1);
+        const double p = ldexp(rint(ldexp(v, -eq)), eq);
+        out[k] = p;
+        v = DSUB(v, p);
     }
 }
-__global__ __launch_bounds__(1024) void sl_touched_final_kernel(uint32_t nblocks, const double *partials, double *out)
+__device__ __forceinline__ int sl_top_exponent(unsigned long long bits)
 {
-    __shared__ double red[32];
-    double e = 0.0, l = 0.0;
-    for (uint32_t j = threadIdx.x; j < nblocks; j += 1024) { e = DADD(e, partials[j]); l = DADD(l, partials[nblocks + j]); }
-    for (int off = 32; off > 0; off >>= 1) { e = DADD(e, __shfl_xor(e, off)); l = DADD(l, __shfl_xor(l, off)); }
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = e; red[16 + (threadIdx.x >> 6)] = l; }
+    if (bits == 0) return 0;
+    int e = 0;
+    (void)frexp(__longlong_as_double((long long)bits), &e);     // value = m 2^e, 0.5 <= m < 1
+    return e < -900 ? -900 : e;                                   // keep every quantum a normal number
+}
+__global__ __launch_bounds__(256) void sl_touched_bins_kernel(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, const double *x,
+                                                              const double *b, const double *r, const unsigned long long *mx, double *bins)
+{
+    uint32_t nt;
+    if (!sl_tail_open(c, gate, round_limit, nt)) return;
+    const unsigned long long be = mx[0], bl = mx[SL_SUM_STRIDE];
+    if ((be >> 52) == 0x7ffull || (bl >> 52) == 0x7ffull) return;           // a non-finite term: the host reports it from the maxima
+    const int Ee = sl_top_exponent(be), El = sl_top_exponent(bl);
+    double acc[2 * SL_BINS];
+#pragma unroll
+    for (int k = 0; k < 2 * SL_BINS; ++k) acc[k] = 0.0;
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nt; t += gridDim.x * 256) {
+        double e, l, pe[SL_BINS], pl[SL_BINS];
+        sl_touched_terms(touched[t], x, b, r, e, l);
+        sl_bin_slices(e, Ee, pe);
+        sl_bin_slices(l, El, pl);
+#pragma unroll
+        for (int k = 0; k < SL_BINS; ++k) { acc[k] = DADD(acc[k], pe[k]); acc[SL_BINS + k] = DADD(acc[SL_BINS + k], pl[k]); }
+    }
+    __shared__ double red[4][2 * SL_BINS];
+#pragma unroll
+    for (int k = 0; k < 2 * SL_BINS; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v = DADD(v, __shfl_xor(v, off));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double te = red[0], tl = red[16];
-        for (int w = 1; w < 16; ++w) { te = DADD(te, red[w]); tl = DADD(tl, red[16 + w]); }
-        out[0] = te; out[1] = tl;
+    if (threadIdx.x < 2 * SL_BINS) {                        // exact additions: neither tree nor arrival order matters
+        const double v = DADD(DADD(red[0][threadIdx.x], red[1][threadIdx.x]), DADD(red[2][threadIdx.x], red[3][threadIdx.x]));
+        if (v != 0.0) atomicAdd(&bins[threadIdx.x * SL_SUM_STRIDE], v);
     }
 }
-__global__ __launch_bounds__(256) void sl_touched_cleanup_kernel(uint32_t nt, const uint32_t *touched, double *x, double *r, double *d0,
-                                                                 double *d1, uint32_t *flag)
+__global__ __launch_bounds__(256) void sl_touched_cleanup_kernel(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, double *x, double *r,
+                                                                 double *d0, double *d1, uint32_t *flag)
 {
+    uint32_t nt;
+    if (!sl_tail_open(c, gate, round_limit, nt)) return;
     const uint32_t stride = gridDim.x * 256;
     for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < nt; t += stride) {
         const uint32_t i = touched[t];
@@ -967,7 +1036,7 @@ static sl_status session_create(const sl_matrix *m, int matrix_is_transpose, con
     auto get = [owned](DevBuf &buf, size_t bytes) { return owned ? buf.alloc_owned(bytes) : buf.alloc(bytes); };
     sl_status st = alloc_state(q->ps, n, m->nnz, q->bufs, owned);
     if (st == SL_OK) st = get(q->touched, (n ? n : 1) * 4);
-    if (st == SL_OK) st = get(q->sums, (2 * ((n + 1023) / 1024) + 8) * sizeof(double));
+    if (st == SL_OK) st = get(q->sums, (2 + 2 * SL_BINS) * SL_SUM_STRIDE * sizeof(double));
     unsigned long long hs[4] = {0, 0, 0, 0};
     if (st == SL_OK) {
         q->ps.touched = q->touched.as<uint32_t>();
@@ -1035,25 +1104,43 @@ sl_status sl_query_session_estimate(sl_query_session *q, uint64_t row, double th
     round_stats rs;
     rs.n_touched = 1;
     float ms = 0.f;
+    // estimate = y . b ; residual_l1 = ||r_y||_1 over the touched rows (binned sums: independent of the list order), then exactly
+    // those rows are zeroed again.  Enqueued behind every sparse batch, acting only if that batch finished the query.
+    unsigned long long *mx = q->sums.as<unsigned long long>();
+    double *bins = q->sums.as<double>() + 2 * SL_SUM_STRIDE;
+    double hs[(2 + 2 * SL_BINS) * SL_SUM_STRIDE] = {0.0};
+    hipError_t tail_err = hipSuccess;
+    const std::function<void(hipStream_t, bool, uint32_t)> tail = [&](hipStream_t ts, bool limit_is_final, uint32_t round_limit) {
+        const int gate = round_limit == 0 ? 0 : (limit_is_final ? 2 : 1);
+        hipError_t e = hipMemsetAsync(q->sums.p, 0, sizeof(hs), ts);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(sl_touched_max_kernel, dim3(128), dim3(256), 0, ts, ps.ctl, gate, round_limit, ps.touched, ps.x, q->db, ps.r, mx);
+            hipLaunchKernelGGL(sl_touched_bins_kernel, dim3(128), dim3(256), 0, ts, ps.ctl, gate, round_limit, ps.touched, ps.x, q->db, ps.r, mx, bins);
+            hipLaunchKernelGGL(sl_touched_cleanup_kernel, dim3(256), dim3(256), 0, ts, ps.ctl, gate, round_limit, ps.touched, ps.x, ps.r, ps.delta[0],
+                               ps.delta[1], ps.cand_flag);
+            e = hipMemcpyAsync(hs, q->sums.p, sizeof(hs), hipMemcpyDeviceToHost, ts);
+        }
+        if (e != hipSuccess) tail_err = e;
+    };
     sl_status st = run_push(ps, q->given_is_transpose ? q->m : nullptr, theta, max_rounds, SL_ORDER_CSR_SEQUENTIAL, q->dense_switch, plog, rs, &ms,
-                            true, (uint32_t)in_frontier);
+                            true, (uint32_t)in_frontier, &tail);
     double h[2] = {0.0, 0.0};
     if (st == SL_OK && !ps.flooded) {
-        // estimate = y . b ; residual_l1 = ||r_y||_1 over the touched rows, in ascending row order
-        const uint32_t nt = rs.n_touched;
-        DevBuf sorted;
-        st = sorted.alloc((size_t)nt * 4);
-        if (st == SL_OK) st = sl_sort_keys_u32(ps.touched, sorted.as<uint32_t>(), nt, s);
+        unsigned long long marker = 0;
+        memcpy(&marker, &hs[2 * SL_SUM_STRIDE - 1], 8);
+        if (marker != 1ull) {                              // no batch ran, or the last one did not end the query on the device's terms
+            tail(s, false, 0);
+            if (tail_err == hipSuccess) tail_err = hipStreamSynchronize(s);
+        }
+        if (tail_err != hipSuccess) st = sl_fail(SL_DEVICE_ERROR, "query readback failed: %s", hipGetErrorString(tail_err));
         if (st == SL_OK) {
-            const uint32_t nb = (nt + 1023) / 1024;
-            double *scr = q->sums.as<double>();
-            hipLaunchKernelGGL(sl_touched_sums_kernel, dim3(nb), dim3(256), 0, s, nt, sorted.as<uint32_t>(), ps.x, q->db, ps.r, scr, nb);
-            hipLaunchKernelGGL(sl_touched_final_kernel, dim3(1), dim3(1024), 0, s, nb, scr, scr + 2 * nb);
-            hipLaunchKernelGGL(sl_touched_cleanup_kernel, dim3((uint32_t)std::min<uint64_t>((nt + 255) / 256, 1024)), dim3(256), 0, s, nt, ps.touched,
-                               ps.x, ps.r, ps.delta[0], ps.delta[1], ps.cand_flag);
-            hipError_t e = hipMemcpyAsync(h, scr + 2 * nb, 16, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (e != hipSuccess) st = sl_fail(SL_DEVICE_ERROR, "query readback failed: %s", hipGetErrorString(e));
+            for (int v = 0; v < 2; ++v) {
+                const double m = hs[v * SL_SUM_STRIDE];                    // bit pattern of a non-negative double
+                double sum = 0.0;
+                if (!std::isfinite(m)) sum = m;                            // inf / nan term: report it
+                else for (int k = SL_BINS - 1; k >= 0; --k) sum += hs[(2 + v * SL_BINS + k) * SL_SUM_STRIDE];   // smallest quantum first
+                h[v] = sum;
+            }
         }
     } else if (st == SL_OK) {
         // the frontier flooded the graph: whole-vector sums and a whole-vector reset
