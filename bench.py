@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the cpu_baseline leg
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary column-structure measurements")
+    ap.add_argument("--exchange", choices=["p2p", "allreduce"], default="p2p",
+                    help="banded systems, N > 1: neighbour sends of the boundary strips (default) or ONE all-reduce over a zero-filled compact strip buffer")
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: do not split boundary / interior rows")
     ap.add_argument("--force-split", action="store_true", help="testing: use the boundary / interior split even on one GPU")
     args = ap.parse_args()
@@ -204,7 +206,12 @@ def main():
     # SL_BENCH_LOOPBACK=1 (with SL_BENCH_FORCE_DIST=1 --force-split): MEASUREMENT mode on one GPU — the rank exchanges both
     # boundary strips with itself over RCCL and all-reduces the norm, i.e. the full per-step enqueue path of an inner rank
     loopback = force_dist and world == 1 and os.environ.get("SL_BENCH_LOOPBACK") == "1" and backend == "nccl"
-    exchange = D.AllGatherExchange(part) if w == 0 else D.HaloExchange(part, w, loopback=loopback)
+    if w == 0:
+        exchange = D.AllGatherExchange(part)
+    elif args.exchange == "allreduce":
+        exchange = D.HaloAllReduceExchange(part, w)
+    else:
+        exchange = D.HaloExchange(part, w, loopback=loopback)
     # the norm log is all-reduced once per batch of 10 steps (= SL_SOLVE_BATCH of the speculative solve loop); 1 = every step
     reduce_every = int(os.environ.get("SL_BENCH_REDUCE_EVERY", "10"))
     drv = D.PartitionedNeumann(part, local_step, exchange, t0, x, reduce_every=reduce_every)

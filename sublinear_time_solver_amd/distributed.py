@@ -237,6 +237,55 @@ class HaloExchange:
         return 8 * self.w * inner
 
 
+class HaloAllReduceExchange:
+    """The same halo as HaloExchange, moved the way BASELINE's north_star words it: ONE all-reduce (sum) over a compact, zero-filled
+    buffer of all boundary strips — boundary k (between ranks k and k + 1) owns two slots of w entries, [last w of rank k | first
+    w of rank k + 1]; every slot is written by exactly one rank and zero everywhere else, so the sum is a copy (x + 0 = x; only a
+    -0.0 would come back as +0.0).  Every rank receives every strip (2 w (P - 1) entries): more bytes and more glue launches than
+    the neighbour sends, which stay the default; selectable for comparison (bench.py --exchange allreduce)."""
+    name = "halo_allreduce"
+    needs_only_boundary = True
+
+    def __init__(self, part: RowPartition, half_bandwidth: int, group=None):
+        sizes = [part.range_of(r)[1] - part.range_of(r)[0] for r in range(part.world)]
+        if part.world > 1 and min([v for v in sizes if v > 0] or [0]) < half_bandwidth:
+            raise ValueError("halo exchange needs at least w rows on every rank")
+        self.part, self.w, self.group = part, int(half_bandwidth), group
+        self.compact = None
+
+    def start(self, t_full: torch.Tensor):
+        p, w = self.part, self.w
+        if p.world == 1 or w == 0:
+            return None
+        if self.compact is None or self.compact.device != t_full.device:
+            self.compact = torch.zeros(p.world - 1, 2, w, dtype=t_full.dtype, device=t_full.device)
+        c = self.compact
+        c.zero_()
+        if p.rank > 0 and p.hi > p.lo:
+            c[p.rank - 1, 1].copy_(t_full[p.lo:p.lo + w])
+        if p.rank < p.world - 1 and p.hi < p.n_global:
+            c[p.rank, 0].copy_(t_full[p.hi - w:p.hi])
+        return all_reduce_scalar(c, dist.ReduceOp.SUM, self.group, async_op=True), t_full
+
+    def finish(self, handle) -> None:
+        if not handle:
+            return
+        work, t_full = handle
+        if work is not None:
+            work.wait()
+        p, w, c = self.part, self.w, self.compact
+        if p.rank > 0 and p.hi > p.lo:
+            t_full[p.lo - w:p.lo].copy_(c[p.rank - 1, 0])
+        if p.rank < p.world - 1 and p.hi < p.n_global:
+            t_full[p.hi:p.hi + w].copy_(c[p.rank, 1])
+
+    def __call__(self, t_full: torch.Tensor) -> None:
+        self.finish(self.start(t_full))
+
+    def bytes_sent_per_step(self) -> int:
+        return 8 * 2 * self.w * max(self.part.world - 1, 0)
+
+
 # local_step(t_in_full, t_out_local, x_local, norm2_out) -> None : one fused Neumann step on the local rows
 LocalStep = Callable[[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor], None]
 

@@ -53,6 +53,8 @@ def _worker(rank, world, port, n, k, w, steps, out_dir, split=False):
         t0 = torch.from_numpy(t0)
         x = t0[part.lo:part.hi].clone()
         ex = D.AllGatherExchange(part) if w == 0 else D.HaloExchange(part, w)
+        if os.environ.get("SL_TEST_EXCHANGE") == "allreduce" and w:
+            ex = D.HaloAllReduceExchange(part, w)
         local = _oracle_local_step(rp, ci, va, dinv, part.lo)
         if split:      # boundary rows first, exchange in flight under the interior rows
             def piece(lo_l, hi_l):
@@ -90,6 +92,24 @@ def test_partitioned_iteration_matches_single_process(tmp_path, n, k, w, split):
         np.testing.assert_allclose(z["norms"], o["term_norms"][1:], rtol=1e-12)
         if w:
             assert int(z["sent"]) == 8 * w          # one neighbour each at world = 2
+    assert (xs.view(np.uint64) == o["x"].view(np.uint64)).all()
+    assert (ts.view(np.uint64) == o["term"].view(np.uint64)).all()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_halo_as_one_allreduce(tmp_path, monkeypatch, split):
+    """the halo moved as ONE all-reduce over a zero-filled compact strip buffer (north_star's wording): same bits, three ranks"""
+    monkeypatch.setenv("SL_TEST_EXCHANGE", "allreduce")
+    n, k, w, world, steps = 6000, 12, 300, 3, 4
+    mp.spawn(_worker, args=(world, _free_port(), n, k, w, steps, str(tmp_path), split), nprocs=world, join=True)
+    rp, ci, va, b = G.sdd_rows(n, k, 3, w)
+    o = O.neumann_solve(rp, ci, va, b, max_terms=steps + 1, series_tolerance=0.0, max_iterations=steps + 1, tolerance=0.0)
+    xs, ts = np.zeros(n), np.zeros(n)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        xs[int(z["lo"]):int(z["hi"])] = z["x"]
+        ts[int(z["lo"]):int(z["hi"])] = z["t"]
+        assert int(z["sent"]) == 8 * 2 * w * (world - 1)
     assert (xs.view(np.uint64) == o["x"].view(np.uint64)).all()
     assert (ts.view(np.uint64) == o["term"].view(np.uint64)).all()
 

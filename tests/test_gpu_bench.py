@@ -49,7 +49,8 @@ def _bench_two_ranks(n_per_rank, w, *extra):
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("w,extra,exchange", [(512, (), "halo+overlap"), (512, ("--no-overlap",), "halo"), (0, (), "allgather")])
+@pytest.mark.parametrize("w,extra,exchange", [(512, (), "halo+overlap"), (512, ("--no-overlap",), "halo"), (0, (), "allgather"),
+                                              (512, ("--exchange", "allreduce"), "halo_allreduce+overlap")])
 def test_bench_two_ranks_reproduce_the_single_rank_iteration(gpu, w, extra, exchange):
     """bench.py at world size 2 (row slices at a non-zero row offset, halo / all-gather exchange, boundary-first overlap,
     norm all-reduce) must run the same iteration as one rank owning all rows: same last term norm"""
