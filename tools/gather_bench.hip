@@ -45,11 +45,18 @@ static int run(const char *name, const double *table, uint64_t table_n, double *
     return 0;
 }
 
-int main()
+int main(int argc, char **argv)
 {
     double *table, *sink;
     const uint64_t big = 1ull << 27;                 // 1 GiB
     CK(hipMalloc(&table, big * 8)); CK(hipMalloc(&sink, 64)); CK(hipMemset(table, 0, big * 8));
+    if (argc > 1 && argv[1][0] == 's') {             // small tables: how fast are gathers that stay inside an XCD's L2 (4 MB)?
+        for (uint64_t kb : {64ull, 256ull, 512ull, 1024ull, 2048ull, 4096ull, 16384ull, 32768ull}) {
+            run<16, 0, 256>("plain", table, kb * 128, sink, 16384);
+            run<32, 0, 256>("plain", table, kb * 128, sink, 16384);
+        }
+        return 0;
+    }
     for (uint64_t tn : {10000000ull, 1000000ull, 100000000ull}) {
         for (int grid : {4096, 16384, 65536}) {
             run<16, 0, 256>("plain", table, tn, sink, grid);
