@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NW * 64) void panel_kernel(uint32_t ntiles, uint32_
             v[u] = __builtin_nontemporal_load(&val[s + k]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) tv[u] = t[cl[u]];
+        for (int u = 0; u < U; ++u) tv[u] = t[(VAR & 1) ? (cl[u] & 0x1ffffu) : cl[u]];   // VAR&1: every gather from the first 1 MB
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t rowl = rl[u];
@@ -116,8 +116,8 @@ static int run(uint32_t n, uint32_t k, uint32_t wt, int pcb)
 int main()
 {
     const uint32_t n = 10000000 / 4096 * 4096;
-    run<4, 4>(n, 16, 2048, 17); run<4, 8>(n, 16, 2048, 17); run<4, 16>(n, 16, 2048, 17); run<4, 4>(n, 16, 1024, 17); run<4, 8>(n, 16, 1024, 17);
-    run<4, 16>(n, 16, 1024, 17); run<2, 16>(n, 16, 2048, 17); run<4, 16>(n, 16, 2560, 17); run<4, 32>(n, 16, 2048, 17);
-    run<4, 16, 2>(n, 16, 2048, 17);
+    // diagnostics: var 1 = every gather from the first panel (perfect locality), var 2 = no scattered LDS update; small tiles = full occupancy
+    run<4, 8, 3>(n, 16, 256, 17); run<4, 16, 3>(n, 16, 256, 17); run<4, 8, 1>(n, 16, 256, 17); run<4, 8, 3>(n, 16, 2048, 17); run<4, 8, 1>(n, 16, 2048, 17);
+    run<4, 8, 3>(n, 16, 1024, 17); run<4, 8, 1>(n, 16, 1024, 17); run<4, 8, 1>(n, 16, 512, 17);
     return 0;
 }
