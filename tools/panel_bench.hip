@@ -33,7 +33,7 @@ template <int NW, int U, int VAR>
 __global__ __launch_bounds__(NW * 64) void panel_kernel(uint32_t ntiles, uint32_t per_tile, uint32_t wt, const uint16_t *__restrict__ rowl_a,
                                                         const uint32_t *__restrict__ col_a, const double *__restrict__ val,
                                                         const double *__restrict__ t, const double *__restrict__ dinv, double *__restrict__ out,
-                                                        double *__restrict__ x, double *partials)
+                                                        double *__restrict__ x, double *partials, uint32_t *done, uint32_t P, uint32_t target)
 {
     extern __shared__ double acc_all[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -42,7 +42,19 @@ __global__ __launch_bounds__(NW * 64) void panel_kernel(uint32_t ntiles, uint32_
     if (tile >= ntiles) return;
     for (uint32_t r = lane; r < wt; r += 64) acc[r] = 0.0;
     const uint64_t s = (uint64_t)tile * per_tile;
+    uint32_t cur_panel = 0;
     for (uint32_t c0 = 0; c0 < per_tile; c0 += 64 * U) {
+        if (VAR & 4) {
+            // tickets (a locality hint, never a correctness condition): a wave enters panel p only when `target` waves have left panel p - 2
+            const uint32_t pnl = (uint32_t)(((uint64_t)c0 * P) / per_tile);
+            if (pnl != cur_panel) {
+                if (lane == 0) {
+                    atomicAdd(&done[cur_panel], 1u);
+                    if (pnl >= 2) { uint32_t spins = 0; while (__hip_atomic_load(&done[pnl - 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < 4000) __builtin_amdgcn_s_sleep(4); }
+                }
+                cur_panel = pnl;
+            }
+        }
         uint32_t rl[U], cl[U]; double v[U], tv[U]; bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -89,6 +101,8 @@ static int run(uint32_t n, uint32_t k, uint32_t wt, int pcb)
 {
     const uint32_t pc = 1u << pcb, P = (n + pc - 1) / pc, ntiles = n / wt;
     const uint32_t per_tile = wt * k;
+    uint32_t *done; CK(hipMalloc(&done, (P + 8) * 4));
+    const uint32_t target = (uint32_t)(0.9 * ntiles);
     const uint64_t total = (uint64_t)ntiles * per_tile;
     uint16_t *rowl; uint32_t *col; double *val, *t, *dinv, *out, *x, *partials;
     CK(hipMalloc(&rowl, total * 2)); CK(hipMalloc(&col, total * 4)); CK(hipMalloc(&val, total * 8));
@@ -97,13 +111,14 @@ static int run(uint32_t n, uint32_t k, uint32_t wt, int pcb)
     CK(hipMemset(t, 0, ((uint64_t)n + 64) * 8)); CK(hipMemset(dinv, 0, (uint64_t)n * 8)); CK(hipMemset(x, 0, (uint64_t)n * 8));
     fill_kernel<<<4096, 256>>>(total, per_tile, wt, pc, P, n, rowl, col, val);
     CK(hipDeviceSynchronize());
+    CK(hipMemset(done, 0, (P + 8) * 4));
     const size_t lds = (size_t)NW * wt * 8;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(panel_kernel<NW, U, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t grid = (ntiles + NW - 1) / NW;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    panel_kernel<NW, U, VAR><<<grid, NW * 64, lds>>>(ntiles, per_tile, wt, rowl, col, val, t, dinv, out, x, partials); CK(hipDeviceSynchronize());
+    panel_kernel<NW, U, VAR><<<grid, NW * 64, lds>>>(ntiles, per_tile, wt, rowl, col, val, t, dinv, out, x, partials, done, P, target); CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int r = 0; r < 5; ++r) panel_kernel<NW, U, VAR><<<grid, NW * 64, lds>>>(ntiles, per_tile, wt, rowl, col, val, t, dinv, out, x, partials);
+    for (int r = 0; r < 5; ++r) { CK(hipMemsetAsync(done, 0, (P + 8) * 4)); panel_kernel<NW, U, VAR><<<grid, NW * 64, lds>>>(ntiles, per_tile, wt, rowl, col, val, t, dinv, out, x, partials, done, P, target); }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
     const double bytes = 12.0 * n * k + 44.0 * n;
@@ -116,8 +131,9 @@ static int run(uint32_t n, uint32_t k, uint32_t wt, int pcb)
 int main()
 {
     const uint32_t n = 10000000 / 4096 * 4096;
-    // diagnostics: var 1 = every gather from the first panel (perfect locality), var 2 = no scattered LDS update; small tiles = full occupancy
-    run<4, 8, 3>(n, 16, 256, 17); run<4, 16, 3>(n, 16, 256, 17); run<4, 8, 1>(n, 16, 256, 17); run<4, 8, 3>(n, 16, 2048, 17); run<4, 8, 1>(n, 16, 2048, 17);
-    run<4, 8, 3>(n, 16, 1024, 17); run<4, 8, 1>(n, 16, 1024, 17); run<4, 8, 1>(n, 16, 512, 17);
+    // var 0 = the real sweep; var 1 = every gather from the first 1 MB (perfect locality: the ceiling of the design); var 4 = tickets
+    run<4, 4, 0>(n, 16, 2048, 17); run<4, 4, 0>(n, 16, 1024, 17); run<4, 8, 0>(n, 16, 512, 17);
+    run<4, 8, 1>(n, 16, 2048, 17); run<4, 8, 1>(n, 16, 512, 17);
+    run<4, 8, 0>(1000000 / 4096 * 4096, 8, 512, 17);
     return 0;
 }
