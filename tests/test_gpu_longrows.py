@@ -166,3 +166,45 @@ def test_long_rows_beside_the_slice_kernel(gpu):
                        cwd=root, capture_output=True, text=True, timeout=900, env=dict(os.environ, SL_LONG_ROWS_BESIDE_MIN="0"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def _column_length_system(n=4000, seed=21):
+    """columns of chosen lengths around the expansion's boundaries (a segment = 64 entries, a piece = 256, four columns per wave
+    step), every other column short; row dominant"""
+    rng = np.random.default_rng(seed)
+    lengths = [2, 3, 63, 64, 65, 66, 127, 128, 129, 255, 256, 257, 258, 511, 512, 513, 1023, 1024, 1025, 2049, 300, 70, 5]
+    special = {100 + 37 * k: L for k, L in enumerate(lengths)}
+    rows_of = {}
+    for j in range(n):
+        L = special.get(j, int(rng.integers(1, 6)))
+        r = rng.choice(n - 1, size=L - 1, replace=False) if L > 1 else np.empty(0, dtype=np.int64)
+        rows_of[j] = r + (r >= j)                                   # L - 1 rows other than j; the diagonal makes it L
+    tr, tc, tv = [], [], []
+    for j, r in rows_of.items():
+        tr += r.tolist(); tc += [j] * r.size; tv += rng.uniform(-1.0, 1.0, size=r.size).tolist()
+    tr, tc, tv = np.asarray(tr), np.asarray(tc), np.asarray(tv)
+    off = np.zeros(n)
+    np.add.at(off, tr, np.abs(tv))
+    tr = np.concatenate([tr, np.arange(n)]); tc = np.concatenate([tc, np.arange(n)]); tv = np.concatenate([tv, 2.0 * off + 1.0])
+    return O.csr_from_triplets(tr.tolist(), tc.tolist(), tv.tolist(), n, n), sorted(special)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_frontier_columns_at_segment_and_piece_boundaries(gpu, order):
+    """the round-0 frontier is exactly the columns of length 2 .. 2049 (63/64/65, 255/256/257, 1023/1024/1025 ...): short columns
+    go four to a wave step, longer ones become (column, piece) items; both with and without frontier logs (one round / twelve per batch)"""
+    (rp, ci, va), cols = _column_length_system()
+    n = rp.size - 1
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    lens = np.bincount(ci, minlength=n)
+    assert {int(lens[j]) for j in cols} >= {64, 65, 256, 257, 1024, 1025, 2049}
+    b = np.zeros(n)
+    b[cols] = 1.0 + 0.125 * np.arange(len(cols))
+    o = O.push_sync_solve(rp, ci, va, b, theta=1e-7, order=order, log_cap=1 << 22)
+    g = S.PushSolver(theta=1e-7, dense_switch=2.0, order=order).solve(m, b, log_frontier=1 << 22)
+    assert g["converged"] and g["dense_rounds"] == 0 and g["rounds"] == o["rounds"] and g["rounds"] > 3
+    assert (g["frontier_log"] == o["frontier_log"]).all()
+    assert _bits_equal(g["solution"], o["x"]) and _bits_equal(g["residual"], o["r"])
+    h = S.PushSolver(theta=1e-7, dense_switch=2.0, order=order).solve(m, b)
+    assert (h["rounds"], h["pushes"], h["rows_touched"]) == (o["rounds"], o["pushes"], o["rows_touched"])
+    assert _bits_equal(h["solution"], o["x"]) and _bits_equal(h["residual"], o["r"])
