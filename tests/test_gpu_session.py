@@ -65,3 +65,29 @@ def test_session_survives_flooding_and_round_limit(gpu):
     with S.QuerySession(mt, b, matrix_is_transpose=True) as qt:  # the caller already holds A^T
         e = qt.estimate(100, theta=1e-3)
         assert (e.rounds, e.pushes) == (ref.rounds, ref.pushes) and abs(e.estimate - ref.estimate) <= 1e-15
+
+
+def test_session_sums_are_exact_to_80_bits_and_order_free(gpu):
+    """estimate = sum_i y_i b_i over the touched rows with a right-hand side spanning 40 decades and alternating signs: the binned
+    sum must agree with the correctly rounded sum (math.fsum of the CPU terms) far below fp64 rounding of a naive sum, and must not
+    depend on the order in which the rounds appended the touched rows (same bits on every repetition and from the one-shot call)"""
+    import math
+    n, k, w = 25_000, 11, 300
+    rp, ci, va, _ = G.sdd_rows(n, k, seed=8, half_bandwidth=w)
+    i = np.arange(n)
+    b = np.where(i % 2 == 0, 1.0, -1.0) * 10.0 ** ((i * 7) % 41 - 20)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+    row, theta = n // 2, 1e-9
+    o, _, _ = _oracle_query(rp, ci, va, n, b, row, theta)
+    terms = o["x"] * b
+    exact = math.fsum(terms.tolist())
+    l1_exact = math.fsum(np.abs(o["r"]).tolist())
+    top = float(np.abs(terms).max())
+    with S.QuerySession(m, b) as q:
+        got = [q.estimate(row, theta=theta) for _ in range(3)]
+    assert got[0].rounds == o["rounds"] and np.count_nonzero(terms) > 1000
+    assert abs(got[0].estimate - exact) <= 2.0 ** -52 * abs(exact) + np.count_nonzero(terms) * 2.0 ** -80 * top
+    assert abs(got[0].residual_l1 - l1_exact) <= 2.0 ** -52 * l1_exact
+    assert all((g.estimate, g.residual_l1) == (got[0].estimate, got[0].residual_l1) for g in got)
+    one = S.estimate_entry(m, b, row, theta=theta)
+    assert (one.estimate, one.residual_l1) == (got[0].estimate, got[0].residual_l1)
