@@ -74,6 +74,8 @@ typedef struct sl_matrix sl_matrix; /* opaque, device resident */
 #define SL_MATRIX_DEFAULT 0u
 #define SL_MATRIX_WITH_TRANSPOSE 1u /* also build the column-structure needed by push / estimateEntry */
 #define SL_MATRIX_KEEP_CSR 2u       /* keep the raw CSR arrays on the device next to the slice layout */
+#define SL_MATRIX_COLUMN_PANELS 4u  /* build the column-panel layout whatever the size (by default: only where it pays) */
+#define SL_MATRIX_NO_COLUMN_PANELS 8u /* never build it (saves 14 B per entry of HBM) */
 
 /* ---- library ------------------------------------------------------------------- */
 int sl_abi_version(void);
@@ -117,6 +119,8 @@ typedef struct {
     uint32_t has_transpose;
     uint32_t long_row_threshold; /* rows with more entries than this are served by the long-row kernel (2.5 x mean length, in [24, 256]) */
     uint32_t n_long_rows;
+    uint32_t column_panels;   /* 1: the matrix also carries the column-panel layout (columns spread beyond the LDS window and the L2) */
+    uint32_t reserved;
 } sl_matrix_info;
 sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info);
 /* download the CSR arrays back to the host (needs SL_MATRIX_KEEP_CSR); for tests / ingest */

@@ -22,7 +22,7 @@ SL_MEM_HOST, SL_MEM_DEVICE = 0, 1
 SL_ORDER_CSR_SEQUENTIAL, SL_ORDER_SIMD4 = 0, 1
 SL_START_ZERO, SL_START_REFERENCE_DEFAULT, SL_START_INITIAL_GUESS = 0, 1, 2
 SL_RESIDUAL_TRUE, SL_RESIDUAL_REFERENCE_SCALED = 0, 1
-SL_MATRIX_WITH_TRANSPOSE, SL_MATRIX_KEEP_CSR = 1, 2
+SL_MATRIX_WITH_TRANSPOSE, SL_MATRIX_KEEP_CSR, SL_MATRIX_COLUMN_PANELS, SL_MATRIX_NO_COLUMN_PANELS = 1, 2, 4, 8
 
 u64, u32, i32, f64 = C.c_uint64, C.c_uint32, C.c_int32, C.c_double
 vp = C.c_void_p
@@ -31,7 +31,8 @@ vp = C.c_void_p
 class MatrixInfo(C.Structure):
     _fields_ = [("n_rows", u64), ("n_cols", u64), ("nnz", u64), ("row_offset", u64), ("padded_nnz", u64),
                 ("n_slices", u64), ("device_bytes", u64), ("bandwidth", u64), ("max_row_nnz", u32), ("min_row_nnz", u32),
-                ("uniform_width", u32), ("has_transpose", u32), ("long_row_threshold", u32), ("n_long_rows", u32)]
+                ("uniform_width", u32), ("has_transpose", u32), ("long_row_threshold", u32), ("n_long_rows", u32),
+                ("column_panels", u32), ("reserved", u32)]
 
 
 class NeumannOptions(C.Structure):

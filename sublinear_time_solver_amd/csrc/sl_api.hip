@@ -166,6 +166,8 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
     a.bandwidth = m->bandwidth; a.uniform_width = m->uniform_width;
     a.csr_ptr = m->d_row_ptr; a.csr_idx = m->d_col_idx; a.csr_val = m->d_values;
     a.long_rows = m->d_long_rows; a.n_long = (uint32_t)m->n_long;
+    a.pan_tile_ptr = m->d_pan_tile_ptr; a.pan_row = m->d_pan_row; a.pan_col = m->d_pan_col; a.pan_val = m->d_pan_val;
+    a.n_pan_tiles = (uint32_t)m->n_pan_tiles;
     return a;
 }
 
@@ -224,6 +226,7 @@ void sl_matrix_destroy(sl_matrix *m)
     hipFree(m->d_slice_ptr); hipFree(m->d_row_len); hipFree(m->d_cols); hipFree(m->d_cols16); hipFree(m->d_vals);
     hipFree(m->d_row_ptr); hipFree(m->d_col_idx); hipFree(m->d_values);
     hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval); hipFree(m->d_tent); hipFree(m->d_long_rows);
+    hipFree(m->d_pan_tile_ptr); hipFree(m->d_pan_row); hipFree(m->d_pan_col); hipFree(m->d_pan_val);
     delete m;
 }
 
@@ -318,6 +321,8 @@ sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info)
     info->max_row_nnz = m->max_row_nnz; info->min_row_nnz = m->min_row_nnz; info->uniform_width = m->uniform_width;
     info->has_transpose = m->d_tptr != nullptr;
     info->long_row_threshold = m->long_row;
+    info->column_panels = m->d_pan_tile_ptr ? 1u : 0u;
+    info->reserved = 0;
     info->n_long_rows = (uint32_t)m->n_long;
     return SL_OK;
 }

@@ -55,8 +55,19 @@ struct sl_matrix {
     uint64_t n_long = 0;
     double *d_tval = nullptr;   // [nnz]
     uint32_t *d_tent = nullptr; // [nnz] CSR entry index of each transposed entry (the permutation of the transpose)
+    // column-panel layout: for matrices whose columns are spread far beyond what the LDS window can hold. The entries
+    // of each tile of SL_PANEL_TILE rows, regrouped by panel of 2^SL_PANEL_COL_BITS columns, then row, then column: one stream per tile.
+    uint32_t *d_pan_tile_ptr = nullptr; // [n_pan_tiles + 1], in entries (every tile padded to a multiple of SL_PANEL_CHUNK)
+    uint16_t *d_pan_row = nullptr;      // row inside the tile (SL_PANEL_TILE = padding)
+    uint32_t *d_pan_col = nullptr;      // global column
+    double *d_pan_val = nullptr;
+    uint64_t n_pan_tiles = 0, pan_entries = 0;
     uint64_t device_bytes = 0;
 };
+#define SL_PANEL_TILE 2048u          // rows per tile = per wave: their running sums live in LDS (16 KiB)
+#define SL_PANEL_COL_BITS 17         // a panel = 2^17 columns = 1 MiB of the gathered vector: stays in an XCD's L2 while the tiles pass it
+#define SL_PANEL_CHUNK 256u          // entries a wave has in flight (4 x 64)
+#define SL_PANEL_WAVES 4
 
 // thread-local launch context
 struct sl_ctx {
@@ -190,6 +201,9 @@ struct sl_row_args {
     uint64_t n_rows, n_cols, n_slices, row_offset;
     uint64_t bandwidth;   // ~0 = unknown / do not use the LDS band kernel
     uint32_t uniform_width;
+    // column-panel layout (null unless the matrix carries one)
+    const uint32_t *pan_tile_ptr; const uint16_t *pan_row; const uint32_t *pan_col; const double *pan_val;
+    uint32_t n_pan_tiles;
     // vectors
     const double *gather; // gathered vector (n_cols)
     const double *dinv;   // n_rows

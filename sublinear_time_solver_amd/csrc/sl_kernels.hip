@@ -542,6 +542,80 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_ro
     sl_block_partials<EPI, NW>(a, red, lane, wave, lb, a.part_stride, part0, part1);
 }
 
+// ---- column-panel kernel: gathers served by the L2 -----------------------------------------------------
+// For matrices whose columns are spread over a vector far larger than the L2 (uniformly random columns — the reference
+// generators' recipe): every gather of the general kernel misses L2, and misses are served at 58 G/s whatever the table size
+// (2.7 ms for 1.6e8 of them; gathers that hit L2 run at 265 G/s).  Here the entries of a tile of SL_PANEL_TILE rows are one
+// stream sorted by (panel of 2^17 columns, row, column); a wave owns a tile, keeps the running sum of each of its rows in
+// LDS and walks the stream: all waves pass the panels in the same order at about the same pace, so the megabyte of the
+// vector they gather from stays in L2.  Within a row the products still arrive in ascending column order and are added one
+// by one (entries of one row that sit in neighbouring lanes of a chunk are applied in lane order), so the sum has the bits
+// of the sequential reference loop.  CSR order only; the 4-lane order keeps the general kernel.
+template <int EPI>
+__global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) double pan_acc[];
+    __shared__ double red[2 * SL_PANEL_WAVES];
+    if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x * SL_PANEL_WAVES + wave;
+    double *acc = pan_acc + (size_t)wave * (SL_PANEL_TILE + 64);    // + the slot padding entries add their zeros to
+    double part0 = 0.0, part1 = 0.0;
+    if (tile < a.n_pan_tiles) {
+        for (uint32_t r = lane; r < SL_PANEL_TILE + 64; r += 64) acc[r] = 0.0;
+        const double *__restrict__ g = a.gather;
+        const uint32_t s = a.pan_tile_ptr[tile], e = a.pan_tile_ptr[tile + 1];
+        constexpr int U = SL_PANEL_CHUNK / 64;
+        for (uint32_t c0 = s; c0 < e; c0 += SL_PANEL_CHUNK) {
+            uint32_t rl[U], cl[U];
+            double v[U], tv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t k = c0 + (uint32_t)u * 64u + lane;
+                rl[u] = __builtin_nontemporal_load(&a.pan_row[k]);
+                cl[u] = __builtin_nontemporal_load(&a.pan_col[k]);
+                v[u] = __builtin_nontemporal_load(&a.pan_val[k]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) tv[u] = g[cl[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t row = rl[u];
+                const double prod = DMUL(v[u], tv[u]);
+                // 64 lanes = 64 consecutive entries of the stream.  Inside one panel they are sorted by (row, column): a row that
+                // appears more than once sits in neighbouring lanes.  Across a panel boundary the rows start over, so the same row
+                // may sit in two places of the chunk: the parts are applied one after the other, runs inside a part in lane order.
+                const uint32_t pan = cl[u] >> SL_PANEL_COL_BITS;
+                const uint32_t prow = __shfl_up(row, 1), ppan = __shfl_up(pan, 1);
+                const unsigned long long same = __ballot(lane > 0 && prow == row);
+                const unsigned long long cut = __ballot(lane > 0 && ppan != pan);
+                if (!(same | cut)) {
+                    acc[row] = DADD(acc[row], prod);
+                } else {
+                    const unsigned long long upto = (2ull << lane) - 1ull;
+                    const uint32_t part = (uint32_t)__popcll(cut & upto), nparts = (uint32_t)__popcll(cut) + 1u;
+                    const uint32_t pos = lane - (63u - (uint32_t)__builtin_clzll(~same & upto));     // place inside the run of equal rows
+                    uint32_t maxpos = pos;
+                    for (int off = 32; off > 0; off >>= 1) maxpos = max(maxpos, (uint32_t)__shfl_xor(maxpos, off));
+                    for (uint32_t f = 0; f < nparts; ++f)
+                        for (uint32_t step = 0; step <= maxpos; ++step)
+                            if (part == f && pos == step) acc[row] = DADD(acc[row], prod);
+                }
+            }
+        }
+        for (uint32_t r = lane; r < SL_PANEL_TILE; r += 64) {
+            const uint64_t i = (uint64_t)tile * SL_PANEL_TILE + r;
+            if (i >= a.n_rows || (a.n_long && a.row_len[i] == SL_LONG_SENTINEL)) continue;
+            double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
+            if constexpr (EPI == SL_EPI_NEUMANN) { e_t = g[a.row_offset + i]; e_d = a.dinv[i]; e_x = a.x[i]; }
+            else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
+            else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = g[a.row_offset + i]; }
+            sl_row_epilogue<EPI>(a, i, acc[r], e_t, e_d, e_x, dself, part0, part1);
+        }
+    }
+    sl_block_partials<EPI, SL_PANEL_WAVES>(a, red, lane, wave, blockIdx.x, a.part_stride, part0, part1);
+}
+
 // ---- long rows: one block per row ------------------------------------------------------------------
 // Rows with more than SL_LONG_ROW entries (hubs of power-law graphs).  The 256 threads fetch the raw CSR
 // entries coalesced and form the products in parallel; the additions stay sequential in the reference's
@@ -797,7 +871,18 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
     // with 3 quads per batch (2 in the 4-lane order) instead of 4
     const bool nw8_pays = !(EPI == SL_EPI_PUSH && uniform_unrolled && a.uniform_width == 16);
     const band_geom g = band_geometry(a, uniform_unrolled || !uniform_octets, nw8_pays);
-    if (g.spw) {
+    if (ORDER == 0 && a.pan_tile_ptr && a.n_pan_tiles) {
+        const uint32_t grid = (a.n_pan_tiles + SL_PANEL_WAVES - 1) / SL_PANEL_WAVES;
+        constexpr uint32_t lds = SL_PANEL_WAVES * (SL_PANEL_TILE + 64) * sizeof(double);
+        static bool attr_done = false;
+        if (!attr_done) {
+            SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sl_panel_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_done = true;
+        }
+        *nparts = grid + a.n_long;
+        a.part_stride = *nparts;
+        hipLaunchKernelGGL((sl_panel_kernel<EPI>), dim3(grid), dim3(SL_PANEL_WAVES * 64), lds, s, a);
+    } else if (g.spw) {
         const uint64_t per_block = (uint64_t)g.nw * g.spw;
         const uint64_t nb = (a.n_slices + per_block - 1) / per_block;
         const uint32_t nb8 = (uint32_t)((nb + 7) / 8);

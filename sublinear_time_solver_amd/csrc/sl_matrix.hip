@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64
 // CSR -> row-slice layout.  One wave per slice, lane = row.  Padding entries carry
 // value 0.0 and a valid column (the row's own index when it exists); the kernels never
 // add them (guarded by row_len), they only keep every gather in bounds.
+#define SL_FAR_COLUMN (1ull << 20)     // |col - row| beyond this: the gather is megabytes of vector away from the row's neighbourhood
 __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, uint64_t n_cols, uint64_t n_slices,
                                                              uint64_t row_offset, const uint32_t *row_ptr,
                                                              const uint32_t *col_idx, const double *values,
@@ -69,17 +70,19 @@ __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, ui
         start = row_ptr[i];
         len = row_len[i] == SL_LONG_SENTINEL ? 0u : row_len[i];
     }
-    unsigned long long bw = 0;
+    unsigned long long bw = 0, far = 0;
     const uint32_t slots = (q1 - q0) * 2;                      // q0, q1: pair blocks
     for (uint32_t k = 0; k < slots; ++k) {
         const bool in = k < len;
         const uint32_t c = in ? col_idx[start + k] : padcol;
         const double v = in ? values[start + k] : 0.0;
-        if (in) { const unsigned long long d = c > gi ? c - gi : gi - c; bw = d > bw ? d : bw; }
+        if (in) { const unsigned long long d = c > gi ? c - gi : gi - c; bw = d > bw ? d : bw; far += d > SL_FAR_COLUMN ? 1u : 0u; }
         cols[sl_col_slot(q0, q1, k, lane)] = c;
         vals[sl_val_slot(q0, k, lane)] = v;
     }
     if (bw) atomicMax(band, bw);
+    for (int off = 32; off > 0; off >>= 1) far += __shfl_xor(far, off);
+    if (lane == 0 && far) atomicAdd(band + 1, far);            // entries more than 8 MB of vector away from their row
 }
 
 // 16-bit column offsets for uniform-width band matrices: [slice][octet][lane][8] int16 = col - row,
@@ -238,12 +241,110 @@ __global__ void sl_transpose_gather_kernel(uint64_t nnz, uint64_t n_rows, const 
 sl_status sl_sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
                             uint64_t n, int end_bit, hipStream_t s);
 
+// ---- column-panel layout ------------------------------------------------------------------------------
+// sort key of every CSR entry: (tile of its row) * n_panels + (panel of its column); entries of long rows (served by the
+// long-row kernel) get the largest key and fall off the end.  Also the row inside the tile, for the gather pass below.
+__global__ __launch_bounds__(256) void sl_panel_keys_kernel(uint64_t n_rows, uint32_t n_panels, const uint32_t *row_ptr, const uint32_t *col_idx,
+                                                            const uint32_t *row_len, uint32_t *key, uint16_t *rowl)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    for (uint64_t i = wave; i < n_rows; i += nwaves) {                        // a wave per row: coalesced over the row's entries
+        const uint32_t s = row_ptr[i], e = row_ptr[i + 1];
+        const bool is_long = row_len[i] == SL_LONG_SENTINEL;
+        const uint32_t base = (uint32_t)(i / SL_PANEL_TILE) * n_panels;
+        const uint16_t rl = (uint16_t)(i % SL_PANEL_TILE);
+        for (uint32_t k = s + lane; k < e; k += 64u) {
+            key[k] = is_long ? 0xffffffffu : base + (col_idx[k] >> SL_PANEL_COL_BITS);
+            rowl[k] = rl;
+        }
+    }
+}
+// entries per tile (long rows excluded)
+__global__ __launch_bounds__(256) void sl_panel_tile_count_kernel(uint64_t n_rows, uint64_t n_tiles, const uint32_t *row_ptr, const uint32_t *row_len,
+                                                                  uint32_t *count)
+{
+    const uint64_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    uint32_t acc = 0;
+    for (uint32_t r = threadIdx.x; r < SL_PANEL_TILE; r += 256) {
+        const uint64_t i = t * SL_PANEL_TILE + r;
+        if (i < n_rows && row_len[i] != SL_LONG_SENTINEL) acc += row_ptr[i + 1] - row_ptr[i];
+    }
+    __shared__ uint32_t red[4];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) count[t] = red[0] + red[1] + red[2] + red[3];
+}
+// the streams: tile t takes sorted positions [src[t], src[t] + count) and lands at [dst[t], dst[t + 1]), the tail padded with entries
+// that add 0 * t[0] to a slot of the sums nobody reads
+__global__ __launch_bounds__(256) void sl_panel_fill_kernel(uint64_t n_tiles, const uint32_t *src, const uint32_t *dst, const uint32_t *perm,
+                                                            const uint16_t *rowl, const uint32_t *col_idx, const double *values,
+                                                            uint16_t *pan_row, uint32_t *pan_col, double *pan_val)
+{
+    const uint64_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t s0 = src[t], cnt = src[t + 1] - s0, d0 = dst[t], padded = dst[t + 1] - d0;
+    for (uint32_t e = threadIdx.x; e < padded; e += 256) {
+        if (e < cnt) {
+            const uint32_t k = perm[s0 + e];
+            pan_row[d0 + e] = rowl[k]; pan_col[d0 + e] = col_idx[k]; pan_val[d0 + e] = values[k];
+        } else {
+            pan_row[d0 + e] = (uint16_t)(SL_PANEL_TILE + (e & 63u)); pan_col[d0 + e] = 0u; pan_val[d0 + e] = 0.0;   // 64 distinct unread slots
+        }
+    }
+}
+
 static uint32_t grid_for(uint64_t n, uint32_t block)
 {
     uint64_t g = (n + block - 1) / block;
     if (g > 65535 * 16) g = 65535 * 16;
     if (g == 0) g = 1;
     return (uint32_t)g;
+}
+
+// One stable radix sort of (key, entry index) regroups the CSR entries by (tile, panel) and keeps them in (row, column) order
+// inside a group — the order the running sums need.  Temporary memory: 18 bytes per entry.
+static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx, const double *d_values,
+                                        uint64_t n_tiles, uint32_t n_panels, hipStream_t st)
+{
+    const uint64_t n = m->n_rows, nnz = m->nnz;
+    DevBuf key, key_out, ent_in, perm, rowl, cnt;
+    SL_TRY(key.alloc_owned(nnz * 4)); SL_TRY(key_out.alloc_owned(nnz * 4)); SL_TRY(ent_in.alloc_owned(nnz * 4)); SL_TRY(perm.alloc_owned(nnz * 4));
+    SL_TRY(rowl.alloc_owned(nnz * 2)); SL_TRY(cnt.alloc_owned((n_tiles + 1) * 4));
+    const uint32_t g = grid_for(nnz, 256) > 8192 ? 8192 : grid_for(nnz, 256);
+    hipLaunchKernelGGL(sl_panel_keys_kernel, dim3(g), dim3(256), 0, st, n, n_panels, d_row_ptr, d_col_idx, m->d_row_len, key.as<uint32_t>(), rowl.as<uint16_t>());
+    hipLaunchKernelGGL(sl_iota_kernel, dim3(g), dim3(256), 0, st, nnz, ent_in.as<uint32_t>());
+    hipLaunchKernelGGL(sl_panel_tile_count_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, n, n_tiles, d_row_ptr, m->d_row_len, cnt.as<uint32_t>());
+    std::vector<uint32_t> count(n_tiles + 1), src(n_tiles + 1), dst(n_tiles + 1);
+    SL_HIP(hipMemcpyAsync(count.data(), cnt.p, n_tiles * 4, hipMemcpyDeviceToHost, st));
+    int bits = 32;                                                             // long rows carry the key 0xffffffff
+    if (!m->n_long) { bits = 1; while (bits < 32 && (1ull << bits) < n_tiles * n_panels) ++bits; }
+    SL_TRY(sl_sort_pairs_u32(key.as<uint32_t>(), key_out.as<uint32_t>(), ent_in.as<uint32_t>(), perm.as<uint32_t>(), nnz, bits, st));   // synchronises
+    uint64_t run_s = 0, run_d = 0;
+    for (uint64_t t = 0; t < n_tiles; ++t) {
+        src[t] = (uint32_t)run_s; dst[t] = (uint32_t)run_d;
+        run_s += count[t];
+        run_d += (count[t] + SL_PANEL_CHUNK - 1) / SL_PANEL_CHUNK * SL_PANEL_CHUNK;
+    }
+    if (run_d > 0xfffffff0ull) return SL_OK;                                   // would not fit 32-bit stream offsets: stay without panels
+    src[n_tiles] = (uint32_t)run_s; dst[n_tiles] = (uint32_t)run_d;
+    DevBuf dsrc;
+    SL_TRY(dsrc.alloc_owned((n_tiles + 1) * 4));
+    SL_HIP(hipMalloc(&m->d_pan_tile_ptr, (n_tiles + 1) * 4));
+    SL_HIP(hipMalloc(&m->d_pan_row, (run_d ? run_d : 1) * 2));
+    SL_HIP(hipMalloc(&m->d_pan_col, (run_d ? run_d : 1) * 4));
+    SL_HIP(hipMalloc(&m->d_pan_val, (run_d ? run_d : 1) * 8));
+    SL_HIP(hipMemcpyAsync(dsrc.p, src.data(), (n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
+    SL_HIP(hipMemcpyAsync(m->d_pan_tile_ptr, dst.data(), (n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(sl_panel_fill_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, n_tiles, dsrc.as<uint32_t>(), m->d_pan_tile_ptr, perm.as<uint32_t>(),
+                       rowl.as<uint16_t>(), d_col_idx, d_values, m->d_pan_row, m->d_pan_col, m->d_pan_val);
+    SL_HIP(hipGetLastError());
+    SL_HIP(hipStreamSynchronize(st));
+    m->n_pan_tiles = n_tiles; m->pan_entries = run_d;
+    m->device_bytes += run_d * 14 + (n_tiles + 1) * 4;
+    return SL_OK;
 }
 
 sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx,
@@ -317,17 +418,18 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     SL_HIP(hipMalloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
     SL_HIP(hipMalloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
     unsigned long long *d_band = nullptr;
-    SL_HIP(hipMalloc(&d_band, sizeof(unsigned long long)));
-    SL_HIP(hipMemsetAsync(d_band, 0, sizeof(unsigned long long), st));
+    SL_HIP(hipMalloc(&d_band, 2 * sizeof(unsigned long long)));
+    SL_HIP(hipMemsetAsync(d_band, 0, 2 * sizeof(unsigned long long), st));
     if (m->n_slices)
         hipLaunchKernelGGL(sl_fill_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_cols,
                            m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_band);
     SL_HIP(hipGetLastError());
-    unsigned long long h_band = 0;
-    SL_HIP(hipMemcpyAsync(&h_band, d_band, sizeof(h_band), hipMemcpyDeviceToHost, st));
+    unsigned long long h_band[2] = {0, 0};
+    SL_HIP(hipMemcpyAsync(h_band, d_band, sizeof(h_band), hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
     hipFree(d_band);
-    m->bandwidth = h_band;
+    m->bandwidth = h_band[0];
+    const uint64_t far_entries = h_band[1];
     if (m->bandwidth < 32768 && m->n_slices && m->padded_nnz) {
         SL_HIP(hipMalloc(&m->d_cols16, m->padded_nnz * sizeof(uint16_t)));
         if (m->uniform_width == 8 || m->uniform_width == 16)      // octet layout of the unrolled uniform path
@@ -339,6 +441,23 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         SL_HIP(hipGetLastError());
     }
     m->device_bytes = (m->n_slices + 1 + padded_rows) * sizeof(uint32_t) + m->padded_nnz * 12 + (m->d_cols16 ? m->padded_nnz * 2 : 0);
+
+    // 2b. column panels: where neither the LDS window (bandwidth) nor the L2 (vector of a few MB) can serve the gathers
+    {
+        static const int env_panels = [] { const char *e = getenv("SL_COLUMN_PANELS"); return e && *e ? atoi(e) : -1; }();   // 0 never, 1 always
+        const bool forced = (m->flags & SL_MATRIX_COLUMN_PANELS) || env_panels == 1;
+        const bool refused = (m->flags & SL_MATRIX_NO_COLUMN_PANELS) || env_panels == 0;
+        // pays where most entries sit megabytes of vector away from their row (uniformly random columns) and the vector is far larger
+        // than the L2 — measured at n = 10^7 x 16: 2.73 -> 1.71 ms; band structures, however wide, are served better by the general
+        // kernel (their gathers hit L2; here the entries of a row would crowd one panel and their sums serialise): w = 10^6: 1.86 vs 2.47 ms
+        const bool pays = m->n_cols >= (3ull << 20) && 2 * far_entries > nnz;
+        const uint64_t n_tiles = (n + SL_PANEL_TILE - 1) / SL_PANEL_TILE;
+        const uint64_t n_panels = (m->n_cols + (1ull << SL_PANEL_COL_BITS) - 1) >> SL_PANEL_COL_BITS;
+        if (!refused && (forced || pays) && nnz && nnz < 0x7fffffffull && n_tiles * n_panels < 0xfffffff0ull) {
+            sl_status ps = sl_build_column_panels(m, d_row_ptr, d_col_idx, d_values, n_tiles, (uint32_t)n_panels, st);
+            if (ps != SL_OK) return ps;
+        }
+    }
 
     // 3. transpose
     if (m->flags & SL_MATRIX_WITH_TRANSPOSE) {

@@ -84,8 +84,10 @@ class SparseMatrix:
 
     @classmethod
     def from_csr(cls, row_ptr, col_idx, values, rows: int, cols: int, row_offset: int = 0,
-                 with_transpose: bool = False, keep_csr: bool = False, device: bool = False):
-        """Adopt CSRStorage arrays (matrix/sparse.rs:16-23); device=True: torch CUDA tensors."""
+                 with_transpose: bool = False, keep_csr: bool = False, device: bool = False, column_panels=None):
+        """Adopt CSRStorage arrays (matrix/sparse.rs:16-23); device=True: torch CUDA tensors.
+        column_panels: None = the library decides (large systems with columns all over the vector), True / False = force / forbid
+        the second, panel-ordered copy of the entries."""
         lib = L.load()
         if not device:
             row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
@@ -96,6 +98,8 @@ class SparseMatrix:
             nnz = int(values.numel())
         h = L.vp()
         flags = (L.SL_MATRIX_WITH_TRANSPOSE if with_transpose else 0) | (L.SL_MATRIX_KEEP_CSR if keep_csr else 0)
+        if column_panels is not None:
+            flags |= L.SL_MATRIX_COLUMN_PANELS if column_panels else L.SL_MATRIX_NO_COLUMN_PANELS
         L.check(lib.sl_matrix_create_csr(rows, cols, nnz, L.ptr(row_ptr), L.ptr(col_idx), L.ptr(values),
                                          L.SL_MEM_DEVICE if device else L.SL_MEM_HOST, row_offset, flags, C.byref(h)))
         return cls(h.value, rows, cols)

@@ -1,0 +1,103 @@
+"""Column-panel layout (sl_panel_kernel): the entries regrouped by (tile of rows, panel of columns) and summed through running
+sums in LDS must give every row the bits of the sequential reference loop — uniform columns, ragged rows with hubs and duplicate
+entries, a row slice of a larger system, every epilogue (SpMV, fused Neumann step, residual, dense push round)."""
+import numpy as np
+import pytest
+
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import _lib as L
+from sublinear_time_solver_amd import generators as G
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits_equal(a, b):
+    return (np.ascontiguousarray(a).view(np.uint64) == np.ascontiguousarray(b).view(np.uint64)).all()
+
+
+@pytest.mark.parametrize("n,k", [(300_000, 16), (70_001, 5), (5000, 8)])
+def test_uniform_columns_spmv_neumann_residual(gpu, n, k):
+    rp, ci, va, b = G.sdd_rows(n, k, seed=4)                               # w = 0: columns all over the vector
+    mp = S.SparseMatrix.from_csr(rp, ci, va, n, n, column_panels=True)
+    mg = S.SparseMatrix.from_csr(rp, ci, va, n, n, column_panels=False)
+    assert mp.info().column_panels == 1 and mg.info().column_panels == 0
+    assert mp.info().device_bytes > mg.info().device_bytes
+    x = np.cos(np.arange(n) * 0.11) + 0.3
+    ref = O.spmv(rp, ci, va, x)
+    assert _bits_equal(mp.multiply_vector(x), ref) and _bits_equal(mg.multiply_vector(x), ref)
+    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-11)
+    for m in (mp, mg):
+        g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-11))
+        assert g.converged and g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
+        np.testing.assert_allclose(g.term_norms, o["term_norms"], rtol=1e-10)      # the CPU sum runs sequentially over n terms
+        assert abs(g.residual_norm - o["residual_norm"]) <= 1e-10 * max(1.0, o["residual_norm"])
+    # the 4-lane order is not served by the panels: same answer as without them
+    g4 = S.NeumannSolver(order=L.SL_ORDER_SIMD4).solve(mp, b, S.SolverOptions(tolerance=1e-11))
+    o4 = O.neumann_solve(rp, ci, va, b, tolerance=1e-11, order=O.ORDER_SIMD4)
+    assert _bits_equal(g4.solution, o4["x"])
+
+
+def _ragged_system(n=9000, seed=3):
+    """row dominant: 2..30 entries per row, hubs of 400..3000, a few rows with the same column stored twice"""
+    rng = np.random.default_rng(seed)
+    tr, tc, tv = [], [], []
+    for i in range(n):
+        m = int(rng.integers(2, 31))
+        if i % 211 == 0:
+            m = int(rng.integers(400, 3000))
+        cols = np.sort(rng.choice(n - 1, size=m - 1, replace=False))
+        cols = cols + (cols >= i)
+        if i % 17 == 0 and cols.size > 2:
+            cols[1] = cols[0]                                              # duplicate entry: kept, added twice in stored order
+        vals = rng.uniform(-1.0, 1.0, size=cols.size)
+        tr += [i] * (cols.size + 1); tc += cols.tolist() + [i]; tv += vals.tolist() + [2.0 * np.abs(vals).sum() + 1.0]
+    return O.csr_from_triplets(tr, tc, tv, n, n)
+
+
+def test_ragged_rows_hubs_duplicates_and_dense_push_rounds(gpu):
+    rp, ci, va = _ragged_system()
+    n = rp.size - 1
+    mp = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True, column_panels=True)
+    assert mp.info().column_panels == 1 and mp.info().n_long_rows > 0
+    x = np.sin(np.arange(n) * 0.7) - 0.2
+    assert _bits_equal(mp.multiply_vector(x), O.spmv(rp, ci, va, x))
+    b = 1.0 + (np.arange(n) % 7) * 0.5
+    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-10)
+    g = S.NeumannSolver().solve(mp, b, S.SolverOptions(tolerance=1e-10))
+    assert g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
+    # thresholded push with dense rounds forced from the start (dense_switch tiny): the PUSH epilogue of the panel kernel
+    q = O.push_sync_solve(rp, ci, va, b, theta=1e-8, log_cap=1 << 22)
+    p = S.PushSolver(theta=1e-8, dense_switch=1e-9).solve(mp, b, log_frontier=1 << 22)
+    assert p["converged"] and p["rounds"] == q["rounds"] and p["dense_rounds"] > 0
+    assert (p["frontier_log"] == q["frontier_log"]).all()
+    assert _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])
+
+
+def test_row_slice_of_a_larger_system(gpu):
+    """rows [lo, hi) of a system as their own matrix with global column ids (what a rank of a partitioned solve holds)"""
+    n, k, lo, hi = 120_000, 12, 33_333, 91_777
+    rp, ci, va, b = G.sdd_rows(n, k, seed=6)
+    prp = (rp[lo:hi + 1].astype(np.int64) - int(rp[lo])).astype(np.uint32)
+    pci, pva = ci[rp[lo]:rp[hi]], va[rp[lo]:rp[hi]]
+    m = S.SparseMatrix.from_csr(prp, pci, pva, hi - lo, n, row_offset=lo, column_panels=True)
+    assert m.info().column_panels == 1
+    x = np.cos(np.arange(n) * 0.05)
+    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x)[lo:hi])
+
+
+def test_thin_panels_same_row_twice_in_one_chunk(gpu):
+    """few entries per (tile, panel): 64 consecutive entries of a tile's stream then span several panels and can hold the same row
+    more than once, far apart — the parts must be applied one after the other (a rectangular operator: 5000 rows, 6 million columns,
+    46 panels, one to three entries per row)"""
+    rng = np.random.default_rng(12)
+    rows, cols = 5000, 6_000_000
+    cnt = rng.integers(1, 4, size=rows)
+    rp = np.zeros(rows + 1, dtype=np.uint32)
+    rp[1:] = np.cumsum(cnt)
+    ci = np.concatenate([np.sort(rng.choice(cols, size=int(c), replace=False)) for c in cnt]).astype(np.uint32)
+    va = rng.uniform(-1.0, 1.0, size=ci.size)
+    m = S.SparseMatrix.from_csr(rp, ci, va, rows, cols, column_panels=True)
+    assert m.info().column_panels == 1
+    x = rng.uniform(-1.0, 1.0, size=cols)
+    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
