@@ -91,8 +91,11 @@ def column_structure_sweep(lib, L, torch, dev, n, k, seed, order, bandwidths, st
         L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm.data_ptr(), order, 3, C.byref(ms)))
         L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), tb.data_ptr(), ta.data_ptr(), x.data_ptr(), nrm.data_ptr(), order, steps, C.byref(ms)))
         per = ms.value / steps
+        mi = L.MatrixInfo()
+        L.check(lib.sl_matrix_get_info(h, C.byref(mi)))
         out["uniform" if w == 0 else f"w{w}"] = {"ms_per_step": per, "nnz_iter_per_s": n * k / (per * 1e-3),
-                                                   "roofline_frac": algorithmic_bytes(n, n * k) / (per * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                                   "roofline_frac": algorithmic_bytes(n, n * k) / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                   "layout": "column panels (gathers from L2)" if mi.column_panels else "row slices"}
         lib.sl_matrix_destroy(h)
         del dinv, ta, tb, x, b
         torch.cuda.empty_cache()
