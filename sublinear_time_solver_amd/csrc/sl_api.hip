@@ -167,7 +167,7 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
     a.csr_ptr = m->d_row_ptr; a.csr_idx = m->d_col_idx; a.csr_val = m->d_values;
     a.long_rows = m->d_long_rows; a.n_long = (uint32_t)m->n_long;
     a.pan_tile_ptr = m->d_pan_tile_ptr; a.pan_row = m->d_pan_row; a.pan_col = m->d_pan_col; a.pan_val = m->d_pan_val;
-    a.n_pan_tiles = (uint32_t)m->n_pan_tiles;
+    a.n_pan_tiles = (uint32_t)m->n_pan_tiles; a.pan_balanced = m->pan_balanced ? 1u : 0u;
     return a;
 }
 

@@ -62,6 +62,7 @@ struct sl_matrix {
     uint32_t *d_pan_col = nullptr;      // global column
     double *d_pan_val = nullptr;
     uint64_t n_pan_tiles = 0, pan_entries = 0;
+    bool pan_balanced = false;          // every tile's stream within 10 % of the mean length: launched one resident round at a time
     uint64_t device_bytes = 0;
 };
 #define SL_PANEL_TILE 2048u          // rows per tile = per wave: their running sums live in LDS (16 KiB)
@@ -204,6 +205,7 @@ struct sl_row_args {
     // column-panel layout (null unless the matrix carries one)
     const uint32_t *pan_tile_ptr; const uint16_t *pan_row; const uint32_t *pan_col; const double *pan_val;
     uint32_t n_pan_tiles;
+    uint32_t pan_balanced;
     // vectors
     const double *gather; // gathered vector (n_cols)
     const double *dinv;   // n_rows

@@ -552,13 +552,14 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_ro
 // by one (entries of one row that sit in neighbouring lanes of a chunk are applied in lane order), so the sum has the bits
 // of the sequential reference loop.  CSR order only; the 4-lane order keeps the general kernel.
 template <int EPI>
-__global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_args a)
+__global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_args a, uint32_t block0)
 {
     extern __shared__ __attribute__((aligned(16))) double pan_acc[];
     __shared__ double red[2 * SL_PANEL_WAVES];
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t tile = blockIdx.x * SL_PANEL_WAVES + wave;
+    const uint32_t lb = block0 + blockIdx.x;
+    const uint32_t tile = lb * SL_PANEL_WAVES + wave;
     double *acc = pan_acc + (size_t)wave * (SL_PANEL_TILE + 64);    // + the slot padding entries add their zeros to
     double part0 = 0.0, part1 = 0.0;
     if (tile < a.n_pan_tiles) {
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
             sl_row_epilogue<EPI>(a, i, acc[r], e_t, e_d, e_x, dself, part0, part1);
         }
     }
-    sl_block_partials<EPI, SL_PANEL_WAVES>(a, red, lane, wave, blockIdx.x, a.part_stride, part0, part1);
+    sl_block_partials<EPI, SL_PANEL_WAVES>(a, red, lane, wave, lb, a.part_stride, part0, part1);
 }
 
 // ---- long rows: one block per row ------------------------------------------------------------------
@@ -881,7 +882,23 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
         }
         *nparts = grid + a.n_long;
         a.part_stride = *nparts;
-        hipLaunchKernelGGL((sl_panel_kernel<EPI>), dim3(grid), dim3(SL_PANEL_WAVES * 64), lds, s, a);
+        // one launch per round of resident blocks: blocks that start together pass the panels together, a second round that trickles
+        // in behind the first does not (n = 10^7 x 16: 1.66 -> 1.50 ms; partial rounds lose it again, and so do tiles of unequal length — the PageRank solve
+        // went 0.314 -> 0.345 s — so only matrices whose tiles are balanced are launched this way).  SL_PANEL_ROUND: blocks per
+        // launch, 0 = a single launch
+        static uint32_t round_blocks = 0xffffffffu;
+        if (round_blocks == 0xffffffffu) {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            if (const char *e = getenv("SL_PANEL_ROUND")) round_blocks = (uint32_t)atoi(e);
+            else if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess
+                     && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sl_panel_kernel<EPI>, SL_PANEL_WAVES * 64, lds) == hipSuccess && per_cu > 0)
+                round_blocks = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+            else round_blocks = 0;
+        }
+        const uint32_t per = (round_blocks && a.pan_balanced) ? round_blocks : grid;     // unequal tiles: every round would wait for its longest
+        for (uint32_t b0 = 0; b0 < grid; b0 += per)
+            hipLaunchKernelGGL((sl_panel_kernel<EPI>), dim3(std::min(per, grid - b0)), dim3(SL_PANEL_WAVES * 64), lds, s, a, b0);
     } else if (g.spw) {
         const uint64_t per_block = (uint64_t)g.nw * g.spw;
         const uint64_t nb = (a.n_slices + per_block - 1) / per_block;

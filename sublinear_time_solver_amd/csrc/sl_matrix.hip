@@ -343,6 +343,9 @@ static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr,
     SL_HIP(hipGetLastError());
     SL_HIP(hipStreamSynchronize(st));
     m->n_pan_tiles = n_tiles; m->pan_entries = run_d;
+    uint32_t longest = 0;
+    for (uint64_t t = 0; t < n_tiles; ++t) longest = std::max(longest, count[t]);
+    m->pan_balanced = n_tiles > 0 && (double)longest * (double)n_tiles <= 1.1 * (double)run_s;
     m->device_bytes += run_d * 14 + (n_tiles + 1) * 4;
     return SL_OK;
 }
