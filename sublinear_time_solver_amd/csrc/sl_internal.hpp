@@ -65,8 +65,13 @@ struct sl_matrix {
     bool pan_balanced = false;          // every tile's stream within 10 % of the mean length: launched one resident round at a time
     uint64_t device_bytes = 0;
 };
+#ifndef SL_PANEL_TILE
 #define SL_PANEL_TILE 2048u          // rows per tile = per wave: their running sums live in LDS (16 KiB)
-#define SL_PANEL_COL_BITS 17         // a panel = 2^17 columns = 1 MiB of the gathered vector: stays in an XCD's L2 while the tiles pass it
+#endif
+#ifndef SL_PANEL_COL_BITS
+#define SL_PANEL_COL_BITS 16         // a panel = 2^16 columns = 512 KiB of the gathered vector: stays in an XCD's L2 while the tiles pass it
+                                     // (n = 10^7 x 16, ms per step by panel size: 2^18 1.57, 2^17 1.49, 2^16 1.39, 2^15 1.36, 2^14 1.43)
+#endif
 #define SL_PANEL_CHUNK 256u          // entries a wave has in flight (4 x 64)
 #define SL_PANEL_WAVES 4
 

@@ -546,8 +546,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_ro
 // For matrices whose columns are spread over a vector far larger than the L2 (uniformly random columns — the reference
 // generators' recipe): every gather of the general kernel misses L2, and misses are served at 58 G/s whatever the table size
 // (2.7 ms for 1.6e8 of them; gathers that hit L2 run at 265 G/s).  Here the entries of a tile of SL_PANEL_TILE rows are one
-// stream sorted by (panel of 2^17 columns, row, column); a wave owns a tile, keeps the running sum of each of its rows in
-// LDS and walks the stream: all waves pass the panels in the same order at about the same pace, so the megabyte of the
+// stream sorted by (panel of 2^16 columns, row, column); a wave owns a tile, keeps the running sum of each of its rows in
+// LDS and walks the stream: all waves pass the panels in the same order at about the same pace, so the half megabyte of the
 // vector they gather from stays in L2.  Within a row the products still arrive in ascending column order and are added one
 // by one (entries of one row that sit in neighbouring lanes of a chunk are applied in lane order), so the sum has the bits
 // of the sequential reference loop.  CSR order only; the 4-lane order keeps the general kernel.
