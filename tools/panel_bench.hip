@@ -16,13 +16,14 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z)
 
 // v2: the entries of a tile are ONE stream sorted by (panel, row, column); an entry carries its row inside the tile (u16) and its
 // global column (u32) — 14 bytes per entry — so chunks of the stream are always full and no per-panel pointers exist
-__global__ void fill_kernel(uint64_t total, uint32_t per_tile, uint32_t wt, uint32_t pc, uint32_t P, uint64_t ncols, uint16_t *rowl, uint32_t *col, double *val)
+__global__ void fill_kernel(uint64_t total, uint32_t per_tile, uint32_t wt, uint32_t pc, uint32_t P, uint64_t ncols, uint16_t *rowl, uint32_t *col, double *val, bool lane_private)
 {
     for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (uint64_t)gridDim.x * 256) {
         const uint32_t within = (uint32_t)(k % per_tile);
         const uint32_t panel = (uint32_t)(((uint64_t)within * P) / per_tile);
         const uint32_t seg0 = (uint32_t)(((uint64_t)panel * per_tile + P - 1) / P), seg1 = (uint32_t)(((uint64_t)(panel + 1) * per_tile + P - 1) / P);
-        rowl[k] = (uint16_t)(((uint64_t)(within - seg0) * wt) / (seg1 - seg0));      // ascending rows inside a panel segment
+        rowl[k] = lane_private ? (uint16_t)((k % 64) + 64 * (mix64(k + 5) % (wt / 64)))                 // every lane only ever meets its own rows
+                               : (uint16_t)(((uint64_t)(within - seg0) * wt) / (seg1 - seg0));      // ascending rows inside a panel segment
         uint64_t c = (uint64_t)panel * pc + mix64(k) % pc;
         col[k] = (uint32_t)(c < ncols ? c : ncols - 1);
         val[k] = 1e-3 * (double)(mix64(k + 77) % 1000);
@@ -119,7 +120,7 @@ static int run(uint32_t n, uint32_t k, uint32_t wt, int pcb)
     CK(hipMalloc(&t, ((uint64_t)n + 64) * 8)); CK(hipMalloc(&dinv, (uint64_t)n * 8)); CK(hipMalloc(&out, (uint64_t)n * 8)); CK(hipMalloc(&x, (uint64_t)n * 8));
     CK(hipMalloc(&partials, (uint64_t)ntiles * 8));
     CK(hipMemset(t, 0, ((uint64_t)n + 64) * 8)); CK(hipMemset(dinv, 0, (uint64_t)n * 8)); CK(hipMemset(x, 0, (uint64_t)n * 8));
-    fill_kernel<<<4096, 256>>>(total, per_tile, wt, pc, P, n, rowl, col, val);
+    fill_kernel<<<4096, 256>>>(total, per_tile, wt, pc, P, n, rowl, col, val, (VAR & 8) != 0);
     CK(hipDeviceSynchronize());
     CK(hipMemset(done, 0, (P + 8) * 128));
     const size_t lds = (size_t)NW * wt * 8;
@@ -141,9 +142,9 @@ static int run(uint32_t n, uint32_t k, uint32_t wt, int pcb)
 int main()
 {
     const uint32_t n = 10000000 / 4096 * 4096;
-    // var 0 = the real sweep; var 1 = every gather from the first 1 MB (perfect locality: the ceiling of the design);
-    // var 4 = tickets per panel (round-aware, bounded wait, self-disabling): 3.5 ms — waiting costs more than drifting
-    run<4, 4, 0>(n, 16, 2048, 17); run<4, 4, 1>(n, 16, 2048, 17); run<4, 4, 4>(n, 16, 2048, 17);
-    run<4, 4, 0>(n, 16, 1024, 17); run<4, 8, 0>(n, 16, 512, 17);
+    // var 0 = the real sweep; var 1 = every gather from the first panel (perfect locality: the ceiling of the design);
+    // var 4 = tickets per panel (round-aware, bounded wait, self-disabling): 3.5 ms — waiting costs more than drifting;
+    // var 8 = rows dealt to lanes (row mod 64 = lane): no two lanes ever meet the same row, LDS updates free of bank conflicts
+    run<4, 4, 0>(n, 16, 2048, 16); run<4, 4, 8>(n, 16, 2048, 16); run<4, 4, 1>(n, 16, 2048, 16); run<4, 4, 9>(n, 16, 2048, 16);
     return 0;
 }
