@@ -172,7 +172,7 @@ struct sl_round_io {
 // the same 8-byte pointer instead of ~200 bytes of arguments (launches got 15 % cheaper; a local query is a few dozen launches).
 __global__ void sl_set_io_kernel(sl_round_io io, sl_round_io *dst) { *dst = io; }
 #define SL_PICK(pair, which) ((which) ? (pair)[1] : (pair)[0])      // no dynamic indexing into kernel arguments
-// where a thread sits in the machine: the round phases run as five wide launches or inside one persistent kernel
+// where a thread sits in the machine (the round phases are written against this, not against blockIdx / gridDim directly)
 struct sl_worker { uint32_t tid, nthreads, wave, nwaves, lane; };
 __device__ __forceinline__ sl_worker sl_worker_here()
 {
