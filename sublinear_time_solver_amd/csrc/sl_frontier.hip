@@ -683,9 +683,10 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
     const double dense_limit = dense_switch * (double)n;               // nf > dense_limit  <=>  nf > floor(dense_limit)
     const uint32_t dense_threshold = dense_limit >= 4294967295.0 ? 0xffffffffu : (dense_limit > 0.0 ? (uint32_t)dense_limit : 0u);
 
-    // a sparse round costs ~40x a dense round per matrix entry it touches (records, atomics, random sectors)
+    // a sparse round costs 40-60x a dense round per matrix entry it touches (records, atomics, random sectors); 64 after the dense
+    // rounds of graph-like matrices got the column-panel kernel (swept 16..96 on the 10^7-node PageRank queries)
     static unsigned long long hit_div = 0;
-    if (!hit_div) { const char *e = getenv("SL_PUSH_HIT_DIV"); hit_div = e ? strtoull(e, nullptr, 10) : 32; if (!hit_div) hit_div = 32; }
+    if (!hit_div) { const char *e = getenv("SL_PUSH_HIT_DIV"); hit_div = e ? strtoull(e, nullptr, 10) : 64; if (!hit_div) hit_div = 64; }
     // (dense_switch >= 1: the caller asked for sparse rounds throughout; only the record buffer limits them)
     const unsigned long long hit_limit = dense_switch >= 1.0 ? ps.rec_cap
                                          : std::min<unsigned long long>(ps.rec_cap, std::max<unsigned long long>(ps.op_nnz / hit_div, 4096));
