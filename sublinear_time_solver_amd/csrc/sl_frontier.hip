@@ -212,11 +212,11 @@ __global__ void sl_hits_gate_kernel(const sl_round_io *iop)
 }
 
 // (1) expansion.  Sparse rounds are HIT-DRIVEN: a frontier column j reaches row i through the entry B_ij, and only
-//     those entries contribute to (B delta)_i.  One wave per frontier column (hub columns: the whole grid, second
-//     kernel) emits a record per entry and links it into its row's list with one atomicExch; a row whose list was
-//     empty becomes a candidate.  Slots in the record, candidate and touched lists are reserved per wave (ballot +
-//     popcount, one atomic for up to 256 entries).  The work of a round follows the column entries under the
-//     frontier, not the lengths of the rows they touch.
+//     those entries contribute to (B delta)_i.  A wave takes four short frontier columns per step (columns of more than 64
+//     entries: 256-entry pieces, second kernel), emits a record per entry and links it into its row's list with one
+//     atomicExch; a row whose list was empty becomes a candidate.  Slots in the record, candidate and touched lists are
+//     reserved per wave (ballot + popcount, one atomic for up to 256 entries).  The work of a round follows the column
+//     entries under the frontier, not the lengths of the rows they touch.
 // Latency, not bandwidth, bounds a sparse round, so the piece is written as three round trips to memory: (1) the slot
 // reservation (it needs only the entry count) next to the loads of row and position; (2) the list link (needs the row and the
 // slot), the value and the row's session flag together; (3) the candidate / touched reservations, then plain stores.

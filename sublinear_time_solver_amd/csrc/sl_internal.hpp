@@ -73,7 +73,9 @@ struct sl_matrix {
                                      // (n = 10^7 x 16, ms per step by panel size: 2^18 1.57, 2^17 1.49, 2^16 1.39, 2^15 1.36, 2^14 1.43)
 #endif
 #define SL_PANEL_CHUNK 256u          // entries a wave has in flight (4 x 64)
+#ifndef SL_PANEL_WAVES
 #define SL_PANEL_WAVES 4
+#endif
 
 // thread-local launch context
 struct sl_ctx {

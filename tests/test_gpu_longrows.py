@@ -79,7 +79,7 @@ def test_long_rows_push_bitwise(gpu, dense_switch):
 
 @pytest.mark.parametrize("order", [0, 1])
 def test_hub_columns_and_batched_sparse_rounds_bitwise(gpu, order):
-    """push on the transpose of the hub system: hub COLUMNS (walked by the whole grid), rows hit by many frontier
+    """push on the transpose of the hub system: hub COLUMNS (cut into pieces spread over the grid), rows hit by many frontier
     columns (whole-row pull) and rows hit by few (hit lists), sparse rounds only, no frontier log — so several rounds
     are enqueued per host round trip"""
     rp, ci, va = _hub_system(seed=11)
