@@ -101,3 +101,34 @@ def test_thin_panels_same_row_twice_in_one_chunk(gpu):
     assert m.info().column_panels == 1
     x = rng.uniform(-1.0, 1.0, size=cols)
     assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
+
+
+def test_seven_million_short_rows_many_thin_panels(gpu):
+    """n = 7.1 million rows of 1..4 off-diagonal entries with uniformly random columns: 109 panels, about 50 entries per
+    (tile, panel) group — every chunk of a tile's stream spans several panels; duplicates and a few hub rows included.
+    SpMV, four fused Neumann steps and a full solve, bit for bit against the CPU restatement."""
+    rng = np.random.default_rng(77)
+    n = 7_100_003
+    cnt = rng.integers(1, 5, size=n)
+    cnt[rng.choice(n, size=40, replace=False)] = rng.integers(300, 2000, size=40)        # hubs: long rows
+    rows = np.repeat(np.arange(n, dtype=np.int64), cnt)
+    cols = rng.integers(0, n, size=rows.size, dtype=np.int64)
+    cols = np.where(cols == rows, (cols + 1) % n, cols)
+    vals = rng.uniform(-1.0, 1.0, size=rows.size)
+    off = np.zeros(n)
+    np.add.at(off, rows, np.abs(vals))
+    rows = np.concatenate([rows, np.arange(n)]); cols = np.concatenate([cols, np.arange(n)]); vals = np.concatenate([vals, 2.0 * off + 1.0])
+    order = np.lexsort((cols, rows))                                                      # stable: duplicate (row, col) keep their order
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    rp = np.zeros(n + 1, dtype=np.uint32)
+    rp[1:] = np.cumsum(np.bincount(rows, minlength=n))
+    ci, va = cols.astype(np.uint32), vals
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, column_panels=True)
+    info = m.info()
+    assert info.column_panels == 1 and info.n_long_rows >= 40
+    x = np.cos(np.arange(n) * 0.001) + 0.2
+    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
+    b = 1.0 + (np.arange(n) % 11) * 0.1
+    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-9)
+    g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-9))
+    assert g.converged and g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
