@@ -119,14 +119,33 @@ static void set_bool(napi_env env, napi_value obj, const char *key, int b)
     napi_set_named_property(env, obj, key, v);
 }
 
-static sl_matrix *matrix_of(napi_env env, napi_value v)
+/* The JS handle is an external holding a box, not the sl_matrix itself: destroyMatrix() empties the box, so a second destroy
+ * or any later use throws instead of touching freed memory; a handle that is garbage collected releases what is left. */
+typedef struct { sl_matrix *m; } matrix_box;
+
+static void matrix_box_finalize(napi_env env, void *data, void *hint)
+{
+    matrix_box *b = (matrix_box *)data;
+    (void)env; (void)hint;
+    if (b) { if (b->m) sl_matrix_destroy(b->m); free(b); }
+}
+
+static matrix_box *box_of(napi_env env, napi_value v)
 {
     void *p = NULL;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
         napi_throw_type_error(env, NULL, "expected a matrix handle");
         return NULL;
     }
-    return (sl_matrix *)p;
+    return (matrix_box *)p;
+}
+
+static sl_matrix *matrix_of(napi_env env, napi_value v)
+{
+    matrix_box *b = box_of(env, v);
+    if (!b) return NULL;
+    if (!b->m) { napi_throw_error(env, NULL, "matrix handle was destroyed"); return NULL; }
+    return b->m;
 }
 
 /* new Float64Array(n) backed by its own ArrayBuffer; *data receives the storage */
@@ -152,6 +171,7 @@ static napi_value CreateMatrix(napi_env env, napi_callback_info info)
     uint64_t *ri, *ci;
     bool with_t = false;
     sl_matrix *m = NULL;
+    matrix_box *box;
     sl_status st;
     if (!get_args(env, info, 6, argv)) return NULL;
     NAPI_OK(napi_get_value_double(env, argv[0], &rows));
@@ -168,17 +188,20 @@ static napi_value CreateMatrix(napi_env env, napi_callback_info info)
     free(ri);
     free(ci);
     if (st != SL_OK) return throw_status(env, st);
-    NAPI_OK(napi_create_external(env, m, NULL, NULL, &out));
+    box = (matrix_box *)malloc(sizeof(*box));
+    if (!box) { sl_matrix_destroy(m); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    box->m = m;
+    if (napi_create_external(env, box, matrix_box_finalize, NULL, &out) != napi_ok) { matrix_box_finalize(env, box, NULL); napi_throw_error(env, NULL, "could not create the matrix handle"); return NULL; }
     return out;
 }
 
 static napi_value DestroyMatrix(napi_env env, napi_callback_info info)
 {
     napi_value argv[1];
-    sl_matrix *m;
+    matrix_box *b;
     if (!get_args(env, info, 1, argv)) return NULL;
-    m = matrix_of(env, argv[0]);
-    if (m) sl_matrix_destroy(m);
+    b = box_of(env, argv[0]);
+    if (b && b->m) { sl_matrix_destroy(b->m); b->m = NULL; }      /* idempotent */
     return NULL;
 }
 

@@ -312,6 +312,9 @@ typedef struct {
     int32_t converged;
     int32_t reserved;
 } sl_cg_result;
+/* Deviation from the reference, on purpose: when r.r turns non-finite the reference loop (optimized_solver.rs:221-263) keeps
+ * iterating on NaNs until max_iterations and returns Ok(converged = false); this entry point stops at once with
+ * SL_NUMERICAL_INSTABILITY (x_out = the last iterate, result filled) — same "not converged" outcome, no wasted launches. */
 sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *opts, double *x_out, sl_cg_result *result);
 
 /* ---- synthetic inputs, generated in HBM (bench / tests) -------------------

@@ -243,6 +243,7 @@ sl_status sl_matrix_create_csr(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, c
         return sl_fail(SL_DIMENSION_MISMATCH, "row slice [%llu, %llu) exceeds the global dimension %llu",
                        (unsigned long long)row_offset, (unsigned long long)(row_offset + n_rows), (unsigned long long)n_cols);
     SL_TRY(require_device());
+    SL_ABI_BEGIN
     sl_matrix *m = new sl_matrix();
     m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz; m->row_offset = row_offset; m->flags = flags;
     hipGetDevice(&m->device);
@@ -278,6 +279,7 @@ sl_status sl_matrix_create_csr(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, c
     if (st != SL_OK) { sl_matrix_destroy(m); return st; }
     *out = m;
     return SL_OK;
+    SL_ABI_END
 }
 
 sl_status sl_matrix_create_from_triplets(uint64_t n_triplets, const uint64_t *rows, const uint64_t *cols,
@@ -286,6 +288,10 @@ sl_status sl_matrix_create_from_triplets(uint64_t n_triplets, const uint64_t *ro
 {
     if (!out) return sl_fail(SL_INVALID_INPUT, "out is null");
     *out = nullptr;
+    if (n_triplets && (!rows || !cols || !values)) return sl_fail(SL_INVALID_INPUT, "null triplet array");
+    if (n_rows > 0xffffffffull || n_cols > 0xffffffffull || n_triplets > 0xffffffffull)      // before any host allocation of that size
+        return sl_fail(SL_INVALID_INPUT, "dimensions exceed IndexType = u32 (types.rs:22)");
+    SL_ABI_BEGIN
     // matrix/mod.rs:165-187: validation in input order
     for (uint64_t k = 0; k < n_triplets; ++k) {
         if (rows[k] >= n_rows)
@@ -311,6 +317,7 @@ sl_status sl_matrix_create_from_triplets(uint64_t n_triplets, const uint64_t *ro
     for (uint64_t k = 0; k < nnz; ++k) { rp[rows[idx[k]] + 1] += 1; ci[k] = (uint32_t)cols[idx[k]]; va[k] = values[idx[k]]; }
     for (uint64_t i = 0; i < n_rows; ++i) rp[i + 1] += rp[i];
     return sl_matrix_create_csr(n_rows, n_cols, nnz, rp.data(), ci.data(), va.data(), SL_MEM_HOST, 0, flags, out);
+    SL_ABI_END
 }
 
 sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info)
@@ -506,6 +513,7 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
                            const sl_neumann_options *o, double *x_out, double *term_norms,
                            sl_neumann_result *res)
 {
+    SL_ABI_BEGIN
     if (!m || !b || !o || !x_out || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
     memset(res, 0, sizeof(*res));
     res->residual_norm = INFINITY;
@@ -692,6 +700,7 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
     if (ce != hipSuccess && status == SL_OK) status = sl_fail(SL_DEVICE_ERROR, "result download failed: %s", hipGetErrorString(ce));
     res->total_time_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return status;
+    SL_ABI_END
 }
 
 } // extern "C"

@@ -141,6 +141,7 @@ void sl_cg_options_default(sl_cg_options *o)
 
 sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *o, double *x_out, sl_cg_result *res)
 {
+    SL_ABI_BEGIN
     if (!m || !b || !o || !x_out || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
     memset(res, 0, sizeof(*res));
     const auto wall0 = std::chrono::steady_clock::now();
@@ -231,6 +232,7 @@ sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *
     if (ce != hipSuccess && st == SL_OK) st = sl_fail(SL_DEVICE_ERROR, "result download failed: %s", hipGetErrorString(ce));
     res->total_time_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return st;
+    SL_ABI_END
 }
 
 } // extern "C"

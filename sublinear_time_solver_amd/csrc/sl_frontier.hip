@@ -826,6 +826,7 @@ void sl_push_options_default(sl_push_options *o)
 sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_options *o, double *x, double *r_out,
                         uint32_t *frontier_log, uint64_t frontier_cap, uint64_t *frontier_words, sl_push_result *res)
 {
+    SL_ABI_BEGIN
     if (!m || !b || !o || !x || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
     memset(res, 0, sizeof(*res));
     if (frontier_words) *frontier_words = 0;
@@ -875,6 +876,7 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
     res->residual_norm = std::sqrt(h);
     if (frontier_words) *frontier_words = plog.words;
     return SL_OK;
+    SL_ABI_END
 }
 
 // ---- query sessions: single-entry queries whose cost follows the rows the push touches ----------------------
@@ -1082,13 +1084,16 @@ static sl_status session_create(const sl_matrix *m, int matrix_is_transpose, con
 // a session may be handed to and released by another thread: its buffers are plain allocations, not pool blocks
 sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, const double *b, sl_mem where, sl_query_session **out)
 {
+    SL_ABI_BEGIN
     return session_create(m, matrix_is_transpose, b, where, true, out);
+    SL_ABI_END
 }
 
 void sl_query_session_destroy(sl_query_session *q) { delete q; }
 
 sl_status sl_query_session_estimate(sl_query_session *q, uint64_t row, double theta, uint64_t max_rounds, sl_estimate_result *res)
 {
+    SL_ABI_BEGIN
     if (!q || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
     memset(res, 0, sizeof(*res));
     const uint64_t n = q->n;
@@ -1165,6 +1170,7 @@ sl_status sl_query_session_estimate(sl_query_session *q, uint64_t row, double th
     res->rounds = rs.rounds; res->pushes = rs.pushes; res->rows_touched = rs.rows_touched;
     res->device_time_ms = ms; res->converged = rs.converged ? 1 : 0;
     return SL_OK;
+    SL_ABI_END
 }
 
 // one-shot queries: a session for the duration of the call
@@ -1185,21 +1191,27 @@ static sl_status estimate_entry_impl(const sl_matrix *m, const double *b, sl_mem
 sl_status sl_estimate_entry(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double theta,
                             uint64_t max_rounds, sl_estimate_result *res)
 {
+    SL_ABI_BEGIN
     return estimate_entry_impl(m, b, where, row, theta, max_rounds, false, res);
+    SL_ABI_END
 }
 
 sl_status sl_estimate_entry_transposed(const sl_matrix *mt, const double *b, sl_mem where, uint64_t row, double theta,
                                        uint64_t max_rounds, sl_estimate_result *res)
 {
+    SL_ABI_BEGIN
     return estimate_entry_impl(mt, b, where, row, theta, max_rounds, true, res);
+    SL_ABI_END
 }
 
 sl_status sl_matrix_transpose(const sl_matrix *m, uint32_t flags, sl_matrix **out)
 {
+    SL_ABI_BEGIN
     if (!m || !out) return sl_fail(SL_INVALID_INPUT, "null argument");
     if (!m->d_tptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "sl_matrix_transpose needs a matrix created with SL_MATRIX_WITH_TRANSPOSE");
     if (m->row_offset != 0) return sl_fail(SL_UNSUPPORTED_FORMAT, "cannot transpose a row slice");
     return sl_matrix_create_csr(m->n_cols, m->n_rows, m->nnz, m->d_tptr, m->d_trow, m->d_tval, SL_MEM_DEVICE, 0, flags, out);
+    SL_ABI_END
 }
 
 } // extern "C"

@@ -166,6 +166,15 @@ struct DevBuf {
     void *release() { void *q = p; p = nullptr; return q; }   // alloc_owned buffers only
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
+// Exception fence of the extern "C" boundary: host-side containers (std::vector, std::function, new) may throw; nothing may
+// unwind through a C caller (Rust: panic = abort; JS / ctypes: process abort).  Usage: the whole body of an entry point sits
+// between SL_ABI_BEGIN and SL_ABI_END.
+#include <new>
+#include <exception>
+#define SL_ABI_BEGIN try {
+#define SL_ABI_END                                                                                                   \
+    } catch (const std::bad_alloc &) { return sl_fail(SL_ALLOCATION, "host allocation failed (%s)", __func__); }     \
+    catch (const std::exception &e_) { return sl_fail(SL_ALGORITHM_ERROR, "internal error in %s: %s", __func__, e_.what()); }
 #define SL_TRY(expr) do { sl_status s_ = (expr); if (s_ != SL_OK) return s_; } while (0)
 
 // entry slot of position k of `lane`'s row inside a slice occupying pair blocks [h0, h1)   (fill / diagnostic kernels)

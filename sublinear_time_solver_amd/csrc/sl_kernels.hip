@@ -464,6 +464,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_ro
         const uint64_t win_lo = (g0 > w ? g0 - w : 0) & ~1ull;  // even => 16-B aligned staging loads
         uint64_t win_hi = g0 + R + w;
         if (win_hi > a.n_cols) win_hi = a.n_cols;
+        if (win_hi < win_lo) win_hi = win_lo;                    // rows past the last column (never selected for such matrices: sl_matrix.hip): empty window
         const uint32_t len = (uint32_t)(win_hi - win_lo);
         const double *__restrict__ src = a.gather + win_lo;
         const f64x2 *__restrict__ src2 = reinterpret_cast<const f64x2 *>(src);

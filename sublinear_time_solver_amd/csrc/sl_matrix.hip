@@ -432,6 +432,9 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     SL_HIP(hipStreamSynchronize(st));
     hipFree(d_band);
     m->bandwidth = h_band[0];
+    // rows beyond the last column (tall matrix / row slice reaching past n_cols): their own index is not a column, so neither the
+    // band window [row - w, row + w] nor the padding column "the row itself" exists for them — such matrices keep the general kernel
+    if (m->row_offset + n > m->n_cols) m->bandwidth = ~0ull;
     const uint64_t far_entries = h_band[1];
     if (m->bandwidth < 32768 && m->n_slices && m->padded_nnz) {
         SL_HIP(hipMalloc(&m->d_cols16, m->padded_nnz * sizeof(uint16_t)));

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void sl_walk_sum_kernel(uint64_t n, const doub
 extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double epsilon,
                                                    uint32_t seed, uint64_t num_samples, double *walk_values, sl_walk_result *res)
 {
+    SL_ABI_BEGIN
     if (!m || !b || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
     memset(res, 0, sizeof(*res));
     if (m->n_rows != m->n_cols || m->row_offset != 0) return sl_fail(SL_INVALID_INPUT, "Matrix must be square");
@@ -141,4 +142,5 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
     hipError_t le = hipGetLastError();
     if (st == SL_OK && le != hipSuccess) st = sl_fail(SL_DEVICE_ERROR, "random-walk kernels failed: %s", hipGetErrorString(le));
     return st;
+    SL_ABI_END
 }

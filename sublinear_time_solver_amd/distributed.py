@@ -159,6 +159,19 @@ class AllGatherExchange:
         return 8 * (self.part.n_local if not self.part.uniform else self.part.rows_per_rank) * (self.part.world - 1)
 
 
+def _check_halo_partition(part: "RowPartition", half_bandwidth: int) -> None:
+    """A neighbour halo pairs rank r with r - 1 / r + 1: every rank must own at least w rows.  A rank with NO rows would leave
+    its neighbours' sends unmatched (hang) or ship stale strips (explicit bounds with an empty middle rank), so such
+    partitions are rejected — e.g. the uniform partition of n = 9 over 4 ranks, whose last rank is [9, 9)."""
+    if part.world <= 1:
+        return
+    sizes = [part.range_of(r)[1] - part.range_of(r)[0] for r in range(part.world)]
+    if min(sizes) <= 0:
+        raise ValueError(f"halo exchange needs rows on every rank; row counts per rank: {sizes}")
+    if min(sizes) < half_bandwidth:
+        raise ValueError("halo exchange needs at least w rows on every rank")
+
+
 class HaloExchange:
     """Banded systems: only w entries on each side of every slice boundary travel (neighbours only)."""
     name = "halo"
@@ -168,9 +181,7 @@ class HaloExchange:
         """loopback (MEASUREMENT mode, world size 1 with an initialised RCCL group): the rank sends both boundary strips to
         ITSELF into scratch strips — same op list, same enqueue cost and same transfer kernels as a rank with two neighbours,
         so the per-step host and device cost of the exchange can be measured on a one-GPU box."""
-        sizes = [part.range_of(r)[1] - part.range_of(r)[0] for r in range(part.world)]
-        if part.world > 1 and min([v for v in sizes if v > 0] or [0]) < half_bandwidth:
-            raise ValueError("halo exchange needs at least w rows on every rank")
+        _check_halo_partition(part, half_bandwidth)
         self.part, self.w, self.group = part, int(half_bandwidth), group
         self.loopback = bool(loopback) and part.world == 1
         self._ops = {}
@@ -247,9 +258,7 @@ class HaloAllReduceExchange:
     needs_only_boundary = True
 
     def __init__(self, part: RowPartition, half_bandwidth: int, group=None):
-        sizes = [part.range_of(r)[1] - part.range_of(r)[0] for r in range(part.world)]
-        if part.world > 1 and min([v for v in sizes if v > 0] or [0]) < half_bandwidth:
-            raise ValueError("halo exchange needs at least w rows on every rank")
+        _check_halo_partition(part, half_bandwidth)
         self.part, self.w, self.group = part, int(half_bandwidth), group
         self.compact = None
 

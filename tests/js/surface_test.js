@@ -76,6 +76,14 @@ async function rejects(p, code, re) {
   }
 
   // ---- on the GPU ----
+  {   // a destroyed handle is dead, not dangling: second destroy is a no-op, any later use throws
+    const h = native.createMatrix(2, 2, [0, 1], [0, 1], new Float64Array([2, 3]), false);
+    assert.strictEqual(native.matrixInfo(h).nnz, 2);
+    native.destroyMatrix(h);
+    native.destroyMatrix(h);
+    assert.throws(() => native.matrixInfo(h), /destroyed/);
+    assert.throws(() => native.neumannSolve(h, new Float64Array([1, 1]), {}), /destroyed/);
+  }
   const b3 = [1, 2, -1], x3 = gauss(dense.data, b3);
   for (const method of ['neumann', 'forward-push', 'backward-push', 'bidirectional']) {
     const r = await new SublinearSolver({ method, epsilon: 1e-12, maxIterations: 10000 }).solve(dense, b3);

@@ -247,3 +247,16 @@ def test_row_partition_bounds():
     assert p[0].n_padded == 12
     with pytest.raises(ValueError):
         D.HaloExchange(D.RowPartition(100, 4, 1), 30)
+
+
+def test_halo_exchanges_reject_partitions_with_an_empty_rank():
+    """n = 9 over 4 ranks: the uniform partition gives the last rank [9, 9) — its neighbour would skip it while it posts
+    sends (unmatched ops, hang); an empty MIDDLE rank of explicit bounds would ship stale strips.  Both are refused."""
+    assert D.RowPartition(9, 4, 3).n_local == 0
+    for cls in (D.HaloExchange, D.HaloAllReduceExchange):
+        for r in range(4):
+            with pytest.raises(ValueError, match="rows on every rank"):
+                cls(D.RowPartition(9, 4, r), 1)
+        with pytest.raises(ValueError, match="rows on every rank"):
+            cls(D.RowPartition(12, 3, 0, bounds=[0, 6, 6, 12]), 2)
+        cls(D.RowPartition(12, 3, 1, bounds=[0, 4, 8, 12]), 2)      # fine

@@ -3,7 +3,8 @@
 
 usage: python tools/prof_summary.py gpurun_out/prof_<tag> <tag> [n k bandwidth]
   stats/stats_results.db      -> profiles/<tag>_kernel_stats.txt   (top_kernels view = `--stats`)
-  pmc_fetch/, pmc_write/      -> profiles/<tag>_pmc.txt and profiles/pmc_traffic.json
+  pmc_fetch/, pmc_write/      -> profiles/<tag>_pmc.txt and one record of profiles/pmc_traffic.json (keyed by column structure)
+  pmc_tcc/                    -> L2 hit rate of the step kernel, same text file
 FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE tallies the 128-B requests
 of a wide coalesced read stream at 64 B, i.e. exactly half the bytes (MI355X_MICROARCH.md §HBM), so the
 corrected HBM read bytes are 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken as reported.
@@ -12,6 +13,9 @@ import json
 import sqlite3
 import sys
 from pathlib import Path
+
+
+STEP_KERNELS = ("sl_band_kernel", "sl_rows_kernel", "sl_panel", "sl_mpass")
 
 
 def q(db, sql):
@@ -30,7 +34,8 @@ def main():
         lines.append(f"{name[:92]:<92} {calls:>6} {tot / 1e3:>10.3f} {avg:>10.2f} {pct:>7.2f}")
     # steady-state average of the dominant kernel: drop the first launches (cold caches / clocks)
     k = q(src / "stats" / "stats_results.db",
-          "select name, duration from kernels where name like '%sl_band_kernel%' or name like '%sl_rows_kernel%' order by start")
+          "select name, duration from kernels where name like '%sl_band_kernel%' or name like '%sl_rows_kernel%' or name like '%sl_panel%' "
+          "or name like '%sl_mpass%' order by start")
     by = {}
     for name, d in k:
         by.setdefault(name, []).append(d)
@@ -43,6 +48,7 @@ def main():
 
     pm = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) : {src}", ""]
     rec = {}
+    best_tcc = [0, 0.0, 0.0]
     for sub, db, cname in (("pmc_fetch", "fetch_results.db", "FETCH_SIZE"), ("pmc_write", "write_results.db", "WRITE_SIZE")):
         p = src / sub / db
         if not p.exists():
@@ -55,22 +61,46 @@ def main():
         best_n = 0
         for kn, cn, avg, n in rows:
             pm.append(f"  {kn[:90]:<90} {cn} avg={avg:.1f} KiB over {n} dispatches")
-            if ("sl_band_kernel" in kn or "sl_rows_kernel" in kn) and n > best_n:   # the step kernel = most dispatches
+            if any(t in kn for t in STEP_KERNELS) and n > best_n:   # the step kernel = most dispatches
                 rec[cn] = avg
                 best_n = n
+    p = src / "pmc_tcc" / "tcc_results.db"
+    if p.exists():
+        rows = q(p, "select kernel_name, counter_name, avg(value), count(*) from counters_collection where counter_name in "
+                    "('TCC_HIT_sum','TCC_MISS_sum') group by kernel_name, counter_name")
+        tcc = {}
+        for kn, cn, avg, n in rows:
+            if any(t in kn for t in STEP_KERNELS):
+                tcc.setdefault(kn, {})[cn] = (avg, n)
+        pm.append("")
+        for kn, d in tcc.items():
+            if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d:
+                h, m = d["TCC_HIT_sum"][0], d["TCC_MISS_sum"][0]
+                pm.append(f"  {kn[:90]:<90} TCC_HIT {h:.4e} TCC_MISS {m:.4e} per launch over {d['TCC_HIT_sum'][1]} dispatches -> L2 hit rate {h / (h + m):.3f}")
+                if d["TCC_HIT_sum"][1] >= best_tcc[0]:
+                    best_tcc[:] = [d["TCC_HIT_sum"][1], h, m]
     if "FETCH_SIZE" in rec or "WRITE_SIZE" in rec:
         rd = 2.0 * rec.get("FETCH_SIZE", 0.0) * 1024.0
         wr = rec.get("WRITE_SIZE", 0.0) * 1024.0
         pm += ["", f"dominant kernel per launch: FETCH_SIZE {rec.get('FETCH_SIZE', 0):.0f} KiB -> corrected read bytes {rd:.4e} (x2, gfx950)",
                f"                            WRITE_SIZE {rec.get('WRITE_SIZE', 0):.0f} KiB -> write bytes {wr:.4e}",
-               f"                            HBM traffic per launch = {rd + wr:.4e} B"]
+               f"                            HBM-side traffic per launch = {rd + wr:.4e} B  (Infinity-Cache hits are counted: this is L2 <-> fabric traffic)"]
         if cfg:
             n, kk, w = cfg
             alg = 12 * n * kk + 4 * (n + 1) + 40 * n
             pm.append(f"                            algorithmic bytes per launch = {alg:.4e} B  (traffic / algorithmic = {(rd + wr) / alg:.3f})")
-            (out / "pmc_traffic.json").write_text(json.dumps({"tag": tag, "n": n, "k": kk, "bandwidth": w, "fetch_size_kib": rec.get("FETCH_SIZE"),
-                                                              "write_size_kib": rec.get("WRITE_SIZE"), "hbm_bytes_per_launch": rd + wr,
-                                                              "algorithmic_bytes_per_launch": alg}) + "\n")
+            tf = out / "pmc_traffic.json"
+            try:
+                allrec = json.loads(tf.read_text())
+                if "records" not in allrec:
+                    allrec = {"records": {f"w{allrec.get('bandwidth')}" if allrec.get("bandwidth") else "uniform": allrec}}
+            except Exception:
+                allrec = {"records": {}}
+            allrec["records"]["uniform" if w == 0 else f"w{w}"] = {
+                "tag": tag, "n": n, "k": kk, "bandwidth": w, "fetch_size_kib": rec.get("FETCH_SIZE"), "write_size_kib": rec.get("WRITE_SIZE"),
+                "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg,
+                "l2_hit_rate": (best_tcc[1] / (best_tcc[1] + best_tcc[2])) if best_tcc[0] else None}
+            tf.write_text(json.dumps(allrec, indent=1) + "\n")
     (out / f"{tag}_pmc.txt").write_text("\n".join(pm) + "\n")
     print("\n".join(pm))
 
