@@ -77,7 +77,7 @@ async function rejects(p, code, re) {
 
   // ---- on the GPU ----
   {   // a destroyed handle is dead, not dangling: second destroy is a no-op, any later use throws
-    const h = native.createMatrix(2, 2, [0, 1], [0, 1], new Float64Array([2, 3]), false);
+    const h = native.createMatrix(2, 2, new Uint32Array([0, 1]), new Uint32Array([0, 1]), new Float64Array([2, 3]), false);
     assert.strictEqual(native.matrixInfo(h).nnz, 2);
     native.destroyMatrix(h);
     native.destroyMatrix(h);

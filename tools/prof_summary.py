@@ -25,8 +25,11 @@ def q(db, sql):
 def main():
     src, tag = Path(sys.argv[1]), sys.argv[2]
     cfg = [int(v) for v in sys.argv[3:6]] if len(sys.argv) >= 6 else None
-    out = Path(__file__).resolve().parent.parent / "profiles"
-    out.mkdir(exist_ok=True)
+    import os
+    # PROF_OUT: where the summaries go.  On the GPU box only gpurun_out/ travels back (<= 64 MiB, the .db files are 22 MB each), so
+    # tools/profile.sh summarises there into gpurun_out/prof_<tag>/summary and deletes the databases; copy the summaries to profiles/.
+    out = Path(os.environ.get("PROF_OUT") or (Path(__file__).resolve().parent.parent / "profiles"))
+    out.mkdir(parents=True, exist_ok=True)
     lines = [f"# rocprofv3 --kernel-trace --stats : {src}/stats  (top_kernels view)", ""]
     rows = q(src / "stats" / "stats_results.db", "select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc")
     lines.append(f"{'kernel':<92} {'calls':>6} {'total_ms':>10} {'avg_us':>10} {'pct':>7}")

@@ -17,3 +17,8 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $B --ste
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_tcc -o tcc -- $B --steps 10 --warmup 2 "$@" > $OUT/bench_tcc.log 2>&1
 tail -n 1 $OUT/bench_stats.log > $OUT/bench_under_rocprof.json
 ls -la $OUT/*/* | head -40
+# summarise ON the box (gpurun_out/ comes back only below 64 MiB; each rocpd database is ~22 MB), then drop the databases
+NKW=${PROF_NKW:-"10000000 16 0"}
+PROF_OUT=$OUT/summary python /root/repo/tools/prof_summary.py $OUT $TAG $NKW > $OUT/summary.log 2>&1
+find $OUT -name '*.db' -delete
+ls -la $OUT/summary
