@@ -168,6 +168,8 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
     a.long_rows = m->d_long_rows; a.n_long = (uint32_t)m->n_long;
     a.pan_tile_ptr = m->d_pan_tile_ptr; a.pan_row = m->d_pan_row; a.pan_col = m->d_pan_col; a.pan_val = m->d_pan_val;
     a.n_pan_tiles = (uint32_t)m->n_pan_tiles; a.pan_balanced = m->pan_balanced ? 1u : 0u;
+    a.pw_idx = m->d_pw_idx; a.pw_val = m->d_pw_val; a.pw_tile_ptr = m->d_pw_tile_ptr;
+    a.pw_tiles = (uint32_t)m->n_pw_tiles; a.pw_rpw = m->pw_rpw; a.pw_blocks = m->pw_blocks; a.pw_slack = m->pw_slack;
     return a;
 }
 
@@ -227,6 +229,7 @@ void sl_matrix_destroy(sl_matrix *m)
     hipFree(m->d_row_ptr); hipFree(m->d_col_idx); hipFree(m->d_values);
     hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval); hipFree(m->d_tent); hipFree(m->d_long_rows);
     hipFree(m->d_pan_tile_ptr); hipFree(m->d_pan_row); hipFree(m->d_pan_col); hipFree(m->d_pan_val);
+    hipFree(m->d_pw_idx); hipFree(m->d_pw_val); hipFree(m->d_pw_tile_ptr);
     delete m;
 }
 
@@ -328,7 +331,7 @@ sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info)
     info->max_row_nnz = m->max_row_nnz; info->min_row_nnz = m->min_row_nnz; info->uniform_width = m->uniform_width;
     info->has_transpose = m->d_tptr != nullptr;
     info->long_row_threshold = m->long_row;
-    info->column_panels = m->d_pan_tile_ptr ? 1u : 0u;
+    info->column_panels = m->d_pw_idx ? 2u : (m->d_pan_tile_ptr ? 1u : 0u);      // 2 = the paced layout
     info->reserved = 0;
     info->n_long_rows = (uint32_t)m->n_long;
     return SL_OK;

@@ -63,6 +63,24 @@ struct sl_matrix {
     double *d_pan_val = nullptr;
     uint64_t n_pan_tiles = 0, pan_entries = 0;
     bool pan_balanced = false;          // every tile's stream within 10 % of the mean length: launched one resident round at a time
+    // paced column-panel layout (round 2; balanced matrices — uniformly random columns): ONE persistent 16-wave block per CU, a wave
+    // owns a tile of pw_rpw rows (running sums in LDS; the CU's whole LDS holds its 16 tiles), tiles are dealt in rounds.  Rows go to
+    // tiles in groups of 16, round robin (group q -> tile q mod n_pw_tiles, slot (q / n_pw_tiles) * 16 + row mod 16): a tile's rows
+    // are spread over the whole matrix, so whatever depends on the row index — the diagonal first of all — lands in all panels alike
+    // and every tile carries the same work in every panel (with consecutive rows a tile's 1200 diagonal entries sit in ONE panel:
+    // ten panel-times of extra work at a different place for every block, which tears the blocks of an XCD apart).  A tile's
+    // entries are one stream sorted by (panel of 2^16 columns, row, column), 12 bytes per entry:
+    //     pw_idx u32 = row in tile << 21 | super-panel step << 20 | column & 0xfffff      pw_val f64
+    // stored in chunks of 256 entries, pre-transposed so that three 16-byte loads hand lane l the entries l, l+64, l+128, l+192:
+    //     pw_idx [chunk][lane][4]      pw_val [chunk][half][lane][2]
+    // (super-panel = 2^20 columns; the step bit is set on the first entry of a tile's stream that lies in the next super-panel,
+    // an empty super-panel is bridged by a padding entry: value 0, row = the tile's spare slot.)
+    uint32_t *d_pw_idx = nullptr;
+    double *d_pw_val = nullptr;
+    uint32_t *d_pw_tile_ptr = nullptr;  // [n_pw_tiles + 1] in chunks
+    uint64_t n_pw_tiles = 0, pw_chunks = 0;
+    uint32_t pw_rpw = 0, pw_blocks = 0;
+    uint32_t pw_slack = 4;              // panels a wave may gather ahead of the slowest wave of its block: about two chunks of its stream
     uint64_t device_bytes = 0;
 };
 #ifndef SL_PANEL_TILE
@@ -73,6 +91,10 @@ struct sl_matrix {
                                      // (n = 10^7 x 16, ms per step by panel size: 2^18 1.57, 2^17 1.49, 2^16 1.39, 2^15 1.36, 2^14 1.43)
 #endif
 #define SL_PANEL_CHUNK 256u          // entries a wave has in flight (4 x 64)
+#define SL_PW_WAVES 16               // paced layout: waves per block = tiles per CU
+#define SL_PW_GROUP 16u              // rows are dealt to tiles in groups of 16 consecutive rows (one 128-byte line of every vector)
+#define SL_PW_MAX_ROWS 1264u         // rows per wave tile (79 groups): 16 x (1264 + 1 spare slot) x 8 B = 161 920 B of the 160 KiB LDS
+#define SL_PW_SP_BITS 20             // super-panel: the column bits an entry carries
 #ifndef SL_PANEL_WAVES
 #define SL_PANEL_WAVES 4
 #endif
@@ -222,6 +244,10 @@ struct sl_row_args {
     const uint32_t *pan_tile_ptr; const uint16_t *pan_row; const uint32_t *pan_col; const double *pan_val;
     uint32_t n_pan_tiles;
     uint32_t pan_balanced;
+    // paced column-panel layout (null unless the matrix carries one)
+    const uint32_t *pw_idx; const double *pw_val; const uint32_t *pw_tile_ptr;
+    uint32_t pw_tiles, pw_rpw, pw_blocks;
+    uint32_t pw_slack;        // panels a wave may run ahead of the slowest wave of its block (set by the launcher; >= 2^20: no pacing)
     // vectors
     const double *gather; // gathered vector (n_cols)
     const double *dinv;   // n_rows

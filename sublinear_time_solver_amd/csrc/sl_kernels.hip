@@ -12,6 +12,7 @@
 // simd_ops::matrix_vector_multiply_simd (simd_ops.rs:20-88).
 #include "sl_internal.hpp"
 #include <cstdlib>
+#include <mutex>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -618,6 +619,158 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
     sl_block_partials<EPI, SL_PANEL_WAVES>(a, red, lane, wave, lb, a.part_stride, part0, part1);
 }
 
+// ---- paced column-panel kernel: persistent blocks, gathers served by the L2 ------------------------------------------------
+// Layout: sl_internal.hpp (sl_matrix::d_pw_*).  ONE 16-wave block per CU; wave w of block b owns, in round r, tile
+// (r * blocks + b) * 16 + w: pw_rpw rows whose running sums live in LDS (the CU's whole LDS = its 16 tiles), and walks the tile's
+// stream — sorted by (panel of 2^16 columns, row, column) — 256 entries at a time: stream loads two chunks ahead, gathers one
+// chunk ahead of the LDS updates (three stream buffers that change ROLES; a copy would wait for everything in flight).
+// What makes the gathers L2 hits is that the waves of an XCD sit on the same few panels (512 KiB of the vector each) at the same
+// time.  Nothing but equal work kept round 1's kernel there (L2 hit rate 64 %, 1.39 ms at n = 10^7 x 16 where perfect locality
+// gives 0.95).  Here the 16 waves of a block PACE each other through progress words in LDS: a wave about to gather from a panel
+// more than one ahead of the slowest wave of its block sleeps.  The pace is a hint with a bounded wait that switches itself off,
+// never a correctness condition; blocks of an XCD start together and carry equal work (the layout is only built for balanced
+// matrices), which keeps them within the L2's reach of each other (tools/panel2_bench.hip: free-running 1.95-2.2 ms, paced inside
+// the block 1.16 ms, pacing across the XCD through an L2-resident line of progress words as well: no further gain).
+// Summation order: within a row the products arrive in ascending column order (panel order = column order) and are added one by
+// one.  Entries of one row that sit in neighbouring lanes (same panel) form a run: the run's first lane adds its followers'
+// products in lane order — explicit shuffles, ONE LDS update per run; a row that comes back behind a panel boundary inside the
+// same 64 entries is a second run, and the runs of different panels are applied one panel after the other with the LDS drained
+// in between.  Bits = the sequential reference loop (sparse.rs:187-203).  CSR order only; the 4-lane order keeps the general kernel.
+template <int EPI>
+__global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) double pw_acc[];
+    __shared__ double red[2 * SL_PW_WAVES];
+    __shared__ uint32_t prog[SL_PW_WAVES + 1];                     // [16] = pacing alive
+    if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t rpw = a.pw_rpw, slack = a.pw_slack;
+    double *acc = pw_acc + (size_t)wave * (rpw + 1);                // + the spare slot padding entries add their zeros to
+    volatile uint32_t *vprog = prog;
+    if (threadIdx.x <= SL_PW_WAVES) prog[threadIdx.x] = threadIdx.x == SL_PW_WAVES ? 1u : 0u;
+    __syncthreads();
+    const double *__restrict__ g = a.gather;
+    const uint32_t nblocks = gridDim.x;
+    const uint32_t rounds = (a.pw_tiles + nblocks * SL_PW_WAVES - 1) / (nblocks * SL_PW_WAVES);
+    double part0 = 0.0, part1 = 0.0;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        const uint32_t tile = (round * nblocks + blockIdx.x) * SL_PW_WAVES + wave;
+        if (tile >= a.pw_tiles) { if (lane == 0) vprog[wave] = 0xffffffffu; continue; }     // nothing to wait for
+        for (uint32_t r = lane; r <= rpw; r += 64) acc[r] = 0.0;
+        const uint32_t ch0 = a.pw_tile_ptr[tile], chunks = a.pw_tile_ptr[tile + 1] - ch0;
+        const u32x4 *__restrict__ idxq = reinterpret_cast<const u32x4 *>(a.pw_idx) + (uint64_t)ch0 * 64;
+        const f64x2 *__restrict__ valq = reinterpret_cast<const f64x2 *>(a.pw_val) + (uint64_t)ch0 * 128;
+        uint32_t sp_g = 0;                                          // super-panel at the gather stage (wave-uniform)
+        uint32_t SI[3][4], GC[3][4];
+        double SV[3][4], GG[3][4];
+        auto load_stream = [&](uint32_t ch, uint32_t (&ii)[4], double (&vv)[4]) {
+            const u32x4 q = __builtin_nontemporal_load(idxq + (uint64_t)ch * 64 + lane);
+            const f64x2 va = __builtin_nontemporal_load(valq + (uint64_t)ch * 128 + lane);
+            const f64x2 vb = __builtin_nontemporal_load(valq + (uint64_t)ch * 128 + 64 + lane);
+            ii[0] = q.x; ii[1] = q.y; ii[2] = q.z; ii[3] = q.w;
+            vv[0] = va.x; vv[1] = va.y; vv[2] = vb.x; vv[3] = vb.y;
+        };
+        auto pace = [&](uint32_t pan) {
+            const uint32_t me = (round << 20) + pan + 1u;           // monotone over the launch (panels < 2^16)
+            if (lane == 0) vprog[wave] = me;
+            if (slack >= (1u << 20) || !vprog[SL_PW_WAVES]) return;
+            for (uint32_t spins = 0;; ++spins) {
+                uint32_t m = lane < SL_PW_WAVES ? vprog[lane] : 0xffffffffu;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor(m, o));
+                m = __builtin_amdgcn_readfirstlane(m);
+                if (me <= m + slack) break;                         // at most `slack` panels ahead of the block's slowest wave
+                if (spins > 2048u) { if (lane == 0) vprog[SL_PW_WAVES] = 0u; break; }     // the hint switches itself off
+                __builtin_amdgcn_s_sleep(4);
+            }
+        };
+        auto gather = [&](const uint32_t (&ii)[4], double (&gg)[4], uint32_t (&cc)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long fl = __ballot((ii[u] >> SL_PW_SP_BITS) & 1u);
+                const uint32_t sp = sp_g + (uint32_t)__popcll(fl & ((2ull << lane) - 1ull));
+                sp_g += (uint32_t)__popcll(fl);
+                cc[u] = (sp << SL_PW_SP_BITS) | (ii[u] & ((1u << SL_PW_SP_BITS) - 1u));
+                gg[u] = g[cc[u]];
+            }
+        };
+        auto accumulate = [&](const uint32_t (&ii)[4], const double (&vv)[4], const double (&gg)[4], const uint32_t (&cc)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t row = ii[u] >> 21;
+                const double prod = DMUL(vv[u], gg[u]);
+                const uint32_t pan = cc[u] >> SL_PANEL_COL_BITS;
+                const uint32_t prow = __shfl_up(row, 1), ppan = __shfl_up(pan, 1);
+                const unsigned long long same = __ballot(lane > 0 && prow == row && ppan == pan);     // continues its left neighbour's run
+                const unsigned long long cut = __ballot(lane > 0 && ppan != pan);
+                if (!(same | cut)) {                                 // 64 distinct rows of one panel
+                    acc[row] = DADD(acc[row], prod);
+                } else {
+                    const unsigned long long lead = ~same;
+                    const unsigned long long above = lead & ~((2ull << lane) - 1ull);                 // run leaders to my right
+                    const uint32_t runlen = (above ? (uint32_t)__builtin_ctzll(above) : 64u) - lane;  // meaningful on leaders
+                    const bool leader = (lead >> lane) & 1ull;
+                    uint32_t maxrun = leader ? runlen : 1u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) maxrun = max(maxrun, (uint32_t)__shfl_xor(maxrun, o));
+                    const uint32_t partno = (uint32_t)__popcll(cut & ((2ull << lane) - 1ull)), nparts = (uint32_t)__popcll(cut) + 1u;
+                    const double q1 = __shfl_down(prod, 1), q2 = __shfl_down(prod, 2), q3 = __shfl_down(prod, 3);
+                    for (uint32_t f = 0; f < nparts; ++f) {
+                        if (leader && partno == f) {
+                            double sacc = DADD(acc[row], prod);
+                            if (runlen > 1) sacc = DADD(sacc, q1);
+                            if (runlen > 2) sacc = DADD(sacc, q2);
+                            if (runlen > 3) sacc = DADD(sacc, q3);
+                            acc[row] = sacc;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the next panel's runs may meet the same rows
+                    }
+                    for (uint32_t st = 4; st < maxrun; ++st) {                    // runs longer than four: the rest, one step at a time
+                        const double qq = __shfl_down(prod, st);
+                        for (uint32_t f = 0; f < nparts; ++f) {
+                            if (leader && partno == f && runlen > st) acc[row] = DADD(acc[row], qq);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+                    }
+                }
+            }
+        };
+        if (chunks) {
+            load_stream(0, SI[0], SV[0]);
+            if (chunks > 1) load_stream(1, SI[1], SV[1]);
+            pace(0);
+            gather(SI[0], GG[0], GC[0]);
+#define SL_PW_STEP(r, r1, r2)                                                                                        \
+            if (ch + 2 < chunks) load_stream(ch + 2, SI[r2], SV[r2]);                                                \
+            if (ch + 1 < chunks) {                                                                                   \
+                const uint32_t nextcol = (sp_g << SL_PW_SP_BITS) | (__builtin_amdgcn_readfirstlane(SI[r1][0]) & ((1u << SL_PW_SP_BITS) - 1u)); \
+                pace(nextcol >> SL_PANEL_COL_BITS);                                                                  \
+                gather(SI[r1], GG[r1], GC[r1]);                                                                      \
+            }                                                                                                        \
+            accumulate(SI[r], SV[r], GG[r], GC[r]);                                                                  \
+            if (++ch >= chunks) break;
+            for (uint32_t ch = 0;;) {
+                SL_PW_STEP(0, 1, 2)
+                SL_PW_STEP(1, 2, 0)
+                SL_PW_STEP(2, 0, 1)
+            }
+#undef SL_PW_STEP
+        }
+        if (lane == 0) vprog[wave] = (round + 1u) << 20;             // as far along as the round's end while the vectors are written
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (uint32_t r = lane; r < rpw; r += 64) {                   // slot r = group r / 16 of the tile, row r % 16 of the group
+            const uint64_t i = ((uint64_t)(r / SL_PW_GROUP) * a.pw_tiles + tile) * SL_PW_GROUP + (r % SL_PW_GROUP);
+            if (i >= a.n_rows || (a.n_long && a.row_len[i] == SL_LONG_SENTINEL)) continue;
+            double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
+            if constexpr (EPI == SL_EPI_NEUMANN) { e_t = g[a.row_offset + i]; e_d = a.dinv[i]; e_x = a.x[i]; }
+            else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
+            else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = g[a.row_offset + i]; }
+            sl_row_epilogue<EPI>(a, i, acc[r], e_t, e_d, e_x, dself, part0, part1);
+        }
+    }
+    sl_block_partials<EPI, SL_PW_WAVES>(a, red, lane, wave, blockIdx.x, a.part_stride, part0, part1);
+}
+
 // ---- long rows: one block per row ------------------------------------------------------------------
 // Rows with more than SL_LONG_ROW entries (hubs of power-law graphs).  The 256 threads fetch the raw CSR
 // entries coalesced and form the products in parallel; the additions stay sequential in the reference's
@@ -873,7 +1026,21 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
     // with 3 quads per batch (2 in the 4-lane order) instead of 4
     const bool nw8_pays = !(EPI == SL_EPI_PUSH && uniform_unrolled && a.uniform_width == 16);
     const band_geom g = band_geometry(a, uniform_unrolled || !uniform_octets, nw8_pays);
-    if (ORDER == 0 && a.pan_tile_ptr && a.n_pan_tiles) {
+    if (ORDER == 0 && a.pw_idx && a.pw_tiles) {
+        const uint32_t lds = (uint32_t)(SL_PW_WAVES * ((size_t)a.pw_rpw + 1) * sizeof(double));
+        static std::once_flag attr_once;                                  // per process and template instance; the value is a constant
+        hipError_t attr_err = hipSuccess;
+        std::call_once(attr_once, [&] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(sl_pw_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double)));
+        });
+        SL_HIP(attr_err);
+        static const uint32_t env_slack = [] { const char *e = getenv("SL_PW_SLACK"); return e && *e ? (uint32_t)atol(e) : 0u; }();   // A/B knob; 1048576 = no pacing
+        if (env_slack) a.pw_slack = env_slack;
+        *nparts = a.pw_blocks + a.n_long;
+        a.part_stride = *nparts;
+        hipLaunchKernelGGL((sl_pw_kernel<EPI>), dim3(a.pw_blocks), dim3(SL_PW_WAVES * 64), lds, s, a);
+    } else if (ORDER == 0 && a.pan_tile_ptr && a.n_pan_tiles) {
         const uint32_t grid = (a.n_pan_tiles + SL_PANEL_WAVES - 1) / SL_PANEL_WAVES;
         constexpr uint32_t lds = SL_PANEL_WAVES * (SL_PANEL_TILE + 64) * sizeof(double);
         static bool attr_done = false;

@@ -244,7 +244,7 @@ sl_status sl_sort_pairs_u32(const uint32_t *keys_in, uint32_t *keys_out, const u
 // ---- column-panel layout ------------------------------------------------------------------------------
 // sort key of every CSR entry: (tile of its row) * n_panels + (panel of its column); entries of long rows (served by the
 // long-row kernel) get the largest key and fall off the end.  Also the row inside the tile, for the gather pass below.
-__global__ __launch_bounds__(256) void sl_panel_keys_kernel(uint64_t n_rows, uint32_t n_panels, const uint32_t *row_ptr, const uint32_t *col_idx,
+__global__ __launch_bounds__(256) void sl_panel_keys_kernel(uint64_t n_rows, uint32_t n_panels, uint32_t tile_rows, const uint32_t *row_ptr, const uint32_t *col_idx,
                                                             const uint32_t *row_len, uint32_t *key, uint16_t *rowl)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(256) void sl_panel_keys_kernel(uint64_t n_rows, uin
     for (uint64_t i = wave; i < n_rows; i += nwaves) {                        // a wave per row: coalesced over the row's entries
         const uint32_t s = row_ptr[i], e = row_ptr[i + 1];
         const bool is_long = row_len[i] == SL_LONG_SENTINEL;
-        const uint32_t base = (uint32_t)(i / SL_PANEL_TILE) * n_panels;
-        const uint16_t rl = (uint16_t)(i % SL_PANEL_TILE);
+        const uint32_t base = (uint32_t)(i / tile_rows) * n_panels;
+        const uint16_t rl = (uint16_t)(i % tile_rows);
         for (uint32_t k = s + lane; k < e; k += 64u) {
             key[k] = is_long ? 0xffffffffu : base + (col_idx[k] >> SL_PANEL_COL_BITS);
             rowl[k] = rl;
@@ -261,14 +261,14 @@ __global__ __launch_bounds__(256) void sl_panel_keys_kernel(uint64_t n_rows, uin
     }
 }
 // entries per tile (long rows excluded)
-__global__ __launch_bounds__(256) void sl_panel_tile_count_kernel(uint64_t n_rows, uint64_t n_tiles, const uint32_t *row_ptr, const uint32_t *row_len,
+__global__ __launch_bounds__(256) void sl_panel_tile_count_kernel(uint64_t n_rows, uint64_t n_tiles, uint32_t tile_rows, const uint32_t *row_ptr, const uint32_t *row_len,
                                                                   uint32_t *count)
 {
     const uint64_t t = blockIdx.x;
     if (t >= n_tiles) return;
     uint32_t acc = 0;
-    for (uint32_t r = threadIdx.x; r < SL_PANEL_TILE; r += 256) {
-        const uint64_t i = t * SL_PANEL_TILE + r;
+    for (uint32_t r = threadIdx.x; r < tile_rows; r += 256) {
+        const uint64_t i = t * tile_rows + r;
         if (i < n_rows && row_len[i] != SL_LONG_SENTINEL) acc += row_ptr[i + 1] - row_ptr[i];
     }
     __shared__ uint32_t red[4];
@@ -314,9 +314,9 @@ static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr,
     SL_TRY(key.alloc_owned(nnz * 4)); SL_TRY(key_out.alloc_owned(nnz * 4)); SL_TRY(ent_in.alloc_owned(nnz * 4)); SL_TRY(perm.alloc_owned(nnz * 4));
     SL_TRY(rowl.alloc_owned(nnz * 2)); SL_TRY(cnt.alloc_owned((n_tiles + 1) * 4));
     const uint32_t g = grid_for(nnz, 256) > 8192 ? 8192 : grid_for(nnz, 256);
-    hipLaunchKernelGGL(sl_panel_keys_kernel, dim3(g), dim3(256), 0, st, n, n_panels, d_row_ptr, d_col_idx, m->d_row_len, key.as<uint32_t>(), rowl.as<uint16_t>());
+    hipLaunchKernelGGL(sl_panel_keys_kernel, dim3(g), dim3(256), 0, st, n, n_panels, (uint32_t)SL_PANEL_TILE, d_row_ptr, d_col_idx, m->d_row_len, key.as<uint32_t>(), rowl.as<uint16_t>());
     hipLaunchKernelGGL(sl_iota_kernel, dim3(g), dim3(256), 0, st, nnz, ent_in.as<uint32_t>());
-    hipLaunchKernelGGL(sl_panel_tile_count_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, n, n_tiles, d_row_ptr, m->d_row_len, cnt.as<uint32_t>());
+    hipLaunchKernelGGL(sl_panel_tile_count_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, n, n_tiles, (uint32_t)SL_PANEL_TILE, d_row_ptr, m->d_row_len, cnt.as<uint32_t>());
     std::vector<uint32_t> count(n_tiles + 1), src(n_tiles + 1), dst(n_tiles + 1);
     SL_HIP(hipMemcpyAsync(count.data(), cnt.p, n_tiles * 4, hipMemcpyDeviceToHost, st));
     int bits = 32;                                                             // long rows carry the key 0xffffffff
@@ -347,6 +347,148 @@ static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr,
     for (uint64_t t = 0; t < n_tiles; ++t) longest = std::max(longest, count[t]);
     m->pan_balanced = n_tiles > 0 && (double)longest * (double)n_tiles <= 1.1 * (double)run_s;
     m->device_bytes += run_d * 14 + (n_tiles + 1) * 4;
+    return SL_OK;
+}
+
+// keys and per-tile entry counts for the paced layout: groups of SL_PW_GROUP rows dealt round robin to n_tiles tiles
+__global__ __launch_bounds__(256) void sl_pw_keys_kernel(uint64_t n_rows, uint32_t n_panels, uint32_t n_tiles, const uint32_t *row_ptr, const uint32_t *col_idx,
+                                                         const uint32_t *row_len, uint32_t *key, uint16_t *rowl, uint32_t *count)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    for (uint64_t i = wave; i < n_rows; i += nwaves) {                        // a wave per row: coalesced over the row's entries
+        const uint32_t s = row_ptr[i], e = row_ptr[i + 1];
+        const bool is_long = row_len[i] == SL_LONG_SENTINEL;
+        const uint64_t q = i / SL_PW_GROUP;
+        const uint32_t tile = (uint32_t)(q % n_tiles);
+        const uint16_t rl = (uint16_t)((q / n_tiles) * SL_PW_GROUP + i % SL_PW_GROUP);
+        for (uint32_t k = s + lane; k < e; k += 64u) {
+            key[k] = is_long ? 0xffffffffu : tile * n_panels + (col_idx[k] >> SL_PANEL_COL_BITS);
+            rowl[k] = rl;
+        }
+        if (lane == 0 && !is_long && e > s) atomicAdd(&count[tile], e - s);
+    }
+}
+
+// ---- paced column-panel layout (sl_internal.hpp, sl_pw_kernel) --------------------------------------------------------------
+// One wave per tile walks the tile's sorted entries (perm[src[t] ..]) 64 at a time.  An entry whose super-panel (col >> 20) lies d
+// steps beyond its predecessor's needs d - 1 bridging entries in front of it (the step bit moves one super-panel at a time).
+// WRITE = false: pads[t] = number of bridging entries of tile t.  WRITE = true: the stream is written, chunk-transposed, and the
+// tail of the last chunk filled with padding entries (value 0, spare row slot, no step).
+__device__ __forceinline__ void sl_pw_store(uint32_t *idx, double *val, uint64_t pos, uint32_t word, double v)
+{
+    const uint64_t chunk0 = pos & ~255ull;
+    const uint32_t e = (uint32_t)(pos & 255u), u = e >> 6, l = e & 63u;
+    idx[chunk0 + l * 4 + u] = word;
+    val[chunk0 + (u >> 1) * 128 + l * 2 + (u & 1u)] = v;
+}
+template <bool WRITE>
+__global__ __launch_bounds__(256) void sl_pw_fill_kernel(uint64_t n_tiles, uint32_t rpw, const uint32_t *src, const uint32_t *dst_chunks, const uint32_t *perm,
+                                                         const uint16_t *rowl, const uint32_t *col_idx, const double *values, uint32_t *pads,
+                                                         uint32_t *idx, double *val)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const uint32_t s0 = src[t], cnt = src[t + 1] - s0;
+    uint32_t prev_sp = 0, pad_run = 0;                         // super-panel of the entry before this group of 64; bridging entries so far
+    const uint64_t out0 = WRITE ? (uint64_t)dst_chunks[t] * 256 : 0;
+    for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const bool in = e < cnt;
+        uint32_t k = 0, sp = prev_sp, c = 0;
+        if (in) { k = perm[s0 + e]; c = col_idx[k]; sp = c >> SL_PW_SP_BITS; }
+        uint32_t left = __shfl_up(sp, 1);
+        if (lane == 0) left = prev_sp;
+        const uint32_t step = in ? sp - left : 0u;             // entries are sorted by panel: never negative
+        const uint32_t bridge = step > 1u ? step - 1u : 0u;
+        uint32_t incl = bridge;                                // inclusive scan of the bridging entries inside the group
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += v; }
+        if (WRITE && in) {
+            const uint64_t pos = out0 + e + pad_run + incl;    // behind its own bridging entries
+            for (uint32_t b = 0; b < bridge; ++b)
+                sl_pw_store(idx, val, pos - bridge + b, (rpw << 21) | (1u << SL_PW_SP_BITS), 0.0);
+            sl_pw_store(idx, val, pos, ((uint32_t)rowl[k] << 21) | ((step ? 1u : 0u) << SL_PW_SP_BITS) | (c & ((1u << SL_PW_SP_BITS) - 1u)), values[k]);
+        }
+        pad_run += __shfl(incl, 63);
+        const uint32_t last = cnt - e0 < 64u ? cnt - e0 - 1u : 63u;
+        prev_sp = __shfl(sp, last);
+    }
+    if (!WRITE) { if (lane == 0) pads[t] = pad_run; return; }
+    const uint64_t end = out0 + cnt + pad_run, stop = (uint64_t)dst_chunks[t + 1] * 256;
+    for (uint64_t pos = end + lane; pos < stop; pos += 64) sl_pw_store(idx, val, pos, rpw << 21, 0.0);
+}
+
+// returns SL_OK with m->d_pw_idx == nullptr when the matrix does not qualify (unbalanced tiles, too few rows per wave ...)
+static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx, const double *d_values, hipStream_t st)
+{
+    const uint64_t n = m->n_rows, nnz = m->nnz;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    SL_HIP(hipGetDevice(&dev));
+    SL_HIP(hipGetDeviceProperties(&prop, dev));
+    uint64_t cus = prop.multiProcessorCount > 0 ? (uint64_t)prop.multiProcessorCount : 256;
+    // test knobs (read per call): SL_PW_CUS = pretend the device has this many CUs (several rounds on small systems),
+    // SL_PW_FORCE=1 = build the paced layout whatever the tile size and balance
+    if (const char *e = getenv("SL_PW_CUS")) { const long v = atol(e); if (v > 0) cus = std::min<uint64_t>(cus, (uint64_t)v); }
+    const bool force = getenv("SL_PW_FORCE") && getenv("SL_PW_FORCE")[0] == '1';
+    const uint64_t waves = cus * SL_PW_WAVES;
+    const uint64_t n_groups = (n + SL_PW_GROUP - 1) / SL_PW_GROUP, max_groups = SL_PW_MAX_ROWS / SL_PW_GROUP;
+    const uint64_t rounds = (n_groups + waves * max_groups - 1) / (waves * max_groups);
+    const uint64_t n_tiles = std::min<uint64_t>(rounds * waves, n_groups);                  // every tile of every round carries work
+    const uint32_t rpw = (uint32_t)(((n_groups + n_tiles - 1) / n_tiles) * SL_PW_GROUP);
+    const size_t lds_avail = std::max({(size_t)prop.sharedMemPerBlock, (size_t)prop.sharedMemPerBlockOptin, (size_t)prop.maxSharedMemoryPerMultiProcessor});
+    if (n == 0 || lds_avail < (size_t)SL_PW_WAVES * (SL_PW_MAX_ROWS + 1) * 8 + 512) return SL_OK;
+    if (rpw < 256 && !force) return SL_OK;                                       // small systems keep the dynamic tiles
+    const uint64_t n_panels = (m->n_cols + (1ull << SL_PANEL_COL_BITS) - 1) >> SL_PANEL_COL_BITS;
+    if (n_tiles * n_panels >= 0xfffffff0ull) return SL_OK;
+    DevBuf key, key_out, ent_in, perm, rowl, cnt, pads;
+    SL_TRY(key.alloc_owned(nnz * 4)); SL_TRY(key_out.alloc_owned(nnz * 4)); SL_TRY(ent_in.alloc_owned(nnz * 4)); SL_TRY(perm.alloc_owned(nnz * 4));
+    SL_TRY(rowl.alloc_owned(nnz * 2)); SL_TRY(cnt.alloc_owned((n_tiles + 1) * 4)); SL_TRY(pads.alloc_owned((n_tiles + 1) * 4));
+    const uint32_t g = grid_for(nnz, 256) > 8192 ? 8192 : grid_for(nnz, 256);
+    SL_HIP(hipMemsetAsync(cnt.p, 0, (n_tiles + 1) * 4, st));
+    hipLaunchKernelGGL(sl_pw_keys_kernel, dim3(g), dim3(256), 0, st, n, (uint32_t)n_panels, (uint32_t)n_tiles, d_row_ptr, d_col_idx, m->d_row_len,
+                       key.as<uint32_t>(), rowl.as<uint16_t>(), cnt.as<uint32_t>());
+    std::vector<uint32_t> count(n_tiles + 1), src(n_tiles + 1), dst(n_tiles + 1), hpads(n_tiles + 1);
+    SL_HIP(hipMemcpyAsync(count.data(), cnt.p, n_tiles * 4, hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    uint64_t total = 0; uint32_t longest = 0;
+    for (uint64_t t = 0; t < n_tiles; ++t) { src[t] = (uint32_t)total; total += count[t]; longest = std::max(longest, count[t]); }
+    src[n_tiles] = (uint32_t)total;
+    // persistent blocks with a fixed deal of tiles: only for matrices whose tiles carry (nearly) equal work
+    if (total == 0 || (!force && (double)longest * (double)n_tiles > 1.1 * (double)total)) return SL_OK;
+    hipLaunchKernelGGL(sl_iota_kernel, dim3(g), dim3(256), 0, st, nnz, ent_in.as<uint32_t>());
+    int bits = 32;
+    if (!m->n_long) { bits = 1; while (bits < 32 && (1ull << bits) < n_tiles * n_panels) ++bits; }
+    // stable: inside a (tile, panel) group the entries keep their CSR order = (row, column) order, and a tile's slots grow with its rows
+    SL_TRY(sl_sort_pairs_u32(key.as<uint32_t>(), key_out.as<uint32_t>(), ent_in.as<uint32_t>(), perm.as<uint32_t>(), nnz, bits, st));   // synchronises
+    DevBuf dsrc, ddst;
+    SL_TRY(dsrc.alloc_owned((n_tiles + 1) * 4));
+    SL_HIP(hipMemcpyAsync(dsrc.p, src.data(), (n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
+    const uint32_t fg = (uint32_t)((n_tiles + 3) / 4);
+    hipLaunchKernelGGL((sl_pw_fill_kernel<false>), dim3(fg), dim3(256), 0, st, n_tiles, rpw, dsrc.as<uint32_t>(), (const uint32_t *)nullptr, perm.as<uint32_t>(),
+                       rowl.as<uint16_t>(), d_col_idx, d_values, pads.as<uint32_t>(), (uint32_t *)nullptr, (double *)nullptr);
+    SL_HIP(hipMemcpyAsync(hpads.data(), pads.p, n_tiles * 4, hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    uint64_t chunks = 0;
+    for (uint64_t t = 0; t < n_tiles; ++t) { dst[t] = (uint32_t)chunks; chunks += ((uint64_t)count[t] + hpads[t] + SL_PANEL_CHUNK - 1) / SL_PANEL_CHUNK; }
+    dst[n_tiles] = (uint32_t)chunks;
+    if (chunks * 256 > 0xfffffff0ull) return SL_OK;
+    SL_HIP(hipMalloc(&m->d_pw_tile_ptr, (n_tiles + 1) * 4));
+    SL_HIP(hipMalloc(&m->d_pw_idx, (chunks ? chunks : 1) * 256 * 4));
+    SL_HIP(hipMalloc(&m->d_pw_val, (chunks ? chunks : 1) * 256 * 8));
+    SL_HIP(hipMemcpyAsync(m->d_pw_tile_ptr, dst.data(), (n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((sl_pw_fill_kernel<true>), dim3(fg), dim3(256), 0, st, n_tiles, rpw, dsrc.as<uint32_t>(), m->d_pw_tile_ptr, perm.as<uint32_t>(),
+                       rowl.as<uint16_t>(), d_col_idx, d_values, (uint32_t *)nullptr, m->d_pw_idx, m->d_pw_val);
+    SL_HIP(hipGetLastError());
+    SL_HIP(hipStreamSynchronize(st));
+    m->n_pw_tiles = n_tiles; m->pw_chunks = chunks; m->pw_rpw = rpw;
+    // a wave moves through about n_panels * 256 / (entries per tile) panels per chunk of its stream; two chunks of lead keep its
+    // pipeline full (n = 10^7 x 16: 4 panels, measured 1 / 2 / 4 panels: 1.36 / 1.35 / 1.28 ms), more than the L2 holds helps nobody
+    m->pw_slack = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(4, (2 * 256 * n_panels * n_tiles + total - 1) / total));
+    m->pw_blocks = (uint32_t)std::min<uint64_t>(cus, (n_tiles + SL_PW_WAVES - 1) / SL_PW_WAVES);
+    m->device_bytes += chunks * 256 * 12 + (n_tiles + 1) * 4;
     return SL_OK;
 }
 
@@ -451,7 +593,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     // 2b. column panels: where neither the LDS window (bandwidth) nor the L2 (vector of a few MB) can serve the gathers
     {
         static const int env_panels = [] { const char *e = getenv("SL_COLUMN_PANELS"); return e && *e ? atoi(e) : -1; }();   // 0 never, 1 always
-        const bool forced = (m->flags & SL_MATRIX_COLUMN_PANELS) || env_panels == 1;
+        const bool forced = (m->flags & SL_MATRIX_COLUMN_PANELS) || env_panels == 1 || env_panels == 3;
         const bool refused = (m->flags & SL_MATRIX_NO_COLUMN_PANELS) || env_panels == 0;
         // pays where most entries sit megabytes of vector away from their row (uniformly random columns) and the vector is far larger
         // than the L2 — measured at n = 10^7 x 16: 2.73 -> 1.71 ms; band structures, however wide, are served better by the general
@@ -460,7 +602,9 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         const uint64_t n_tiles = (n + SL_PANEL_TILE - 1) / SL_PANEL_TILE;
         const uint64_t n_panels = (m->n_cols + (1ull << SL_PANEL_COL_BITS) - 1) >> SL_PANEL_COL_BITS;
         if (!refused && (forced || pays) && nnz && nnz < 0x7fffffffull && n_tiles * n_panels < 0xfffffff0ull) {
-            sl_status ps = sl_build_column_panels(m, d_row_ptr, d_col_idx, d_values, n_tiles, (uint32_t)n_panels, st);
+            // balanced matrices of some size: persistent paced blocks (SL_COLUMN_PANELS=3 forces the dynamic tiles instead)
+            sl_status ps = env_panels == 3 ? SL_OK : sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st);
+            if (ps == SL_OK && !m->d_pw_idx) ps = sl_build_column_panels(m, d_row_ptr, d_col_idx, d_values, n_tiles, (uint32_t)n_panels, st);
             if (ps != SL_OK) return ps;
         }
     }

@@ -125,10 +125,81 @@ def test_seven_million_short_rows_many_thin_panels(gpu):
     ci, va = cols.astype(np.uint32), vals
     m = S.SparseMatrix.from_csr(rp, ci, va, n, n, column_panels=True)
     info = m.info()
-    assert info.column_panels == 1 and info.n_long_rows >= 40
+    assert info.column_panels == 2 and info.n_long_rows >= 40          # balanced tiles at this size: the paced persistent layout
     x = np.cos(np.arange(n) * 0.001) + 0.2
     assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
     b = 1.0 + (np.arange(n) % 11) * 0.1
     o = O.neumann_solve(rp, ci, va, b, tolerance=1e-9)
     g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-9))
     assert g.converged and g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
+
+
+# ---- the paced layout (sl_pw_kernel): persistent 16-wave blocks, tiles dealt in rounds -----------------------------------------
+@pytest.fixture
+def paced(monkeypatch):
+    """build the paced layout whatever the size / balance, on a pretended 2-CU device: 32 waves, so small systems take several rounds"""
+    monkeypatch.setenv("SL_PW_FORCE", "1")
+    monkeypatch.setenv("SL_PW_CUS", "2")
+
+
+@pytest.mark.parametrize("n,k", [(100_000, 16), (70_001, 5), (3000, 8)])
+def test_paced_uniform_columns_all_epilogues(gpu, paced, n, k):
+    rp, ci, va, b = G.sdd_rows(n, k, seed=9)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True, column_panels=True)
+    assert m.info().column_panels == 2
+    x = np.cos(np.arange(n) * 0.13) - 0.4
+    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
+    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-11)
+    g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-11))
+    assert g.converged and g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
+    np.testing.assert_allclose(g.term_norms, o["term_norms"], rtol=1e-10)
+    assert abs(g.residual_norm - o["residual_norm"]) <= 1e-10 * max(1.0, o["residual_norm"])
+    bs = b * (np.arange(n) % 3 == 0)
+    q = O.push_sync_solve(rp, ci, va, bs, theta=1e-8, log_cap=1 << 22)
+    p = S.PushSolver(theta=1e-8, dense_switch=1e-9).solve(m, bs, log_frontier=1 << 22)       # dense rounds: the PUSH epilogue
+    assert p["converged"] and p["rounds"] == q["rounds"] and p["dense_rounds"] > 0
+    assert (p["frontier_log"] == q["frontier_log"]).all() and _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])
+
+
+def test_paced_ragged_rows_hubs_duplicates(gpu, paced):
+    """unequal tiles (the pace then waits for the slowest wave), runs of one row inside a panel (duplicates; rows of up to 30 entries
+    over a 9000-column vector = ONE panel: every row is a run, many longer than four), long rows left to the long-row kernel"""
+    rp, ci, va = _ragged_system()
+    n = rp.size - 1
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, column_panels=True)
+    assert m.info().column_panels == 2 and m.info().n_long_rows > 0
+    x = np.sin(np.arange(n) * 0.7) - 0.2
+    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
+    b = 1.0 + (np.arange(n) % 7) * 0.5
+    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-10)
+    g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-10))
+    assert g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
+
+
+def test_paced_thin_panels_and_empty_super_panels(gpu, paced):
+    """5000 rows x 9 million columns, one to three entries per row, columns only in [0, 10^6) and [7 * 10^6, 9 * 10^6): 64 consecutive
+    entries of a tile's stream span many panels (the same row twice, far apart), and whole super-panels of 2^20 columns are empty —
+    the stream bridges them with padding entries"""
+    rng = np.random.default_rng(21)
+    rows, cols = 5000, 9_000_000
+    cnt = rng.integers(1, 4, size=rows)
+    rp = np.zeros(rows + 1, dtype=np.uint32)
+    rp[1:] = np.cumsum(cnt)
+    pool = np.concatenate([np.arange(0, 1_000_000), np.arange(7_000_000, 9_000_000)])
+    ci = np.concatenate([np.sort(rng.choice(pool, size=int(c), replace=False)) for c in cnt]).astype(np.uint32)
+    va = rng.uniform(-1.0, 1.0, size=ci.size)
+    m = S.SparseMatrix.from_csr(rp, ci, va, rows, cols, column_panels=True)
+    assert m.info().column_panels == 2
+    x = rng.uniform(-1.0, 1.0, size=cols)
+    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
+
+
+def test_paced_row_slice(gpu, paced):
+    n, k, lo, hi = 120_000, 12, 33_333, 91_777
+    rp, ci, va, b = G.sdd_rows(n, k, seed=6)
+    prp = (rp[lo:hi + 1].astype(np.int64) - int(rp[lo])).astype(np.uint32)
+    pci, pva = ci[rp[lo]:rp[hi]], va[rp[lo]:rp[hi]]
+    m = S.SparseMatrix.from_csr(prp, pci, pva, hi - lo, n, row_offset=lo, column_panels=True)
+    assert m.info().column_panels == 2
+    x = np.cos(np.arange(n) * 0.05)
+    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x)[lo:hi])

@@ -15,7 +15,7 @@ import sys
 from pathlib import Path
 
 
-STEP_KERNELS = ("sl_band_kernel", "sl_rows_kernel", "sl_panel", "sl_mpass")
+STEP_KERNELS = ("sl_band_kernel", "sl_rows_kernel", "sl_panel_kernel", "sl_pw_kernel", "sl_mpass_kernel")
 
 
 def q(db, sql):
@@ -37,8 +37,8 @@ def main():
         lines.append(f"{name[:92]:<92} {calls:>6} {tot / 1e3:>10.3f} {avg:>10.2f} {pct:>7.2f}")
     # steady-state average of the dominant kernel: drop the first launches (cold caches / clocks)
     k = q(src / "stats" / "stats_results.db",
-          "select name, duration from kernels where name like '%sl_band_kernel%' or name like '%sl_rows_kernel%' or name like '%sl_panel%' "
-          "or name like '%sl_mpass%' order by start")
+          "select name, duration from kernels where name like '%sl_band_kernel%' or name like '%sl_rows_kernel%' or name like '%sl_panel_kernel%' "
+          "or name like '%sl_pw_kernel%' or name like '%sl_mpass_kernel%' order by start")
     by = {}
     for name, d in k:
         by.setdefault(name, []).append(d)
