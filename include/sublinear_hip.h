@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 1
+#define SL_ABI_VERSION 2
 
 /* ---- status codes: 1:1 with SolverError variants (src/error.rs:16-140) ---------- */
 typedef enum {
@@ -221,8 +221,9 @@ typedef struct {
     int32_t order;           /* sl_order */
     int32_t mem;             /* sl_mem of b / x / r */
     double dense_switch;     /* frontier fraction above which a round runs the dense kernel (default 1/16) */
-    int32_t sparse_rhs;      /* != 0: b is given as (b_idx, b_val) pairs — see sl_push_solve_sparse */
-    int32_t reserved;
+    const double *theta_rows;/* NULL, or n per-row thresholds (memory space `mem`) used INSTEAD of theta: row i enters a frontier when
+                              * |r_i dinv_i| >= theta_rows[i] — the degree-scaled admission / skip rule of the ACL push,
+                              * residual[u] >= epsilon * max(out_degree(u), 1) (forward_push.rs:93-99, graph/mod.rs:171-212) */
 } sl_push_options;
 void sl_push_options_default(sl_push_options *o);
 
@@ -236,6 +237,30 @@ typedef struct {
     int32_t converged;       /* frontier became empty */
     int32_t reserved;
 } sl_push_result;
+
+/* ---- a14 in the reference's own visiting order: TS solveForwardPush (src/core/solver.ts:437-522) ----
+ * Gauss-Southwell: every step pushes the FIRST index of largest |r_i| (r = b - A x, x0 = 0), p = r_i / a_ii, x_i += p, r_i = 0,
+ * r_j -= a_ji p over column i; stops when max |r_i| < epsilon; `iterations` = pushes.  Sequential across pushes by definition
+ * (the |F| = 1 member of the push family): this entry point is for order-exact parity with the reference — push sequence,
+ * iteration count, solution bits — the throughput path is sl_push_solve.  Needs SL_MATRIX_WITH_TRANSPOSE.
+ * Status: SL_CONVERGENCE_FAILURE after max_iterations pushes (solver.ts:509-515; x_out / r_out / result still filled),
+ * SL_NUMERICAL_INSTABILITY for |a_ii| < 1e-15 (:471-473).  push_log (may be NULL): the pushed index of every step, up to log_cap. */
+typedef struct {
+    double epsilon;          /* SolverConfig.epsilon        src/core/types.ts:28-46 */
+    uint64_t max_iterations; /* SolverConfig.maxIterations  */
+    int32_t mem;             /* sl_mem of b / x_out / r_out */
+    int32_t reserved;
+} sl_southwell_options;
+void sl_southwell_options_default(sl_southwell_options *o);
+typedef struct {
+    uint64_t iterations;     /* pushes = SolverResult.iterations of the reference */
+    double residual_norm;    /* l2(r) after the last push; +inf before the first (solver.ts:446) */
+    double device_time_ms;
+    int32_t converged;
+    int32_t reserved;
+} sl_southwell_result;
+sl_status sl_forward_push_southwell(const sl_matrix *m, const double *b, const sl_southwell_options *opts, double *x_out, double *r_out,
+                                    uint32_t *push_log, uint64_t log_cap, sl_southwell_result *result);
 
 /* x: in = x0 / out = solution; r_out: residual at exit (may be NULL).
  * frontier_log (may be NULL): per round, |F| followed by the ascending indices, up to

@@ -34,7 +34,7 @@ class NeumannResult(C.Structure):
 
 
 class PushOpts(C.Structure):
-    _fields_ = [("theta", f64), ("max_rounds", u64), ("order", i32), ("pad", i32)]
+    _fields_ = [("theta", f64), ("max_rounds", u64), ("order", i32), ("pad", i32), ("theta_rows", C.c_void_p)]
 
 
 class PushResult(C.Structure):
@@ -221,12 +221,13 @@ def neumann_steps(rp, ci, va, dinv, t, x, steps, order=ORDER_SEQ, threads=1, fas
                                C.c_int(order), C.c_int(threads))
 
 
-def push_sync_solve(rp, ci, va, b, theta, max_rounds=100000, order=ORDER_SEQ, x0=None, log_cap=0):
+def push_sync_solve(rp, ci, va, b, theta, max_rounds=100000, order=ORDER_SEQ, x0=None, log_cap=0, theta_rows=None):
     rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
     n = rp.size - 1
     x = np.zeros(n) if x0 is None else _f(x0).copy()
     r = np.zeros(n)
-    o = PushOpts(theta, max_rounds, order, 0)
+    th = None if theta_rows is None else _f(theta_rows)
+    o = PushOpts(theta, max_rounds, order, 0, None if th is None else th.ctypes.data)
     res = PushResult()
     log = np.zeros(max(log_cap, 1), dtype=np.uint32)
     words = u64(0)

@@ -438,7 +438,7 @@ int orc_push_sync_solve(uint64_t n, const uint32_t *row_ptr, const uint32_t *col
         if (flog && w < fcap) ++w;
         for (uint64_t i = 0; i < n; ++i) {
             double p = r[i] * dinv[i];
-            if (fabs(p) >= o->theta) {
+            if (fabs(p) >= (o->theta_rows ? o->theta_rows[i] : o->theta)) {
                 inF[i] = 1; delta[i] = p; ++nf;
                 if (flog && w < fcap) flog[w++] = (uint32_t)i;
             } else { inF[i] = 0; delta[i] = 0.0; }

@@ -118,6 +118,7 @@ typedef struct {
     uint64_t max_rounds;
     int32_t order;
     int32_t pad;
+    const double *theta_rows; /* NULL, or one threshold per row used instead of theta (degree-scaled rule, forward_push.rs:93-99) */
 } orc_push_opts;
 typedef struct {
     uint64_t rounds;

@@ -49,12 +49,20 @@ class NeumannResult(C.Structure):
 
 class PushOptions(C.Structure):
     _fields_ = [("theta", f64), ("max_rounds", u64), ("order", i32), ("mem", i32), ("dense_switch", f64),
-                ("sparse_rhs", i32), ("reserved", i32)]
+                ("theta_rows", C.c_void_p)]
 
 
 class PushResult(C.Structure):
     _fields_ = [("rounds", u64), ("pushes", u64), ("rows_touched", u64), ("dense_rounds", u64),
                 ("residual_norm", f64), ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
+
+
+class SouthwellOptions(C.Structure):
+    _fields_ = [("epsilon", f64), ("max_iterations", u64), ("mem", i32), ("reserved", i32)]
+
+
+class SouthwellResult(C.Structure):
+    _fields_ = [("iterations", u64), ("residual_norm", f64), ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
 
 
 class EstimateResult(C.Structure):
@@ -107,6 +115,8 @@ SIGNATURES = {
     "sl_push_options_default": (None, [C.POINTER(PushOptions)]),
     "sl_push_solve": (C.c_int, [vp, vp, C.POINTER(PushOptions), vp, vp, vp, u64, C.POINTER(u64),
                                 C.POINTER(PushResult)]),
+    "sl_southwell_options_default": (None, [C.POINTER(SouthwellOptions)]),
+    "sl_forward_push_southwell": (C.c_int, [vp, vp, C.POINTER(SouthwellOptions), vp, vp, vp, u64, C.POINTER(SouthwellResult)]),
     "sl_estimate_entry": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
     "sl_synth_sdd_device": (C.c_int, [u64, u32, u64, u64, u64, u64, vp, vp, vp, vp]),
     "sl_estimate_entry_random_walk": (C.c_int, [vp, vp, C.c_int, u64, f64, u32, u64, vp, C.POINTER(WalkResult)]),
@@ -173,7 +183,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.sl_abi_version() != 1:
+    if lib.sl_abi_version() != 2:
         raise ImportError("libsublinear_hip ABI version mismatch")
     _lib = lib
     return lib

@@ -36,12 +36,12 @@ struct op_view {
 // tile = 2048 consecutive indices per 256-thread block; wave w owns 512 of them, 8 passes of 64.
 #define SL_CTILE 2048
 
-__device__ __forceinline__ bool sl_pred(const double *delta, double theta, uint64_t i)
+__device__ __forceinline__ bool sl_pred(const double *delta, sl_theta theta, uint64_t i)
 {
-    return theta <= 0.0 ? true : (delta[i] != 0.0);
+    return theta.everything() ? true : (delta[i] != 0.0);
 }
 
-__global__ __launch_bounds__(256) void sl_compact_count_kernel(uint64_t n, const double *delta, double theta, uint32_t *block_count)
+__global__ __launch_bounds__(256) void sl_compact_count_kernel(uint64_t n, const double *delta, sl_theta theta, uint32_t *block_count)
 {
     __shared__ uint32_t wsum[4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void sl_scan_kernel(uint32_t nb, const uint32
     for (uint32_t k = lo; k < hi; ++k) { const uint32_t v = in[k]; out[k] = run; run += v; }
 }
 
-__global__ __launch_bounds__(256) void sl_compact_write_kernel(uint64_t n, const double *delta, double theta,
+__global__ __launch_bounds__(256) void sl_compact_write_kernel(uint64_t n, const double *delta, sl_theta theta,
                                                                const uint32_t *block_off, uint32_t *list)
 {
     __shared__ uint32_t wsum[4];
@@ -108,13 +108,13 @@ __global__ __launch_bounds__(256) void sl_compact_write_kernel(uint64_t n, const
 }
 
 // ---- dense select (round 0): delta_i = r_i*dinv_i if |.| >= theta else 0 --------------------
-__global__ __launch_bounds__(256) void sl_select_kernel(uint64_t n, const double *r, const double *dinv, double theta,
+__global__ __launch_bounds__(256) void sl_select_kernel(uint64_t n, const double *r, const double *dinv, sl_theta theta,
                                                         double *delta)
 {
     const uint64_t stride = (uint64_t)gridDim.x * 256;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const double p = DMUL(r[i], dinv[i]);
-        delta[i] = (fabs(p) >= theta) ? p : 0.0;
+        delta[i] = (fabs(p) >= theta.at(i)) ? p : 0.0;
     }
 }
 
@@ -161,7 +161,7 @@ struct sl_round_io {
     sl_hit *recs;
     uint32_t *head, *cand, *flag, *touched, *heavy;
     uint2 *long_cols;                          // (column, piece) work items of the running round
-    double theta;
+    sl_theta theta;
     int order;
     uint32_t dense_threshold, round_limit;     // a batch runs rounds while c->rounds < round_limit
     unsigned long long hit_limit;
@@ -392,7 +392,7 @@ struct sl_row_acc {
 
 // (2) candidate rows: r_i -= (B delta_old)_i ; next frontier from |r_i dinv_i| >= theta.  Appends to the next frontier
 //     (and the count of column entries under it) are reserved per wave.
-__device__ __forceinline__ void sl_pull_finish_wave(bool live, uint32_t i, double acc, double r_old, double dinv_i, double theta, uint32_t lane,
+__device__ __forceinline__ void sl_pull_finish_wave(bool live, uint32_t i, double acc, double r_old, double dinv_i, sl_theta theta, uint32_t lane,
                                                     const uint32_t *tptr, double *r, double *delta_new, uint32_t *next, sl_push_ctl *c)
 {
     double p = 0.0;
@@ -401,7 +401,7 @@ __device__ __forceinline__ void sl_pull_finish_wave(bool live, uint32_t i, doubl
         r[i] = rn;
         p = DMUL(rn, dinv_i);
     }
-    const bool pass = live && fabs(p) >= theta;
+    const bool pass = live && fabs(p) >= theta.at(i);
     const unsigned long long m = __ballot(pass);
     if (!m) return;
     unsigned long long colw = pass ? (unsigned long long)(tptr[i + 1] - tptr[i]) : 0ull;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void sl_batch_end_kernel(const sl_round_io *io
 // generic (any operator given as CSR) dense round, one thread per row — used by estimate_entry
 // when the frontier of A^T grows past the dense switch (A^T has no row-slice layout).
 __global__ __launch_bounds__(256) void sl_dense_csr_round_kernel(uint64_t n, op_view op, const double *delta_old, const double *dinv,
-                                                                 double theta, int order, double *r, double *x, double *delta_new)
+                                                                 sl_theta theta, int order, double *r, double *x, double *delta_new)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void sl_dense_csr_round_kernel(uint64_t n, op_
     const double rn = DSUB(r[i], acc);
     r[i] = rn;
     const double p = DMUL(rn, dinv[i]);
-    delta_new[i] = (fabs(p) >= theta) ? p : 0.0;
+    delta_new[i] = (fabs(p) >= theta.at(i)) ? p : 0.0;
 }
 
 namespace {
@@ -608,7 +608,7 @@ struct push_state {
     sl_round_io *io_dev = nullptr;              // argument block of the running batch
 };
 
-sl_status compact(push_state &ps, const double *delta, double theta, uint32_t *list, uint32_t *h_count, hipStream_t s)
+sl_status compact(push_state &ps, const double *delta, sl_theta theta, uint32_t *list, uint32_t *h_count, hipStream_t s)
 {
     if (ps.n == 0) { *h_count = 0; return SL_OK; }
     hipLaunchKernelGGL(sl_compact_count_kernel, dim3(ps.nblocks), dim3(256), 0, s, ps.n, delta, theta, ps.block_count);
@@ -652,7 +652,7 @@ struct round_stats { uint64_t rounds = 0, pushes = 0, rows_touched = 0, dense_ro
 // The round loop.  `m` != null enables the row-slice dense kernel (operator = A itself).
 // preseeded: the caller has already written the round-0 frontier (list in frontier[0], values in delta[0], delta[1]
 // all zero) and passes its size — a query session seeds one row without touching the other n - 1.
-sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t max_rounds, int order, double dense_switch,
+sl_status run_push(push_state &ps, const sl_matrix *m, sl_theta theta, uint64_t max_rounds, int order, double dense_switch,
                    push_log &plog, round_stats &rs, float *device_ms, bool preseeded = false, uint32_t nf0 = 0,
                    const std::function<void(hipStream_t, bool, uint32_t)> *tail = nullptr)
 {
@@ -706,7 +706,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, double theta, uint64_t ma
             uint32_t nf_next = 0;
             if (m) {
                 sl_row_args a = sl_matrix_row_args(m);
-                a.gather = ps.delta[cur]; a.dinv = ps.dinv; a.out = ps.delta[1 - cur]; a.x = ps.x; a.r = ps.r; a.theta = theta;
+                a.gather = ps.delta[cur]; a.dinv = ps.dinv; a.out = ps.delta[1 - cur]; a.x = ps.x; a.r = ps.r; a.theta = theta.s; a.theta_rows = theta.rows;
                 a.partials = scr; a.partials_slack = 4096; a.result = resbuf.as<double>();
                 st = sl_launch_rows(a, (sl_order)order, SL_EPI_PUSH, s);
                 if (st != SL_OK) break;
@@ -861,7 +861,16 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
     plog.log = frontier_log; plog.cap = frontier_cap;
     round_stats rs;
     float ms = 0.f;
-    sl_status st = run_push(ps, m, o->theta, o->max_rounds, o->order, o->dense_switch > 0 ? o->dense_switch : 1.0 / 16.0, plog, rs, &ms);
+    sl_theta th{o->theta, nullptr};
+    DevBuf thbuf;
+    if (o->theta_rows) {
+        if (o->mem == SL_MEM_HOST) {
+            SL_TRY(thbuf.alloc(n * 8));
+            SL_HIP(hipMemcpyAsync(thbuf.p, o->theta_rows, n * 8, hipMemcpyHostToDevice, s));
+            th.rows = thbuf.as<double>();
+        } else th.rows = o->theta_rows;
+    }
+    sl_status st = run_push(ps, m, th, o->max_rounds, o->order, o->dense_switch > 0 ? o->dense_switch : 1.0 / 16.0, plog, rs, &ms);
     if (st != SL_OK) return st;
     res->rounds = rs.rounds; res->pushes = rs.pushes; res->rows_touched = rs.rows_touched; res->dense_rounds = rs.dense_rounds;
     res->converged = rs.converged ? 1 : 0; res->device_time_ms = ms;
@@ -1128,7 +1137,7 @@ sl_status sl_query_session_estimate(sl_query_session *q, uint64_t row, double th
         }
         if (e != hipSuccess) tail_err = e;
     };
-    sl_status st = run_push(ps, q->given_is_transpose ? q->m : nullptr, theta, max_rounds, SL_ORDER_CSR_SEQUENTIAL, q->dense_switch, plog, rs, &ms,
+    sl_status st = run_push(ps, q->given_is_transpose ? q->m : nullptr, sl_theta{theta, nullptr}, max_rounds, SL_ORDER_CSR_SEQUENTIAL, q->dense_switch, plog, rs, &ms,
                             true, (uint32_t)in_frontier, &tail);
     double h[2] = {0.0, 0.0};
     if (st == SL_OK && !ps.flooded) {

@@ -227,6 +227,15 @@ struct sl_solve_ctl {
 };
 enum { SL_JUDGE_NONE = 0, SL_JUDGE_LT = 1, SL_JUDGE_LE_OR_NONFINITE = 2 };
 
+// Frontier threshold of the push: one value for all rows, or (rows != null) one per row — the degree-scaled admission rule of the
+// ACL push, r[u] >= epsilon * max(deg_u, 1) (forward_push.rs:93-99, graph/mod.rs:171-212), as a vector theta_u
+struct sl_theta {
+    double s;
+    const double *rows;
+    __host__ __device__ double at(uint64_t i) const { return rows ? rows[i] : s; }
+    __host__ __device__ bool everything() const { return !rows && s <= 0.0; }      // theta <= 0: every row is in every frontier
+};
+
 struct sl_row_args {
     // matrix
     const uint32_t *slice_ptr, *row_len, *cols;
@@ -256,6 +265,7 @@ struct sl_row_args {
     double *x;            // NEUMANN / PUSH: x in/out
     double *r;            // PUSH: r in/out
     double theta;         // PUSH
+    const double *theta_rows; // PUSH: per-row thresholds (null: `theta` for every row)
     double *partials;     // per-block partial sums (norm^2); PUSH: also counts at partials + nblocks (as u64)
     uint32_t partials_slack; // doubles available behind the two partial sets (>= 512 enables the two-stage reduction of very many partials)
     double *result;       // device scalar(s): [0] = sum of squares, PUSH: [1] = frontier count (as double bits u64)

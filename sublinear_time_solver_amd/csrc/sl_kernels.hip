@@ -140,7 +140,7 @@ __device__ __forceinline__ void sl_row_epilogue(const sl_row_args &a, uint64_t i
         const double rn = DSUB(e_t, sum);
         a.r[i] = rn;
         const double p = DMUL(rn, e_d);
-        const bool f = fabs(p) >= a.theta;
+        const bool f = fabs(p) >= (a.theta_rows ? a.theta_rows[i] : a.theta);
         a.out[i] = f ? p : 0.0;
         part0 = DADD(part0, DMUL(rn, rn));
         part1 += f ? 1.0 : 0.0;

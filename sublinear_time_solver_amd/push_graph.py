@@ -13,8 +13,11 @@ synchronous form of the same push: personalised PageRank pi_s = alpha e_s^T (I -
 of A x = alpha e_s with A = I - (1-alpha) P^T, and the reference's (estimate, residual) pair corresponds to
 (x, r / alpha) of the residual push r = b - A x: `estimate[u] += alpha r[u]; r[v] += (1-alpha) r[u] w_uv / deg_u`
 is exactly one Gauss-Southwell push on that system.  Same fixed point, same invariants (non-negativity, mass
-conservation sum(estimate) + sum(residual) = 1), different visiting order; the stop rule is the absolute
-threshold r_u >= epsilon (the queue's degree scaling of forward_push.rs:96-99 only orders the sequential visits).
+conservation sum(estimate) + sum(residual) = 1), different visiting order.  The admission / skip rule is the spec's:
+node u is pushed while residual[u] >= epsilon * max(out_degree(u), 1) (forward_push.rs:93-99; the queue admits
+residual / degree >= queue_threshold = 1e-8 << epsilon, graph/mod.rs:171-181, so the skip rule is the one that binds) —
+passed to the device as one threshold per row (sl_push_options.theta_rows); at exit every node is below ITS threshold,
+as after the reference's loop.  ForwardPushConfig.degree_scaled = False gives the absolute threshold epsilon instead.
 Dangling nodes keep their mass on themselves (forward_push.rs:210-215): a self loop of weight 1.
 """
 from __future__ import annotations
@@ -34,6 +37,7 @@ class ForwardPushConfig:
     max_pushes: int = 1_000_000
     queue_threshold: float = 1e-8        # kept for signature parity; the synchronous form has no queue
     adaptive_threshold: bool = True
+    degree_scaled: bool = True           # skip rule residual[u] < epsilon * max(deg_u, 1) (forward_push.rs:96-99); False: residual[u] < epsilon
 
 
 BackwardPushConfig = ForwardPushConfig
@@ -125,7 +129,11 @@ class _PushBase:
         b = np.zeros(n)
         np.add.at(b, valid, c.alpha / len(seeds))              # unit mass split over the sources, :131-137
         m = self.graph.system(c.alpha, self.backward)
-        out = PushSolver(theta=c.alpha * c.epsilon, max_rounds=max(1, c.max_pushes)).solve(m, b)
+        # admission / skip rule of the spec (forward_push.rs:93-99, graph/mod.rs:171-212): node u is pushed while
+        # residual[u] >= epsilon * max(degree(u), 1); the device residual is alpha x the spec's, so theta_u = alpha * epsilon * max(deg_u, 1)
+        deg = self.graph.reverse_degrees if self.backward else self.graph.degrees
+        theta_rows = c.alpha * c.epsilon * np.maximum(deg, 1.0) if getattr(c, "degree_scaled", True) else None
+        out = PushSolver(theta=c.alpha * c.epsilon, max_rounds=max(1, c.max_pushes), theta_rows=theta_rows).solve(m, b)
         residual = out["residual"] / c.alpha
         est = out["solution"]
         return PushResult(est, residual, out["pushes"], int(np.count_nonzero(est)), float(np.linalg.norm(residual)))

@@ -274,6 +274,7 @@ class PushSolver:
     max_rounds: int = 10_000
     order: int = L.SL_ORDER_CSR_SEQUENTIAL
     dense_switch: float = 1.0 / 16.0
+    theta_rows: object = None      # optional per-row thresholds (used instead of theta): the degree-scaled rule of forward_push.rs:93-99
 
     def solve(self, matrix: SparseMatrix, b, x0=None, log_frontier: int = 0):
         lib = L.load()
@@ -284,6 +285,12 @@ class PushSolver:
         o = L.PushOptions()
         lib.sl_push_options_default(C.byref(o))
         o.theta, o.max_rounds, o.order, o.mem, o.dense_switch = self.theta, self.max_rounds, self.order, L.SL_MEM_HOST, self.dense_switch
+        th = None
+        if self.theta_rows is not None:
+            th = _f64(self.theta_rows)
+            if th.size != n:
+                raise SolverError(5, f"theta_rows: expected {n}, actual {th.size}")
+            o.theta_rows = th.ctypes.data
         x = np.zeros(n, dtype=np.float64) if x0 is None else _f64(x0).copy()
         r = np.empty(n, dtype=np.float64)
         log = np.zeros(max(log_frontier, 1), dtype=np.uint32)
@@ -297,6 +304,38 @@ class PushSolver:
                "device_time_ms": res.device_time_ms}
         if log_frontier:
             out["frontier_log"] = log[: int(words.value)].copy()
+        return out
+
+
+@dataclass
+class GaussSouthwellSolver:
+    """TS solveForwardPush (src/core/solver.ts:437-522) in the reference's own visiting order: one push per step at the first
+    index of largest |r_i|.  Sequential by definition — for order-exact parity (push sequence, iteration count, solution bits);
+    PushSolver is the throughput path.  Raises SolverError(ConvergenceFailure) after max_iterations pushes like the reference;
+    `on_failure="return"` hands back the partial state instead."""
+    epsilon: float = 1e-6
+    max_iterations: int = 1000
+
+    def solve(self, matrix: SparseMatrix, b, log_pushes: bool = False, on_failure: str = "raise"):
+        lib = L.load()
+        b = _f64(b)
+        n = matrix.rows()
+        if b.size != n:
+            raise SolverError(5, f"expected {n}, actual {b.size}")
+        o = L.SouthwellOptions()
+        lib.sl_southwell_options_default(C.byref(o))
+        o.epsilon, o.max_iterations, o.mem = self.epsilon, self.max_iterations, L.SL_MEM_HOST
+        x, r = np.zeros(n), np.zeros(n)
+        cap = min(self.max_iterations, 1 << 26) if log_pushes else 0
+        log = np.zeros(max(cap, 1), dtype=np.uint32)
+        res = L.SouthwellResult()
+        st = lib.sl_forward_push_southwell(matrix._h, L.ptr(b), C.byref(o), L.ptr(x), L.ptr(r), L.ptr(log) if cap else None, cap, C.byref(res))
+        if st != 0 and not (st == 3 and on_failure == "return"):
+            L.check(st)
+        out = {"solution": x, "residual_vector": r, "iterations": int(res.iterations), "residual": res.residual_norm,
+               "converged": bool(res.converged), "device_time_ms": res.device_time_ms}
+        if log_pushes:
+            out["push_log"] = log[: min(cap, int(res.iterations))].copy()
         return out
 
 
@@ -388,10 +427,15 @@ class SublinearSolver:
 
     `neumann` runs the exact series (the TS sign bug of solver.ts:157-163 is NOT reproduced,
     SURVEY.md §0.3); `forward-push` / `backward-push` / `bidirectional` (aliases in the reference,
-    solver.ts:527-545) run the thresholded push with theta = epsilon."""
+    solver.ts:527-545) run the push: `push_order="reference"` = solveForwardPush's own order, one Gauss-Southwell push per
+    iteration (GaussSouthwellSolver; `iterations` = pushes, as the reference reports them), `"synchronous"` = the data-parallel
+    thresholded push with theta = epsilon (`iterations` = rounds), `"auto"` (default) = reference order up to 4096 rows."""
 
     def __init__(self, method: str = "neumann", epsilon: float = 1e-6, max_iterations: int = 1000,
-                 timeout: Optional[float] = None, seed: Optional[int] = None):
+                 timeout: Optional[float] = None, seed: Optional[int] = None, push_order: str = "auto"):
+        if push_order not in ("auto", "reference", "synchronous"):
+            raise SolverError(4, f"Unknown push_order: {push_order}")
+        self.push_order = push_order
         if method not in ("neumann", "random-walk", "forward-push", "backward-push", "bidirectional"):
             raise SolverError(4, f"Unknown method: {method}")
         if not (epsilon > 0):
@@ -412,6 +456,9 @@ class SublinearSolver:
             ns = NeumannSolver(max_terms=self.max_iterations, series_tolerance=self.epsilon)
             r = ns.solve(m, b, SolverOptions(tolerance=self.epsilon, max_iterations=self.max_iterations))
             sol, it, res, conv = r.solution, r.iterations, r.residual_norm, r.converged
+        elif self.push_order == "reference" or (self.push_order == "auto" and m.rows() <= 4096):
+            gs = GaussSouthwellSolver(epsilon=self.epsilon, max_iterations=self.max_iterations).solve(m, b)      # raises ConvergenceFailure like solver.ts:509-515
+            sol, it, res, conv = gs["solution"], gs["iterations"], gs["residual"], True
         else:
             pr = PushSolver(theta=self.epsilon, max_rounds=self.max_iterations).solve(m, b)
             if not pr["converged"]:
