@@ -208,6 +208,26 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
                            const sl_neumann_options *opts, double *x_out, double *term_norms,
                            sl_neumann_result *result);
 
+/* ---- NeumannState as an object: SolverAlgorithm::initialize / update_rhs / extract_solution (solver/mod.rs:223-333) --------
+ * sl_neumann_state_create   = NeumannState::new (neumann.rs:139-249): same checks and errors as sl_neumann_solve; the state owns
+ *                             device copies of b, D^-1, the scaled rhs, the solution and the current term.
+ * sl_neumann_state_run      = the loop of NeumannSolver::solve (neumann.rs:477-555) from the state's current position (iteration
+ *                             count from 0, terms / matvec counters carried by the state); create + run + solution == sl_neumann_solve.
+ * sl_neumann_state_update_rhs = NeumannSolver::update_rhs (neumann.rs:436-462), statement for statement: for every (index, delta)
+ *                             IN LIST ORDER rhs[i] += delta * dinv[i] and solution[i] += the same; then current_term = rhs,
+ *                             terms_computed = 0, series_converged = false.  An index >= n ends the call with
+ *                             SL_INDEX_OUT_OF_BOUNDS: the pairs before it stay applied and the series state is not reset, as in
+ *                             the reference.  (b itself is updated too, so the TRUE residual follows the new right-hand side.)
+ * sl_neumann_state_reset    = SolverState::reset (neumann.rs:367-378).   indices / deltas are HOST arrays. */
+typedef struct sl_neumann_state sl_neumann_state;
+sl_status sl_neumann_state_create(const sl_matrix *m, const double *b, const double *initial_guess, const sl_neumann_options *opts,
+                                  sl_neumann_state **out);
+void sl_neumann_state_destroy(sl_neumann_state *st);
+sl_status sl_neumann_state_update_rhs(sl_neumann_state *st, uint64_t count, const uint64_t *indices, const double *deltas);
+sl_status sl_neumann_state_run(sl_neumann_state *st, double *term_norms, sl_neumann_result *result);
+sl_status sl_neumann_state_solution(const sl_neumann_state *st, double *x_out, sl_mem where);
+sl_status sl_neumann_state_reset(sl_neumann_state *st);
+
 /* ---- (a-P) / a13 / a14: synchronous thresholded residual push ------------------------
  * The data-parallel member of the reference's push family — ForwardPushSolver::push_node
  * (solver/forward_push.rs:179-216) and TS solveForwardPush (src/core/solver.ts:437-522):

@@ -112,6 +112,12 @@ SIGNATURES = {
     "sl_neumann_run_steps": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, u64, C.POINTER(C.c_float)]),
     "sl_neumann_options_default": (None, [C.POINTER(NeumannOptions)]),
     "sl_neumann_solve": (C.c_int, [vp, vp, vp, C.POINTER(NeumannOptions), vp, vp, C.POINTER(NeumannResult)]),
+    "sl_neumann_state_create": (C.c_int, [vp, vp, vp, C.POINTER(NeumannOptions), C.POINTER(vp)]),
+    "sl_neumann_state_destroy": (None, [vp]),
+    "sl_neumann_state_update_rhs": (C.c_int, [vp, u64, vp, vp]),
+    "sl_neumann_state_run": (C.c_int, [vp, vp, C.POINTER(NeumannResult)]),
+    "sl_neumann_state_solution": (C.c_int, [vp, vp, C.c_int]),
+    "sl_neumann_state_reset": (C.c_int, [vp]),
     "sl_push_options_default": (None, [C.POINTER(PushOptions)]),
     "sl_push_solve": (C.c_int, [vp, vp, C.POINTER(PushOptions), vp, vp, vp, u64, C.POINTER(u64),
                                 C.POINTER(PushResult)]),

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <dlfcn.h>
+#include <initializer_list>
 #include <numeric>
 #include <vector>
 
@@ -16,6 +18,45 @@ sl_ctx &sl_context()
     static thread_local sl_ctx ctx;
     return ctx;
 }
+// ---- tracing / logging ------------------------------------------------------------------------
+namespace {
+struct roctx_api {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    roctx_api()
+    {
+        const char *off = getenv("SL_ROCTX");
+        if (off && off[0] == '0') return;
+        for (const char *lib : {"libroctx64.so", "libroctx64.so.4", "librocprofiler-sdk-roctx.so"}) {
+            if (void *h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const roctx_api &roctx() { static const roctx_api api; return api; }     // initialised once, thread-safe (C++11 static)
+}
+void sl_range_push(const char *name) { if (roctx().push) roctx().push(name); sl_log(2, "range > %s", name); }
+void sl_range_pop() { if (roctx().pop) roctx().pop(); }
+int sl_log_level()
+{
+    static const int level = [] { const char *e = getenv("SL_LOG"); return e && *e ? atoi(e) : 0; }();
+    return level;
+}
+void sl_log(int level, const char *fmt, ...)
+{
+    if (level > sl_log_level()) return;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "[sublinear_hip] %s\n", buf);
+}
+
 sl_status sl_fail(sl_status s, const char *fmt, ...)
 {
     char buf[512];
@@ -24,6 +65,7 @@ sl_status sl_fail(sl_status s, const char *fmt, ...)
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     sl_context().last_error = buf;
+    sl_log(1, "status %d: %s", (int)s, buf);
     return s;
 }
 void *sl_scratch(size_t bytes)
@@ -512,59 +554,88 @@ void sl_neumann_options_default(sl_neumann_options *o)
     o->mem = SL_MEM_HOST;
 }
 
-sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *initial_guess,
-                           const sl_neumann_options *o, double *x_out, double *term_norms,
-                           sl_neumann_result *res)
+// ---- NeumannState (neumann.rs:95-249) as an object behind the ABI: initialize / update_rhs / run / extract_solution -----------
+// sl_neumann_solve is create + run + solution on a state that lives for one call (NeumannSolver::solve, neumann.rs:469-555).
+} // extern "C"
+
+struct sl_neumann_state {
+    const sl_matrix *m = nullptr;
+    sl_neumann_options o{};
+    uint64_t n = 0;
+    int device = 0;
+    DevBuf b, dinv, rhs, x, ta, tb, scal, ctlbuf;      // b: the state's own device copy of the right-hand side (update_rhs changes it)
+    bool owned = false;                                // true: the vectors are allocations of their own (a state that outlives the call), not pool loans
+    double *t_cur = nullptr, *t_nxt = nullptr;
+    double resn = INFINITY, tn = 0.0;
+    bool series_conv = false;
+    uint64_t terms = 0, matvec = 0, step_launches = 0, resid_launches = 0;
+};
+
+namespace {
+
+bool state_converged(const sl_neumann_state &st)      // is_converged, neumann.rs:422-430
 {
-    SL_ABI_BEGIN
-    if (!m || !b || !o || !x_out || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
-    memset(res, 0, sizeof(*res));
-    res->residual_norm = INFINITY;
-    res->error_bound = -1.0;
-    const auto wall0 = std::chrono::steady_clock::now();
-    // NeumannState::new, neumann.rs:139-249 — order of checks preserved
+    return (st.resn <= st.o.tolerance) || (st.series_conv && !(st.terms >= st.o.max_terms));
+}
+
+// NeumannState::new, neumann.rs:139-249 — order of checks preserved
+sl_status state_init(sl_neumann_state &st, const sl_matrix *m, const double *b, const double *initial_guess, const sl_neumann_options *o)
+{
     if (m->row_offset == 0 && m->n_rows != m->n_cols)
         return sl_fail(SL_INVALID_INPUT, "Matrix must be square for Neumann series");
     if (m->row_offset != 0 || m->n_rows != m->n_cols)
         return sl_fail(SL_UNSUPPORTED_FORMAT, "sl_neumann_solve needs the whole matrix; drive row slices with sl_neumann_step");
-    const uint64_t n = m->n_rows;
+    st.m = m; st.o = *o; st.n = m->n_rows;
+    (void)hipGetDevice(&st.device);
+    const uint64_t n = st.n;
     const sl_mem where = (sl_mem)o->mem;
-    const sl_order order = (sl_order)o->order;
     hipStream_t s = sl_context().stream;
-
-    DevBuf bbuf, dinv, rhs, x, ta, tb, scal;
-    const double *db;
-    SL_TRY(stage_in(b, n, where, bbuf, &db));
-    SL_TRY(dinv.alloc(n * 8)); SL_TRY(rhs.alloc(n * 8)); SL_TRY(x.alloc(n * 8));
-    SL_TRY(ta.alloc(n * 8)); SL_TRY(tb.alloc(n * 8)); SL_TRY(scal.alloc(64));
-    double *scr = static_cast<double *>(sl_scratch(partial_bytes(m)));
-    if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
-    double *d_res = scal.as<double>();
-
+    auto get = [&](DevBuf &d, size_t bytes) { return st.owned ? d.alloc_owned(bytes) : d.alloc(bytes); };
+    SL_TRY(get(st.b, n * 8)); SL_TRY(get(st.dinv, n * 8)); SL_TRY(get(st.rhs, n * 8)); SL_TRY(get(st.x, n * 8));
+    SL_TRY(get(st.ta, n * 8)); SL_TRY(get(st.tb, n * 8)); SL_TRY(get(st.scal, 64)); SL_TRY(get(st.ctlbuf, sizeof(sl_solve_ctl)));
+    if (n) SL_HIP(hipMemcpyAsync(st.b.p, b, n * 8, where == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
     unsigned long long hs[4];
-    SL_TRY(sl_matrix_diag_pass(m, dinv.as<double>(), hs));
+    SL_TRY(sl_matrix_diag_pass(m, st.dinv.as<double>(), hs));
     if (hs[0] & 1ull) return sl_fail(SL_NOT_DIAGONALLY_DOMINANT, "matrix is not row diagonally dominant (first failing row %llu)", hs[1]);
     if (hs[0] & 2ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2]);
     if (hs[0] & 4ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3]);
-    SL_TRY(sl_launch_scale_rows(n, db, dinv.as<double>(), rhs.as<double>(), s));        // rhs = b * dinv  (:191-194)
+    SL_TRY(sl_launch_scale_rows(n, st.b.as<double>(), st.dinv.as<double>(), st.rhs.as<double>(), s));     // rhs = b * dinv  (:191-194)
     if (o->start == SL_START_INITIAL_GUESS) {
         if (!initial_guess) return sl_fail(SL_INVALID_INPUT, "initial_guess is null");
-        SL_HIP(hipMemcpyAsync(x.p, initial_guess, n * 8, where == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+        SL_HIP(hipMemcpyAsync(st.x.p, initial_guess, n * 8, where == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
     } else if (o->start == SL_START_REFERENCE_DEFAULT) {
-        SL_HIP(hipMemcpyAsync(x.p, rhs.p, n * 8, hipMemcpyDeviceToDevice, s));           // :197-208
+        SL_HIP(hipMemcpyAsync(st.x.p, st.rhs.p, n * 8, hipMemcpyDeviceToDevice, s));     // :197-208
     } else {
-        SL_HIP(hipMemsetAsync(x.p, 0, n * 8, s));
+        SL_HIP(hipMemsetAsync(st.x.p, 0, n * 8, s));
     }
-    SL_HIP(hipMemcpyAsync(ta.p, rhs.p, n * 8, hipMemcpyDeviceToDevice, s));              // current_term = rhs (:211)
+    SL_HIP(hipMemcpyAsync(st.ta.p, st.rhs.p, n * 8, hipMemcpyDeviceToDevice, s));        // current_term = rhs (:211)
+    st.t_cur = st.ta.as<double>(); st.t_nxt = st.tb.as<double>();
+    return SL_OK;
+}
 
-    double *t_cur = ta.as<double>(), *t_nxt = tb.as<double>();
-    const double *res_rhs = (o->residual == SL_RESIDUAL_REFERENCE_SCALED) ? rhs.as<double>() : db;
-    double resn = INFINITY, tn = 0.0;
-    bool series_conv = false;
-    uint64_t terms = 0, it = 0, matvec = 0, step_launches = 0, resid_launches = 0;
+// the loop of NeumannSolver::solve (neumann.rs:477-555) from the state's current position; iteration count starts at 0
+sl_status state_run(sl_neumann_state &st, double *term_norms, sl_neumann_result *res)
+{
+    const sl_matrix *m = st.m;
+    const sl_neumann_options *o = &st.o;
+    const uint64_t n = st.n;
+    const sl_order order = (sl_order)o->order;
+    hipStream_t s = sl_context().stream;
+    const auto wall0 = std::chrono::steady_clock::now();
+    double *scr = static_cast<double *>(sl_scratch(partial_bytes(m)));
+    if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
+    double *d_res = st.scal.as<double>();
+    DevBuf &dinv = st.dinv, &rhs = st.rhs, &x = st.x, &ta = st.ta, &tb = st.tb;
+    double *&t_cur = st.t_cur, *&t_nxt = st.t_nxt;
+    const double *res_rhs = (o->residual == SL_RESIDUAL_REFERENCE_SCALED) ? rhs.as<double>() : st.b.as<double>();
+    double &resn = st.resn, &tn = st.tn;
+    bool &series_conv = st.series_conv;
+    uint64_t &terms = st.terms, &matvec = st.matvec, &step_launches = st.step_launches, &resid_launches = st.resid_launches;
+    uint64_t it = 0;
     sl_status status = SL_OK;
+    sl_range_push("neumann solve loop");
 
-    auto is_converged = [&]() { return (resn <= o->tolerance) || (series_conv && !(terms >= o->max_terms)); };
+    auto is_converged = [&]() { return state_converged(st); };
     auto update_residual = [&]() -> sl_status {                                         // neumann.rs:302-318
         sl_row_args a = row_args(m);
         a.gather = x.as<double>(); a.aux = res_rhs; a.out = nullptr; a.partials = scr; a.partials_slack = 4096; a.result = d_res;
@@ -580,11 +651,8 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
     // read back inside a batch, the reducing launches apply the stop rules on the device and later launches gate
     // themselves off; the host then replays the reference's control flow over the logged sums.  Same decisions and
     // bits as an iteration-by-iteration loop, one host round trip per batch instead of one or two per iteration.
-    static int batch_env = -1;
-    if (batch_env < 0) { const char *e = getenv("SL_SOLVE_BATCH"); batch_env = e ? atoi(e) : 10; if (batch_env < 1) batch_env = 1; if (batch_env > 25) batch_env = 25; }
-    DevBuf ctlbuf;
-    SL_TRY(ctlbuf.alloc(sizeof(sl_solve_ctl)));
-    sl_solve_ctl *d_ctl = ctlbuf.as<sl_solve_ctl>();
+    static const int batch_env = [] { const char *e = getenv("SL_SOLVE_BATCH"); int v = e ? atoi(e) : 10; return v < 1 ? 1 : (v > 25 ? 25 : v); }();
+    sl_solve_ctl *d_ctl = st.ctlbuf.as<sl_solve_ctl>();
     const double thr_series = sq_threshold_lt(o->series_tolerance), thr_tol = sq_threshold_le(o->tolerance);
     struct planned { int kind; double *t_after; };      // kind 0: term k = 0, 1: fused step, 2: residual
     std::vector<planned> plan;
@@ -698,11 +766,143 @@ sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *in
     res->device_time_ms = loop_ms;
     res->bytes_moved = (step_launches + resid_launches) * (12ull * m->nnz + 4ull * (n + 1)) + step_launches * 40ull * n
                        + resid_launches * 16ull * n;
-    hipError_t ce = hipMemcpyAsync(x_out, x.p, n * 8, where == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s);
+    res->total_time_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    sl_range_pop();
+    sl_log(1, "neumann: %llu iterations, %llu terms, residual %.3e, %s, %.3f ms on the device", (unsigned long long)it, (unsigned long long)terms, resn,
+           res->converged ? "converged" : "not converged", (double)loop_ms);
+    return status;
+}
+
+sl_status state_solution(const sl_neumann_state &st, double *x_out, sl_mem where)
+{
+    hipStream_t s = sl_context().stream;
+    hipError_t ce = st.n ? hipMemcpyAsync(x_out, st.x.p, st.n * 8, where == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s) : hipSuccess;
     if (ce == hipSuccess) ce = hipStreamSynchronize(s);
-    if (ce != hipSuccess && status == SL_OK) status = sl_fail(SL_DEVICE_ERROR, "result download failed: %s", hipGetErrorString(ce));
+    if (ce != hipSuccess) return sl_fail(SL_DEVICE_ERROR, "result download failed: %s", hipGetErrorString(ce));
+    return SL_OK;
+}
+
+// NeumannSolver::update_rhs, neumann.rs:436-462: in list order, one after the other (the same index may come twice)
+__global__ void sl_update_rhs_kernel(uint64_t count, const uint64_t *idx, const double *delta, const double *dinv, double *rhs, double *x, double *b)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    for (uint64_t k = 0; k < count; ++k) {
+        const uint64_t i = idx[k];
+        const double scaled = __dmul_rn(delta[k], dinv[i]);             // :448
+        rhs[i] = __dadd_rn(rhs[i], scaled);                             // :449
+        x[i] = __dadd_rn(x[i], scaled);                                 // :453
+        b[i] = __dadd_rn(b[i], delta[k]);                               // the unscaled right-hand side the TRUE residual is measured against
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *initial_guess,
+                           const sl_neumann_options *o, double *x_out, double *term_norms,
+                           sl_neumann_result *res)
+{
+    SL_ABI_BEGIN
+    if (!m || !b || !o || !x_out || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
+    memset(res, 0, sizeof(*res));
+    res->residual_norm = INFINITY;
+    res->error_bound = -1.0;
+    const auto wall0 = std::chrono::steady_clock::now();
+    sl_neumann_state st;
+    SL_TRY(state_init(st, m, b, initial_guess, o));
+    sl_status status = state_run(st, term_norms, res);
+    const sl_status cs = state_solution(st, x_out, (sl_mem)o->mem);       // on CONVERGENCE_FAILURE x_out is still filled
+    if (status == SL_OK) status = cs;
     res->total_time_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return status;
+    SL_ABI_END
+}
+
+sl_status sl_neumann_state_create(const sl_matrix *m, const double *b, const double *initial_guess, const sl_neumann_options *o,
+                                  sl_neumann_state **out)
+{
+    SL_ABI_BEGIN
+    if (!out) return sl_fail(SL_INVALID_INPUT, "out is null");
+    *out = nullptr;
+    if (!m || !b || !o) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_TRY(require_device());
+    sl_neumann_state *st = new sl_neumann_state();
+    st->owned = true;          // the state outlives the call (and may die on another thread): no loans from the per-thread workspace pool
+    const sl_status s0 = state_init(*st, m, b, initial_guess, o);
+    if (s0 != SL_OK) { sl_neumann_state_destroy(st); return s0; }
+    *out = st;
+    return SL_OK;
+    SL_ABI_END
+}
+
+void sl_neumann_state_destroy(sl_neumann_state *st)
+{
+    if (!st) return;
+    (void)hipStreamSynchronize(sl_context().stream);
+    delete st;
+}
+
+sl_status sl_neumann_state_update_rhs(sl_neumann_state *st, uint64_t count, const uint64_t *indices, const double *deltas)
+{
+    SL_ABI_BEGIN
+    if (!st || (count && (!indices || !deltas))) return sl_fail(SL_INVALID_INPUT, "null argument");
+    hipStream_t s = sl_context().stream;
+    // neumann.rs:438-445: the first index out of range ends the call with IndexOutOfBounds — the updates before it stay applied and
+    // the series state is NOT reset (the reference returns from inside the loop)
+    uint64_t good = count;
+    for (uint64_t k = 0; k < count; ++k) if (indices[k] >= st->n) { good = k; break; }
+    if (good) {
+        DevBuf di, dd;
+        SL_TRY(di.alloc(good * 8)); SL_TRY(dd.alloc(good * 8));
+        SL_HIP(hipMemcpyAsync(di.p, indices, good * 8, hipMemcpyHostToDevice, s));
+        SL_HIP(hipMemcpyAsync(dd.p, deltas, good * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(sl_update_rhs_kernel, dim3(1), dim3(1), 0, s, good, di.as<uint64_t>(), dd.as<double>(), st->dinv.as<double>(),
+                           st->rhs.as<double>(), st->x.as<double>(), st->b.as<double>());
+        SL_HIP(hipGetLastError());
+        SL_HIP(hipStreamSynchronize(s));                                   // the staging buffers go back to the pool
+    }
+    if (good < count)
+        return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "Index %llu out of bounds (max %llu) in rhs_update", (unsigned long long)indices[good],
+                       (unsigned long long)(st->n ? st->n - 1 : 0));
+    // :456-459 reset series computation state
+    SL_HIP(hipMemcpyAsync(st->ta.p, st->rhs.p, st->n * 8, hipMemcpyDeviceToDevice, s));   // current_term = rhs
+    st->t_cur = st->ta.as<double>(); st->t_nxt = st->tb.as<double>();
+    st->terms = 0;
+    st->series_conv = false;
+    return SL_OK;
+    SL_ABI_END
+}
+
+sl_status sl_neumann_state_run(sl_neumann_state *st, double *term_norms, sl_neumann_result *res)
+{
+    SL_ABI_BEGIN
+    if (!st || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
+    memset(res, 0, sizeof(*res));
+    res->residual_norm = INFINITY;
+    res->error_bound = -1.0;
+    return state_run(*st, term_norms, res);
+    SL_ABI_END
+}
+
+sl_status sl_neumann_state_solution(const sl_neumann_state *st, double *x_out, sl_mem where)
+{
+    SL_ABI_BEGIN
+    if (!st || !x_out) return sl_fail(SL_INVALID_INPUT, "null argument");
+    return state_solution(*st, x_out, where);
+    SL_ABI_END
+}
+
+sl_status sl_neumann_state_reset(sl_neumann_state *st)                      // SolverState::reset, neumann.rs:367-378
+{
+    SL_ABI_BEGIN
+    if (!st) return sl_fail(SL_INVALID_INPUT, "null argument");
+    hipStream_t s = sl_context().stream;
+    SL_HIP(hipMemsetAsync(st->x.p, 0, st->n * 8, s));
+    SL_HIP(hipMemcpyAsync(st->ta.p, st->rhs.p, st->n * 8, hipMemcpyDeviceToDevice, s));
+    st->t_cur = st->ta.as<double>(); st->t_nxt = st->tb.as<double>();
+    st->resn = INFINITY; st->tn = 0.0; st->terms = 0; st->matvec = 0; st->step_launches = 0; st->resid_launches = 0; st->series_conv = false;
+    return SL_OK;
     SL_ABI_END
 }
 

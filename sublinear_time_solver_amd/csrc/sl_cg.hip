@@ -142,6 +142,7 @@ void sl_cg_options_default(sl_cg_options *o)
 sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *o, double *x_out, sl_cg_result *res)
 {
     SL_ABI_BEGIN
+    sl_range trace_range("cg solve");
     if (!m || !b || !o || !x_out || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
     memset(res, 0, sizeof(*res));
     const auto wall0 = std::chrono::steady_clock::now();
@@ -177,8 +178,7 @@ sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *
     sl_solve_ctl *d_ctl = ctlbuf.as<sl_solve_ctl>();
     sl_cg_scalars *d_sc = scbuf.as<sl_cg_scalars>();
     hipLaunchKernelGGL(sl_cg_set_rsold_kernel, dim3(1), dim3(1), 0, s, d_sc, rsold);
-    static int batch_env = -1;
-    if (batch_env < 0) { const char *e = getenv("SL_SOLVE_BATCH"); batch_env = e ? atoi(e) : 10; if (batch_env < 1) batch_env = 1; if (batch_env > 25) batch_env = 25; }
+    static const int batch_env = [] { const char *e = getenv("SL_SOLVE_BATCH"); const int v = e ? atoi(e) : 10; return v < 1 ? 1 : (v > 25 ? 25 : v); }();
     sl_timer timer;
     SL_TRY(timer.start(s));
     sl_status st = SL_OK;

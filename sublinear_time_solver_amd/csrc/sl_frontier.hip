@@ -678,15 +678,13 @@ sl_status run_push(push_state &ps, const sl_matrix *m, sl_theta theta, uint64_t 
     DevBuf resbuf;
     SL_TRY(resbuf.alloc(64));
 
-    static int cfg_batch = -1;
-    if (cfg_batch < 0) { const char *e = getenv("SL_PUSH_BATCH"); cfg_batch = e ? atoi(e) : 12; if (cfg_batch < 1) cfg_batch = 1; }
+    static const int cfg_batch = [] { const char *e = getenv("SL_PUSH_BATCH"); const int v = e ? atoi(e) : 12; return v < 1 ? 1 : v; }();
     const double dense_limit = dense_switch * (double)n;               // nf > dense_limit  <=>  nf > floor(dense_limit)
     const uint32_t dense_threshold = dense_limit >= 4294967295.0 ? 0xffffffffu : (dense_limit > 0.0 ? (uint32_t)dense_limit : 0u);
 
     // a sparse round costs 40-60x a dense round per matrix entry it touches (records, atomics, random sectors); 64 after the dense
     // rounds of graph-like matrices got the column-panel kernel (swept 16..96 on the 10^7-node PageRank queries)
-    static unsigned long long hit_div = 0;
-    if (!hit_div) { const char *e = getenv("SL_PUSH_HIT_DIV"); hit_div = e ? strtoull(e, nullptr, 10) : 64; if (!hit_div) hit_div = 64; }
+    static const unsigned long long hit_div = [] { const char *e = getenv("SL_PUSH_HIT_DIV"); const unsigned long long v = e ? strtoull(e, nullptr, 10) : 64; return v ? v : 64ull; }();
     // (dense_switch >= 1: the caller asked for sparse rounds throughout; only the record buffer limits them)
     const unsigned long long hit_limit = dense_switch >= 1.0 ? ps.rec_cap
                                          : std::min<unsigned long long>(ps.rec_cap, std::max<unsigned long long>(ps.op_nnz / hit_div, 4096));
@@ -838,6 +836,7 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
     const hipMemcpyKind in_kind = o->mem == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     const hipMemcpyKind out_kind = o->mem == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
 
+    sl_range trace_range("push solve");
     push_state ps;
     DevBuf bufs[20], bbuf, ax;
     SL_TRY(alloc_state(ps, n, m->nnz, bufs));

@@ -115,6 +115,15 @@ struct sl_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int side_device = -1;
 };
+// ---- tracing and logging (hook points of the reference: optimized_solver.rs:25-28,73-75, lib.rs:137-141) ----------
+// roctx ranges around layout build / solve loops / exchange steps: resolved at run time from libroctx64.so (rocprofv3 --marker-trace
+// shows them); without the library they cost one branch.  SL_LOG=1 (phases) / 2 (launch decisions) writes lines to stderr.
+void sl_range_push(const char *name);
+void sl_range_pop();
+int sl_log_level();
+void sl_log(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+struct sl_range { explicit sl_range(const char *n) { sl_range_push(n); } ~sl_range() { sl_range_pop(); } sl_range(const sl_range &) = delete; sl_range &operator=(const sl_range &) = delete; };
+
 bool sl_side_stream(sl_ctx &c);      // lazily creates the side stream / events for the current device; false if that failed
 sl_ctx &sl_context();
 sl_status sl_fail(sl_status s, const char *fmt, ...);

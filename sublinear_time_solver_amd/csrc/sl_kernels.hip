@@ -916,32 +916,60 @@ uint32_t sl_row_grid(uint64_t n_slices)
 #define SL_BAND_MAX_LDS_ONE (158u * 1024u)  // one 16-wave block per CU: windows up to w ~ 9500 (leaves room for the static arrays)
 struct band_geom { uint32_t spw, lds, nw; bool pipe, c16; };
 // matrices with at least this many slices run their long-row kernel beside the slice kernel (env SL_LONG_ROWS_BESIDE_MIN; tests use 0)
-static uint64_t long_rows_beside_min()
-{
-    static long long v = -1;
-    if (v < 0) {
-        const char *e = getenv("SL_LONG_ROWS_BESIDE_MIN");
-        v = e ? atoll(e) : 16384;
-        if (getenv("SL_LONG_ROWS_SERIAL") && getenv("SL_LONG_ROWS_SERIAL")[0] == '1') v = (long long)1 << 62;
+// Environment knobs of this file (A/B measurements and tests): read ONCE per process, in a thread-safe static
+// initialisation — the library documents itself re-entrant (include/sublinear_hip.h), so nothing here is lazily written.
+struct sl_kernel_knobs {
+    uint64_t long_rows_beside_min = 16384;   // matrices with at least this many slices run their long-row kernel beside the slice kernel
+    bool band_disabled = false, c16_off = false, wide_off = false;
+    int forced_spw = 0, forced_pipe = -1, forced_nw = 0;
+    long panel_round = -1;                   // SL_PANEL_ROUND: blocks per launch of the dynamic-tile panel kernel (-1: from the occupancy)
+    uint32_t pw_slack = 0;                   // SL_PW_SLACK: panels of lead in the paced panel kernel (0: the matrix's own figure)
+    sl_kernel_knobs()
+    {
+        auto flag = [](const char *n, char v) { const char *e = getenv(n); return e && e[0] == v; };
+        auto num = [](const char *n, long dflt) { const char *e = getenv(n); return e && *e ? atol(e) : dflt; };
+        long_rows_beside_min = (uint64_t)num("SL_LONG_ROWS_BESIDE_MIN", 16384);
+        if (flag("SL_LONG_ROWS_SERIAL", '1')) long_rows_beside_min = 1ull << 62;
+        band_disabled = flag("SL_BAND_DISABLE", '1');
+        forced_spw = (int)num("SL_BAND_SPW", 0);
+        forced_pipe = (int)num("SL_BAND_PIPE", -1);
+        c16_off = flag("SL_BAND_C16", '0');
+        forced_nw = (int)num("SL_BAND_NW", 0);
+        wide_off = flag("SL_BAND_NW16", '0');
+        panel_round = num("SL_PANEL_ROUND", -1);
+        pw_slack = (uint32_t)num("SL_PW_SLACK", 0);
     }
-    return (uint64_t)v;
+};
+static const sl_kernel_knobs &knobs()
+{
+    static const sl_kernel_knobs k;
+    return k;
+}
+static uint64_t long_rows_beside_min() { return knobs().long_rows_beside_min; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel AND device (one process may drive several devices from several
+// threads); KFN is the kernel itself, so every instantiation has its own flags
+#define SL_MAX_DEVICES 32
+template <auto KFN>
+static sl_status set_max_lds_once(int bytes)
+{
+    static std::once_flag once[SL_MAX_DEVICES];
+    static hipError_t err[SL_MAX_DEVICES];
+    int dev = 0;
+    SL_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= SL_MAX_DEVICES) {
+        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(KFN), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        return SL_OK;
+    }
+    std::call_once(once[dev], [&] { err[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(KFN), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    SL_HIP(err[dev]);
+    return SL_OK;
 }
 
 static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool nw8_pays)
 {
-    static int disabled = -1, forced_spw = 0, forced_pipe = -1, c16_off = 0, forced_nw = 0;
-    if (disabled < 0) {
-        const char *e = getenv("SL_BAND_DISABLE");
-        disabled = (e && e[0] == '1') ? 1 : 0;
-        const char *f = getenv("SL_BAND_SPW");
-        forced_spw = f ? atoi(f) : 0;
-        const char *g = getenv("SL_BAND_PIPE");
-        forced_pipe = g ? atoi(g) : -1;
-        const char *h = getenv("SL_BAND_C16");
-        c16_off = (h && h[0] == '0') ? 1 : 0;
-        const char *nwe = getenv("SL_BAND_NW");
-        forced_nw = nwe ? atoi(nwe) : 0;
-    }
+    const sl_kernel_knobs &kn = knobs();
+    const int disabled = kn.band_disabled ? 1 : 0, forced_spw = kn.forced_spw, forced_pipe = kn.forced_pipe, c16_off = kn.c16_off ? 1 : 0, forced_nw = kn.forced_nw;
     band_geom out{0, 0, 4, false, false};
     if (disabled || a.bandwidth == ~0ull || a.n_cols > 0xffffffffull) return out;
     // measured (profiles/r01_ab_wave_blocks.txt and earlier spw sweeps; +-5 % DVFS noise between repetitions): narrow windows
@@ -960,7 +988,7 @@ static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool
     if (entries * 8 > SL_BAND_MAX_LDS || forced_nw == 16) {
         // the window does not fit twice per CU: one 16-wave block per CU with (almost) the whole LDS, if that variant exists
         // (w = 6000..9400: 52-56 % with the general kernel -> 72-82 %)
-        static const bool wide_off = getenv("SL_BAND_NW16") && getenv("SL_BAND_NW16")[0] == '0';
+        const bool wide_off = kn.wide_off;
         if (wide_off || !pipe || !c16 || !nw8_pays || forced_nw == 4 || forced_nw == 8) return out;
         nw = 16;
         spw = forced_spw > 0 ? (uint32_t)forced_spw : 4u;
@@ -977,13 +1005,8 @@ static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool
 template <int ORDER, int EPI, int UWV, bool PIPE, bool C16, int NW>
 static sl_status launch_band_nw(const sl_row_args &a, const band_geom &g, uint32_t grid, uint32_t nb8, hipStream_t s)
 {
-    auto kfn = sl_band_kernel<(UWV) ? 0 : ORDER, EPI, UWV, PIPE, C16, NW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   NW == 16 ? SL_BAND_MAX_LDS_ONE : SL_BAND_MAX_LDS));
-        attr_done = true;
-    }
+    constexpr auto kfn = sl_band_kernel<(UWV) ? 0 : ORDER, EPI, UWV, PIPE, C16, NW>;
+    SL_TRY(set_max_lds_once<kfn>(NW == 16 ? SL_BAND_MAX_LDS_ONE : SL_BAND_MAX_LDS));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NW * 64), g.lds, s, a, nb8, g.spw, (uint32_t)a.bandwidth);
     return SL_OK;
 }
@@ -1028,42 +1051,30 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
     const band_geom g = band_geometry(a, uniform_unrolled || !uniform_octets, nw8_pays);
     if (ORDER == 0 && a.pw_idx && a.pw_tiles) {
         const uint32_t lds = (uint32_t)(SL_PW_WAVES * ((size_t)a.pw_rpw + 1) * sizeof(double));
-        static std::once_flag attr_once;                                  // per process and template instance; the value is a constant
-        hipError_t attr_err = hipSuccess;
-        std::call_once(attr_once, [&] {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(sl_pw_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double)));
-        });
-        SL_HIP(attr_err);
-        static const uint32_t env_slack = [] { const char *e = getenv("SL_PW_SLACK"); return e && *e ? (uint32_t)atol(e) : 0u; }();   // A/B knob; 1048576 = no pacing
-        if (env_slack) a.pw_slack = env_slack;
+        SL_TRY(set_max_lds_once<sl_pw_kernel<EPI>>((int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double))));
+        if (knobs().pw_slack) a.pw_slack = knobs().pw_slack;               // A/B knob; 1048576 = no pacing
         *nparts = a.pw_blocks + a.n_long;
         a.part_stride = *nparts;
         hipLaunchKernelGGL((sl_pw_kernel<EPI>), dim3(a.pw_blocks), dim3(SL_PW_WAVES * 64), lds, s, a);
     } else if (ORDER == 0 && a.pan_tile_ptr && a.n_pan_tiles) {
         const uint32_t grid = (a.n_pan_tiles + SL_PANEL_WAVES - 1) / SL_PANEL_WAVES;
         constexpr uint32_t lds = SL_PANEL_WAVES * (SL_PANEL_TILE + 64) * sizeof(double);
-        static bool attr_done = false;
-        if (!attr_done) {
-            SL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sl_panel_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_done = true;
-        }
+        SL_TRY(set_max_lds_once<sl_panel_kernel<EPI>>((int)lds));
         *nparts = grid + a.n_long;
         a.part_stride = *nparts;
         // one launch per round of resident blocks: blocks that start together pass the panels together, a second round that trickles
         // in behind the first does not (n = 10^7 x 16: 1.66 -> 1.50 ms; partial rounds lose it again, and so do tiles of unequal length — the PageRank solve
         // went 0.314 -> 0.345 s — so only matrices whose tiles are balanced are launched this way).  SL_PANEL_ROUND: blocks per
         // launch, 0 = a single launch
-        static uint32_t round_blocks = 0xffffffffu;
-        if (round_blocks == 0xffffffffu) {
+        static const uint32_t round_blocks = [] {                         // thread-safe static initialisation, per template instance
+            if (knobs().panel_round >= 0) return (uint32_t)knobs().panel_round;
             int per_cu = 0, dev = 0;
             hipDeviceProp_t prop;
-            if (const char *e = getenv("SL_PANEL_ROUND")) round_blocks = (uint32_t)atoi(e);
-            else if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess
-                     && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sl_panel_kernel<EPI>, SL_PANEL_WAVES * 64, lds) == hipSuccess && per_cu > 0)
-                round_blocks = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
-            else round_blocks = 0;
-        }
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess
+                && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sl_panel_kernel<EPI>, SL_PANEL_WAVES * 64, lds) == hipSuccess && per_cu > 0)
+                return (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+            return 0u;
+        }();
         const uint32_t per = (round_blocks && a.pan_balanced) ? round_blocks : grid;     // unequal tiles: every round would wait for its longest
         for (uint32_t b0 = 0; b0 < grid; b0 += per)
             hipLaunchKernelGGL((sl_panel_kernel<EPI>), dim3(std::min(per, grid - b0)), dim3(SL_PANEL_WAVES * 64), lds, s, a, b0);

@@ -498,6 +498,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     hipStream_t st = sl_context().stream;
     const uint64_t n = m->n_rows, nnz = m->nnz;
     m->n_slices = (n + SL_SLICE - 1) / SL_SLICE;
+    sl_range trace_range("matrix layout build");
 
     // 1. validate
     uint32_t *d_err = nullptr;
@@ -657,6 +658,11 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         m->device_bytes += (n + 1) * sizeof(uint32_t) + nnz * 12;
     }
     SL_HIP(hipStreamSynchronize(st));
+    sl_log(1, "matrix %llu x %llu, %llu entries (rows %u..%u, %llu long): row slices%s%s, bandwidth %llu, %s%s, %.1f MB on the device",
+           (unsigned long long)n, (unsigned long long)m->n_cols, (unsigned long long)nnz, m->min_row_nnz, m->max_row_nnz, (unsigned long long)m->n_long,
+           m->uniform_width ? " (uniform width)" : "", m->d_cols16 ? " + 16-bit offsets" : "", (unsigned long long)m->bandwidth,
+           m->d_pw_idx ? "paced column panels" : (m->d_pan_tile_ptr ? "column panels (dynamic tiles)" : "no column panels"),
+           m->d_tptr ? ", transpose" : "", (double)m->device_bytes / 1e6);
     return SL_OK;
 }
 

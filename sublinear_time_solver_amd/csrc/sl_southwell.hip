@@ -130,6 +130,7 @@ sl_status sl_forward_push_southwell(const sl_matrix *m, const double *b, const s
     res->residual_norm = INFINITY;
     if (m->n_rows != m->n_cols || m->row_offset != 0) return sl_fail(SL_INVALID_INPUT, "Matrix must be square");
     if (!m->d_tptr || !m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "the Gauss-Southwell push walks columns: create the matrix with SL_MATRIX_WITH_TRANSPOSE");
+    sl_range trace_range("gauss-southwell push");
     const uint64_t n = m->n_rows;
     hipStream_t s = sl_context().stream;
     const hipMemcpyKind in_kind = o->mem == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;

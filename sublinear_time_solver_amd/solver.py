@@ -204,6 +204,43 @@ class NeumannSolver:
     def algorithm_name(self) -> str:
         return "neumann"
 
+    def _options(self, matrix, b, options):
+        lib = L.load()
+        if matrix.is_square() and b.size != matrix.rows():           # neumann.rs:154-160
+            raise SolverError(5, f"expected {matrix.rows()}, actual {b.size} in neumann_initialization")
+        o = L.NeumannOptions()
+        lib.sl_neumann_options_default(C.byref(o))
+        o.tolerance, o.max_iterations = options.tolerance, options.max_iterations
+        o.max_terms, o.series_tolerance = self.max_terms, self.series_tolerance
+        o.order, o.start, o.residual, o.mem = self.order, self.start, self.residual, L.SL_MEM_HOST
+        o.collect_stats = int(options.collect_stats)
+        o.compute_error_bounds = int(options.compute_error_bounds and self.adaptive_truncation)
+        guess = None
+        if options.initial_guess is not None:
+            guess = _f64(options.initial_guess)
+            if guess.size != matrix.rows():                          # neumann.rs:198-204
+                raise SolverError(5, f"expected {matrix.rows()}, actual {guess.size} in initial_guess")
+            o.start = L.SL_START_INITIAL_GUESS
+        return o, guess
+
+    # SolverAlgorithm::{initialize, update_rhs, extract_solution} (solver/mod.rs:223-333) over the state object of the ABI
+    def initialize(self, matrix: SparseMatrix, b, options: Optional[SolverOptions] = None) -> "NeumannState":
+        options = options or SolverOptions()
+        b = _f64(b)
+        o, guess = self._options(matrix, b, options)
+        h = C.c_void_p()
+        L.check(L.load().sl_neumann_state_create(matrix._h, L.ptr(b), L.ptr(guess), C.byref(o), C.byref(h)))
+        return NeumannState(h, matrix, self.max_terms, options)
+
+    def update_rhs(self, state: "NeumannState", delta_b) -> None:
+        state.update_rhs(delta_b)
+
+    def extract_solution(self, state: "NeumannState") -> np.ndarray:
+        return state.solution()
+
+    def is_converged(self, state: "NeumannState") -> bool:
+        return state.converged
+
     def solve(self, matrix: SparseMatrix, b, options: Optional[SolverOptions] = None) -> SolverResult:
         options = options or SolverOptions()
         lib = L.load()
@@ -239,6 +276,61 @@ class NeumannSolver:
                      "device_time_ms": r.device_time_ms, "bytes_moved": int(r.bytes_moved)}
         return SolverResult(x, r.residual_norm, int(r.iterations), bool(r.converged),
                             r.error_bound if r.error_bound >= 0 else None, stats, tn[: int(r.terms_computed)].copy())
+
+
+class NeumannState:
+    """NeumannState (src/solver/neumann.rs:95-137) living on the device behind sl_neumann_state_*: the matrix layout, D^-1 and the
+    vectors stay resident across update_rhs / run / reset — what an incremental caller of the reference's SolverAlgorithm holds."""
+
+    def __init__(self, handle, matrix: SparseMatrix, max_terms: int, options: SolverOptions):
+        self._h, self._matrix, self._max_terms, self._options = handle, matrix, max_terms, options   # the matrix must outlive the state
+        self.converged = False
+        self.last = None
+
+    def update_rhs(self, delta_b) -> None:
+        """NeumannSolver::update_rhs(state, &[(index, delta)]) — neumann.rs:436-462, in list order"""
+        pairs = list(delta_b)
+        idx = np.ascontiguousarray([int(i) for i, _ in pairs], dtype=np.uint64)
+        val = np.ascontiguousarray([float(v) for _, v in pairs], dtype=np.float64)
+        L.check(L.load().sl_neumann_state_update_rhs(self._h, len(pairs), L.ptr(idx), L.ptr(val)))
+
+    def run(self) -> SolverResult:
+        """the loop of NeumannSolver::solve (neumann.rs:477-555) from the state's current position"""
+        tn = np.zeros(max(self._max_terms, 1), dtype=np.float64)
+        r = L.NeumannResult()
+        st = L.load().sl_neumann_state_run(self._h, L.ptr(tn), C.byref(r))
+        self.converged = bool(r.converged)
+        res = SolverResult(self.solution(), r.residual_norm, int(r.iterations), bool(r.converged),
+                           r.error_bound if r.error_bound >= 0 else None,
+                           {"matvec_count": int(r.matvec_count), "device_time_ms": r.device_time_ms, "terms_computed": int(r.terms_computed)},
+                           tn[: min(int(r.terms_computed), tn.size)].copy())
+        self.last = res
+        if st != L.SL_OK:
+            err = SolverError(st, L.load().sl_last_error_message().decode())
+            err.result = res
+            raise err
+        return res
+
+    def solution(self) -> np.ndarray:
+        x = np.empty(self._matrix.rows(), dtype=np.float64)
+        L.check(L.load().sl_neumann_state_solution(self._h, L.ptr(x), L.SL_MEM_HOST))
+        return x
+
+    def reset(self) -> None:
+        """SolverState::reset (neumann.rs:367-378): solution = 0, current term = the (updated) scaled rhs, counters cleared"""
+        L.check(L.load().sl_neumann_state_reset(self._h))
+        self.converged = False
+
+    def close(self) -> None:
+        if self._h:
+            L.load().sl_neumann_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 @dataclass
