@@ -289,3 +289,12 @@ def test_g9_pagerank_system_matches_the_reference_power_iteration():
         r = O.push_sync_solve(rp, ci, va, b, theta=1e-18)
         ref = z[f"{key}__pagerank"]
         assert r["converged"] and np.abs(r["x"] - ref).max() <= 1e-13, (key, np.abs(r["x"] - ref).max())
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """`make -C oracle asan`: every oracle entry point on empty / tiny / ragged / duplicate-laden / hub systems under
+    AddressSanitizer + UndefinedBehaviorSanitizer (oracle/asan_check.c).  The oracle is the checker of the GPU parity tests."""
+    import subprocess
+    from pathlib import Path
+    r = subprocess.run(["make", "-C", str(Path(__file__).resolve().parent.parent / "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan_check ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
