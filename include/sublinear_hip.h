@@ -258,6 +258,36 @@ typedef struct {
     int32_t reserved;
 } sl_push_result;
 
+/* ---- multi-GPU: one process per GPU of ONE node, row-range partition ----------------------------------
+ * Precedent in the reference: simd_ops::parallel_matrix_vector_multiply (src/simd_ops.rs:201-239) hides row chunks behind one
+ * call.  Here a rank holds a contiguous row range on its own GPU (the process's current device):
+ *   sl_comm_create(rank, world, name)      every rank of the job calls it with the same `name` (no '/'); the rendezvous is a POSIX
+ *                                          shared-memory block /dev/shm/slcomm_<name> (removed again once all ranks have joined).
+ *                                          No MPI / RCCL / launcher dependence: any host language that can start N processes can
+ *                                          drive N GPUs.  world <= 16.
+ *   sl_matrix_create_csr(rows, n_global, nnz, ..., row_offset = first row of the rank, ...)   the rank's rows, GLOBAL column ids
+ *   sl_neumann_state_create_partitioned    NeumannState::new over the partition (collective; b / initial guess = the rank's rows)
+ *   sl_neumann_state_run / _run_steps / _update_rhs / _reset / _solution / _destroy            as for one GPU; collective calls —
+ *                                          every rank makes the same calls in the same order; _solution returns the rank's rows;
+ *                                          _update_rhs takes GLOBAL row indices (the same list on every rank).
+ * Per iteration a rank (i) runs the fused step on its rows, (ii) publishes its share of ||t||^2 and waits for all ranks' shares
+ * (summed in rank order: the same bits everywhere, so every rank takes the same stop decision), (iii) pulls the pieces of the new
+ * term its columns reach (the measured bandwidth of its rows) out of its peers' vectors over xGMI (IPC-mapped device memory);
+ * every 5th iteration the solution travels the same way for the residual (neumann.rs:489-491).  Per-row results equal the
+ * one-GPU solve bit for bit; norms are sums of per-rank sums (equal to ~1e-16 relative).  A peer that never arrives turns
+ * into SL_DEVICE_ERROR after SL_COMM_TIMEOUT_MS (20 s), never into a hung queue. */
+typedef struct sl_comm sl_comm;
+sl_status sl_comm_create(int rank, int world, const char *rendezvous_name, sl_comm **out);
+void sl_comm_destroy(sl_comm *c);
+sl_status sl_comm_rank(const sl_comm *c, int *rank, int *world);
+sl_status sl_comm_barrier(sl_comm *c);                                      /* drains the calling thread's stream, then all ranks meet */
+sl_status sl_comm_allgather_u64(sl_comm *c, uint64_t mine, uint64_t *all); /* e.g. row counts -> row ranges; all[world] */
+sl_status sl_neumann_state_create_partitioned(sl_comm *c, const sl_matrix *local_rows, const double *b_local, const double *initial_guess_local,
+                                              const sl_neumann_options *opts, sl_neumann_state **out);
+/* `steps` fused steps (a8 + a9) from the state's current term without the stop rule — the measurement loop; *last_norm2 = ||t||^2
+ * of the last step (over all ranks), *elapsed_ms = device time of the loop on this rank.  One GPU or partitioned. */
+sl_status sl_neumann_state_run_steps(sl_neumann_state *st, uint64_t steps, double *last_norm2, float *elapsed_ms);
+
 /* ---- a14 in the reference's own visiting order: TS solveForwardPush (src/core/solver.ts:437-522) ----
  * Gauss-Southwell: every step pushes the FIRST index of largest |r_i| (r = b - A x, x0 = 0), p = r_i / a_ii, x_i += p, r_i = 0,
  * r_j -= a_ji p over column i; stops when max |r_i| < epsilon; `iterations` = pushes.  Sequential across pushes by definition

@@ -118,6 +118,13 @@ SIGNATURES = {
     "sl_neumann_state_run": (C.c_int, [vp, vp, C.POINTER(NeumannResult)]),
     "sl_neumann_state_solution": (C.c_int, [vp, vp, C.c_int]),
     "sl_neumann_state_reset": (C.c_int, [vp]),
+    "sl_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),
+    "sl_comm_destroy": (None, [vp]),
+    "sl_comm_rank": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sl_comm_barrier": (C.c_int, [vp]),
+    "sl_comm_allgather_u64": (C.c_int, [vp, u64, vp]),
+    "sl_neumann_state_create_partitioned": (C.c_int, [vp, vp, vp, vp, C.POINTER(NeumannOptions), C.POINTER(vp)]),
+    "sl_neumann_state_run_steps": (C.c_int, [vp, u64, C.POINTER(f64), C.POINTER(C.c_float)]),
     "sl_push_options_default": (None, [C.POINTER(PushOptions)]),
     "sl_push_solve": (C.c_int, [vp, vp, C.POINTER(PushOptions), vp, vp, vp, u64, C.POINTER(u64),
                                 C.POINTER(PushResult)]),

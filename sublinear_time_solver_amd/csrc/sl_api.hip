@@ -565,6 +565,11 @@ struct sl_neumann_state {
     int device = 0;
     DevBuf b, dinv, rhs, x, ta, tb, scal, ctlbuf;      // b: the state's own device copy of the right-hand side (update_rhs changes it)
     bool owned = false;                                // true: the vectors are allocations of their own (a state that outlives the call), not pool loans
+    // partitioned state (sl_neumann_state_create_partitioned): n = this rank's rows; the term vectors are the full-length gathered
+    // vectors of the partition (dist->t[0/1]); x / rhs / dinv / b stay local
+    sl_dist *dist = nullptr;
+    double *tpair[2] = {nullptr, nullptr};             // the two term buffers t_cur / t_nxt alternate between
+    ~sl_neumann_state() { sl_dist_destroy(dist); }
     double *t_cur = nullptr, *t_nxt = nullptr;
     double resn = INFINITY, tn = 0.0;
     bool series_conv = false;
@@ -609,7 +614,71 @@ sl_status state_init(sl_neumann_state &st, const sl_matrix *m, const double *b, 
         SL_HIP(hipMemsetAsync(st.x.p, 0, n * 8, s));
     }
     SL_HIP(hipMemcpyAsync(st.ta.p, st.rhs.p, n * 8, hipMemcpyDeviceToDevice, s));        // current_term = rhs (:211)
-    st.t_cur = st.ta.as<double>(); st.t_nxt = st.tb.as<double>();
+    st.tpair[0] = st.ta.as<double>(); st.tpair[1] = st.tb.as<double>();
+    st.t_cur = st.tpair[0]; st.t_nxt = st.tpair[1];
+    return SL_OK;
+}
+
+// collective: the same verdict on every rank (a rank that left alone would let the others wait for its tickets)
+sl_status dist_agree(sl_comm *c, sl_status mine)
+{
+    std::vector<int32_t> all((size_t)c->world);
+    const int32_t v = (int32_t)mine;
+    const std::string msg = sl_context().last_error;
+    SL_TRY(sl_comm_allgather_blob(c, &v, sizeof(v), all.data()));
+    for (int p = 0; p < c->world; ++p)
+        if (all[p] != SL_OK) {
+            if (p == c->rank) { sl_context().last_error = msg; return mine; }
+            return sl_fail((sl_status)all[p], "rank %d failed: %s", p, sl_status_string((sl_status)all[p]));
+        }
+    return SL_OK;
+}
+
+// NeumannState::new on a row partition: `m` = this rank's rows [lo, hi) with global column ids (row_offset = lo, n_cols = n_global)
+sl_status state_init_partitioned(sl_neumann_state &st, sl_comm *c, const sl_matrix *m, const double *b, const double *initial_guess,
+                                 const sl_neumann_options *o)
+{
+    st.m = m; st.o = *o; st.n = m->n_rows; st.owned = true;
+    (void)hipGetDevice(&st.device);
+    const uint64_t n = st.n;
+    const sl_mem where = (sl_mem)o->mem;
+    hipStream_t s = sl_context().stream;
+    SL_TRY(sl_dist_create(c, m, &st.dist));                             // collective: row ranges, reach, pull plan
+    sl_dist *d = st.dist;
+    sl_status mine = SL_OK;
+    do {
+        if ((mine = sl_dist_vector_create(c, d->n_global, &d->t[0])) != SL_OK) break;
+        if ((mine = sl_dist_vector_create(c, d->n_global, &d->t[1])) != SL_OK) break;
+        if ((mine = sl_dist_vector_create(c, d->n_global, &d->x)) != SL_OK) break;
+    } while (0);
+    if (mine != SL_OK) return mine;                                     // the exchanges inside are collective: everybody fails alike or not at all
+    auto get = [&](DevBuf &dv, size_t bytes) { return dv.alloc_owned(bytes); };
+    do {
+        if ((mine = get(st.b, n * 8)) != SL_OK || (mine = get(st.dinv, n * 8)) != SL_OK || (mine = get(st.rhs, n * 8)) != SL_OK
+            || (mine = get(st.x, n * 8)) != SL_OK || (mine = get(st.scal, 64)) != SL_OK || (mine = get(st.ctlbuf, sizeof(sl_solve_ctl))) != SL_OK) break;
+        if (n && hipMemcpyAsync(st.b.p, b, n * 8, where == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "upload of b failed"); break; }
+        unsigned long long hs[4];
+        if ((mine = sl_matrix_diag_pass(m, st.dinv.as<double>(), hs)) != SL_OK) break;
+        if (hs[0] & 1ull) { mine = sl_fail(SL_NOT_DIAGONALLY_DOMINANT, "matrix is not row diagonally dominant (first failing row %llu)", hs[1] + d->lo); break; }
+        if (hs[0] & 2ull) { mine = sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2] + d->lo); break; }
+        if (hs[0] & 4ull) { mine = sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3] + d->lo); break; }
+        if ((mine = sl_launch_scale_rows(n, st.b.as<double>(), st.dinv.as<double>(), st.rhs.as<double>(), s)) != SL_OK) break;
+        if (o->start == SL_START_INITIAL_GUESS) {
+            if (!initial_guess) { mine = sl_fail(SL_INVALID_INPUT, "initial_guess is null"); break; }
+            if (hipMemcpyAsync(st.x.p, initial_guess, n * 8, where == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "upload of the initial guess failed"); break; }
+        } else if (o->start == SL_START_REFERENCE_DEFAULT) {
+            if (hipMemcpyAsync(st.x.p, st.rhs.p, n * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "copy failed"); break; }
+        } else if (hipMemsetAsync(st.x.p, 0, n * 8, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "memset failed"); break; }
+        if (hipMemcpyAsync(d->t[0].mine + d->lo, st.rhs.p, n * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "copy failed"); break; }   // current_term = rhs
+    } while (0);
+    SL_TRY(dist_agree(c, mine));
+    st.tpair[0] = d->t[0].mine; st.tpair[1] = d->t[1].mine;
+    st.t_cur = st.tpair[0]; st.t_nxt = st.tpair[1];
+    // the first term on every rank: "my rows are written" ticket, then the pieces this rank's columns reach
+    SL_TRY(sl_comm_launch_ticket(c, nullptr, nullptr, nullptr, 0, 0, SL_JUDGE_NONE, 0.0, s));
+    SL_TRY(sl_dist_pull(d, &d->t[0], s));
+    SL_HIP(hipStreamSynchronize(s));
+    if (sl_comm_failed(c)) return sl_fail(SL_DEVICE_ERROR, "a rank of the communicator did not arrive (first exchange)");
     return SL_OK;
 }
 
@@ -625,7 +694,7 @@ sl_status state_run(sl_neumann_state &st, double *term_norms, sl_neumann_result 
     double *scr = static_cast<double *>(sl_scratch(partial_bytes(m)));
     if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
     double *d_res = st.scal.as<double>();
-    DevBuf &dinv = st.dinv, &rhs = st.rhs, &x = st.x, &ta = st.ta, &tb = st.tb;
+    DevBuf &dinv = st.dinv, &rhs = st.rhs, &x = st.x;
     double *&t_cur = st.t_cur, *&t_nxt = st.t_nxt;
     const double *res_rhs = (o->residual == SL_RESIDUAL_REFERENCE_SCALED) ? rhs.as<double>() : st.b.as<double>();
     double &resn = st.resn, &tn = st.tn;
@@ -634,12 +703,24 @@ sl_status state_run(sl_neumann_state &st, double *term_norms, sl_neumann_result 
     uint64_t it = 0;
     sl_status status = SL_OK;
     sl_range_push("neumann solve loop");
+    sl_dist *D = st.dist;                                    // partitioned: sums over all ranks, pulls after every new term / before every residual
+    const uint64_t lo = D ? D->lo : 0;
+    double *d_loc = d_res + 2;                               // this rank's share of a sum (partitioned)
+    auto vec_of = [&](double *p) { return p == D->t[0].mine ? &D->t[0] : &D->t[1]; };
+    // gather x for a residual: my rows into the gathered solution, "written" ticket, pull
+    auto gather_x = [&](sl_solve_ctl *ctl, uint32_t rel) -> sl_status {
+        SL_HIP(hipMemcpyAsync(D->x.mine + lo, x.p, n * 8, hipMemcpyDeviceToDevice, s));
+        SL_TRY(sl_comm_launch_ticket(D->c, nullptr, nullptr, ctl, rel, 0, SL_JUDGE_LOCAL, 0.0, s));
+        return sl_dist_pull(D, &D->x, s);
+    };
 
     auto is_converged = [&]() { return state_converged(st); };
     auto update_residual = [&]() -> sl_status {                                         // neumann.rs:302-318
         sl_row_args a = row_args(m);
         a.gather = x.as<double>(); a.aux = res_rhs; a.out = nullptr; a.partials = scr; a.partials_slack = 4096; a.result = d_res;
+        if (D) { SL_TRY(gather_x(nullptr, 0)); a.gather = D->x.mine; a.result = d_loc; }
         SL_TRY(sl_launch_rows(a, order, SL_EPI_RESIDUAL, s));
+        if (D) SL_TRY(sl_comm_launch_ticket(D->c, d_loc, d_res, nullptr, 0, 0, SL_JUDGE_NONE, 0.0, s));
         double h;
         SL_TRY(read_scalars(d_res, &h, 1));
         resn = std::sqrt(h);
@@ -672,16 +753,20 @@ sl_status state_run(sl_neumann_state &st, double *term_norms, sl_neumann_result 
             if (p_terms < o->max_terms) {                                                // compute_next_term :252-277
                 if (p_terms > 0) {
                     sl_row_args a = row_args(m);
-                    a.gather = p_cur; a.dinv = dinv.as<double>(); a.out = p_nxt; a.x = x.as<double>();
-                    a.partials = scr; a.partials_slack = 4096; a.result = nullptr;
-                    a.ctl = d_ctl; a.gate_it = rel; a.ctl_slot = (uint32_t)plan.size(); a.ctl_mode = SL_JUDGE_LT; a.ctl_threshold = thr_series;
+                    a.gather = p_cur; a.dinv = dinv.as<double>(); a.out = p_nxt + lo; a.x = x.as<double>();
+                    a.partials = scr; a.partials_slack = 4096; a.result = D ? d_loc : nullptr;
+                    a.ctl = d_ctl; a.gate_it = rel; a.ctl_slot = (uint32_t)plan.size(); a.ctl_mode = D ? SL_JUDGE_LOCAL : SL_JUDGE_LT; a.ctl_threshold = thr_series;
                     status = sl_launch_rows(a, order, SL_EPI_NEUMANN, s);
+                    if (D && status == SL_OK) status = sl_comm_launch_ticket(D->c, d_loc, nullptr, d_ctl, rel, (uint32_t)plan.size(), SL_JUDGE_LT, thr_series, s);
+                    if (D && status == SL_OK) status = sl_dist_pull(D, vec_of(p_nxt), s);   // the new term's pieces this rank's columns reach
                     std::swap(p_cur, p_nxt);
                     plan.push_back({1, p_cur});
                 } else {
-                    status = sl_launch_axpy(n, 1.0, p_cur, x.as<double>(), s);           // x += term (k = 0)
+                    status = sl_launch_axpy(n, 1.0, p_cur + lo, x.as<double>(), s);      // x += term (k = 0)
                     if (status == SL_OK)
-                        status = sl_launch_sumsq_judged(n, p_cur, scr, d_ctl, rel, (uint32_t)plan.size(), SL_JUDGE_LT, thr_series, s);
+                        status = sl_launch_sumsq_judged(n, p_cur + lo, scr, d_ctl, rel, (uint32_t)plan.size(), D ? SL_JUDGE_LOCAL : SL_JUDGE_LT, thr_series, s,
+                                                        D ? d_loc : nullptr);
+                    if (D && status == SL_OK) status = sl_comm_launch_ticket(D->c, d_loc, nullptr, d_ctl, rel, (uint32_t)plan.size(), SL_JUDGE_LT, thr_series, s);
                     plan.push_back({0, p_cur});
                 }
                 ++p_terms;
@@ -690,7 +775,10 @@ sl_status state_run(sl_neumann_state &st, double *term_norms, sl_neumann_result 
                 sl_row_args a = row_args(m);
                 a.gather = x.as<double>(); a.aux = res_rhs; a.out = nullptr; a.partials = scr; a.partials_slack = 4096; a.result = nullptr;
                 a.ctl = d_ctl; a.gate_it = rel; a.ctl_slot = (uint32_t)plan.size(); a.ctl_mode = SL_JUDGE_LE_OR_NONFINITE; a.ctl_threshold = thr_tol;
-                status = sl_launch_rows(a, order, SL_EPI_RESIDUAL, s);
+                if (D) { status = gather_x(d_ctl, rel); a.gather = D->x.mine; a.result = d_loc; a.ctl_mode = SL_JUDGE_LOCAL; }
+                if (status == SL_OK) status = sl_launch_rows(a, order, SL_EPI_RESIDUAL, s);
+                if (D && status == SL_OK)
+                    status = sl_comm_launch_ticket(D->c, d_loc, nullptr, d_ctl, rel, (uint32_t)plan.size(), SL_JUDGE_LE_OR_NONFINITE, thr_tol, s);
                 plan.push_back({2, nullptr});
             }
         }
@@ -733,7 +821,8 @@ sl_status state_run(sl_neumann_state &st, double *term_norms, sl_neumann_result 
             }
             if (series_conv) { done = true; break; }                                     // :510-512
         }
-        t_nxt = (t_cur == ta.as<double>()) ? tb.as<double>() : ta.as<double>();
+        t_nxt = (t_cur == st.tpair[0]) ? st.tpair[1] : st.tpair[0];
+        if (D && sl_comm_failed(D->c)) { status = sl_fail(SL_DEVICE_ERROR, "a rank of the communicator did not arrive within the time limit"); break; }
         if (!in_sync || used != h_ctl.n_done) {
             status = sl_fail(SL_DEVICE_ERROR, "speculative solve loop out of step with the device (%zu of %u reductions consumed)",
                              used, h_ctl.n_done);
@@ -752,7 +841,8 @@ sl_status state_run(sl_neumann_state &st, double *term_norms, sl_neumann_result 
         }
     }
     // estimate_error_bounds, neumann.rs:321-347
-    if (o->compute_error_bounds && series_conv && terms > 1 && status == SL_OK) {
+    if (D && status == SL_OK && sl_comm_failed(D->c)) status = sl_fail(SL_DEVICE_ERROR, "a rank of the communicator did not arrive within the time limit");
+    if (o->compute_error_bounds && series_conv && terms > 1 && status == SL_OK && !D) {      // (needs ||rhs|| over all ranks: not offered for partitions)
         double h;
         if (sl_launch_sumsq(n, rhs.as<double>(), scr, d_res, s) == SL_OK && read_scalars(d_res, &h, 1) == SL_OK) {
             const double rhs_norm = std::sqrt(h);
@@ -795,9 +885,75 @@ __global__ void sl_update_rhs_kernel(uint64_t count, const uint64_t *idx, const 
     }
 }
 
+// current_term = rhs (neumann.rs:211, 372, 457) — on a partition: my rows, "written" ticket, the pieces my columns reach
+sl_status state_restart_series(sl_neumann_state &st)
+{
+    hipStream_t s = sl_context().stream;
+    st.t_cur = st.tpair[0]; st.t_nxt = st.tpair[1];
+    const uint64_t lo = st.dist ? st.dist->lo : 0;
+    SL_HIP(hipMemcpyAsync(st.t_cur + lo, st.rhs.p, st.n * 8, hipMemcpyDeviceToDevice, s));
+    if (st.dist) {
+        SL_TRY(sl_comm_launch_ticket(st.dist->c, nullptr, nullptr, nullptr, 0, 0, SL_JUDGE_NONE, 0.0, s));
+        SL_TRY(sl_dist_pull(st.dist, &st.dist->t[0], s));
+        SL_HIP(hipStreamSynchronize(s));
+        if (sl_comm_failed(st.dist->c)) return sl_fail(SL_DEVICE_ERROR, "a rank of the communicator did not arrive within the time limit");
+    }
+    return SL_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+sl_status sl_neumann_state_create_partitioned(sl_comm *comm, const sl_matrix *local, const double *b_local, const double *initial_guess_local,
+                                              const sl_neumann_options *o, sl_neumann_state **out)
+{
+    SL_ABI_BEGIN
+    if (!out) return sl_fail(SL_INVALID_INPUT, "out is null");
+    *out = nullptr;
+    if (!comm || !local || !b_local || !o) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_TRY(require_device());
+    sl_range trace_range("partitioned neumann state");
+    sl_neumann_state *st = new sl_neumann_state();
+    const sl_status s0 = state_init_partitioned(*st, comm, local, b_local, initial_guess_local, o);
+    if (s0 != SL_OK) { sl_neumann_state_destroy(st); return s0; }
+    *out = st;
+    return SL_OK;
+    SL_ABI_END
+}
+
+// K fused steps t <- (I - D^-1 A) t, x += t, ||t||^2 (a8 + a9) from the state's current term, no stop rule — the measurement loop
+// (bench.py); on a partition every step ends with the sum over all ranks and the pull of the new term's pieces.
+sl_status sl_neumann_state_run_steps(sl_neumann_state *st, uint64_t steps, double *last_norm2, float *elapsed_ms)
+{
+    SL_ABI_BEGIN
+    if (!st) return sl_fail(SL_INVALID_INPUT, "null argument");
+    hipStream_t s = sl_context().stream;
+    double *scr = static_cast<double *>(sl_scratch(partial_bytes(st->m)));
+    if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
+    sl_dist *D = st->dist;
+    const uint64_t lo = D ? D->lo : 0;
+    double *d_res = st->scal.as<double>(), *d_loc = d_res + 2;
+    sl_timer timer;
+    SL_TRY(timer.start(s));
+    for (uint64_t k = 0; k < steps; ++k) {
+        sl_row_args a = sl_matrix_row_args(st->m);
+        a.gather = st->t_cur; a.dinv = st->dinv.as<double>(); a.out = st->t_nxt + lo; a.x = st->x.as<double>();
+        a.partials = scr; a.partials_slack = 4096; a.result = D ? d_loc : d_res;
+        SL_TRY(sl_launch_rows(a, (sl_order)st->o.order, SL_EPI_NEUMANN, s));
+        if (D) {
+            SL_TRY(sl_comm_launch_ticket(D->c, d_loc, d_res, nullptr, 0, 0, SL_JUDGE_NONE, 0.0, s));
+            SL_TRY(sl_dist_pull(D, st->t_nxt == D->t[0].mine ? &D->t[0] : &D->t[1], s));
+        }
+        std::swap(st->t_cur, st->t_nxt);
+    }
+    const float ms = timer.stop();
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (last_norm2) SL_TRY(read_scalars(d_res, last_norm2, 1));
+    if (D && sl_comm_failed(D->c)) return sl_fail(SL_DEVICE_ERROR, "a rank of the communicator did not arrive within the time limit");
+    return SL_OK;
+    SL_ABI_END
+}
 
 sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *initial_guess,
                            const sl_neumann_options *o, double *x_out, double *term_norms,
@@ -840,6 +996,7 @@ void sl_neumann_state_destroy(sl_neumann_state *st)
 {
     if (!st) return;
     (void)hipStreamSynchronize(sl_context().stream);
+    if (st->dist) (void)sl_comm_host_barrier(st->dist->c);     // collective: no peer still pulls from the vectors this frees
     delete st;
 }
 
@@ -850,24 +1007,28 @@ sl_status sl_neumann_state_update_rhs(sl_neumann_state *st, uint64_t count, cons
     hipStream_t s = sl_context().stream;
     // neumann.rs:438-445: the first index out of range ends the call with IndexOutOfBounds — the updates before it stay applied and
     // the series state is NOT reset (the reference returns from inside the loop)
+    // partitioned state: a collective call with the SAME list of GLOBAL row indices on every rank; a rank applies the pairs of its rows
+    const uint64_t dim = st->dist ? st->dist->n_global : st->n, lo = st->dist ? st->dist->lo : 0, hi = lo + st->n;
     uint64_t good = count;
-    for (uint64_t k = 0; k < count; ++k) if (indices[k] >= st->n) { good = k; break; }
-    if (good) {
+    for (uint64_t k = 0; k < count; ++k) if (indices[k] >= dim) { good = k; break; }
+    std::vector<uint64_t> li; std::vector<double> ld;
+    for (uint64_t k = 0; k < good; ++k) if (indices[k] >= lo && indices[k] < hi) { li.push_back(indices[k] - lo); ld.push_back(deltas[k]); }
+    if (!li.empty()) {
+        const uint64_t cnt = li.size();
         DevBuf di, dd;
-        SL_TRY(di.alloc(good * 8)); SL_TRY(dd.alloc(good * 8));
-        SL_HIP(hipMemcpyAsync(di.p, indices, good * 8, hipMemcpyHostToDevice, s));
-        SL_HIP(hipMemcpyAsync(dd.p, deltas, good * 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(sl_update_rhs_kernel, dim3(1), dim3(1), 0, s, good, di.as<uint64_t>(), dd.as<double>(), st->dinv.as<double>(),
+        SL_TRY(di.alloc(cnt * 8)); SL_TRY(dd.alloc(cnt * 8));
+        SL_HIP(hipMemcpyAsync(di.p, li.data(), cnt * 8, hipMemcpyHostToDevice, s));
+        SL_HIP(hipMemcpyAsync(dd.p, ld.data(), cnt * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(sl_update_rhs_kernel, dim3(1), dim3(1), 0, s, cnt, di.as<uint64_t>(), dd.as<double>(), st->dinv.as<double>(),
                            st->rhs.as<double>(), st->x.as<double>(), st->b.as<double>());
         SL_HIP(hipGetLastError());
         SL_HIP(hipStreamSynchronize(s));                                   // the staging buffers go back to the pool
     }
     if (good < count)
         return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "Index %llu out of bounds (max %llu) in rhs_update", (unsigned long long)indices[good],
-                       (unsigned long long)(st->n ? st->n - 1 : 0));
+                       (unsigned long long)(dim ? dim - 1 : 0));
     // :456-459 reset series computation state
-    SL_HIP(hipMemcpyAsync(st->ta.p, st->rhs.p, st->n * 8, hipMemcpyDeviceToDevice, s));   // current_term = rhs
-    st->t_cur = st->ta.as<double>(); st->t_nxt = st->tb.as<double>();
+    SL_TRY(state_restart_series(*st));                                  // current_term = rhs
     st->terms = 0;
     st->series_conv = false;
     return SL_OK;
@@ -899,8 +1060,7 @@ sl_status sl_neumann_state_reset(sl_neumann_state *st)                      // S
     if (!st) return sl_fail(SL_INVALID_INPUT, "null argument");
     hipStream_t s = sl_context().stream;
     SL_HIP(hipMemsetAsync(st->x.p, 0, st->n * 8, s));
-    SL_HIP(hipMemcpyAsync(st->ta.p, st->rhs.p, st->n * 8, hipMemcpyDeviceToDevice, s));
-    st->t_cur = st->ta.as<double>(); st->t_nxt = st->tb.as<double>();
+    SL_TRY(state_restart_series(*st));
     st->resn = INFINITY; st->tn = 0.0; st->terms = 0; st->matvec = 0; st->step_launches = 0; st->resid_launches = 0; st->series_conv = false;
     return SL_OK;
     SL_ABI_END

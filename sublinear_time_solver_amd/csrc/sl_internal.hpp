@@ -234,7 +234,8 @@ struct sl_solve_ctl {
     uint32_t pad[2];
     double log[SL_CTL_LOG];
 };
-enum { SL_JUDGE_NONE = 0, SL_JUDGE_LT = 1, SL_JUDGE_LE_OR_NONFINITE = 2 };
+enum { SL_JUDGE_NONE = 0, SL_JUDGE_LT = 1, SL_JUDGE_LE_OR_NONFINITE = 2,
+       SL_JUDGE_LOCAL = 3 };   // gated like the others, but the sum only goes to `result`: a partitioned solve judges the sum over ALL ranks (sl_comm.hip)
 
 // Frontier threshold of the push: one value for all rows, or (rows != null) one per row — the degree-scaled admission rule of the
 // ACL push, r[u] >= epsilon * max(deg_u, 1) (forward_push.rs:93-99, graph/mod.rs:171-212), as a vector theta_u
@@ -291,7 +292,7 @@ uint32_t sl_row_grid(uint64_t n_slices);
 
 sl_status sl_launch_sumsq(uint64_t n, const double *x, double *partials, double *result, hipStream_t s);
 sl_status sl_launch_sumsq_judged(uint64_t n, const double *x, double *partials, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot,
-                                 int mode, double threshold, hipStream_t s);
+                                 int mode, double threshold, hipStream_t s, double *result = nullptr);
 sl_status sl_launch_ctl_reset(sl_solve_ctl *ctl, hipStream_t s);
 sl_status sl_launch_dot(uint64_t n, const double *x, const double *y, double *partials, double *result, hipStream_t s);
 sl_status sl_launch_axpy(uint64_t n, double alpha, const double *x, double *y, hipStream_t s);
@@ -308,3 +309,46 @@ sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long 
 // same rules over a plain CSR operator (used for A^T, which has no row-slice layout)
 sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx, const double *val, double *d_dinv,
                            unsigned long long h_status[4]);
+
+// ---- multi-GPU: communicator, partition, partitioned vectors (sl_comm.hip) -----------------------------------------------------
+#define SL_COMM_MAX_RANKS 16
+#define SL_COMM_RING 32
+#define SL_COMM_BLOB 512
+#define SL_COMM_MAGIC 0x534c434f4d4d3032ull      /* "SLCOMM02" */
+// the shared block of a communicator (POSIX shared memory, mapped by every rank, registered with the HIP runtime)
+struct sl_comm_shm {
+    volatile uint64_t magic, world;
+    volatile uint64_t arrive[SL_COMM_MAX_RANKS];                 // host barrier
+    volatile uint64_t blob_seq[SL_COMM_MAX_RANKS];               // host exchange of small blobs (IPC handles, row ranges)
+    volatile unsigned char blob[SL_COMM_MAX_RANKS][SL_COMM_BLOB];
+    uint64_t ready[SL_COMM_MAX_RANKS][16];                       // device side: one 128-byte line per rank, [0] = last published ticket
+    double value[SL_COMM_RING][SL_COMM_MAX_RANKS];               // device side: the values published with the tickets (ring)
+    uint64_t error;                                              // a wait timed out (rank + 1)
+};
+struct sl_comm {
+    int rank = 0, world = 1, device = 0, fd = -1;
+    std::string path;
+    sl_comm_shm *h_shm = nullptr, *d_shm = nullptr;
+    size_t shm_bytes = 0;
+    bool registered = false;
+    uint64_t barrier_count = 0, blob_count = 0, ticket = 0;      // advanced in the same order on every rank
+};
+struct sl_dist_vector { uint64_t n = 0; double *mine = nullptr; std::vector<double *> peer; };
+struct sl_dist {
+    sl_comm *c = nullptr;
+    uint64_t n_global = 0, lo = 0, hi = 0, pull_bytes = 0;
+    std::vector<uint64_t> bounds;                                // world + 1
+    struct piece { int rank; uint64_t lo, hi; };
+    std::vector<piece> need;                                     // what this rank pulls per exchange: global index ranges of its peers' rows
+    sl_dist_vector t[2], x;                                      // gathered term vectors (ping-pong) and gathered solution
+};
+sl_status sl_comm_host_barrier(sl_comm *c);
+sl_status sl_comm_allgather_blob(sl_comm *c, const void *mine, size_t bytes, void *all);
+sl_status sl_comm_launch_ticket(sl_comm *c, const double *local, double *result, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot, int mode,
+                                double thr, hipStream_t s);
+bool sl_comm_failed(const sl_comm *c);
+sl_status sl_dist_create(sl_comm *c, const sl_matrix *local, sl_dist **out);
+void sl_dist_destroy(sl_dist *d);
+sl_status sl_dist_vector_create(sl_comm *c, uint64_t n_global, sl_dist_vector *v);
+void sl_dist_vector_destroy(sl_comm *c, sl_dist_vector *v);
+sl_status sl_dist_pull(const sl_dist *d, sl_dist_vector *v, hipStream_t s);

@@ -881,6 +881,7 @@ __global__ __launch_bounds__(1024) void sl_judge_reduce_kernel(const double *par
         double t = red[0];
         for (int w = 1; w < 16; ++w) t += red[w];
         if (result) result[0] = t;
+        if (mode == SL_JUDGE_LOCAL) return;                 // partitioned solve: the sum over all ranks is logged and judged by sl_comm_ticket_kernel
         ctl->log[slot] = t;
         ctl->n_done = slot + 1;
         bool stop = false;
@@ -1208,11 +1209,11 @@ sl_status sl_launch_sumsq(uint64_t n, const double *x, double *partials, double 
     return SL_OK;
 }
 sl_status sl_launch_sumsq_judged(uint64_t n, const double *x, double *partials, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot,
-                                 int mode, double threshold, hipStream_t s)
+                                 int mode, double threshold, hipStream_t s, double *result)
 {
     const uint32_t g = vec_grid(n);
     hipLaunchKernelGGL((sl_reduce_kernel<0>), dim3(g), dim3(256), 0, s, n, x, x, partials);
-    hipLaunchKernelGGL(sl_judge_reduce_kernel, dim3(1), dim3(1024), 0, s, partials, g, (double *)nullptr, ctl, gate_it, slot, mode, threshold);
+    hipLaunchKernelGGL(sl_judge_reduce_kernel, dim3(1), dim3(1024), 0, s, partials, g, result, ctl, gate_it, slot, mode, threshold);
     SL_HIP(hipGetLastError());
     return SL_OK;
 }

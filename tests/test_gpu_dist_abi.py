@@ -1,0 +1,33 @@
+"""Multi-GPU behind the C ABI: tests/c/dist_smoke.c — strict C99, no Python in the solve — forks one process per
+rank (the ranks share the box's GPU), partitions a seeded system by rows, and solves it through sl_comm_* /
+sl_neumann_state_create_partitioned / _update_rhs / _reset / _run / _solution; the parent compares with the one-GPU solve through
+the same ABI: same iteration count, same convergence flag, solution bit for bit."""
+import os
+import subprocess
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def dist_exe(tmp_path_factory):
+    exe = tmp_path_factory.mktemp("dist") / "dist_smoke"
+    pkg = ROOT / "sublinear_time_solver_amd"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c" / "dist_smoke.c"),
+                        "-o", str(exe), f"-L{pkg}", "-lsublinear_hip", "-lm", f"-Wl,-rpath,{pkg}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.parametrize("world,n,w,uneven", [(2, 20000, 300, False),       # neighbour halo only
+                                              (3, 50000, 700, True),        # three ranks, unequal row ranges
+                                              (2, 30000, 10**9, False),     # columns all over the matrix: every rank pulls everything
+                                              (4, 40000, 15000, True),      # reach beyond the next neighbour
+                                              (1, 5000, 50, False)])        # a communicator of one
+def test_partitioned_solve_through_the_c_abi(gpu, dist_exe, world, n, w, uneven):
+    env = dict(os.environ, SL_COMM_TIMEOUT_MS="30000")
+    r = subprocess.run([str(dist_exe), str(world), str(n), str(w)] + (["uneven"] if uneven else []), capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "dist_smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
