@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark: fused push/Neumann iterations on S-DD(n = 10M per GPU, 16 nnz/row).
+"""bench.py — headline benchmark: fused push/Neumann iterations on S-DD(n = 10M per GPU, 16 nnz/row), SURVEY §8(d)'s input:
+uniformly random columns (`--bandwidth 0`, the default).  The same step on the banded variant of the recipe (half-width 4096, the
+"locality" form of config 5) is measured in the same run and reported with its own full roofline block (`roofline_banded`).
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
@@ -7,8 +9,10 @@ A "step" is one pass of the hot path over the whole (synthetic) system: the fuse
     t' = t - dinv .* (A t);  x += t';  ||t'||^2
 (NeumannState::apply_iteration_matrix + compute_next_term, src/solver/neumann.rs:252-299), inputs
 resident in HBM before the timed region.  value = nnz * K * N / max-over-ranks time.
-Weak scaling: every rank owns `--n` rows of an N*n-row system (row-range partition, one exchange of
-the term vector per step: all-gather for uniform columns, neighbour halo for banded ones).
+Weak scaling: every rank owns `--n` rows of an N*n-row system (row-range partition, one exchange of the term vector per step).
+N > 1 runs through the library's own communicator by default (`--exchange abi`: sl_comm + partitioned NeumannState behind the C ABI —
+IPC-mapped vectors pulled over xGMI, the norm summed over all ranks every step); `--exchange p2p | allreduce` runs the exchange over
+torch.distributed / RCCL instead (grouped send/recv of the halo strips, or the all-reduce form; all-gather for uniform columns).
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
 """
@@ -25,6 +29,24 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+
+LAYOUTS = {0: "row slices", 1: "column panels, dynamic tiles (gathers from L2)", 2: "column panels, paced persistent blocks (gathers from L2)"}
+
+
+def recorded_traffic(n, k, w):
+    """HBM-side bytes per step of the step kernel from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by
+    tools/prof_summary.py) — a RECORDED figure of an earlier profiled run of this configuration, not a measurement of this run."""
+    tf = ROOT / "profiles" / "pmc_traffic.json"
+    try:
+        rec = json.loads(tf.read_text())
+        recs = rec.get("records", {"x": rec})
+        for r in recs.values():
+            if r.get("n") == n and r.get("k") == k and r.get("bandwidth") == w:
+                return r.get("hbm_bytes_per_step", r.get("hbm_bytes_per_launch")), f"profiles/pmc_traffic.json [{r.get('tag')}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this configuration; not measured in this run)"
+    except Exception:
+        pass
+    return None, None
 
 
 def algorithmic_bytes(n_rows: int, nnz: int) -> int:
@@ -93,13 +115,87 @@ def column_structure_sweep(lib, L, torch, dev, n, k, seed, order, bandwidths, st
         per = ms.value / steps
         mi = L.MatrixInfo()
         L.check(lib.sl_matrix_get_info(h, C.byref(mi)))
-        out["uniform" if w == 0 else f"w{w}"] = {"ms_per_step": per, "nnz_iter_per_s": n * k / (per * 1e-3),
-                                                   "roofline_frac": algorithmic_bytes(n, n * k) / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                   "layout": "column panels (gathers from L2)" if mi.column_panels else "row slices"}
+        ach = algorithmic_bytes(n, n * k) / (per * 1e-3) / 1e9
+        out["uniform" if w == 0 else f"w{w}"] = {"ms_per_step": per, "nnz_iter_per_s": n * k / (per * 1e-3), "achieved_GBps": ach,
+                                                   "roofline_frac": ach / HBM_PEAK_GBS,
+                                                   "layout": LAYOUTS[int(mi.column_panels)] if mi.column_panels else "row slices"}
         lib.sl_matrix_destroy(h)
         del dinv, ta, tb, x, b
         torch.cuda.empty_cache()
     return out
+
+
+def main_abi(args, world, rank, local_rank):
+    """N > 1 through the C ABI alone (sl_comm + partitioned NeumannState): torch only provides the device buffers the generator
+    writes into.  Barrier = sl_comm_barrier (drains the stream, then all ranks meet), MAX over ranks through sl_comm_allgather."""
+    import torch
+    from sublinear_time_solver_amd import _lib as L
+    from sublinear_time_solver_amd import Communicator
+    local_rank %= max(1, torch.cuda.device_count())         # fewer devices than ranks (test boxes): ranks share a GPU, which the communicator supports
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = L.load()
+    L.check(lib.sl_set_device(local_rank))
+    comm = Communicator(rank, world, f"bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"[:60].replace("/", "_"))
+    n_local, k = args.n, args.k
+    n_global = n_local * world
+    w = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
+    lo, hi = rank * n_local, (rank + 1) * n_local
+    rp = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
+    ci = torch.empty(n_local * k, dtype=torch.int32, device=dev)
+    va = torch.empty(n_local * k, dtype=torch.float64, device=dev)
+    bb = torch.empty(n_local, dtype=torch.float64, device=dev)
+    L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), bb.data_ptr()))
+    h = C.c_void_p()
+    L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, lo, 0, C.byref(h)))
+    del rp, ci, va
+    torch.cuda.empty_cache()
+    info = L.MatrixInfo()
+    L.check(lib.sl_matrix_get_info(h, C.byref(info)))
+    o = L.NeumannOptions()
+    lib.sl_neumann_options_default(C.byref(o))
+    o.order, o.mem, o.start = args.order, L.SL_MEM_DEVICE, L.SL_START_REFERENCE_DEFAULT      # x0 = D^-1 b like the one-GPU bench loop (x = t0)
+    st = C.c_void_p()
+    L.check(lib.sl_neumann_state_create_partitioned(comm._h, h, bb.data_ptr(), None, C.byref(o), C.byref(st)))
+    nrm, ms = C.c_double(0.0), C.c_float(0.0)
+    if args.warmup:
+        L.check(lib.sl_neumann_state_run_steps(st, args.warmup, C.byref(nrm), C.byref(ms)))
+    comm.barrier()
+    torch.cuda.synchronize(dev)
+    t_start = time.perf_counter()
+    L.check(lib.sl_neumann_state_run_steps(st, args.steps, C.byref(nrm), C.byref(ms)))     # returns when the K steps are done on this rank
+    torch.cuda.synchronize(dev)
+    comm.barrier()
+    elapsed = max(comm.allgather_f64(time.perf_counter() - t_start))
+    dev_ms = max(comm.allgather_f64(float(ms.value)))
+    if rank == 0:
+        nnz_total = n_global * k
+        per_launch_bytes = algorithmic_bytes(n_local, n_local * k)
+        launch_ms = dev_ms / args.steps
+        achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
+        value = nnz_total * args.steps / elapsed
+        out = {
+            "metric": "push_iterations_x_nnz_per_sec", "value": value, "unit": "nnz*iter/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"S-DD(n={n_local} rows/GPU, nnz/row={k}, seed={args.seed}, "
+                                   f"{'uniform columns' if w == 0 else f'band half-width {w}'}) fused Neumann/push step, fp64, "
+                                   f"{world}xMI355X row-partitioned (BASELINE configs[4] per-GPU shape)",
+                       "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w,
+                       "order": "csr_sequential" if args.order == 0 else "simd4",
+                       "exchange": "abi: sl_comm (IPC-mapped vectors pulled over xGMI, norm summed over all ranks every step)", "partition": f"rows{world}",
+                       "norm_allreduce_every": 1, "rows_iter_per_s": value / k, "last_term_norm": float(nrm.value) ** 0.5},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "traffic_source": None,
+                         "column_structure": "uniform over all columns (SURVEY 8(d) S-DD)" if w == 0 else f"band half-width {w}",
+                         "kernel": LAYOUTS.get(int(info.column_panels), "row slices") if info.column_panels else "row slices",
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": launch_ms,
+                         "note": "per GPU: one step = fused kernel + all-rank ticket + pulls; launch_ms = the slowest rank's device time per step"},
+        }
+        print(json.dumps(out), flush=True)
+    lib.sl_neumann_state_destroy(st)
+    lib.sl_matrix_destroy(h)
+    comm.close()
 
 
 def main():
@@ -116,8 +212,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the cpu_baseline leg
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary column-structure measurements")
-    ap.add_argument("--exchange", choices=["p2p", "allreduce"], default="p2p",
-                    help="banded systems, N > 1: neighbour sends of the boundary strips (default) or ONE all-reduce over a zero-filled compact strip buffer")
+    ap.add_argument("--exchange", choices=["abi", "p2p", "allreduce"], default="abi",
+                    help="N > 1: abi = the library's own communicator and partitioned state behind the C ABI (default); p2p / allreduce = "
+                         "torch.distributed over RCCL: neighbour sends of the boundary strips, or ONE all-reduce over a zero-filled compact strip buffer")
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: do not split boundary / interior rows")
     ap.add_argument("--force-split", action="store_true", help="testing: use the boundary / interior split even on one GPU")
     args = ap.parse_args()
@@ -139,6 +236,14 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
+    if world > 1 and args.exchange == "abi" and not args.force_split:
+        try:
+            return main_abi(args, world, rank, local_rank)
+        except Exception as e:                      # collective by construction (every wait in the communicator is bounded): all ranks land here together
+            print(f"[bench rank {rank}] ABI communicator path failed ({e}); falling back to torch.distributed / RCCL", file=sys.stderr, flush=True)
+            args.exchange = "p2p"
+    if args.exchange == "abi":
+        args.exchange = "p2p"
     # SL_BENCH_BACKEND=gloo is a TEST mode: ranks may share a GPU and the exchanges are staged through the host
     backend = os.environ.get("SL_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -265,15 +370,7 @@ def main():
         per_launch_bytes = algorithmic_bytes(n_local, n_local * k)
         launch_ms = kern_ms if kern_ms is not None else dev_ms / args.steps
         achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tf = ROOT / "profiles" / "pmc_traffic.json"
-        if tf.exists():
-            try:
-                rec = json.loads(tf.read_text())
-                if rec.get("n") == n_local and rec.get("k") == k and rec.get("bandwidth") == w:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = recorded_traffic(n_local, k, w)
         out = {
             "metric": "push_iterations_x_nnz_per_sec", "value": value, "unit": "nnz*iter/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -287,15 +384,27 @@ def main():
                        "norm_allreduce_every": reduce_every if (world > 1 or loopback) else None,
                        "rows_iter_per_s": value / k, "last_term_norm": term_norm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "column_structure": "uniform over all columns (SURVEY 8(d) S-DD)" if w == 0 else f"band half-width {w}",
+                         "kernel": LAYOUTS.get(int(info.column_panels), "row slices") if info.column_panels else ("LDS-window band kernel" if 0 < w <= 9400 else "row-slice general kernel"),
                          "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": launch_ms,
                          "timed_region_device_ms_per_step": dev_ms / args.steps,     # HIP events around the K timed steps, same stream
                          "host_enqueue_ms_per_step": enqueue_s * 1e3 / args.steps,
-                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+                         # algorithmic bytes count 12 B per entry; 16-bit column offsets move 10, so this ratio can exceed 1 on banded inputs
+                         "algorithmic_over_copy_ceiling_6290": achieved / 6290.0},
         }
         if world == 1 and not args.no_sweep:
-            others = [v for v in (0, 512, 32768) if v != w]
-            out["config"]["other_column_structures"] = column_structure_sweep(lib, L, torch, dev, n_local, k, args.seed, args.order, others)
+            others = [v for v in (0, BANDED_BANDWIDTH, 512, 32768) if v != w]
+            sweep = column_structure_sweep(lib, L, torch, dev, n_local, k, args.seed, args.order, others)
+            out["config"]["other_column_structures"] = sweep
+            bk = f"w{BANDED_BANDWIDTH}"
+            if bk in sweep:     # the banded variant of the recipe: a full roofline block of its own, same run, same box
+                tb_, tsrc = recorded_traffic(n_local, k, BANDED_BANDWIDTH)
+                out["roofline_banded"] = {"bound": "hbm", "achieved": sweep[bk]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": sweep[bk]["roofline_frac"], "traffic": tb_, "traffic_source": tsrc,
+                                          "column_structure": f"band half-width {BANDED_BANDWIDTH}", "kernel": "LDS-window band kernel",
+                                          "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": sweep[bk]["ms_per_step"],
+                                          "nnz_iter_per_s": sweep[bk]["nnz_iter_per_s"]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 import subprocess
@@ -313,9 +422,11 @@ def main():
         dist.destroy_process_group()
 
 
-# default column structure of the headline run: band half-width 4096 ~ 1.3 sqrt(n), the bandwidth
-# class of a naturally ordered 2-D grid operator; 0 = uniform over all columns (reported as a secondary figure)
-DEFAULT_BANDWIDTH = 4096
+# default column structure of the headline run: 0 = uniform over all columns — S-DD exactly as SURVEY §8(d) writes it (the reference
+# generators' recipe j = s mod n).  The banded variant (half-width 4096 ~ 1.3 sqrt(n), a naturally ordered 2-D grid operator; the
+# "locality" form of config 5) gets its own full roofline block in the same line.
+DEFAULT_BANDWIDTH = 0
+BANDED_BANDWIDTH = 4096      # the banded variant reported next to the headline (roofline_banded)
 
 if __name__ == "__main__":
     main()

@@ -4,9 +4,9 @@ One hot path of ruvnet/sublinear-time-solver rebuilt for gfx950: hand-written HI
 C ABI (include/sublinear_hip.h, csrc/), plus this host-side mirror of the reference's solver interfaces.
 """
 from ._lib import SolverError, load  # noqa: F401
-from .solver import (ConjugateGradientSolver, GaussSouthwellSolver, NeumannSolver, NeumannState, PushSolver, QuerySession, SolverOptions, SolverResult,  # noqa: F401
+from .solver import (Communicator, ConjugateGradientSolver, GaussSouthwellSolver, NeumannSolver, NeumannState, PushSolver, QuerySession, SolverOptions, SolverResult,  # noqa: F401
                      SparseMatrix, SublinearSolver, estimate_entry)
 from . import generators  # noqa: F401
 
-__all__ = ["SolverError", "load", "ConjugateGradientSolver", "GaussSouthwellSolver", "NeumannSolver", "NeumannState", "PushSolver", "QuerySession", "SolverOptions", "SolverResult", "SparseMatrix",
+__all__ = ["SolverError", "load", "Communicator", "ConjugateGradientSolver", "GaussSouthwellSolver", "NeumannSolver", "NeumannState", "PushSolver", "QuerySession", "SolverOptions", "SolverResult", "SparseMatrix",
            "SublinearSolver", "estimate_entry", "generators"]

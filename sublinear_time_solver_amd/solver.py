@@ -232,6 +232,20 @@ class NeumannSolver:
         L.check(L.load().sl_neumann_state_create(matrix._h, L.ptr(b), L.ptr(guess), C.byref(o), C.byref(h)))
         return NeumannState(h, matrix, self.max_terms, options)
 
+    def initialize_partitioned(self, comm: "Communicator", local_rows: SparseMatrix, b_local, options: Optional[SolverOptions] = None) -> "NeumannState":
+        """NeumannState::new over a row partition (sl_neumann_state_create_partitioned): `local_rows` = this rank's rows with global
+        column ids (SparseMatrix.from_csr(..., row_offset=lo)), `b_local` its part of the right-hand side.  Collective."""
+        options = options or SolverOptions()
+        b = _f64(b_local)
+        if b.size != local_rows.rows():
+            raise SolverError(5, f"expected {local_rows.rows()}, actual {b.size} in neumann_initialization")
+        o, guess = self._options(local_rows, b, options)
+        h = C.c_void_p()
+        L.check(L.load().sl_neumann_state_create_partitioned(comm._h, local_rows._h, L.ptr(b), L.ptr(guess), C.byref(o), C.byref(h)))
+        st = NeumannState(h, local_rows, self.max_terms, options)
+        st._comm = comm
+        return st
+
     def update_rhs(self, state: "NeumannState", delta_b) -> None:
         state.update_rhs(delta_b)
 
@@ -278,6 +292,39 @@ class NeumannSolver:
                             r.error_bound if r.error_bound >= 0 else None, stats, tn[: int(r.terms_computed)].copy())
 
 
+class Communicator:
+    """sl_comm: one process per GPU of one node; every rank of the job passes the same `name` (the rendezvous is a shared-memory
+    block that disappears once all ranks have joined).  No torch / MPI / RCCL involved (include/sublinear_hip.h, multi-GPU)."""
+
+    def __init__(self, rank: int, world: int, name: str):
+        self._h = C.c_void_p()
+        L.check(L.load().sl_comm_create(int(rank), int(world), name.encode(), C.byref(self._h)))
+        self.rank, self.world = int(rank), int(world)
+
+    def barrier(self) -> None:
+        L.check(L.load().sl_comm_barrier(self._h))
+
+    def allgather_u64(self, value: int) -> list:
+        out = (C.c_uint64 * self.world)()
+        L.check(L.load().sl_comm_allgather_u64(self._h, int(value), out))
+        return [int(v) for v in out]
+
+    def allgather_f64(self, value: float) -> list:
+        bits = int(np.array([value], dtype=np.float64).view(np.uint64)[0])
+        return [float(np.array([b], dtype=np.uint64).view(np.float64)[0]) for b in self.allgather_u64(bits)]
+
+    def close(self) -> None:
+        if self._h:
+            L.load().sl_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class NeumannState:
     """NeumannState (src/solver/neumann.rs:95-137) living on the device behind sl_neumann_state_*: the matrix layout, D^-1 and the
     vectors stay resident across update_rhs / run / reset — what an incremental caller of the reference's SolverAlgorithm holds."""
@@ -315,6 +362,12 @@ class NeumannState:
         x = np.empty(self._matrix.rows(), dtype=np.float64)
         L.check(L.load().sl_neumann_state_solution(self._h, L.ptr(x), L.SL_MEM_HOST))
         return x
+
+    def run_steps(self, steps: int):
+        """`steps` fused steps without the stop rule (the measurement loop): returns (||t||^2 of the last step, device ms)"""
+        nrm, ms = C.c_double(0.0), C.c_float(0.0)
+        L.check(L.load().sl_neumann_state_run_steps(self._h, int(steps), C.byref(nrm), C.byref(ms)))
+        return nrm.value, ms.value
 
     def reset(self) -> None:
         """SolverState::reset (neumann.rs:367-378): solution = 0, current term = the (updated) scaled rhs, counters cleared"""

@@ -24,7 +24,7 @@ def test_bench_line_contract_and_split_equivalence(gpu):
                 "dtype", "data", "config", "roofline"):
         assert key in a
     assert a["n_gpus"] == 1 and a["steps"] == 7 and a["dtype"] == "f64" and a["scaling"] == "weak" and a["vs_baseline"] is None
-    assert set(a["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and a["roofline"]["bound"] == "hbm"
+    assert set(a["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "column_structure"} and a["roofline"]["bound"] == "hbm"
     assert abs(a["roofline"]["frac"] - a["roofline"]["achieved"] / 8000.0) < 1e-12 and "workload" in a["config"]
     b = _bench("--force-split")
     assert b["config"]["exchange"] == "halo+overlap"
@@ -49,8 +49,10 @@ def _bench_two_ranks(n_per_rank, w, *extra):
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("w,extra,exchange", [(512, (), "halo+overlap"), (512, ("--no-overlap",), "halo"), (0, (), "allgather"),
-                                              (512, ("--exchange", "allreduce"), "halo_allreduce+overlap")])
+@pytest.mark.parametrize("w,extra,exchange", [(512, ("--exchange", "p2p"), "halo+overlap"), (512, ("--exchange", "p2p", "--no-overlap"), "halo"),
+                                              (0, ("--exchange", "p2p"), "allgather"),
+                                              (512, ("--exchange", "allreduce"), "halo_allreduce+overlap"),
+                                              (512, (), "abi"), (0, (), "abi")])       # the default: the library's own communicator (C ABI)
 def test_bench_two_ranks_reproduce_the_single_rank_iteration(gpu, w, extra, exchange):
     """bench.py at world size 2 (row slices at a non-zero row offset, halo / all-gather exchange, boundary-first overlap,
     norm all-reduce) must run the same iteration as one rank owning all rows: same last term norm"""
@@ -59,7 +61,8 @@ def test_bench_two_ranks_reproduce_the_single_rank_iteration(gpu, w, extra, exch
     assert one.returncode == 0, one.stderr[-2000:]
     a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     b = _bench_two_ranks(150000, w, *extra)
-    assert b["n_gpus"] == 2 and b["config"]["n_global"] == 300000 and b["config"]["exchange"] == exchange and b["scaling"] == "weak"
+    assert b["n_gpus"] == 2 and b["config"]["n_global"] == 300000 and b["scaling"] == "weak"
+    assert b["config"]["exchange"].startswith("abi: sl_comm") if exchange == "abi" else b["config"]["exchange"] == exchange
     na, nb = a["config"]["last_term_norm"], b["config"]["last_term_norm"]
     assert na > 0 and abs(na - nb) <= 1e-12 * na
     assert abs(b["value"] - 300000 * 16 * 7 / (b["ms_per_step"] * 7e-3)) <= 1e-6 * b["value"]     # whole-job units / max-over-ranks time
