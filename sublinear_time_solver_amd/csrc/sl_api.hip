@@ -205,7 +205,7 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
     memset(&a, 0, sizeof(a));
     a.slice_ptr = m->d_slice_ptr; a.row_len = m->d_row_len; a.cols = m->d_cols; a.cols16 = m->d_cols16; a.vals = m->d_vals;
     a.n_rows = m->n_rows; a.n_cols = m->n_cols; a.n_slices = m->n_slices; a.row_offset = m->row_offset;
-    a.bandwidth = m->bandwidth; a.uniform_width = m->uniform_width;
+    a.bandwidth = m->bandwidth; a.uniform_width = m->uniform_width; a.max_row_nnz = m->max_row_nnz;
     a.csr_ptr = m->d_row_ptr; a.csr_idx = m->d_col_idx; a.csr_val = m->d_values;
     a.long_rows = m->d_long_rows; a.n_long = (uint32_t)m->n_long;
     a.pan_tile_ptr = m->d_pan_tile_ptr; a.pan_row = m->d_pan_row; a.pan_col = m->d_pan_col; a.pan_val = m->d_pan_val;

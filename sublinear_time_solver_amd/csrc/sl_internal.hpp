@@ -259,6 +259,7 @@ struct sl_row_args {
     uint64_t n_rows, n_cols, n_slices, row_offset;
     uint64_t bandwidth;   // ~0 = unknown / do not use the LDS band kernel
     uint32_t uniform_width;
+    uint32_t max_row_nnz;     // longest row kept in the slice layout (selects the multi-pass window kernel: rows of at most 16 entries)
     // column-panel layout (null unless the matrix carries one)
     const uint32_t *pan_tile_ptr; const uint16_t *pan_row; const uint32_t *pan_col; const double *pan_val;
     uint32_t n_pan_tiles;

@@ -544,6 +544,158 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_ro
     sl_block_partials<EPI, NW>(a, red, lane, wave, lb, a.part_stride, part0, part1);
 }
 
+// ---- multi-pass window kernel: bands too wide for ONE LDS window ------------------------------------------------------------
+// Half-widths beyond ~9.5 K (window > 158 KiB) used to fall back to the general kernel, whose gathers go through L1 / L2 at one
+// lane per cycle: w = 32768 43 %, the 7-point stencil on 215^3 69 % of the roofline.  Here a block of 8 waves keeps the matrix
+// bytes of its rows — SPW slices per wave, every row at most 4 * MAXQ entries — in REGISTERS (one coalesced pass over HBM, as
+// in the band kernel), and walks the window [r0 - w, r0 + R + w) segment by segment: a segment of SL_MP_SEG columns (64 KiB) is
+// staged into one of two LDS buffers with direct global -> LDS loads while the other one is being consumed; every lane then adds
+// those of its entries whose column lies in the segment.  Entries of a row ascend in column and segments ascend, so a row's
+// products are still added left to right, one by one, by the lane that owns the row: the bits of the sequential reference loop
+// (sparse.rs:187-203).  Segments none of the block's entries fall into are skipped (one 64-bit occupancy mask per block: the three
+// clusters of a 3-D stencil stage 6 segments instead of 12), and inside a segment an entry position k is only visited when some
+// lane of the wave has it in range.  Staged bytes: (R + 2 w) * 8 per R rows out of the L2 (neighbouring blocks stage overlapping
+// windows; the union is read from HBM once), R = 8 * SPW * 64 rows — 2048 at 16 entries per row.
+#define SL_MP_SEG 8192u                       // columns per segment: 64 KiB
+#define SL_MP_WAVES 8
+template <int EPI, int MAXQ, int SPW>
+__global__ __launch_bounds__(SL_MP_WAVES * 64, 2) void sl_mpass_kernel(sl_row_args a, uint32_t nb8, uint32_t w)
+{
+    extern __shared__ __attribute__((aligned(16))) double mp_seg[];          // two segment buffers
+    __shared__ double red[2 * SL_MP_WAVES];
+    __shared__ unsigned long long occ;
+    if (a.ctl && a.gate_it > a.ctl->stop_after) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);        // XCD-aware: an XCD's blocks own one contiguous row range
+    constexpr uint64_t R = (uint64_t)SL_MP_WAVES * SPW * SL_SLICE;
+    const uint64_t r0 = (uint64_t)lb * R;
+    double part0 = 0.0, part1 = 0.0;
+    if (threadIdx.x == 0) occ = 0ull;
+    __syncthreads();
+    if (r0 < a.n_rows) {                                                     // block-uniform
+        const uint64_t s0 = (uint64_t)lb * SPW * SL_MP_WAVES + wave;         // this wave's slices: s0, s0 + 8, ...
+        const uint64_t g0 = a.row_offset + r0;
+        const uint64_t win_lo = (g0 > w ? g0 - w : 0) & ~1ull;
+        uint64_t win_hi = g0 + R + w;
+        if (win_hi > a.n_cols) win_hi = a.n_cols;
+        if (win_hi < win_lo) win_hi = win_lo;
+        const uint32_t nseg = (uint32_t)((win_hi - win_lo + SL_MP_SEG - 1) / SL_MP_SEG);      // <= 64 (checked by the launcher)
+        const u32x4 *__restrict__ cq = reinterpret_cast<const u32x4 *>(a.cols);
+        const f64x2 *__restrict__ vq = reinterpret_cast<const f64x2 *>(a.vals);
+        // ---- the block's matrix bytes into registers; column = position in the window (0 for slots that are never added) ----
+        uint32_t col[SPW][MAXQ * 4], len[SPW];
+        double val[SPW][MAXQ * 4], sum[SPW], e_d[SPW], e_x[SPW], e_aux[SPW], e_own[SPW];
+        unsigned long long mymask = 0ull;
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) {
+            const uint64_t s = s0 + (uint64_t)j * SL_MP_WAVES;
+            const uint64_t i = s * SL_SLICE + lane;
+            len[j] = 0u; sum[j] = 0.0; e_d[j] = 0.0; e_x[j] = 0.0; e_aux[j] = 0.0; e_own[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < MAXQ * 4; ++k) { col[j][k] = 0u; val[j][k] = 0.0; }
+            if (s < a.n_slices) {                                            // wave-uniform
+                const uint32_t h0 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s]), h1 = __builtin_amdgcn_readfirstlane(a.slice_ptr[s + 1]);
+                const uint32_t lr = a.row_len[i];
+                len[j] = (i < a.n_rows && lr != SL_LONG_SENTINEL) ? lr : 0u;
+#pragma unroll
+                for (int q = 0; q < MAXQ; ++q) {
+                    const uint32_t h = h0 + 2u * (uint32_t)q;
+                    if (h + 1 < h1) {
+                        const u32x4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.cols + (uint64_t)h * 128) + lane);
+                        const f64x2 va = __builtin_nontemporal_load(&vq[(uint64_t)h * 64 + lane]), vb = __builtin_nontemporal_load(&vq[(uint64_t)(h + 1) * 64 + lane]);
+                        col[j][4 * q] = c.x; col[j][4 * q + 1] = c.y; col[j][4 * q + 2] = c.z; col[j][4 * q + 3] = c.w;
+                        val[j][4 * q] = va.x; val[j][4 * q + 1] = va.y; val[j][4 * q + 2] = vb.x; val[j][4 * q + 3] = vb.y;
+                    } else if (h < h1) {                                     // the slice's odd last pair block: entries 4q, 4q + 1 only
+                        const u32x2 c2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(a.cols + (uint64_t)h * 128) + lane);
+                        const f64x2 va = __builtin_nontemporal_load(&vq[(uint64_t)h * 64 + lane]);
+                        col[j][4 * q] = c2.x; col[j][4 * q + 1] = c2.y;
+                        val[j][4 * q] = va.x; val[j][4 * q + 1] = va.y;
+                    }
+                }
+                if (len[j]) {
+                    if constexpr (EPI == SL_EPI_NEUMANN) { e_own[j] = a.gather[a.row_offset + i]; e_d[j] = a.dinv[i]; e_x[j] = a.x[i]; }
+                    else if constexpr (EPI == SL_EPI_RESIDUAL) { e_aux[j] = a.aux[i]; }
+                    else if constexpr (EPI == SL_EPI_PUSH) { e_aux[j] = a.r[i]; e_d[j] = a.dinv[i]; e_x[j] = a.x[i]; e_own[j] = a.gather[a.row_offset + i]; }
+                }
+#pragma unroll
+                for (int k = 0; k < MAXQ * 4; ++k) {
+                    const bool in = (uint32_t)k < len[j];
+                    const uint32_t rel = in ? (uint32_t)(col[j][k] - (uint32_t)win_lo) : 0u;
+                    col[j][k] = in ? rel : 0xffffffffu;                      // out of every segment
+                    if (in) mymask |= 1ull << (rel / SL_MP_SEG);
+                }
+            }
+        }
+        (void)cq;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mymask |= __shfl_xor(mymask, o);
+        if (lane == 0 && mymask) atomicOr(&occ, mymask);
+        __syncthreads();
+        unsigned long long todo = occ;
+        if (nseg < 64u) todo &= (1ull << nseg) - 1ull;
+        // ---- segments: stage the next occupied one while the current one is consumed ----
+        auto stage = [&](uint32_t sg, uint32_t buf) {
+            const uint64_t lo = win_lo + (uint64_t)sg * SL_MP_SEG;
+            uint64_t hi = lo + SL_MP_SEG;
+            if (hi > win_hi) hi = win_hi;
+            const uint32_t cnt = (uint32_t)(hi - lo), pairs = cnt >> 1;
+            const f64x2 *__restrict__ src2 = reinterpret_cast<const f64x2 *>(a.gather + lo);
+            f64x2 *dst2 = reinterpret_cast<f64x2 *>(mp_seg + (size_t)buf * SL_MP_SEG);
+            for (uint32_t p0 = wave * 64u; p0 < pairs; p0 += SL_MP_WAVES * 64)
+                if (p0 + lane < pairs)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src2 + p0 + lane),
+                                                     (__attribute__((address_space(3))) void *)(dst2 + p0), 16, 0, 0);
+            if ((cnt & 1u) && threadIdx.x == 0) mp_seg[(size_t)buf * SL_MP_SEG + cnt - 1] = a.gather[lo + cnt - 1];
+        };
+        uint32_t buf = 0;
+        if (todo) stage((uint32_t)__builtin_ctzll(todo), 0);
+        while (todo) {
+            const uint32_t sg = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                                 // segment sg is complete in `buf`; the other buffer is free again
+            if (todo) stage((uint32_t)__builtin_ctzll(todo), buf ^ 1u);
+            const double *lw = mp_seg + (size_t)buf * SL_MP_SEG;
+            const uint32_t base = sg * SL_MP_SEG;
+#pragma unroll
+            for (int j = 0; j < SPW; ++j) {
+#pragma unroll
+                for (int k = 0; k < MAXQ * 4; ++k) {
+                    const uint32_t off = col[j][k] - base;
+                    const bool in = off < SL_MP_SEG;                         // padding slots (0xffffffff) are in no segment
+                    if (__ballot(in)) {
+                        const double tv = lw[in ? off : 0u];
+                        const double sn = DADD(sum[j], DMUL(val[j][k], tv));
+                        sum[j] = in ? sn : sum[j];
+                    }
+                }
+            }
+            buf ^= 1u;
+        }
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) {
+            const uint64_t s = s0 + (uint64_t)j * SL_MP_WAVES;
+            const uint64_t i = s * SL_SLICE + lane;
+            if (s < a.n_slices && i < a.n_rows && (len[j] || !(a.n_long && a.row_len[i] == SL_LONG_SENTINEL))) {
+                if constexpr (EPI == SL_EPI_NEUMANN) {
+                    const double own = len[j] ? e_own[j] : a.gather[a.row_offset + i];
+                    const double dd = len[j] ? e_d[j] : a.dinv[i], xx = len[j] ? e_x[j] : a.x[i];
+                    sl_row_epilogue<EPI>(a, i, sum[j], own, dd, xx, 0.0, part0, part1);
+                } else if constexpr (EPI == SL_EPI_PUSH) {
+                    const double own = len[j] ? e_own[j] : a.gather[a.row_offset + i];
+                    const double rr = len[j] ? e_aux[j] : a.r[i], dd = len[j] ? e_d[j] : a.dinv[i], xx = len[j] ? e_x[j] : a.x[i];
+                    sl_row_epilogue<EPI>(a, i, sum[j], rr, dd, xx, own, part0, part1);
+                } else if constexpr (EPI == SL_EPI_RESIDUAL) {
+                    sl_row_epilogue<EPI>(a, i, sum[j], len[j] ? e_aux[j] : a.aux[i], 0.0, 0.0, 0.0, part0, part1);
+                } else {
+                    sl_row_epilogue<EPI>(a, i, sum[j], 0.0, 0.0, 0.0, 0.0, part0, part1);
+                }
+            }
+        }
+    }
+    sl_block_partials<EPI, SL_MP_WAVES>(a, red, lane, wave, lb, a.part_stride, part0, part1);
+}
+
 // ---- column-panel kernel: gathers served by the L2 -----------------------------------------------------
 // For matrices whose columns are spread over a vector far larger than the L2 (uniformly random columns — the reference
 // generators' recipe): every gather of the general kernel misses L2, and misses are served at 58 G/s whatever the table size
@@ -925,6 +1077,7 @@ struct sl_kernel_knobs {
     int forced_spw = 0, forced_pipe = -1, forced_nw = 0;
     long panel_round = -1;                   // SL_PANEL_ROUND: blocks per launch of the dynamic-tile panel kernel (-1: from the occupancy)
     uint32_t pw_slack = 0;                   // SL_PW_SLACK: panels of lead in the paced panel kernel (0: the matrix's own figure)
+    bool mpass_force = false;                // SL_MPASS=1: use the multi-pass window kernel wherever it applies (measured slower: not selected by default)
     sl_kernel_knobs()
     {
         auto flag = [](const char *n, char v) { const char *e = getenv(n); return e && e[0] == v; };
@@ -939,6 +1092,7 @@ struct sl_kernel_knobs {
         wide_off = flag("SL_BAND_NW16", '0');
         panel_round = num("SL_PANEL_ROUND", -1);
         pw_slack = (uint32_t)num("SL_PW_SLACK", 0);
+        mpass_force = flag("SL_MPASS", '1');
     }
 };
 static const sl_kernel_knobs &knobs()
@@ -1030,6 +1184,21 @@ static sl_status launch_band_u(const sl_row_args &a, const band_geom &g, uint32_
     return g.c16 ? launch_band<ORDER, EPI, UWV, false, true>(a, g, grid, nb8, s) : launch_band<ORDER, EPI, UWV, false, false>(a, g, grid, nb8, s);
 }
 
+// multi-pass window kernel: rows of at most 16 entries in the slice layout, a measured bandwidth beyond the LDS window, a window of
+// at most 64 segments, and enough rows per staged window that the staging (out of the L2) stays below ~2.5 x the matrix bytes
+static bool mpass_eligible(const sl_row_args &a)
+{
+    if (a.bandwidth == ~0ull || a.n_cols > 0xffffffffull || a.max_row_nnz == 0 || a.max_row_nnz > 16 || a.n_long) return false;
+    const uint64_t R = (uint64_t)SL_MP_WAVES * (a.max_row_nnz <= 8 ? 6 : 4) * SL_SLICE;
+    const uint64_t window = R + 2 * a.bandwidth + 2;
+    if (window > 64ull * SL_MP_SEG - 2) return false;
+    // Measured (tools/ab_wide.sh, n = 10^7 x 16, ms per step multi-pass / general kernel): w = 12000 0.588 / 0.598, w = 32768 0.812 / 0.683,
+    // w = 100000 1.49 / 0.73, 7-point stencil on 215^3 0.358 / 0.244 — a block alternates between its HBM phase (matrix bytes into
+    // registers) and its LDS phase (9+ segments behind barriers) with two waves per SIMD, and stages R + 2 w entries for R = 2048
+    // rows; the general kernel's L2-served gathers win from w ~ 15 K on.  Kept as an opt-in (SL_MPASS=1, parity-tested), not selected.
+    return knobs().mpass_force;
+}
+
 template <int ORDER, int EPI>
 static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t *nparts)
 {
@@ -1093,6 +1262,22 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
             st = launch_band_u<ORDER, EPI, 0>(a, g, grid, nb8, s);
         }
         if (st != SL_OK) return st;
+    } else if (ORDER == 0 && mpass_eligible(a)) {
+        // bands too wide for one LDS window: the window in segments, the rows' matrix bytes in registers (sl_mpass_kernel)
+        const bool narrow = a.max_row_nnz <= 8;                          // rows of at most 8 entries: six slices per wave instead of four
+        const uint64_t per_block = (uint64_t)SL_MP_WAVES * (narrow ? 6 : 4);
+        const uint64_t nb = (a.n_slices + per_block - 1) / per_block;
+        const uint32_t nb8 = (uint32_t)((nb + 7) / 8), grid = nb8 * 8;
+        constexpr int lds = 2 * SL_MP_SEG * sizeof(double);
+        *nparts = grid + a.n_long;
+        a.part_stride = *nparts;
+        if (narrow) {
+            SL_TRY((set_max_lds_once<sl_mpass_kernel<EPI, 2, 6>>(lds)));
+            hipLaunchKernelGGL((sl_mpass_kernel<EPI, 2, 6>), dim3(grid), dim3(SL_MP_WAVES * 64), lds, s, a, nb8, (uint32_t)a.bandwidth);
+        } else {
+            SL_TRY((set_max_lds_once<sl_mpass_kernel<EPI, 4, 4>>(lds)));
+            hipLaunchKernelGGL((sl_mpass_kernel<EPI, 4, 4>), dim3(grid), dim3(SL_MP_WAVES * 64), lds, s, a, nb8, (uint32_t)a.bandwidth);
+        }
     } else {
         const uint32_t grid = sl_row_grid(a.n_slices), nb8 = grid / 8;
         *nparts = grid + a.n_long;
