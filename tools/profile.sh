@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $B --steps 30 --warmu
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $B --steps 10 --warmup 2 "$@" > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $B --steps 10 --warmup 2 "$@" > $OUT/bench_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_tcc -o tcc -- $B --steps 10 --warmup 2 "$@" > $OUT/bench_tcc.log 2>&1
-tail -n 1 $OUT/bench_stats.log > $OUT/bench_under_rocprof.json
+grep '^{"metric"' $OUT/bench_stats.log | tail -n 1 > $OUT/bench_under_rocprof.json
 ls -la $OUT/*/* | head -40
 # summarise ON the box (gpurun_out/ comes back only below 64 MiB; each rocpd database is ~22 MB), then drop the databases
 NKW=${PROF_NKW:-"10000000 16 0"}
