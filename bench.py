@@ -139,62 +139,81 @@ def main_abi(args, world, rank, local_rank):
     comm = Communicator(rank, world, f"bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"[:60].replace("/", "_"))
     n_local, k = args.n, args.k
     n_global = n_local * world
-    w = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
+    w_head = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
     lo, hi = rank * n_local, (rank + 1) * n_local
-    rp = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
-    ci = torch.empty(n_local * k, dtype=torch.int32, device=dev)
-    va = torch.empty(n_local * k, dtype=torch.float64, device=dev)
-    bb = torch.empty(n_local, dtype=torch.float64, device=dev)
-    L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), bb.data_ptr()))
-    h = C.c_void_p()
-    L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, lo, 0, C.byref(h)))
-    del rp, ci, va
-    torch.cuda.empty_cache()
-    info = L.MatrixInfo()
-    L.check(lib.sl_matrix_get_info(h, C.byref(info)))
-    o = L.NeumannOptions()
-    lib.sl_neumann_options_default(C.byref(o))
-    o.order, o.mem, o.start = args.order, L.SL_MEM_DEVICE, L.SL_START_REFERENCE_DEFAULT      # x0 = D^-1 b like the one-GPU bench loop (x = t0)
-    st = C.c_void_p()
-    L.check(lib.sl_neumann_state_create_partitioned(comm._h, h, bb.data_ptr(), None, C.byref(o), C.byref(st)))
-    nrm, ms = C.c_double(0.0), C.c_float(0.0)
-    if args.warmup:
-        L.check(lib.sl_neumann_state_run_steps(st, args.warmup, C.byref(nrm), C.byref(ms)))
-    comm.barrier()
-    torch.cuda.synchronize(dev)
-    t_start = time.perf_counter()
-    L.check(lib.sl_neumann_state_run_steps(st, args.steps, C.byref(nrm), C.byref(ms)))     # returns when the K steps are done on this rank
-    torch.cuda.synchronize(dev)
-    comm.barrier()
-    elapsed = max(comm.allgather_f64(time.perf_counter() - t_start))
-    dev_ms = max(comm.allgather_f64(float(ms.value)))
+
+    def measure(w):
+        rp = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
+        ci = torch.empty(n_local * k, dtype=torch.int32, device=dev)
+        va = torch.empty(n_local * k, dtype=torch.float64, device=dev)
+        bb = torch.empty(n_local, dtype=torch.float64, device=dev)
+        L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), bb.data_ptr()))
+        h = C.c_void_p()
+        L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, lo, 0, C.byref(h)))
+        del rp, ci, va
+        torch.cuda.empty_cache()
+        info = L.MatrixInfo()
+        L.check(lib.sl_matrix_get_info(h, C.byref(info)))
+        o = L.NeumannOptions()
+        lib.sl_neumann_options_default(C.byref(o))
+        o.order, o.mem, o.start = args.order, L.SL_MEM_DEVICE, L.SL_START_REFERENCE_DEFAULT      # x0 = D^-1 b like the one-GPU bench loop (x = t0)
+        st = C.c_void_p()
+        L.check(lib.sl_neumann_state_create_partitioned(comm._h, h, bb.data_ptr(), None, C.byref(o), C.byref(st)))
+        nrm, ms = C.c_double(0.0), C.c_float(0.0)
+        if args.warmup:
+            L.check(lib.sl_neumann_state_run_steps(st, args.warmup, C.byref(nrm), C.byref(ms)))
+        comm.barrier()
+        torch.cuda.synchronize(dev)
+        t_start = time.perf_counter()
+        L.check(lib.sl_neumann_state_run_steps(st, args.steps, C.byref(nrm), C.byref(ms)))     # returns when the K steps are done on this rank
+        torch.cuda.synchronize(dev)
+        comm.barrier()
+        elapsed = max(comm.allgather_f64(time.perf_counter() - t_start))
+        dev_ms = max(comm.allgather_f64(float(ms.value)))
+        lib.sl_neumann_state_destroy(st)
+        lib.sl_matrix_destroy(h)
+        del bb
+        torch.cuda.empty_cache()
+        return {"elapsed": elapsed, "dev_ms": dev_ms, "norm": float(nrm.value) ** 0.5, "panels": int(info.column_panels)}
+
+    m = measure(w_head)
+    other = None
+    if not args.no_sweep:      # the other column structure of the recipe in the same job: config 5's halo variant next to S-DD as written, or vice versa
+        w_other = BANDED_BANDWIDTH if w_head == 0 else 0
+        other = (w_other, measure(w_other))
     if rank == 0:
         nnz_total = n_global * k
         per_launch_bytes = algorithmic_bytes(n_local, n_local * k)
-        launch_ms = dev_ms / args.steps
+        launch_ms = m["dev_ms"] / args.steps
         achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
-        value = nnz_total * args.steps / elapsed
+        value = nnz_total * args.steps / m["elapsed"]
+        name = lambda w: "uniform columns" if w == 0 else f"band half-width {w}"
         out = {
             "metric": "push_iterations_x_nnz_per_sec", "value": value, "unit": "nnz*iter/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["elapsed"] * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"S-DD(n={n_local} rows/GPU, nnz/row={k}, seed={args.seed}, "
-                                   f"{'uniform columns' if w == 0 else f'band half-width {w}'}) fused Neumann/push step, fp64, "
+            "config": {"workload": f"S-DD(n={n_local} rows/GPU, nnz/row={k}, seed={args.seed}, {name(w_head)}) fused Neumann/push step, fp64, "
                                    f"{world}xMI355X row-partitioned (BASELINE configs[4] per-GPU shape)",
-                       "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w,
+                       "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w_head,
                        "order": "csr_sequential" if args.order == 0 else "simd4",
                        "exchange": "abi: sl_comm (IPC-mapped vectors pulled over xGMI, norm summed over all ranks every step)", "partition": f"rows{world}",
-                       "norm_allreduce_every": 1, "rows_iter_per_s": value / k, "last_term_norm": float(nrm.value) ** 0.5},
+                       "norm_allreduce_every": 1, "rows_iter_per_s": value / k, "last_term_norm": m["norm"],
+                       "bytes_pulled_per_rank_per_step": (8 * n_local * (world - 1)) if w_head == 0 else 8 * w_head * min(2, world - 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
-                         "column_structure": "uniform over all columns (SURVEY 8(d) S-DD)" if w == 0 else f"band half-width {w}",
-                         "kernel": LAYOUTS.get(int(info.column_panels), "row slices") if info.column_panels else "row slices",
+                         "column_structure": "uniform over all columns (SURVEY 8(d) S-DD)" if w_head == 0 else f"band half-width {w_head}",
+                         "kernel": LAYOUTS.get(m["panels"], "row slices") if m["panels"] else "row slices",
                          "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": launch_ms,
                          "note": "per GPU: one step = fused kernel + all-rank ticket + pulls; launch_ms = the slowest rank's device time per step"},
         }
+        if other is not None:
+            w_o, mo = other
+            out["config"]["other_column_structure_same_job"] = {
+                "half_bandwidth": w_o, "column_structure": name(w_o) + (" (config 5's halo variant: only the strips at the range boundaries travel)" if w_o else ""),
+                "value": nnz_total * args.steps / mo["elapsed"], "ms_per_step": mo["elapsed"] * 1e3 / args.steps,
+                "device_ms_per_step_slowest_rank": mo["dev_ms"] / args.steps,
+                "roofline_frac_per_gpu": per_launch_bytes / (mo["dev_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, "last_term_norm": mo["norm"]}
         print(json.dumps(out), flush=True)
-    lib.sl_neumann_state_destroy(st)
-    lib.sl_matrix_destroy(h)
     comm.close()
 
 
