@@ -798,7 +798,10 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t rpw = a.pw_rpw, slack = a.pw_slack;
     double *acc = pw_acc + (size_t)wave * (rpw + 1);                // + the spare slot padding entries add their zeros to
-    volatile uint32_t *vprog = prog;
+    // progress words: relaxed workgroup-scope atomics = plain ds_read / ds_write.  NOT volatile: a volatile access makes the backend
+    // wait for every load in flight (s_waitcnt vmcnt(0)), which would serialise the stream loads and gathers the pipeline keeps ahead
+    auto prog_ld = [&](uint32_t k) { return __hip_atomic_load(&prog[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto prog_st = [&](uint32_t k, uint32_t v) { __hip_atomic_store(&prog[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     if (threadIdx.x <= SL_PW_WAVES) prog[threadIdx.x] = threadIdx.x == SL_PW_WAVES ? 1u : 0u;
     __syncthreads();
     const double *__restrict__ g = a.gather;
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
     double part0 = 0.0, part1 = 0.0;
     for (uint32_t round = 0; round < rounds; ++round) {
         const uint32_t tile = (round * nblocks + blockIdx.x) * SL_PW_WAVES + wave;
-        if (tile >= a.pw_tiles) { if (lane == 0) vprog[wave] = 0xffffffffu; continue; }     // nothing to wait for
+        if (tile >= a.pw_tiles) { if (lane == 0) prog_st(wave, 0xffffffffu); continue; }     // nothing to wait for
         for (uint32_t r = lane; r <= rpw; r += 64) acc[r] = 0.0;
         const uint32_t ch0 = a.pw_tile_ptr[tile], chunks = a.pw_tile_ptr[tile + 1] - ch0;
         const u32x4 *__restrict__ idxq = reinterpret_cast<const u32x4 *>(a.pw_idx) + (uint64_t)ch0 * 64;
@@ -824,25 +827,27 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         };
         auto pace = [&](uint32_t pan) {
             const uint32_t me = (round << 20) + pan + 1u;           // monotone over the launch (panels < 2^16)
-            if (lane == 0) vprog[wave] = me;
-            if (slack >= (1u << 20) || !vprog[SL_PW_WAVES]) return;
+            if (lane == 0) prog_st(wave, me);
+            if (slack >= (1u << 20) || !prog_ld(SL_PW_WAVES)) return;
             for (uint32_t spins = 0;; ++spins) {
-                uint32_t m = lane < SL_PW_WAVES ? vprog[lane] : 0xffffffffu;
+                uint32_t m = lane < SL_PW_WAVES ? prog_ld(lane) : 0xffffffffu;
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor(m, o));
                 m = __builtin_amdgcn_readfirstlane(m);
                 if (me <= m + slack) break;                         // at most `slack` panels ahead of the block's slowest wave
-                if (spins > 2048u) { if (lane == 0) vprog[SL_PW_WAVES] = 0u; break; }     // the hint switches itself off
+                if (spins > 2048u) { if (lane == 0) prog_st(SL_PW_WAVES, 0u); break; }     // the hint switches itself off
                 __builtin_amdgcn_s_sleep(4);
             }
         };
-        auto gather = [&](const uint32_t (&ii)[4], double (&gg)[4], uint32_t (&cc)[4]) {
+        // real = false: the pipeline's filler behind the last chunk (the loads are issued all the same, so that the number of loads
+        // in flight at every wait is a compile-time constant; a load under a branch would turn every wait into vmcnt(0))
+        auto gather = [&](const uint32_t (&ii)[4], double (&gg)[4], uint32_t (&cc)[4], bool real) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const unsigned long long fl = __ballot((ii[u] >> SL_PW_SP_BITS) & 1u);
                 const uint32_t sp = sp_g + (uint32_t)__popcll(fl & ((2ull << lane) - 1ull));
-                sp_g += (uint32_t)__popcll(fl);
-                cc[u] = (sp << SL_PW_SP_BITS) | (ii[u] & ((1u << SL_PW_SP_BITS) - 1u));
+                sp_g += real ? (uint32_t)__popcll(fl) : 0u;
+                cc[u] = real ? ((sp << SL_PW_SP_BITS) | (ii[u] & ((1u << SL_PW_SP_BITS) - 1u))) : 0u;
                 gg[u] = g[cc[u]];
             }
         };
@@ -888,16 +893,20 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
             }
         };
         if (chunks) {
+            const uint32_t lastc = chunks - 1u;
             load_stream(0, SI[0], SV[0]);
-            if (chunks > 1) load_stream(1, SI[1], SV[1]);
+            load_stream(min(1u, lastc), SI[1], SV[1]);
             pace(0);
-            gather(SI[0], GG[0], GC[0]);
+            gather(SI[0], GG[0], GC[0], true);
 #define SL_PW_STEP(r, r1, r2)                                                                                        \
-            if (ch + 2 < chunks) load_stream(ch + 2, SI[r2], SV[r2]);                                                \
-            if (ch + 1 < chunks) {                                                                                   \
-                const uint32_t nextcol = (sp_g << SL_PW_SP_BITS) | (__builtin_amdgcn_readfirstlane(SI[r1][0]) & ((1u << SL_PW_SP_BITS) - 1u)); \
-                pace(nextcol >> SL_PANEL_COL_BITS);                                                                  \
-                gather(SI[r1], GG[r1], GC[r1]);                                                                      \
+            load_stream(min(ch + 2u, lastc), SI[r2], SV[r2]);                                                        \
+            {                                                                                                        \
+                const bool real1 = ch + 1u < chunks;                                                                 \
+                if (real1) {                                                                                         \
+                    const uint32_t nextcol = (sp_g << SL_PW_SP_BITS) | (__builtin_amdgcn_readfirstlane(SI[r1][0]) & ((1u << SL_PW_SP_BITS) - 1u)); \
+                    pace(nextcol >> SL_PANEL_COL_BITS);                                                              \
+                }                                                                                                    \
+                gather(SI[r1], GG[r1], GC[r1], real1);                                                               \
             }                                                                                                        \
             accumulate(SI[r], SV[r], GG[r], GC[r]);                                                                  \
             if (++ch >= chunks) break;
@@ -908,7 +917,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
             }
 #undef SL_PW_STEP
         }
-        if (lane == 0) vprog[wave] = (round + 1u) << 20;             // as far along as the round's end while the vectors are written
+        if (lane == 0) prog_st(wave, (round + 1u) << 20);            // as far along as the round's end while the vectors are written
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (uint32_t r = lane; r < rpw; r += 64) {                   // slot r = group r / 16 of the tile, row r % 16 of the group
             const uint64_t i = ((uint64_t)(r / SL_PW_GROUP) * a.pw_tiles + tile) * SL_PW_GROUP + (r % SL_PW_GROUP);
