@@ -255,7 +255,8 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
-    if world > 1 and args.exchange == "abi" and not args.force_split:
+    # SL_BENCH_FORCE_ABI=1 (measurement): the communicator path at world size 1 — the per-step cost of the ticket kernel on top of the fused step
+    if (world > 1 or os.environ.get("SL_BENCH_FORCE_ABI") == "1") and args.exchange == "abi" and not args.force_split:
         try:
             return main_abi(args, world, rank, local_rank)
         except Exception as e:                      # collective by construction (every wait in the communicator is bounded): all ranks land here together
