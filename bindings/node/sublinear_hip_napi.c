@@ -308,6 +308,38 @@ static napi_value PushSolve(napi_env env, napi_callback_info info)
     return o;
 }
 
+/* solveForwardPush in the reference's own visiting order (src/core/solver.ts:437-522): one Gauss-Southwell push per iteration */
+static napi_value ForwardPushSouthwell(napi_env env, napi_callback_info info)
+{
+    napi_value argv[3], o, sol;
+    sl_matrix *m;
+    const double *b;
+    size_t nb = 0;
+    sl_southwell_options opt;
+    sl_southwell_result r;
+    sl_matrix_info mi;
+    double *x;
+    sl_status st;
+    if (!get_args(env, info, 3, argv)) return NULL;
+    if (!(m = matrix_of(env, argv[0])) || !f64_view(env, argv[1], &b, &nb)) return NULL;
+    if (sl_matrix_get_info(m, &mi) != SL_OK || nb != mi.n_rows) { napi_throw_range_error(env, NULL, "vector length does not match the matrix"); return NULL; }
+    sl_southwell_options_default(&opt);
+    opt.epsilon = opt_number(env, argv[2], "epsilon", opt.epsilon);
+    opt.max_iterations = (uint64_t)opt_number(env, argv[2], "maxIterations", (double)opt.max_iterations);
+    opt.mem = SL_MEM_HOST;
+    if (!(sol = new_f64(env, nb, &x))) return NULL;
+    st = sl_forward_push_southwell(m, b, &opt, x, NULL, NULL, 0, &r);
+    if (st != SL_OK) return throw_status(env, st);
+    NAPI_OK(napi_create_object(env, &o));
+    napi_set_named_property(env, o, "solution", sol);
+    set_num(env, o, "iterations", (double)r.iterations);
+    set_num(env, o, "residualNorm", r.residual_norm);
+    set_bool(env, o, "converged", r.converged);
+    set_num(env, o, "deviceTimeMs", r.device_time_ms);
+    set_num(env, o, "deviceBytes", (double)mi.device_bytes);
+    return o;
+}
+
 static napi_value EstimateEntry(napi_env env, napi_callback_info info)
 {
     napi_value argv[5], o;
@@ -405,6 +437,7 @@ static napi_value Init(napi_env env, napi_value exports)
         {"isDiagonallyDominant", NULL, IsDiagonallyDominant, NULL, NULL, NULL, napi_default, NULL},
         {"neumannSolve", NULL, NeumannSolve, NULL, NULL, NULL, napi_default, NULL},
         {"pushSolve", NULL, PushSolve, NULL, NULL, NULL, napi_default, NULL},
+        {"forwardPushSouthwell", NULL, ForwardPushSouthwell, NULL, NULL, NULL, napi_default, NULL},
         {"estimateEntry", NULL, EstimateEntry, NULL, NULL, NULL, napi_default, NULL},
         {"estimateEntryRandomWalk", NULL, EstimateEntryRandomWalk, NULL, NULL, NULL, napi_default, NULL},
         {"cgSolve", NULL, CgSolve, NULL, NULL, NULL, napi_default, NULL},

@@ -176,6 +176,13 @@ class SublinearSolver {
                                               maxTerms: this.config.maxIterations, seriesTolerance: this.config.epsilon });
         return { solution: Array.from(r.solution), iterations: r.iterations, residual: r.residualNorm, converged: r.converged, memoryUsed: r.deviceBytes };
       }
+      // solveForwardPush (solver.ts:437-522): up to 4096 rows in the reference's own order — one Gauss-Southwell push per iteration,
+      // `iterations` = pushes as the reference reports them (ConvergenceFailure after maxIterations pushes comes back as an
+      // exception of the native call); larger systems through the data-parallel thresholded push (`iterations` = rounds)
+      if (matrix.rows <= 4096 && this.config.pushOrder !== 'synchronous') {
+        const g = native.forwardPushSouthwell(h, b, { epsilon: this.config.epsilon, maxIterations: this.config.maxIterations });
+        return { solution: Array.from(g.solution), iterations: g.iterations, residual: g.residualNorm, converged: true, memoryUsed: g.deviceBytes };
+      }
       const r = native.pushSolve(h, b, { theta: this.config.epsilon, maxRounds: this.config.maxIterations });
       if (!r.converged) throw new SolverError(`Forward push failed to converge after ${this.config.maxIterations} iterations`, ErrorCodes.CONVERGENCE_FAILED);
       return { solution: Array.from(r.solution), iterations: r.rounds, residual: r.residualNorm, converged: true, memoryUsed: r.deviceBytes };

@@ -115,6 +115,14 @@ async function rejects(p, code, re) {
   for (let i = 0; i < 10; i++) for (const [j, v] of [[i - 1, -1], [i, 10], [i + 1, -1]]) if (j >= 0 && j < 10) { tri.rowIndices.push(i); tri.colIndices.push(j); tri.values.push(v); }
   const wt = await seeded.estimateEntry(tri, new Array(10).fill(1), { row: 0, column: 0, epsilon: 0.05, confidence: 0.95, method: 'random-walk' });
   assert(wt.numSamples === 400 && Math.abs(wt.estimate - 0.1) < 1e-9 && wt.confidence === 0.95, JSON.stringify(wt));
+  {   // G6 (tests/mcp/mcp-tool-tests.js:27-52): 10 x 10 tridiag(-1, 10, -1), b = e0 + e9, epsilon 1e-3 -> 12 pushes, ||r|| = 5.2915e-4
+    const t = { rows: 10, cols: 10, format: 'coo', values: [], rowIndices: [], colIndices: [] };
+    for (let i = 0; i < 10; i++) for (const [j, v] of [[i - 1, -1], [i, 10], [i + 1, -1]]) if (j >= 0 && j < 10) { t.rowIndices.push(i); t.colIndices.push(j); t.values.push(v); }
+    const bb = new Array(10).fill(0); bb[0] = 1; bb[9] = 1;
+    const g6 = await new SublinearSolver({ method: 'forward-push', epsilon: 1e-3, maxIterations: 1000 }).solve(t, bb);
+    assert(g6.converged && g6.iterations === 12 && Math.abs(g6.residual - 5.2915e-4) < 1e-7, JSON.stringify(g6));
+    await rejects(new SublinearSolver({ method: 'forward-push', epsilon: 1e-12, maxIterations: 3 }).solve(t, bb), ErrorCodes.CONVERGENCE_FAILED, /failed to converge after 3/);
+  }
   // PageRank of a small graph against power iteration
   const adj = { rows: 5, cols: 5, format: 'dense', data: [[0, 1, 1, 0, 0], [0, 0, 1, 0, 0], [1, 0, 0, 1, 0], [0, 0, 0, 0, 1], [1, 0, 0, 0, 0]] };
   const pr = await new SublinearSolver({ method: 'forward-push', epsilon: 1e-13, maxIterations: 100000 }).computePageRank(adj, { damping: 0.85, epsilon: 1e-13, maxIterations: 100000 });
