@@ -14,6 +14,8 @@
 //   SolverError variants         error.rs:16-140      sublinear::SolverError::kind
 #pragma once
 #include <cstdint>
+#include <cstring>
+#include <limits>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -116,6 +118,43 @@ private:
     size_t rows_, cols_;
 };
 
+enum class StepResult { Continue, Converged, Failed };        // solver/mod.rs:197-221
+
+// sl_comm: one process per GPU of one node (include/sublinear_hip.h, multi-GPU); every rank passes the same name
+class Communicator {
+public:
+    Communicator(int rank, int world, const std::string &name) { check(sl_comm_create(rank, world, name.c_str(), &c_)); }
+    Communicator(const Communicator &) = delete;
+    Communicator &operator=(const Communicator &) = delete;
+    ~Communicator() { if (c_) sl_comm_destroy(c_); }
+    void barrier() const { check(sl_comm_barrier(c_)); }
+    sl_comm *handle() const { return c_; }
+
+private:
+    sl_comm *c_ = nullptr;
+};
+
+// NeumannState (neumann.rs:95-137) + trait SolverState (solver/mod.rs:336-351) on the device
+class NeumannState {
+public:
+    NeumannState(NeumannState &&o) noexcept : h_(o.h_), n_(o.n_), last_(o.last_), ran_(o.ran_) { o.h_ = nullptr; }
+    NeumannState(const NeumannState &) = delete;
+    NeumannState &operator=(const NeumannState &) = delete;
+    ~NeumannState() { if (h_) sl_neumann_state_destroy(h_); }
+    Precision residual_norm() const { return ran_ ? last_.residual_norm : std::numeric_limits<Precision>::infinity(); }
+    size_t matvec_count() const { return (size_t)last_.matvec_count; }
+    size_t iterations() const { return (size_t)last_.iterations; }
+    void reset() { check(sl_neumann_state_reset(h_)); ran_ = false; }                     // neumann.rs:367-378
+
+private:
+    friend class NeumannSolver;
+    NeumannState(sl_neumann_state *h, size_t n) : h_(h), n_(n) { std::memset(&last_, 0, sizeof(last_)); }
+    sl_neumann_state *h_;
+    size_t n_;
+    sl_neumann_result last_;
+    bool ran_ = false;
+};
+
 class NeumannSolver {                        // neumann.rs:24-92
 public:
     NeumannSolver(size_t max_terms, Precision series_tolerance) : max_terms_(max_terms), series_tolerance_(series_tolerance) {}
@@ -152,12 +191,100 @@ public:
         return out;
     }
 
+    // ---- trait SolverAlgorithm (solver/mod.rs:223-333): initialize / step / is_converged / extract_solution / update_rhs --------
+    // The state lives on the device (sl_neumann_state_*); `comm` != nullptr: NeumannState::new over a row partition (`matrix` = this
+    // rank's rows with global column ids, `b` = its part of the right-hand side; every call on the state is then collective).
+    NeumannState initialize(const SparseMatrix &matrix, const std::vector<Precision> &b, const SolverOptions &options = SolverOptions(),
+                            const Communicator *comm = nullptr) const;
+    // One call runs the whole loop of neumann.rs:477-555 on the device (the reference's own `step` cannot iterate: :393-419)
+    StepResult step(NeumannState &state) const;
+    bool is_converged(const NeumannState &state) const;
+    std::vector<Precision> extract_solution(const NeumannState &state) const;
+    void update_rhs(NeumannState &state, const std::vector<std::pair<size_t, Precision>> &delta_b) const;     // neumann.rs:436-462
+
 private:
+    sl_neumann_options abi_options(const SparseMatrix &matrix, const SolverOptions &options, const double **guess) const
+    {
+        sl_neumann_options o;
+        sl_neumann_options_default(&o);
+        o.tolerance = options.tolerance; o.max_iterations = options.max_iterations;
+        o.max_terms = max_terms_; o.series_tolerance = series_tolerance_;
+        o.order = order_; o.start = start_; o.residual = residual_; o.mem = SL_MEM_HOST;
+        o.collect_stats = options.collect_stats; o.compute_error_bounds = options.compute_error_bounds;
+        *guess = nullptr;
+        if (options.initial_guess) {
+            if (options.initial_guess->size() != matrix.rows()) throw SolverError(SL_DIMENSION_MISMATCH, "initial_guess");        // :198-204
+            *guess = options.initial_guess->data();
+            o.start = SL_START_INITIAL_GUESS;
+        }
+        return o;
+    }
     size_t max_terms_;
     Precision series_tolerance_;
     sl_order order_ = SL_ORDER_CSR_SEQUENTIAL;
     sl_start start_ = SL_START_ZERO;
     sl_residual residual_ = SL_RESIDUAL_TRUE;
+};
+
+inline NeumannState NeumannSolver::initialize(const SparseMatrix &matrix, const std::vector<Precision> &b, const SolverOptions &options,
+                                              const Communicator *comm) const
+{
+    if (b.size() != matrix.rows()) throw SolverError(SL_DIMENSION_MISMATCH, "neumann_initialization");     // :154-160
+    const double *guess = nullptr;
+    const sl_neumann_options o = abi_options(matrix, options, &guess);
+    sl_neumann_state *st = nullptr;
+    if (comm) check(sl_neumann_state_create_partitioned(comm->handle(), matrix.handle(), b.data(), guess, &o, &st));
+    else check(sl_neumann_state_create(matrix.handle(), b.data(), guess, &o, &st));
+    return NeumannState(st, matrix.rows());
+}
+inline StepResult NeumannSolver::step(NeumannState &state) const
+{
+    const sl_status st = sl_neumann_state_run(state.h_, nullptr, &state.last_);
+    state.ran_ = true;
+    if (st == SL_OK) return StepResult::Converged;
+    if (st == SL_CONVERGENCE_FAILURE) return StepResult::Failed;
+    check(st);
+    return StepResult::Failed;
+}
+inline bool NeumannSolver::is_converged(const NeumannState &state) const { return state.ran_ && state.last_.converged != 0; }
+inline std::vector<Precision> NeumannSolver::extract_solution(const NeumannState &state) const
+{
+    std::vector<Precision> x(state.n_);
+    check(sl_neumann_state_solution(state.h_, x.data(), SL_MEM_HOST));
+    return x;
+}
+inline void NeumannSolver::update_rhs(NeumannState &state, const std::vector<std::pair<size_t, Precision>> &delta_b) const
+{
+    std::vector<uint64_t> idx; std::vector<double> val;
+    for (const auto &p : delta_b) { idx.push_back(p.first); val.push_back(p.second); }
+    check(sl_neumann_state_update_rhs(state.h_, idx.size(), idx.data(), val.data()));
+    state.last_.converged = 0;
+}
+
+// TS solveForwardPush (src/core/solver.ts:437-522) in the reference's own visiting order: one Gauss-Southwell push per iteration
+class GaussSouthwellSolver {
+public:
+    explicit GaussSouthwellSolver(Precision epsilon = 1e-6, size_t max_iterations = 1000) : epsilon_(epsilon), max_iterations_(max_iterations) {}
+    SolverResult solve(const SparseMatrix &matrix, const std::vector<Precision> &b, std::vector<uint32_t> *push_log = nullptr) const
+    {
+        if (b.size() != matrix.rows()) throw SolverError(SL_DIMENSION_MISMATCH, "forward push");
+        sl_southwell_options o;
+        sl_southwell_options_default(&o);
+        o.epsilon = epsilon_; o.max_iterations = max_iterations_;
+        SolverResult out;
+        out.solution.resize(matrix.rows());
+        sl_southwell_result r;
+        if (push_log) push_log->assign(max_iterations_, 0u);
+        check(sl_forward_push_southwell(matrix.handle(), b.data(), &o, out.solution.data(), nullptr, push_log ? push_log->data() : nullptr,
+                                        push_log ? push_log->size() : 0, &r));
+        if (push_log) push_log->resize(r.iterations);
+        out.residual_norm = r.residual_norm; out.iterations = r.iterations; out.converged = r.converged != 0;
+        return out;
+    }
+
+private:
+    Precision epsilon_;
+    size_t max_iterations_;
 };
 
 struct PushResult {

@@ -50,6 +50,38 @@ int main()
             EXPECT(session.query_single_entry(1, 1e-12) == e1);
         }
     }
+    // trait SolverAlgorithm on a device state: initialize / step / is_converged / extract_solution / update_rhs / reset
+    {
+        NeumannSolver ns(60, 1e-14);
+        SolverOptions opt; opt.tolerance = 1e-12;
+        NeumannState st = ns.initialize(a, {5.0, 4.0}, opt);
+        EXPECT(!ns.is_converged(st) && std::isinf(st.residual_norm()));
+        EXPECT(ns.step(st) == StepResult::Converged && ns.is_converged(st));
+        auto x = ns.extract_solution(st);
+        EXPECT(std::fabs(x[0] - 1.0) < 1e-10 && std::fabs(x[1] - 1.0) < 1e-10);
+        ns.update_rhs(st, {{0, 4.0}});                           // b = (9, 4): rhs[0] += 4 / 4, solution[0] += the same (neumann.rs:448-453)
+        auto x1 = ns.extract_solution(st);
+        EXPECT(x1[0] == x[0] + 1.0 && x1[1] == x[1] && !ns.is_converged(st));
+        st.reset();                                              // SolverState::reset, then the loop again: the solve of the updated system
+        EXPECT(ns.step(st) == StepResult::Converged);
+        auto x2 = ns.extract_solution(st);                       // [[4,1],[1,3]] x = (9, 4): x = (23/11, 7/11)
+        EXPECT(std::fabs(x2[0] - 23.0 / 11.0) < 1e-10 && std::fabs(x2[1] - 7.0 / 11.0) < 1e-10);
+        try { ns.update_rhs(st, {{5, 1.0}}); EXPECT(false); } catch (const SolverError &e) { EXPECT(e.kind == SL_INDEX_OUT_OF_BOUNDS); }
+        // a communicator of one: the partitioned state is the same state
+        Communicator comm(0, 1, "cpp_mirror_test");
+        NeumannState sp = ns.initialize(a, {5.0, 4.0}, opt, &comm);
+        EXPECT(ns.step(sp) == StepResult::Converged);
+        auto xp = ns.extract_solution(sp);
+        EXPECT(xp[0] == x[0] && xp[1] == x[1]);
+    }
+    // TS solveForwardPush in its own order (solver.ts:437-522): first maximum first
+    {
+        std::vector<uint32_t> log;
+        auto g = GaussSouthwellSolver(1e-12, 10000).solve(a, {5.0, 4.0}, &log);
+        EXPECT(g.converged && g.iterations == log.size() && log.size() > 2 && log[0] == 0);      // |5| > |4|: row 0 first
+        EXPECT(std::fabs(g.solution[0] - 1.0) < 1e-10 && std::fabs(g.solution[1] - 1.0) < 1e-10);
+        try { GaussSouthwellSolver(1e-12, 2).solve(a, {5.0, 4.0}); EXPECT(false); } catch (const SolverError &e) { EXPECT(e.kind == SL_CONVERGENCE_FAILURE); }
+    }
     // CG on a symmetric positive definite system (optimized_solver.rs tests: 2x2 SPD)
     auto spd = SparseMatrix::from_triplets({{0, 0, 4.0}, {0, 1, 1.0}, {1, 0, 1.0}, {1, 1, 3.0}}, 2, 2);
     auto c = ConjugateGradientSolver(100, 1e-10).solve(spd, {1.0, 2.0});
