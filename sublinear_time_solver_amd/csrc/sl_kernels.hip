@@ -1130,7 +1130,7 @@ static sl_status set_max_lds_once(int bytes)
     return SL_OK;
 }
 
-static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool nw8_pays)
+static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool nw8_pays, bool ragged)
 {
     const sl_kernel_knobs &kn = knobs();
     const int disabled = kn.band_disabled ? 1 : 0, forced_spw = kn.forced_spw, forced_pipe = kn.forced_pipe, c16_off = kn.c16_off ? 1 : 0, forced_nw = kn.forced_nw;
@@ -1141,9 +1141,13 @@ static band_geom band_geometry(const sl_row_args &a, bool offsets16_usable, bool
     // 8 waves x 3 slices (the window is re-staged nw * spw * 64 rows at a time); pipelining never hurts
     const bool pipe = forced_pipe >= 0 ? forced_pipe != 0 : true;
     const bool c16 = a.cols16 != nullptr && !c16_off && offsets16_usable;
-    uint32_t nw = (forced_nw == 4 || forced_nw == 8) ? (uint32_t)forced_nw : (a.bandwidth > 1024 ? 8u : 4u);
+    // ragged rows (the batched path) behind a narrow window: 8 waves x 8 slices — a slice of short rows is one or two loads per
+    // array, and it takes that many of them in flight per CU to keep the stream going (tools/sweep_short_rows.sh, w = 512, ms per
+    // step 4 x 4 -> 8 x 8: 5 entries per row 0.211 -> 0.183, 9 per row 0.280 -> 0.252; no gain behind wide windows or for uniform rows)
+    const bool ragged_narrow = ragged && a.bandwidth <= 1024;
+    uint32_t nw = (forced_nw == 4 || forced_nw == 8) ? (uint32_t)forced_nw : ((a.bandwidth > 1024 || ragged_narrow) ? 8u : 4u);
     if (!pipe || !c16 || !nw8_pays) nw = 4;                         // 8-wave blocks: pipelined 16-bit-offset variants that gain from them
-    uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : (a.bandwidth <= 1024 ? 4u : (nw == 8 ? 3u : 6u));
+    uint32_t spw = forced_spw > 0 ? (uint32_t)forced_spw : (a.bandwidth <= 1024 ? ((ragged_narrow && nw == 8) ? 8u : 4u) : (nw == 8 ? 3u : 6u));
     uint64_t entries = (uint64_t)nw * spw * SL_SLICE + 2 * a.bandwidth + 2;
     while (entries * 8 > SL_BAND_MAX_LDS && forced_spw <= 0 && spw > 1) {   // a shorter block may still fit
         spw = spw == 3 ? 2 : spw >> 1;
@@ -1227,7 +1231,7 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
     // epilogue at width 16, which would spill ~100 B per lane and lose 10 %: it stays at 4 waves); the batched path fits
     // with 3 quads per batch (2 in the 4-lane order) instead of 4
     const bool nw8_pays = !(EPI == SL_EPI_PUSH && uniform_unrolled && a.uniform_width == 16);
-    const band_geom g = band_geometry(a, uniform_unrolled || !uniform_octets, nw8_pays);
+    const band_geom g = band_geometry(a, uniform_unrolled || !uniform_octets, nw8_pays, !uniform_unrolled);
     if (ORDER == 0 && a.pw_idx && a.pw_tiles) {
         const uint32_t lds = (uint32_t)(SL_PW_WAVES * ((size_t)a.pw_rpw + 1) * sizeof(double));
         SL_TRY(set_max_lds_once<sl_pw_kernel<EPI>>((int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double))));
