@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64
 // CSR -> row-slice layout.  One wave per slice, lane = row.  Padding entries carry
 // value 0.0 and a valid column (the row's own index when it exists); the kernels never
 // add them (guarded by row_len), they only keep every gather in bounds.
-#define SL_FAR_COLUMN (1ull << 20)     // |col - row| beyond this: the gather is megabytes of vector away from the row's neighbourhood
+#define SL_FAR_COLUMN (1ull << 18)     // |col - row| beyond this (2 MB of vector, half an XCD's L2): the gather is far from what the row's neighbours keep cached
 __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, uint64_t n_cols, uint64_t n_slices,
                                                              uint64_t row_offset, const uint32_t *row_ptr,
                                                              const uint32_t *col_idx, const double *values,
@@ -599,13 +599,18 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         // pays where most entries sit megabytes of vector away from their row (uniformly random columns) and the vector is far larger
         // than the L2 — measured at n = 10^7 x 16: 2.73 -> 1.71 ms; band structures, however wide, are served better by the general
         // kernel (their gathers hit L2; here the entries of a row would crowd one panel and their sums serialise): w = 10^6: 1.86 vs 2.47 ms
-        const bool pays = m->n_cols >= (3ull << 20) && 2 * far_entries > nnz;
+        // Round 2 (tools/ab_c2.sh, paced layout against the general kernel, ms per step): n = 10^6 x 8 0.087 / 0.087, 10^6 x 16
+        // 0.108 / 0.146, 2 * 10^6 x 8 0.135 / 0.223, 3 * 10^6 x 16 0.290 / 0.660 — the paced layout pays from a vector of ~8 MB on;
+        // the DYNAMIC tiles (fallback for unbalanced matrices) only from ~24 MB on (10^6 x 8: 0.168, worse than no panels).
+        const bool spread = 2 * far_entries > nnz;
+        const bool pays = m->n_cols >= (3ull << 20) && spread;
+        const bool pays_paced = m->n_cols >= (1ull << 20) && spread;
         const uint64_t n_tiles = (n + SL_PANEL_TILE - 1) / SL_PANEL_TILE;
         const uint64_t n_panels = (m->n_cols + (1ull << SL_PANEL_COL_BITS) - 1) >> SL_PANEL_COL_BITS;
-        if (!refused && (forced || pays) && nnz && nnz < 0x7fffffffull && n_tiles * n_panels < 0xfffffff0ull) {
+        if (!refused && (forced || pays || pays_paced) && nnz && nnz < 0x7fffffffull && n_tiles * n_panels < 0xfffffff0ull) {
             // balanced matrices of some size: persistent paced blocks (SL_COLUMN_PANELS=3 forces the dynamic tiles instead)
             sl_status ps = env_panels == 3 ? SL_OK : sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st);
-            if (ps == SL_OK && !m->d_pw_idx) ps = sl_build_column_panels(m, d_row_ptr, d_col_idx, d_values, n_tiles, (uint32_t)n_panels, st);
+            if (ps == SL_OK && !m->d_pw_idx && (forced || pays)) ps = sl_build_column_panels(m, d_row_ptr, d_col_idx, d_values, n_tiles, (uint32_t)n_panels, st);
             if (ps != SL_OK) return ps;
         }
     }
