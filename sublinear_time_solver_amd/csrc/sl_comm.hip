@@ -31,7 +31,9 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
+#include <time.h>
 #include <unistd.h>
+#define SL_COMM_FRESH_S 120u
 
 static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the blob slots assume");
 
@@ -201,29 +203,36 @@ sl_status sl_comm_create(int rank, int world, const char *rendezvous, sl_comm **
     (void)hipGetDevice(&c->device);
     const size_t bytes = (sizeof(sl_comm_shm) + 4095) & ~(size_t)4095;
     auto fail = [&](sl_status st) { sl_comm_destroy(c); return st; };
-    // rank 0 creates the block (zero-filled by ftruncate) and stamps it last; the others wait for the stamp
+    // rank 0 creates the block (zero-filled by ftruncate) and stamps it last; the others wait for a FRESH stamped block — a block
+    // left behind under the same name by a job that died before all its ranks had joined (the name is unlinked at that point) is
+    // older than SL_COMM_FRESH_S and is not joined
+    const uint64_t now = (uint64_t)time(nullptr);
     if (rank == 0) {
         (void)unlink(c->path.c_str());
         c->fd = open(c->path.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (c->fd < 0 || ftruncate(c->fd, (off_t)bytes) != 0) return fail(sl_fail(SL_DEVICE_ERROR, "cannot create %s", c->path.c_str()));
+        void *map = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
+        if (map == MAP_FAILED) return fail(sl_fail(SL_DEVICE_ERROR, "mmap of %s failed", c->path.c_str()));
+        c->h_shm = static_cast<sl_comm_shm *>(map);
+        c->shm_bytes = bytes;
+        c->h_shm->world = (uint64_t)world; c->h_shm->created_unix = now;
+        st_rel(&c->h_shm->magic, SL_COMM_MAGIC);
     } else {
         const bool ok = wait_until([&] {
-            c->fd = open(c->path.c_str(), O_RDWR);
-            if (c->fd < 0) return false;
+            const int fd = open(c->path.c_str(), O_RDWR);
+            if (fd < 0) return false;
             struct stat sb;
-            if (fstat(c->fd, &sb) == 0 && (size_t)sb.st_size >= bytes) return true;
-            close(c->fd); c->fd = -1;
+            if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) { close(fd); return false; }
+            void *map = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (map == MAP_FAILED) { close(fd); return false; }
+            sl_comm_shm *h = static_cast<sl_comm_shm *>(map);
+            if (ld_acq(&h->magic) == SL_COMM_MAGIC && h->created_unix + SL_COMM_FRESH_S >= now) { c->fd = fd; c->h_shm = h; c->shm_bytes = bytes; return true; }
+            munmap(map, bytes); close(fd);
             return false;
         });
-        if (!ok) return fail(sl_fail(SL_DEVICE_ERROR, "rank %d: %s did not appear within %ld ms", rank, c->path.c_str(), comm_timeout_ms()));
+        if (!ok) return fail(sl_fail(SL_DEVICE_ERROR, "rank %d: no fresh rendezvous block %s within %ld ms", rank, c->path.c_str(), comm_timeout_ms()));
     }
-    void *map = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
-    if (map == MAP_FAILED) return fail(sl_fail(SL_DEVICE_ERROR, "mmap of %s failed", c->path.c_str()));
-    c->h_shm = static_cast<sl_comm_shm *>(map);
-    c->shm_bytes = bytes;
-    if (rank == 0) { c->h_shm->world = (uint64_t)world; st_rel(&c->h_shm->magic, SL_COMM_MAGIC); }
-    else if (!wait_until([&] { return ld_acq(&c->h_shm->magic) == SL_COMM_MAGIC; }))
-        return fail(sl_fail(SL_DEVICE_ERROR, "rank %d: rendezvous block was never initialised", rank));
+    void *map = c->h_shm;
     if (c->h_shm->world != (uint64_t)world) return fail(sl_fail(SL_INVALID_INPUT, "rank %d joins a communicator of %llu ranks, asked for %d", rank,
                                                                   (unsigned long long)c->h_shm->world, world));
     if (hipHostRegister(map, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess)

@@ -318,7 +318,7 @@ sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx,
 #define SL_COMM_MAGIC 0x534c434f4d4d3032ull      /* "SLCOMM02" */
 // the shared block of a communicator (POSIX shared memory, mapped by every rank, registered with the HIP runtime)
 struct sl_comm_shm {
-    volatile uint64_t magic, world;
+    volatile uint64_t magic, world, created_unix;                // created_unix: when rank 0 made the block (stale blocks of crashed jobs are not joined)
     volatile uint64_t arrive[SL_COMM_MAX_RANKS];                 // host barrier
     volatile uint64_t blob_seq[SL_COMM_MAX_RANKS];               // host exchange of small blobs (IPC handles, row ranges)
     volatile unsigned char blob[SL_COMM_MAX_RANKS][SL_COMM_BLOB];
