@@ -153,7 +153,10 @@ __global__ __launch_bounds__(NW * 64) void panel2_kernel(uint32_t ntiles, uint32
                 cc[u] = col;
                 if (VAR & 16) gg[u] = 1.0;
                 else {
-                    const double *ga = &t[(VAR & 32) ? (col & 0x3ffu) : (VAR & 1) ? (col & 0xffffu) : col];
+                    // 1024: ascending columns inside the wave-instruction, about two 128-byte lines apart (density 0.5 entries per line, what a
+                    // CU-wide column-sorted panel segment would give): do lanes that fall into one line share an L2 request?
+                    const uint32_t sorted = (((uint32_t)u * 64u + lane) * 32u + (col & 31u)) & 0xffffu;
+                    const double *ga = &t[(VAR & 1024) ? sorted : (VAR & 32) ? (col & 0x3ffu) : (VAR & 1) ? (col & 0xffffu) : col];
                     if (VAR & 256) gg[u] = __hip_atomic_load(ga, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: served by the L2, no L1 line fill
                     else if (VAR & 512) gg[u] = __builtin_nontemporal_load(ga);
                     else gg[u] = *ga;
@@ -312,6 +315,11 @@ int main(int argc, char **argv)
         run<16, 4, 12>(n, 16, 1221, 15, 2, 4);      // smaller panels
         run<16, 4, 12>(n, 16, 1221, 17, 1, 1);      // larger panels
         run<16, 4, 12>(n, 16, 1221, 16, 1, 2, 1);   // with runs of equal rows
+    } else if (set == 5) {
+        run<16, 4, 67>(n, 16, 1221, 16);            // gathers only, random inside the panel
+        run<16, 4, 1024 + 67>(n, 16, 1221, 16);     // gathers only, ascending ~2 lines apart
+        run<16, 4, 1>(n, 16, 1221, 16);             // whole kernel, perfect locality, random
+        run<16, 4, 1024 + 1>(n, 16, 1221, 16);      // whole kernel, ascending ~2 lines apart
     } else if (set == 4) {
         run<16, 4, 256 + 67>(n, 16, 1221, 16);      // gathers only, sc1
         run<16, 4, 512 + 67>(n, 16, 1221, 16);      // gathers only, nt
