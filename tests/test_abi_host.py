@@ -105,6 +105,19 @@ def test_compute_entry_points_fail_loudly_without_gpu():
     assert e.value.kind == "DeviceError" and "no CPU fallback" in str(e.value)
 
 
+def test_communicator_fails_loudly_without_gpu_and_validates_its_arguments():
+    lib = L.load()
+    h = ctypes.c_void_p()
+    assert lib.sl_comm_create(2, 2, b"x", ctypes.byref(h)) == 4 and not h.value            # rank out of range: InvalidInput
+    assert lib.sl_comm_create(0, 17, b"x", ctypes.byref(h)) == 4                            # more ranks than one node holds
+    assert lib.sl_comm_create(0, 1, b"a/b", ctypes.byref(h)) == 4                           # the rendezvous is a name, not a path
+    n = ctypes.c_int(0)
+    lib.sl_device_count(ctypes.byref(n))
+    if n.value == 0:
+        assert lib.sl_comm_create(0, 1, b"cpu_only_test", ctypes.byref(h)) == 11 and not h.value   # DeviceError, no CPU fallback
+        assert b"no CPU fallback" in lib.sl_last_error_message()
+
+
 def test_triplet_validation_happens_before_any_device_work():
     from sublinear_time_solver_amd import SparseMatrix, SolverError
     with pytest.raises(SolverError) as e:
