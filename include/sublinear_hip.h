@@ -282,6 +282,9 @@ void sl_comm_destroy(sl_comm *c);
 sl_status sl_comm_rank(const sl_comm *c, int *rank, int *world);
 sl_status sl_comm_barrier(sl_comm *c);                                      /* drains the calling thread's stream, then all ranks meet */
 sl_status sl_comm_allgather_u64(sl_comm *c, uint64_t mine, uint64_t *all); /* e.g. row counts -> row ranges; all[world] */
+/* row ranges with equal shares of STORED ENTRIES from a host row_ptr (rank r starts at the first row whose prefix
+ * reaches r * nnz / world); bounds[world + 1].  Pure host arithmetic: needs neither a device nor a communicator. */
+sl_status sl_balanced_row_bounds(uint64_t n_rows, const uint32_t *row_ptr, int world, uint64_t *bounds);
 sl_status sl_neumann_state_create_partitioned(sl_comm *c, const sl_matrix *local_rows, const double *b_local, const double *initial_guess_local,
                                               const sl_neumann_options *opts, sl_neumann_state **out);
 /* `steps` fused steps (a8 + a9) from the state's current term without the stop rule — the measurement loop; *last_norm2 = ||t||^2

@@ -123,6 +123,7 @@ SIGNATURES = {
     "sl_comm_rank": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sl_comm_barrier": (C.c_int, [vp]),
     "sl_comm_allgather_u64": (C.c_int, [vp, u64, vp]),
+    "sl_balanced_row_bounds": (C.c_int, [u64, vp, C.c_int, vp]),
     "sl_neumann_state_create_partitioned": (C.c_int, [vp, vp, vp, vp, C.POINTER(NeumannOptions), C.POINTER(vp)]),
     "sl_neumann_state_run_steps": (C.c_int, [vp, u64, C.POINTER(f64), C.POINTER(C.c_float)]),
     "sl_push_options_default": (None, [C.POINTER(PushOptions)]),

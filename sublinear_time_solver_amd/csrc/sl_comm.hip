@@ -276,6 +276,23 @@ sl_status sl_comm_rank(const sl_comm *c, int *rank, int *world)
     return SL_OK;
 }
 
+// contiguous row ranges balanced by stored entries — rank r starts at the first row whose prefix sum of row_ptr
+// reaches r * nnz / world.  Host arithmetic on a host row_ptr; every rank derives the same bounds from the same row_ptr.
+sl_status sl_balanced_row_bounds(uint64_t n_rows, const uint32_t *row_ptr, int world, uint64_t *bounds)
+{
+    if (!row_ptr || !bounds || world < 1) return sl_fail(SL_INVALID_INPUT, "null argument or world < 1");
+    const uint64_t nnz = row_ptr[n_rows];
+    bounds[0] = 0;
+    for (int r = 1; r < world; ++r) {
+        const uint64_t target = (uint64_t)r * nnz / (uint64_t)world;
+        uint64_t lo = 0, hi = n_rows + 1;                         // first index i in [0, n_rows] with row_ptr[i] >= target
+        while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (row_ptr[mid] < target) lo = mid + 1; else hi = mid; }
+        bounds[r] = std::max<uint64_t>(std::min<uint64_t>(lo, n_rows), bounds[r - 1]);
+    }
+    bounds[world] = n_rows;
+    return SL_OK;
+}
+
 sl_status sl_comm_allgather_u64(sl_comm *c, uint64_t mine, uint64_t *all)
 {
     SL_ABI_BEGIN

@@ -105,6 +105,22 @@ def test_compute_entry_points_fail_loudly_without_gpu():
     assert e.value.kind == "DeviceError" and "no CPU fallback" in str(e.value)
 
 
+def test_balanced_row_bounds_match_the_python_partition():
+    """sl_balanced_row_bounds (host arithmetic) == distributed.nnz_balanced_bounds on ragged row_ptrs"""
+    from sublinear_time_solver_amd import distributed as D
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    for n, world in ((5, 2), (1000, 8), (17, 4), (1, 3), (6000, 16)):
+        cnt = rng.integers(0, 40, size=n)
+        cnt[rng.integers(0, n)] = 5000                                     # a hub row
+        rp = np.zeros(n + 1, dtype=np.uint32)
+        rp[1:] = np.cumsum(cnt)
+        out = np.zeros(world + 1, dtype=np.uint64)
+        assert lib.sl_balanced_row_bounds(n, L.ptr(rp), world, L.ptr(out)) == 0
+        assert out.tolist() == D.nnz_balanced_bounds(rp, world)
+    assert lib.sl_balanced_row_bounds(5, None, 2, L.ptr(np.zeros(3, dtype=np.uint64))) == 4
+
+
 def test_communicator_fails_loudly_without_gpu_and_validates_its_arguments():
     lib = L.load()
     h = ctypes.c_void_p()
