@@ -150,9 +150,20 @@ class ForwardPushSolver(_PushBase):
     def solve_multi_source(self, sources: Sequence[int]) -> PushResult:  # :125-177
         return self._solve(list(sources))
 
-    def query_single_entry(self, source: int, target: int) -> float:   # :224-231
-        r = self.solve_single_source(source)
-        return float(r.estimate[target]) if 0 <= target < r.estimate.size else 0.0
+    def query_single_entry(self, source: int, target: int, via: str = "local") -> float:   # :224-231
+        """pi_source(target).  via="local" (default): ONE entry of the solution of A x = alpha e_source — a local push on A^T from
+        e_target on the device (sl_estimate_entry: cost = the rows that push touches, nothing of size n comes back);
+        via="solve": the spec's own route, the whole single-source solve, then one entry of it."""
+        n, c = self.graph.n, self.config
+        if not (0 <= source < n) or not (0 <= target < n):            # :75-83 / :226-230
+            return 0.0
+        if via == "solve":
+            return float(self.solve_single_source(source).estimate[target])
+        from .solver import estimate_entry
+        b = np.zeros(n)
+        b[source] = c.alpha
+        m = self.graph.system(c.alpha, self.backward)
+        return float(estimate_entry(m, b, target, theta=c.alpha * c.epsilon, max_rounds=max(1, c.max_pushes)).estimate)
 
 
 class BackwardPushSolver(_PushBase):

@@ -72,3 +72,16 @@ def test_random_graph_forward_backward_bidirectional(gpu):
     br = b.solve_single_target(17)
     combined = b.combine_with_forward(br, fr.estimate, fr.residual)                 # backward_push.rs:314-333
     assert np.isfinite(combined) and combined >= 0
+
+
+def test_single_entry_query_is_local(gpu):
+    """query_single_entry (forward_push.rs:224-231): the default route is ONE entry through a local push on the transposed system
+    (nothing of size n comes back); it agrees with the spec's route — the whole single-source solve, then one entry — within the
+    stop rule's error on a 5000-node graph"""
+    g = random_graph(5000, 4)
+    s = ForwardPushSolver(g, ForwardPushConfig(alpha=0.15, epsilon=1e-9))
+    full = s.solve_single_source(11).estimate
+    for t in (0, 11, 1234, 4999):
+        assert abs(s.query_single_entry(11, t) - full[t]) < 1e-6
+        assert s.query_single_entry(11, t, via="solve") == full[t]
+    assert s.query_single_entry(11, 5000) == 0.0 and s.query_single_entry(-1, 3) == 0.0
