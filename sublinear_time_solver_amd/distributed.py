@@ -627,3 +627,42 @@ def hip_local_ops(matrix_handle: int, dinv_local: torch.Tensor, order: int = 0) 
         out[0] = h.value
 
     return LocalOps(step, residual_norm2, axpy, sumsq)
+
+
+class AbiPartitionedNeumannSolver:
+    """The partitioned solve through the library's OWN multi-GPU path (C ABI: sl_comm_*, sl_neumann_state_create_partitioned, _run,
+    _solution) — this class only passes pointers; PartitionedNeumannSolver above is the same loop over torch.distributed / RCCL.
+    One instance per rank; every rank of the job passes the same `name`."""
+
+    def __init__(self, rank: int, world: int, name: str):
+        from .solver import Communicator
+        self.comm = Communicator(rank, world, name)
+
+    def solve(self, matrix_handle, b_local: torch.Tensor, tolerance: float = 1e-6, max_iterations: int = 1000, max_terms: int = 50,
+              series_tolerance: float = 1e-8, order: int = 0) -> dict:
+        """matrix_handle: this rank's row slice (sl_matrix_create_csr with row_offset = first row, n_cols = n_global);
+        b_local: its rows of the right-hand side (device tensor).  Collective."""
+        import ctypes as C
+
+        from . import _lib as L
+        lib = L.load()
+        o = L.NeumannOptions()
+        lib.sl_neumann_options_default(C.byref(o))
+        o.tolerance, o.max_iterations, o.max_terms, o.series_tolerance = tolerance, max_iterations, max_terms, series_tolerance
+        o.order, o.mem = order, L.SL_MEM_DEVICE
+        st = C.c_void_p()
+        L.check(lib.sl_neumann_state_create_partitioned(self.comm._h, matrix_handle, b_local.data_ptr(), None, C.byref(o), C.byref(st)))
+        try:
+            res = L.NeumannResult()
+            status = lib.sl_neumann_state_run(st, None, C.byref(res))
+            x = torch.empty_like(b_local)
+            L.check(lib.sl_neumann_state_solution(st, x.data_ptr(), L.SL_MEM_DEVICE))
+            if status not in (0, 3):
+                L.check(status)
+            return {"solution_local": x, "iterations": int(res.iterations), "terms": int(res.terms_computed), "converged": bool(res.converged),
+                    "residual_norm": res.residual_norm, "last_term_norm": res.last_term_norm, "device_time_ms": res.device_time_ms}
+        finally:
+            lib.sl_neumann_state_destroy(st)
+
+    def close(self) -> None:
+        self.comm.close()

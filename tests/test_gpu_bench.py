@@ -74,7 +74,7 @@ def test_partitioned_solve_script_two_ranks_equals_one(gpu):
     import os
     import socket
 
-    def run(ranks, rows, bandwidth=700, bounds=None):
+    def run(ranks, rows, bandwidth=700, bounds=None, exchange="torch"):
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -83,6 +83,7 @@ def test_partitioned_solve_script_two_ranks_equals_one(gpu):
                "--master-port", str(port), "tools/solve_partitioned.py", "--rows", str(rows), "--bandwidth", str(bandwidth), "--tolerance", "1e-9"]
         if bounds:
             cmd += ["--bounds", bounds]
+        cmd += ["--exchange", exchange]
         r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, SL_BENCH_BACKEND="gloo"))
         assert r.returncode == 0, r.stderr[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -92,6 +93,12 @@ def test_partitioned_solve_script_two_ranks_equals_one(gpu):
     assert (one["iterations"], one["terms"]) == (two["iterations"], two["terms"])
     for key in ("residual_norm", "sum_x", "sum_x2", "last_term_norm"):
         assert abs(one[key] - two[key]) <= 1e-11 * max(1.0, abs(one[key])), key
+    # the same solve through the library's own communicator (C ABI), two ranks sharing the GPU, equal and unequal ranges
+    for kw in (dict(rows=100_000), dict(rows=0, bounds="0,61234,200000")):
+        abi = run(2, exchange="abi", **kw)
+        assert abi["converged"] and (one["iterations"], one["terms"]) == (abi["iterations"], abi["terms"]) and "abi" in abi["config"]
+        for key in ("residual_norm", "sum_x", "sum_x2", "last_term_norm"):
+            assert abs(one[key] - abi[key]) <= 1e-11 * max(1.0, abs(one[key])), key
     # unequal row ranges (RowPartition with explicit bounds, as nnz_balanced_bounds returns): halo and gather exchanges
     for bw in (700, 0):
         ref = one if bw == 700 else run(1, 200_000, bw)

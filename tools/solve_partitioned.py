@@ -7,8 +7,10 @@ residual check, all-reduced norms).  One process per GPU:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \\
         tools/solve_partitioned.py --rows 10000000
 
-SL_BENCH_BACKEND=gloo stages the exchanges through the host so that several ranks can share one GPU (tests).  Rank 0 prints
-one JSON object."""
+`--exchange abi` runs the SAME solve through the library's own communicator and partitioned NeumannState (C ABI: sl_comm_*,
+sl_neumann_state_create_partitioned / _run / _solution; no process group is initialised, ranks may share a GPU).
+SL_BENCH_BACKEND=gloo stages the torch.distributed exchanges through the host so that several ranks can share one GPU (tests).
+Rank 0 prints one JSON object."""
 import argparse
 import ctypes as C
 import json
@@ -21,6 +23,49 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL peer access on this platform needs dmabuf IPC
 
 
+def main_abi(a, world, rank, local_rank, dev):
+    """the same solve through distributed.AbiPartitionedNeumannSolver: communicator + partitioned NeumannState of the C ABI"""
+    import torch
+    from sublinear_time_solver_amd import _lib as L
+    from sublinear_time_solver_amd import distributed as D
+    lib = L.load()
+    L.check(lib.sl_set_device(local_rank))
+    k, w = a.k, a.bandwidth
+    if a.bounds:
+        bounds = [int(v) for v in a.bounds.split(",")]
+        n_global = bounds[-1]
+        part = D.RowPartition(n_global, world, rank, bounds=bounds)
+    else:
+        n_global = a.rows * world
+        part = D.RowPartition(n_global, world, rank)
+    n_local = part.n_local
+    rp = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
+    ci = torch.empty(n_local * k, dtype=torch.int32, device=dev)
+    va = torch.empty(n_local * k, dtype=torch.float64, device=dev)
+    b = torch.empty(n_local, dtype=torch.float64, device=dev)
+    L.check(lib.sl_synth_sdd_device(n_global, k, a.seed, w, part.lo, part.hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), b.data_ptr()))
+    h = C.c_void_p()
+    L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, part.lo, 0, C.byref(h)))
+    del rp, ci, va
+    solver = D.AbiPartitionedNeumannSolver(rank, world, f"solve_{os.environ.get('MASTER_PORT', '0')}")
+    solver.comm.barrier()
+    t0 = time.perf_counter()
+    r = solver.solve(h, b, tolerance=a.tolerance, order=a.order)
+    solver.comm.barrier()
+    dt = time.perf_counter() - t0
+    x = r["solution_local"]
+    sx = sum(solver.comm.allgather_f64(float(x.sum())))
+    sx2 = sum(solver.comm.allgather_f64(float((x * x).sum())))
+    if rank == 0:
+        launches = r["terms"] - 1 + (r["iterations"] + 4) // 5 + 1
+        print(json.dumps({"config": f"S-DD(n={n_global}, nnz/row={k}, w={w}) over {world} rank(s), exchange abi (sl_comm)", "n_gpus": world,
+                          "iterations": r["iterations"], "terms": r["terms"], "converged": r["converged"], "residual_norm": r["residual_norm"],
+                          "solve_s": dt, "rows_iter_per_s": n_global * launches / dt, "nnz_iter_per_s": n_global * k * launches / dt,
+                          "sum_x": sx, "sum_x2": sx2, "last_term_norm": r["last_term_norm"]}), flush=True)
+    solver.close()
+    lib.sl_matrix_destroy(h)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per rank")
@@ -29,6 +74,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tolerance", type=float, default=1e-8)
     ap.add_argument("--order", type=int, default=0)
+    ap.add_argument("--exchange", choices=["torch", "abi"], default="torch", help="torch = torch.distributed (RCCL / gloo); abi = sl_comm behind the C ABI")
     ap.add_argument("--bounds", type=str, default="", help="explicit row bounds b0,b1,...,bN (N = ranks, b0 = 0, bN = n_global) instead of "
                     "--rows per rank: unequal row ranges, as nnz-balanced bounds of a ragged system would be")
     a = ap.parse_args()
@@ -43,8 +89,12 @@ def main():
     backend = os.environ.get("SL_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
+    if a.exchange == "abi":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if a.exchange == "abi":
+        return main_abi(a, world, rank, local_rank, dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
