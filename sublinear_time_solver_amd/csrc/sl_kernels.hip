@@ -872,22 +872,24 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
                     for (int o = 32; o > 0; o >>= 1) maxrun = max(maxrun, (uint32_t)__shfl_xor(maxrun, o));
                     const uint32_t partno = (uint32_t)__popcll(cut & ((2ull << lane) - 1ull)), nparts = (uint32_t)__popcll(cut) + 1u;
                     const double q1 = __shfl_down(prod, 1), q2 = __shfl_down(prod, 2), q3 = __shfl_down(prod, 3);
+                    // one panel (part) after the other, and a part's runs COMPLETELY — also those longer than four — before the next
+                    // part begins: the row a panel ends with may be the row the next panel starts with (its first entries must not
+                    // overtake the tail of the run before it)
                     for (uint32_t f = 0; f < nparts; ++f) {
-                        if (leader && partno == f) {
-                            double sacc = DADD(acc[row], prod);
+                        const bool mine = leader && partno == f;
+                        double sacc = 0.0;
+                        if (mine) {
+                            sacc = DADD(acc[row], prod);
                             if (runlen > 1) sacc = DADD(sacc, q1);
                             if (runlen > 2) sacc = DADD(sacc, q2);
                             if (runlen > 3) sacc = DADD(sacc, q3);
-                            acc[row] = sacc;
                         }
+                        for (uint32_t st = 4; st < maxrun; ++st) {                // wave-uniform trip count; the shuffle runs on all lanes
+                            const double qq = __shfl_down(prod, st);
+                            if (mine && runlen > st) sacc = DADD(sacc, qq);
+                        }
+                        if (mine) acc[row] = sacc;
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the next panel's runs may meet the same rows
-                    }
-                    for (uint32_t st = 4; st < maxrun; ++st) {                    // runs longer than four: the rest, one step at a time
-                        const double qq = __shfl_down(prod, st);
-                        for (uint32_t f = 0; f < nparts; ++f) {
-                            if (leader && partno == f && runlen > st) acc[row] = DADD(acc[row], qq);
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        }
                     }
                 }
             }

@@ -203,3 +203,25 @@ def test_paced_row_slice(gpu, paced):
     assert m.info().column_panels == 2
     x = np.cos(np.arange(n) * 0.05)
     assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x)[lo:hi])
+
+
+def test_paced_runs_longer_than_four_ending_a_panel_followed_by_the_same_row(gpu, monkeypatch):
+    """A band of half-width 14000 over 120 000 columns through the paced layout with the device's real CU count: tiles of 16 rows,
+    every row a run of up to 16 entries inside one panel — and the rows around column 65536 with 15 entries in panel 0 and one in
+    panel 1: the row that ends a tile's panel-0 segment is the row that starts its panel-1 segment, inside the same 64 entries.  The
+    first panel's run (longer than four) has to be complete before the next panel's entry is added (a regression test: the tail of
+    long runs used to be applied after ALL panels' heads)."""
+    monkeypatch.setenv("SL_PW_FORCE", "1")
+    n, k, w = 120_000, 16, 14_000
+    rp, ci, va, b = G.sdd_rows(n, k, seed=9, half_bandwidth=w)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, column_panels=True)
+    assert m.info().column_panels == 2
+    x = np.sin(np.arange(n) * 0.05) + 0.3
+    assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
+    lo, hi = 41_111, 99_999
+    prp = (rp[lo:hi + 1].astype(np.int64) - int(rp[lo])).astype(np.uint32)
+    ms = S.SparseMatrix.from_csr(prp, ci[rp[lo]:rp[hi]], va[rp[lo]:rp[hi]], hi - lo, n, row_offset=lo, column_panels=True)
+    assert ms.info().column_panels == 2 and _bits_equal(ms.multiply_vector(x), O.spmv(rp, ci, va, x)[lo:hi])
+    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-10)
+    g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-10))
+    assert g.iterations == o["iterations"] and _bits_equal(g.solution, o["x"])
