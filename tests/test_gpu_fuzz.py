@@ -73,3 +73,56 @@ def test_random_systems_bitwise(gpu, n, w, max_len, long_rows):
             assert (e.rounds, e.pushes) == (q["rounds"], q["pushes"])
             est = float(np.dot(q["x"], b))
             assert abs(e.estimate - est) <= 1e-13 * max(1.0, np.abs(q["x"]).sum() * np.abs(b).max())
+
+
+# ---- the paced column-panel layout under random structure --------------------------------------------------------------------
+def _structured_system(rng, rows, cols, kind, max_len, dup):
+    """rows x cols operator (cols >= rows, diagonal inside): columns uniform / banded / clustered around a few centres / a mix;
+    empty rows, duplicates (the same column stored twice: kept, added twice in stored order), a few rows beyond the long-row limit"""
+    tr, tc, tv = [], [], []
+    centres = rng.integers(0, cols, size=5)
+    for i in range(rows):
+        m = int(rng.integers(0, max_len + 1))
+        if rng.random() < 0.004:
+            m = int(rng.integers(300, 900))
+        m = min(m, cols - 1)
+        k = kind if kind != "mix" else ("uniform", "band", "cluster")[i % 3]
+        if k == "uniform":
+            c = rng.integers(0, cols, size=m)
+        elif k == "band":
+            w = max(4, cols // 7)
+            c = np.clip(i + rng.integers(-w, w + 1, size=m), 0, cols - 1)
+        else:
+            c = np.clip(centres[rng.integers(0, 5, size=m)] + rng.integers(-40, 41, size=m), 0, cols - 1)
+        c = np.unique(c[c != i])
+        if dup and c.size > 2 and i % 5 == 0:
+            c = np.sort(np.concatenate([c, c[:2]]))                       # two duplicated columns
+        v = rng.uniform(-1.0, 1.0, size=c.size)
+        tr += [i] * (c.size + 1); tc += c.tolist() + [i]; tv += v.tolist() + [2.0 * np.abs(v).sum() + 1.0]
+    return O.csr_from_triplets(tr, tc, tv, rows, cols)
+
+
+PACED = [(70, 70, "uniform", 6, False, 1), (1000, 1000, "band", 20, True, 1), (4097, 4097, "cluster", 12, True, 2), (9001, 9001, "mix", 30, True, 3),
+         (3000, 200_000, "uniform", 9, False, 2), (5000, 3_000_000, "cluster", 14, True, 1), (20_011, 20_011, "band", 16, False, 2),
+         (12_345, 2_200_000, "mix", 25, True, 3), (257, 70_000, "uniform", 40, True, 1)]
+
+
+@pytest.mark.parametrize("rows,cols,kind,max_len,dup,cus", PACED)
+def test_paced_panels_random_structures_bitwise(gpu, monkeypatch, rows, cols, kind, max_len, dup, cus):
+    """the paced layout forced on matrices it would never be chosen for: tiny and ragged tiles, one to three pretended CUs (several
+    rounds), panels with one entry or hundreds, runs of any length, the same row on both sides of a panel boundary, empty rows,
+    duplicates, rows left to the long-row kernel, rectangular operators whose super-panels are mostly empty"""
+    monkeypatch.setenv("SL_PW_FORCE", "1")
+    monkeypatch.setenv("SL_PW_CUS", str(cus))
+    rng = np.random.default_rng(rows * 7 + cols + cus)
+    rp, ci, va = _structured_system(rng, rows, cols, kind, max_len, dup)
+    m = S.SparseMatrix.from_csr(rp, ci, va, rows, cols, column_panels=True)
+    assert m.info().column_panels == 2
+    for rep in range(2):
+        x = rng.standard_normal(cols)
+        assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x)), rep
+    if rows == cols:
+        b = rng.standard_normal(rows)
+        g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-11))
+        o = O.neumann_solve(rp, ci, va, b, tolerance=1e-11)
+        assert (g.iterations, g.converged) == (o["iterations"], o["converged"]) and _bits_equal(g.solution, o["x"])
