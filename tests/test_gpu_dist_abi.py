@@ -31,3 +31,15 @@ def test_partitioned_solve_through_the_c_abi(gpu, dist_exe, world, n, w, uneven)
     env = dict(os.environ, SL_COMM_TIMEOUT_MS="30000")
     r = subprocess.run([str(dist_exe), str(world), str(n), str(w)] + (["uneven"] if uneven else []), capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "dist_smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_a_rank_that_never_arrives_becomes_an_error_not_a_hang(gpu):
+    """world = 2 with only rank 0 present: the rendezvous wait is bounded (SL_COMM_TIMEOUT_MS) and comes back as DeviceError"""
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r); import sublinear_time_solver_amd as S\n"
+            "t0 = time.time()\n"
+            "try:\n    S.Communicator(0, 2, 'lonely_rank_test')\n    print('NO ERROR')\n"
+            "except S.SolverError as e:\n    print('kind', e.kind, 'after', round(time.time() - t0, 1))\n") % str(ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, SL_COMM_TIMEOUT_MS="1500"))
+    assert r.returncode == 0 and "kind DeviceError" in r.stdout, r.stdout + r.stderr[-1500:]
+    assert float(r.stdout.split("after")[1]) < 30.0
