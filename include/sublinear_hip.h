@@ -273,7 +273,10 @@ typedef struct {
  * Per iteration a rank (i) runs the fused step on its rows, (ii) publishes its share of ||t||^2 and waits for all ranks' shares
  * (summed in rank order: the same bits everywhere, so every rank takes the same stop decision), (iii) pulls the pieces of the new
  * term its columns reach (the measured bandwidth of its rows) out of its peers' vectors over xGMI (IPC-mapped device memory);
- * every 5th iteration the solution travels the same way for the residual (neumann.rs:489-491).  Per-row results equal the
+ * every 5th iteration the solution travels the same way for the residual (neumann.rs:489-491).  Where every rank has interior
+ * rows beyond the largest reach (banded systems), the step runs BOUNDARY FIRST: the blocks at both ends of the rank's range, a
+ * "halo ready" handshake and the pulls on a second stream beside the interior blocks, joined before the sum (SL_DIST_OVERLAP=0
+ * keeps the plain order).  Per-row results equal the
  * one-GPU solve bit for bit; norms are sums of per-rank sums (equal to ~1e-16 relative).  A peer that never arrives turns
  * into SL_DEVICE_ERROR after SL_COMM_TIMEOUT_MS (20 s), never into a hung queue. */
 typedef struct sl_comm sl_comm;

@@ -88,7 +88,11 @@ bool sl_side_stream(sl_ctx &c)
     if (hipGetDevice(&dev) != hipSuccess) return false;
     if (c.side && c.side_device == dev) return true;
     if (c.side) { (void)hipStreamDestroy(c.side); (void)hipEventDestroy(c.ev_fork); (void)hipEventDestroy(c.ev_join); c.side = nullptr; }
-    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) { c.side = nullptr; return false; }
+    // the side stream carries the short chains that others wait for (hub rows beside the slice kernel; a partition's edge blocks, halo
+    // ticket and pulls beside the interior): highest priority, so that its blocks are dispatched ahead of the long kernel's
+    int pr_least = 0, pr_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+    if (hipStreamCreateWithPriority(&c.side, hipStreamNonBlocking, pr_greatest) != hipSuccess) { c.side = nullptr; return false; }
     if (hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(c.side); c.side = nullptr; return false;
     }
@@ -569,7 +573,17 @@ struct sl_neumann_state {
     // vectors of the partition (dist->t[0/1]); x / rhs / dinv / b stay local
     sl_dist *dist = nullptr;
     double *tpair[2] = {nullptr, nullptr};             // the two term buffers t_cur / t_nxt alternate between
-    ~sl_neumann_state() { sl_dist_destroy(dist); }
+    // boundary-first step of a partition (dist_step): the step launch's blocks [0, ov_edge) and [ov_tail, ov_blocks) — the rows the
+    // peers pull — run on the side stream with the "halo ready" ticket and the pulls behind them, the interior blocks beside them on
+    // the main stream.  ov_edge = 0: off (one launch, then ticket and pulls)
+    uint32_t ov_edge = 0, ov_tail = 0, ov_blocks = 0;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    ~sl_neumann_state()
+    {
+        if (ev_main) (void)hipEventDestroy(ev_main);
+        if (ev_side) (void)hipEventDestroy(ev_side);
+        sl_dist_destroy(dist);
+    }
     double *t_cur = nullptr, *t_nxt = nullptr;
     double resn = INFINITY, tn = 0.0;
     bool series_conv = false;
@@ -634,6 +648,80 @@ sl_status dist_agree(sl_comm *c, sl_status mine)
     return SL_OK;
 }
 
+// Collective: does every rank have an interior to hide the exchange behind?  A rank's edge = the blocks holding the rows within the
+// largest reach of any rank from either end of its range (what a neighbour pulls); the step kernel must be one that launches in
+// ranges (band / general kernel, no hub rows), and the edges must leave at least one interior block.  SL_DIST_OVERLAP=0 turns the
+// boundary-first step off, =2 keeps it on at world size 1 (tests).
+sl_status dist_plan_overlap(sl_neumann_state &st)
+{
+    static const int env = [] { const char *e = getenv("SL_DIST_OVERLAP"); return e && *e ? atoi(e) : 1; }();
+    sl_dist *d = st.dist;
+    uint32_t R = 0, NB = 0;
+    SL_TRY(sl_rows_geometry(sl_matrix_row_args(st.m), (sl_order)st.o.order, SL_EPI_NEUMANN, &R, &NB));
+    const uint64_t W = d->max_reach;
+    uint64_t edge = 0, real_blocks = 0;
+    bool mine = env != 0 && R != 0 && W > 0 && W < d->n_global && (d->c->world > 1 || env == 2) && sl_side_stream(sl_context());
+    if (mine) {
+        edge = (W + R - 1) / R + 1;                                     // + 1: the last block may be ragged
+        real_blocks = (st.n + R - 1) / R;
+        mine = 2 * edge + 1 <= real_blocks;
+    }
+    if (mine && (!st.ev_main || !st.ev_side))
+        mine = hipEventCreateWithFlags(&st.ev_main, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&st.ev_side, hipEventDisableTiming) == hipSuccess;
+    std::vector<uint64_t> all((size_t)d->c->world);
+    const uint64_t flag = mine ? 1 : 0;
+    SL_TRY(sl_comm_allgather_blob(d->c, &flag, sizeof(flag), all.data()));
+    for (uint64_t f : all) if (!f) mine = false;
+    if (mine) { st.ov_edge = (uint32_t)edge; st.ov_tail = (uint32_t)(real_blocks - edge); st.ov_blocks = NB; }
+    sl_log(1, "partition: rank %d %s (reach %llu, %u rows per block, %llu edge blocks of %llu)", d->c->rank,
+           mine ? "runs its edge blocks first, the exchange beside the interior" : "exchanges after the whole step", (unsigned long long)W, R,
+           (unsigned long long)(2 * edge), (unsigned long long)real_blocks);
+    return SL_OK;
+}
+
+// One fused step t_nxt = (I - D^-1 A) t_cur, x += t_nxt on a partition, enqueued on `s`: this rank's share of ||t_nxt||^2 into
+// d_loc, the sum over all ranks (rank order) into `result` / judged against the stop rule, the pieces of the new term this rank's
+// columns reach pulled into `vec`.  `a` carries the step's vectors and — inside a speculative batch — the gate.
+// Boundary-first form (ov_edge != 0), per step k:
+//   side:  wait(main so far: the sum ticket of step k-1)  edge blocks  ->  ticket "halo ready" (all ranks)  ->  pulls
+//   main:  interior blocks                                 wait(side)  ->  reduction  ->  sum ticket
+// The side chain starts behind the previous sum ticket, so every rank gates the same launches off when a stop rule has fired (a
+// "halo ready" ticket that one rank skipped and another waits for cannot happen); edge blocks write rows the peers pull only after
+// the peers' previous pulls (their halo ticket k follows those pulls in stream order, and this rank's edge blocks of step k+1 follow
+// its own wait on halo ticket k); interior and edge blocks write disjoint rows; the pulls write outside this rank's rows.
+sl_status dist_step(sl_neumann_state &st, sl_row_args a, sl_dist_vector *vec, double *d_loc, double *result, sl_solve_ctl *ctl, uint32_t rel,
+                    uint32_t slot, int mode, double thr, hipStream_t s)
+{
+    sl_dist *D = st.dist;
+    const sl_order order = (sl_order)st.o.order;
+    a.result = d_loc;
+    a.ctl = ctl; a.gate_it = rel; a.ctl_slot = slot; a.ctl_mode = SL_JUDGE_LOCAL; a.ctl_threshold = thr;
+    if (!st.ov_edge) {
+        SL_TRY(sl_launch_rows(a, order, SL_EPI_NEUMANN, s));
+        SL_TRY(sl_comm_launch_ticket(D->c, d_loc, result, ctl, rel, slot, mode, thr, s));
+        return sl_dist_pull(D, vec, s);
+    }
+    sl_ctx &c = sl_context();
+    if (!sl_side_stream(c)) return sl_fail(SL_DEVICE_ERROR, "no side stream for the boundary-first step");
+    uint32_t nparts = 0;
+    SL_HIP(hipEventRecord(st.ev_main, s));
+    SL_HIP(hipStreamWaitEvent(c.side, st.ev_main, 0));
+    sl_row_args e = a;
+    e.blk_lo = 0; e.blk_cnt = st.ov_edge;
+    SL_TRY(sl_launch_rows(e, order, SL_EPI_NEUMANN, c.side, &nparts));
+    e.blk_lo = st.ov_tail; e.blk_cnt = st.ov_blocks - st.ov_tail;       // to the end of the grid: the padding blocks write their zero partials
+    SL_TRY(sl_launch_rows(e, order, SL_EPI_NEUMANN, c.side));
+    SL_TRY(sl_comm_launch_ticket(D->c, nullptr, nullptr, ctl, rel, 0, SL_JUDGE_LOCAL, 0.0, c.side, 1));
+    SL_TRY(sl_dist_pull(D, vec, c.side));
+    SL_HIP(hipEventRecord(st.ev_side, c.side));
+    sl_row_args in = a;
+    in.blk_lo = st.ov_edge; in.blk_cnt = st.ov_tail - st.ov_edge;
+    SL_TRY(sl_launch_rows(in, order, SL_EPI_NEUMANN, s));
+    SL_HIP(hipStreamWaitEvent(s, st.ev_side, 0));
+    SL_TRY(sl_launch_rows_reduce(a, SL_EPI_NEUMANN, nparts, s));
+    return sl_comm_launch_ticket(D->c, d_loc, result, ctl, rel, slot, mode, thr, s);
+}
+
 // NeumannState::new on a row partition: `m` = this rank's rows [lo, hi) with global column ids (row_offset = lo, n_cols = n_global)
 sl_status state_init_partitioned(sl_neumann_state &st, sl_comm *c, const sl_matrix *m, const double *b, const double *initial_guess,
                                  const sl_neumann_options *o)
@@ -679,7 +767,7 @@ sl_status state_init_partitioned(sl_neumann_state &st, sl_comm *c, const sl_matr
     SL_TRY(sl_dist_pull(d, &d->t[0], s));
     SL_HIP(hipStreamSynchronize(s));
     if (sl_comm_failed(c)) return sl_fail(SL_DEVICE_ERROR, "a rank of the communicator did not arrive (first exchange)");
-    return SL_OK;
+    return dist_plan_overlap(st);
 }
 
 // the loop of NeumannSolver::solve (neumann.rs:477-555) from the state's current position; iteration count starts at 0
@@ -755,10 +843,9 @@ sl_status state_run(sl_neumann_state &st, double *term_norms, sl_neumann_result 
                     sl_row_args a = row_args(m);
                     a.gather = p_cur; a.dinv = dinv.as<double>(); a.out = p_nxt + lo; a.x = x.as<double>();
                     a.partials = scr; a.partials_slack = 4096; a.result = D ? d_loc : nullptr;
-                    a.ctl = d_ctl; a.gate_it = rel; a.ctl_slot = (uint32_t)plan.size(); a.ctl_mode = D ? SL_JUDGE_LOCAL : SL_JUDGE_LT; a.ctl_threshold = thr_series;
-                    status = sl_launch_rows(a, order, SL_EPI_NEUMANN, s);
-                    if (D && status == SL_OK) status = sl_comm_launch_ticket(D->c, d_loc, nullptr, d_ctl, rel, (uint32_t)plan.size(), SL_JUDGE_LT, thr_series, s);
-                    if (D && status == SL_OK) status = sl_dist_pull(D, vec_of(p_nxt), s);   // the new term's pieces this rank's columns reach
+                    a.ctl = d_ctl; a.gate_it = rel; a.ctl_slot = (uint32_t)plan.size(); a.ctl_mode = SL_JUDGE_LT; a.ctl_threshold = thr_series;
+                    if (D) status = dist_step(st, a, vec_of(p_nxt), d_loc, nullptr, d_ctl, rel, (uint32_t)plan.size(), SL_JUDGE_LT, thr_series, s);
+                    else status = sl_launch_rows(a, order, SL_EPI_NEUMANN, s);
                     std::swap(p_cur, p_nxt);
                     plan.push_back({1, p_cur});
                 } else {
@@ -940,11 +1027,8 @@ sl_status sl_neumann_state_run_steps(sl_neumann_state *st, uint64_t steps, doubl
         sl_row_args a = sl_matrix_row_args(st->m);
         a.gather = st->t_cur; a.dinv = st->dinv.as<double>(); a.out = st->t_nxt + lo; a.x = st->x.as<double>();
         a.partials = scr; a.partials_slack = 4096; a.result = D ? d_loc : d_res;
-        SL_TRY(sl_launch_rows(a, (sl_order)st->o.order, SL_EPI_NEUMANN, s));
-        if (D) {
-            SL_TRY(sl_comm_launch_ticket(D->c, d_loc, d_res, nullptr, 0, 0, SL_JUDGE_NONE, 0.0, s));
-            SL_TRY(sl_dist_pull(D, st->t_nxt == D->t[0].mine ? &D->t[0] : &D->t[1], s));
-        }
+        if (D) SL_TRY(dist_step(*st, a, st->t_nxt == D->t[0].mine ? &D->t[0] : &D->t[1], d_loc, d_res, nullptr, 0, 0, SL_JUDGE_NONE, 0.0, s));
+        else SL_TRY(sl_launch_rows(a, (sl_order)st->o.order, SL_EPI_NEUMANN, s));
         std::swap(st->t_cur, st->t_nxt);
     }
     const float ms = timer.stop();

@@ -88,23 +88,27 @@ __device__ __forceinline__ uint64_t sys_load(const uint64_t *p) { return __hip_a
 
 // One wave.  `local` (device) holds this rank's contribution (may be null: a pure "data ready" ticket, value 0).  With ctl: gated
 // like every launch of a speculative batch; the sum is logged and judged exactly as sl_judge_reduce_kernel does for one GPU.
+// Channel 1 ("halo ready", the boundary-first step) carries no value and judges nothing: it has its own ticket counter and its own
+// word of the rank's line, so that it may run on a second stream beside the sums of channel 0.
 __global__ __launch_bounds__(64) void sl_comm_ticket_kernel(sl_comm_shm *shm, int rank, int world, uint64_t ticket, const double *local,
                                                              double *result, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot, int mode, double thr,
-                                                             unsigned long long timeout_ticks)
+                                                             unsigned long long timeout_ticks, int chan)
 {
     if (ctl && gate_it > ctl->stop_after) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t ring = (uint32_t)(ticket % SL_COMM_RING);
     if (__hip_atomic_load(&shm->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;      // a rank gave up: drain the queue without waiting
     if (lane == 0) {
-        const double v = local ? *local : 0.0;
-        __hip_atomic_store(&shm->value[ring][rank], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&shm->ready[rank][0], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // everything before this launch is done (stream order)
+        if (chan == 0) {
+            const double v = local ? *local : 0.0;
+            __hip_atomic_store(&shm->value[ring][rank], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __hip_atomic_store(&shm->ready[rank][chan], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // everything before this launch is done (stream order)
     }
     bool ok = true;
     if (lane < (uint32_t)world) {
         const unsigned long long t0 = wall_clock64();
-        while (sys_load(&shm->ready[lane][0]) < ticket) {
+        while (sys_load(&shm->ready[lane][chan]) < ticket) {
             __builtin_amdgcn_s_sleep(16);
             if (wall_clock64() - t0 > timeout_ticks) { ok = false; break; }
         }
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(64) void sl_comm_ticket_kernel(sl_comm_shm *shm, in
         if (ctl) ctl->stop_after = 0;                                    // nothing enqueued behind this runs
         return;
     }
+    if (chan != 0) return;
     double t = 0.0;
     for (int p = 0; p < world; ++p) t += __hip_atomic_load(&shm->value[ring][p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // rank order: same bits everywhere
     if (result) result[0] = t;
@@ -130,12 +135,12 @@ __global__ __launch_bounds__(64) void sl_comm_ticket_kernel(sl_comm_shm *shm, in
 }
 
 sl_status sl_comm_launch_ticket(sl_comm *c, const double *local, double *result, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot, int mode,
-                                double thr, hipStream_t s)
+                                double thr, hipStream_t s, int channel)
 {
-    const uint64_t ticket = ++c->ticket;
+    const uint64_t ticket = ++c->ticket[channel ? 1 : 0];
     const unsigned long long ticks = (unsigned long long)comm_timeout_ms() * 100000ull;            // wall_clock64: 100 MHz
     hipLaunchKernelGGL(sl_comm_ticket_kernel, dim3(1), dim3(64), 0, s, c->d_shm, c->rank, c->world, ticket, local, result, ctl, gate_it, slot, mode,
-                       thr, ticks);
+                       thr, ticks, channel ? 1 : 0);
     SL_HIP(hipGetLastError());
     return SL_OK;
 }
@@ -327,6 +332,13 @@ sl_status sl_dist_create(sl_comm *c, const sl_matrix *local, sl_dist **out)
                                                                        (unsigned long long)ng, (unsigned long long)local->n_cols); }
     d->lo = d->bounds[c->rank]; d->hi = d->bounds[c->rank + 1];
     const uint64_t w = (local->bandwidth == ~0ull || local->nnz == 0) ? (local->nnz ? d->n_global : 0) : local->bandwidth;
+    d->reach = w;
+    {
+        std::vector<uint64_t> reaches((size_t)c->world);
+        st = sl_comm_allgather_blob(c, &w, sizeof(uint64_t), reaches.data());
+        if (st != SL_OK) { delete d; return st; }
+        d->max_reach = *std::max_element(reaches.begin(), reaches.end());
+    }
     const uint64_t a = d->lo > w ? d->lo - w : 0, b = std::min<uint64_t>(d->n_global, d->hi + w);
     for (int p = 0; p < c->world; ++p) {
         if (p == c->rank) continue;

@@ -285,8 +285,15 @@ struct sl_row_args {
     uint32_t gate_it, ctl_slot;
     int ctl_mode;         // SL_JUDGE_*: which comparison of the reduced sum against ctl_threshold closes the gate
     double ctl_threshold;
+    // a RANGE of the launch's row blocks (blk_cnt != 0): logical blocks [blk_lo, blk_lo + blk_cnt) only, no closing reduction — the
+    // partitioned step runs the blocks at the edges of a rank's row range apart from the interior (sl_rows_geometry, sl_launch_rows_reduce)
+    uint32_t blk_lo, blk_cnt;
 };
 sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s, uint32_t *n_partials = nullptr);
+// rows per block and blocks (padding included) of the launch sl_launch_rows would make; rows_per_block = 0: this matrix / kernel has no range launches
+sl_status sl_rows_geometry(const sl_row_args &a, sl_order order, sl_epilogue epi, uint32_t *rows_per_block, uint32_t *n_blocks);
+// the closing reduction of a launch made in ranges (n_partials as sl_launch_rows reports it for the whole launch)
+sl_status sl_launch_rows_reduce(const sl_row_args &a, sl_epilogue epi, uint32_t n_partials, hipStream_t s);
 sl_status sl_launch_final_reduce(const double *partials, uint32_t n, double *result, hipStream_t s);
 sl_row_args sl_matrix_row_args(const sl_matrix *m);   // matrix part filled, vectors null
 uint32_t sl_row_grid(uint64_t n_slices);
@@ -322,7 +329,7 @@ struct sl_comm_shm {
     volatile uint64_t arrive[SL_COMM_MAX_RANKS];                 // host barrier
     volatile uint64_t blob_seq[SL_COMM_MAX_RANKS];               // host exchange of small blobs (IPC handles, row ranges)
     volatile unsigned char blob[SL_COMM_MAX_RANKS][SL_COMM_BLOB];
-    uint64_t ready[SL_COMM_MAX_RANKS][16];                       // device side: one 128-byte line per rank, [0] = last published ticket
+    uint64_t ready[SL_COMM_MAX_RANKS][16];                       // device side: one 128-byte line per rank, [c] = last published ticket of channel c (0: sums, 1: halo ready)
     double value[SL_COMM_RING][SL_COMM_MAX_RANKS];               // device side: the values published with the tickets (ring)
     uint64_t error;                                              // a wait timed out (rank + 1)
 };
@@ -332,7 +339,7 @@ struct sl_comm {
     sl_comm_shm *h_shm = nullptr, *d_shm = nullptr;
     size_t shm_bytes = 0;
     bool registered = false;
-    uint64_t barrier_count = 0, blob_count = 0, ticket = 0;      // advanced in the same order on every rank
+    uint64_t barrier_count = 0, blob_count = 0, ticket[2] = {0, 0};   // advanced in the same order on every rank; ticket[channel]
 };
 struct sl_dist_vector { uint64_t n = 0; double *mine = nullptr; std::vector<double *> peer; };
 struct sl_dist {
@@ -341,12 +348,13 @@ struct sl_dist {
     std::vector<uint64_t> bounds;                                // world + 1
     struct piece { int rank; uint64_t lo, hi; };
     std::vector<piece> need;                                     // what this rank pulls per exchange: global index ranges of its peers' rows
+    uint64_t reach = 0, max_reach = 0;                           // columns this rank's rows reach beyond its range; the largest over all ranks
     sl_dist_vector t[2], x;                                      // gathered term vectors (ping-pong) and gathered solution
 };
 sl_status sl_comm_host_barrier(sl_comm *c);
 sl_status sl_comm_allgather_blob(sl_comm *c, const void *mine, size_t bytes, void *all);
 sl_status sl_comm_launch_ticket(sl_comm *c, const double *local, double *result, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot, int mode,
-                                double thr, hipStream_t s);
+                                double thr, hipStream_t s, int channel = 0);
 bool sl_comm_failed(const sl_comm *c);
 sl_status sl_dist_create(sl_comm *c, const sl_matrix *local, sl_dist **out);
 void sl_dist_destroy(sl_dist *d);

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32
     // XCD-aware mapping: physical block b is dispatched to XCD b % 8; give every XCD a
     // contiguous range of row blocks so that its private L2 sees one band of the gathered
     // vector (speed only — correctness does not depend on placement).
-    const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
+    uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
+    if (a.blk_cnt) { if (lb >= a.blk_cnt) return; lb += a.blk_lo; }     // a range of the launch's blocks (block-uniform)
     const uint64_t s = (uint64_t)lb * SL_WAVES_PER_BLOCK + wave;
     const uint64_t i = s * SL_SLICE + lane;
     const bool live_slice = s < a.n_slices;
@@ -447,7 +448,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_ro
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
+    uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
+    if (a.blk_cnt) { if (lb >= a.blk_cnt) return; lb += a.blk_lo; }     // a range of the launch's blocks (block-uniform)
     const uint64_t R = (uint64_t)NW * spw * SL_SLICE;
     const uint64_t r0 = (uint64_t)lb * R;                       // first local row of the block
     double part0 = 0.0, part1 = 0.0;
@@ -1215,6 +1217,41 @@ static bool mpass_eligible(const sl_row_args &a)
 }
 
 template <int ORDER, int EPI>
+static band_geom pick_band(const sl_row_args &a)
+{
+    const bool uniform_unrolled = ORDER == 0 && (a.uniform_width == 16 || a.uniform_width == 8);
+    // a uniform-width matrix carries its 16-bit offsets in the OCTET layout of the unrolled path; when it runs through
+    // the batched path instead (simd4 order), that path — which reads the QUAD layout — uses the u32 columns
+    const bool uniform_octets = a.uniform_width == 8 || a.uniform_width == 16;
+    // 8-wave blocks (wide windows) are held to 128 VGPRs.  The unrolled uniform-width variants fit (except the push
+    // epilogue at width 16, which would spill ~100 B per lane and lose 10 %: it stays at 4 waves); the batched path fits
+    // with 3 quads per batch (2 in the 4-lane order) instead of 4
+    const bool nw8_pays = !(EPI == SL_EPI_PUSH && uniform_unrolled && a.uniform_width == 16);
+    return band_geometry(a, uniform_unrolled || !uniform_octets, nw8_pays, !uniform_unrolled);
+}
+
+// rows per block / blocks of the launch launch_rows_t would make; *rows = 0: a layout without range launches
+template <int ORDER, int EPI>
+static void rows_geom_t(const sl_row_args &a, uint32_t *rows, uint32_t *blocks)
+{
+    *rows = 0; *blocks = 0;
+    if (a.n_long || a.n_slices == 0) return;
+    if (ORDER == 0 && ((a.pw_idx && a.pw_tiles) || (a.pan_tile_ptr && a.n_pan_tiles))) return;
+    const band_geom g = pick_band<ORDER, EPI>(a);
+    if (g.spw) {
+        const uint64_t per_block = (uint64_t)g.nw * g.spw;
+        const uint64_t nb = (a.n_slices + per_block - 1) / per_block;
+        *rows = (uint32_t)(per_block * SL_SLICE);
+        *blocks = (uint32_t)((nb + 7) / 8) * 8;
+    } else if (ORDER == 0 && mpass_eligible(a)) {
+        return;
+    } else {
+        *rows = SL_WAVES_PER_BLOCK * SL_SLICE;
+        *blocks = sl_row_grid(a.n_slices);
+    }
+}
+
+template <int ORDER, int EPI>
 static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t *nparts)
 {
     sl_row_args a = a_in;
@@ -1225,15 +1262,10 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
             SL_HIP(hipStreamWaitEvent(c.side, c.ev_fork, 0));
         }
     }
-    const bool uniform_unrolled = ORDER == 0 && (a.uniform_width == 16 || a.uniform_width == 8);
-    // a uniform-width matrix carries its 16-bit offsets in the OCTET layout of the unrolled path; when it runs through
-    // the batched path instead (simd4 order), that path — which reads the QUAD layout — uses the u32 columns
-    const bool uniform_octets = a.uniform_width == 8 || a.uniform_width == 16;
-    // 8-wave blocks (wide windows) are held to 128 VGPRs.  The unrolled uniform-width variants fit (except the push
-    // epilogue at width 16, which would spill ~100 B per lane and lose 10 %: it stays at 4 waves); the batched path fits
-    // with 3 quads per batch (2 in the 4-lane order) instead of 4
-    const bool nw8_pays = !(EPI == SL_EPI_PUSH && uniform_unrolled && a.uniform_width == 16);
-    const band_geom g = band_geometry(a, uniform_unrolled || !uniform_octets, nw8_pays, !uniform_unrolled);
+    const band_geom g = pick_band<ORDER, EPI>(a);
+    const uint32_t range_cnt = a.blk_cnt;                              // != 0: a range of the blocks (band and general kernel only)
+    if (range_cnt && (a.n_long || (ORDER == 0 && ((a.pw_idx && a.pw_tiles) || (a.pan_tile_ptr && a.n_pan_tiles) || (!g.spw && mpass_eligible(a))))))
+        return sl_fail(SL_UNSUPPORTED_FORMAT, "this matrix layout has no range launches");
     if (ORDER == 0 && a.pw_idx && a.pw_tiles) {
         const uint32_t lds = (uint32_t)(SL_PW_WAVES * ((size_t)a.pw_rpw + 1) * sizeof(double));
         SL_TRY(set_max_lds_once<sl_pw_kernel<EPI>>((int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double))));
@@ -1266,10 +1298,11 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
     } else if (g.spw) {
         const uint64_t per_block = (uint64_t)g.nw * g.spw;
         const uint64_t nb = (a.n_slices + per_block - 1) / per_block;
-        const uint32_t nb8 = (uint32_t)((nb + 7) / 8);
-        const uint32_t grid = nb8 * 8;
+        uint32_t nb8 = (uint32_t)((nb + 7) / 8);
+        uint32_t grid = nb8 * 8;
         *nparts = grid + a.n_long;
         a.part_stride = *nparts;
+        if (range_cnt) { nb8 = (range_cnt + 7) / 8; grid = nb8 * 8; }   // the range's own XCD-contiguous mapping
         sl_status st;
         if (ORDER == 0 && a.uniform_width == 16) st = launch_band_u<ORDER, EPI, 16>(a, g, grid, nb8, s);
         else if (ORDER == 0 && a.uniform_width == 8) st = launch_band_u<ORDER, EPI, 8>(a, g, grid, nb8, s);
@@ -1294,9 +1327,10 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
             hipLaunchKernelGGL((sl_mpass_kernel<EPI, 4, 4>), dim3(grid), dim3(SL_MP_WAVES * 64), lds, s, a, nb8, (uint32_t)a.bandwidth);
         }
     } else {
-        const uint32_t grid = sl_row_grid(a.n_slices), nb8 = grid / 8;
+        uint32_t grid = sl_row_grid(a.n_slices), nb8 = grid / 8;
         *nparts = grid + a.n_long;
         a.part_stride = *nparts;
+        if (range_cnt) { nb8 = (range_cnt + 7) / 8; grid = nb8 * 8; }
         if (ORDER == 0 && a.uniform_width == 16)
             hipLaunchKernelGGL((sl_rows_kernel<0, EPI, 16>), dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
         else if (ORDER == 0 && a.uniform_width == 8)
@@ -1344,6 +1378,24 @@ sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, 
     }
     if (st != SL_OK) return st;
     if (n_partials) *n_partials = nparts;
+    if (a.blk_cnt) return SL_OK;                                        // a range: the caller closes with sl_launch_rows_reduce
+    return sl_launch_rows_reduce(a, epi, nparts, s);
+}
+
+sl_status sl_rows_geometry(const sl_row_args &a, sl_order order, sl_epilogue epi, uint32_t *rows_per_block, uint32_t *n_blocks)
+{
+    const bool simd4 = (order == SL_ORDER_SIMD4);
+    switch (epi) {
+    case SL_EPI_SPMV: simd4 ? rows_geom_t<1, SL_EPI_SPMV>(a, rows_per_block, n_blocks) : rows_geom_t<0, SL_EPI_SPMV>(a, rows_per_block, n_blocks); break;
+    case SL_EPI_NEUMANN: simd4 ? rows_geom_t<1, SL_EPI_NEUMANN>(a, rows_per_block, n_blocks) : rows_geom_t<0, SL_EPI_NEUMANN>(a, rows_per_block, n_blocks); break;
+    case SL_EPI_RESIDUAL: simd4 ? rows_geom_t<1, SL_EPI_RESIDUAL>(a, rows_per_block, n_blocks) : rows_geom_t<0, SL_EPI_RESIDUAL>(a, rows_per_block, n_blocks); break;
+    case SL_EPI_PUSH: simd4 ? rows_geom_t<1, SL_EPI_PUSH>(a, rows_per_block, n_blocks) : rows_geom_t<0, SL_EPI_PUSH>(a, rows_per_block, n_blocks); break;
+    }
+    return SL_OK;
+}
+
+sl_status sl_launch_rows_reduce(const sl_row_args &a, sl_epilogue epi, uint32_t nparts, hipStream_t s)
+{
     const double *parts = a.partials;
     if (epi != SL_EPI_SPMV && (a.ctl || a.result) && nparts > SL_PRE_THRESHOLD && a.partials_slack >= 2 * SL_PRE_BLOCKS) {
         const int nsets = epi == SL_EPI_PUSH ? 2 : 1;

@@ -33,6 +33,20 @@ def test_partitioned_solve_through_the_c_abi(gpu, dist_exe, world, n, w, uneven)
     assert r.returncode == 0 and "dist_smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("world,n,w,overlap,expect", [(2, 200000, 300, "1", True),      # edge blocks first, exchange beside the interior
+                                                      (2, 200000, 300, "0", False),     # the same system, exchange after the whole step
+                                                      (3, 600000, 5000, "1", True),     # band kernel with a wide window, unequal ranges
+                                                      (4, 40000, 15000, "1", False),    # reach beyond the neighbour: no interior to hide behind
+                                                      (1, 300000, 2000, "2", True)])    # forced on at world size 1 (no peers, same stream topology)
+def test_boundary_first_step_gives_the_same_bits(gpu, dist_exe, world, n, w, overlap, expect):
+    """the partitioned step with its edge blocks, halo ticket and pulls on the side stream beside the interior blocks: same iteration
+    count, same solution bit for bit as the one-GPU solve (checked inside dist_smoke), and the log says which form ran"""
+    env = dict(os.environ, SL_COMM_TIMEOUT_MS="30000", SL_DIST_OVERLAP=overlap, SL_LOG="1")
+    r = subprocess.run([str(dist_exe), str(world), str(n), str(w)] + (["uneven"] if world == 3 else []), capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "dist_smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert ("runs its edge blocks first" in r.stderr) == expect, r.stderr[-3000:]
+
+
 def test_a_rank_that_never_arrives_becomes_an_error_not_a_hang(gpu):
     """world = 2 with only rank 0 present: the rendezvous wait is bounded (SL_COMM_TIMEOUT_MS) and comes back as DeviceError"""
     import sys
