@@ -12,6 +12,12 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
+# the layout small matrices get: dynamic tiles (1) — or the paced layout (2) when a run forces it on every size (SL_PW_FORCE=1:
+# the whole file then exercises the paced kernel on these inputs as well)
+import os
+_SMALL = 2 if os.environ.get("SL_PW_FORCE") == "1" else 1
+
+
 def _bits_equal(a, b):
     return (np.ascontiguousarray(a).view(np.uint64) == np.ascontiguousarray(b).view(np.uint64)).all()
 
@@ -21,7 +27,7 @@ def test_uniform_columns_spmv_neumann_residual(gpu, n, k):
     rp, ci, va, b = G.sdd_rows(n, k, seed=4)                               # w = 0: columns all over the vector
     mp = S.SparseMatrix.from_csr(rp, ci, va, n, n, column_panels=True)
     mg = S.SparseMatrix.from_csr(rp, ci, va, n, n, column_panels=False)
-    assert mp.info().column_panels == 1 and mg.info().column_panels == 0
+    assert mp.info().column_panels == _SMALL and mg.info().column_panels == 0
     assert mp.info().device_bytes > mg.info().device_bytes
     x = np.cos(np.arange(n) * 0.11) + 0.3
     ref = O.spmv(rp, ci, va, x)
@@ -59,7 +65,7 @@ def test_ragged_rows_hubs_duplicates_and_dense_push_rounds(gpu):
     rp, ci, va = _ragged_system()
     n = rp.size - 1
     mp = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True, column_panels=True)
-    assert mp.info().column_panels == 1 and mp.info().n_long_rows > 0
+    assert mp.info().column_panels == _SMALL and mp.info().n_long_rows > 0
     x = np.sin(np.arange(n) * 0.7) - 0.2
     assert _bits_equal(mp.multiply_vector(x), O.spmv(rp, ci, va, x))
     b = 1.0 + (np.arange(n) % 7) * 0.5
@@ -81,7 +87,7 @@ def test_row_slice_of_a_larger_system(gpu):
     prp = (rp[lo:hi + 1].astype(np.int64) - int(rp[lo])).astype(np.uint32)
     pci, pva = ci[rp[lo]:rp[hi]], va[rp[lo]:rp[hi]]
     m = S.SparseMatrix.from_csr(prp, pci, pva, hi - lo, n, row_offset=lo, column_panels=True)
-    assert m.info().column_panels == 1
+    assert m.info().column_panels == _SMALL
     x = np.cos(np.arange(n) * 0.05)
     assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x)[lo:hi])
 
@@ -98,7 +104,7 @@ def test_thin_panels_same_row_twice_in_one_chunk(gpu):
     ci = np.concatenate([np.sort(rng.choice(cols, size=int(c), replace=False)) for c in cnt]).astype(np.uint32)
     va = rng.uniform(-1.0, 1.0, size=ci.size)
     m = S.SparseMatrix.from_csr(rp, ci, va, rows, cols, column_panels=True)
-    assert m.info().column_panels == 1
+    assert m.info().column_panels == _SMALL
     x = rng.uniform(-1.0, 1.0, size=cols)
     assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x))
 
