@@ -179,11 +179,37 @@ void sl_dist_vector_destroy(sl_comm *c, sl_dist_vector *v)
     v->mine = nullptr;
 }
 
-sl_status sl_dist_pull(const sl_dist *d, sl_dist_vector *v, hipStream_t s)
+#define SL_PULL_PARALLEL_BYTES (4u << 20)      // below this an exchange is two halo strips: one stream, no forks
+sl_status sl_dist_pull(sl_dist *d, sl_dist_vector *v, hipStream_t s)
 {
-    for (const sl_dist::piece &pc : d->need)
-        if (pc.hi > pc.lo)
-            SL_HIP(hipMemcpyAsync(v->mine + pc.lo, v->peer[pc.rank] + pc.lo, (pc.hi - pc.lo) * sizeof(double), hipMemcpyDeviceToDevice, s));
+    static const bool parallel_ok = [] { const char *e = getenv("SL_PULL_STREAMS"); return !(e && *e && atoi(e) == 0); }();
+    auto copy = [&](const sl_dist::piece &pc, hipStream_t q) {
+        return hipMemcpyAsync(v->mine + pc.lo, v->peer[pc.rank] + pc.lo, (pc.hi - pc.lo) * sizeof(double), hipMemcpyDeviceToDevice, q);
+    };
+    if (!parallel_ok || d->need.size() < 2 || d->pull_bytes < SL_PULL_PARALLEL_BYTES) {
+        for (const sl_dist::piece &pc : d->need)
+            if (pc.hi > pc.lo) SL_HIP(copy(pc, s));
+        return SL_OK;
+    }
+    const size_t ns = std::min<size_t>(d->need.size(), 8);
+    if (d->pull_streams.size() < ns) {
+        if (!d->pull_fork) SL_HIP(hipEventCreateWithFlags(&d->pull_fork, hipEventDisableTiming));
+        while (d->pull_streams.size() < ns) {
+            hipStream_t q = nullptr;
+            hipEvent_t e = nullptr;
+            SL_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(q); return sl_fail(SL_DEVICE_ERROR, "event creation failed"); }
+            d->pull_streams.push_back(q); d->pull_done.push_back(e);
+        }
+    }
+    SL_HIP(hipEventRecord(d->pull_fork, s));
+    for (size_t q = 0; q < ns; ++q) SL_HIP(hipStreamWaitEvent(d->pull_streams[q], d->pull_fork, 0));
+    for (size_t i = 0; i < d->need.size(); ++i)
+        if (d->need[i].hi > d->need[i].lo) SL_HIP(copy(d->need[i], d->pull_streams[i % ns]));
+    for (size_t q = 0; q < ns; ++q) {
+        SL_HIP(hipEventRecord(d->pull_done[q], d->pull_streams[q]));
+        SL_HIP(hipStreamWaitEvent(s, d->pull_done[q], 0));
+    }
     return SL_OK;
 }
 
@@ -354,6 +380,9 @@ sl_status sl_dist_create(sl_comm *c, const sl_matrix *local, sl_dist **out)
 void sl_dist_destroy(sl_dist *d)
 {
     if (!d) return;
+    for (hipStream_t q : d->pull_streams) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    for (hipEvent_t e : d->pull_done) (void)hipEventDestroy(e);
+    if (d->pull_fork) (void)hipEventDestroy(d->pull_fork);
     for (sl_dist_vector *v : {&d->t[0], &d->t[1], &d->x}) sl_dist_vector_destroy(d->c, v);
     delete d;
 }

@@ -350,6 +350,11 @@ struct sl_dist {
     std::vector<piece> need;                                     // what this rank pulls per exchange: global index ranges of its peers' rows
     uint64_t reach = 0, max_reach = 0;                           // columns this rank's rows reach beyond its range; the largest over all ranks
     sl_dist_vector t[2], x;                                      // gathered term vectors (ping-pong) and gathered solution
+    // large exchanges (uniform columns: every peer's whole range): one copy stream per peer, so that the pulls travel over their
+    // xGMI links side by side instead of one after the other (created on first use)
+    std::vector<hipStream_t> pull_streams;
+    std::vector<hipEvent_t> pull_done;
+    hipEvent_t pull_fork = nullptr;
 };
 sl_status sl_comm_host_barrier(sl_comm *c);
 sl_status sl_comm_allgather_blob(sl_comm *c, const void *mine, size_t bytes, void *all);
@@ -360,4 +365,4 @@ sl_status sl_dist_create(sl_comm *c, const sl_matrix *local, sl_dist **out);
 void sl_dist_destroy(sl_dist *d);
 sl_status sl_dist_vector_create(sl_comm *c, uint64_t n_global, sl_dist_vector *v);
 void sl_dist_vector_destroy(sl_comm *c, sl_dist_vector *v);
-sl_status sl_dist_pull(const sl_dist *d, sl_dist_vector *v, hipStream_t s);
+sl_status sl_dist_pull(sl_dist *d, sl_dist_vector *v, hipStream_t s);

@@ -26,6 +26,7 @@ def dist_exe(tmp_path_factory):
                                               (3, 50000, 700, True),        # three ranks, unequal row ranges
                                               (2, 30000, 10**9, False),     # columns all over the matrix: every rank pulls everything
                                               (4, 40000, 15000, True),      # reach beyond the next neighbour
+                                              (3, 1500000, 10**9, True),    # 8 MB per exchange: the pulls run on one stream per peer
                                               (1, 5000, 50, False)])        # a communicator of one
 def test_partitioned_solve_through_the_c_abi(gpu, dist_exe, world, n, w, uneven):
     env = dict(os.environ, SL_COMM_TIMEOUT_MS="30000")
