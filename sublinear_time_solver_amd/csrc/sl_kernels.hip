@@ -698,6 +698,109 @@ __global__ __launch_bounds__(SL_MP_WAVES * 64, 2) void sl_mpass_kernel(sl_row_ar
     sl_block_partials<EPI, SL_MP_WAVES>(a, red, lane, wave, lb, a.part_stride, part0, part1);
 }
 
+// ---- cross-lane moves on the VALU (DPP) instead of the LDS pipe (ds_bpermute) ----------------------------------------------------
+// gfx9 wave shifts (checked on gfx950, tools/dpp_check.hip): wave_shl:1 hands lane l the value of lane l + 1, wave_shr:1 that of
+// lane l - 1; the lane without a source reads 0.
+__device__ __forceinline__ uint32_t dpp_from_right(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t dpp_from_left(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ double dpp_from_right(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = dpp_from_right((uint32_t)b), hi = dpp_from_right((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// minimum over each row of 16 lanes, left in every lane of the row: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ uint32_t dpp_row_min(uint32_t m)
+{
+    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0xB1, 0xf, 0xf, false));
+    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x4E, 0xf, 0xf, false));
+    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x141, 0xf, 0xf, false));
+    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x140, 0xf, 0xf, false));
+    return m;
+}
+// number of set bits of a wave mask at lanes below this one
+__device__ __forceinline__ uint32_t mask_count_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+// One group of 64 consecutive stream entries of a column-panel layout (sorted by (panel, row slot, column)) added into the running
+// sums `acc` (LDS, one wave's tile) in the order of the sequential reference loop.  Entries of one row inside one panel sit in
+// neighbouring lanes and form a RUN: the run's first lane adds its followers' products in lane order and makes ONE LDS update; a row
+// that comes back behind a panel boundary inside the same 64 entries is a second run, and the runs of different panels (PARTS) are
+// applied one panel after the other.  The cross-lane work runs on the VALU / SALU (DPP wave shifts, wave masks): the LDS pipe sees
+// one read and one write per run — it carried 21 instructions per 64 entries when the neighbours, the run lengths and the follower
+// products travelled by ds_bpermute.  LDS accesses of one wave execute in issue order, so a row that comes back in a later part
+// (or a later group) reads what the earlier one wrote without a wait in between.  All 64 lanes must be active.
+// ROWBITS: row slots < 2^ROWBITS; panels < 2^(32 - ROWBITS).
+template <int ROWBITS>
+__device__ __forceinline__ void sl_ordered_accumulate(double *acc, uint32_t lane, uint32_t row, double prod, uint32_t pan)
+{
+    const uint32_t key = (pan << ROWBITS) | row;
+    const uint32_t pkey = dpp_from_left(key);
+    const unsigned long long same = __ballot(pkey == key) & ~1ull;                       // continues its left neighbour's run
+    const unsigned long long cut = __ballot(((pkey ^ key) >> ROWBITS) != 0u) & ~1ull;   // first entry of a panel
+    if (!(same | cut)) {                                 // 64 distinct rows of one panel
+        acc[row] = DADD(acc[row], prod);
+        return;
+    }
+    // lane l leads a run when it does not continue one; its followers sit in lanes l + 1, l + 2, ...
+    const unsigned long long s1 = same >> 1, s2 = s1 & (same >> 2), s3 = s2 & (same >> 3), s4 = s3 & (same >> 4);
+    if (s4) {
+        // a run longer than four entries (a row with five entries inside one panel: rare for uniform columns, the rule for the
+        // heavy rows of a graph): the follower products by general shuffles, as many steps as the longest run
+        const unsigned long long lead = ~same;
+        const unsigned long long above = lead & ~((2ull << lane) - 1ull);                 // run leaders to my right
+        const uint32_t runlen = (above ? (uint32_t)__builtin_ctzll(above) : 64u) - lane;  // meaningful on leaders
+        const bool leader = (lead >> lane) & 1ull;
+        uint32_t maxrun = 1u;                                                            // longest run = longest stretch of set bits in `same`, + 1
+        for (unsigned long long m = same; m; m &= m >> 1) ++maxrun;                       // scalar: one step per entry of the longest run
+        const uint32_t partno = mask_count_below(cut) + (__builtin_amdgcn_inverse_ballot_w64(cut) ? 1u : 0u);
+        const uint32_t nparts = (uint32_t)__popcll(cut) + 1u;
+        for (uint32_t f = 0; f < nparts; ++f) {
+            const bool mine = leader && partno == f;
+            double sacc = mine ? DADD(acc[row], prod) : 0.0;
+            for (uint32_t st = 1; st < maxrun; ++st) {                // wave-uniform trip count; the shuffle runs on all lanes
+                const double qq = __shfl_down(prod, st);
+                if (mine && runlen > st) sacc = DADD(sacc, qq);
+            }
+            if (mine) acc[row] = sacc;
+            asm volatile("" ::: "memory");                           // program order between the parts
+        }
+        return;
+    }
+    const bool leader = !__builtin_amdgcn_inverse_ballot_w64(same);
+    const bool f1 = __builtin_amdgcn_inverse_ballot_w64(s1);
+    const double q1 = dpp_from_right(prod);
+    double q2 = 0.0, q3 = 0.0;
+    bool f2 = false, f3 = false;
+    if (s2) {                                            // some row has three entries in this panel
+        q2 = dpp_from_right(q1); f2 = __builtin_amdgcn_inverse_ballot_w64(s2);
+        if (s3) { q3 = dpp_from_right(q2); f3 = __builtin_amdgcn_inverse_ballot_w64(s3); }
+    }
+    // one panel (part) after the other, and a part's runs COMPLETELY before the next part begins: the row a panel ends with may be
+    // the row the next panel starts with
+    if (!cut) {
+        if (leader) {
+            double sacc = DADD(acc[row], prod);
+            if (f1) sacc = DADD(sacc, q1);
+            if (f2) sacc = DADD(sacc, q2);
+            if (f3) sacc = DADD(sacc, q3);
+            acc[row] = sacc;
+        }
+    } else {
+        const uint32_t partno = mask_count_below(cut) + (__builtin_amdgcn_inverse_ballot_w64(cut) ? 1u : 0u);
+        const uint32_t nparts = (uint32_t)__popcll(cut) + 1u;
+        for (uint32_t f = 0; f < nparts; ++f) {
+            if (leader && partno == f) {
+                double sacc = DADD(acc[row], prod);
+                if (f1) sacc = DADD(sacc, q1);
+                if (f2) sacc = DADD(sacc, q2);
+                if (f3) sacc = DADD(sacc, q3);
+                acc[row] = sacc;
+            }
+            asm volatile("" ::: "memory");               // program order between the parts
+        }
+    }
+}
+
 // ---- column-panel kernel: gathers served by the L2 -----------------------------------------------------
 // For matrices whose columns are spread over a vector far larger than the L2 (uniformly random columns — the reference
 // generators' recipe): every gather of the general kernel misses L2, and misses are served at 58 G/s whatever the table size
@@ -739,25 +842,8 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
             for (int u = 0; u < U; ++u) {
                 const uint32_t row = rl[u];
                 const double prod = DMUL(v[u], tv[u]);
-                // 64 lanes = 64 consecutive entries of the stream.  Inside one panel they are sorted by (row, column): a row that
-                // appears more than once sits in neighbouring lanes.  Across a panel boundary the rows start over, so the same row
-                // may sit in two places of the chunk: the parts are applied one after the other, runs inside a part in lane order.
-                const uint32_t pan = cl[u] >> SL_PANEL_COL_BITS;
-                const uint32_t prow = __shfl_up(row, 1), ppan = __shfl_up(pan, 1);
-                const unsigned long long same = __ballot(lane > 0 && prow == row);
-                const unsigned long long cut = __ballot(lane > 0 && ppan != pan);
-                if (!(same | cut)) {
-                    acc[row] = DADD(acc[row], prod);
-                } else {
-                    const unsigned long long upto = (2ull << lane) - 1ull;
-                    const uint32_t part = (uint32_t)__popcll(cut & upto), nparts = (uint32_t)__popcll(cut) + 1u;
-                    const uint32_t pos = lane - (63u - (uint32_t)__builtin_clzll(~same & upto));     // place inside the run of equal rows
-                    uint32_t maxpos = pos;
-                    for (int off = 32; off > 0; off >>= 1) maxpos = max(maxpos, (uint32_t)__shfl_xor(maxpos, off));
-                    for (uint32_t f = 0; f < nparts; ++f)
-                        for (uint32_t step = 0; step <= maxpos; ++step)
-                            if (part == f && pos == step) acc[row] = DADD(acc[row], prod);
-                }
+                // 64 lanes = 64 consecutive entries of the stream (row slots < 2048 + 64: 12 bits)
+                sl_ordered_accumulate<12>(acc, lane, row, prod, cl[u] >> SL_PANEL_COL_BITS);
             }
         }
         for (uint32_t r = lane; r < SL_PANEL_TILE; r += 64) {
@@ -772,29 +858,6 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
     }
     sl_block_partials<EPI, SL_PANEL_WAVES>(a, red, lane, wave, lb, a.part_stride, part0, part1);
 }
-
-// ---- cross-lane moves on the VALU (DPP) instead of the LDS pipe (ds_bpermute) ----------------------------------------------------
-// gfx9 wave shifts (checked on gfx950, tools/dpp_check.hip): wave_shl:1 hands lane l the value of lane l + 1, wave_shr:1 that of
-// lane l - 1; the lane without a source reads 0.
-__device__ __forceinline__ uint32_t dpp_from_right(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
-__device__ __forceinline__ uint32_t dpp_from_left(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
-__device__ __forceinline__ double dpp_from_right(double v)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const uint32_t lo = dpp_from_right((uint32_t)b), hi = dpp_from_right((uint32_t)(b >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-// minimum over each row of 16 lanes, left in every lane of the row: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
-__device__ __forceinline__ uint32_t dpp_row_min(uint32_t m)
-{
-    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0xB1, 0xf, 0xf, false));
-    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x4E, 0xf, 0xf, false));
-    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x141, 0xf, 0xf, false));
-    m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x140, 0xf, 0xf, false));
-    return m;
-}
-// number of set bits of a wave mask at lanes below this one
-__device__ __forceinline__ uint32_t mask_count_below(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 // ---- paced column-panel kernel: persistent blocks, gathers served by the L2 ------------------------------------------------
 // Layout: sl_internal.hpp (sl_matrix::d_pw_*).  ONE 16-wave block per CU; wave w of block b owns, in round r, tile
@@ -876,80 +939,10 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
                 gg[u] = g[cc[u]];
             }
         };
-        // runs longer than four entries (a row with five entries inside one panel: rare): the follower products by general shuffles
-        auto accumulate_long_runs = [&](uint32_t row, double prod, unsigned long long same, unsigned long long cut) {
-            const unsigned long long lead = ~same;
-            const unsigned long long above = lead & ~((2ull << lane) - 1ull);                 // run leaders to my right
-            const uint32_t runlen = (above ? (uint32_t)__builtin_ctzll(above) : 64u) - lane;  // meaningful on leaders
-            const bool leader = (lead >> lane) & 1ull;
-            uint32_t maxrun = leader ? runlen : 1u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) maxrun = max(maxrun, (uint32_t)__shfl_xor(maxrun, o));
-            const uint32_t partno = (uint32_t)__popcll(cut & ((2ull << lane) - 1ull)), nparts = (uint32_t)__popcll(cut) + 1u;
-            for (uint32_t f = 0; f < nparts; ++f) {
-                const bool mine = leader && partno == f;
-                double sacc = mine ? DADD(acc[row], prod) : 0.0;
-                for (uint32_t st = 1; st < maxrun; ++st) {                // wave-uniform trip count; the shuffle runs on all lanes
-                    const double qq = __shfl_down(prod, st);
-                    if (mine && runlen > st) sacc = DADD(sacc, qq);
-                }
-                if (mine) acc[row] = sacc;
-            }
-        };
-        // The cross-lane work runs on the VALU / SALU (DPP wave shifts, wave masks), the LDS pipe sees one read and one write per
-        // run: it carried 21 instructions per 64 entries when the neighbours, the run lengths and the follower products travelled
-        // by ds_bpermute.  LDS accesses of one wave execute in issue order, so a row that comes back in a later part (or a later
-        // group of 64) reads what the earlier one wrote without a wait in between.
         auto accumulate = [&](const uint32_t (&ii)[4], const double (&vv)[4], const double (&gg)[4], const uint32_t (&cc)[4]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t row = ii[u] >> 21;
-                const double prod = DMUL(vv[u], gg[u]);
-                const uint32_t key = ((cc[u] >> SL_PANEL_COL_BITS) << 11) | row;                    // (panel, row slot < 2^11)
-                const uint32_t pkey = dpp_from_left(key);
-                const unsigned long long same = __ballot(pkey == key) & ~1ull;                       // continues its left neighbour's run
-                const unsigned long long cut = __ballot(((pkey ^ key) >> 11) != 0u) & ~1ull;        // first entry of a panel
-                if (!(same | cut)) {                                 // 64 distinct rows of one panel
-                    acc[row] = DADD(acc[row], prod);
-                    continue;
-                }
-                // lane l leads a run when it does not continue one; its followers sit in lanes l + 1, l + 2, ...
-                const unsigned long long s1 = same >> 1, s2 = s1 & (same >> 2), s3 = s2 & (same >> 3), s4 = s3 & (same >> 4);
-                if (s4) { accumulate_long_runs(row, prod, same, cut); continue; }
-                const bool leader = !__builtin_amdgcn_inverse_ballot_w64(same);
-                const bool f1 = __builtin_amdgcn_inverse_ballot_w64(s1);
-                const double q1 = dpp_from_right(prod);
-                double q2 = 0.0, q3 = 0.0;
-                bool f2 = false, f3 = false;
-                if (s2) {                                            // some row has three entries in this panel
-                    q2 = dpp_from_right(q1); f2 = __builtin_amdgcn_inverse_ballot_w64(s2);
-                    if (s3) { q3 = dpp_from_right(q2); f3 = __builtin_amdgcn_inverse_ballot_w64(s3); }
-                }
-                // one panel (part) after the other, and a part's runs COMPLETELY before the next part begins: the row a panel ends
-                // with may be the row the next panel starts with
-                if (!cut) {
-                    if (leader) {
-                        double sacc = DADD(acc[row], prod);
-                        if (f1) sacc = DADD(sacc, q1);
-                        if (f2) sacc = DADD(sacc, q2);
-                        if (f3) sacc = DADD(sacc, q3);
-                        acc[row] = sacc;
-                    }
-                } else {
-                    const uint32_t partno = mask_count_below(cut) + (__builtin_amdgcn_inverse_ballot_w64(cut) ? 1u : 0u);
-                    const uint32_t nparts = (uint32_t)__popcll(cut) + 1u;
-                    for (uint32_t f = 0; f < nparts; ++f) {
-                        if (leader && partno == f) {
-                            double sacc = DADD(acc[row], prod);
-                            if (f1) sacc = DADD(sacc, q1);
-                            if (f2) sacc = DADD(sacc, q2);
-                            if (f3) sacc = DADD(sacc, q3);
-                            acc[row] = sacc;
-                        }
-                        asm volatile("" ::: "memory");               // program order between the parts
-                    }
-                }
-            }
+            for (int u = 0; u < 4; ++u)                              // row slots < 2^11 (SL_PW_MAX_ROWS + the spare slot)
+                sl_ordered_accumulate<11>(acc, lane, ii[u] >> 21, DMUL(vv[u], gg[u]), cc[u] >> SL_PANEL_COL_BITS);
         };
         if (chunks) {
             const uint32_t lastc = chunks - 1u;
