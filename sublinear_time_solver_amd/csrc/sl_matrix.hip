@@ -484,9 +484,11 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     SL_HIP(hipGetLastError());
     SL_HIP(hipStreamSynchronize(st));
     m->n_pw_tiles = n_tiles; m->pw_chunks = chunks; m->pw_rpw = rpw;
-    // a wave moves through about n_panels * 256 / (entries per tile) panels per chunk of its stream; two chunks of lead keep its
-    // pipeline full (n = 10^7 x 16: 4 panels, measured 1 / 2 / 4 panels: 1.36 / 1.35 / 1.28 ms), more than the L2 holds helps nobody
-    m->pw_slack = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(4, (2 * 256 * n_panels * n_tiles + total - 1) / total));
+    // a wave moves through about n_panels * 256 / (entries per tile) panels per chunk of its stream.  The lead it is allowed over the
+    // slowest wave of its block: two thirds of that, at least one panel — since the accumulation got cheaper, waves that stay closer
+    // together win (tools/ab_slack.sh, n = 10^7 x 16, lead 1 / 2 / 3 / 4 / 6 panels: 0.950 / 0.966 / 0.966 / 0.985 / 1.000 ms; the same
+    // order at 10^6 x 8 .. 5 * 10^6 x 16; at two panels per chunk (10^7 x 8, 2 * 10^7 x 16) leads 1..3 lie within 1 %)
+    m->pw_slack = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (2 * 256 * n_panels * n_tiles + total * 3 / 2) / (total * 3)));
     m->pw_blocks = (uint32_t)std::min<uint64_t>(cus, (n_tiles + SL_PW_WAVES - 1) / SL_PW_WAVES);
     m->device_bytes += chunks * 256 * 12 + (n_tiles + 1) * 4;
     return SL_OK;
@@ -602,9 +604,11 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         // Round 2 (tools/ab_c2.sh, paced layout against the general kernel, ms per step): n = 10^6 x 8 0.087 / 0.087, 10^6 x 16
         // 0.108 / 0.146, 2 * 10^6 x 8 0.135 / 0.223, 3 * 10^6 x 16 0.290 / 0.660 — the paced layout pays from a vector of ~8 MB on;
         // the DYNAMIC tiles (fallback for unbalanced matrices) only from ~24 MB on (10^6 x 8: 0.168, worse than no panels).
-        const bool spread = 2 * far_entries > nnz;
+        const bool spread = 2 * far_entries > nnz - std::min<uint64_t>(n, nnz);      // of the off-diagonal entries (the diagonal is never far)
         const bool pays = m->n_cols >= (3ull << 20) && spread;
-        const bool pays_paced = m->n_cols >= (1ull << 20) && spread;
+        // (tools/ab_small_paced.sh after the accumulation moved to the VALU, paced / general: 7 * 10^5 x 8 0.058 / 0.048, 7 * 10^5 x 16
+        // 0.074 / 0.088, 10^6 x 8 0.070 / 0.086, 10^6 x 16 0.099 / 0.145, 1.5 * 10^6 x 8 0.094 / 0.151: from 9 * 10^5 columns on)
+        const bool pays_paced = m->n_cols >= 900000ull && spread;
         const uint64_t n_tiles = (n + SL_PANEL_TILE - 1) / SL_PANEL_TILE;
         const uint64_t n_panels = (m->n_cols + (1ull << SL_PANEL_COL_BITS) - 1) >> SL_PANEL_COL_BITS;
         if (!refused && (forced || pays || pays_paced) && nnz && nnz < 0x7fffffffull && n_tiles * n_panels < 0xfffffff0ull) {
