@@ -984,27 +984,53 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
     sl_block_partials<EPI, SL_PW_WAVES>(a, red, lane, wave, blockIdx.x, a.part_stride, part0, part1);
 }
 
-// ---- long rows: one block per row ------------------------------------------------------------------
-// Rows with more than SL_LONG_ROW entries (hubs of power-law graphs).  The 256 threads fetch the raw CSR
-// entries coalesced and form the products in parallel; the additions stay sequential in the reference's
-// order (thread 0 walks the products through LDS), so the result is bit-identical to the slice path.
+// ---- long rows: one wave per row ---------------------------------------------------------------------
+// Rows with more than the matrix's long_row entries (hubs of power-law graphs; 3.5 * 10^5 of them in the transposed PageRank
+// graph at n = 10^7, 27 to 31 000 entries each).  The 64 lanes fetch the raw CSR entries coalesced and form the products in
+// parallel; the additions stay sequential in the reference's order (lane 0 walks the products through the wave's LDS line), so
+// the result is bit-identical to the slice path.  One WAVE per row, four rows per block, no block barrier: most long rows are one
+// or two batches of 64 entries, i.e. a chain of load latencies (row pointers -> entries -> gather -> 64 adds -> store) — what
+// counts is how many rows are in flight per CU (round 2: a 256-thread block per row took 1.27 ms per dense PageRank round, more
+// than the panel kernel beside it).  Longer rows keep the next batch's loads in flight under the add chain of the current one.
 template <int ORDER, int EPI>
 __global__ __launch_bounds__(SL_BLOCK) void sl_long_rows_kernel(sl_row_args a, uint32_t slot0)
 {
-    __shared__ double prod[SL_BLOCK];
+    __shared__ double prod_lds[SL_BLOCK];
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;
-    const uint32_t i = a.long_rows[blockIdx.x];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t li = blockIdx.x * (SL_BLOCK / 64) + wave;           // position in the list of long rows = partial slot
+    if (li >= a.n_long) return;                                       // whole waves; no block barrier below
+    double *prod = prod_lds + wave * 64;
+    const uint32_t i = a.long_rows[li];
     const double *__restrict__ g = a.gather;
     const uint32_t s = a.csr_ptr[i], e = a.csr_ptr[i + 1], len = e - s;
+    // epilogue operands up front (lane 0): their latency hides under the row
+    double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
+    if (lane == 0) {
+        if constexpr (EPI == SL_EPI_NEUMANN) { e_t = g[a.row_offset + i]; e_d = a.dinv[i]; e_x = a.x[i]; }
+        else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
+        else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = g[a.row_offset + i]; }
+    }
     const uint32_t chunks4 = (ORDER == 1) ? ((len >> 2) << 2) : 0u;     // entries covered by full simd chunks (len >= 8 here)
     double sum = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
     bool merged = false;
-    for (uint32_t base = s; base < e; base += SL_BLOCK) {
-        const uint32_t k = base + threadIdx.x;
-        prod[threadIdx.x] = k < e ? DMUL(a.csr_val[k], g[a.csr_idx[k]]) : 0.0;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t cnt = (e - base) < SL_BLOCK ? (e - base) : SL_BLOCK;
+    // pipeline: entries (value, column) one batch ahead of their gather, the gather one batch ahead of the add chain
+    uint32_t k = s + lane;
+    double v_cur = k < e ? a.csr_val[k] : 0.0;
+    uint32_t c_cur = k < e ? a.csr_idx[k] : (uint32_t)(a.row_offset + i);
+    double g_cur = g[c_cur];
+    k += 64;
+    double v_nxt = k < e ? a.csr_val[k] : 0.0;
+    uint32_t c_nxt = k < e ? a.csr_idx[k] : (uint32_t)(a.row_offset + i);
+    for (uint32_t base = s; base < e; base += 64) {
+        const double g_nxt = g[c_nxt];                                  // gather of the next batch: in flight under this batch's chain
+        const uint32_t k2 = base + 128 + lane;
+        const double v_n2 = k2 < e ? a.csr_val[k2] : 0.0;               // entries of the batch after it
+        const uint32_t c_n2 = k2 < e ? a.csr_idx[k2] : (uint32_t)(a.row_offset + i);
+        prod[lane] = DMUL(v_cur, g_cur);                                // padding lanes: 0 * (own entry) — never added
+        __builtin_amdgcn_wave_barrier();                                // same wave: LDS accesses execute in issue order
+        if (lane == 0) {
+            const uint32_t cnt = (e - base) < 64u ? (e - base) : 64u;
             if constexpr (ORDER == 0) {
 #pragma unroll 8
                 for (uint32_t j = 0; j < cnt; ++j) sum = DADD(sum, prod[j]);
@@ -1022,18 +1048,17 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_long_rows_kernel(sl_row_args a, u
                 }
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        v_cur = v_nxt; g_cur = g_nxt;
+        v_nxt = v_n2; c_nxt = c_n2;
     }
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         if constexpr (ORDER == 1) { if (!merged) sum = DADD(DADD(DADD(l0, l1), l2), l3); }
-        double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0, part0 = 0.0, part1 = 0.0;
-        if constexpr (EPI == SL_EPI_NEUMANN) { e_t = g[a.row_offset + i]; e_d = a.dinv[i]; e_x = a.x[i]; }
-        else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
-        else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = g[a.row_offset + i]; }
+        double part0 = 0.0, part1 = 0.0;
         sl_row_epilogue<EPI>(a, i, sum, e_t, e_d, e_x, dself, part0, part1);
         if constexpr (EPI != SL_EPI_SPMV) {
-            a.partials[slot0 + blockIdx.x] = part0;
-            if constexpr (EPI == SL_EPI_PUSH) a.partials[(uint64_t)a.part_stride + slot0 + blockIdx.x] = part1;
+            a.partials[slot0 + li] = part0;
+            if constexpr (EPI == SL_EPI_PUSH) a.partials[(uint64_t)a.part_stride + slot0 + li] = part1;
         }
     }
 }
@@ -1394,11 +1419,11 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
         const bool beside = a.n_slices >= long_rows_beside_min() && sl_side_stream(c);
         if (beside) {
             // fork point = everything enqueued on s BEFORE the slice kernel of this launch; it was recorded by the caller below
-            hipLaunchKernelGGL((sl_long_rows_kernel<ORDER, EPI>), dim3(a.n_long), dim3(SL_BLOCK), 0, c.side, a, *nparts - a.n_long);
+            hipLaunchKernelGGL((sl_long_rows_kernel<ORDER, EPI>), dim3((a.n_long + SL_BLOCK / 64 - 1) / (SL_BLOCK / 64)), dim3(SL_BLOCK), 0, c.side, a, *nparts - a.n_long);
             SL_HIP(hipEventRecord(c.ev_join, c.side));
             SL_HIP(hipStreamWaitEvent(s, c.ev_join, 0));
         } else {
-            hipLaunchKernelGGL((sl_long_rows_kernel<ORDER, EPI>), dim3(a.n_long), dim3(SL_BLOCK), 0, s, a, *nparts - a.n_long);
+            hipLaunchKernelGGL((sl_long_rows_kernel<ORDER, EPI>), dim3((a.n_long + SL_BLOCK / 64 - 1) / (SL_BLOCK / 64)), dim3(SL_BLOCK), 0, s, a, *nparts - a.n_long);
         }
     }
     SL_HIP(hipGetLastError());
