@@ -81,8 +81,10 @@ __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, ui
         vals[sl_val_slot(q0, k, lane)] = v;
     }
     if (bw) atomicMax(band, bw);
-    for (int off = 32; off > 0; off >>= 1) far += __shfl_xor(far, off);
-    if (lane == 0 && far) atomicAdd(band + 1, far);            // entries more than 8 MB of vector away from their row
+    unsigned long long held = len;                             // entries of the slice layout (the long rows' entries are not in it)
+    for (int off = 32; off > 0; off >>= 1) { far += __shfl_xor(far, off); held += __shfl_xor(held, off); }
+    if (lane == 0 && far) atomicAdd(band + 1, far);            // entries more than 2 MB of vector away from their row
+    if (lane == 0 && held) atomicAdd(band + 2, held);
 }
 
 // 16-bit column offsets for uniform-width band matrices: [slice][octet][lane][8] int16 = col - row,
@@ -566,13 +568,13 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     SL_HIP(hipMalloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
     SL_HIP(hipMalloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
     unsigned long long *d_band = nullptr;
-    SL_HIP(hipMalloc(&d_band, 2 * sizeof(unsigned long long)));
-    SL_HIP(hipMemsetAsync(d_band, 0, 2 * sizeof(unsigned long long), st));
+    SL_HIP(hipMalloc(&d_band, 3 * sizeof(unsigned long long)));
+    SL_HIP(hipMemsetAsync(d_band, 0, 3 * sizeof(unsigned long long), st));
     if (m->n_slices)
         hipLaunchKernelGGL(sl_fill_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_cols,
                            m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_band);
     SL_HIP(hipGetLastError());
-    unsigned long long h_band[2] = {0, 0};
+    unsigned long long h_band[3] = {0, 0, 0};
     SL_HIP(hipMemcpyAsync(h_band, d_band, sizeof(h_band), hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
     hipFree(d_band);
@@ -580,7 +582,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     // rows beyond the last column (tall matrix / row slice reaching past n_cols): their own index is not a column, so neither the
     // band window [row - w, row + w] nor the padding column "the row itself" exists for them — such matrices keep the general kernel
     if (m->row_offset + n > m->n_cols) m->bandwidth = ~0ull;
-    const uint64_t far_entries = h_band[1];
+    const uint64_t far_entries = h_band[1], slice_entries = h_band[2];
     if (m->bandwidth < 32768 && m->n_slices && m->padded_nnz) {
         SL_HIP(hipMalloc(&m->d_cols16, m->padded_nnz * sizeof(uint16_t)));
         if (m->uniform_width == 8 || m->uniform_width == 16)      // octet layout of the unrolled uniform path
@@ -604,7 +606,9 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         // Round 2 (tools/ab_c2.sh, paced layout against the general kernel, ms per step): n = 10^6 x 8 0.087 / 0.087, 10^6 x 16
         // 0.108 / 0.146, 2 * 10^6 x 8 0.135 / 0.223, 3 * 10^6 x 16 0.290 / 0.660 — the paced layout pays from a vector of ~8 MB on;
         // the DYNAMIC tiles (fallback for unbalanced matrices) only from ~24 MB on (10^6 x 8: 0.168, worse than no panels).
-        const bool spread = 2 * far_entries > nnz - std::min<uint64_t>(n, nnz);      // of the off-diagonal entries (the diagonal is never far)
+        // of the off-diagonal entries of the rows the count covers (the diagonal is never far; the long rows' entries are not counted:
+        // a graph whose hubs hold most of the entries — PageRank's out-link side — is judged by its other rows)
+        const bool spread = 2 * far_entries > slice_entries - std::min<uint64_t>(n, slice_entries);
         const bool pays = m->n_cols >= (3ull << 20) && spread;
         // (tools/ab_small_paced.sh after the accumulation moved to the VALU, paced / general: 7 * 10^5 x 8 0.058 / 0.048, 7 * 10^5 x 16
         // 0.074 / 0.088, 10^6 x 8 0.070 / 0.086, 10^6 x 16 0.099 / 0.145, 1.5 * 10^6 x 8 0.094 / 0.151: from 9 * 10^5 columns on)
