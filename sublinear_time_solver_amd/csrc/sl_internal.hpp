@@ -92,7 +92,9 @@ struct sl_matrix {
 #endif
 #define SL_PANEL_CHUNK 256u          // entries a wave has in flight (4 x 64)
 #define SL_PW_WAVES 16               // paced layout: waves per block = tiles per CU
+#ifndef SL_PW_GROUP
 #define SL_PW_GROUP 16u              // rows are dealt to tiles in groups of 16 consecutive rows (one 128-byte line of every vector)
+#endif
 #define SL_PW_MAX_ROWS 1264u         // rows per wave tile (79 groups): 16 x (1264 + 1 spare slot) x 8 B = 161 920 B of the 160 KiB LDS
 #define SL_PW_SP_BITS 20             // super-panel: the column bits an entry carries
 #ifndef SL_PANEL_WAVES

@@ -876,6 +876,9 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
 // products in lane order — explicit shuffles, ONE LDS update per run; a row that comes back behind a panel boundary inside the
 // same 64 entries is a second run, and the runs of different panels are applied one panel after the other with the LDS drained
 // in between.  Bits = the sequential reference loop (sparse.rs:187-203).  CSR order only; the 4-lane order keeps the general kernel.
+#ifndef SL_PW_SLEEP
+#define SL_PW_SLEEP 4            // s_sleep argument of a paced wave that waits (x 64 cycles)
+#endif
 template <int EPI>
 __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
 {
@@ -922,7 +925,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
                 m = __builtin_amdgcn_readfirstlane(dpp_row_min(m));   // the 16 progress words sit in lanes 0..15 = one DPP row
                 if (me <= m + slack) break;                         // at most `slack` panels ahead of the block's slowest wave
                 if (spins > 2048u) { if (lane == 0) prog_st(SL_PW_WAVES, 0u); break; }     // the hint switches itself off
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(SL_PW_SLEEP);
             }
         };
         // real = false: the pipeline's filler behind the last chunk (the loads are issued all the same, so that the number of loads
