@@ -31,7 +31,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 
 
-LAYOUTS = {0: "row slices", 1: "column panels, dynamic tiles (gathers from L2)", 2: "column panels, paced persistent blocks (gathers from L2)"}
+LAYOUTS = {0: "row slices", 1: "column panels, dynamic tiles (gathers from L2)", 2: "column panels, paced persistent blocks (gathers from L2)",
+           3: "narrow column panels over block-local rows, paced persistent blocks (wide band: gathers from L1)"}
 
 
 def recorded_traffic(n, k, w):
@@ -89,7 +90,7 @@ def cpu_baseline(n_global: int, k: int, seed: int, w: int, threads_all: int):
             "single_thread_simd4": out["simd4_1t"], "all_threads_rowchunk": out["rowchunk_all"]}
 
 
-def column_structure_sweep(lib, L, torch, dev, n, k, seed, order, bandwidths, steps=12):
+def column_structure_sweep(lib, L, torch, dev, n, k, seed, order, bandwidths, steps=30):
     """Secondary, clearly-labelled measurements on ONE GPU: the same fused step on the same S-DD recipe with
     other column structures (half-bandwidth w; 0 = uniform over all columns, the reference generators' recipe).
     Reported next to the headline so the dependence on gather locality is visible."""

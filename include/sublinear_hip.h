@@ -120,7 +120,8 @@ typedef struct {
     uint32_t long_row_threshold; /* rows with more entries than this are served by the long-row kernel (2.5 x mean length, in [24, 256]) */
     uint32_t n_long_rows;
     uint32_t column_panels;   /* != 0: the matrix also carries a column-panel layout (columns spread beyond the LDS window and the L2):
-                               * 1 = dynamic tiles (ragged matrices), 2 = paced persistent blocks (balanced matrices) */
+                               * 1 = dynamic tiles (ragged matrices), 2 = paced persistent blocks (balanced matrices), 3 = the same with
+                               * block-local rows and narrow panels (bands too wide for the LDS window: the gathers hit the CU's L1) */
     uint32_t reserved;
 } sl_matrix_info;
 sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info);

@@ -216,6 +216,7 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
     a.n_pan_tiles = (uint32_t)m->n_pan_tiles; a.pan_balanced = m->pan_balanced ? 1u : 0u;
     a.pw_idx = m->d_pw_idx; a.pw_val = m->d_pw_val; a.pw_tile_ptr = m->d_pw_tile_ptr;
     a.pw_tiles = (uint32_t)m->n_pw_tiles; a.pw_rpw = m->pw_rpw; a.pw_blocks = m->pw_blocks; a.pw_slack = m->pw_slack;
+    a.pw_deal = m->pw_deal; a.pw_pbits = m->pw_pbits;
     return a;
 }
 
@@ -377,7 +378,7 @@ sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info)
     info->max_row_nnz = m->max_row_nnz; info->min_row_nnz = m->min_row_nnz; info->uniform_width = m->uniform_width;
     info->has_transpose = m->d_tptr != nullptr;
     info->long_row_threshold = m->long_row;
-    info->column_panels = m->d_pw_idx ? 2u : (m->d_pan_tile_ptr ? 1u : 0u);      // 2 = the paced layout
+    info->column_panels = m->d_pw_idx ? (m->pw_band ? 3u : 2u) : (m->d_pan_tile_ptr ? 1u : 0u);      // 2 = the paced layout, 3 = its wide-band form
     info->reserved = 0;
     info->n_long_rows = (uint32_t)m->n_long;
     return SL_OK;

@@ -80,6 +80,11 @@ struct sl_matrix {
     uint32_t *d_pw_tile_ptr = nullptr;  // [n_pw_tiles + 1] in chunks
     uint64_t n_pw_tiles = 0, pw_chunks = 0;
     uint32_t pw_rpw = 0, pw_blocks = 0;
+    // the same layout for WIDE BANDS (windows beyond the LDS): groups of rows are dealt among the 16 tiles of ONE block (pw_deal = 16
+    // instead of all tiles), so that a block owns a contiguous range of rows and its waves walk the same narrow panels
+    // (2^pw_pbits columns, a few KB of the vector) at the same time: the gathers become hits in the CU's L1
+    uint32_t pw_deal = 0, pw_pbits = 16;
+    bool pw_band = false;               // the wide-band form (block-local rows, narrow panels)
     uint32_t pw_slack = 4;              // panels a wave may gather ahead of the slowest wave of its block: about two chunks of its stream
     uint64_t device_bytes = 0;
 };
@@ -269,6 +274,7 @@ struct sl_row_args {
     // paced column-panel layout (null unless the matrix carries one)
     const uint32_t *pw_idx; const double *pw_val; const uint32_t *pw_tile_ptr;
     uint32_t pw_tiles, pw_rpw, pw_blocks;
+    uint32_t pw_deal, pw_pbits; // tiles a run of row groups is dealt among (all tiles, or the 16 of a block); log2 of the panel width
     uint32_t pw_slack;        // panels a wave may run ahead of the slowest wave of its block (set by the launcher; >= 2^20: no pacing)
     // vectors
     const double *gather; // gathered vector (n_cols)

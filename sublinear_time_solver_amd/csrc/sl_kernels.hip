@@ -887,7 +887,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
     __shared__ uint32_t prog[SL_PW_WAVES + 1];                     // [16] = pacing alive
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t rpw = a.pw_rpw, slack = a.pw_slack;
+    const uint32_t rpw = a.pw_rpw, slack = a.pw_slack, pbits = a.pw_pbits, deal = a.pw_deal;
     double *acc = pw_acc + (size_t)wave * (rpw + 1);                // + the spare slot padding entries add their zeros to
     // progress words: relaxed workgroup-scope atomics = plain ds_read / ds_write.  NOT volatile: a volatile access makes the backend
     // wait for every load in flight (s_waitcnt vmcnt(0)), which would serialise the stream loads and gathers the pipeline keeps ahead
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         auto accumulate = [&](const uint32_t (&ii)[4], const double (&vv)[4], const double (&gg)[4], const uint32_t (&cc)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)                              // row slots < 2^11 (SL_PW_MAX_ROWS + the spare slot)
-                sl_ordered_accumulate<11>(acc, lane, ii[u] >> 21, DMUL(vv[u], gg[u]), cc[u] >> SL_PANEL_COL_BITS);
+                sl_ordered_accumulate<11>(acc, lane, ii[u] >> 21, DMUL(vv[u], gg[u]), cc[u] >> pbits);
         };
         if (chunks) {
             const uint32_t lastc = chunks - 1u;
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
                 const bool real1 = ch + 1u < chunks;                                                                 \
                 if (real1) {                                                                                         \
                     const uint32_t nextcol = (sp_g << SL_PW_SP_BITS) | (__builtin_amdgcn_readfirstlane(SI[r1][0]) & ((1u << SL_PW_SP_BITS) - 1u)); \
-                    pace(nextcol >> SL_PANEL_COL_BITS);                                                              \
+                    pace(nextcol >> pbits);                                                              \
                 }                                                                                                    \
                 gather(SI[r1], GG[r1], GC[r1], real1);                                                               \
             }                                                                                                        \
@@ -975,7 +975,8 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         if (lane == 0) prog_st(wave, (round + 1u) << 20);            // as far along as the round's end while the vectors are written
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (uint32_t r = lane; r < rpw; r += 64) {                   // slot r = group r / 16 of the tile, row r % 16 of the group
-            const uint64_t i = ((uint64_t)(r / SL_PW_GROUP) * a.pw_tiles + tile) * SL_PW_GROUP + (r % SL_PW_GROUP);
+            // groups of SL_PW_GROUP rows are dealt among `deal` tiles: span = tile / deal owns deal * rpw consecutive rows
+            const uint64_t i = ((uint64_t)(tile / deal) * deal * (rpw / SL_PW_GROUP) + (uint64_t)(r / SL_PW_GROUP) * deal + tile % deal) * SL_PW_GROUP + (r % SL_PW_GROUP);
             if (i >= a.n_rows || (a.n_long && a.row_len[i] == SL_LONG_SENTINEL)) continue;
             double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
             if constexpr (EPI == SL_EPI_NEUMANN) { e_t = g[a.row_offset + i]; e_d = a.dinv[i]; e_x = a.x[i]; }

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64
 // CSR -> row-slice layout.  One wave per slice, lane = row.  Padding entries carry
 // value 0.0 and a valid column (the row's own index when it exists); the kernels never
 // add them (guarded by row_len), they only keep every gather in bounds.
+#define SL_PW_BAND_AUTO 0xffu
 #define SL_FAR_COLUMN (1ull << 18)     // |col - row| beyond this (2 MB of vector, half an XCD's L2): the gather is far from what the row's neighbours keep cached
 __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, uint64_t n_cols, uint64_t n_slices,
                                                              uint64_t row_offset, const uint32_t *row_ptr,
@@ -354,18 +355,21 @@ static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr,
 
 // keys and per-tile entry counts for the paced layout: groups of SL_PW_GROUP rows dealt round robin to n_tiles tiles
 __global__ __launch_bounds__(256) void sl_pw_keys_kernel(uint64_t n_rows, uint32_t n_panels, uint32_t n_tiles, const uint32_t *row_ptr, const uint32_t *col_idx,
-                                                         const uint32_t *row_len, uint32_t *key, uint16_t *rowl, uint32_t *count)
+                                                         const uint32_t *row_len, uint32_t *key, uint16_t *rowl, uint32_t *count, uint32_t deal, uint32_t gpt,
+                                                         uint32_t pbits)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     for (uint64_t i = wave; i < n_rows; i += nwaves) {                        // a wave per row: coalesced over the row's entries
         const uint32_t s = row_ptr[i], e = row_ptr[i + 1];
         const bool is_long = row_len[i] == SL_LONG_SENTINEL;
+        // group q of SL_PW_GROUP rows: span q / (deal * gpt) owns `deal` tiles (gpt = groups per tile), its groups go round them
         const uint64_t q = i / SL_PW_GROUP;
-        const uint32_t tile = (uint32_t)(q % n_tiles);
-        const uint16_t rl = (uint16_t)((q / n_tiles) * SL_PW_GROUP + i % SL_PW_GROUP);
+        const uint64_t span = q / ((uint64_t)deal * gpt), ql = q % ((uint64_t)deal * gpt);
+        const uint32_t tile = (uint32_t)(span * deal + ql % deal);
+        const uint16_t rl = (uint16_t)((ql / deal) * SL_PW_GROUP + i % SL_PW_GROUP);
         for (uint32_t k = s + lane; k < e; k += 64u) {
-            key[k] = is_long ? 0xffffffffu : tile * n_panels + (col_idx[k] >> SL_PANEL_COL_BITS);
+            key[k] = is_long ? 0xffffffffu : tile * n_panels + (col_idx[k] >> pbits);
             rowl[k] = rl;
         }
         if (lane == 0 && !is_long && e > s) atomicAdd(&count[tile], e - s);
@@ -423,7 +427,10 @@ __global__ __launch_bounds__(256) void sl_pw_fill_kernel(uint64_t n_tiles, uint3
 }
 
 // returns SL_OK with m->d_pw_idx == nullptr when the matrix does not qualify (unbalanced tiles, too few rows per wave ...)
-static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx, const double *d_values, hipStream_t st)
+// band_pbits = 0: uniform columns (panels of 2^16 columns, row groups dealt among all tiles).  band_pbits > 0: a wide band — panels of
+// 2^band_pbits columns, row groups dealt among the 16 tiles of one block (sl_internal.hpp)
+static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx, const double *d_values, hipStream_t st,
+                                       uint32_t band_pbits = 0)
 {
     const uint64_t n = m->n_rows, nnz = m->nnz;
     int dev = 0;
@@ -438,20 +445,35 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     const uint64_t waves = cus * SL_PW_WAVES;
     const uint64_t n_groups = (n + SL_PW_GROUP - 1) / SL_PW_GROUP, max_groups = SL_PW_MAX_ROWS / SL_PW_GROUP;
     const uint64_t rounds = (n_groups + waves * max_groups - 1) / (waves * max_groups);
-    const uint64_t n_tiles = std::min<uint64_t>(rounds * waves, n_groups);                  // every tile of every round carries work
-    const uint32_t rpw = (uint32_t)(((n_groups + n_tiles - 1) / n_tiles) * SL_PW_GROUP);
+    uint64_t n_tiles = std::min<uint64_t>(rounds * waves, n_groups);                        // every tile of every round carries work
+    if (band_pbits) n_tiles = (n_tiles + SL_PW_WAVES - 1) / SL_PW_WAVES * SL_PW_WAVES;       // whole blocks: a block's 16 tiles share its rows
+    const uint32_t gpt = (uint32_t)((n_groups + n_tiles - 1) / n_tiles);                    // groups per tile
+    const uint32_t rpw = gpt * SL_PW_GROUP;
+    const uint32_t deal = band_pbits ? (uint32_t)SL_PW_WAVES : (uint32_t)n_tiles;
+    // wide band: a block of 16 tiles owns deal * rpw consecutive rows and walks the columns of those rows +- the bandwidth.  The panel
+    // width is the smallest (from 2^9 = 4 KB of vector) that gives a tile ~90 entries per panel (tools/ab_band_paced*.sh, n = 10^7 x 16,
+    // ms per step 2^9 / 2^10 / 2^11: w = 12 000 0.473 / 0.536 / 0.677, 32 768 0.499 / 0.532 / 0.675, 100 000 0.634 / 0.592 / 0.731);
+    // SL_PW_BAND_AUTO (0xff): that rule, any other value: the width as given (experiments)
+    uint32_t pbits = band_pbits ? band_pbits : (uint32_t)SL_PANEL_COL_BITS;
+    const uint64_t span_cols = (uint64_t)deal * rpw + 2 * (m->bandwidth == ~0ull ? 0 : m->bandwidth) + 1;
+    const double tile_entries = (double)nnz / (double)n_tiles;
+    if (band_pbits == SL_PW_BAND_AUTO) {
+        pbits = 9;
+        while (pbits < 10 && tile_entries * (double)(1u << pbits) / (double)span_cols < 90.0) ++pbits;
+        if (tile_entries * (double)(1u << pbits) / (double)span_cols < 30.0) return SL_OK;      // too thin a band for the CU's L1 to see reuse: general kernel
+    }
     const size_t lds_avail = std::max({(size_t)prop.sharedMemPerBlock, (size_t)prop.sharedMemPerBlockOptin, (size_t)prop.maxSharedMemoryPerMultiProcessor});
     if (n == 0 || lds_avail < (size_t)SL_PW_WAVES * (SL_PW_MAX_ROWS + 1) * 8 + 512) return SL_OK;
     if (rpw < 256 && !force) return SL_OK;                                       // small systems keep the dynamic tiles
-    const uint64_t n_panels = (m->n_cols + (1ull << SL_PANEL_COL_BITS) - 1) >> SL_PANEL_COL_BITS;
-    if (n_tiles * n_panels >= 0xfffffff0ull) return SL_OK;
+    const uint64_t n_panels = (m->n_cols + (1ull << pbits) - 1) >> pbits;
+    if (n_tiles * n_panels >= 0xfffffff0ull || n_panels >= (1ull << 20)) return SL_OK;
     DevBuf key, key_out, ent_in, perm, rowl, cnt, pads;
     SL_TRY(key.alloc_owned(nnz * 4)); SL_TRY(key_out.alloc_owned(nnz * 4)); SL_TRY(ent_in.alloc_owned(nnz * 4)); SL_TRY(perm.alloc_owned(nnz * 4));
     SL_TRY(rowl.alloc_owned(nnz * 2)); SL_TRY(cnt.alloc_owned((n_tiles + 1) * 4)); SL_TRY(pads.alloc_owned((n_tiles + 1) * 4));
     const uint32_t g = grid_for(nnz, 256) > 8192 ? 8192 : grid_for(nnz, 256);
     SL_HIP(hipMemsetAsync(cnt.p, 0, (n_tiles + 1) * 4, st));
     hipLaunchKernelGGL(sl_pw_keys_kernel, dim3(g), dim3(256), 0, st, n, (uint32_t)n_panels, (uint32_t)n_tiles, d_row_ptr, d_col_idx, m->d_row_len,
-                       key.as<uint32_t>(), rowl.as<uint16_t>(), cnt.as<uint32_t>());
+                       key.as<uint32_t>(), rowl.as<uint16_t>(), cnt.as<uint32_t>(), deal, gpt, pbits);
     std::vector<uint32_t> count(n_tiles + 1), src(n_tiles + 1), dst(n_tiles + 1), hpads(n_tiles + 1);
     SL_HIP(hipMemcpyAsync(count.data(), cnt.p, n_tiles * 4, hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
@@ -491,6 +513,15 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     // together win (tools/ab_slack.sh, n = 10^7 x 16, lead 1 / 2 / 3 / 4 / 6 panels: 0.950 / 0.966 / 0.966 / 0.985 / 1.000 ms; the same
     // order at 10^6 x 8 .. 5 * 10^6 x 16; at two panels per chunk (10^7 x 8, 2 * 10^7 x 16) leads 1..3 lie within 1 %)
     m->pw_slack = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (2 * 256 * n_panels * n_tiles + total * 3 / 2) / (total * 3)));
+    if (band_pbits) {
+        // a tile walks only the panels of its block's window; the lead = the panels it crosses per chunk of 256 entries, held to
+        // what the L1 keeps beside the stream (~16 KB of vector: w = 32 768 at 2^9 lead 1 / 2 / 4 0.533 / 0.499 / 0.513 ms, w = 100 000 at
+        // 2^10 lead 1 / 2 / 3 0.592 / 0.619 / 0.630)
+        const double per_chunk = 256.0 * (double)(span_cols >> pbits) * (double)n_tiles / (double)total;
+        const uint32_t cap = std::max<uint32_t>(1u, (2048u >> pbits) ? (2048u >> pbits) - 1u : 1u);
+        m->pw_slack = std::min<uint32_t>(cap, std::max<uint32_t>(1u, (uint32_t)(per_chunk + 0.5)));
+    }
+    m->pw_deal = deal; m->pw_pbits = pbits; m->pw_band = band_pbits != 0;
     m->pw_blocks = (uint32_t)std::min<uint64_t>(cus, (n_tiles + SL_PW_WAVES - 1) / SL_PW_WAVES);
     m->device_bytes += chunks * 256 * 12 + (n_tiles + 1) * 4;
     return SL_OK;
@@ -615,6 +646,18 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         const bool pays_paced = m->n_cols >= 900000ull && spread;
         const uint64_t n_tiles = (n + SL_PANEL_TILE - 1) / SL_PANEL_TILE;
         const uint64_t n_panels = (m->n_cols + (1ull << SL_PANEL_COL_BITS) - 1) >> SL_PANEL_COL_BITS;
+        // wide bands (experiment knob SL_PW_BAND = log2 of the panel width): the paced layout with block-local rows and narrow panels
+        // Wide bands — a measured bandwidth beyond the LDS window of the band kernel (w > ~9 500), gathers that the general kernel
+        // serves from the L2 one request each: the paced layout with block-local rows and narrow panels makes them L1 hits
+        // (w = 12 000 .. 100 000: 0.60-0.74 -> 0.47-0.59 ms at n = 10^7 x 16; from w ~ 3 * 10^5 on the band is too thin for that and
+        // the general kernel — beyond ~10^6 the uniform-column layout above — keeps it).  SL_PW_BAND: 0 off, n = force panels of 2^n.
+        static const int env_band = [] { const char *e = getenv("SL_PW_BAND"); return e && *e ? atoi(e) : -1; }();
+        const bool band_wide = m->bandwidth != ~0ull && m->bandwidth >= 9500 && !spread && !m->n_long && nnz && nnz < 0x7fffffffull
+                               && m->row_offset + n <= m->n_cols;
+        if (env_band != 0 && !refused && band_wide && (env_band > 0 || n >= 1500000ull)) {           // n = 2^20 x 16, w = 32 768: 0.090 against 0.077 ms; 1.5 * 10^6: 0.092 / 0.098
+            sl_status ps = sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st, env_band > 0 ? (uint32_t)env_band : SL_PW_BAND_AUTO);
+            if (ps != SL_OK) return ps;
+        } else
         if (!refused && (forced || pays || pays_paced) && nnz && nnz < 0x7fffffffull && n_tiles * n_panels < 0xfffffff0ull) {
             // balanced matrices of some size: persistent paced blocks (SL_COLUMN_PANELS=3 forces the dynamic tiles instead)
             sl_status ps = env_panels == 3 ? SL_OK : sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st);

@@ -101,11 +101,14 @@ def _fused_step_sampled(n_global, lo, hi, k, seed, w, sample_starts, label, step
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("w", [4096, 0], ids=["band4096", "uniform"])
+@pytest.mark.parametrize("w", [4096, 0, 32768], ids=["band4096", "uniform", "band32768"])
 def test_headline_instances_sampled_rows(gpu, w):
     """bench.py's two headline inputs at their own size: n = 10^7, 16/row, seed 1 (the kernel instance the bench times)."""
     n = 10_000_000
-    _fused_step_sampled(n, 0, n, 16, 1, w, (0, 4_999_937, n - 4096), f"C3 w={w}")
+    rec = _fused_step_sampled(n, 0, n, 16, 1, w, (0, 4_999_937, n - 4096), f"C3 w={w}")
+    # which layout the instance runs on: row slices behind the LDS window, paced column panels for uniform columns and — with block-local
+    # rows and narrow panels — for the band too wide for the window (bench.py's secondary line)
+    assert rec["column_panels"] == {4096: 0, 0: 2, 32768: 3}[w]
 
 
 @pytest.mark.parametrize("w", [4096, 0], ids=["band4096", "uniform"])

@@ -26,7 +26,9 @@ def bits(a):
 def _check_all(rp, ci, va, b, n, tol=1e-10):
     m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
     info = m.info()
-    assert info.column_panels == 0 and info.bandwidth > 9500 and info.max_row_nnz <= 16 and info.n_long_rows == 0   # the kernel's territory
+    # the kernel's territory; in the child run with SL_PW_BAND set the same matrices carry the paced layout with block-local rows
+    assert info.column_panels == (3 if int(os.environ.get("SL_PW_BAND", "0") or 0) > 0 else 0)
+    assert info.bandwidth > 9500 and info.max_row_nnz <= 16 and info.n_long_rows == 0
     x = np.cos(np.arange(n) * 0.37) + 0.1
     assert (bits(m.multiply_vector(x)) == bits(O.spmv(rp, ci, va, x))).all()
     o = O.neumann_solve(rp, ci, va, b, tolerance=tol)
@@ -86,8 +88,26 @@ def test_row_slice_of_a_wide_band(gpu):
     assert (bits(m.multiply_vector(x)) == bits(O.spmv(rp, ci, va, x)[lo:hi])).all()
 
 
+def _inside_child():
+    return os.environ.get("SL_MPASS") == "1" or int(os.environ.get("SL_PW_BAND", "0") or 0) > 0
+
+
+@pytest.mark.parametrize("bits_", ["9", "11"])
+def test_the_same_checks_through_the_wide_band_panel_layout(gpu, bits_):
+    """wide bands at full size run on the paced column-panel layout with block-local rows and panels of 2^9 / 2^10 columns (selected
+    from 1.5 * 10^6 rows on); here it is forced on these small systems (SL_PW_BAND = log2 of the panel width, a pretended 2-CU device:
+    several rounds of tiles) and must give the same bits: SpMV, Neumann solve, residual, dense push rounds, ragged rows, the stencil
+    whose window has three occupied clusters, a row slice"""
+    if _inside_child():
+        pytest.skip("already inside a child run")
+    env = dict(os.environ, SL_PW_BAND=bits_, SL_PW_FORCE="1", SL_PW_CUS="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_the_same_checks_through_the_multi_pass_kernel(gpu):
-    if os.environ.get("SL_MPASS") == "1":
+    if _inside_child():
         pytest.skip("already inside the child run")
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
                        capture_output=True, text=True, timeout=1200, env=dict(os.environ, SL_MPASS="1"))
