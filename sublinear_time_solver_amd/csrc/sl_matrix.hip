@@ -71,21 +71,26 @@ __global__ __launch_bounds__(256) void sl_fill_slices_kernel(uint64_t n_rows, ui
         start = row_ptr[i];
         len = row_len[i] == SL_LONG_SENTINEL ? 0u : row_len[i];
     }
-    unsigned long long bw = 0, far = 0;
+    unsigned long long bw = 0, far = 0, diag = 0;
     const uint32_t slots = (q1 - q0) * 2;                      // q0, q1: pair blocks
     for (uint32_t k = 0; k < slots; ++k) {
         const bool in = k < len;
         const uint32_t c = in ? col_idx[start + k] : padcol;
         const double v = in ? values[start + k] : 0.0;
         if (in) { const unsigned long long d = c > gi ? c - gi : gi - c; bw = d > bw ? d : bw; far += d > SL_FAR_COLUMN ? 1u : 0u; }
+        // the same slot of the row above holds the column to the left: a diagonal of a stencil — neighbouring lanes gather from one line
+        const uint32_t c_up = __shfl_up(c, 1);
+        const uint32_t in_up = __shfl_up((uint32_t)in, 1);
+        if (in && lane > 0 && in_up && c == c_up + 1u) ++diag;
         cols[sl_col_slot(q0, q1, k, lane)] = c;
         vals[sl_val_slot(q0, k, lane)] = v;
     }
     if (bw) atomicMax(band, bw);
     unsigned long long held = len;                             // entries of the slice layout (the long rows' entries are not in it)
-    for (int off = 32; off > 0; off >>= 1) { far += __shfl_xor(far, off); held += __shfl_xor(held, off); }
+    for (int off = 32; off > 0; off >>= 1) { far += __shfl_xor(far, off); held += __shfl_xor(held, off); diag += __shfl_xor(diag, off); }
     if (lane == 0 && far) atomicAdd(band + 1, far);            // entries more than 2 MB of vector away from their row
     if (lane == 0 && held) atomicAdd(band + 2, held);
+    if (lane == 0 && diag) atomicAdd(band + 3, diag);          // entries that continue a diagonal from the row above
 }
 
 // 16-bit column offsets for uniform-width band matrices: [slice][octet][lane][8] int16 = col - row,
@@ -599,13 +604,13 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     SL_HIP(hipMalloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
     SL_HIP(hipMalloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
     unsigned long long *d_band = nullptr;
-    SL_HIP(hipMalloc(&d_band, 3 * sizeof(unsigned long long)));
-    SL_HIP(hipMemsetAsync(d_band, 0, 3 * sizeof(unsigned long long), st));
+    SL_HIP(hipMalloc(&d_band, 4 * sizeof(unsigned long long)));
+    SL_HIP(hipMemsetAsync(d_band, 0, 4 * sizeof(unsigned long long), st));
     if (m->n_slices)
         hipLaunchKernelGGL(sl_fill_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_cols,
                            m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_band);
     SL_HIP(hipGetLastError());
-    unsigned long long h_band[3] = {0, 0, 0};
+    unsigned long long h_band[4] = {0, 0, 0, 0};
     SL_HIP(hipMemcpyAsync(h_band, d_band, sizeof(h_band), hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
     hipFree(d_band);
@@ -613,7 +618,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     // rows beyond the last column (tall matrix / row slice reaching past n_cols): their own index is not a column, so neither the
     // band window [row - w, row + w] nor the padding column "the row itself" exists for them — such matrices keep the general kernel
     if (m->row_offset + n > m->n_cols) m->bandwidth = ~0ull;
-    const uint64_t far_entries = h_band[1], slice_entries = h_band[2];
+    const uint64_t far_entries = h_band[1], slice_entries = h_band[2], diagonal_entries = h_band[3];
     if (m->bandwidth < 32768 && m->n_slices && m->padded_nnz) {
         SL_HIP(hipMalloc(&m->d_cols16, m->padded_nnz * sizeof(uint16_t)));
         if (m->uniform_width == 8 || m->uniform_width == 16)      // octet layout of the unrolled uniform path
@@ -652,9 +657,13 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         // (w = 12 000 .. 100 000: 0.60-0.74 -> 0.47-0.59 ms at n = 10^7 x 16; from w ~ 3 * 10^5 on the band is too thin for that and
         // the general kernel — beyond ~10^6 the uniform-column layout above — keeps it).  SL_PW_BAND: 0 off, n = force panels of 2^n.
         static const int env_band = [] { const char *e = getenv("SL_PW_BAND"); return e && *e ? atoi(e) : -1; }();
+        // Not for stencils: where most entries continue a diagonal from the row above, neighbouring lanes of the general kernel gather
+        // from the same lines already (7-point stencil on 215^3, w = 46 225: 0.234 ms there, 0.364 ms on this layout).
         const bool band_wide = m->bandwidth != ~0ull && m->bandwidth >= 9500 && !spread && !m->n_long && nnz && nnz < 0x7fffffffull
                                && m->row_offset + n <= m->n_cols;
-        if (env_band != 0 && !refused && band_wide && (env_band > 0 || n >= 1500000ull)) {           // n = 2^20 x 16, w = 32 768: 0.090 against 0.077 ms; 1.5 * 10^6: 0.092 / 0.098
+        const bool band_pays = n >= 1500000ull                       // n = 2^20 x 16, w = 32 768: 0.090 against 0.077 ms; 1.5 * 10^6: 0.092 / 0.098
+                               && 2 * diagonal_entries < slice_entries;
+        if (env_band != 0 && !refused && band_wide && (env_band > 0 || band_pays)) {
             sl_status ps = sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st, env_band > 0 ? (uint32_t)env_band : SL_PW_BAND_AUTO);
             if (ps != SL_OK) return ps;
         } else
