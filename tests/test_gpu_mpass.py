@@ -64,6 +64,29 @@ def test_ragged_rows_in_a_wide_band(gpu):
     _check_all(rp, ci, va, 1.0 + (np.arange(n) % 13) * 0.25, n)
 
 
+def test_duplicates_and_bare_rows_in_a_wide_band(gpu):
+    """the same column stored twice in a row (kept, added twice in stored order: a run of two in one panel) and rows that hold only
+    their diagonal, scattered through a wide band"""
+    rng = np.random.default_rng(21)
+    n, w = 64_000, 15_000
+    tr, tc, tv = [], [], []
+    for i in range(n):
+        m = 0 if i % 11 == 0 else int(rng.integers(2, 13))
+        lo, hi = max(0, i - w), min(n, i + w + 1)
+        cols = np.unique(rng.integers(lo, hi, size=m)) if m else np.zeros(0, dtype=np.int64)
+        cols = cols[cols != i]
+        if i % 7 == 0 and cols.size > 2:
+            cols = np.sort(np.concatenate([cols, cols[:2]]))                # two duplicated columns
+        vals = rng.uniform(-1.0, 1.0, size=cols.size)
+        order = np.argsort(np.concatenate([cols, [i]]), kind="stable")
+        allc = np.concatenate([cols, [i]])[order]
+        allv = np.concatenate([vals, [2.0 * np.abs(vals).sum() + 1.0]])[order]
+        tr += [i] * allc.size; tc += allc.tolist(); tv += allv.tolist()
+    rp = np.zeros(n + 1, dtype=np.uint32)
+    rp[1:] = np.cumsum(np.bincount(np.array(tr), minlength=n))
+    _check_all(rp, np.array(tc, dtype=np.uint32), np.array(tv), 1.0 + (np.arange(n) % 17) * 0.125, n)
+
+
 def test_seven_point_stencil_three_clusters(gpu):
     nx, ny, nz = 110, 110, 8                                               # bandwidth nx * ny = 12100, rows of 4..7 entries
     n = nx * ny * nz
