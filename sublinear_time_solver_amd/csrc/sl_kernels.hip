@@ -886,7 +886,9 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
     __shared__ double red[2 * SL_PW_WAVES];
     __shared__ uint32_t prog[SL_PW_WAVES + 1];                     // [16] = pacing alive
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: tile, chunk counts, loop control and the stream's base addresses then live in SGPRs (the compiler
+    // cannot see that threadIdx.x >> 6 is the same in all lanes and would keep all of them — and their arithmetic — in vector registers)
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t rpw = a.pw_rpw, slack = a.pw_slack, pbits = a.pw_pbits, deal = a.pw_deal;
     double *acc = pw_acc + (size_t)wave * (rpw + 1);                // + the spare slot padding entries add their zeros to
     // progress words: relaxed workgroup-scope atomics = plain ds_read / ds_write.  NOT volatile: a volatile access makes the backend
@@ -937,7 +939,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
                 const unsigned long long fl = __ballot(stepbit);
                 uint32_t sp = sp_g;
                 if (fl) sp += mask_count_below(fl) + stepbit;           // a handful of times per tile: the first entry of a super-panel
-                sp_g += real ? (uint32_t)__popcll(fl) : 0u;
+                sp_g = __builtin_amdgcn_readfirstlane(sp_g + (real ? (uint32_t)__popcll(fl) : 0u));
                 cc[u] = real ? ((sp << SL_PW_SP_BITS) | (ii[u] & ((1u << SL_PW_SP_BITS) - 1u))) : 0u;
                 gg[u] = g[cc[u]];
             }
