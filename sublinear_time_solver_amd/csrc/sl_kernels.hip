@@ -816,7 +816,7 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
     extern __shared__ __attribute__((aligned(16))) double pan_acc[];
     __shared__ double red[2 * SL_PANEL_WAVES];
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lb = block0 + blockIdx.x;
     const uint32_t tile = lb * SL_PANEL_WAVES + wave;
     double *acc = pan_acc + (size_t)wave * (SL_PANEL_TILE + 64);    // + the slot padding entries add their zeros to
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_long_rows_kernel(sl_row_args a, u
 {
     __shared__ double prod_lds[SL_BLOCK];
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t li = blockIdx.x * (SL_BLOCK / 64) + wave;           // position in the list of long rows = partial slot
     if (li >= a.n_long) return;                                       // whole waves; no block barrier below
     double *prod = prod_lds + wave * 64;
