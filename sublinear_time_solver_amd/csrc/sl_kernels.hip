@@ -872,10 +872,11 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
 // matrices), which keeps them within the L2's reach of each other (tools/panel2_bench.hip: free-running 1.95-2.2 ms, paced inside
 // the block 1.16 ms, pacing across the XCD through an L2-resident line of progress words as well: no further gain).
 // Summation order: within a row the products arrive in ascending column order (panel order = column order) and are added one by
-// one.  Entries of one row that sit in neighbouring lanes (same panel) form a run: the run's first lane adds its followers'
-// products in lane order — explicit shuffles, ONE LDS update per run; a row that comes back behind a panel boundary inside the
-// same 64 entries is a second run, and the runs of different panels are applied one panel after the other with the LDS drained
-// in between.  Bits = the sequential reference loop (sparse.rs:187-203).  CSR order only; the 4-lane order keeps the general kernel.
+// one (sl_ordered_accumulate above).  Bits = the sequential reference loop (sparse.rs:187-203).  CSR order only; the 4-lane order
+// keeps the general kernel.
+// Two forms of the layout share the kernel (launch parameters pw_deal / pw_pbits): uniform columns — panels of 2^16 columns, row
+// groups dealt among ALL tiles, gathers served by the L2 as described; wide bands — panels of 2^9..2^10 columns, row groups dealt
+// among the 16 tiles of ONE block, so that the CU's waves gather from the same few KB of vector: hits in its own L1.
 #ifndef SL_PW_SLEEP
 #define SL_PW_SLEEP 4            // s_sleep argument of a paced wave that waits (x 64 cycles)
 #endif
