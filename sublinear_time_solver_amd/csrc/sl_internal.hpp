@@ -96,12 +96,20 @@ struct sl_matrix {
                                      // (n = 10^7 x 16, ms per step by panel size: 2^18 1.57, 2^17 1.49, 2^16 1.39, 2^15 1.36, 2^14 1.43)
 #endif
 #define SL_PANEL_CHUNK 256u          // entries a wave has in flight (4 x 64)
+#ifndef SL_PW_WAVES
 #define SL_PW_WAVES 16               // paced layout: waves per block = tiles per CU
+#endif
 #ifndef SL_PW_GROUP
 #define SL_PW_GROUP 16u              // rows are dealt to tiles in groups of 16 consecutive rows (one 128-byte line of every vector)
 #endif
+#ifndef SL_PW_MAX_ROWS
 #define SL_PW_MAX_ROWS 1264u         // rows per wave tile (79 groups): 16 x (1264 + 1 spare slot) x 8 B = 161 920 B of the 160 KiB LDS
-#define SL_PW_SP_BITS 20             // super-panel: the column bits an entry carries
+#endif
+#ifndef SL_PW_ROW_BITS
+#define SL_PW_ROW_BITS 11            // bits of the row slot in an entry's index word (slots <= SL_PW_MAX_ROWS); the rest: step bit + column bits
+#endif
+#define SL_PW_ROW_SHIFT (32 - SL_PW_ROW_BITS)
+#define SL_PW_SP_BITS (SL_PW_ROW_SHIFT - 1)   // super-panel: the column bits an entry carries (20)
 #ifndef SL_PANEL_WAVES
 #define SL_PANEL_WAVES 4
 #endif

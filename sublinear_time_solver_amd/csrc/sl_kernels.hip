@@ -947,8 +947,8 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         };
         auto accumulate = [&](const uint32_t (&ii)[4], const double (&vv)[4], const double (&gg)[4], const uint32_t (&cc)[4]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)                              // row slots < 2^11 (SL_PW_MAX_ROWS + the spare slot)
-                sl_ordered_accumulate<11>(acc, lane, ii[u] >> 21, DMUL(vv[u], gg[u]), cc[u] >> pbits);
+            for (int u = 0; u < 4; ++u)                              // row slots < 2^SL_PW_ROW_BITS (SL_PW_MAX_ROWS + the spare slot)
+                sl_ordered_accumulate<SL_PW_ROW_BITS>(acc, lane, ii[u] >> SL_PW_ROW_SHIFT, DMUL(vv[u], gg[u]), cc[u] >> pbits);
         };
         if (chunks) {
             const uint32_t lastc = chunks - 1u;

@@ -419,8 +419,8 @@ __global__ __launch_bounds__(256) void sl_pw_fill_kernel(uint64_t n_tiles, uint3
         if (WRITE && in) {
             const uint64_t pos = out0 + e + pad_run + incl;    // behind its own bridging entries
             for (uint32_t b = 0; b < bridge; ++b)
-                sl_pw_store(idx, val, pos - bridge + b, (rpw << 21) | (1u << SL_PW_SP_BITS), 0.0);
-            sl_pw_store(idx, val, pos, ((uint32_t)rowl[k] << 21) | ((step ? 1u : 0u) << SL_PW_SP_BITS) | (c & ((1u << SL_PW_SP_BITS) - 1u)), values[k]);
+                sl_pw_store(idx, val, pos - bridge + b, (rpw << SL_PW_ROW_SHIFT) | (1u << SL_PW_SP_BITS), 0.0);
+            sl_pw_store(idx, val, pos, ((uint32_t)rowl[k] << SL_PW_ROW_SHIFT) | ((step ? 1u : 0u) << SL_PW_SP_BITS) | (c & ((1u << SL_PW_SP_BITS) - 1u)), values[k]);
         }
         pad_run += __shfl(incl, 63);
         const uint32_t last = cnt - e0 < 64u ? cnt - e0 - 1u : 63u;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void sl_pw_fill_kernel(uint64_t n_tiles, uint3
     }
     if (!WRITE) { if (lane == 0) pads[t] = pad_run; return; }
     const uint64_t end = out0 + cnt + pad_run, stop = (uint64_t)dst_chunks[t + 1] * 256;
-    for (uint64_t pos = end + lane; pos < stop; pos += 64) sl_pw_store(idx, val, pos, rpw << 21, 0.0);
+    for (uint64_t pos = end + lane; pos < stop; pos += 64) sl_pw_store(idx, val, pos, rpw << SL_PW_ROW_SHIFT, 0.0);
 }
 
 // returns SL_OK with m->d_pw_idx == nullptr when the matrix does not qualify (unbalanced tiles, too few rows per wave ...)
