@@ -3,7 +3,7 @@
 uniformly random columns (`--bandwidth 0`, the default).  The same step on the banded variant of the recipe (half-width 4096, the
 "locality" form of config 5) is measured in the same run and reported with its own full roofline block (`roofline_banded`).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own ranks, or runs under torch.distributed.run)
 
 A "step" is one pass of the hot path over the whole (synthetic) system: the fused kernel
     t' = t - dinv .* (A t);  x += t';  ||t'||^2
@@ -27,8 +27,12 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the ranks of a fresh box reach their rendezvous tens of seconds apart (the first `import torch` pages the image in): the
+# communicator's bounded waits get room for that; a rank that DIES is noticed at once all the same (marked communicator / the parent)
+os.environ.setdefault("SL_COMM_TIMEOUT_MS", "180000")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+L2_REQUEST_RATE = 2.7e11       # L2 requests/s the eight XCDs serve together: 34.5 TB/s / 128 B, = the 265-280 G gathers/s tools/gather_bench.hip measures on L2-resident tables
 
 
 LAYOUTS = {0: "row slices", 1: "column panels, dynamic tiles (gathers from L2)", 2: "column panels, paced persistent blocks (gathers from L2)",
@@ -126,40 +130,31 @@ def column_structure_sweep(lib, L, torch, dev, n, k, seed, order, bandwidths, st
     return out
 
 
-def main_abi(args, world, rank, local_rank):
-    """N > 1 through the C ABI alone (sl_comm + partitioned NeumannState): torch only provides the device buffers the generator
-    writes into.  Barrier = sl_comm_barrier (drains the stream, then all ranks meet), MAX over ranks through sl_comm_allgather."""
-    import torch
-    from sublinear_time_solver_amd import _lib as L
-    from sublinear_time_solver_amd import Communicator
-    local_rank %= max(1, torch.cuda.device_count())         # fewer devices than ranks (test boxes): ranks share a GPU, which the communicator supports
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    lib = L.load()
-    L.check(lib.sl_set_device(local_rank))
-    comm = Communicator(rank, world, f"bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"[:60].replace("/", "_"))
+def _abi_measure(args, lib, L, torch, dev, comm, world, rank, w, verify=True):
+    """One column structure through the C ABI: this rank's rows synthesized in HBM, row-slice / panel layouts built, partitioned
+    NeumannState over `comm`, W warm-up steps, then K timed steps bracketed by comm.barrier() + torch.cuda.synchronize() on both
+    sides; MAX over ranks of wall time and of the library's own HIP-event time of the loop."""
     n_local, k = args.n, args.k
     n_global = n_local * world
-    w_head = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
     lo, hi = rank * n_local, (rank + 1) * n_local
-
-    def measure(w):
-        rp = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
-        ci = torch.empty(n_local * k, dtype=torch.int32, device=dev)
-        va = torch.empty(n_local * k, dtype=torch.float64, device=dev)
-        bb = torch.empty(n_local, dtype=torch.float64, device=dev)
-        L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), bb.data_ptr()))
-        h = C.c_void_p()
-        L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, lo, 0, C.byref(h)))
-        del rp, ci, va
-        torch.cuda.empty_cache()
-        info = L.MatrixInfo()
-        L.check(lib.sl_matrix_get_info(h, C.byref(info)))
-        o = L.NeumannOptions()
-        lib.sl_neumann_options_default(C.byref(o))
-        o.order, o.mem, o.start = args.order, L.SL_MEM_DEVICE, L.SL_START_REFERENCE_DEFAULT      # x0 = D^-1 b like the one-GPU bench loop (x = t0)
-        st = C.c_void_p()
-        L.check(lib.sl_neumann_state_create_partitioned(comm._h, h, bb.data_ptr(), None, C.byref(o), C.byref(st)))
+    rp = torch.empty(n_local + 1, dtype=torch.int32, device=dev)
+    ci = torch.empty(n_local * k, dtype=torch.int32, device=dev)
+    va = torch.empty(n_local * k, dtype=torch.float64, device=dev)
+    bb = torch.empty(n_local, dtype=torch.float64, device=dev)
+    L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), bb.data_ptr()))
+    h = C.c_void_p()
+    L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, lo, 0, C.byref(h)))
+    del rp, ci, va
+    torch.cuda.empty_cache()
+    info = L.MatrixInfo()
+    L.check(lib.sl_matrix_get_info(h, C.byref(info)))
+    o = L.NeumannOptions()
+    lib.sl_neumann_options_default(C.byref(o))
+    o.order, o.mem, o.start = args.order, L.SL_MEM_DEVICE, L.SL_START_REFERENCE_DEFAULT      # x0 = D^-1 b: x = t0, the bench loop's start
+    st = C.c_void_p()
+    L.check(lib.sl_neumann_state_create_partitioned(comm._h, h, bb.data_ptr(), None, C.byref(o), C.byref(st)))
+    out = {}
+    try:
         nrm, ms = C.c_double(0.0), C.c_float(0.0)
         if args.warmup:
             L.check(lib.sl_neumann_state_run_steps(st, args.warmup, C.byref(nrm), C.byref(ms)))
@@ -171,51 +166,247 @@ def main_abi(args, world, rank, local_rank):
         comm.barrier()
         elapsed = max(comm.allgather_f64(time.perf_counter() - t_start))
         dev_ms = max(comm.allgather_f64(float(ms.value)))
+        bad = C.c_uint64(0)
+        if verify:      # did the transport move what the owners wrote?  (position-weighted checksums of every piece against its owner's copy)
+            L.check(lib.sl_neumann_state_verify_exchange(st, C.byref(bad)))
+        bad_all = sum(comm.allgather_u64(int(bad.value)))
+        out = {"elapsed": elapsed, "dev_ms": dev_ms, "norm": float(nrm.value) ** 0.5, "panels": int(info.column_panels), "pieces_bad": bad_all,
+               "verified": bool(verify)}
+        if world == 1:      # kernel-only duration: the same launches (fused step + closing reduction) through the library's HIP-event bracket, no ticket
+            dinv = torch.empty(n_local, dtype=torch.float64, device=dev)
+            L.check(lib.sl_matrix_diagonal_inverse(h, dinv.data_ptr(), L.SL_MEM_DEVICE))
+            ta = bb * dinv
+            tb, x = torch.empty_like(ta), ta.clone()
+            nrm2 = torch.zeros(2, dtype=torch.float64, device=dev)
+            km = C.c_float(0)
+            L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm2.data_ptr(), args.order, 3, C.byref(km)))
+            L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), tb.data_ptr(), ta.data_ptr(), x.data_ptr(), nrm2.data_ptr(), args.order, args.steps, C.byref(km)))
+            out["kern_ms"] = km.value / args.steps
+            del dinv, ta, tb, x, nrm2
+    finally:
         lib.sl_neumann_state_destroy(st)
         lib.sl_matrix_destroy(h)
         del bb
         torch.cuda.empty_cache()
-        return {"elapsed": elapsed, "dev_ms": dev_ms, "norm": float(nrm.value) ** 0.5, "panels": int(info.column_panels)}
+    return out
 
-    m = measure(w_head)
-    other = None
-    if not args.no_sweep:      # the other column structure of the recipe in the same job: config 5's halo variant next to S-DD as written, or vice versa
-        w_other = BANDED_BANDWIDTH if w_head == 0 else 0
-        other = (w_other, measure(w_other))
-    if rank == 0:
+
+def main_abi(args, world, rank, local_rank, attempt=0):
+    """Every N (1 included) through the C ABI alone: sl_comm + partitioned NeumannState; torch only provides the device buffers the
+    generator writes into and the device synchronisation.  Barrier = sl_comm_barrier (drains the stream, then all ranks meet), MAX
+    over ranks through sl_comm_allgather.  The transport of the vectors and sums is the library's (SL_COMM_TRANSPORT: ipc | rccl)."""
+    import torch
+    from sublinear_time_solver_amd import _lib as L
+    from sublinear_time_solver_amd import Communicator
+    ndev = max(1, torch.cuda.device_count())
+    local_rank %= ndev                                       # fewer devices than ranks (test boxes): ranks share a GPU, which the ipc transport supports
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = L.load()
+    L.check(lib.sl_set_device(local_rank))
+    name = f"bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', os.environ.get('SL_BENCH_JOB', 'x'))}_{attempt}"
+    comm = Communicator(rank, world, name[:60].replace("/", "_"))
+    try:
+        ci_ = L.CommInfo()
+        L.check(lib.sl_comm_info(comm._h, C.byref(ci_)))
+        devices = comm.allgather_u64(int(ci_.device))
+        transport = ("rccl" + ("+halo-allreduce" if ci_.halo_allreduce else "")) if ci_.transport == 1 else "ipc"
+        n_local, k = args.n, args.k
+        n_global = n_local * world
+        w_head = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
+        m = _abi_measure(args, lib, L, torch, dev, comm, world, rank, w_head)
+        if m["pieces_bad"]:
+            raise RuntimeError(f"exchange verification failed: {m['pieces_bad']} pieces differ from their owners' copies (transport {transport})")
+        other = None
+        if not args.no_sweep and (world > 1 or w_head != BANDED_BANDWIDTH):      # the other column structure of the recipe in the same job
+            w_other = BANDED_BANDWIDTH if w_head == 0 else 0
+            if world > 1:
+                mo = _abi_measure(args, lib, L, torch, dev, comm, world, rank, w_other)
+                if mo["pieces_bad"]:
+                    raise RuntimeError(f"exchange verification failed on the second column structure: {mo['pieces_bad']} pieces (transport {transport})")
+                other = (w_other, mo)
+        if rank != 0:
+            return
         nnz_total = n_global * k
         per_launch_bytes = algorithmic_bytes(n_local, n_local * k)
-        launch_ms = m["dev_ms"] / args.steps
+        launch_ms = m.get("kern_ms", m["dev_ms"] / args.steps)
         achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
         value = nnz_total * args.steps / m["elapsed"]
-        name = lambda w: "uniform columns" if w == 0 else f"band half-width {w}"
+        name_of = lambda w: "uniform columns" if w == 0 else f"band half-width {w}"
+        traffic, traffic_source = recorded_traffic(n_local, k, w_head) if world == 1 else (None, None)
+        kernel = LAYOUTS.get(m["panels"], "row slices") if m["panels"] else ("LDS-window band kernel" if 0 < w_head <= 9400 else "row-slice general kernel")
+        exchange = f"abi: sl_comm, transport {transport}" + (" (one rank: tickets of one, no peers)" if world == 1 else
+                   (" — term all-gathered: every rank needs every row" if w_head == 0 else " — halo strips at the range boundaries only"))
         out = {
             "metric": "push_iterations_x_nnz_per_sec", "value": value, "unit": "nnz*iter/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["elapsed"] * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"S-DD(n={n_local} rows/GPU, nnz/row={k}, seed={args.seed}, {name(w_head)}) fused Neumann/push step, fp64, "
-                                   f"{world}xMI355X row-partitioned (BASELINE configs[4] per-GPU shape)",
+            "config": {"workload": f"S-DD(n={n_local} rows/GPU, nnz/row={k}, seed={args.seed}, {name_of(w_head)}) fused Neumann/push step, fp64, "
+                                   + ("1xMI355X HBM roofline run (BASELINE configs[2])" if world == 1 else
+                                      f"{world}xMI355X row-partitioned (BASELINE configs[4] per-GPU shape)"),
                        "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w_head,
                        "order": "csr_sequential" if args.order == 0 else "simd4",
-                       "exchange": "abi: sl_comm (IPC-mapped vectors pulled over xGMI, norm summed over all ranks every step)", "partition": f"rows{world}",
-                       "norm_allreduce_every": 1, "rows_iter_per_s": value / k, "last_term_norm": m["norm"],
-                       "bytes_pulled_per_rank_per_step": (8 * n_local * (world - 1)) if w_head == 0 else 8 * w_head * min(2, world - 1)},
+                       "exchange": exchange, "transport": transport, "partition": f"rows{world}",
+                       "n_ranks_joined": int(ci_.ranks_joined), "devices": devices, "devices_visible": ndev,
+                       "exchange_verified": bool(m["verified"] and not m["pieces_bad"]) if world > 1 else None,
+                       "norm_allreduce_every": 1 if world > 1 else None, "rows_iter_per_s": value / k, "last_term_norm": m["norm"],
+                       "bytes_received_per_rank_per_step": 0 if world == 1 else ((8 * n_local * (world - 1)) if w_head == 0 else 8 * w_head * min(2, world - 1))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "traffic_source": None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "column_structure": "uniform over all columns (SURVEY 8(d) S-DD)" if w_head == 0 else f"band half-width {w_head}",
-                         "kernel": LAYOUTS.get(m["panels"], "row slices") if m["panels"] else "row slices",
-                         "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": launch_ms,
-                         "note": "per GPU: one step = fused kernel + all-rank ticket + pulls; launch_ms = the slowest rank's device time per step"},
+                         "kernel": kernel, "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": launch_ms,
+                         "timed_region_device_ms_per_step": m["dev_ms"] / args.steps,      # HIP events around the K timed steps, same stream (world 1: + the ticket of one)
+                         "algorithmic_over_copy_ceiling_6290": achieved / 6290.0,
+                         "note": ("launch_ms = fused step kernel + closing reduction, HIP events over the same K launches without the ticket" if world == 1 else
+                                  "per GPU: one step = fused kernel + all-rank sum + exchange; launch_ms = the slowest rank's device time per step")},
         }
+        if w_head == 0 and m["panels"]:      # the bound this kernel actually meets (DESIGN.md §5): one L2 request per gathered entry
+            req = n_local * k
+            floor_ms = req / L2_REQUEST_RATE * 1e3
+            out["roofline"]["l2_request"] = {"bound": "l2 requests (one 128-byte request per 8-byte gather)", "requests_per_launch": req,
+                                            "peak_requests_per_s": L2_REQUEST_RATE, "floor_ms": floor_ms, "frac": floor_ms / launch_ms,
+                                            "source": "tools/gather_bench.hip: 265-280 G gathers/s from L2-resident tables = 34.5 TB/s / 128 B (profiles/r01_gather_bench.txt, r02_panel2_prototype.txt)"}
         if other is not None:
             w_o, mo = other
-            out["config"]["other_column_structure_same_job"] = {
-                "half_bandwidth": w_o, "column_structure": name(w_o) + (" (config 5's halo variant: only the strips at the range boundaries travel)" if w_o else ""),
-                "value": nnz_total * args.steps / mo["elapsed"], "ms_per_step": mo["elapsed"] * 1e3 / args.steps,
-                "device_ms_per_step_slowest_rank": mo["dev_ms"] / args.steps,
-                "roofline_frac_per_gpu": per_launch_bytes / (mo["dev_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, "last_term_norm": mo["norm"]}
+            out["halo_variant" if w_o else "uniform_variant"] = {
+                "half_bandwidth": w_o, "column_structure": name_of(w_o) + (" (config 5's halo variant: only the strips at the range boundaries travel)" if w_o else ""),
+                "value": nnz_total * args.steps / mo["elapsed"], "unit": "nnz*iter/s", "ms_per_step": mo["elapsed"] * 1e3 / args.steps,
+                "device_ms_per_step_slowest_rank": mo["dev_ms"] / args.steps, "exchange_verified": bool(mo["verified"] and not mo["pieces_bad"]),
+                "roofline_frac_per_gpu": per_launch_bytes / (mo["dev_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, "last_term_norm": mo["norm"],
+                "bytes_received_per_rank_per_step": (8 * n_local * (world - 1)) if w_o == 0 else 8 * w_o * min(2, world - 1)}
+        if world == 1 and not args.no_sweep:
+            others = [v for v in (0, BANDED_BANDWIDTH, 512, 32768) if v != w_head]
+            sweep = column_structure_sweep(lib, L, torch, dev, n_local, k, args.seed, args.order, others)
+            out["config"]["other_column_structures"] = sweep
+            bk = f"w{BANDED_BANDWIDTH}"
+            if bk in sweep:     # the banded variant of the recipe: a full roofline block of its own, same run, same box
+                tb_, tsrc = recorded_traffic(n_local, k, BANDED_BANDWIDTH)
+                out["roofline_banded"] = {"bound": "hbm", "achieved": sweep[bk]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": sweep[bk]["roofline_frac"], "traffic": tb_, "traffic_source": tsrc,
+                                          "column_structure": f"band half-width {BANDED_BANDWIDTH}", "kernel": "LDS-window band kernel",
+                                          "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": sweep[bk]["ms_per_step"],
+                                          "nnz_iter_per_s": sweep[bk]["nnz_iter_per_s"]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = run_cpu_baseline(n_global, k, args.seed, w_head)
         print(json.dumps(out), flush=True)
-    comm.close()
+    finally:
+        comm.close()
+
+
+def run_cpu_baseline(n_global, k, seed, w):
+    """the oracle leg in its own process: a crash of the CPU checker must not take the GPU line with it"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--rows", str(n_global), "--k", str(k),
+                            "--seed", str(seed), "--bandwidth", str(w)], capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            raise RuntimeError(f"child exited with {r.returncode}: {r.stderr[-300:]}")
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:  # the baseline is reported context; never lose the GPU line over it
+        return {"value": None, "unit": "nnz*iter/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+
+
+# ---- N > 1 without a launcher: `python bench.py --gpus N` starts its own ranks -------------------------------------------------------
+# Precedent: simd_ops::parallel_matrix_vector_multiply (src/simd_ops.rs:201-239) hides its row chunks behind ONE call; here one
+# command hides the N processes.  The parent starts one child per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+# environment, the contract torch.distributed.run would set up), waits with a time limit, and — being the one place that sees all
+# ranks — decides the fallback: the library's ipc transport, then its rccl transport, then torch.distributed over RCCL.  An attempt
+# counts when every rank exits 0, rank 0 printed its line, and the exchange verification inside the line is green.
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher(args, argv):
+    import signal
+    import subprocess
+    import tempfile
+    n = args.gpus
+    ndev = 0
+    try:
+        from sublinear_time_solver_amd import _lib as L
+        cnt = C.c_int(0)
+        L.load().sl_device_count(C.byref(cnt))
+        ndev = int(cnt.value)
+    except Exception as e:
+        print(f"[bench launcher] device count unavailable ({e})", file=sys.stderr, flush=True)
+    order = [t for t in os.environ.get("SL_BENCH_TRANSPORTS", "ipc,rccl,torch").split(",") if t in ("ipc", "rccl", "torch")]
+    if 0 < ndev < n:      # ranks share GPUs (test boxes): RCCL refuses two ranks on one device; only the ipc transport can run
+        print(f"[bench launcher] {n} ranks on {ndev} device(s): ranks share GPUs, ipc transport only", file=sys.stderr, flush=True)
+        order = [t for t in order if t == "ipc"] or ["ipc"]
+    attempts = []
+    for att, transport in enumerate(order):
+        port = _free_port()
+        job = f"{os.getpid()}_{att}"
+        procs, logs = [], []
+        t0 = time.time()
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       SL_BENCH_CHILD="1", SL_BENCH_TRANSPORT=transport, SL_BENCH_JOB=job, SL_BENCH_ATTEMPT=str(att))
+            env.pop("TORCHELASTIC_RUN_ID", None)
+            err = tempfile.TemporaryFile(mode="w+")
+            logs.append(err)
+            procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py")] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                          stderr=err, text=True, start_new_session=True, cwd=str(ROOT)))
+        deadline, failed, why = t0 + args.attempt_timeout, False, ""
+        out0 = ""
+        import threading
+        buf = []
+        th = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+        th.start()
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                failed, why = True, f"rank {[i for i, c in enumerate(codes) if c not in (None, 0)][0]} exited with {[c for c in codes if c not in (None, 0)][0]}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                failed, why = True, f"time limit of {args.attempt_timeout} s"
+                break
+            time.sleep(0.2)
+        if failed:
+            time.sleep(1.0)            # the peers' bounded waits notice a marked communicator at once; give them a moment to leave by themselves
+            for p in procs:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)      # the exact process groups started above
+                    except ProcessLookupError:
+                        pass
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:
+                pass
+        th.join(timeout=10)
+        out0 = buf[0] if buf else ""
+        lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+        tails = []
+        for r, f in enumerate(logs):
+            f.seek(0)
+            txt = f.read()
+            f.close()
+            if failed or not lines:
+                tails.append(f"--- rank {r} stderr tail ---\n{txt[-1500:]}")
+            elif r == 0 and txt.strip():
+                sys.stderr.write(txt[-4000:])
+        rec = {"transport": transport, "ok": (not failed) and bool(lines), "seconds": round(time.time() - t0, 1)}
+        if failed or not lines:
+            rec["why"] = why or "rank 0 printed no line"
+            attempts.append(rec)
+            print(f"[bench launcher] attempt {att} (transport {transport}) failed: {rec['why']}\n" + "\n".join(tails), file=sys.stderr, flush=True)
+            continue
+        attempts.append(rec)
+        line = json.loads(lines[-1])
+        line.setdefault("config", {})["launcher"] = {"self_launched_ranks": n, "attempts": attempts}
+        print(json.dumps(line), flush=True)
+        return 0
+    print(f"[bench launcher] every transport failed: {attempts}", file=sys.stderr, flush=True)
+    return 1
 
 
 def main():
@@ -233,36 +424,74 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the cpu_baseline leg
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary column-structure measurements")
     ap.add_argument("--exchange", choices=["abi", "p2p", "allreduce"], default="abi",
-                    help="N > 1: abi = the library's own communicator and partitioned state behind the C ABI (default); p2p / allreduce = "
-                         "torch.distributed over RCCL: neighbour sends of the boundary strips, or ONE all-reduce over a zero-filled compact strip buffer")
-    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: do not split boundary / interior rows")
-    ap.add_argument("--force-split", action="store_true", help="testing: use the boundary / interior split even on one GPU")
+                    help="abi = the library's own communicator and partitioned state behind the C ABI (default, every N; transport ipc | rccl: "
+                         "SL_COMM_TRANSPORT); p2p / allreduce = the exchange ABOVE the ABI over torch.distributed / RCCL: neighbour sends of the boundary strips, "
+                         "or ONE all-reduce over a zero-filled compact strip buffer")
+    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU (torch path): do not split boundary / interior rows")
+    ap.add_argument("--force-split", action="store_true", help="testing (torch path): use the boundary / interior split even on one GPU")
+    ap.add_argument("--attempt-timeout", type=float, default=float(os.environ.get("SL_BENCH_ATTEMPT_TIMEOUT", "900")),
+                    help="self-launched N > 1: seconds one transport attempt may take before the parent ends it and tries the next")
     args = ap.parse_args()
     if args.cpu_baseline_only:      # runs in its own process: a crash of the CPU checker must not take the GPU line with it
         w0 = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
         print(json.dumps(cpu_baseline(args.n, args.k, args.seed, w0, os.cpu_count() or 1)), flush=True)
         return
 
-    import torch
-    import torch.distributed as dist
-    from sublinear_time_solver_amd import _lib as L
-    from sublinear_time_solver_amd import distributed as D
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # `python bench.py --gpus N`: no launcher around us, so be one
+        sys.exit(launcher(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
-    # SL_BENCH_FORCE_ABI=1 (measurement): the communicator path at world size 1 — the per-step cost of the ticket kernel on top of the fused step
-    if (world > 1 or os.environ.get("SL_BENCH_FORCE_ABI") == "1") and args.exchange == "abi" and not args.force_split:
-        try:
-            return main_abi(args, world, rank, local_rank)
-        except Exception as e:                      # collective by construction (every wait in the communicator is bounded): all ranks land here together
-            print(f"[bench rank {rank}] ABI communicator path failed ({e}); falling back to torch.distributed / RCCL", file=sys.stderr, flush=True)
-            args.exchange = "p2p"
+    child = os.environ.get("SL_BENCH_CHILD") == "1"
+    use_abi = args.exchange == "abi" and not args.force_split and os.environ.get("SL_BENCH_FORCE_DIST") != "1"
+    if use_abi and child:                                   # one attempt with the transport the parent chose; the parent decides what comes next
+        transport = os.environ.get("SL_BENCH_TRANSPORT", "ipc")
+        if os.environ.get("SL_BENCH_FAIL_ATTEMPT") == os.environ.get("SL_BENCH_ATTEMPT", "0") and rank == world - 1:
+            raise SystemExit("SL_BENCH_FAIL_ATTEMPT: this rank leaves before the rendezvous (test of the launcher's fallback)")
+        if transport in ("ipc", "rccl"):
+            os.environ["SL_COMM_TRANSPORT"] = transport
+            return main_abi(args, world, rank, local_rank, int(os.environ.get("SL_BENCH_ATTEMPT", "0")))
+        args.exchange = "p2p"
+    elif use_abi and world == 1:
+        return main_abi(args, world, rank, local_rank)
+    elif use_abi:
+        # under torch.distributed.run: the ranks agree on the outcome of every attempt (a gloo all-reduce) before anyone moves on
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("cpu:gloo,cuda:nccl" if os.environ.get("SL_BENCH_BACKEND", "nccl") == "nccl" else "gloo", rank=rank, world_size=world)
+        import torch
+        transports = [os.environ["SL_COMM_TRANSPORT"]] if os.environ.get("SL_COMM_TRANSPORT") else ["ipc", "rccl"]
+        if max(1, torch.cuda.device_count()) < world:
+            transports = [t for t in transports if t == "ipc"] or ["ipc"]
+        for att, transport in enumerate(transports):
+            os.environ["SL_COMM_TRANSPORT"] = transport
+            ok, err = 1, None
+            try:
+                main_abi(args, world, rank, local_rank, att)
+            except Exception as e:                          # every wait in the communicator is bounded: all ranks get here
+                ok, err = 0, e
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
+                dist.destroy_process_group()
+                return
+            print(f"[bench rank {rank}] ABI path with transport {transport} failed on {'this rank: ' + repr(err) if err else 'another rank'}", file=sys.stderr, flush=True)
+        print(f"[bench rank {rank}] falling back to the exchange over torch.distributed / RCCL", file=sys.stderr, flush=True)
+        args.exchange = "p2p"
+    return main_torch(args, world, rank, local_rank)
+
+
+def main_torch(args, world, rank, local_rank):
+    """The exchange ABOVE the ABI, over torch.distributed (backend "nccl" = RCCL): --exchange p2p | allreduce, --force-split, and the
+    last fallback of N > 1.  One GPU without --force-split never comes here."""
+    import torch
+    import torch.distributed as dist
+    from sublinear_time_solver_amd import _lib as L
+    from sublinear_time_solver_amd import distributed as D
+
     if args.exchange == "abi":
         args.exchange = "p2p"
     # SL_BENCH_BACKEND=gloo is a TEST mode: ranks may share a GPU and the exchanges are staged through the host
@@ -275,7 +504,9 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
+        if dist.is_initialized():
+            pass                                                     # the agreed fallback of the ABI attempts: the group exists already
+        elif backend == "nccl":
             os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # the small transfer kernels must not queue behind a 20 K-block launch
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -401,7 +632,7 @@ def main():
                                    "1xMI355X HBM roofline run (BASELINE configs[2])",
                        "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w,
                        "order": "csr_sequential" if args.order == 0 else "simd4",
-                       "exchange": (exchange.name + ("+overlap" if overlap else "") + ("+loopback" if loopback else "")) if (world > 1 or overlap) else "none", "partition": f"rows{world}",
+                       "transport": "torch.distributed (" + backend + ")", "exchange": (exchange.name + ("+overlap" if overlap else "") + ("+loopback" if loopback else "")) if (world > 1 or overlap) else "none", "partition": f"rows{world}",
                        "norm_allreduce_every": reduce_every if (world > 1 or loopback) else None,
                        "rows_iter_per_s": value / k, "last_term_norm": term_norm},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -427,21 +658,12 @@ def main():
                                           "algorithmic_bytes_per_launch": per_launch_bytes, "launch_ms": sweep[bk]["ms_per_step"],
                                           "nnz_iter_per_s": sweep[bk]["nnz_iter_per_s"]}
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                import subprocess
-                r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--rows", str(n_global), "--k", str(k),
-                                    "--seed", str(args.seed), "--bandwidth", str(w)], capture_output=True, text=True, timeout=600)
-                if r.returncode != 0:
-                    raise RuntimeError(f"child exited with {r.returncode}: {r.stderr[-300:]}")
-                out["cpu_baseline"] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-            except Exception as e:  # the baseline is reported context; never lose the GPU line over it
-                out["cpu_baseline"] = {"value": None, "unit": "nnz*iter/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+            out["cpu_baseline"] = run_cpu_baseline(n_global, k, args.seed, w)
         print(json.dumps(out), flush=True)
     for hh in handles:
         lib.sl_matrix_destroy(hh)
     if world > 1 or force_dist:
         dist.destroy_process_group()
-
 
 # default column structure of the headline run: 0 = uniform over all columns — S-DD exactly as SURVEY §8(d) writes it (the reference
 # generators' recipe j = s mod n).  The banded variant (half-width 4096 ~ 1.3 sqrt(n), a naturally ordered 2-D grid operator; the

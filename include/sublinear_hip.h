@@ -279,12 +279,27 @@ typedef struct {
  * "halo ready" handshake and the pulls on a second stream beside the interior blocks, joined before the sum (SL_DIST_OVERLAP=0
  * keeps the plain order).  Per-row results equal the
  * one-GPU solve bit for bit; norms are sums of per-rank sums (equal to ~1e-16 relative).  A peer that never arrives turns
- * into SL_DEVICE_ERROR after SL_COMM_TIMEOUT_MS (20 s), never into a hung queue. */
+ * into SL_DEVICE_ERROR after SL_COMM_TIMEOUT_MS (20 s), never into a hung queue; a rank that fails locally between two collective
+ * points marks the communicator, its peers' waits end at once, and no further collective runs on it.
+ * TRANSPORTS (environment, the same on every rank): SL_COMM_TRANSPORT=ipc (default; ranks may share a GPU) as described above;
+ * SL_COMM_TRANSPORT=rccl — the collectives SURVEY §8(e) names, inside the library (librccl resolved at run time, one rank per GPU):
+ * ncclAllGather of the term when every rank needs every row (uniform columns), one group of ncclSend / ncclRecv for halo strips
+ * (SL_COMM_HALO=allreduce: ONE ncclAllReduce over a compact buffer of all ranks' strips, -0.0 elsewhere — BASELINE north_star's
+ * wording), ncclAllGather of the ranks' partial sums, added in rank order on the device.  Both transports are copies: same bits. */
 typedef struct sl_comm sl_comm;
 sl_status sl_comm_create(int rank, int world, const char *rendezvous_name, sl_comm **out);
 void sl_comm_destroy(sl_comm *c);
 sl_status sl_comm_rank(const sl_comm *c, int *rank, int *world);
 sl_status sl_comm_barrier(sl_comm *c);                                      /* drains the calling thread's stream, then all ranks meet */
+typedef struct sl_comm_info_t {
+    int32_t rank, world, device;
+    int32_t transport;        /* 0 = ipc, 1 = rccl */
+    int32_t halo_allreduce;   /* rccl: halo strips as one all-reduce over the compact buffer */
+    int32_t ranks_joined;     /* ranks that took part in the rendezvous (= world on a live communicator) */
+    int32_t failed;           /* a rank failed or did not arrive: the communicator refuses further collectives */
+    int32_t reserved;
+} sl_comm_info_t;
+sl_status sl_comm_info(const sl_comm *c, sl_comm_info_t *info);
 sl_status sl_comm_allgather_u64(sl_comm *c, uint64_t mine, uint64_t *all); /* e.g. row counts -> row ranges; all[world] */
 /* row ranges with equal shares of STORED ENTRIES from a host row_ptr (rank r starts at the first row whose prefix
  * reaches r * nnz / world); bounds[world + 1].  Pure host arithmetic: needs neither a device nor a communicator. */
@@ -294,6 +309,10 @@ sl_status sl_neumann_state_create_partitioned(sl_comm *c, const sl_matrix *local
 /* `steps` fused steps (a8 + a9) from the state's current term without the stop rule — the measurement loop; *last_norm2 = ||t||^2
  * of the last step (over all ranks), *elapsed_ms = device time of the loop on this rank.  One GPU or partitioned. */
 sl_status sl_neumann_state_run_steps(sl_neumann_state *st, uint64_t steps, double *last_norm2, float *elapsed_ms);
+/* Collective check of the last exchange of the current term: every piece a rank holds of its peers' rows against the owner's own
+ * copy (position-weighted checksums of the bit patterns); *pieces_bad = 0 on every rank when the transport moved what the owners
+ * wrote.  What bench.py asks before it reports a multi-GPU figure.  One GPU: nothing to compare, 0. */
+sl_status sl_neumann_state_verify_exchange(sl_neumann_state *st, uint64_t *pieces_bad);
 
 /* ---- a14 in the reference's own visiting order: TS solveForwardPush (src/core/solver.ts:437-522) ----
  * Gauss-Southwell: every step pushes the FIRST index of largest |r_i| (r = b - A x, x0 = 0), p = r_i / a_ii, x_i += p, r_i = 0,

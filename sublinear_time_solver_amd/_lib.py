@@ -74,6 +74,11 @@ class WalkResult(C.Structure):
     _fields_ = [("estimate", f64), ("variance", f64), ("num_samples", u64), ("device_time_ms", f64)]
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("rank", i32), ("world", i32), ("device", i32), ("transport", i32), ("halo_allreduce", i32), ("ranks_joined", i32),
+                ("failed", i32), ("reserved", i32)]
+
+
 class CgOptions(C.Structure):
     _fields_ = [("tolerance", f64), ("max_iterations", u64), ("order", i32), ("mem", i32)]
 
@@ -123,6 +128,8 @@ SIGNATURES = {
     "sl_comm_rank": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sl_comm_barrier": (C.c_int, [vp]),
     "sl_comm_allgather_u64": (C.c_int, [vp, u64, vp]),
+    "sl_comm_info": (C.c_int, [vp, C.POINTER(CommInfo)]),
+    "sl_neumann_state_verify_exchange": (C.c_int, [vp, C.POINTER(u64)]),
     "sl_balanced_row_bounds": (C.c_int, [u64, vp, C.c_int, vp]),
     "sl_neumann_state_create_partitioned": (C.c_int, [vp, vp, vp, vp, C.POINTER(NeumannOptions), C.POINTER(vp)]),
     "sl_neumann_state_run_steps": (C.c_int, [vp, u64, C.POINTER(f64), C.POINTER(C.c_float)]),

@@ -634,21 +634,6 @@ sl_status state_init(sl_neumann_state &st, const sl_matrix *m, const double *b, 
     return SL_OK;
 }
 
-// collective: the same verdict on every rank (a rank that left alone would let the others wait for its tickets)
-sl_status dist_agree(sl_comm *c, sl_status mine)
-{
-    std::vector<int32_t> all((size_t)c->world);
-    const int32_t v = (int32_t)mine;
-    const std::string msg = sl_context().last_error;
-    SL_TRY(sl_comm_allgather_blob(c, &v, sizeof(v), all.data()));
-    for (int p = 0; p < c->world; ++p)
-        if (all[p] != SL_OK) {
-            if (p == c->rank) { sl_context().last_error = msg; return mine; }
-            return sl_fail((sl_status)all[p], "rank %d failed: %s", p, sl_status_string((sl_status)all[p]));
-        }
-    return SL_OK;
-}
-
 // Collective: does every rank have an interior to hide the exchange behind?  A rank's edge = the blocks holding the rows within the
 // largest reach of any rank from either end of its range (what a neighbour pulls); the step kernel must be one that launches in
 // ranges (band / general kernel, no hub rows), and the edges must leave at least one interior block.  SL_DIST_OVERLAP=0 turns the
@@ -734,13 +719,12 @@ sl_status state_init_partitioned(sl_neumann_state &st, sl_comm *c, const sl_matr
     hipStream_t s = sl_context().stream;
     SL_TRY(sl_dist_create(c, m, &st.dist));                             // collective: row ranges, reach, pull plan
     sl_dist *d = st.dist;
+    // each of these is collective and ends in an agreement: a rank whose allocation / IPC export / import failed still takes part in
+    // every exchange, and all ranks leave with the same verdict (the communicator's counters stay in step)
+    SL_TRY(sl_dist_vector_create(c, d->n_global, &d->t[0]));
+    SL_TRY(sl_dist_vector_create(c, d->n_global, &d->t[1]));
+    SL_TRY(sl_dist_vector_create(c, d->n_global, &d->x));
     sl_status mine = SL_OK;
-    do {
-        if ((mine = sl_dist_vector_create(c, d->n_global, &d->t[0])) != SL_OK) break;
-        if ((mine = sl_dist_vector_create(c, d->n_global, &d->t[1])) != SL_OK) break;
-        if ((mine = sl_dist_vector_create(c, d->n_global, &d->x)) != SL_OK) break;
-    } while (0);
-    if (mine != SL_OK) return mine;                                     // the exchanges inside are collective: everybody fails alike or not at all
     auto get = [&](DevBuf &dv, size_t bytes) { return dv.alloc_owned(bytes); };
     do {
         if ((mine = get(st.b, n * 8)) != SL_OK || (mine = get(st.dinv, n * 8)) != SL_OK || (mine = get(st.rhs, n * 8)) != SL_OK
@@ -760,13 +744,15 @@ sl_status state_init_partitioned(sl_neumann_state &st, sl_comm *c, const sl_matr
         } else if (hipMemsetAsync(st.x.p, 0, n * 8, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "memset failed"); break; }
         if (hipMemcpyAsync(d->t[0].mine + d->lo, st.rhs.p, n * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "copy failed"); break; }   // current_term = rhs
     } while (0);
-    SL_TRY(dist_agree(c, mine));
+    SL_TRY(sl_comm_agree(c, mine));
     st.tpair[0] = d->t[0].mine; st.tpair[1] = d->t[1].mine;
     st.t_cur = st.tpair[0]; st.t_nxt = st.tpair[1];
-    // the first term on every rank: "my rows are written" ticket, then the pieces this rank's columns reach
-    SL_TRY(sl_comm_launch_ticket(c, nullptr, nullptr, nullptr, 0, 0, SL_JUDGE_NONE, 0.0, s));
-    SL_TRY(sl_dist_pull(d, &d->t[0], s));
-    SL_HIP(hipStreamSynchronize(s));
+    // the first term on every rank: "my rows are written" ticket, then the pieces this rank's columns reach.  A failure here is
+    // local: the communicator is marked, so that the peers' waits end at once instead of running into their time limit
+    mine = sl_comm_launch_ticket(c, nullptr, nullptr, nullptr, 0, 0, SL_JUDGE_NONE, 0.0, s);
+    if (mine == SL_OK) mine = sl_dist_pull(d, &d->t[0], s);
+    if (mine == SL_OK && hipStreamSynchronize(s) != hipSuccess) mine = sl_fail(SL_DEVICE_ERROR, "the first exchange failed on the device");
+    if (mine != SL_OK) { sl_comm_poison(c); return mine; }
     if (sl_comm_failed(c)) return sl_fail(SL_DEVICE_ERROR, "a rank of the communicator did not arrive (first exchange)");
     return dist_plan_overlap(st);
 }
@@ -1040,6 +1026,21 @@ sl_status sl_neumann_state_run_steps(sl_neumann_state *st, uint64_t steps, doubl
     SL_ABI_END
 }
 
+// Collective check of the partition's last exchange of the current term: every piece this rank holds of its peers' rows against the
+// owner's own copy (position-weighted wrapping sums of the bit patterns).  *pieces_bad = 0 on every rank when the exchange moved
+// what the owners wrote — the first thing to ask of a transport on hardware it has not seen.  One GPU / world 1: nothing to compare.
+sl_status sl_neumann_state_verify_exchange(sl_neumann_state *st, uint64_t *pieces_bad)
+{
+    SL_ABI_BEGIN
+    if (!st || !pieces_bad) return sl_fail(SL_INVALID_INPUT, "null argument");
+    *pieces_bad = 0;
+    if (!st->dist) return SL_OK;
+    SL_HIP(hipStreamSynchronize(sl_context().stream));
+    sl_dist *D = st->dist;
+    return sl_dist_verify(D, st->t_cur == D->t[0].mine ? &D->t[0] : &D->t[1], pieces_bad);
+    SL_ABI_END
+}
+
 sl_status sl_neumann_solve(const sl_matrix *m, const double *b, const double *initial_guess,
                            const sl_neumann_options *o, double *x_out, double *term_norms,
                            sl_neumann_result *res)
@@ -1081,7 +1082,9 @@ void sl_neumann_state_destroy(sl_neumann_state *st)
 {
     if (!st) return;
     (void)hipStreamSynchronize(sl_context().stream);
-    if (st->dist) (void)sl_comm_host_barrier(st->dist->c);     // collective: no peer still pulls from the vectors this frees
+    // collective: no peer still pulls from the vectors this frees.  Not on a communicator that has failed (nobody waits there any
+    // more) or that the host already closed (sl_comm_destroy with states alive: the ranks are past their last collective)
+    if (st->dist && !st->dist->c->closed && !sl_comm_failed(st->dist->c)) (void)sl_comm_host_barrier(st->dist->c);
     delete st;
 }
 

@@ -4,11 +4,13 @@
 // call; here a rank = a row chunk on its own GPU, and the pieces below hide the exchange behind sl_neumann_state_* so that a host
 // in any language reaches N GPUs through include/sublinear_hip.h alone.
 //
-// Transport (what moves, and how it is kept coherent BY CONSTRUCTION — nothing here has run on two devices in the build image):
-//   * rendezvous + control words: ONE POSIX shared-memory file per communicator (/dev/shm/slcomm_<name>), mapped by every rank and
-//     registered with the HIP runtime (hipHostRegister, mapped): host memory is never cached on a device, so a system-scope store by
-//     a kernel on one GPU is what a system-scope load on another GPU (or a host) sees.  It carries the host barrier, the exchange
-//     of IPC handles, and per rank one 128-byte line {ticket} plus a ring of published doubles.
+// Rendezvous + control words (both transports): ONE POSIX shared-memory file per communicator (/dev/shm/slcomm_<name>), mapped by
+// every rank and registered with the HIP runtime (hipHostRegister, mapped): host memory is never cached on a device, so a
+// system-scope store by a kernel on one GPU is what a system-scope load on another GPU (or a host) sees.  It carries the host
+// barrier, the exchange of small blobs (IPC handles, row ranges, the ncclUniqueId), and per rank one 128-byte line {ticket} plus
+// a ring of published doubles.
+//
+// Transport IPC (SL_COMM_TRANSPORT=ipc, the default; ranks may share a GPU):
 //   * vectors: the full-length gathered vectors (two term buffers + the solution, n_global doubles each) are ordinary device
 //     allocations exported with hipIpcGetMemHandle; a rank PULLS the pieces it needs out of its peers' buffers with
 //     hipMemcpyAsync (device to device over xGMI between GPUs; a plain copy when two ranks share a GPU — the test setup): the
@@ -20,14 +22,25 @@
 //     the "data ready" handshake of the halo in one kernel of 64 lanes.  Because every ticket waits for ALL ranks, a buffer is
 //     never overwritten while a peer still pulls from it (its next writer has passed a later ticket than the puller's copy).
 //     A wait is bounded (SL_COMM_TIMEOUT_MS, default 20 s): a dead peer turns into SL_DEVICE_ERROR, not into a hung GPU.
-//   RCCL: the exchange through torch.distributed / RCCL (all-gather, grouped send/recv, all-reduce form) stays available above the
-//   ABI in sublinear_time_solver_amd/distributed.py; this file needs neither RCCL nor torch.
+// Transport RCCL (SL_COMM_TRANSPORT=rccl; one rank per GPU — RCCL refuses two ranks on one device) — the collectives SURVEY §8(e)
+// lists, inside the library (librccl is resolved at run time; without it the transport reports SL_DEVICE_ERROR):
+//   * vectors: ncclAllGather (in place) when every rank needs every peer's whole range and the ranges are equal (uniform
+//     columns); otherwise ONE group of ncclSend / ncclRecv of the pieces (the halo strips; unequal ranges), or — SL_COMM_HALO=allreduce,
+//     the form BASELINE's north_star words — ONE ncclAllReduce(sum) over a compact buffer that holds every rank's exported strips
+//     and -0.0 (the neutral element of IEEE addition: x + -0.0 = x for every x, +0.0 and -0.0 included) everywhere else.  All
+//     three are copies: the bits a rank computes with are the bits its peer wrote.
+//   * sums: ncclAllGather of the ranks' partial sums (8 bytes each), added in rank order and judged by a one-wave kernel — the
+//     same bits as the ticket form.  Send / receive pairs synchronise the two ranks, so the "data ready" tickets fall away.
+//   A speculative batch enqueues the exchanges of iterations that a stop rule later gates off; every rank enqueues the same
+//   sequence (the plan is a function of the options), the gated-off ones move unchanged buffers.
 #include "sl_internal.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <rccl/rccl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
@@ -36,6 +49,7 @@
 #define SL_COMM_FRESH_S 120u
 
 static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the blob slots assume");
+static_assert(sizeof(ncclUniqueId) <= SL_COMM_BLOB, "ncclUniqueId larger than a blob slot");
 
 // ---- host side of the shared block --------------------------------------------------------------------------------------------
 namespace {
@@ -48,24 +62,113 @@ long comm_timeout_ms()
     return v;
 }
 
-template <class F> bool wait_until(F cond)
+// 1 = cond became true, 0 = timed out, -1 = `stop` became true first
+template <class F, class G> int wait_until(F cond, G stop)
 {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spin = 0; !cond(); ++spin) {
+        if (stop()) return -1;
         if (spin > 1000) std::this_thread::sleep_for(std::chrono::microseconds(50));
-        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)comm_timeout_ms()) return false;
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)comm_timeout_ms()) return 0;
     }
-    return true;
+    return 1;
 }
+template <class F> bool wait_until(F cond) { return wait_until(cond, [] { return false; }) == 1; }
+
+// ---- librccl, resolved at run time: the library loads (and the IPC transport works) where RCCL is absent --------------------------
+struct rccl_api {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+const rccl_api &rccl()
+{
+    static const rccl_api api = [] {
+        rccl_api a;
+        // the soname first: a host process that already holds an RCCL (PyTorch bundles one) shares that copy instead of loading a second
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+        bool all = true;
+        auto sym = [&](const char *n) { void *p = dlsym(a.lib, n); if (!p) all = false; return p; };
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(sym("ncclCommAbort"));
+        a.CommGetAsyncError = reinterpret_cast<decltype(a.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+        a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+        a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        a.ok = all;
+        return a;
+    }();
+    return api;
+}
+#define SL_NCCL(call)                                                                                                    \
+    do {                                                                                                                 \
+        ncclResult_t r_ = (call);                                                                                        \
+        if (r_ != ncclSuccess && r_ != ncclInProgress)                                                                   \
+            return sl_fail(SL_DEVICE_ERROR, "%s failed: %s (%s:%d)", #call, rccl().GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+inline ncclComm_t nccl_of(const sl_comm *c) { return static_cast<ncclComm_t>(c->nccl); }
 } // namespace
+
+void sl_comm_poison(sl_comm *c)
+{
+    if (c && c->h_shm) {
+        uint64_t zero = 0;
+        (void)__atomic_compare_exchange_n(&c->h_shm->error, &zero, (uint64_t)(c->rank + 1), false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+    }
+}
+
+bool sl_comm_failed(const sl_comm *c)
+{
+    if (__atomic_load_n(&c->h_shm->error, __ATOMIC_ACQUIRE) != 0) return true;
+    if (c->transport == SL_TRANSPORT_RCCL && c->nccl) {
+        ncclResult_t ae = ncclSuccess;
+        if (rccl().CommGetAsyncError(nccl_of(c), &ae) != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress)) return true;
+    }
+    return false;
+}
+
+const char *sl_comm_transport_name(const sl_comm *c)
+{
+    if (c->transport == SL_TRANSPORT_RCCL) return c->halo_allreduce ? "rccl (all-gather / all-reduce over the compact halo buffer)" : "rccl (all-gather / grouped send + recv)";
+    return "ipc (peer buffers mapped, pulled with device copies; tickets in shared host memory)";
+}
+
+static sl_status poisoned(const sl_comm *c, const char *what)
+{
+    return sl_fail(SL_DEVICE_ERROR, "communicator %s: rank %llu of the job failed or did not arrive; no further collective runs on this communicator (rank %d of %d)",
+                   what, (unsigned long long)ld_acq(&c->h_shm->error) - 1ull, c->rank, c->world);
+}
 
 sl_status sl_comm_host_barrier(sl_comm *c)
 {
     sl_comm_shm *h = c->h_shm;
     const uint64_t k = ++c->barrier_count;
     st_rel(&h->arrive[c->rank], k);
-    const bool ok = wait_until([&] { for (int p = 0; p < c->world; ++p) if (ld_acq(&h->arrive[p]) < k) return false; return true; });
-    if (!ok) return sl_fail(SL_DEVICE_ERROR, "communicator barrier timed out after %ld ms (rank %d of %d)", comm_timeout_ms(), c->rank, c->world);
+    const int ok = wait_until([&] { for (int p = 0; p < c->world; ++p) if (ld_acq(&h->arrive[p]) < k) return false; return true; },
+                              [&] { return ld_acq(&h->error) != 0; });
+    if (ok < 0) return poisoned(c, "barrier");
+    if (!ok) { sl_comm_poison(c); return sl_fail(SL_DEVICE_ERROR, "communicator barrier timed out after %ld ms (rank %d of %d)", comm_timeout_ms(), c->rank, c->world); }
     return SL_OK;
 }
 
@@ -77,14 +180,46 @@ sl_status sl_comm_allgather_blob(sl_comm *c, const void *mine, size_t bytes, voi
     const uint64_t k = ++c->blob_count;
     memcpy(const_cast<unsigned char *>(h->blob[c->rank]), mine, bytes);
     st_rel(&h->blob_seq[c->rank], k);
-    const bool ok = wait_until([&] { for (int p = 0; p < c->world; ++p) if (ld_acq(&h->blob_seq[p]) < k) return false; return true; });
-    if (!ok) return sl_fail(SL_DEVICE_ERROR, "communicator exchange timed out after %ld ms (rank %d of %d)", comm_timeout_ms(), c->rank, c->world);
+    const int ok = wait_until([&] { for (int p = 0; p < c->world; ++p) if (ld_acq(&h->blob_seq[p]) < k) return false; return true; },
+                              [&] { return ld_acq(&h->error) != 0; });
+    if (ok < 0) { ++c->barrier_count; return poisoned(c, "exchange"); }
+    if (!ok) { ++c->barrier_count; sl_comm_poison(c); return sl_fail(SL_DEVICE_ERROR, "communicator exchange timed out after %ld ms (rank %d of %d)", comm_timeout_ms(), c->rank, c->world); }
     for (int p = 0; p < c->world; ++p) memcpy(static_cast<unsigned char *>(all) + (size_t)p * bytes, const_cast<unsigned char *>(h->blob[p]), bytes);
     return sl_comm_host_barrier(c);                 // nobody overwrites its slot before everybody has read it
 }
 
+// collective: the same verdict on every rank (a rank that left alone would let the others wait for it).  Every stage of a
+// collective construction ends here, whatever happened locally: all ranks take part in every exchange, in the same order.
+sl_status sl_comm_agree(sl_comm *c, sl_status mine)
+{
+    std::vector<int32_t> all((size_t)c->world);
+    const int32_t v = (int32_t)mine;
+    const std::string msg = sl_context().last_error;
+    const sl_status ex = sl_comm_allgather_blob(c, &v, sizeof(v), all.data());
+    if (ex != SL_OK) { if (mine != SL_OK) { sl_context().last_error = msg; return mine; } return ex; }
+    for (int p = 0; p < c->world; ++p)
+        if (all[p] != SL_OK) {
+            if (p == c->rank) { sl_context().last_error = msg; return mine; }
+            return sl_fail((sl_status)all[p], "rank %d failed: %s", p, sl_status_string((sl_status)all[p]));
+        }
+    return SL_OK;
+}
+
 // ---- device side: publish / wait for all / sum in rank order / stop rule --------------------------------------------------------
 __device__ __forceinline__ uint64_t sys_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+__device__ __forceinline__ void sl_comm_judge(double t, double *result, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot, int mode, double thr)
+{
+    if (result) result[0] = t;
+    if (ctl && mode != SL_JUDGE_LOCAL) {
+        ctl->log[slot] = t;
+        ctl->n_done = slot + 1;
+        bool stop = false;
+        if (mode == SL_JUDGE_LT) stop = t < thr;
+        else if (mode == SL_JUDGE_LE_OR_NONFINITE) stop = (t <= thr) || (t != t) || (fabs(t) == INFINITY);
+        if (stop && gate_it < ctl->stop_after) ctl->stop_after = gate_it;
+    }
+}
 
 // One wave.  `local` (device) holds this rank's contribution (may be null: a pure "data ready" ticket, value 0).  With ctl: gated
 // like every launch of a speculative batch; the sum is logged and judged exactly as sl_judge_reduce_kernel does for one GPU.
@@ -111,32 +246,47 @@ __global__ __launch_bounds__(64) void sl_comm_ticket_kernel(sl_comm_shm *shm, in
         while (sys_load(&shm->ready[lane][chan]) < ticket) {
             __builtin_amdgcn_s_sleep(16);
             if (wall_clock64() - t0 > timeout_ticks) { ok = false; break; }
+            if (__hip_atomic_load(&shm->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { ok = false; break; }
         }
     }
     const bool all_ok = __ballot(!ok) == 0ull;
     if (lane != 0) return;
     if (!all_ok) {
-        __hip_atomic_store(&shm->error, (uint64_t)(rank + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned long long expect = 0ull;
+        (void)__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(&shm->error), &expect, (unsigned long long)(rank + 1),
+                                                   __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (ctl) ctl->stop_after = 0;                                    // nothing enqueued behind this runs
         return;
     }
     if (chan != 0) return;
     double t = 0.0;
     for (int p = 0; p < world; ++p) t += __hip_atomic_load(&shm->value[ring][p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // rank order: same bits everywhere
-    if (result) result[0] = t;
-    if (ctl && mode != SL_JUDGE_LOCAL) {
-        ctl->log[slot] = t;
-        ctl->n_done = slot + 1;
-        bool stop = false;
-        if (mode == SL_JUDGE_LT) stop = t < thr;
-        else if (mode == SL_JUDGE_LE_OR_NONFINITE) stop = (t <= thr) || (t != t) || (fabs(t) == INFINITY);
-        if (stop && gate_it < ctl->stop_after) ctl->stop_after = gate_it;
-    }
+    sl_comm_judge(t, result, ctl, gate_it, slot, mode, thr);
+}
+
+// RCCL transport: the ranks' shares arrive by ncclAllGather; this adds them in rank order and judges — the same bits as the ticket
+__global__ __launch_bounds__(64) void sl_comm_sum_kernel(const double *vals, int world, double *result, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot,
+                                                          int mode, double thr)
+{
+    if (ctl && gate_it > ctl->stop_after) return;
+    if (threadIdx.x) return;
+    double t = 0.0;
+    for (int p = 0; p < world; ++p) t += vals[p];
+    sl_comm_judge(t, result, ctl, gate_it, slot, mode, thr);
 }
 
 sl_status sl_comm_launch_ticket(sl_comm *c, const double *local, double *result, sl_solve_ctl *ctl, uint32_t gate_it, uint32_t slot, int mode,
                                 double thr, hipStream_t s, int channel)
 {
+    if (c->transport == SL_TRANSPORT_RCCL) {
+        // send / receive pairs synchronise the ranks themselves: the pure "data ready" tickets (no value) have nothing to do
+        if (channel != 0 || !local) return SL_OK;
+        double *slot_vals = c->d_sums + (size_t)(c->sums_seq++ % SL_COMM_RING) * (size_t)c->world;
+        SL_NCCL(rccl().AllGather(local, slot_vals, 1, ncclDouble, nccl_of(c), s));
+        hipLaunchKernelGGL(sl_comm_sum_kernel, dim3(1), dim3(64), 0, s, slot_vals, c->world, result, ctl, gate_it, slot, mode, thr);
+        SL_HIP(hipGetLastError());
+        return SL_OK;
+    }
     const uint64_t ticket = ++c->ticket[channel ? 1 : 0];
     const unsigned long long ticks = (unsigned long long)comm_timeout_ms() * 100000ull;            // wall_clock64: 100 MHz
     hipLaunchKernelGGL(sl_comm_ticket_kernel, dim3(1), dim3(64), 0, s, c->d_shm, c->rank, c->world, ticket, local, result, ctl, gate_it, slot, mode,
@@ -145,43 +295,105 @@ sl_status sl_comm_launch_ticket(sl_comm *c, const double *local, double *result,
     return SL_OK;
 }
 
-bool sl_comm_failed(const sl_comm *c) { return __atomic_load_n(&c->h_shm->error, __ATOMIC_ACQUIRE) != 0; }
-
 // ---- partitioned vectors --------------------------------------------------------------------------------------------------------
-// A full-length vector (n_global doubles) per rank, exported to the peers; pull() copies the pieces this rank needs from their
-// owners' copies into its own.
+// A full-length vector (n_global doubles) per rank; IPC: exported to the peers, pull() copies the pieces this rank needs from their
+// owners' copies into its own.  Collective and failure-safe: a rank whose allocation / export / import fails still takes part in
+// the handle exchange and in both agreements, so every rank leaves with the same verdict and the communicator's counters in step.
 sl_status sl_dist_vector_create(sl_comm *c, uint64_t n_global, sl_dist_vector *v)
 {
     v->n = n_global;
     v->peer.assign((size_t)c->world, nullptr);
-    SL_HIP(hipMalloc(&v->mine, (n_global ? n_global : 1) * sizeof(double)));
-    SL_HIP(hipMemset(v->mine, 0, (n_global ? n_global : 1) * sizeof(double)));
+    const size_t bytes = (n_global ? n_global : 1) * sizeof(double);
+    sl_status mine = SL_OK;
+    if (hipMalloc(&v->mine, bytes) != hipSuccess) { v->mine = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc(%zu) for a gathered vector failed", bytes); }
+    if (mine == SL_OK && hipMemset(v->mine, 0, bytes) != hipSuccess) mine = sl_fail(SL_DEVICE_ERROR, "hipMemset of a gathered vector failed");
+    if (c->transport != SL_TRANSPORT_IPC) { if (v->mine) v->peer[c->rank] = v->mine; return sl_comm_agree(c, mine); }
     hipIpcMemHandle_t h;
     memset(&h, 0, sizeof(h));
-    if (c->world > 1) SL_HIP(hipIpcGetMemHandle(&h, v->mine));
+    if (mine == SL_OK && c->world > 1) {
+        const hipError_t e = hipIpcGetMemHandle(&h, v->mine);
+        if (e != hipSuccess) mine = sl_fail(SL_DEVICE_ERROR, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
+    }
     std::vector<hipIpcMemHandle_t> all((size_t)c->world);
-    SL_TRY(sl_comm_allgather_blob(c, &h, sizeof(h), all.data()));
-    for (int p = 0; p < c->world; ++p) {
+    const sl_status ex = sl_comm_allgather_blob(c, &h, sizeof(h), all.data());
+    if (ex != SL_OK) return mine != SL_OK ? mine : ex;                  // the communicator itself is gone (timeout / poisoned): nothing collective is left to do
+    SL_TRY(sl_comm_agree(c, mine));                                     // every handle in `all` is a real one from here on
+    for (int p = 0; p < c->world && mine == SL_OK; ++p) {
         if (p == c->rank) { v->peer[p] = v->mine; continue; }
         void *q = nullptr;
-        SL_HIP(hipIpcOpenMemHandle(&q, all[p], hipIpcMemLazyEnablePeerAccess));
+        const hipError_t e = hipIpcOpenMemHandle(&q, all[p], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "hipIpcOpenMemHandle of rank %d's vector failed: %s", p, hipGetErrorString(e)); break; }
         v->peer[p] = static_cast<double *>(q);
     }
-    return SL_OK;
+    return sl_comm_agree(c, mine);
 }
 
 void sl_dist_vector_destroy(sl_comm *c, sl_dist_vector *v)
 {
-    for (int p = 0; p < (int)v->peer.size(); ++p)
-        if (p != c->rank && v->peer[p]) (void)hipIpcCloseMemHandle(v->peer[p]);
+    if (c->transport == SL_TRANSPORT_IPC)
+        for (int p = 0; p < (int)v->peer.size(); ++p)
+            if (p != c->rank && v->peer[p]) (void)hipIpcCloseMemHandle(v->peer[p]);
     v->peer.clear();
     if (v->mine) (void)hipFree(v->mine);
     v->mine = nullptr;
 }
 
+// all-reduce form of the halo: own strips at their place, -0.0 (x + -0.0 = x, bit for bit, for every x) everywhere else
+__global__ __launch_bounds__(256) void sl_halo_pack_kernel(double *halo, uint64_t len, uint64_t off, const double *mine, uint64_t lo0, uint64_t hi0,
+                                                            uint64_t lo1, uint64_t hi1)
+{
+    const uint64_t n0 = hi0 - lo0, n1 = hi1 - lo1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x) {
+        double v = -0.0;
+        if (i >= off && i < off + n0) v = mine[lo0 + (i - off)];
+        else if (i >= off + n0 && i < off + n0 + n1) v = mine[lo1 + (i - off - n0)];
+        halo[i] = v;
+    }
+}
+
+static sl_status pull_rccl(sl_dist *d, sl_dist_vector *v, hipStream_t s)
+{
+    sl_comm *c = d->c;
+    const rccl_api &R = rccl();
+    if (c->world == 1) return SL_OK;
+    if (d->all_to_all && d->equal_ranges) {
+        const uint64_t cnt = d->hi - d->lo;
+        SL_NCCL(R.AllGather(v->mine + d->lo, v->mine, cnt, ncclDouble, nccl_of(c), s));         // in place: sendbuff = recvbuff + rank * count
+        return SL_OK;
+    }
+    if (c->halo_allreduce && !d->all_to_all && d->d_halo) {
+        const sl_dist::strips &e = d->exports[(size_t)c->rank];
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((d->halo_len + 255) / 256, 2048);
+        hipLaunchKernelGGL(sl_halo_pack_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, d->d_halo, d->halo_len, e.off, v->mine, e.lo0, e.hi0, e.lo1, e.hi1);
+        SL_HIP(hipGetLastError());
+        SL_NCCL(R.AllReduce(d->d_halo, d->d_halo, d->halo_len, ncclDouble, ncclSum, nccl_of(c), s));
+        for (const sl_dist::piece &pc : d->need) {
+            if (pc.hi <= pc.lo) continue;
+            const sl_dist::strips &x = d->exports[(size_t)pc.rank];
+            // a piece lies inside ONE strip of its owner, or spans both when they touch (then they are stored back to back)
+            uint64_t src;
+            if (pc.lo >= x.lo0 && pc.lo < x.hi0) src = x.off + (pc.lo - x.lo0);
+            else src = x.off + (x.hi0 - x.lo0) + (pc.lo - x.lo1);
+            SL_HIP(hipMemcpyAsync(v->mine + pc.lo, d->d_halo + src, (pc.hi - pc.lo) * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        return SL_OK;
+    }
+    SL_NCCL(R.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (const sl_dist::piece &pc : d->give)
+        if (pc.hi > pc.lo && r == ncclSuccess) r = R.Send(v->mine + pc.lo, pc.hi - pc.lo, ncclDouble, pc.rank, nccl_of(c), s);
+    for (const sl_dist::piece &pc : d->need)
+        if (pc.hi > pc.lo && r == ncclSuccess) r = R.Recv(v->mine + pc.lo, pc.hi - pc.lo, ncclDouble, pc.rank, nccl_of(c), s);
+    const ncclResult_t ge = R.GroupEnd();
+    if (r != ncclSuccess) return sl_fail(SL_DEVICE_ERROR, "ncclSend / ncclRecv failed: %s", R.GetErrorString(r));
+    SL_NCCL(ge);
+    return SL_OK;
+}
+
 #define SL_PULL_PARALLEL_BYTES (4u << 20)      // below this an exchange is two halo strips: one stream, no forks
 sl_status sl_dist_pull(sl_dist *d, sl_dist_vector *v, hipStream_t s)
 {
+    if (d->c->transport == SL_TRANSPORT_RCCL) return pull_rccl(d, v, s);
     static const bool parallel_ok = [] { const char *e = getenv("SL_PULL_STREAMS"); return !(e && *e && atoi(e) == 0); }();
     auto copy = [&](const sl_dist::piece &pc, hipStream_t q) {
         return hipMemcpyAsync(v->mine + pc.lo, v->peer[pc.rank] + pc.lo, (pc.hi - pc.lo) * sizeof(double), hipMemcpyDeviceToDevice, q);
@@ -213,7 +425,72 @@ sl_status sl_dist_pull(sl_dist *d, sl_dist_vector *v, hipStream_t s)
     return SL_OK;
 }
 
+// ---- verification of an exchange: what a rank holds of its peers' rows against the owners' own copies ---------------------------
+__global__ __launch_bounds__(256) void sl_checksum_kernel(const unsigned long long *data, uint64_t n, unsigned long long *out)
+{
+    unsigned long long acc = 0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        acc += data[i] * (2ull * (i & 0xffffull) + 1ull);               // position-weighted inside the piece: a shifted or permuted copy does not pass
+    for (int o = 32; o; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63u) == 0 && acc) atomicAdd(out, acc);
+}
+
+sl_status sl_dist_verify(sl_dist *d, sl_dist_vector *v, uint64_t *n_bad)
+{
+    sl_comm *c = d->c;
+    hipStream_t s = sl_context().stream;
+    const int W = c->world;
+    *n_bad = 0;
+    sl_status mine = SL_OK;
+    std::vector<uint64_t> sums((size_t)2 * SL_COMM_MAX_RANKS, 0);       // [0, W): what I give to rank q (my own copy); [16, 16 + W): what I hold of rank p
+    do {
+        if (!d->d_check && hipMalloc(&d->d_check, 2 * SL_COMM_MAX_RANKS * sizeof(uint64_t)) != hipSuccess) { d->d_check = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); break; }
+        if (hipMemsetAsync(d->d_check, 0, 2 * SL_COMM_MAX_RANKS * sizeof(uint64_t), s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "memset failed"); break; }
+        auto launch = [&](const sl_dist::piece &pc, uint64_t *out) {
+            const uint64_t n = pc.hi - pc.lo;
+            if (!n) return;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+            // the weight uses the index INSIDE the piece: data pointer at the piece, i from 0
+            hipLaunchKernelGGL(sl_checksum_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const unsigned long long *>(v->mine + pc.lo), n,
+                               reinterpret_cast<unsigned long long *>(out));
+        };
+        for (const sl_dist::piece &pc : d->give) launch(pc, d->d_check + pc.rank);
+        for (const sl_dist::piece &pc : d->need) launch(pc, d->d_check + SL_COMM_MAX_RANKS + pc.rank);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(sums.data(), d->d_check, 2 * SL_COMM_MAX_RANKS * sizeof(uint64_t), hipMemcpyDeviceToHost, s) != hipSuccess
+            || hipStreamSynchronize(s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "checksum pass failed"); break; }
+    } while (0);
+    std::vector<uint64_t> all((size_t)W * SL_COMM_MAX_RANKS);
+    const sl_status ex = sl_comm_allgather_blob(c, sums.data(), SL_COMM_MAX_RANKS * sizeof(uint64_t), all.data());
+    if (ex != SL_OK) return mine != SL_OK ? mine : ex;
+    SL_TRY(sl_comm_agree(c, mine));
+    for (const sl_dist::piece &pc : d->need) {
+        const uint64_t owners = all[(size_t)pc.rank * SL_COMM_MAX_RANKS + (size_t)c->rank], held = sums[(size_t)SL_COMM_MAX_RANKS + (size_t)pc.rank];
+        if (owners != held) {
+            ++*n_bad;
+            sl_log(0, "exchange check: rank %d holds rows [%llu, %llu) of rank %d with checksum %016llx, the owner has %016llx", c->rank,
+                   (unsigned long long)pc.lo, (unsigned long long)pc.hi, pc.rank, (unsigned long long)held, (unsigned long long)owners);
+        }
+    }
+    return SL_OK;
+}
+
 // ---- the communicator ----------------------------------------------------------------------------------------------------------
+static void comm_free(sl_comm *c)
+{
+    if (c->nccl) { (void)rccl().CommDestroy(nccl_of(c)); c->nccl = nullptr; }
+    if (c->d_sums) (void)hipFree(c->d_sums);
+    if (c->registered) (void)hipHostUnregister(c->h_shm);
+    if (c->h_shm) munmap(c->h_shm, c->shm_bytes);
+    if (c->fd >= 0) close(c->fd);
+    delete c;
+}
+
+void sl_comm_release(sl_comm *c)
+{
+    if (!c) return;
+    if (--c->refs <= 0 && c->closed) comm_free(c);
+}
+
 extern "C" {
 
 sl_status sl_comm_create(int rank, int world, const char *rendezvous, sl_comm **out)
@@ -227,67 +504,129 @@ sl_status sl_comm_create(int rank, int world, const char *rendezvous, sl_comm **
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return sl_fail(SL_DEVICE_ERROR, "no HIP device available; libsublinear_hip has no CPU fallback");
+    int transport = SL_TRANSPORT_IPC;
+    if (const char *e = getenv("SL_COMM_TRANSPORT")) {
+        if (!strcmp(e, "rccl") || !strcmp(e, "nccl")) transport = SL_TRANSPORT_RCCL;
+        else if (*e && strcmp(e, "ipc")) return sl_fail(SL_INVALID_INPUT, "SL_COMM_TRANSPORT=%s: ipc or rccl", e);
+    }
+    if (transport == SL_TRANSPORT_RCCL && !rccl().ok) return sl_fail(SL_DEVICE_ERROR, "SL_COMM_TRANSPORT=rccl: librccl.so.1 not found or incomplete");
     sl_range trace_range("communicator create");
     sl_comm *c = new sl_comm();
-    c->rank = rank; c->world = world;
+    c->rank = rank; c->world = world; c->transport = transport;
+    { const char *e = getenv("SL_COMM_HALO"); c->halo_allreduce = e && !strcmp(e, "allreduce"); }
     c->path = std::string("/dev/shm/slcomm_") + rendezvous;
     (void)hipGetDevice(&c->device);
     const size_t bytes = (sizeof(sl_comm_shm) + 4095) & ~(size_t)4095;
-    auto fail = [&](sl_status st) { sl_comm_destroy(c); return st; };
-    // rank 0 creates the block (zero-filled by ftruncate) and stamps it last; the others wait for a FRESH stamped block — a block
-    // left behind under the same name by a job that died before all its ranks had joined (the name is unlinked at that point) is
-    // older than SL_COMM_FRESH_S and is not joined
+    auto fail = [&](sl_status st) { comm_free(c); return st; };
+    // rank 0 builds the block under a temporary name (zero-filled by ftruncate), stamps it with a nonce of THIS job and renames it into
+    // place; the others join a FRESH stamped block in which their own slot is untouched, and stay only once rank 0 has confirmed —
+    // with the nonce they saw — that every rank of this job has arrived.  A block left behind under the same name by a job that died
+    // during its rendezvous never confirms: a rank that mapped it notices the name changing hands (inode) or waits out the confirm
+    // and looks again.
     const uint64_t now = (uint64_t)time(nullptr);
     if (rank == 0) {
-        (void)unlink(c->path.c_str());
-        c->fd = open(c->path.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (c->fd < 0 || ftruncate(c->fd, (off_t)bytes) != 0) return fail(sl_fail(SL_DEVICE_ERROR, "cannot create %s", c->path.c_str()));
+        const std::string tmp = c->path + ".tmp" + std::to_string((long)getpid());
+        (void)unlink(tmp.c_str());
+        c->fd = open(tmp.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (c->fd < 0 || ftruncate(c->fd, (off_t)bytes) != 0) { (void)unlink(tmp.c_str()); return fail(sl_fail(SL_DEVICE_ERROR, "cannot create %s", tmp.c_str())); }
         void *map = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
-        if (map == MAP_FAILED) return fail(sl_fail(SL_DEVICE_ERROR, "mmap of %s failed", c->path.c_str()));
+        if (map == MAP_FAILED) { (void)unlink(tmp.c_str()); return fail(sl_fail(SL_DEVICE_ERROR, "mmap of %s failed", tmp.c_str())); }
         c->h_shm = static_cast<sl_comm_shm *>(map);
         c->shm_bytes = bytes;
-        c->h_shm->world = (uint64_t)world; c->h_shm->created_unix = now;
+        struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        uint64_t gen = ((uint64_t)getpid() << 40) ^ ((uint64_t)ts.tv_sec << 20) ^ (uint64_t)ts.tv_nsec;
+        if (!gen) gen = 1;
+        c->h_shm->world = (uint64_t)world; c->h_shm->created_unix = now; c->h_shm->generation = gen;
         st_rel(&c->h_shm->magic, SL_COMM_MAGIC);
+        if (rename(tmp.c_str(), c->path.c_str()) != 0) { (void)unlink(tmp.c_str()); return fail(sl_fail(SL_DEVICE_ERROR, "cannot publish %s", c->path.c_str())); }
+        // the rendezvous barrier (count 1), then the confirmation the joiners wait for
+        const sl_status bs = sl_comm_host_barrier(c);
+        (void)unlink(c->path.c_str());                    // everybody has it mapped (or never will): the name can go, the memory lives while mapped
+        if (bs != SL_OK) return fail(bs);
+        st_rel(&c->h_shm->confirmed, gen);
     } else {
-        const bool ok = wait_until([&] {
+        const auto t0 = std::chrono::steady_clock::now();
+        auto expired = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)comm_timeout_ms(); };
+        bool joined = false;
+        while (!joined && !expired()) {
             const int fd = open(c->path.c_str(), O_RDWR);
-            if (fd < 0) return false;
             struct stat sb;
-            if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) { close(fd); return false; }
+            if (fd < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) { if (fd >= 0) close(fd); std::this_thread::sleep_for(std::chrono::microseconds(200)); continue; }
             void *map = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-            if (map == MAP_FAILED) { close(fd); return false; }
+            if (map == MAP_FAILED) { close(fd); std::this_thread::sleep_for(std::chrono::microseconds(200)); continue; }
             sl_comm_shm *h = static_cast<sl_comm_shm *>(map);
-            if (ld_acq(&h->magic) == SL_COMM_MAGIC && h->created_unix + SL_COMM_FRESH_S >= now) { c->fd = fd; c->h_shm = h; c->shm_bytes = bytes; return true; }
+            const bool fresh = ld_acq(&h->magic) == SL_COMM_MAGIC && h->created_unix + SL_COMM_FRESH_S >= now && ld_acq(&h->arrive[rank]) == 0 && ld_acq(&h->blob_seq[rank]) == 0
+                               && ld_acq(&h->confirmed) == 0;
+            if (!fresh) { munmap(map, bytes); close(fd); std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }
+            const uint64_t gen = h->generation;
+            const ino_t ino = sb.st_ino;
+            st_rel(&h->arrive[rank], 1);                   // the rendezvous barrier, by hand: leave again if the name changes hands meanwhile
+            bool stale = false;
+            while (!expired()) {
+                if (ld_acq(&h->confirmed) == gen && gen) { joined = true; break; }
+                struct stat cur;
+                const bool all = [&] { for (int p = 0; p < world; ++p) if (ld_acq(&h->arrive[p]) < 1) return false; return true; }();
+                if (!all && stat(c->path.c_str(), &cur) == 0 && cur.st_ino != ino) { stale = true; break; }    // a new rank 0 published its block: this one is a leftover
+                std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+            if (joined) { c->fd = fd; c->h_shm = h; c->shm_bytes = bytes; c->barrier_count = 1; break; }
             munmap(map, bytes); close(fd);
-            return false;
-        });
-        if (!ok) return fail(sl_fail(SL_DEVICE_ERROR, "rank %d: no fresh rendezvous block %s within %ld ms", rank, c->path.c_str(), comm_timeout_ms()));
+            if (!stale) break;
+        }
+        if (!joined) return fail(sl_fail(SL_DEVICE_ERROR, "rank %d: no fresh rendezvous block %s within %ld ms", rank, c->path.c_str(), comm_timeout_ms()));
     }
     void *map = c->h_shm;
-    if (c->h_shm->world != (uint64_t)world) return fail(sl_fail(SL_INVALID_INPUT, "rank %d joins a communicator of %llu ranks, asked for %d", rank,
-                                                                  (unsigned long long)c->h_shm->world, world));
-    if (hipHostRegister(map, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess)
-        return fail(sl_fail(SL_DEVICE_ERROR, "hipHostRegister of the rendezvous block failed"));
-    c->registered = true;
-    void *dptr = nullptr;
-    if (hipHostGetDevicePointer(&dptr, map, 0) != hipSuccess) return fail(sl_fail(SL_DEVICE_ERROR, "no device pointer for the rendezvous block"));
-    c->d_shm = static_cast<sl_comm_shm *>(dptr);
-    const sl_status bs = sl_comm_host_barrier(c);
-    if (bs != SL_OK) return fail(bs);
-    if (rank == 0) (void)unlink(c->path.c_str());      // everybody has it mapped: the name can go (the memory lives while mapped)
-    sl_log(1, "communicator '%s': rank %d of %d on device %d", rendezvous, rank, world, c->device);
+    sl_status mine = SL_OK;
+    if (c->h_shm->world != (uint64_t)world) mine = sl_fail(SL_INVALID_INPUT, "rank %d joins a communicator of %llu ranks, asked for %d", rank, (unsigned long long)c->h_shm->world, world);
+    if (mine == SL_OK && hipHostRegister(map, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) mine = sl_fail(SL_DEVICE_ERROR, "hipHostRegister of the rendezvous block failed");
+    if (mine == SL_OK) {
+        c->registered = true;
+        void *dptr = nullptr;
+        if (hipHostGetDevicePointer(&dptr, map, 0) != hipSuccess) mine = sl_fail(SL_DEVICE_ERROR, "no device pointer for the rendezvous block");
+        c->d_shm = static_cast<sl_comm_shm *>(dptr);
+    }
+    // every rank must have asked for the same transport
+    {
+        std::vector<int32_t> tr((size_t)world);
+        const int32_t t = (int32_t)transport | (c->halo_allreduce ? 256 : 0);
+        const sl_status ex = sl_comm_allgather_blob(c, &t, sizeof(t), tr.data());
+        if (ex != SL_OK) return fail(mine != SL_OK ? mine : ex);
+        for (int p = 0; p < world && mine == SL_OK; ++p)
+            if (tr[p] != t) mine = sl_fail(SL_INVALID_INPUT, "rank %d asked for transport %d, rank %d for %d (SL_COMM_TRANSPORT / SL_COMM_HALO must agree)", rank, t, p, tr[p]);
+    }
+    sl_status st = sl_comm_agree(c, mine);
+    if (st != SL_OK) return fail(st);
+    if (transport == SL_TRANSPORT_RCCL) {
+        ncclUniqueId id;
+        memset(&id, 0, sizeof(id));
+        if (rank == 0) {
+            const ncclResult_t r = rccl().GetUniqueId(&id);
+            if (r != ncclSuccess) mine = sl_fail(SL_DEVICE_ERROR, "ncclGetUniqueId failed: %s", rccl().GetErrorString(r));
+        }
+        std::vector<ncclUniqueId> ids((size_t)world);
+        const sl_status ex = sl_comm_allgather_blob(c, &id, sizeof(id), ids.data());
+        if (ex != SL_OK) return fail(mine != SL_OK ? mine : ex);
+        if ((st = sl_comm_agree(c, mine)) != SL_OK) return fail(st);
+        ncclComm_t nc = nullptr;
+        const ncclResult_t r = rccl().CommInitRank(&nc, world, ids[0], rank);
+        if (r != ncclSuccess) mine = sl_fail(SL_DEVICE_ERROR, "ncclCommInitRank failed on rank %d (device %d): %s — RCCL needs one rank per GPU", rank, c->device, rccl().GetErrorString(r));
+        else c->nccl = nc;
+        if (mine == SL_OK && hipMalloc(&c->d_sums, (size_t)SL_COMM_RING * (size_t)world * sizeof(double)) != hipSuccess) { c->d_sums = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); }
+        if ((st = sl_comm_agree(c, mine)) != SL_OK) return fail(st);
+    }
+    sl_log(1, "communicator '%s': rank %d of %d on device %d, transport %s", rendezvous, rank, world, c->device, sl_comm_transport_name(c));
     *out = c;
     return SL_OK;
     SL_ABI_END
 }
 
+// With partitioned states still alive on it the communicator only closes: the last state to go frees it (a state's destructor
+// may run late — a garbage-collected host object, an error path — and must not find its communicator gone).
 void sl_comm_destroy(sl_comm *c)
 {
     if (!c) return;
-    if (c->registered) (void)hipHostUnregister(c->h_shm);
-    if (c->h_shm) munmap(c->h_shm, c->shm_bytes);
-    if (c->fd >= 0) close(c->fd);
-    delete c;
+    if (c->refs > 0) { c->closed = true; return; }
+    comm_free(c);
 }
 
 sl_status sl_comm_barrier(sl_comm *c)
@@ -304,6 +643,20 @@ sl_status sl_comm_rank(const sl_comm *c, int *rank, int *world)
     if (!c) return sl_fail(SL_INVALID_INPUT, "null communicator");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
+    return SL_OK;
+}
+
+sl_status sl_comm_info(const sl_comm *c, sl_comm_info_t *info)
+{
+    if (!c || !info) return sl_fail(SL_INVALID_INPUT, "null argument");
+    memset(info, 0, sizeof(*info));
+    info->rank = c->rank; info->world = c->world; info->device = c->device;
+    info->transport = c->transport; info->halo_allreduce = c->halo_allreduce ? 1 : 0;
+    // ranks that have joined = slots of the rendezvous barrier that were ever written
+    int joined = 0;
+    for (int p = 0; p < c->world; ++p) if (ld_acq(&c->h_shm->arrive[p]) >= 1) ++joined;
+    info->ranks_joined = joined;
+    info->failed = sl_comm_failed(c) ? 1 : 0;
     return SL_OK;
 }
 
@@ -337,42 +690,84 @@ sl_status sl_comm_allgather_u64(sl_comm *c, uint64_t mine, uint64_t *all)
 // ---- the partition of one solve -------------------------------------------------------------------------------------------------
 // bounds from the ranks' row counts (consecutive ranges in rank order); need = for every peer the part of ITS rows this rank's
 // columns can reach: [lo - w, hi + w) with w = the measured bandwidth of the local rows (sl_matrix::bandwidth), everything for
-// matrices without a usable bandwidth.
+// matrices without a usable bandwidth; give = the same question asked by every peer about this rank's rows.
 sl_status sl_dist_create(sl_comm *c, const sl_matrix *local, sl_dist **out)
 {
     *out = nullptr;
     sl_dist *d = new sl_dist();
     d->c = c;
-    std::vector<uint64_t> rows((size_t)c->world), offs((size_t)c->world);
+    ++c->refs;                                                        // from here on every exit with an error goes through sl_dist_destroy
+    const int W = c->world;
+    std::vector<uint64_t> rows((size_t)W), offs((size_t)W);
     sl_status st = sl_comm_allgather_blob(c, &local->n_rows, sizeof(uint64_t), rows.data());
     if (st == SL_OK) st = sl_comm_allgather_blob(c, &local->row_offset, sizeof(uint64_t), offs.data());
-    if (st != SL_OK) { delete d; return st; }
-    d->bounds.assign((size_t)c->world + 1, 0);
-    for (int p = 0; p < c->world; ++p) {
-        if (offs[p] != d->bounds[p]) { delete d; return sl_fail(SL_DIMENSION_MISMATCH, "rank %d's rows start at %llu, the ranks before it hold %llu rows", p,
-                                                                 (unsigned long long)offs[p], (unsigned long long)d->bounds[p]); }
+    if (st != SL_OK) { sl_dist_destroy(d); return st; }
+    // the checks below see the same numbers on every rank: they fail everywhere or nowhere
+    d->bounds.assign((size_t)W + 1, 0);
+    for (int p = 0; p < W; ++p) {
+        if (offs[p] != d->bounds[p]) { const uint64_t held = d->bounds[p]; sl_dist_destroy(d); return sl_fail(SL_DIMENSION_MISMATCH, "rank %d's rows start at %llu, the ranks before it hold %llu rows", p,
+                                                                 (unsigned long long)offs[p], (unsigned long long)held); }
         d->bounds[p + 1] = d->bounds[p] + rows[p];
     }
-    d->n_global = d->bounds[c->world];
-    if (d->n_global != local->n_cols) { const uint64_t ng = d->n_global; delete d; return sl_fail(SL_DIMENSION_MISMATCH, "the ranks hold %llu rows in total, the matrix has %llu columns",
-                                                                       (unsigned long long)ng, (unsigned long long)local->n_cols); }
+    d->n_global = d->bounds[W];
+    {   // n_cols is a local number: agree
+        sl_status mine = SL_OK;
+        if (d->n_global != local->n_cols) mine = sl_fail(SL_DIMENSION_MISMATCH, "the ranks hold %llu rows in total, the matrix has %llu columns",
+                                                          (unsigned long long)d->n_global, (unsigned long long)local->n_cols);
+        if ((st = sl_comm_agree(c, mine)) != SL_OK) { sl_dist_destroy(d); return st; }
+    }
     d->lo = d->bounds[c->rank]; d->hi = d->bounds[c->rank + 1];
     const uint64_t w = (local->bandwidth == ~0ull || local->nnz == 0) ? (local->nnz ? d->n_global : 0) : local->bandwidth;
     d->reach = w;
-    {
-        std::vector<uint64_t> reaches((size_t)c->world);
-        st = sl_comm_allgather_blob(c, &w, sizeof(uint64_t), reaches.data());
-        if (st != SL_OK) { delete d; return st; }
-        d->max_reach = *std::max_element(reaches.begin(), reaches.end());
-    }
-    const uint64_t a = d->lo > w ? d->lo - w : 0, b = std::min<uint64_t>(d->n_global, d->hi + w);
-    for (int p = 0; p < c->world; ++p) {
+    d->reaches.assign((size_t)W, 0);
+    st = sl_comm_allgather_blob(c, &w, sizeof(uint64_t), d->reaches.data());
+    if (st != SL_OK) { sl_dist_destroy(d); return st; }
+    d->max_reach = *std::max_element(d->reaches.begin(), d->reaches.end());
+    auto window = [&](int r, uint64_t *a, uint64_t *b) {               // the columns rank r's rows reach
+        const uint64_t wr = d->reaches[(size_t)r], lo = d->bounds[r], hi = d->bounds[r + 1];
+        *a = lo > wr ? lo - wr : 0;
+        *b = std::min<uint64_t>(d->n_global, hi > UINT64_MAX - wr ? UINT64_MAX : hi + wr);
+    };
+    uint64_t a, b;
+    window(c->rank, &a, &b);
+    for (int p = 0; p < W; ++p) {
         if (p == c->rank) continue;
         const uint64_t plo = std::max(a, d->bounds[p]), phi = std::min(b, d->bounds[p + 1]);
         if (phi > plo) { d->need.push_back({p, plo, phi}); d->pull_bytes += (phi - plo) * 8; }
+        uint64_t pa, pb;
+        window(p, &pa, &pb);
+        const uint64_t glo = std::max(pa, d->lo), ghi = std::min(pb, d->hi);
+        if (ghi > glo && d->bounds[p + 1] > d->bounds[p] && d->reaches[(size_t)p] > 0) d->give.push_back({p, glo, ghi});
     }
-    sl_log(1, "partition: rank %d holds rows [%llu, %llu) of %llu, reach %llu columns, pulls %.1f KB from %zu peers per exchange", c->rank,
-           (unsigned long long)d->lo, (unsigned long long)d->hi, (unsigned long long)d->n_global, (unsigned long long)w, (double)d->pull_bytes / 1e3, d->need.size());
+    // all-to-all: every rank's window covers everything (uniform columns); equal ranges allow the in-place all-gather
+    d->all_to_all = W > 1;
+    d->equal_ranges = true;
+    for (int r = 0; r < W; ++r) {
+        uint64_t ra, rb;
+        window(r, &ra, &rb);
+        if (ra != 0 || rb != d->n_global) d->all_to_all = false;
+        if (rows[r] != rows[0]) d->equal_ranges = false;
+    }
+    // the compact halo buffer of the all-reduce form: every rank's rows within max_reach of either end of its range
+    if (c->transport == SL_TRANSPORT_RCCL && c->halo_allreduce && !d->all_to_all && W > 1) {
+        uint64_t off = 0;
+        for (int p = 0; p < W; ++p) {
+            const uint64_t lo = d->bounds[p], hi = d->bounds[p + 1], M = d->max_reach;
+            sl_dist::strips e{off, lo, std::min(hi, lo + M), 0, 0};
+            e.lo1 = std::max(e.hi0, hi > M ? hi - M : 0); e.hi1 = hi;
+            if (e.lo1 < e.hi0) e.lo1 = e.hi0;
+            if (e.lo1 > e.hi1) e.lo1 = e.hi1;
+            d->exports.push_back(e);
+            off += (e.hi0 - e.lo0) + (e.hi1 - e.lo1);
+        }
+        d->halo_len = off;
+        sl_status mine = SL_OK;
+        if (off && hipMalloc(&d->d_halo, off * sizeof(double)) != hipSuccess) { d->d_halo = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc of the halo buffer failed"); }
+        if ((st = sl_comm_agree(c, mine)) != SL_OK) { sl_dist_destroy(d); return st; }
+    }
+    sl_log(1, "partition: rank %d holds rows [%llu, %llu) of %llu, reach %llu columns, receives %.1f KB from %zu peers per exchange (%s)", c->rank,
+           (unsigned long long)d->lo, (unsigned long long)d->hi, (unsigned long long)d->n_global, (unsigned long long)w, (double)d->pull_bytes / 1e3, d->need.size(),
+           sl_comm_transport_name(c));
     *out = d;
     return SL_OK;
 }
@@ -384,5 +779,9 @@ void sl_dist_destroy(sl_dist *d)
     for (hipEvent_t e : d->pull_done) (void)hipEventDestroy(e);
     if (d->pull_fork) (void)hipEventDestroy(d->pull_fork);
     for (sl_dist_vector *v : {&d->t[0], &d->t[1], &d->x}) sl_dist_vector_destroy(d->c, v);
+    if (d->d_halo) (void)hipFree(d->d_halo);
+    if (d->d_check) (void)hipFree(d->d_check);
+    sl_comm *c = d->c;
     delete d;
+    sl_comm_release(c);
 }

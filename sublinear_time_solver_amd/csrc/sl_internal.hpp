@@ -338,17 +338,24 @@ sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx,
 #define SL_COMM_MAX_RANKS 16
 #define SL_COMM_RING 32
 #define SL_COMM_BLOB 512
-#define SL_COMM_MAGIC 0x534c434f4d4d3032ull      /* "SLCOMM02" */
+#define SL_COMM_MAGIC 0x534c434f4d4d3033ull      /* "SLCOMM03" */
 // the shared block of a communicator (POSIX shared memory, mapped by every rank, registered with the HIP runtime)
 struct sl_comm_shm {
     volatile uint64_t magic, world, created_unix;                // created_unix: when rank 0 made the block (stale blocks of crashed jobs are not joined)
+    volatile uint64_t generation, confirmed;                     // rank 0's nonce of this job; confirmed = generation once every rank of THIS job has joined
     volatile uint64_t arrive[SL_COMM_MAX_RANKS];                 // host barrier
     volatile uint64_t blob_seq[SL_COMM_MAX_RANKS];               // host exchange of small blobs (IPC handles, row ranges)
     volatile unsigned char blob[SL_COMM_MAX_RANKS][SL_COMM_BLOB];
     uint64_t ready[SL_COMM_MAX_RANKS][16];                       // device side: one 128-byte line per rank, [c] = last published ticket of channel c (0: sums, 1: halo ready)
     double value[SL_COMM_RING][SL_COMM_MAX_RANKS];               // device side: the values published with the tickets (ring)
-    uint64_t error;                                              // a wait timed out (rank + 1)
+    uint64_t error;                                              // a wait timed out / a rank failed locally (rank + 1): no further collective on this communicator
 };
+// Transports of the vectors and sums (SL_COMM_TRANSPORT): IPC = peers' buffers mapped with hipIpc*, pulled with hipMemcpyAsync, sums
+// and handshakes through tickets in the shared block (ranks may share a GPU); RCCL = the form BASELINE's north_star words:
+// ncclAllGather / grouped ncclSend + ncclRecv (or ONE ncclAllReduce over a compact halo buffer, SL_COMM_HALO=allreduce) for the
+// vectors, ncclAllGather of the ranks' partial sums (added in rank order by a one-wave kernel) for the norms.  The shared block
+// stays the rendezvous (it carries the ncclUniqueId) and the host barrier in both.
+enum { SL_TRANSPORT_IPC = 0, SL_TRANSPORT_RCCL = 1 };
 struct sl_comm {
     int rank = 0, world = 1, device = 0, fd = -1;
     std::string path;
@@ -356,6 +363,13 @@ struct sl_comm {
     size_t shm_bytes = 0;
     bool registered = false;
     uint64_t barrier_count = 0, blob_count = 0, ticket[2] = {0, 0};   // advanced in the same order on every rank; ticket[channel]
+    int transport = SL_TRANSPORT_IPC;
+    bool halo_allreduce = false;                                  // RCCL: halo strips as one all-reduce over a compact buffer instead of sends / receives
+    void *nccl = nullptr;                                         // ncclComm_t
+    double *d_sums = nullptr;                                     // RCCL: [SL_COMM_RING][world] all-gathered partial sums
+    uint64_t sums_seq = 0;
+    int refs = 0;                                                 // partitioned states alive on this communicator
+    bool closed = false;                                          // sl_comm_destroy was called while states were alive: the last state frees it
 };
 struct sl_dist_vector { uint64_t n = 0; double *mine = nullptr; std::vector<double *> peer; };
 struct sl_dist {
@@ -364,6 +378,8 @@ struct sl_dist {
     std::vector<uint64_t> bounds;                                // world + 1
     struct piece { int rank; uint64_t lo, hi; };
     std::vector<piece> need;                                     // what this rank pulls per exchange: global index ranges of its peers' rows
+    std::vector<piece> give;                                     // what its peers pull from it: ranges of ITS rows (rank = the peer) — the send list of the RCCL transport
+    std::vector<uint64_t> reaches;                               // every rank's reach
     uint64_t reach = 0, max_reach = 0;                           // columns this rank's rows reach beyond its range; the largest over all ranks
     sl_dist_vector t[2], x;                                      // gathered term vectors (ping-pong) and gathered solution
     // large exchanges (uniform columns: every peer's whole range): one copy stream per peer, so that the pulls travel over their
@@ -371,6 +387,14 @@ struct sl_dist {
     std::vector<hipStream_t> pull_streams;
     std::vector<hipEvent_t> pull_done;
     hipEvent_t pull_fork = nullptr;
+    // RCCL, all-reduce form of the halo: the strips every rank exports (its rows within max_reach of either end of its range), all
+    // ranks' strips one after the other in one compact buffer; exp_off[p] = where rank p's strips start, exp_lo/exp_hi the two strips
+    double *d_halo = nullptr;
+    uint64_t halo_len = 0;
+    struct strips { uint64_t off, lo0, hi0, lo1, hi1; };         // rows [lo0, hi0) at off, rows [lo1, hi1) at off + (hi0 - lo0)
+    std::vector<strips> exports;
+    bool equal_ranges = false, all_to_all = false;               // every rank needs every peer's whole range (uniform columns): ncclAllGather when the ranges are equal
+    uint64_t *d_check = nullptr;                                 // sl_dist_verify: checksums of pieces
 };
 sl_status sl_comm_host_barrier(sl_comm *c);
 sl_status sl_comm_allgather_blob(sl_comm *c, const void *mine, size_t bytes, void *all);
@@ -382,3 +406,10 @@ void sl_dist_destroy(sl_dist *d);
 sl_status sl_dist_vector_create(sl_comm *c, uint64_t n_global, sl_dist_vector *v);
 void sl_dist_vector_destroy(sl_comm *c, sl_dist_vector *v);
 sl_status sl_dist_pull(sl_dist *d, sl_dist_vector *v, hipStream_t s);
+// collective: every piece this rank holds of its peers' rows of `v` against the owner's own copy (wrapping sums of the bit patterns);
+// *n_bad = pieces that differ on THIS rank.  The stream must be idle on every rank (the caller synchronises).
+sl_status sl_dist_verify(sl_dist *d, sl_dist_vector *v, uint64_t *n_bad);
+sl_status sl_comm_agree(sl_comm *c, sl_status mine);              // collective: the first failing rank's status on every rank
+void sl_comm_poison(sl_comm *c);                                 // a local failure between collectives: the peers stop waiting for this rank
+void sl_comm_release(sl_comm *c);                                // a state lets go of its communicator
+const char *sl_comm_transport_name(const sl_comm *c);

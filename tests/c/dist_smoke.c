@@ -107,7 +107,11 @@ static int rank_main(int rank, int world, uint64_t n, uint64_t w, int uneven, co
     fclose(f);
     {   /* a few measured steps through the same state (bench.py's loop) */
         double nrm = -1.0; float ms = 0.f;
+        uint64_t bad = 99; sl_comm_info_t ci2;
         if (sl_neumann_state_reset(st) != SL_OK || sl_neumann_state_run_steps(st, 5, &nrm, &ms) != SL_OK || !(nrm >= 0.0)) DIE(31, "run_steps");
+        /* what this rank holds of its peers' rows of the current term = what the owners wrote (checksums, collective) */
+        if (sl_neumann_state_verify_exchange(st, &bad) != SL_OK || bad != 0) DIE(33, "rank %d: verify_exchange, %llu pieces differ", rank, (unsigned long long)bad);
+        if (sl_comm_info(c, &ci2) != SL_OK || ci2.world != world || ci2.rank != rank || ci2.ranks_joined != world || ci2.failed) DIE(34, "comm_info");
     }
     if (sl_comm_barrier(c) != SL_OK) DIE(32, "barrier");
     sl_neumann_state_destroy(st); sl_matrix_destroy(m); sl_comm_destroy(c);

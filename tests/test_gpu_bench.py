@@ -68,6 +68,42 @@ def test_bench_two_ranks_reproduce_the_single_rank_iteration(gpu, w, extra, exch
     assert abs(b["value"] - 300000 * 16 * 7 / (b["ms_per_step"] * 7e-3)) <= 1e-6 * b["value"]     # whole-job units / max-over-ranks time
 
 
+def test_bench_starts_its_own_ranks(gpu):
+    """exactly what the driver runs for N > 1 — `python bench.py --gpus 2 ...`, no launcher around it: the parent starts one process
+    per rank (sharing the box's GPU here), the ranks meet in sl_comm, the exchange is verified against the owners' copies, rank 0's
+    line comes out of the parent; and the same iteration as one rank owning all rows"""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rows", "300000", "--steps", "5"], cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    a = json.loads(lines[0])
+    cfg = a["config"]
+    assert a["n_gpus"] == 2 and a["steps"] == 5 and a["warmup"] == 5 and cfg["n_global"] == 600000 and a["scaling"] == "weak"
+    assert cfg["n_ranks_joined"] == 2 and len(cfg["devices"]) == 2 and cfg["transport"] == "ipc" and cfg["exchange_verified"] is True
+    assert cfg["launcher"]["self_launched_ranks"] == 2 and cfg["launcher"]["attempts"][-1]["ok"]
+    assert a["halo_variant"]["exchange_verified"] is True and a["halo_variant"]["value"] > 0
+    assert abs(a["value"] - 600000 * 16 * 5 / (a["ms_per_step"] * 5e-3)) <= 1e-6 * a["value"]
+    one = subprocess.run([sys.executable, "bench.py", "--rows", "600000", "--steps", "5", "--no-cpu-baseline", "--no-sweep"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    b = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert b["n_gpus"] == 1 and b["config"]["n_ranks_joined"] == 1 and b["config"]["transport"] == "ipc"      # N = 1 runs the same host path
+    na, nb = cfg["last_term_norm"], b["config"]["last_term_norm"]
+    assert na > 0 and abs(na - nb) <= 1e-12 * na
+
+
+def test_bench_launcher_falls_back_to_the_next_transport(gpu):
+    """a rank that dies before the rendezvous: the attempt ends (bounded waits, then the parent's kill), the next one runs, the
+    line records both"""
+    import os
+    env = dict(os.environ, SL_BENCH_TRANSPORTS="ipc,ipc", SL_BENCH_FAIL_ATTEMPT="0", SL_COMM_TIMEOUT_MS="4000")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-sweep"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    a = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    att = a["config"]["launcher"]["attempts"]
+    assert [x["ok"] for x in att] == [False, True] and a["config"]["exchange_verified"] is True
+
+
 def test_partitioned_solve_script_two_ranks_equals_one(gpu):
     """tools/solve_partitioned.py (BASELINE config 5 as a full solve): two ranks sharing the GPU run the same iterations to the
     same residual and solution sums as one rank owning all rows"""

@@ -48,6 +48,27 @@ def test_boundary_first_step_gives_the_same_bits(gpu, dist_exe, world, n, w, ove
     assert ("runs its edge blocks first" in r.stderr) == expect, r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("halo", ["", "allreduce"])
+def test_rccl_transport_of_the_library_at_world_one(gpu, dist_exe, halo):
+    """SL_COMM_TRANSPORT=rccl: librccl resolved at run time, ncclCommInitRank with the id passed through the shared block, the
+    partial sums through ncclAllGather + the rank-order sum kernel — everything of the transport that one GPU can run (RCCL refuses
+    two ranks on one device; the first multi-GPU box runs tools/ab_transport.sh).  Same bits as the one-GPU solve."""
+    env = dict(os.environ, SL_COMM_TIMEOUT_MS="30000", SL_COMM_TRANSPORT="rccl", SL_LOG="1")
+    if halo:
+        env["SL_COMM_HALO"] = halo
+    r = subprocess.run([str(dist_exe), "1", "60000", "400"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "dist_smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "transport rccl" in r.stderr, r.stderr[-2000:]
+
+
+def test_two_ranks_on_one_device_are_refused_by_the_rccl_transport_collectively(gpu, dist_exe):
+    """RCCL needs one rank per GPU: on the one-GPU box ncclCommInitRank fails — on every rank, with an error, within the time limit
+    (the agreement after the init), never with a hang or a half-built communicator"""
+    env = dict(os.environ, SL_COMM_TIMEOUT_MS="20000", SL_COMM_TRANSPORT="rccl")
+    r = subprocess.run([str(dist_exe), "2", "20000", "300"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0 and "dist_smoke ok" not in r.stdout, r.stdout[-2000:]
+
+
 def test_a_rank_that_never_arrives_becomes_an_error_not_a_hang(gpu):
     """world = 2 with only rank 0 present: the rendezvous wait is bounded (SL_COMM_TIMEOUT_MS) and comes back as DeviceError"""
     import sys
