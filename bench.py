@@ -35,7 +35,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 L2_REQUEST_RATE = 2.7e11       # L2 requests/s the eight XCDs serve together: 34.5 TB/s / 128 B, = the 265-280 G gathers/s tools/gather_bench.hip measures on L2-resident tables
 
 
-LAYOUTS = {0: "row slices", 1: "column panels, dynamic tiles (gathers from L2)", 2: "column panels, paced persistent blocks (gathers from L2)",
+LAYOUTS = {4: "order-free column stream: a CU's entries sorted by column, sums by LDS atomics (SL_ORDER_ANY; gathers from L2)",
+           0: "row slices", 1: "column panels, dynamic tiles (gathers from L2)", 2: "column panels, paced persistent blocks (gathers from L2)",
            3: "narrow column panels over block-local rows, paced persistent blocks (wide band: gathers from L1)"}
 
 
@@ -143,7 +144,8 @@ def _abi_measure(args, lib, L, torch, dev, comm, world, rank, w, verify=True):
     bb = torch.empty(n_local, dtype=torch.float64, device=dev)
     L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), bb.data_ptr()))
     h = C.c_void_p()
-    L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, lo, 0, C.byref(h)))
+    L.check(lib.sl_matrix_create_csr(n_local, n_global, n_local * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, lo,
+                                     L.SL_MATRIX_ORDER_ANY if args.order == L.SL_ORDER_ANY else 0, C.byref(h)))
     del rp, ci, va
     torch.cuda.empty_cache()
     info = L.MatrixInfo()
@@ -245,7 +247,7 @@ def main_abi(args, world, rank, local_rank, attempt=0):
                                    + ("1xMI355X HBM roofline run (BASELINE configs[2])" if world == 1 else
                                       f"{world}xMI355X row-partitioned (BASELINE configs[4] per-GPU shape)"),
                        "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w_head,
-                       "order": "csr_sequential" if args.order == 0 else "simd4",
+                       "order": {0: "csr_sequential", 1: "simd4", 2: "any (SL_ORDER_ANY)"}[args.order],
                        "exchange": exchange, "transport": transport, "partition": f"rows{world}",
                        "n_ranks_joined": int(ci_.ranks_joined), "devices": devices, "devices_visible": ndev,
                        "exchange_verified": bool(m["verified"] and not m["pieces_bad"]) if world > 1 else None,
@@ -419,7 +421,7 @@ def main():
     ap.add_argument("--k", type=int, default=16, help="entries per row (diagonal included)")
     ap.add_argument("--bandwidth", type=int, default=-1, help="half bandwidth w of the column window; 0 = uniform columns; -1 = default")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--order", type=int, default=0, help="0 = CSR sequential (sparse.rs), 1 = simd4 (simd_ops.rs)")
+    ap.add_argument("--order", type=int, default=0, help="0 = CSR sequential (sparse.rs), 1 = simd4 (simd_ops.rs), 2 = any order (SL_ORDER_ANY: results to rounding)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # child process of the cpu_baseline leg
     ap.add_argument("--no-sweep", action="store_true", help="skip the secondary column-structure measurements")
@@ -631,7 +633,7 @@ def main_torch(args, world, rank, local_rank):
                                    f"{'uniform columns' if w == 0 else f'band half-width {w}'}) fused Neumann/push step, fp64, "
                                    "1xMI355X HBM roofline run (BASELINE configs[2])",
                        "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w,
-                       "order": "csr_sequential" if args.order == 0 else "simd4",
+                       "order": {0: "csr_sequential", 1: "simd4", 2: "any (SL_ORDER_ANY)"}[args.order],
                        "transport": "torch.distributed (" + backend + ")", "exchange": (exchange.name + ("+overlap" if overlap else "") + ("+loopback" if loopback else "")) if (world > 1 or overlap) else "none", "partition": f"rows{world}",
                        "norm_allreduce_every": reduce_every if (world > 1 or loopback) else None,
                        "rows_iter_per_s": value / k, "last_term_norm": term_norm},

@@ -54,7 +54,13 @@ typedef enum { SL_MEM_HOST = 0, SL_MEM_DEVICE = 1 } sl_mem;
 /* summation order of one row's dot product */
 typedef enum {
     SL_ORDER_CSR_SEQUENTIAL = 0, /* CSRStorage::multiply_vector, matrix/sparse.rs:187-203 */
-    SL_ORDER_SIMD4 = 1           /* simd_ops::matrix_vector_multiply_simd, simd_ops.rs:20-88 */
+    SL_ORDER_SIMD4 = 1,          /* simd_ops::matrix_vector_multiply_simd, simd_ops.rs:20-88 */
+    /* Any order (opt-in): the caller accepts row sums added in whatever order the device finds fastest — results equal the
+     * reference's to rounding (<= 1e-10 relative on x, BASELINE north_star's tolerance) instead of bit for bit, and differ by rounding
+     * from run to run.  Takes the order-free column stream of a matrix created with SL_MATRIX_ORDER_ANY (uniformly random columns:
+     * accumulation by LDS atomics, a CU's entries sorted by column); on any other matrix it runs the CSR order.  Neumann / SpMV /
+     * residual only: the thresholded push (frontier lists bit-exact by contract) always runs an exact order. */
+    SL_ORDER_ANY = 2
 } sl_order;
 
 typedef enum {
@@ -76,6 +82,8 @@ typedef struct sl_matrix sl_matrix; /* opaque, device resident */
 #define SL_MATRIX_KEEP_CSR 2u       /* keep the raw CSR arrays on the device next to the slice layout */
 #define SL_MATRIX_COLUMN_PANELS 4u  /* build the column-panel layout whatever the size (by default: only where it pays) */
 #define SL_MATRIX_NO_COLUMN_PANELS 8u /* never build it (saves 14 B per entry of HBM) */
+#define SL_MATRIX_ORDER_ANY 16u     /* where column panels pay, build the ORDER-FREE column stream (12 B per entry) instead of the ordered
+                                       one: what SL_ORDER_ANY solves run on; exact orders on such a matrix take the row-slice kernels */
 
 /* ---- library ------------------------------------------------------------------- */
 int sl_abi_version(void);

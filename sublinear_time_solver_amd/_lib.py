@@ -19,10 +19,10 @@ STATUS_NAMES = {
     8: "IndexOutOfBounds", 9: "InvalidSparseMatrix", 10: "AlgorithmError", 11: "DeviceError",
 }
 SL_MEM_HOST, SL_MEM_DEVICE = 0, 1
-SL_ORDER_CSR_SEQUENTIAL, SL_ORDER_SIMD4 = 0, 1
+SL_ORDER_CSR_SEQUENTIAL, SL_ORDER_SIMD4, SL_ORDER_ANY = 0, 1, 2
 SL_START_ZERO, SL_START_REFERENCE_DEFAULT, SL_START_INITIAL_GUESS = 0, 1, 2
 SL_RESIDUAL_TRUE, SL_RESIDUAL_REFERENCE_SCALED = 0, 1
-SL_MATRIX_WITH_TRANSPOSE, SL_MATRIX_KEEP_CSR, SL_MATRIX_COLUMN_PANELS, SL_MATRIX_NO_COLUMN_PANELS = 1, 2, 4, 8
+SL_MATRIX_WITH_TRANSPOSE, SL_MATRIX_KEEP_CSR, SL_MATRIX_COLUMN_PANELS, SL_MATRIX_NO_COLUMN_PANELS, SL_MATRIX_ORDER_ANY = 1, 2, 4, 8, 16
 
 u64, u32, i32, f64 = C.c_uint64, C.c_uint32, C.c_int32, C.c_double
 vp = C.c_void_p

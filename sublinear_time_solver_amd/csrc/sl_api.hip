@@ -217,6 +217,8 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
     a.pw_idx = m->d_pw_idx; a.pw_val = m->d_pw_val; a.pw_tile_ptr = m->d_pw_tile_ptr;
     a.pw_tiles = (uint32_t)m->n_pw_tiles; a.pw_rpw = m->pw_rpw; a.pw_blocks = m->pw_blocks; a.pw_slack = m->pw_slack;
     a.pw_deal = m->pw_deal; a.pw_pbits = m->pw_pbits;
+    a.pwr_idx = m->d_pwr_idx; a.pwr_val = m->d_pwr_val; a.pwr_base = m->d_pwr_base; a.pwr_tile_ptr = m->d_pwr_tile_ptr; a.pwr_diag = m->d_pwr_diag;
+    a.pwr_tiles = (uint32_t)m->n_pwr_tiles; a.pwr_rpb = m->pwr_rpb; a.pwr_blocks = m->pwr_blocks;
     return a;
 }
 
@@ -277,6 +279,7 @@ void sl_matrix_destroy(sl_matrix *m)
     hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval); hipFree(m->d_tent); hipFree(m->d_long_rows);
     hipFree(m->d_pan_tile_ptr); hipFree(m->d_pan_row); hipFree(m->d_pan_col); hipFree(m->d_pan_val);
     hipFree(m->d_pw_idx); hipFree(m->d_pw_val); hipFree(m->d_pw_tile_ptr);
+    hipFree(m->d_pwr_idx); hipFree(m->d_pwr_val); hipFree(m->d_pwr_base); hipFree(m->d_pwr_tile_ptr); hipFree(m->d_pwr_diag);
     delete m;
 }
 
@@ -378,7 +381,7 @@ sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info)
     info->max_row_nnz = m->max_row_nnz; info->min_row_nnz = m->min_row_nnz; info->uniform_width = m->uniform_width;
     info->has_transpose = m->d_tptr != nullptr;
     info->long_row_threshold = m->long_row;
-    info->column_panels = m->d_pw_idx ? (m->pw_band ? 3u : 2u) : (m->d_pan_tile_ptr ? 1u : 0u);      // 2 = the paced layout, 3 = its wide-band form
+    info->column_panels = m->d_pwr_idx ? 4u : m->d_pw_idx ? (m->pw_band ? 3u : 2u) : (m->d_pan_tile_ptr ? 1u : 0u);      // 2 = the paced layout, 3 = its wide-band form, 4 = the order-free column stream
     info->reserved = 0;
     info->n_long_rows = (uint32_t)m->n_long;
     return SL_OK;

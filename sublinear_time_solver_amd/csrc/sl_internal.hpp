@@ -86,6 +86,20 @@ struct sl_matrix {
     uint32_t pw_deal = 0, pw_pbits = 16;
     bool pw_band = false;               // the wide-band form (block-local rows, narrow panels)
     uint32_t pw_slack = 4;              // panels a wave may gather ahead of the slowest wave of its block: about two chunks of its stream
+    // ORDER-FREE column stream (SL_MATRIX_ORDER_ANY / SL_ORDER_ANY, round 3): ONE persistent 16-wave block per CU owns a BLOCK tile of
+    // pwr_rpb rows (running sums in LDS, the CU's whole LDS; groups of 16 rows dealt round robin among the block tiles), and the
+    // off-diagonal entries of those rows form ONE stream sorted by COLUMN, cut into chunks of 64 entries that the block's 16 waves
+    // take in turn: the 64 gathers of a wave-instruction walk ascending lines a few hundred bytes apart, all CUs sweep the vector at
+    // the same pace (equal work), and the sums are added by LDS atomics (ds_add_f64) in whatever order they arrive.  12 bytes per entry:
+    //     pwr_idx u32 = slot in the block tile << 17 | column - pwr_base[chunk]  (chunks are cut early where the offset would not fit)
+    //     pwr_val f64              pwr_base[chunk] u32 = the chunk's first column
+    // chunk layout [chunk][lane] for both arrays.  The diagonal is not in the stream: pwr_diag[row] (the sum of
+    // the row's entries at its own column) enters in the epilogue, where the row's own vector entry is loaded anyway.
+    uint32_t *d_pwr_idx = nullptr, *d_pwr_base = nullptr, *d_pwr_tile_ptr = nullptr;
+    double *d_pwr_val = nullptr, *d_pwr_diag = nullptr;
+    uint64_t n_pwr_tiles = 0, pwr_chunks = 0;
+    uint32_t pwr_rpb = 0, pwr_blocks = 0;
+
     uint64_t device_bytes = 0;
 };
 #ifndef SL_PANEL_TILE
@@ -108,6 +122,13 @@ struct sl_matrix {
 #ifndef SL_PW_ROW_BITS
 #define SL_PW_ROW_BITS 11            // bits of the row slot in an entry's index word (slots <= SL_PW_MAX_ROWS); the rest: step bit + column bits
 #endif
+#ifndef SL_PWR_MAX_ROWS
+#define SL_PWR_MAX_ROWS 19968u       // rows per BLOCK tile of the order-free stream (1248 groups): 159 744 B of the 160 KiB LDS
+#endif
+#define SL_PWR_CHUNK 64u             // entries per chunk of the order-free stream = one wave-instruction (small chunks keep the part of
+                                     // the vector a CU's 16 waves gather from at any time to a few hundred KB: 256-entry chunks spanned
+                                     // 2.2 MB per CU at n = 10^7 and the L2 hit rate fell to 72 %)
+#define SL_PWR_OFF_BITS 17           // column offset bits of an entry (relative to its chunk's base); slot bits = 15 (slots < 2^15 > SL_PWR_MAX_ROWS)
 #define SL_PW_ROW_SHIFT (32 - SL_PW_ROW_BITS)
 #define SL_PW_SP_BITS (SL_PW_ROW_SHIFT - 1)   // super-panel: the column bits an entry carries (20)
 #ifndef SL_PANEL_WAVES
@@ -284,6 +305,9 @@ struct sl_row_args {
     uint32_t pw_tiles, pw_rpw, pw_blocks;
     uint32_t pw_deal, pw_pbits; // tiles a run of row groups is dealt among (all tiles, or the 16 of a block); log2 of the panel width
     uint32_t pw_slack;        // panels a wave may run ahead of the slowest wave of its block (set by the launcher; >= 2^20: no pacing)
+    // order-free column stream (null unless the matrix carries one)
+    const uint32_t *pwr_idx, *pwr_base, *pwr_tile_ptr; const double *pwr_val, *pwr_diag;
+    uint32_t pwr_tiles, pwr_rpb, pwr_blocks;
     // vectors
     const double *gather; // gathered vector (n_cols)
     const double *dinv;   // n_rows

@@ -991,6 +991,136 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
     sl_block_partials<EPI, SL_PW_WAVES>(a, red, lane, wave, blockIdx.x, a.part_stride, part0, part1);
 }
 
+
+// ---- order-free column stream: persistent blocks, a CU's entries sorted by column, sums by LDS atomics (SL_ORDER_ANY) --------------
+// Layout: sl_internal.hpp (sl_matrix::d_pwr_*).  ONE 16-wave block per CU; in round r block b owns block tile r * blocks + b: pwr_rpb
+// rows whose running sums fill the CU's LDS, and ONE stream of their off-diagonal entries sorted by column, which the 16 waves take
+// chunk by chunk in turn (wave w: chunks w, w + 16, ...).  What the ordered kernel above pays for the reference's summation order —
+// runs detected per 64 entries, a stream per wave sorted by (panel, row), waves pacing each other — falls away: the caller asked for
+// any order (results to rounding, BASELINE north_star's 1e-10), so a product goes to its row by ds_add_f64 whenever it arrives and the
+// 64 gathers of a wave-instruction walk ascending lines of the vector (a CU-wide sort has ~0.5 entries per 128-byte line at n = 10^7).
+// MEASURED (round 3, profiles/r03_order_any.txt; n = 10^7 x 16, uniform columns): this kernel is NOT faster than the ordered one —
+// 1.00-1.09 ms against 0.95 ms.  The accumulation was never what bounded the step: with the LDS update removed altogether the launch
+// takes the same time (1.04-1.09 ms), with plain read-add-write instead of atomics 0.98-1.08; gathers + stream alone, no sums and no
+// epilogue, take 0.77-1.00 ms.  The sorted gathers do coalesce (L1 -> L2 read requests 1.40 * 10^8 against 1.63 * 10^8), but the L2
+// misses go UP (4.0-4.2 * 10^7 against 2.79 * 10^7, memory-side reads 5.1 against 3.5 GB): every block of an XCD meets a line of the
+// vector within the same few microseconds, and what the panels of the ordered layout buy — an XCD dwelling on 512 KB for the time of a
+// panel, every line touched ~16 times at leisure — is lost.  Pacing the blocks of an XCD against each other through a line of progress
+// words changed nothing about the misses (and cost a factor of five through the polling), 256-entry chunks (1.00 ms) beat 64-entry
+// chunks (1.08 ms) by their cheaper stream loads only, touching the lines ahead with return-less atomics made it 1.35 ms.  Kept as the
+// tested, opt-in implementation of SL_ORDER_ANY (hub rows need no kernel of their own here), not selected by default anywhere.
+// Pipeline per wave: stream loads three chunks ahead, gathers one chunk ahead of the LDS updates, buffers that change roles.
+// VAR (measurement builds only, SL_PWR_VAR): 1 = plain read-add-write instead of the LDS atomic (WRONG sums: timing of the atomics),
+// 2 = no LDS update, 4 = no gathers, 8 = no epilogue traffic.  (Tried and dropped: the XCD's waves touching the vector lines of the chunk
+// positions ahead with return-less atomic-or 0, so that the L2 fetches them without a read slot of an L1 held: 0.99 -> 1.35 ms.)
+template <int EPI, int VAR = 0>
+__global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pwr_kernel(sl_row_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) double pwr_acc[];
+    __shared__ double red[2 * SL_PW_WAVES];
+    if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rpb = a.pwr_rpb, nblocks = gridDim.x, ntiles = a.pwr_tiles;
+    const double *__restrict__ g = a.gather;
+    const uint32_t rounds = (ntiles + nblocks - 1) / nblocks;
+    for (uint32_t r = threadIdx.x; r < rpb; r += SL_PW_WAVES * 64) pwr_acc[r] = 0.0;
+    __syncthreads();
+    double part0 = 0.0, part1 = 0.0;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        const uint32_t tile = round * nblocks + blockIdx.x;
+        if (tile >= ntiles) break;                                  // block-uniform
+        const uint32_t ch0 = a.pwr_tile_ptr[tile], chunks = a.pwr_tile_ptr[tile + 1] - ch0;
+        const uint32_t *__restrict__ idxq = a.pwr_idx + (uint64_t)ch0 * SL_PWR_CHUNK;
+        const double *__restrict__ valq = a.pwr_val + (uint64_t)ch0 * SL_PWR_CHUNK;
+        const uint32_t *__restrict__ baseq = a.pwr_base + ch0;
+        // this wave's chunks: wave, wave + 16, ... ; mine = how many
+        const uint32_t mine = chunks > wave ? (chunks - wave + SL_PW_WAVES - 1) / SL_PW_WAVES : 0u;
+        uint32_t SI[4], SB[4];
+        double SV[4], GG[2];
+        uint32_t vzero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));              // a zero the compiler cannot fold: keeps the base-column load on the vector memory path
+        auto load_stream = [&](uint32_t j, uint32_t &ii, double &vv, uint32_t &bb) {
+            const uint32_t ch = wave + j * SL_PW_WAVES;
+            ii = __builtin_nontemporal_load(idxq + (uint64_t)ch * SL_PWR_CHUNK + lane);
+            vv = __builtin_nontemporal_load(valq + (uint64_t)ch * SL_PWR_CHUNK + lane);
+            bb = __builtin_nontemporal_load(baseq + ch + vzero);     // a VECTOR load of one address (one request): a scalar load would share its counter with the LDS atomics
+        };
+        auto gather = [&](uint32_t ii, double &gg, uint32_t bb) {
+            asm volatile("" : "+v"(ii), "+v"(bb));                   // the address is formed HERE (hoisted to the top of the loop it would wait for the newest stream loads)
+            gg = (VAR & 4) ? 1.0 : g[bb + (ii & ((1u << SL_PWR_OFF_BITS) - 1u))];
+        };
+        auto accumulate = [&](uint32_t ii, double vv, double gg, bool real) {
+            asm volatile("" : "+v"(gg));                             // the product is formed HERE, behind the loads issued above: hoisted over them it would wait for the newest gather
+            const double prod = real ? DMUL(vv, gg) : 0.0;
+            if constexpr (VAR & 2) { if (prod == 123.456) pwr_acc[0] = prod; }
+            else if constexpr (VAR & 1) { double *q = &pwr_acc[ii >> SL_PWR_OFF_BITS]; *q = DADD(*q, prod); }
+            else (void)__hip_atomic_fetch_add(&pwr_acc[ii >> SL_PWR_OFF_BITS], prod, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if (mine) {
+            const uint32_t last = mine - 1u;
+            load_stream(0, SI[0], SV[0], SB[0]);
+            load_stream(min(1u, last), SI[1], SV[1], SB[1]);
+            load_stream(min(2u, last), SI[2], SV[2], SB[2]);
+            asm volatile("" ::: "memory");
+            gather(SI[0], GG[0], SB[0]);
+            asm volatile("" ::: "memory");
+            // Stream loads three chunks ahead, gathers one chunk ahead of the LDS update.  The steps behind the last chunk are fillers:
+            // they repeat the last chunk's loads (the number of loads in flight at every wait is then a compile-time constant) and add
+            // zeros; the loop runs whole quadruples — one back edge, no exit in the middle — so that the buffers change ROLES instead of
+            // being copied (a copy would wait for everything in flight).  The empty asm statements keep the compiler from sinking the
+            // loads of a stage towards their uses: issue order = program order.
+#define SL_PWR_STEP(r, r1, r3, gq, gq1, jj)                                                                          \
+            load_stream(min((jj) + 3u, last), SI[r3], SV[r3], SB[r3]);                                               \
+            asm volatile("" ::: "memory");                                                                           \
+            gather(SI[r1], GG[gq1], SB[r1]);                                                                         \
+            asm volatile("" ::: "memory");                                                                           \
+            accumulate(SI[r], SV[r], GG[gq], (jj) < mine);                                                           \
+            asm volatile("" ::: "memory");
+            for (uint32_t j = 0; j < mine; j += 4u) {
+                SL_PWR_STEP(0, 1, 3, 0, 1, j)
+                SL_PWR_STEP(1, 2, 0, 1, 0, j + 1u)
+                SL_PWR_STEP(2, 3, 1, 0, 1, j + 2u)
+                SL_PWR_STEP(3, 0, 2, 1, 0, j + 3u)
+            }
+#undef SL_PWR_STEP
+        }
+        __syncthreads();                                             // every wave's sums are in
+        // epilogue: four rows per thread at a time, their sixteen loads in flight together (one row at a time, 20 dependent round trips
+        // per thread and round stood beside the stream phase instead of under it: 0.23 ms of the launch at n = 10^7)
+        constexpr uint32_t NT = SL_PW_WAVES * 64;
+        for (uint32_t r0 = threadIdx.x; r0 < rpb; r0 += 4u * NT) {   // slot r = group r / 16 of the block tile, row r % 16 of the group
+            uint64_t ri[4];
+            bool live[4];
+            double own[4], dg[4], e_t[4], e_d[4], e_x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t r = r0 + (uint32_t)q * NT;
+                const uint64_t i = ((uint64_t)(r / SL_PW_GROUP) * ntiles + tile) * SL_PW_GROUP + (r % SL_PW_GROUP);
+                live[q] = r < rpb && i < a.n_rows;
+                ri[q] = live[q] ? i : 0;                             // dead slots load row 0 (no branch around the loads)
+                if constexpr (VAR & 8) continue;
+                own[q] = g[a.row_offset + ri[q]];
+                dg[q] = a.pwr_diag[ri[q]];
+                e_t[q] = 0.0; e_d[q] = 0.0; e_x[q] = 0.0;
+                if constexpr (EPI == SL_EPI_NEUMANN) { e_d[q] = a.dinv[ri[q]]; e_x[q] = a.x[ri[q]]; }
+                else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t[q] = a.aux[ri[q]]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t r = r0 + (uint32_t)q * NT;
+                if (!live[q]) continue;
+                if constexpr (VAR & 8) { part0 += pwr_acc[r]; pwr_acc[r] = 0.0; continue; }
+                const double sum = DADD(pwr_acc[r], DMUL(dg[q], own[q]));
+                pwr_acc[r] = 0.0;                                    // ready for the next round
+                if constexpr (EPI == SL_EPI_NEUMANN) e_t[q] = own[q];
+                sl_row_epilogue<EPI>(a, ri[q], sum, e_t[q], e_d[q], e_x[q], 0.0, part0, part1);
+            }
+        }
+        __syncthreads();
+    }
+    sl_block_partials<EPI, SL_PW_WAVES>(a, red, lane, wave, blockIdx.x, a.part_stride, part0, part1);
+}
+
 // ---- long rows: one wave per row ---------------------------------------------------------------------
 // Rows with more than the matrix's long_row entries (hubs of power-law graphs; 3.5 * 10^5 of them in the transposed PageRank
 // graph at n = 10^7, 27 to 31 000 entries each).  The 64 lanes fetch the raw CSR entries coalesced and form the products in
@@ -1437,6 +1567,36 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
     return SL_OK;
 }
 
+// SL_ORDER_ANY on a matrix that carries the order-free column stream (Neumann / SpMV / residual; whole launches only)
+static bool order_free_launch(const sl_row_args &a, sl_order order, sl_epilogue epi)
+{
+    return order == SL_ORDER_ANY && a.pwr_idx && a.pwr_tiles && epi != SL_EPI_PUSH && !a.blk_cnt;
+}
+
+template <int EPI>
+static sl_status launch_pwr(sl_row_args a, hipStream_t s, uint32_t *nparts)
+{
+    SL_TRY(set_max_lds_once<sl_pwr_kernel<EPI>>((int)((size_t)SL_PWR_MAX_ROWS * sizeof(double))));
+    *nparts = a.pwr_blocks;
+    a.part_stride = *nparts;
+    a.n_long = 0;                                                    // hub rows are in the stream like every other row
+    const uint32_t lds = (uint32_t)((size_t)a.pwr_rpb * sizeof(double));
+#ifdef SL_PWR_VARIANTS
+    static const int var = [] { const char *e = getenv("SL_PWR_VAR"); return e ? atoi(e) : 0; }();
+    if (EPI == SL_EPI_NEUMANN && var) {
+#define SL_PWR_V(v) case v: SL_TRY((set_max_lds_once<sl_pwr_kernel<SL_EPI_NEUMANN, v>>((int)((size_t)SL_PWR_MAX_ROWS * sizeof(double))))); \
+                            hipLaunchKernelGGL((sl_pwr_kernel<SL_EPI_NEUMANN, v>), dim3(a.pwr_blocks), dim3(SL_PW_WAVES * 64), lds, s, a); break;
+        switch (var) { SL_PWR_V(1) SL_PWR_V(2) SL_PWR_V(4) SL_PWR_V(6) SL_PWR_V(10) SL_PWR_V(14) default: return sl_fail(SL_INVALID_INPUT, "SL_PWR_VAR"); }
+#undef SL_PWR_V
+        SL_HIP(hipGetLastError());
+        return SL_OK;
+    }
+#endif
+    hipLaunchKernelGGL((sl_pwr_kernel<EPI>), dim3(a.pwr_blocks), dim3(SL_PW_WAVES * 64), lds, s, a);
+    SL_HIP(hipGetLastError());
+    return SL_OK;
+}
+
 sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, hipStream_t s, uint32_t *n_partials)
 {
     if (n_partials) *n_partials = 0;
@@ -1450,6 +1610,14 @@ sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, 
     const bool simd4 = (order == SL_ORDER_SIMD4);
     uint32_t nparts = 0;
     sl_status st = SL_OK;
+    if (order_free_launch(a, order, epi)) {
+        st = epi == SL_EPI_SPMV ? launch_pwr<SL_EPI_SPMV>(a, s, &nparts) : epi == SL_EPI_NEUMANN ? launch_pwr<SL_EPI_NEUMANN>(a, s, &nparts) : launch_pwr<SL_EPI_RESIDUAL>(a, s, &nparts);
+        if (st != SL_OK) return st;
+        if (n_partials) *n_partials = nparts;
+        sl_row_args b = a;
+        b.n_long = 0;
+        return sl_launch_rows_reduce(b, epi, nparts, s);
+    }
     switch (epi) {
     case SL_EPI_SPMV: st = simd4 ? launch_rows_t<1, SL_EPI_SPMV>(a, s, &nparts) : launch_rows_t<0, SL_EPI_SPMV>(a, s, &nparts); break;
     case SL_EPI_NEUMANN: st = simd4 ? launch_rows_t<1, SL_EPI_NEUMANN>(a, s, &nparts) : launch_rows_t<0, SL_EPI_NEUMANN>(a, s, &nparts); break;
@@ -1464,6 +1632,7 @@ sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, 
 
 sl_status sl_rows_geometry(const sl_row_args &a, sl_order order, sl_epilogue epi, uint32_t *rows_per_block, uint32_t *n_blocks)
 {
+    if (order_free_launch(a, order, epi)) { *rows_per_block = 0; *n_blocks = 0; return SL_OK; }      // persistent blocks: no range launches
     const bool simd4 = (order == SL_ORDER_SIMD4);
     switch (epi) {
     case SL_EPI_SPMV: simd4 ? rows_geom_t<1, SL_EPI_SPMV>(a, rows_per_block, n_blocks) : rows_geom_t<0, SL_EPI_SPMV>(a, rows_per_block, n_blocks); break;

@@ -532,6 +532,152 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     return SL_OK;
 }
 
+
+// ---- order-free column stream (sl_internal.hpp, sl_pwr_kernel; SL_MATRIX_ORDER_ANY) ---------------------------------------------------
+sl_status sl_sort_pairs_u64(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, int end_bit, hipStream_t s);
+
+// a wave per row: key = block tile << 32 | column for the off-diagonal entries, block tile = n_btiles (sorts behind every stream) for
+// the diagonal, whose values are summed into diag[row]; slot = the row's place among its block tile's running sums
+__global__ __launch_bounds__(256) void sl_pwr_keys_kernel(uint64_t n_rows, uint32_t n_btiles, uint64_t row_offset, const uint32_t *row_ptr, const uint32_t *col_idx,
+                                                          const double *values, unsigned long long *key, uint16_t *slot, uint32_t *count, double *diag)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    for (uint64_t i = wave; i < n_rows; i += nwaves) {
+        const uint32_t s = row_ptr[i], e = row_ptr[i + 1];
+        const uint64_t q = i / SL_PW_GROUP;
+        const uint32_t bt = (uint32_t)(q % n_btiles);
+        const uint16_t sl = (uint16_t)((q / n_btiles) * SL_PW_GROUP + i % SL_PW_GROUP);
+        uint32_t off = 0;
+        for (uint32_t k0 = s; k0 < e; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            bool offd = false;
+            if (k < e) {
+                const uint32_t c = col_idx[k];
+                offd = (uint64_t)c != row_offset + i;
+                key[k] = ((unsigned long long)(offd ? bt : n_btiles) << 32) | c;
+                slot[k] = sl;
+                if (!offd) atomicAdd(&diag[i], values[k]);              // one entry per row unless the matrix carries duplicates
+            }
+            off += (uint32_t)__popcll(__ballot(offd));
+        }
+        if (lane == 0 && off) atomicAdd(&count[bt], off);
+    }
+}
+
+// One wave per block tile walks the tile's column-sorted entries 64 at a time and cuts them into chunks of at most 64 entries whose
+// columns lie within 2^SL_PWR_OFF_BITS of the chunk's first.  WRITE = false: nchunks[t].  WRITE = true: the chunks are written,
+// entry l of a chunk in lane l's place, each padded to 64 entries with {slot 0, the base column, 0.0}.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void sl_pwr_fill_kernel(uint64_t n_btiles, const uint32_t *src, const uint32_t *dst_chunks, const uint32_t *perm, const uint16_t *slot,
+                                                          const uint32_t *col_idx, const double *values, uint32_t *nchunks, uint32_t *idx, double *val, uint32_t *base)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= n_btiles) return;
+    const uint32_t s0 = src[t], cnt = src[t + 1] - s0;
+    const uint64_t c0 = WRITE ? dst_chunks[t] : 0;
+    uint32_t chunk = 0, fill = 0, B = 0;
+    auto close_chunk = [&]() {
+        if (WRITE) for (uint32_t p = fill + lane; p < SL_PWR_CHUNK; p += 64u) { idx[(c0 + chunk) * SL_PWR_CHUNK + p] = 0u; val[(c0 + chunk) * SL_PWR_CHUNK + p] = 0.0; }
+        ++chunk; fill = 0;
+    };
+    for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
+        const uint32_t nvalid = cnt - e0 < 64u ? cnt - e0 : 64u;
+        uint32_t k = 0, c = 0xffffffffu;
+        if (lane < nvalid) { k = perm[s0 + e0 + lane]; c = col_idx[k]; }
+        uint32_t cur = 0;
+        while (cur < nvalid) {
+            if (fill == 0) { B = __shfl(c, (int)cur); if (WRITE && lane == 0) base[c0 + chunk] = B; }
+            const bool fits = lane >= cur && lane < nvalid && (c - B) < (1u << SL_PWR_OFF_BITS) && fill + (lane - cur) < SL_PWR_CHUNK;
+            const unsigned long long m = __ballot(fits) >> cur;                    // sorted columns: the lanes that fit are a prefix
+            const uint32_t take = (~m) ? (uint32_t)__builtin_ctzll(~m) : 64u - cur;
+            if (WRITE && fits && lane < cur + take) {
+                const uint64_t pos = (c0 + chunk) * SL_PWR_CHUNK + fill + (lane - cur);
+                idx[pos] = ((uint32_t)slot[k] << SL_PWR_OFF_BITS) | (c - B);
+                val[pos] = values[k];
+            }
+            fill += take; cur += take;
+            if (cur < nvalid || fill == SL_PWR_CHUNK) close_chunk();
+        }
+    }
+    if (fill) close_chunk();
+    if (!WRITE && lane == 0) nchunks[t] = chunk;
+}
+
+// returns SL_OK with m->d_pwr_idx == nullptr when the matrix does not qualify (block tiles of unequal work, columns too sparse for the
+// 17-bit offsets ...): the caller then builds the ordered layouts as usual
+static sl_status sl_build_order_free_stream(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx, const double *d_values, hipStream_t st)
+{
+    const uint64_t n = m->n_rows, nnz = m->nnz;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    SL_HIP(hipGetDevice(&dev));
+    SL_HIP(hipGetDeviceProperties(&prop, dev));
+    uint64_t cus = prop.multiProcessorCount > 0 ? (uint64_t)prop.multiProcessorCount : 256;
+    if (const char *e = getenv("SL_PW_CUS")) { const long v = atol(e); if (v > 0) cus = std::min<uint64_t>(cus, (uint64_t)v); }      // tests: several rounds on small systems
+    const bool force = getenv("SL_PW_FORCE") && getenv("SL_PW_FORCE")[0] == '1';
+    uint32_t max_rows = SL_PWR_MAX_ROWS;
+    if (const char *e = getenv("SL_PWR_ROWS")) { const long v = atol(e); if (v >= 16) max_rows = std::min<uint32_t>(SL_PWR_MAX_ROWS, (uint32_t)v / SL_PW_GROUP * SL_PW_GROUP); }   // tests / A-B
+    const size_t lds_avail = std::max({(size_t)prop.sharedMemPerBlock, (size_t)prop.sharedMemPerBlockOptin, (size_t)prop.maxSharedMemoryPerMultiProcessor});
+    if (n == 0 || nnz == 0 || lds_avail < (size_t)SL_PWR_MAX_ROWS * 8 + 2048 || m->row_offset + n > m->n_cols) return SL_OK;
+    const uint64_t n_groups = (n + SL_PW_GROUP - 1) / SL_PW_GROUP, max_groups = max_rows / SL_PW_GROUP;
+    const uint64_t rounds = (n_groups + cus * max_groups - 1) / (cus * max_groups);
+    const uint64_t n_btiles = std::min<uint64_t>(rounds * cus, n_groups);
+    const uint32_t gpt = (uint32_t)((n_groups + n_btiles - 1) / n_btiles), rpb = gpt * SL_PW_GROUP;
+    if (n_btiles >= 0xffffull) return SL_OK;
+    if (rpb < 1024 && !force) return SL_OK;
+    DevBuf key, key_out, ent_in, perm, slot, cnt, nch, diag;
+    SL_TRY(key.alloc_owned(nnz * 8)); SL_TRY(key_out.alloc_owned(nnz * 8)); SL_TRY(ent_in.alloc_owned(nnz * 4)); SL_TRY(perm.alloc_owned(nnz * 4));
+    SL_TRY(slot.alloc_owned(nnz * 2)); SL_TRY(cnt.alloc_owned((n_btiles + 1) * 4)); SL_TRY(nch.alloc_owned((n_btiles + 1) * 4)); SL_TRY(diag.alloc_owned(n * 8));
+    const uint32_t g = grid_for(nnz, 256) > 8192 ? 8192 : grid_for(nnz, 256);
+    SL_HIP(hipMemsetAsync(cnt.p, 0, (n_btiles + 1) * 4, st));
+    SL_HIP(hipMemsetAsync(diag.p, 0, n * 8, st));
+    hipLaunchKernelGGL(sl_pwr_keys_kernel, dim3(g), dim3(256), 0, st, n, (uint32_t)n_btiles, m->row_offset, d_row_ptr, d_col_idx, d_values,
+                       key.as<unsigned long long>(), slot.as<uint16_t>(), cnt.as<uint32_t>(), diag.as<double>());
+    std::vector<uint32_t> count(n_btiles + 1), src(n_btiles + 1), dst(n_btiles + 1), hch(n_btiles + 1);
+    SL_HIP(hipMemcpyAsync(count.data(), cnt.p, n_btiles * 4, hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    uint64_t total = 0; uint32_t longest = 0;
+    for (uint64_t t = 0; t < n_btiles; ++t) { src[t] = (uint32_t)total; total += count[t]; longest = std::max(longest, count[t]); }
+    src[n_btiles] = (uint32_t)total;
+    // persistent blocks with a fixed deal of block tiles: only for matrices whose tiles carry (nearly) equal work
+    if (total == 0 || (!force && (double)longest * (double)n_btiles > 1.1 * (double)total)) return SL_OK;
+    hipLaunchKernelGGL(sl_iota_kernel, dim3(g), dim3(256), 0, st, nnz, ent_in.as<uint32_t>());
+    int bits = 33;
+    while (bits < 64 && (1ull << (bits - 32)) <= n_btiles) ++bits;                            // tile ids 0 .. n_btiles (the diagonal's)
+    SL_TRY(sl_sort_pairs_u64(key.as<uint64_t>(), key_out.as<uint64_t>(), ent_in.as<uint32_t>(), perm.as<uint32_t>(), nnz, bits, st));   // synchronises
+    key.reset(); key_out.reset(); ent_in.reset();
+    DevBuf dsrc;
+    SL_TRY(dsrc.alloc_owned((n_btiles + 1) * 4));
+    SL_HIP(hipMemcpyAsync(dsrc.p, src.data(), (n_btiles + 1) * 4, hipMemcpyHostToDevice, st));
+    const uint32_t fg = (uint32_t)((n_btiles + 3) / 4);
+    hipLaunchKernelGGL((sl_pwr_fill_kernel<false>), dim3(fg), dim3(256), 0, st, n_btiles, dsrc.as<uint32_t>(), (const uint32_t *)nullptr, perm.as<uint32_t>(), slot.as<uint16_t>(),
+                       d_col_idx, d_values, nch.as<uint32_t>(), (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
+    SL_HIP(hipMemcpyAsync(hch.data(), nch.p, n_btiles * 4, hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    uint64_t chunks = 0;
+    for (uint64_t t = 0; t < n_btiles; ++t) { dst[t] = (uint32_t)chunks; chunks += hch[t]; }
+    dst[n_btiles] = (uint32_t)chunks;
+    // columns too sparse for the offsets (chunks cut early) or streams too short: more than 12 % padding — not a matrix for this layout
+    if (chunks * SL_PWR_CHUNK > 0xfffffff0ull || (!force && (double)chunks * SL_PWR_CHUNK > 1.12 * (double)total + (double)SL_PWR_CHUNK * (double)n_btiles)) return SL_OK;
+    SL_HIP(hipMalloc(&m->d_pwr_tile_ptr, (n_btiles + 1) * 4));
+    SL_HIP(hipMalloc(&m->d_pwr_idx, (chunks ? chunks : 1) * SL_PWR_CHUNK * 4));
+    SL_HIP(hipMalloc(&m->d_pwr_val, (chunks ? chunks : 1) * SL_PWR_CHUNK * 8));
+    SL_HIP(hipMalloc(&m->d_pwr_base, (chunks ? chunks : 1) * 4));
+    SL_HIP(hipMemcpyAsync(m->d_pwr_tile_ptr, dst.data(), (n_btiles + 1) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((sl_pwr_fill_kernel<true>), dim3(fg), dim3(256), 0, st, n_btiles, dsrc.as<uint32_t>(), m->d_pwr_tile_ptr, perm.as<uint32_t>(), slot.as<uint16_t>(),
+                       d_col_idx, d_values, (uint32_t *)nullptr, m->d_pwr_idx, m->d_pwr_val, m->d_pwr_base);
+    SL_HIP(hipGetLastError());
+    SL_HIP(hipStreamSynchronize(st));
+    m->d_pwr_diag = static_cast<double *>(diag.release());
+
+    m->n_pwr_tiles = n_btiles; m->pwr_chunks = chunks; m->pwr_rpb = rpb;
+    m->pwr_blocks = (uint32_t)std::min<uint64_t>(cus, n_btiles);
+    m->device_bytes += chunks * (SL_PWR_CHUNK * 12 + 4) + (n_btiles + 1) * 4 + n * 8;
+    return SL_OK;
+}
+
 sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx,
                                    const double *d_values, bool keep_csr_copy)
 {
@@ -663,6 +809,15 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
                                && m->row_offset + n <= m->n_cols;
         const bool band_pays = n >= 1500000ull                       // n = 2^20 x 16, w = 32 768: 0.090 against 0.077 ms; 1.5 * 10^6: 0.092 / 0.098
                                && 2 * diagonal_entries < slice_entries;
+        // SL_MATRIX_ORDER_ANY: where column panels pay, the order-free column stream takes their place (SL_ORDER_ANY solves run on it; exact
+        // orders on such a matrix take the row-slice kernels).  Hub rows need no separate kernel there: LDS atomics do not care how many
+        // entries of a row arrive at once.
+        if ((m->flags & SL_MATRIX_ORDER_ANY) && !refused && (forced || pays_paced) && nnz && nnz < 0x7fffffffull) {
+            const sl_status ps = sl_build_order_free_stream(m, d_row_ptr, d_col_idx, d_values, st);
+            if (ps != SL_OK) return ps;
+        }
+        if (m->d_pwr_idx) {
+        } else
         if (env_band != 0 && !refused && band_wide && (env_band > 0 || band_pays)) {
             sl_status ps = sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st, env_band > 0 ? (uint32_t)env_band : SL_PW_BAND_AUTO);
             if (ps != SL_OK) return ps;
@@ -726,7 +881,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     sl_log(1, "matrix %llu x %llu, %llu entries (rows %u..%u, %llu long): row slices%s%s, bandwidth %llu, %s%s, %.1f MB on the device",
            (unsigned long long)n, (unsigned long long)m->n_cols, (unsigned long long)nnz, m->min_row_nnz, m->max_row_nnz, (unsigned long long)m->n_long,
            m->uniform_width ? " (uniform width)" : "", m->d_cols16 ? " + 16-bit offsets" : "", (unsigned long long)m->bandwidth,
-           m->d_pw_idx ? "paced column panels" : (m->d_pan_tile_ptr ? "column panels (dynamic tiles)" : "no column panels"),
+           m->d_pwr_idx ? "order-free column stream" : m->d_pw_idx ? "paced column panels" : (m->d_pan_tile_ptr ? "column panels (dynamic tiles)" : "no column panels"),
            m->d_tptr ? ", transpose" : "", (double)m->device_bytes / 1e6);
     return SL_OK;
 }
