@@ -322,6 +322,54 @@ sl_status sl_neumann_state_run_steps(sl_neumann_state *st, uint64_t steps, doubl
  * wrote.  What bench.py asks before it reports a multi-GPU figure.  One GPU: nothing to compare, 0. */
 sl_status sl_neumann_state_verify_exchange(sl_neumann_state *st, uint64_t *pieces_bad);
 
+/* ---- a13, graph side: PushGraph, the PageRank / PPR systems over it, and the ACL push in the spec's own visiting order ----------
+ * sl_push_graph = PushGraph (src/graph/adjacency.rs:199-277): the weighted adjacency in CSR (u32 indices; the entries of a row are
+ * walked in the order given, as forward_neighbors does), its transpose (graph/mod.rs:92-130), degrees = row sums and reverse degrees
+ * = column sums, each added left to right (graph/mod.rs:81-89) — all built and kept on the device.
+ * sl_push_graph_system: I - (1 - alpha) P^T (SL_SYSTEM_FORWARD) or I - (1 - alpha) P (SL_SYSTEM_BACKWARD), P_uv = w_uv / deg_u, a node
+ * without out-weight keeps its mass (P_uu = 1, forward_push.rs:210-215; SL_SYSTEM_DANGLING_IDENTITY: it contributes nothing), assembled on the device and returned as an sl_matrix (row diagonally
+ * dominant in the backward form, column dominant in the forward one): what sl_push_solve / sl_estimate_entry* / sl_query_session_* and
+ * the TS computePageRank path (core/solver.ts:664-722, d = 1 - alpha) run on.
+ * sl_forward_push_acl / _with_target / sl_backward_push_acl: ForwardPushSolver::solve_single_source / solve_multi_source
+ * (forward_push.rs:67-177), solve_with_target (:233-290) and BackwardPushSolver::solve_single_target (backward_push.rs:67-220) with the
+ * WorkQueue's order (graph/mod.rs:132-213: largest priority first; equal priorities: larger node id — the reference leaves it open):
+ * push_count, nodes_visited and every bit of estimate / residual equal the CPU restatement's.  Sequential across pushes by
+ * definition: for parity and small graphs; the throughput path is sl_push_solve on the system matrix with theta_rows. */
+typedef struct sl_push_graph sl_push_graph;
+sl_status sl_push_graph_create(uint64_t num_nodes, const uint32_t *row_ptr, const uint32_t *col_idx, const double *weights, sl_mem where,
+                               sl_push_graph **out);
+void sl_push_graph_destroy(sl_push_graph *g);
+sl_status sl_push_graph_size(const sl_push_graph *g, uint64_t *num_nodes, uint64_t *num_edges);
+sl_status sl_push_graph_degrees(const sl_push_graph *g, double *out_degrees, double *in_degrees, sl_mem where);   /* either may be NULL */
+#define SL_SYSTEM_FORWARD 0u              /* I - (1 - alpha) P^T */
+#define SL_SYSTEM_BACKWARD 1u             /* I - (1 - alpha) P   */
+#define SL_SYSTEM_DANGLING_IDENTITY 2u    /* a node without out-weight contributes nothing (its column / row stays the identity's): TS
+                                             computePageRank's rule (solver.ts:690-700, mass leaks) instead of the push spec's self loop */
+sl_status sl_push_graph_system(const sl_push_graph *g, double alpha, uint32_t system_flags, uint32_t matrix_flags, sl_matrix **out);
+typedef struct sl_acl_options {   /* ForwardPushConfig / BackwardPushConfig, forward_push.rs:24-49 */
+    double alpha;             /* 0.15 */
+    double epsilon;           /* 1e-6 */
+    double queue_threshold;   /* 1e-8 */
+    uint64_t max_pushes;      /* 1 000 000 */
+    int32_t adaptive_threshold; /* 1 */
+    int32_t mem;              /* sl_mem of estimate / residual (sources are always host indices) */
+} sl_acl_options;
+void sl_acl_options_default(sl_acl_options *o);
+typedef struct sl_acl_result {    /* ForwardPushResult scalars, forward_push.rs:10-22 */
+    uint64_t push_count, nodes_visited;
+    double residual_norm, device_time_ms;
+    int32_t stopped_by;       /* 0 nothing ran (source / target out of range), 1 queue empty, 2 max_pushes, 3 target precision reached */
+    int32_t reserved;
+} sl_acl_result;
+/* estimate / residual: num_nodes doubles each; push_log (may be NULL): the pushed nodes in order, up to log_cap */
+sl_status sl_forward_push_acl(const sl_push_graph *g, uint64_t n_sources, const uint64_t *sources, const sl_acl_options *o, double *estimate,
+                              double *residual, uint32_t *push_log, uint64_t log_cap, sl_acl_result *res);
+sl_status sl_backward_push_acl(const sl_push_graph *g, uint64_t n_targets, const uint64_t *targets, const sl_acl_options *o, double *estimate,
+                               double *residual, uint32_t *push_log, uint64_t log_cap, sl_acl_result *res);
+sl_status sl_forward_push_acl_with_target(const sl_push_graph *g, uint64_t source, uint64_t target, double target_precision,
+                                          const sl_acl_options *o, double *estimate, double *residual, uint32_t *push_log, uint64_t log_cap,
+                                          sl_acl_result *res);
+
 /* ---- a14 in the reference's own visiting order: TS solveForwardPush (src/core/solver.ts:437-522) ----
  * Gauss-Southwell: every step pushes the FIRST index of largest |r_i| (r = b - A x, x0 = 0), p = r_i / a_ii, x_i += p, r_i = 0,
  * r_j -= a_ji p over column i; stops when max |r_i| < epsilon; `iterations` = pushes.  Sequential across pushes by definition

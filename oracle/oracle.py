@@ -241,7 +241,9 @@ def push_sync_solve(rp, ci, va, b, theta, max_rounds=100000, order=ORDER_SEQ, x0
 
 
 def acl_push(rp, ci, w, sources, *, alpha=0.15, epsilon=1e-6, max_pushes=1_000_000, queue_threshold=1e-8,
-             adaptive_threshold=True, backward=False):
+             adaptive_threshold=True, backward=False, target=None, target_precision=0.0, log_cap=0):
+    """ACL forward / backward push in the spec's visiting order (forward_push.rs:67-216, backward_push.rs:67-220); target != None:
+    solve_with_target (forward_push.rs:233-290; one source); log_cap > 0: also the sequence of pushed nodes ("push_log")"""
     rp, ci, w = _u32(rp), _u32(ci), _f(w)
     n = rp.size - 1
     src = np.ascontiguousarray(sources, dtype=np.uint64)
@@ -249,12 +251,21 @@ def acl_push(rp, ci, w, sources, *, alpha=0.15, epsilon=1e-6, max_pushes=1_000_0
     res = np.zeros(max(n, 1))
     o = AclOpts(alpha, epsilon, max_pushes, queue_threshold, int(adaptive_threshold), 0)
     out = AclResult()
-    fn = lib().orc_acl_backward_push if backward else lib().orc_acl_forward_push
-    st = fn(u64(n), _p(rp), _p(ci), _p(w), u64(src.size), _p(src), C.byref(o), _p(est), _p(res), C.byref(out))
+    log = np.zeros(max(int(log_cap), 1), dtype=np.uint32)
+    l = lib()
+    if target is not None:
+        st = l.orc_acl_forward_push_with_target(u64(n), _p(rp), _p(ci), _p(w), u64(int(src[0])), u64(int(target)), C.c_double(target_precision),
+                                                C.byref(o), _p(est), _p(res), C.byref(out), _p(log), u64(int(log_cap)))
+    else:
+        st = l.orc_acl_forward_push_logged(u64(n), _p(rp), _p(ci), _p(w), u64(src.size), _p(src), C.byref(o), _p(est), _p(res), C.byref(out),
+                                           C.c_int(1 if backward else 0), _p(log), u64(int(log_cap)))
     if st:
         raise OracleError(st)
-    return {"estimate": est[:n], "residual": res[:n], "push_count": out.push_count,
-            "nodes_visited": out.nodes_visited, "residual_norm": out.residual_norm}
+    r = {"estimate": est[:n], "residual": res[:n], "push_count": out.push_count,
+         "nodes_visited": out.nodes_visited, "residual_norm": out.residual_norm}
+    if log_cap:
+        r["push_log"] = log[: min(int(log_cap), int(out.push_count))].copy()
+    return r
 
 
 def csr_transpose(rp, ci, va, ncols=None):

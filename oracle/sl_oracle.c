@@ -547,13 +547,18 @@ static void row_sums(uint64_t n, const uint32_t *rp, const double *w, double *ou
 }
 
 /* direction 0 = forward (forward_push.rs:67-216), 1 = backward (backward_push.rs:67-220) */
+/* target != NULL: ForwardPushSolver::solve_with_target (forward_push.rs:233-290) — source and target both in range or an empty
+ * result, and the loop ends as soon as estimate[target] > precision and residual[target] < 0.1 precision (checked before every pop).
+ * push_log (may be NULL): the nodes pushed, in order, up to log_cap. */
 static int acl_push(uint64_t n, const uint32_t *rp, const uint32_t *ci, const double *w,
                     uint64_t nsrc, const uint64_t *src, const orc_acl_opts *o,
-                    double *est, double *res, orc_acl_result *out, int backward)
+                    double *est, double *res, orc_acl_result *out, int backward,
+                    const uint64_t *target, double target_precision, uint32_t *push_log, uint64_t log_cap)
 {
     memset(out, 0, sizeof(*out));
     for (uint64_t i = 0; i < n; ++i) { est[i] = 0.0; res[i] = 0.0; }
     if (nsrc == 1 && src[0] >= n) return ORC_OK;                       /* forward_push.rs:75-83 */
+    if (target && *target >= n) return ORC_OK;                         /* :238-246 */
     uint64_t nnz = n ? rp[n] : 0;
     double *outdeg = (double *)malloc((n ? n : 1) * sizeof(double));
     double *indeg = 0;
@@ -579,6 +584,7 @@ static int acl_push(uint64_t n, const uint32_t *rp, const uint32_t *ci, const do
 
     uint64_t pushes = 0, nvis = 0, u;
     while (q.len && pushes < o->max_pushes) {
+        if (target && est[*target] > target_precision && res[*target] < target_precision * 0.1) break;   /* :262-265 */
         if (!wq_pop(&q, &u)) break;
         double du = fmax(qdeg[u], 1.0);
         if (res[u] < o->epsilon * du) continue;                        /* :96-99 */
@@ -604,6 +610,7 @@ static int acl_push(uint64_t n, const uint32_t *rp, const uint32_t *ci, const do
             }
         }
         if (!visited[u]) { visited[u] = 1; ++nvis; }
+        if (push_log && pushes < log_cap) push_log[pushes] = (uint32_t)u;
         ++pushes;
         if (o->adaptive_threshold && pushes % 1000 == 0) wq_adaptive(&q, 10000, 100);
     }
@@ -616,13 +623,25 @@ int orc_acl_forward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *co
                          const double *weights, uint64_t nsrc, const uint64_t *sources,
                          const orc_acl_opts *opts, double *estimate, double *residual, orc_acl_result *res)
 {
-    return acl_push(n, row_ptr, col_idx, weights, nsrc, sources, opts, estimate, residual, res, 0);
+    return acl_push(n, row_ptr, col_idx, weights, nsrc, sources, opts, estimate, residual, res, 0, 0, 0.0, 0, 0);
+}
+int orc_acl_forward_push_logged(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *weights, uint64_t nsrc,
+                                const uint64_t *sources, const orc_acl_opts *opts, double *estimate, double *residual, orc_acl_result *res,
+                                int backward, uint32_t *push_log, uint64_t log_cap)
+{
+    return acl_push(n, row_ptr, col_idx, weights, nsrc, sources, opts, estimate, residual, res, backward, 0, 0.0, push_log, log_cap);
+}
+int orc_acl_forward_push_with_target(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *weights, uint64_t source,
+                                     uint64_t target, double target_precision, const orc_acl_opts *opts, double *estimate, double *residual,
+                                     orc_acl_result *res, uint32_t *push_log, uint64_t log_cap)
+{
+    return acl_push(n, row_ptr, col_idx, weights, 1, &source, opts, estimate, residual, res, 0, &target, target_precision, push_log, log_cap);
 }
 int orc_acl_backward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx,
                           const double *weights, uint64_t ntgt, const uint64_t *targets,
                           const orc_acl_opts *opts, double *estimate, double *residual, orc_acl_result *res)
 {
-    return acl_push(n, row_ptr, col_idx, weights, ntgt, targets, opts, estimate, residual, res, 1);
+    return acl_push(n, row_ptr, col_idx, weights, ntgt, targets, opts, estimate, residual, res, 1, 0, 0.0, 0, 0);
 }
 
 /* ------------------------------------------------------------------ a14 -- */

@@ -161,6 +161,14 @@ int orc_acl_backward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *c
                           const double *weights, uint64_t ntgt, const uint64_t *targets,
                           const orc_acl_opts *opts, double *estimate, double *residual,
                           orc_acl_result *res);
+/* the same with the sequence of pushed nodes logged (backward = 1: the backward push) */
+int orc_acl_forward_push_logged(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *weights, uint64_t nsrc,
+                                const uint64_t *sources, const orc_acl_opts *opts, double *estimate, double *residual, orc_acl_result *res,
+                                int backward, uint32_t *push_log, uint64_t log_cap);
+/* ForwardPushSolver::solve_with_target, forward_push.rs:233-290 */
+int orc_acl_forward_push_with_target(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *weights, uint64_t source,
+                                     uint64_t target, double target_precision, const orc_acl_opts *opts, double *estimate, double *residual,
+                                     orc_acl_result *res, uint32_t *push_log, uint64_t log_cap);
 /* CompressedSparseRow::transpose, graph/mod.rs:92-130 */
 void orc_csr_transpose(uint64_t nrows, uint64_t ncols, const uint32_t *row_ptr, const uint32_t *col_idx,
                        const double *values, uint32_t *t_row_ptr, uint32_t *t_col_idx, double *t_values);

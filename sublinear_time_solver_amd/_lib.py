@@ -22,6 +22,7 @@ SL_MEM_HOST, SL_MEM_DEVICE = 0, 1
 SL_ORDER_CSR_SEQUENTIAL, SL_ORDER_SIMD4, SL_ORDER_ANY = 0, 1, 2
 SL_START_ZERO, SL_START_REFERENCE_DEFAULT, SL_START_INITIAL_GUESS = 0, 1, 2
 SL_RESIDUAL_TRUE, SL_RESIDUAL_REFERENCE_SCALED = 0, 1
+SL_SYSTEM_FORWARD, SL_SYSTEM_BACKWARD, SL_SYSTEM_DANGLING_IDENTITY = 0, 1, 2
 SL_MATRIX_WITH_TRANSPOSE, SL_MATRIX_KEEP_CSR, SL_MATRIX_COLUMN_PANELS, SL_MATRIX_NO_COLUMN_PANELS, SL_MATRIX_ORDER_ANY = 1, 2, 4, 8, 16
 
 u64, u32, i32, f64 = C.c_uint64, C.c_uint32, C.c_int32, C.c_double
@@ -77,6 +78,14 @@ class WalkResult(C.Structure):
 class CommInfo(C.Structure):
     _fields_ = [("rank", i32), ("world", i32), ("device", i32), ("transport", i32), ("halo_allreduce", i32), ("ranks_joined", i32),
                 ("failed", i32), ("reserved", i32)]
+
+
+class AclOptions(C.Structure):
+    _fields_ = [("alpha", f64), ("epsilon", f64), ("queue_threshold", f64), ("max_pushes", u64), ("adaptive_threshold", i32), ("mem", i32)]
+
+
+class AclResult(C.Structure):
+    _fields_ = [("push_count", u64), ("nodes_visited", u64), ("residual_norm", f64), ("device_time_ms", f64), ("stopped_by", i32), ("reserved", i32)]
 
 
 class CgOptions(C.Structure):
@@ -136,6 +145,15 @@ SIGNATURES = {
     "sl_push_options_default": (None, [C.POINTER(PushOptions)]),
     "sl_push_solve": (C.c_int, [vp, vp, C.POINTER(PushOptions), vp, vp, vp, u64, C.POINTER(u64),
                                 C.POINTER(PushResult)]),
+    "sl_push_graph_create": (C.c_int, [u64, vp, vp, vp, C.c_int, C.POINTER(vp)]),
+    "sl_push_graph_destroy": (None, [vp]),
+    "sl_push_graph_size": (C.c_int, [vp, C.POINTER(u64), C.POINTER(u64)]),
+    "sl_push_graph_degrees": (C.c_int, [vp, vp, vp, C.c_int]),
+    "sl_push_graph_system": (C.c_int, [vp, f64, u32, u32, C.POINTER(vp)]),
+    "sl_acl_options_default": (None, [C.POINTER(AclOptions)]),
+    "sl_forward_push_acl": (C.c_int, [vp, u64, vp, C.POINTER(AclOptions), vp, vp, vp, u64, C.POINTER(AclResult)]),
+    "sl_backward_push_acl": (C.c_int, [vp, u64, vp, C.POINTER(AclOptions), vp, vp, vp, u64, C.POINTER(AclResult)]),
+    "sl_forward_push_acl_with_target": (C.c_int, [vp, u64, u64, f64, C.POINTER(AclOptions), vp, vp, vp, u64, C.POINTER(AclResult)]),
     "sl_southwell_options_default": (None, [C.POINTER(SouthwellOptions)]),
     "sl_forward_push_southwell": (C.c_int, [vp, vp, C.POINTER(SouthwellOptions), vp, vp, vp, u64, C.POINTER(SouthwellResult)]),
     "sl_estimate_entry": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),

@@ -25,8 +25,11 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Iterable, Sequence, Tuple
 
+import ctypes as C
+
 import numpy as np
 
+from . import _lib as L
 from .solver import PushSolver, SparseMatrix
 
 
@@ -53,18 +56,28 @@ class PushResult:
 
 
 class PushGraph:
-    """adjacency CSR + degrees (row sums) + reverse degrees (column sums)"""
+    """PushGraph (src/graph/adjacency.rs:199-277) on the device behind sl_push_graph_*: adjacency CSR, its transpose, degrees (row
+    sums) and reverse degrees (column sums) are built by the library; the host keeps the CSR arrays it was given for inspection."""
 
     def __init__(self, row_ptr, col_idx, weights, n: int):
         self.n = int(n)
         self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
         self.col_idx = np.ascontiguousarray(col_idx, dtype=np.uint32)
         self.weights = np.ascontiguousarray(weights, dtype=np.float64)
-        rows = np.repeat(np.arange(self.n), np.diff(self.row_ptr.astype(np.int64)))
-        self.degrees = np.bincount(rows, weights=self.weights, minlength=self.n)                  # graph/mod.rs:81-89
-        self.reverse_degrees = np.bincount(self.col_idx.astype(np.int64), weights=self.weights, minlength=self.n)
-        self._rows = rows
+        self._h = L.vp()
+        L.check(L.load().sl_push_graph_create(self.n, L.ptr(self.row_ptr), L.ptr(self.col_idx), L.ptr(self.weights), L.SL_MEM_HOST, C.byref(self._h)))
+        self.degrees = np.zeros(self.n)                                                           # graph/mod.rs:81-89
+        self.reverse_degrees = np.zeros(self.n)
+        L.check(L.load().sl_push_graph_degrees(self._h, L.ptr(self.degrees), L.ptr(self.reverse_degrees), L.SL_MEM_HOST))
         self._cache = {}
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.load().sl_push_graph_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     @classmethod
     def from_edges(cls, num_nodes: int, edges: Iterable[Tuple[int, int, float]]):
@@ -93,26 +106,42 @@ class PushGraph:
     def in_degree(self, node: int) -> float:
         return float(self.reverse_degrees[node]) if 0 <= node < self.n else 0.0
 
-    def system(self, alpha: float, backward: bool) -> SparseMatrix:
-        """forward: A = I - (1-alpha) P^T ; backward: A = I - (1-alpha) P  (P_uv = w_uv / deg_u; dangling u: P_uu = 1)"""
-        key = (float(alpha), bool(backward))
+    def system(self, alpha: float, backward: bool, flags: int = L.SL_MATRIX_WITH_TRANSPOSE, dangling_identity: bool = False) -> SparseMatrix:
+        """forward: A = I - (1-alpha) P^T ; backward: A = I - (1-alpha) P  (P_uv = w_uv / deg_u; dangling u: P_uu = 1, or — dangling_identity,
+        TS computePageRank's rule — nothing) — assembled on the device by sl_push_graph_system"""
+        key = (float(alpha), bool(backward), int(flags), bool(dangling_identity))
         if key not in self._cache:
-            deg = self.degrees
-            safe = np.where(deg > 0, deg, 1.0)
-            pr, pc = self._rows, self.col_idx.astype(np.int64)
-            pv = self.weights / safe[pr]
-            dang = np.nonzero(deg <= 0)[0]
-            pr = np.concatenate([pr, dang])
-            pc = np.concatenate([pc, dang])
-            pv = np.concatenate([pv, np.ones(dang.size)])
-            if not backward:
-                pr, pc = pc, pr                               # P^T
-            import scipy.sparse as sp
-            A = (sp.identity(self.n, format="csr") - (1.0 - alpha) * sp.csr_matrix((pv, (pr, pc)), shape=(self.n, self.n))).tocsr()
-            A.sum_duplicates()
-            A.sort_indices()
-            self._cache[key] = SparseMatrix.from_csr(A.indptr, A.indices, A.data, self.n, self.n, with_transpose=True)
+            h = L.vp()
+            mode = (L.SL_SYSTEM_BACKWARD if backward else L.SL_SYSTEM_FORWARD) | (L.SL_SYSTEM_DANGLING_IDENTITY if dangling_identity else 0)
+            L.check(L.load().sl_push_graph_system(self._h, float(alpha), mode, int(flags), C.byref(h)))
+            self._cache[key] = SparseMatrix(h, self.n, self.n)
         return self._cache[key]
+
+    # ---- the ACL push in the spec's own visiting order (order-exact parity entries) ----
+    def _acl(self, fn, args, config, log_cap):
+        o = L.AclOptions()
+        L.load().sl_acl_options_default(C.byref(o))
+        o.alpha, o.epsilon, o.queue_threshold, o.max_pushes = config.alpha, config.epsilon, config.queue_threshold, int(config.max_pushes)
+        o.adaptive_threshold, o.mem = (1 if config.adaptive_threshold else 0), L.SL_MEM_HOST
+        est, res = np.zeros(max(self.n, 1)), np.zeros(max(self.n, 1))
+        log = np.zeros(max(int(log_cap), 1), dtype=np.uint32)
+        r = L.AclResult()
+        L.check(fn(self._h, *args, C.byref(o), L.ptr(est), L.ptr(res), L.ptr(log) if log_cap else None, int(log_cap), C.byref(r)))
+        out = PushResult(est[: self.n], res[: self.n], int(r.push_count), int(r.nodes_visited), float(r.residual_norm))
+        out.push_log = log[: min(int(log_cap), int(r.push_count))].copy() if log_cap else None
+        out.stopped_by = int(r.stopped_by)
+        return out
+
+    def acl_forward(self, sources, config, log_cap: int = 0):
+        src = np.ascontiguousarray(list(sources), dtype=np.uint64)
+        return self._acl(L.load().sl_forward_push_acl, (int(src.size), L.ptr(src)), config, log_cap)
+
+    def acl_backward(self, targets, config, log_cap: int = 0):
+        tg = np.ascontiguousarray(list(targets), dtype=np.uint64)
+        return self._acl(L.load().sl_backward_push_acl, (int(tg.size), L.ptr(tg)), config, log_cap)
+
+    def acl_forward_with_target(self, source: int, target: int, target_precision: float, config, log_cap: int = 0):
+        return self._acl(L.load().sl_forward_push_acl_with_target, (int(source), int(target), float(target_precision)), config, log_cap)
 
 
 class _PushBase:
@@ -144,11 +173,24 @@ class _PushBase:
 
 
 class ForwardPushSolver(_PushBase):
-    def solve_single_source(self, source: int) -> PushResult:          # forward_push.rs:67-122
+    """order="synchronous" (default): the data-parallel push on the system matrix (same fixed point, per-row thresholds);
+    order="reference": the spec's own visiting order — WorkQueue pops, push_count / nodes_visited / every bit as the reference's loop
+    (sl_forward_push_acl; sequential across pushes, for parity and small graphs)"""
+
+    def solve_single_source(self, source: int, order: str = "synchronous", log_cap: int = 0) -> PushResult:          # forward_push.rs:67-122
+        if order == "reference":
+            return self.graph.acl_forward([source], self.config, log_cap)
         return self._solve([source])
 
-    def solve_multi_source(self, sources: Sequence[int]) -> PushResult:  # :125-177
+    def solve_multi_source(self, sources: Sequence[int], order: str = "synchronous", log_cap: int = 0) -> PushResult:  # :125-177
+        if order == "reference":
+            return self.graph.acl_forward(list(sources), self.config, log_cap)
         return self._solve(list(sources))
+
+    def solve_with_target(self, source: int, target: int, target_precision: float, log_cap: int = 0) -> PushResult:   # :233-290
+        """early termination once estimate[target] > target_precision and residual[target] < 0.1 target_precision — defined by the
+        visiting order, so it always runs the spec's own"""
+        return self.graph.acl_forward_with_target(source, target, target_precision, self.config, log_cap)
 
     def query_single_entry(self, source: int, target: int, via: str = "local") -> float:   # :224-231
         """pi_source(target).  via="local" (default): ONE entry of the solution of A x = alpha e_source — a local push on A^T from
@@ -169,7 +211,9 @@ class ForwardPushSolver(_PushBase):
 class BackwardPushSolver(_PushBase):
     backward = True
 
-    def solve_single_target(self, target: int) -> PushResult:          # backward_push.rs:67-122
+    def solve_single_target(self, target: int, order: str = "synchronous", log_cap: int = 0) -> PushResult:          # backward_push.rs:67-122
+        if order == "reference":
+            return self.graph.acl_backward([target], self.config, log_cap)
         return self._solve([target])
 
     def solve_multi_target(self, targets: Sequence[int]) -> PushResult:

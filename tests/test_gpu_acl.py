@@ -1,0 +1,189 @@
+"""a13 in the spec's OWN visiting order, and the graph side behind the C ABI (sl_push_graph_*, sl_*_push_acl*):
+ForwardPushSolver::{solve_single_source, solve_multi_source, solve_with_target} (src/solver/forward_push.rs:67-290) and
+BackwardPushSolver::solve_single_target (src/solver/backward_push.rs:67-220) with the WorkQueue's pop order (src/graph/mod.rs:132-213)
+against the CPU restatement (oracle acl_push): the sequence of pushed nodes, push_count, nodes_visited and every bit of estimate /
+residual; PushGraph degrees (adjacency.rs:212-224) bit for bit; the device-assembled systems I - (1 - alpha) P^T / I - (1 - alpha) P
+against a host assembly and against the golden PageRank vectors of the reference's Python power iteration."""
+import numpy as np
+import pytest
+
+from sublinear_time_solver_amd import generators as G
+from sublinear_time_solver_amd.push_graph import BackwardPushSolver, ForwardPushConfig, ForwardPushSolver, PushGraph
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def simple_graph():
+    # create_simple_graph, tests/rust/push_tests.rs:15-22
+    return PushGraph([0, 2, 4, 6, 7], [1, 2, 0, 3, 0, 3, 1], [0.5, 0.5, 0.8, 0.2, 0.6, 0.4, 1.0], 4)
+
+
+def messy_graph(n, seed, unsorted=True):
+    """weighted digraph with dangling nodes, self loops, repeated (u, v) edges and rows in no particular column order"""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, 9, size=n)
+    deg[rng.integers(0, n, size=max(1, n // 50))] = rng.integers(50, 200, size=max(1, n // 50))      # a few hubs
+    deg[rng.integers(0, n, size=max(1, n // 20))] = 0                                               # dangling nodes
+    src = np.repeat(np.arange(n), deg)
+    tgt = np.minimum((rng.random(src.size) ** 2 * n).astype(np.int64), n - 1)
+    w = rng.uniform(0.1, 2.0, size=src.size)
+    if not unsorted:
+        o = np.lexsort((tgt, src))
+        src, tgt, w = src[o], tgt[o], w[o]
+    rp = np.zeros(n + 1, dtype=np.uint32)
+    np.add.at(rp, src + 1, 1)
+    return PushGraph(np.cumsum(rp).astype(np.uint32), tgt.astype(np.uint32), w, n)
+
+
+def same_as_oracle(r, o, what):
+    assert r.push_count == o["push_count"] and r.nodes_visited == o["nodes_visited"], (what, r.push_count, o["push_count"], r.nodes_visited, o["nodes_visited"])
+    if r.push_log is not None:
+        assert (r.push_log == o["push_log"]).all(), f"{what}: the sequence of pushed nodes differs, first at {np.nonzero(r.push_log != o['push_log'])[0][:3]}"
+    assert (bits(r.estimate) == bits(o["estimate"])).all(), f"{what}: estimate bits"
+    assert (bits(r.residual) == bits(o["residual"])).all(), f"{what}: residual bits"
+    assert abs(r.residual_norm - o["residual_norm"]) <= 1e-14 * (1.0 + o["residual_norm"])
+
+
+def test_g5_fixture_in_the_specs_order(gpu):
+    """the 4-node fixture, alpha = 0.15, epsilon = 1e-6 -> 200 pushes, est = [0.431272, 0.276168, 0.183291, 0.109267]"""
+    g = simple_graph()
+    cfg = ForwardPushConfig(alpha=0.15, epsilon=1e-6)
+    r = ForwardPushSolver(g, cfg).solve_single_source(0, order="reference", log_cap=1000)
+    o = O.acl_push(g.row_ptr, g.col_idx, g.weights, [0], alpha=0.15, epsilon=1e-6, log_cap=1000)
+    same_as_oracle(r, o, "G5")
+    assert r.push_count == 200 and r.stopped_by == 1
+    np.testing.assert_allclose(r.estimate, [0.431272, 0.276168, 0.183291, 0.109267], atol=1e-6)
+    assert abs(r.estimate.sum() + 0.15 * r.residual.sum() - 1.0) < 0.01 and (r.estimate >= 0).all() and (r.residual >= 0).all()   # push_tests.rs:107-129
+
+
+@pytest.mark.parametrize("n,seed,eps,unsorted", [(300, 1, 1e-5, True), (2000, 2, 1e-4, True), (2000, 3, 1e-5, False), (64, 4, 1e-7, True)])
+def test_forward_push_order_exact_on_messy_graphs(gpu, n, seed, eps, unsorted):
+    g = messy_graph(n, seed, unsorted)
+    cfg = ForwardPushConfig(alpha=0.2, epsilon=eps, max_pushes=200_000)
+    for sources in ([5], [n - 1], [3, 7, 3, n + 5]):                     # a repeated and an out-of-range source in the multi-source form
+        r = g.acl_forward(sources, cfg, log_cap=200_000)
+        o = O.acl_push(g.row_ptr, g.col_idx, g.weights, sources, alpha=0.2, epsilon=eps, max_pushes=200_000, log_cap=200_000)
+        same_as_oracle(r, o, f"forward {sources}")
+    d = np.nonzero(g.degrees <= 0)[0]
+    if d.size:                                                           # a dangling source: the mass stays on it (forward_push.rs:210-215)
+        r = g.acl_forward([int(d[0])], cfg, log_cap=1000)
+        same_as_oracle(r, O.acl_push(g.row_ptr, g.col_idx, g.weights, [int(d[0])], alpha=0.2, epsilon=eps, max_pushes=200_000, log_cap=1000), "dangling source")
+
+
+def test_backward_push_and_degrees(gpu):
+    g = messy_graph(1500, 7)
+    rows = np.repeat(np.arange(g.n), np.diff(g.row_ptr.astype(np.int64)))
+    # degrees: sequential row sums (graph/mod.rs:81-89); reverse degrees: sources of a node ascending = storage order per target
+    dref = np.zeros(g.n)
+    for i in range(g.n):
+        s = 0.0
+        for k in range(g.row_ptr[i], g.row_ptr[i + 1]):
+            s = s + g.weights[k]
+        dref[i] = s
+    assert (bits(g.degrees) == bits(dref)).all()
+    trp, tci, tw = O.csr_transpose(g.row_ptr, g.col_idx, g.weights, g.n)
+    rref = np.zeros(g.n)
+    for i in range(g.n):
+        s = 0.0
+        for k in range(trp[i], trp[i + 1]):
+            s = s + tw[k]
+        rref[i] = s
+    assert (bits(g.reverse_degrees) == bits(rref)).all()
+    cfg = ForwardPushConfig(alpha=0.15, epsilon=1e-5, max_pushes=100_000)
+    for t in (0, 17, g.n - 1):
+        r = BackwardPushSolver(g, cfg).solve_single_target(t, order="reference", log_cap=100_000)
+        o = O.acl_push(g.row_ptr, g.col_idx, g.weights, [t], alpha=0.15, epsilon=1e-5, max_pushes=100_000, backward=True, log_cap=100_000)
+        same_as_oracle(r, o, f"backward {t}")
+
+
+def test_solve_with_target_and_limits(gpu):
+    g = messy_graph(800, 11)
+    cfg = ForwardPushConfig(alpha=0.15, epsilon=1e-7, max_pushes=50_000)
+    full = g.acl_forward([2], cfg)
+    tgt = int(np.argsort(full.estimate)[-3])
+    prec = float(full.estimate[tgt]) * 0.5
+    r = ForwardPushSolver(g, cfg).solve_with_target(2, tgt, prec, log_cap=50_000)
+    o = O.acl_push(g.row_ptr, g.col_idx, g.weights, [2], alpha=0.15, epsilon=1e-7, max_pushes=50_000, target=tgt, target_precision=prec, log_cap=50_000)
+    same_as_oracle(r, o, "with target")
+    assert r.stopped_by == 3 and r.push_count < full.push_count and r.estimate[tgt] > prec          # forward_push.rs:262-265
+    # source or target out of range: an empty result (:238-246)
+    for s, t in ((9999, 1), (1, 9999)):
+        e = ForwardPushSolver(g, cfg).solve_with_target(s, t, 1e-3)
+        assert e.push_count == 0 and e.nodes_visited == 0 and e.estimate.sum() == 0.0 and e.residual.sum() == 0.0 and e.residual_norm == 0.0
+    # max_pushes cuts the loop (:93), the same partial state as the oracle's
+    cut = ForwardPushConfig(alpha=0.15, epsilon=1e-7, max_pushes=137)
+    same_as_oracle(g.acl_forward([2], cut, log_cap=200), O.acl_push(g.row_ptr, g.col_idx, g.weights, [2], alpha=0.15, epsilon=1e-7, max_pushes=137, log_cap=200), "max_pushes")
+    assert g.acl_forward([2], cut).stopped_by == 2
+
+
+def test_adaptive_queue_threshold(gpu):
+    """more than a thousand pushes with a short queue: WorkQueue::adaptive_threshold lowers the threshold every 1000 pushes
+    (graph/mod.rs:204-212); a large starting threshold makes it bind"""
+    g = messy_graph(400, 5)
+    for adaptive in (True, False):
+        cfg = ForwardPushConfig(alpha=0.1, epsilon=1e-9, max_pushes=30_000, queue_threshold=1e-6, adaptive_threshold=adaptive)
+        r = g.acl_forward([1], cfg, log_cap=30_000)
+        o = O.acl_push(g.row_ptr, g.col_idx, g.weights, [1], alpha=0.1, epsilon=1e-9, max_pushes=30_000, queue_threshold=1e-6, adaptive_threshold=adaptive, log_cap=30_000)
+        same_as_oracle(r, o, f"adaptive={adaptive}")
+        assert r.push_count > 1000
+
+
+def host_system(g, alpha, backward):
+    import scipy.sparse as sp
+    n = g.n
+    rows = np.repeat(np.arange(n), np.diff(g.row_ptr.astype(np.int64)))
+    deg = g.degrees
+    live = deg[rows] > 0
+    pv = np.where(live, g.weights / np.where(deg[rows] > 0, deg[rows], 1.0), 0.0)
+    pr, pc = rows, g.col_idx.astype(np.int64)
+    dang = np.nonzero(deg <= 0)[0]
+    P = sp.csr_matrix((np.concatenate([pv, np.ones(dang.size)]), (np.concatenate([pr, dang]), np.concatenate([pc, dang]))), shape=(n, n))
+    A = sp.identity(n, format="csr") - (1.0 - alpha) * (P if backward else P.T)
+    return A.tocsr()
+
+
+@pytest.mark.parametrize("backward", [False, True])
+def test_system_assembly_on_the_device(gpu, backward):
+    import scipy.sparse as sp
+    for g in (messy_graph(1200, 21), PushGraph(*G.pagerank_graph(5000, 3), 5000), simple_graph()):
+        m = g.system(0.15, backward, flags=0x3)                          # with transpose + raw CSR kept
+        rp, ci, va = m.to_csr()
+        A = sp.csr_matrix((va, ci, rp), shape=(g.n, g.n))
+        assert (np.diff(rp) > 0).all()
+        for i in range(g.n):                                             # sorted columns, exactly one diagonal entry per row
+            c = ci[rp[i]:rp[i + 1]]
+            assert (np.diff(c.astype(np.int64)) >= 0).all() and int((c == i).sum()) == 1
+        H = host_system(g, 0.15, backward)
+        D = (A - H).tocsr()
+        assert D.nnz == 0 or np.max(np.abs(D.data)) <= 4e-16, "device-assembled system differs from the host assembly"
+        # the system does what the push needs of it: x = alpha e_s solved on it is the personalised PageRank of s
+        if not backward and g.n <= 1200:
+            cfg = ForwardPushConfig(alpha=0.15, epsilon=1e-12, max_pushes=10_000)
+            sync = ForwardPushSolver(g, cfg).solve_single_source(1)
+            # (the spec's queue admits residual / degree >= queue_threshold only: with its default 1e-8 the loop ends ~1e-5 short of the fixed point)
+            ref = g.acl_forward([1], ForwardPushConfig(alpha=0.15, epsilon=1e-12, max_pushes=5_000_000, queue_threshold=1e-15))
+            np.testing.assert_allclose(sync.estimate, ref.estimate, atol=1e-8)
+
+
+def test_pagerank_through_the_device_assembled_system(gpu):
+    """G9: the fixed points of the reference's Python power iteration (tests/golden/reference_pagerank.npz) from the system that
+    sl_push_graph_system assembles — TS computePageRank's matrix (core/solver.ts:664-722: dangling columns stay the identity's) in CSR,
+    no host assembly in between"""
+    import pathlib
+    import scipy.sparse as sp
+    import sublinear_time_solver_amd as S
+    z = np.load(pathlib.Path(__file__).resolve().parent / "golden" / "reference_pagerank.npz")
+    for key in (str(c) for c in z["__cases"]):
+        n, d = int(z[f"{key}__n"][0]), float(z[f"{key}__damping"][0])
+        A = sp.csr_matrix((z[f"{key}__vals"], (z[f"{key}__rows"].astype(np.int64), z[f"{key}__cols"].astype(np.int64))), shape=(n, n))
+        A.sort_indices()
+        g = PushGraph(A.indptr.astype(np.uint32), A.indices.astype(np.uint32), A.data, n)
+        m = g.system(1.0 - d, backward=False, dangling_identity=True)
+        out = S.PushSolver(theta=1e-18).solve(m, np.full(n, (1.0 - d) / n))
+        ref = z[f"{key}__pagerank"]
+        assert out["converged"] and np.abs(out["solution"] - ref).max() <= 1e-13, key
