@@ -60,39 +60,66 @@ def algorithmic_bytes(n_rows: int, nnz: int) -> int:
     return 12 * nnz + 4 * (n_rows + 1) + 40 * n_rows
 
 
-def cpu_baseline(n_global: int, k: int, seed: int, w: int, threads_all: int):
-    """The reference's CPU hot loop (oracle restatement of simd_ops.rs SpMV variants inside the Neumann
-    step) on a bounded sample: rows [0, n_s) of the SAME system, gathered vector of full length."""
+def cpu_baseline(n_global: int, k: int, seed: int, w: int, threads_all: int, rows: int = 0):
+    """The reference's CPU hot loop (oracle restatement of simd_ops.rs SpMV variants inside the Neumann step, a8 + a9) on the WHOLE
+    system (rows = 0) or on its first `rows` rows against the full-length vector, with the time split SpMV / vector passes: the
+    reference's vector passes are serial loops (neumann.rs:289-296, 264-266), which is what bounds its all-thread figure.  A third,
+    clearly labelled leg threads those passes too (not the reference).  The input is the same S-DD system, synthesised by the
+    library's generator on the GPU when there is one (1.9 GB down the PCIe) and by generators.sdd_rows otherwise."""
     import numpy as np
     from oracle import oracle as O
     from sublinear_time_solver_amd import generators as G
 
     O.build(fast=True)
-    n_s = min(n_global, 1_000_000)
-    rp, ci, va, b = G.sdd_rows(n_global, k, seed, w, 0, n_s)
+    n_s = n_global if rows <= 0 else min(n_global, rows)
+    rp = ci = va = None
+    try:
+        import torch
+        from sublinear_time_solver_amd import _lib as L
+        if torch.cuda.is_available():
+            lib, dev = L.load(), torch.device("cuda", 0)
+            d_rp = torch.empty(n_s + 1, dtype=torch.int32, device=dev); d_ci = torch.empty(n_s * k, dtype=torch.int32, device=dev)
+            d_va = torch.empty(n_s * k, dtype=torch.float64, device=dev); d_b = torch.empty(n_s, dtype=torch.float64, device=dev)
+            L.check(lib.sl_synth_sdd_device(n_global, k, seed, w, 0, n_s, d_rp.data_ptr(), d_ci.data_ptr(), d_va.data_ptr(), d_b.data_ptr()))
+            rp, ci, va = d_rp.cpu().numpy().view(np.uint32), d_ci.cpu().numpy().view(np.uint32), d_va.cpu().numpy()
+            del d_rp, d_ci, d_va, d_b
+            torch.cuda.empty_cache()
+    except Exception:
+        rp = None
+    if rp is None:
+        parts = [G.sdd_rows(n_global, k, seed, w, lo, min(n_s, lo + 1_000_000)) for lo in range(0, n_s, 1_000_000)]
+        rp = np.concatenate([[0]] + [p[0][1:].astype(np.int64) + i * 1_000_000 * k for i, p in enumerate(parts)]).astype(np.uint32)
+        ci = np.concatenate([p[1] for p in parts]); va = np.concatenate([p[2] for p in parts])
     dinv = 1.0 / (10.0 + 0.01 * (np.arange(n_s) % 1000))
-    out = {}
-    for label, order, threads in (("simd4_1t", O.ORDER_SIMD4, 1), ("rowchunk_all", O.ORDER_SEQ, threads_all)):
-        t_init = 1.0 + 0.001 * (np.arange(n_global) % 1000)
-        t_init[:n_s] *= dinv
+    t_init = 1.0 + 0.001 * (np.arange(n_global) % 1000)
+    t_init[:n_s] *= dinv
+    out, split = {}, {}
+    legs = (("simd4_1t", O.ORDER_SIMD4, 1, False), ("rowchunk_all", O.ORDER_SEQ, threads_all, False), ("rowchunk_all_parallel_passes", O.ORDER_SEQ, threads_all, True))
+    for label, order, threads, par in legs:
         t, x = t_init.copy(), t_init[:n_s].copy()
-        O.neumann_steps(rp, ci, va, dinv, t, x, 2, order, threads, fast=True)          # warm (page faults, thread pool)
-        done, dt, steps = 0, 0.0, 32
+        O.neumann_steps_split(rp, ci, va, dinv, t, x, 1, order, threads, par, fast=True)          # warm (page faults, thread pool)
+        done, dt, sp, ve = 0, 0.0, 0.0, 0.0
+        steps = 2 if n_s >= 4_000_000 else 16
         while dt < 4.0 and done < 8192:                                                # ~4 s of CPU work per leg
             t[:] = t_init                                                              # restart the series: no denormal tail
             x[:] = t_init[:n_s]
             t0 = time.perf_counter()
-            O.neumann_steps(rp, ci, va, dinv, t, x, steps, order, threads, fast=True)
+            _, a_, b_ = O.neumann_steps_split(rp, ci, va, dinv, t, x, steps, order, threads, par, fast=True)
             dt += time.perf_counter() - t0
+            sp += a_; ve += b_
             done += steps
         out[label] = n_s * k * done / dt
-    best = max(out, key=out.get)
+        split[label] = {"spmv_s_per_step": sp / done, "vector_passes_s_per_step": ve / done}
+    best = max(("simd4_1t", "rowchunk_all"), key=out.get)       # the faithful legs only
+    whole = "the WHOLE system" if n_s == n_global else f"rows [0,{n_s}) of the same system (gathered vector full length {n_global})"
     return {"value": out[best], "unit": "nnz*iter/s", "cores": threads_all if best == "rowchunk_all" else 1,
             "kind": "port",
-            "sample": f"rows [0,{n_s}) of the same S-DD system (gathered vector full length {n_global}), "
-                      f"a8+a9 steps; simd_ops.rs 4-lane SpMV 1 thread = {out['simd4_1t']:.3e}, "
-                      f"row-chunk threads x{threads_all} = {out['rowchunk_all']:.3e} nnz*iter/s",
-            "single_thread_simd4": out["simd4_1t"], "all_threads_rowchunk": out["rowchunk_all"]}
+            "sample": f"{whole}: S-DD(n={n_global}, k={k}, seed={seed}), a8+a9 steps; simd_ops.rs 4-lane SpMV 1 thread = {out['simd4_1t']:.3e}, "
+                      f"row-chunk threads x{threads_all} = {out['rowchunk_all']:.3e} nnz*iter/s — bounded by the reference's SERIAL vector passes "
+                      f"({split['rowchunk_all']['vector_passes_s_per_step']:.3f} s of {split['rowchunk_all']['spmv_s_per_step'] + split['rowchunk_all']['vector_passes_s_per_step']:.3f} s per step)",
+            "single_thread_simd4": out["simd4_1t"], "all_threads_rowchunk": out["rowchunk_all"], "time_split": split,
+            "port_plus_parallel_passes": {"value": out["rowchunk_all_parallel_passes"], "cores": threads_all,
+                                          "note": "NOT the reference: its vector passes threaded like its SpMV (simd_ops.rs:219 chunks) — what the same cores give once those loops are parallel"}}
 
 
 def column_structure_sweep(lib, L, torch, dev, n, k, seed, order, bandwidths, steps=30):

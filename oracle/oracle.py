@@ -221,6 +221,19 @@ def neumann_steps(rp, ci, va, dinv, t, x, steps, order=ORDER_SEQ, threads=1, fas
                                C.c_int(order), C.c_int(threads))
 
 
+def neumann_steps_split(rp, ci, va, dinv, t, x, steps, order=ORDER_SEQ, threads=1, parallel_passes=False, fast=False):
+    """neumann_steps with its time split: returns (last term norm, seconds in the SpMV, seconds in the vector passes + norm);
+    parallel_passes: the vector passes row-chunk threaded too (beyond the reference: a labelled second figure)"""
+    rows = rp.size - 1
+    tmp = np.empty(rows)
+    l = lib(fast)
+    l.orc_neumann_steps_split.restype = f64
+    a, b = C.c_double(0.0), C.c_double(0.0)
+    tn = l.orc_neumann_steps_split(u64(rows), _p(rp), _p(ci), _p(va), _p(dinv), _p(t), _p(x), _p(tmp), u64(steps), C.c_int(order), C.c_int(threads),
+                                   C.c_int(1 if parallel_passes else 0), C.byref(a), C.byref(b))
+    return tn, a.value, b.value
+
+
 def push_sync_solve(rp, ci, va, b, theta, max_rounds=100000, order=ORDER_SEQ, x0=None, log_cap=0, theta_rows=None):
     rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
     n = rp.size - 1

@@ -10,6 +10,7 @@
 #include <math.h>
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -140,10 +141,25 @@ void orc_spmv_simd4(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_
  * chunk_size = ceil(rows / num_threads); each chunk sequential rows, scalar sums. */
 typedef struct {
     uint64_t lo, hi; const uint32_t *rp, *ci; const double *v, *x; double *y;
+    /* mode 1 (NOT in the reference — its vector passes are serial, neumann.rs:289-296,264-266): the a8 / a9 vector passes of the
+     * chunk's rows: tmp *= dinv, t -= tmp, x += t, partial sum of t^2 */
+    int mode; const double *dinv; double *t, *xs, *tmp; double acc;
 } par_arg;
 static void *par_worker(void *p)
 {
     par_arg *a = (par_arg *)p;
+    if (a->mode == 1) {
+        double s = 0.0;
+        for (uint64_t i = a->lo; i < a->hi; ++i) {
+            const double q = a->tmp[i] * a->dinv[i];
+            const double tn = a->t[i] - q;
+            a->t[i] = tn;
+            a->xs[i] = a->xs[i] + tn;
+            s = s + tn * tn;
+        }
+        a->acc = s;
+        return 0;
+    }
     for (uint64_t i = a->lo; i < a->hi; ++i) {
         double s = 0.0;
         for (uint64_t k = a->rp[i]; k < a->rp[i + 1]; ++k) { double q = a->v[k] * a->x[a->ci[k]]; s = s + q; }
@@ -200,7 +216,7 @@ void orc_spmv_parallel(uint64_t rows, const uint32_t *row_ptr, const uint32_t *c
         uint64_t lo = (uint64_t)t * chunk, hi = lo + chunk;
         if (hi > rows) hi = rows;
         g_pool.has_work[t] = lo < rows;
-        g_pool.args[t] = (par_arg){lo, hi, row_ptr, col_idx, values, x, y};
+        g_pool.args[t] = (par_arg){lo, hi, row_ptr, col_idx, values, x, y, 0, 0, 0, 0, 0, 0.0};
     }
     if (threads > 1) pthread_barrier_wait(&g_pool.start);
     if (g_pool.has_work[0]) par_worker(&g_pool.args[0]);
@@ -390,6 +406,51 @@ double orc_neumann_steps(uint64_t rows, const uint32_t *row_ptr, const uint32_t 
         for (uint64_t i = 0; i < rows; ++i) x[i] = x[i] + t[i];
         tn = orc_l2_norm(rows, t);
     }
+    return tn;
+}
+
+/* The same loop with its time split: seconds in the SpMV and in the vector passes + norm.  parallel_passes = 1: the vector passes run
+ * row-chunk threaded like the SpMV (simd_ops.rs:219 chunks) — NOT what the reference does (its passes are serial loops), reported by
+ * bench.py as a clearly labelled second figure ("port + parallel passes"); the norm is then a sum of per-chunk sums. */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+double orc_neumann_steps_split(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, const double *dinv, double *t,
+                               double *x, double *tmp, uint64_t steps, int order, int threads, int parallel_passes, double *sec_spmv, double *sec_vec)
+{
+    orc_neumann_opts o; memset(&o, 0, sizeof(o));
+    o.order = order; o.threads = threads;
+    double tn = 0.0, a_spmv = 0.0, a_vec = 0.0;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    for (uint64_t s = 0; s < steps; ++s) {
+        const double t0 = now_s();
+        spmv_by_opts(&o, rows, row_ptr, col_idx, values, t, tmp);
+        const double t1 = now_s();
+        if (parallel_passes && threads > 1) {
+            const uint64_t chunk = (rows + (uint64_t)threads - 1) / (uint64_t)threads;
+            pool_resize(threads - 1);
+            for (int k = 0; k < threads; ++k) {
+                uint64_t lo = (uint64_t)k * chunk, hi = lo + chunk;
+                if (hi > rows) hi = rows;
+                g_pool.has_work[k] = lo < rows;
+                g_pool.args[k] = (par_arg){lo, hi, 0, 0, 0, 0, 0, 1, dinv, t, x, tmp, 0.0};
+            }
+            pthread_barrier_wait(&g_pool.start);
+            if (g_pool.has_work[0]) par_worker(&g_pool.args[0]);
+            pthread_barrier_wait(&g_pool.done);
+            double sum = 0.0;
+            for (int k = 0; k < threads; ++k) if (g_pool.has_work[k]) sum = sum + g_pool.args[k].acc;
+            tn = sqrt(sum);
+        } else {
+            for (uint64_t i = 0; i < rows; ++i) tmp[i] = tmp[i] * dinv[i];
+            for (uint64_t i = 0; i < rows; ++i) t[i] = t[i] - tmp[i];
+            for (uint64_t i = 0; i < rows; ++i) x[i] = x[i] + t[i];
+            tn = orc_l2_norm(rows, t);
+        }
+        const double t2 = now_s();
+        a_spmv += t1 - t0; a_vec += t2 - t1;
+    }
+    if (sec_spmv) *sec_spmv = a_spmv;
+    if (sec_vec) *sec_vec = a_vec;
     return tn;
 }
 

@@ -111,6 +111,10 @@ int orc_neumann_solve(uint64_t rows, uint64_t cols, const uint32_t *row_ptr, con
 /* bench.py cpu_baseline: `steps` passes of a8 + a9 on rows [0, rows) with a gathered vector of any length */
 double orc_neumann_steps(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values,
                          const double *dinv, double *t, double *x, double *tmp, uint64_t steps, int order, int threads);
+/* the same with its time split (seconds in the SpMV / in the vector passes + norm); parallel_passes = 1: the passes row-chunk threaded
+ * too — beyond the reference, a labelled second figure of the CPU baseline */
+double orc_neumann_steps_split(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, const double *dinv, double *t,
+                               double *x, double *tmp, uint64_t steps, int order, int threads, int parallel_passes, double *sec_spmv, double *sec_vec);
 
 /* ---- (a-P) synchronous thresholded push, SURVEY.md §8 (a-P) ---- */
 typedef struct {
