@@ -431,6 +431,13 @@ sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, c
                                   sl_query_session **out);
 sl_status sl_query_session_estimate(sl_query_session *q, uint64_t row, double theta, uint64_t max_rounds,
                                     sl_estimate_result *result);
+/* `count` independent queries of one session at once (query_single_entry for many pairs, forward_push.rs:224-231): they run on up to
+ * `lanes` lanes (0 = 8) — per lane a state of its own (the session's vectors cloned on first use, ~1.2 GB at n = 10^7; matrix, D^-1
+ * source and b shared), a HIP stream and a host thread — so that the launch trains of different queries overlap on the device.
+ * results[i] equals what sl_query_session_estimate(rows[i]) returns, bit for bit, whatever the lane.  The first failing query's
+ * status is returned (the other results are still filled). */
+sl_status sl_query_session_estimate_batch(sl_query_session *q, uint64_t count, const uint64_t *rows, double theta, uint64_t max_rounds,
+                                          uint32_t lanes, sl_estimate_result *results);
 void sl_query_session_destroy(sl_query_session *q);
 
 /* A^T as a matrix of its own (CompressedSparseRow::transpose, src/graph/mod.rs:92-130; PushGraph::from_matrix

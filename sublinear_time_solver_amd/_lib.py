@@ -164,6 +164,7 @@ SIGNATURES = {
     "sl_estimate_entry_transposed": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
     "sl_query_session_create": (C.c_int, [vp, C.c_int, vp, C.c_int, C.POINTER(vp)]),
     "sl_query_session_estimate": (C.c_int, [vp, u64, f64, u64, C.POINTER(EstimateResult)]),
+    "sl_query_session_estimate_batch": (C.c_int, [vp, u64, vp, f64, u64, u32, vp]),
     "sl_query_session_destroy": (None, [vp]),
     "sl_matrix_transpose": (C.c_int, [vp, u32, C.POINTER(vp)]),
     "sl_synth_pagerank_device": (C.c_int, [u64, u64, f64, u32, u32, vp, vp, vp, C.POINTER(u64)]),

@@ -894,15 +894,19 @@ sl_status sl_push_solve(const sl_matrix *m, const double *b, const sl_push_optio
 // exactly those again.  Nothing in a query is O(n) unless its frontier floods past the dense switch.
 } // extern "C"
 
+struct sl_query_pool;
 struct sl_query_session {
     const sl_matrix *m = nullptr;
     bool given_is_transpose = false;
     uint64_t n = 0;
+    int device = 0;
     push_state ps;
     DevBuf bufs[20], bbuf, touched, sums, tinv;
     const double *db = nullptr;
     std::vector<double> h_dinv;           // host copy: the seed's threshold test needs dinv[row] only
     double dense_switch = 0.25;
+    sl_query_pool *pool = nullptr;        // lanes of sl_query_session_estimate_batch (created on first use)
+    ~sl_query_session();
 };
 
 __global__ void sl_invert_perm_kernel(uint64_t nnz, const uint32_t *perm, uint32_t *inv)
@@ -1043,6 +1047,7 @@ static sl_status session_create(const sl_matrix *m, int matrix_is_transpose, con
     sl_query_session *q = new (std::nothrow) sl_query_session();
     if (!q) return sl_fail(SL_ALLOCATION, "out of host memory");
     q->m = m; q->n = n; q->given_is_transpose = matrix_is_transpose != 0;
+    (void)hipGetDevice(&q->device);
     q->dense_switch = q->given_is_transpose ? 1.0 / 16.0 : 0.25;
     auto get = [owned](DevBuf &buf, size_t bytes) { return owned ? buf.alloc_owned(bytes) : buf.alloc(bytes); };
     sl_status st = alloc_state(q->ps, n, m->nnz, q->bufs, owned);
@@ -1098,6 +1103,137 @@ sl_status sl_query_session_create(const sl_matrix *m, int matrix_is_transpose, c
 }
 
 void sl_query_session_destroy(sl_query_session *q) { delete q; }
+
+} // extern "C"
+
+// ---- many independent queries at once: lanes ------------------------------------------------------------------------------------------
+// A local query is a train of tiny launches (four per round, a dozen rounds) with nothing else on the GPU: 0.4 ms of which the device
+// computes for a few microseconds.  Independent queries (ForwardPushSolver::query_single_entry called for many pairs,
+// forward_push.rs:224-231; TS estimateEntry per request, core/solver.ts:550-659) do not depend on each other, so the batch entry runs
+// them on LANES: each lane = a state of its own (the session's vectors cloned; D^-1, b and the matrix are shared read-only), a HIP
+// stream of its own and a host thread that drives it — the launch trains of different lanes overlap on the device (up to the
+// runtime's hardware queues: GPU_MAX_HW_QUEUES, 4 by default), and one lane's host round trip hides under the others' launches.
+// Every query runs exactly the code of sl_query_session_estimate on a state that is all-zero between queries: its result does not
+// depend on the lane or on what ran beside it (tests: bitwise equal to the one-at-a-time answers).
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+struct sl_query_pool {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::vector<std::thread> threads;
+    // the job (valid while active > 0)
+    const uint64_t *rows = nullptr;
+    uint64_t count = 0, max_rounds = 0, generation = 0;
+    double theta = 0.0;
+    sl_estimate_result *results = nullptr;
+    std::atomic<uint64_t> next{0};
+    int active = 0, ready = 0;
+    bool quit = false;
+    sl_status first_error = SL_OK;
+    std::string first_msg;
+};
+
+static void query_lane_main(sl_query_session *q, sl_query_pool *p)
+{
+    sl_query_session *sub = nullptr;
+    hipStream_t st = nullptr;
+    sl_status init = SL_OK;
+    if (hipSetDevice(q->device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) init = sl_fail(SL_DEVICE_ERROR, "lane: no stream");
+    if (init == SL_OK) {
+        sl_context().stream = st;
+        init = session_create(q->m, q->given_is_transpose ? 1 : 0, q->db, SL_MEM_DEVICE, true, &sub);     // shares b (device) and the matrix; own state vectors
+    }
+    uint64_t seen = 0;
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        if (init != SL_OK && p->first_error == SL_OK) { p->first_error = init; p->first_msg = sl_context().last_error; }
+        ++p->ready;
+        p->cv_done.notify_all();
+    }
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_job.wait(lk, [&] { return p->quit || p->generation != seen; });
+            if (p->quit) break;
+            seen = p->generation;
+        }
+        if (sub) {
+            for (;;) {
+                const uint64_t i = p->next.fetch_add(1);
+                if (i >= p->count) break;
+                const sl_status e = sl_query_session_estimate(sub, p->rows[i], p->theta, p->max_rounds, &p->results[i]);
+                if (e != SL_OK) {
+                    std::unique_lock<std::mutex> lk(p->mu);
+                    if (p->first_error == SL_OK) { p->first_error = e; p->first_msg = sl_context().last_error; }
+                }
+            }
+        }
+        std::unique_lock<std::mutex> lk(p->mu);
+        if (--p->active == 0) p->cv_done.notify_all();
+    }
+    delete sub;
+    sl_release_workspace();
+    sl_ctx &c = sl_context();
+    if (c.scratch) { (void)hipFree(c.scratch); c.scratch = nullptr; c.scratch_bytes = 0; }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+}
+
+sl_query_session::~sl_query_session()
+{
+    if (!pool) return;
+    { std::unique_lock<std::mutex> lk(pool->mu); pool->quit = true; pool->cv_job.notify_all(); }
+    for (std::thread &t : pool->threads) if (t.joinable()) t.join();
+    delete pool;
+}
+
+extern "C" {
+
+sl_status sl_query_session_estimate_batch(sl_query_session *q, uint64_t count, const uint64_t *rows, double theta, uint64_t max_rounds, uint32_t lanes,
+                                          sl_estimate_result *results)
+{
+    SL_ABI_BEGIN
+    if (!q || (count && (!rows || !results))) return sl_fail(SL_INVALID_INPUT, "null argument");
+    if (count == 0) return SL_OK;
+    for (uint64_t i = 0; i < count; ++i)
+        if (rows[i] >= q->n) return sl_fail(SL_INVALID_INPUT, "Row index %llu out of bounds. Matrix has %llu rows", (unsigned long long)rows[i], (unsigned long long)q->n);
+    if (lanes == 0) lanes = 8;
+    lanes = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(lanes, 64u), count);
+    if (!q->pool) q->pool = new sl_query_pool();
+    sl_query_pool *p = q->pool;
+    // the calling thread is lane 0 (the session's own state, the caller's stream); lanes 1.. are threads that stay with the session
+    while (p->threads.size() + 1 < lanes) {
+        const size_t want = p->threads.size() + 1;
+        p->threads.emplace_back(query_lane_main, q, p);
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_done.wait(lk, [&] { return (size_t)p->ready >= want; });
+    }
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        if (p->first_error != SL_OK) { const sl_status e = p->first_error; p->first_error = SL_OK; return sl_fail(e, "a lane of the batch could not be set up: %s", p->first_msg.c_str()); }
+        p->rows = rows; p->count = count; p->theta = theta; p->max_rounds = max_rounds; p->results = results;
+        p->next.store(0);
+        p->active = (int)p->threads.size();
+        ++p->generation;
+        p->cv_job.notify_all();
+    }
+    sl_status mine = SL_OK;
+    std::string mine_msg;
+    for (;;) {
+        const uint64_t i = p->next.fetch_add(1);
+        if (i >= count) break;
+        const sl_status e = sl_query_session_estimate(q, rows[i], theta, max_rounds, &results[i]);
+        if (e != SL_OK && mine == SL_OK) { mine = e; mine_msg = sl_context().last_error; }
+    }
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_done.wait(lk, [&] { return p->active == 0; });
+    if (mine == SL_OK && p->first_error != SL_OK) { mine = p->first_error; mine_msg = p->first_msg; }
+    p->first_error = SL_OK;
+    if (mine != SL_OK) return sl_fail(mine, "%s", mine_msg.c_str());
+    return SL_OK;
+    SL_ABI_END
+}
 
 sl_status sl_query_session_estimate(sl_query_session *q, uint64_t row, double theta, uint64_t max_rounds, sl_estimate_result *res)
 {

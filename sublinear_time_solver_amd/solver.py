@@ -524,6 +524,17 @@ class QuerySession:
         L.check(L.load().sl_query_session_estimate(self._h, row, theta, max_rounds, C.byref(res)))
         return res
 
+    def estimate_batch(self, rows, theta: float = 1e-8, max_rounds: int = 100_000, lanes: int = 0):
+        """many independent queries at once (sl_query_session_estimate_batch): lanes with a state, a stream and a host thread each;
+        every result equals the one-at-a-time answer bit for bit"""
+        rows = np.ascontiguousarray([int(r) for r in rows], dtype=np.uint64)
+        n = self._matrix.rows()
+        if rows.size and int(rows.max()) >= n:
+            raise SolverError(4, f"Row index {int(rows.max())} out of bounds. Matrix has {n} rows")
+        res = (L.EstimateResult * max(1, rows.size))()
+        L.check(L.load().sl_query_session_estimate_batch(self._h, int(rows.size), L.ptr(rows), theta, max_rounds, int(lanes), res))
+        return list(res)[: rows.size]
+
     def close(self):
         if getattr(self, "_h", None):
             L.load().sl_query_session_destroy(self._h)

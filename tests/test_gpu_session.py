@@ -91,3 +91,28 @@ def test_session_sums_are_exact_to_80_bits_and_order_free(gpu):
     assert all((g.estimate, g.residual_l1) == (got[0].estimate, got[0].residual_l1) for g in got)
     one = S.estimate_entry(m, b, row, theta=theta)
     assert (one.estimate, one.residual_l1) == (got[0].estimate, got[0].residual_l1)
+
+
+def test_batch_of_queries_on_lanes_equals_one_at_a_time(gpu):
+    """sl_query_session_estimate_batch: independent queries on lanes (own state, stream and host thread each) — every result equals the
+    one-at-a-time answer bit for bit, whatever lane ran it and whatever ran beside it; the session stays usable afterwards"""
+    import sublinear_time_solver_amd as S
+    from sublinear_time_solver_amd import generators as G
+    n = 200_000
+    rp, ci, va = G.pagerank_graph(n, 5)
+    rp2, ci2, va2, b = G.pagerank_system(n, rp, ci, va, 0.85)
+    m = S.SparseMatrix.from_csr(rp2, ci2, va2, n, n, with_transpose=True)
+    rows = [0, 17, n - 1, n // 2, 12345, 99_999, 3, n - 2, 54_321, 1] * 3                 # repeats included
+    with S.QuerySession(m, b) as sess:
+        one = [sess.estimate(r, theta=1e-7) for r in rows]
+        for lanes in (1, 3, 8):
+            got = sess.estimate_batch(rows, theta=1e-7, lanes=lanes)
+            assert len(got) == len(rows)
+            for a, g in zip(one, got):
+                assert np.float64(a.estimate).view(np.uint64) == np.float64(g.estimate).view(np.uint64)
+                assert np.float64(a.residual_l1).view(np.uint64) == np.float64(g.residual_l1).view(np.uint64)
+                assert (a.rounds, a.pushes, a.rows_touched, a.converged) == (g.rounds, g.pushes, g.rows_touched, g.converged)
+        again = sess.estimate(rows[2], theta=1e-7)                                        # lane 0's state is all-zero again
+        assert np.float64(again.estimate).view(np.uint64) == np.float64(one[2].estimate).view(np.uint64)
+        with pytest.raises(S.SolverError):
+            sess.estimate_batch([0, n + 7], theta=1e-7)

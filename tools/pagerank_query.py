@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--thetas", type=str, default="1e-5,1e-7,1e-9")
     ap.add_argument("--no-full-solve", action="store_true")
     args = ap.parse_args()
+    import os
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # the lanes of the batch entry overlap on the device up to the runtime's hardware queues
     import torch
     import sublinear_time_solver_amd as S
     from sublinear_time_solver_amd import _lib as L
@@ -91,6 +93,17 @@ def main():
     dt = time.perf_counter() - t2
     out["query_stream"] = {"queries": len(qrows), "theta": 1e-5, "mean_wall_ms": dt / len(qrows) * 1e3, "queries_per_s": len(qrows) / dt,
                            "mean_rows_touched": touched / len(qrows)}
+    # the same kind of stream through the batch entry: K queries at once on lanes (own state + stream + host thread each)
+    out["query_batches"] = []
+    for lanes in (1, 2, 4, 8, 16):
+        for K in (16, 256):
+            rows_k = [rnd.randrange(n) for _ in range(K)]
+            sess.estimate_batch(rows_k[: min(K, lanes)], theta=1e-5, lanes=lanes)          # lanes set up / warm
+            t2 = time.perf_counter()
+            res = sess.estimate_batch(rows_k, theta=1e-5, lanes=lanes)
+            dt = time.perf_counter() - t2
+            out["query_batches"].append({"K": K, "lanes": lanes, "theta": 1e-5, "queries_per_s": K / dt, "mean_wall_ms_per_query": dt / K * 1e3,
+                                         "mean_rows_touched": sum(r.rows_touched for r in res) / K})
     sess.close()
     print(json.dumps(out))
 
