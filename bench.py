@@ -63,7 +63,7 @@ def algorithmic_bytes(n_rows: int, nnz: int) -> int:
 def cpu_baseline(n_global: int, k: int, seed: int, w: int, threads_all: int, rows: int = 0):
     """The reference's CPU hot loop (oracle restatement of simd_ops.rs SpMV variants inside the Neumann step, a8 + a9) on the WHOLE
     system (rows = 0) or on its first `rows` rows against the full-length vector, with the time split SpMV / vector passes: the
-    reference's vector passes are serial loops (neumann.rs:289-296, 264-266), which is what bounds its all-thread figure.  A third,
+    reference's vector passes are serial loops (neumann.rs:289-296, 264-266) beside its threaded SpMV.  A third,
     clearly labelled leg threads those passes too (not the reference).  The input is the same S-DD system, synthesised by the
     library's generator on the GPU when there is one (1.9 GB down the PCIe) and by generators.sdd_rows otherwise."""
     import numpy as np
@@ -115,8 +115,9 @@ def cpu_baseline(n_global: int, k: int, seed: int, w: int, threads_all: int, row
     return {"value": out[best], "unit": "nnz*iter/s", "cores": threads_all if best == "rowchunk_all" else 1,
             "kind": "port",
             "sample": f"{whole}: S-DD(n={n_global}, k={k}, seed={seed}), a8+a9 steps; simd_ops.rs 4-lane SpMV 1 thread = {out['simd4_1t']:.3e}, "
-                      f"row-chunk threads x{threads_all} = {out['rowchunk_all']:.3e} nnz*iter/s — bounded by the reference's SERIAL vector passes "
-                      f"({split['rowchunk_all']['vector_passes_s_per_step']:.3f} s of {split['rowchunk_all']['spmv_s_per_step'] + split['rowchunk_all']['vector_passes_s_per_step']:.3f} s per step)",
+                      f"row-chunk threads x{threads_all} = {out['rowchunk_all']:.3e} nnz*iter/s; per step of the all-thread leg: SpMV "
+                      f"{split['rowchunk_all']['spmv_s_per_step']:.3f} s (random gathers over the host's memory) + the reference's serial vector passes "
+                      f"{split['rowchunk_all']['vector_passes_s_per_step']:.3f} s",
             "single_thread_simd4": out["simd4_1t"], "all_threads_rowchunk": out["rowchunk_all"], "time_split": split,
             "port_plus_parallel_passes": {"value": out["rowchunk_all_parallel_passes"], "cores": threads_all,
                                           "note": "NOT the reference: its vector passes threaded like its SpMV (simd_ops.rs:219 chunks) — what the same cores give once those loops are parallel"}}
