@@ -880,7 +880,7 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
 #ifndef SL_PW_SLEEP
 #define SL_PW_SLEEP 4            // s_sleep argument of a paced wave that waits (x 64 cycles)
 #endif
-template <int EPI>
+template <int EPI, bool ANY_ORDER = false>
 __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
 {
     extern __shared__ __attribute__((aligned(16))) double pw_acc[];
@@ -947,8 +947,10 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         };
         auto accumulate = [&](const uint32_t (&ii)[4], const double (&vv)[4], const double (&gg)[4], const uint32_t (&cc)[4]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)                              // row slots < 2^SL_PW_ROW_BITS (SL_PW_MAX_ROWS + the spare slot)
-                sl_ordered_accumulate<SL_PW_ROW_BITS>(acc, lane, ii[u] >> SL_PW_ROW_SHIFT, DMUL(vv[u], gg[u]), cc[u] >> pbits);
+            for (int u = 0; u < 4; ++u) {                            // row slots < 2^SL_PW_ROW_BITS (SL_PW_MAX_ROWS + the spare slot)
+                if constexpr (ANY_ORDER) (void)__hip_atomic_fetch_add(&acc[ii[u] >> SL_PW_ROW_SHIFT], DMUL(vv[u], gg[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else sl_ordered_accumulate<SL_PW_ROW_BITS>(acc, lane, ii[u] >> SL_PW_ROW_SHIFT, DMUL(vv[u], gg[u]), cc[u] >> pbits);
+            }
         };
         if (chunks) {
             const uint32_t lastc = chunks - 1u;
@@ -1011,7 +1013,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
 // tested, opt-in implementation of SL_ORDER_ANY (hub rows need no kernel of their own here), not selected by default anywhere.
 // Pipeline per wave: stream loads three chunks ahead, gathers one chunk ahead of the LDS updates, buffers that change roles.
 // VAR (measurement builds only, SL_PWR_VAR): 1 = plain read-add-write instead of the LDS atomic (WRONG sums: timing of the atomics),
-// 2 = no LDS update, 4 = no gathers, 8 = no epilogue traffic.  (Tried and dropped: the XCD's waves touching the vector lines of the chunk
+// 2 = no LDS update, 4 = no gathers, 8 = no epilogue traffic, 32 = gathers folded into the first 2 MB of the vector (no first touches).  (Tried and dropped: the XCD's waves touching the vector lines of the chunk
 // positions ahead with return-less atomic-or 0, so that the L2 fetches them without a read slot of an L1 held: 0.99 -> 1.35 ms.)
 template <int EPI, int VAR = 0>
 __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pwr_kernel(sl_row_args a)
@@ -1047,7 +1049,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pwr_kernel(sl_row_args a)
         };
         auto gather = [&](uint32_t ii, double &gg, uint32_t bb) {
             asm volatile("" : "+v"(ii), "+v"(bb));                   // the address is formed HERE (hoisted to the top of the loop it would wait for the newest stream loads)
-            gg = (VAR & 4) ? 1.0 : g[bb + (ii & ((1u << SL_PWR_OFF_BITS) - 1u))];
+            gg = (VAR & 4) ? 1.0 : (VAR & 32) ? g[(bb + (ii & ((1u << SL_PWR_OFF_BITS) - 1u))) & 0x3ffffu] : g[bb + (ii & ((1u << SL_PWR_OFF_BITS) - 1u))];
         };
         auto accumulate = [&](uint32_t ii, double vv, double gg, bool real) {
             asm volatile("" : "+v"(gg));                             // the product is formed HERE, behind the loads issued above: hoisted over them it would wait for the newest gather
@@ -1482,6 +1484,13 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
         if (knobs().pw_slack) a.pw_slack = knobs().pw_slack;               // A/B knob; 1048576 = no pacing
         *nparts = a.pw_blocks + a.n_long;
         a.part_stride = *nparts;
+#ifdef SL_PWR_VARIANTS
+        static const bool pw_any = [] { const char *e = getenv("SL_PW_ANY"); return e && *e == '1'; }();
+        if (pw_any && EPI == SL_EPI_NEUMANN) {
+            SL_TRY((set_max_lds_once<sl_pw_kernel<SL_EPI_NEUMANN, true>>((int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double)))));
+            hipLaunchKernelGGL((sl_pw_kernel<SL_EPI_NEUMANN, true>), dim3(a.pw_blocks), dim3(SL_PW_WAVES * 64), lds, s, a);
+        } else
+#endif
         hipLaunchKernelGGL((sl_pw_kernel<EPI>), dim3(a.pw_blocks), dim3(SL_PW_WAVES * 64), lds, s, a);
     } else if (ORDER == 0 && a.pan_tile_ptr && a.n_pan_tiles) {
         const uint32_t grid = (a.n_pan_tiles + SL_PANEL_WAVES - 1) / SL_PANEL_WAVES;
@@ -1586,7 +1595,7 @@ static sl_status launch_pwr(sl_row_args a, hipStream_t s, uint32_t *nparts)
     if (EPI == SL_EPI_NEUMANN && var) {
 #define SL_PWR_V(v) case v: SL_TRY((set_max_lds_once<sl_pwr_kernel<SL_EPI_NEUMANN, v>>((int)((size_t)SL_PWR_MAX_ROWS * sizeof(double))))); \
                             hipLaunchKernelGGL((sl_pwr_kernel<SL_EPI_NEUMANN, v>), dim3(a.pwr_blocks), dim3(SL_PW_WAVES * 64), lds, s, a); break;
-        switch (var) { SL_PWR_V(1) SL_PWR_V(2) SL_PWR_V(4) SL_PWR_V(6) SL_PWR_V(10) SL_PWR_V(14) default: return sl_fail(SL_INVALID_INPUT, "SL_PWR_VAR"); }
+        switch (var) { SL_PWR_V(1) SL_PWR_V(2) SL_PWR_V(4) SL_PWR_V(6) SL_PWR_V(10) SL_PWR_V(14) SL_PWR_V(32) SL_PWR_V(42) default: return sl_fail(SL_INVALID_INPUT, "SL_PWR_VAR"); }
 #undef SL_PWR_V
         SL_HIP(hipGetLastError());
         return SL_OK;
