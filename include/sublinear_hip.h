@@ -376,7 +376,12 @@ sl_status sl_forward_push_acl_with_target(const sl_push_graph *g, uint64_t sourc
  * (the |F| = 1 member of the push family): this entry point is for order-exact parity with the reference — push sequence,
  * iteration count, solution bits — the throughput path is sl_push_solve.  Needs SL_MATRIX_WITH_TRANSPOSE.
  * Status: SL_CONVERGENCE_FAILURE after max_iterations pushes (solver.ts:509-515; x_out / r_out / result still filled),
- * SL_NUMERICAL_INSTABILITY for |a_ii| < 1e-15 (:471-473).  push_log (may be NULL): the pushed index of every step, up to log_cap. */
+ * SL_NUMERICAL_INSTABILITY for |a_ii| < 1e-15 (:471-473).  push_log (may be NULL): the pushed index of every step, up to log_cap.
+ * Matrices that store the same (i, j) twice: the reference reads entries through MatrixOperations.getEntry / getDiagonal, which return
+ * the FIRST stored match of a COO input, so later duplicates never enter its arithmetic; this entry point works on the CSR the Rust
+ * side defines (duplicates are separate entries that a product sums, sparse.rs:80-132) — every stored duplicate of a column is
+ * subtracted and the diagonal is the entry the midpoint search of CSRStorage::get lands on.  Parity with solver.ts is therefore
+ * stated for matrices without duplicates (every fixture and golden of the reference); coalesce duplicates first where they occur. */
 typedef struct {
     double epsilon;          /* SolverConfig.epsilon        src/core/types.ts:28-46 */
     uint64_t max_iterations; /* SolverConfig.maxIterations  */
