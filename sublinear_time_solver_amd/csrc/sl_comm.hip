@@ -425,6 +425,63 @@ sl_status sl_dist_pull(sl_dist *d, sl_dist_vector *v, hipStream_t s)
     return SL_OK;
 }
 
+
+// ---- the ipc transport proves itself before anything is built on it ---------------------------------------------------------------
+// One page per rank, filled by a kernel with a pattern of (rank, job nonce), exported, mapped by every peer and pulled with the same
+// device copy the exchanges use; every rank checks what arrived against what the owner must have written.  A box on which mapped peer
+// memory or device-to-device copies do not deliver (no peer access between two GPUs, an IPC mode the driver refuses) fails HERE, on
+// every rank alike, with a status — the caller (bench.py's parent, a host's own retry) then takes the rccl transport.
+__global__ void sl_comm_pattern_kernel(unsigned long long *p, uint32_t words, unsigned long long seed)
+{
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) p[i] = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)i * 0xBF58476D1CE4E5B9ull;
+}
+__global__ void sl_comm_pattern_check_kernel(const unsigned long long *p, uint32_t words, unsigned long long seed, uint32_t *bad)
+{
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x)
+        if (p[i] != seed * 0x9E3779B97F4A7C15ull + (unsigned long long)i * 0xBF58476D1CE4E5B9ull) atomicAdd(bad, 1u);
+}
+static sl_status comm_ipc_selftest(sl_comm *c)
+{
+    if (c->world < 2) return SL_OK;
+    constexpr uint32_t WORDS = 512;                      // 4 KB
+    hipStream_t s = sl_context().stream;
+    sl_dist_vector v;
+    // (a gathered "vector" of WORDS doubles per rank slot: reuses the collective-safe create of the real vectors)
+    SL_TRY(sl_dist_vector_create(c, (uint64_t)WORDS * (uint64_t)c->world, &v));
+    sl_status mine = SL_OK;
+    uint32_t *d_bad = nullptr;
+    const unsigned long long nonce = (unsigned long long)c->h_shm->generation;
+    do {
+        if (hipMalloc(&d_bad, 4) != hipSuccess) { d_bad = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); break; }
+        if (hipMemsetAsync(d_bad, 0, 4, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "memset failed"); break; }
+        hipLaunchKernelGGL(sl_comm_pattern_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<unsigned long long *>(v.mine) + (size_t)c->rank * WORDS, WORDS,
+                           nonce + (unsigned long long)c->rank);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "self-test: pattern kernel failed"); break; }
+    } while (0);
+    sl_status st = sl_comm_agree(c, mine);               // every rank's page is written (and visible: the stream was drained)
+    if (st == SL_OK) {
+        uint32_t bad = 0;
+        do {
+            for (int p = 0; p < c->world && mine == SL_OK; ++p) {
+                if (p == c->rank) continue;
+                if (hipMemcpyAsync(v.mine + (size_t)p * WORDS, v.peer[p] + (size_t)p * WORDS, WORDS * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                    { mine = sl_fail(SL_DEVICE_ERROR, "self-test: device copy from rank %d's mapped buffer failed", p); break; }
+                hipLaunchKernelGGL(sl_comm_pattern_check_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const unsigned long long *>(v.mine) + (size_t)p * WORDS, WORDS,
+                                   nonce + (unsigned long long)p, d_bad);
+            }
+            if (mine != SL_OK) break;
+            if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "self-test: readback failed"); break; }
+            if (bad) mine = sl_fail(SL_DEVICE_ERROR, "self-test of the ipc transport: %u of %u words pulled from the peers differ from what they wrote (rank %d)", bad,
+                                    WORDS * (uint32_t)(c->world - 1), c->rank);
+        } while (0);
+        st = sl_comm_agree(c, mine);
+    }
+    if (d_bad) (void)hipFree(d_bad);
+    const sl_status bs = st == SL_OK ? sl_comm_host_barrier(c) : st;     // nobody frees its page while a peer still copies from it
+    sl_dist_vector_destroy(c, &v);
+    return st != SL_OK ? st : bs;
+}
+
 // ---- verification of an exchange: what a rank holds of its peers' rows against the owners' own copies ---------------------------
 __global__ __launch_bounds__(256) void sl_checksum_kernel(const unsigned long long *data, uint64_t n, unsigned long long *out)
 {
@@ -613,6 +670,9 @@ sl_status sl_comm_create(int rank, int world, const char *rendezvous, sl_comm **
         else c->nccl = nc;
         if (mine == SL_OK && hipMalloc(&c->d_sums, (size_t)SL_COMM_RING * (size_t)world * sizeof(double)) != hipSuccess) { c->d_sums = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); }
         if ((st = sl_comm_agree(c, mine)) != SL_OK) return fail(st);
+    }
+    if (transport == SL_TRANSPORT_IPC && !(getenv("SL_COMM_SELFTEST") && getenv("SL_COMM_SELFTEST")[0] == '0')) {
+        if ((st = comm_ipc_selftest(c)) != SL_OK) return fail(st);
     }
     sl_log(1, "communicator '%s': rank %d of %d on device %d, transport %s", rendezvous, rank, world, c->device, sl_comm_transport_name(c));
     *out = c;
