@@ -21,6 +21,7 @@
 #include <string>
 #include <tuple>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "sublinear_hip.h"
@@ -326,6 +327,119 @@ private:
     size_t max_rounds_;
 };
 
+
+// ---- the graph side of the push spec: PushGraph, ForwardPushSolver, BackwardPushSolver (reference names) -----------------------------
+// PushGraph (src/graph/adjacency.rs:199-277) on the device behind sl_push_graph_*; ForwardPushConfig (forward_push.rs:24-49);
+// ForwardPushResult (:10-22).  solve_single_source / solve_multi_source / solve_with_target / solve_single_target run the spec's OWN
+// visiting order (WorkQueue pops, graph/mod.rs:132-213): push_count, nodes_visited and every bit as the reference's loop.
+struct ForwardPushConfig {
+    Precision alpha = 0.15, epsilon = 1e-6, queue_threshold = 1e-8;
+    size_t max_pushes = 1000000;
+    bool adaptive_threshold = true;
+};
+using BackwardPushConfig = ForwardPushConfig;
+struct ForwardPushResult {
+    std::vector<Precision> estimate, residual;
+    size_t push_count = 0, nodes_visited = 0;
+    Precision residual_norm = 0;
+};
+using BackwardPushResult = ForwardPushResult;
+
+class PushGraph {
+public:
+    // PushGraph::from_matrix: the weighted adjacency in CSR (u32 indices)
+    PushGraph(size_t num_nodes, const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col_idx, const std::vector<Precision> &weights) : n_(num_nodes)
+    {
+        if (row_ptr.size() != num_nodes + 1 || col_idx.size() != weights.size()) throw SolverError(SL_DIMENSION_MISMATCH, "push graph arrays");
+        check(sl_push_graph_create(num_nodes, row_ptr.data(), col_idx.data(), weights.data(), SL_MEM_HOST, &g_));
+    }
+    // PushGraph::from_edges (adjacency.rs:226-238): endpoints out of range are skipped
+    static PushGraph from_edges(size_t num_nodes, std::vector<std::tuple<size_t, size_t, Precision>> edges)
+    {
+        edges.erase(std::remove_if(edges.begin(), edges.end(), [&](const auto &e) { return std::get<0>(e) >= num_nodes || std::get<1>(e) >= num_nodes; }), edges.end());
+        std::stable_sort(edges.begin(), edges.end(), [](const auto &a, const auto &b) { return std::get<0>(a) != std::get<0>(b) ? std::get<0>(a) < std::get<0>(b) : std::get<1>(a) < std::get<1>(b); });
+        std::vector<uint32_t> rp(num_nodes + 1, 0), ci;
+        std::vector<Precision> w;
+        for (const auto &e : edges) { ++rp[std::get<0>(e) + 1]; ci.push_back((uint32_t)std::get<1>(e)); w.push_back(std::get<2>(e)); }
+        for (size_t i = 0; i < num_nodes; ++i) rp[i + 1] += rp[i];
+        return PushGraph(num_nodes, rp, ci, w);
+    }
+    PushGraph(PushGraph &&o) noexcept : n_(o.n_), g_(o.g_) { o.g_ = nullptr; }
+    PushGraph(const PushGraph &) = delete;
+    PushGraph &operator=(const PushGraph &) = delete;
+    ~PushGraph() { if (g_) sl_push_graph_destroy(g_); }
+    size_t num_nodes() const { return n_; }
+    size_t num_edges() const { uint64_t e = 0; check(sl_push_graph_size(g_, nullptr, &e)); return (size_t)e; }
+    std::vector<Precision> degrees() const { std::vector<Precision> d(n_); check(sl_push_graph_degrees(g_, d.data(), nullptr, SL_MEM_HOST)); return d; }
+    std::vector<Precision> reverse_degrees() const { std::vector<Precision> d(n_); check(sl_push_graph_degrees(g_, nullptr, d.data(), SL_MEM_HOST)); return d; }
+    Precision out_degree(size_t node) const { return node < n_ ? degrees()[node] : 0.0; }
+    Precision in_degree(size_t node) const { return node < n_ ? reverse_degrees()[node] : 0.0; }
+    const sl_push_graph *handle() const { return g_; }
+
+private:
+    size_t n_ = 0;
+    sl_push_graph *g_ = nullptr;
+};
+
+class ForwardPushSolver {
+public:
+    ForwardPushSolver(const PushGraph &graph, ForwardPushConfig config = {}) : graph_(graph), config_(config) {}
+    ForwardPushResult solve_single_source(size_t source) const { const uint64_t s = source; return run(false, 1, &s, nullptr, 0.0); }        // forward_push.rs:67-122
+    ForwardPushResult solve_multi_source(const std::vector<size_t> &sources) const                                                           // :125-177
+    {
+        std::vector<uint64_t> s(sources.begin(), sources.end());
+        return run(false, s.size(), s.data(), nullptr, 0.0);
+    }
+    Precision query_single_entry(size_t source, size_t target) const                                                                        // :224-231
+    {
+        const ForwardPushResult r = solve_single_source(source);
+        return target < r.estimate.size() ? r.estimate[target] : 0.0;
+    }
+    ForwardPushResult solve_with_target(size_t source, size_t target, Precision target_precision) const                                      // :233-290
+    {
+        const uint64_t s = source, t = target;
+        return run(false, 1, &s, &t, target_precision);
+    }
+    std::vector<Precision> extrapolated_solution(const ForwardPushResult &r) const                                                          // :292-301
+    {
+        std::vector<Precision> x = r.estimate;
+        for (size_t i = 0; i < x.size(); ++i) x[i] += config_.alpha * r.residual[i];
+        return x;
+    }
+
+protected:
+    ForwardPushResult run(bool backward, uint64_t count, const uint64_t *nodes, const uint64_t *target, Precision target_precision) const
+    {
+        sl_acl_options o;
+        sl_acl_options_default(&o);
+        o.alpha = config_.alpha; o.epsilon = config_.epsilon; o.queue_threshold = config_.queue_threshold; o.max_pushes = config_.max_pushes;
+        o.adaptive_threshold = config_.adaptive_threshold ? 1 : 0; o.mem = SL_MEM_HOST;
+        ForwardPushResult out;
+        const size_t n = graph_.num_nodes();
+        out.estimate.assign(n ? n : 1, 0.0); out.residual.assign(n ? n : 1, 0.0);
+        sl_acl_result r;
+        if (target) check(sl_forward_push_acl_with_target(graph_.handle(), nodes[0], *target, target_precision, &o, out.estimate.data(), out.residual.data(), nullptr, 0, &r));
+        else if (backward) check(sl_backward_push_acl(graph_.handle(), count, nodes, &o, out.estimate.data(), out.residual.data(), nullptr, 0, &r));
+        else check(sl_forward_push_acl(graph_.handle(), count, nodes, &o, out.estimate.data(), out.residual.data(), nullptr, 0, &r));
+        out.estimate.resize(n); out.residual.resize(n);
+        out.push_count = r.push_count; out.nodes_visited = r.nodes_visited; out.residual_norm = r.residual_norm;
+        return out;
+    }
+    const PushGraph &graph_;
+    ForwardPushConfig config_;
+};
+
+class BackwardPushSolver : private ForwardPushSolver {      // backward_push.rs:67-334
+public:
+    BackwardPushSolver(const PushGraph &graph, BackwardPushConfig config = {}) : ForwardPushSolver(graph, config) {}
+    BackwardPushResult solve_single_target(size_t target) const { const uint64_t t = target; return run(true, 1, &t, nullptr, 0.0); }
+    Precision query_transition_probability(size_t source, size_t target) const                                                              // :228-235
+    {
+        const BackwardPushResult r = solve_single_target(target);
+        return source < r.estimate.size() ? r.estimate[source] : 0.0;
+    }
+};
+
 // Many single-entry queries against one system: ForwardPushSolver::new(graph, config) once, query_single_entry per
 // query (forward_push.rs:52-66, 224-231).  Setup is paid once; a query costs the rows its push touches.  `matrix` and
 // `b` are captured: the matrix must outlive the session.
@@ -348,6 +462,17 @@ public:
         if (error_l1) *error_l1 = r.residual_l1;
         if (rows_touched) *rows_touched = r.rows_touched;
         return r.estimate;
+    }
+
+    // many independent queries at once, on lanes (sl_query_session_estimate_batch): results as the one-at-a-time answers, bit for bit
+    std::vector<Precision> query_batch(const std::vector<size_t> &rows, Precision theta = 1e-8, size_t max_rounds = 100000, unsigned lanes = 0) const
+    {
+        std::vector<uint64_t> r64(rows.begin(), rows.end());
+        std::vector<sl_estimate_result> res(rows.size() ? rows.size() : 1);
+        check(sl_query_session_estimate_batch(q_, r64.size(), r64.data(), theta, max_rounds, lanes, res.data()));
+        std::vector<Precision> out(rows.size());
+        for (size_t i = 0; i < rows.size(); ++i) out[i] = res[i].estimate;
+        return out;
     }
 
 private:

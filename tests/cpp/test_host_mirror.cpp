@@ -49,6 +49,33 @@ int main()
             EXPECT(std::fabs(session.query_single_entry(0, 1e-12, 100000, &err, &touched) - 1.0) < 1e-9 && touched > 0);
             EXPECT(session.query_single_entry(1, 1e-12) == e1);
         }
+        const auto batch = session.query_batch({1, 0, 1}, 1e-12, 100000, 2);                     // lanes: same bits as one at a time
+        EXPECT(batch.size() == 3 && batch[0] == e1 && batch[2] == e1 && std::fabs(batch[1] - 1.0) < 1e-9);
+    }
+    // the graph side under the reference's names: PushGraph + ForwardPushSolver / BackwardPushSolver in the spec's own visiting order
+    // (tests/rust/push_tests.rs: the 4-node fixture :15-22, 200 pushes at alpha = 0.15 / epsilon = 1e-6 — SURVEY 8(c) G5)
+    {
+        PushGraph g(4, {0, 2, 4, 6, 7}, {1, 2, 0, 3, 0, 3, 1}, {0.5, 0.5, 0.8, 0.2, 0.6, 0.4, 1.0});
+        EXPECT(g.num_nodes() == 4 && g.num_edges() == 7 && g.out_degree(0) == 1.0 && g.out_degree(9) == 0.0);
+        ForwardPushSolver fps(g);
+        const ForwardPushResult r = fps.solve_single_source(0);
+        EXPECT(r.push_count == 200 && r.nodes_visited == 4);
+        const double want[4] = {0.431272, 0.276168, 0.183291, 0.109267};
+        double mass = 0.0;
+        for (int i = 0; i < 4; ++i) { EXPECT(std::fabs(r.estimate[i] - want[i]) < 1e-6 && r.residual[i] >= 0.0); mass += r.estimate[i] + 0.15 * r.residual[i]; }
+        EXPECT(std::fabs(mass - 1.0) < 0.01);                                                    // push_tests.rs:107-129
+        EXPECT(fps.query_single_entry(0, 2) == r.estimate[2] && fps.query_single_entry(0, 99) == 0.0);
+        EXPECT(fps.solve_single_source(10).push_count == 0);                                     // out-of-range source: empty result (:433-495)
+        const ForwardPushResult t = fps.solve_with_target(0, 3, 0.05);
+        EXPECT(t.push_count > 0 && t.push_count < r.push_count && t.estimate[3] > 0.05);         // forward_push.rs:262-265
+        const ForwardPushResult m2 = fps.solve_multi_source({0, 3});
+        double mm = 0.0;
+        for (int i = 0; i < 4; ++i) mm += m2.estimate[i] + 0.15 * m2.residual[i];
+        EXPECT(std::fabs(mm - 1.0) < 0.01);
+        BackwardPushSolver bps(g);
+        EXPECT(bps.solve_single_target(1).push_count > 0 && bps.query_transition_probability(0, 1) > 0.0);
+        auto e = PushGraph::from_edges(5, {{0, 1, 1.0}, {1, 2, 1.0}, {2, 3, 1.0}, {7, 1, 1.0}});     // the invalid edge is skipped
+        EXPECT(e.num_edges() == 3 && ForwardPushSolver(e).solve_single_source(0).estimate[4] == 0.0);
     }
     // trait SolverAlgorithm on a device state: initialize / step / is_converged / extract_solution / update_rhs / reset
     {
