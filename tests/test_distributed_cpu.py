@@ -260,3 +260,23 @@ def test_halo_exchanges_reject_partitions_with_an_empty_rank():
         with pytest.raises(ValueError, match="rows on every rank"):
             cls(D.RowPartition(12, 3, 0, bounds=[0, 6, 6, 12]), 2)
         cls(D.RowPartition(12, 3, 1, bounds=[0, 4, 8, 12]), 2)      # fine
+
+
+def test_bench_launcher_without_a_gpu_fails_loudly_after_trying_every_transport():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks per attempt; without a device every rank stops
+    with the library's loud DeviceError (no CPU fallback), the parent walks the transports in order and exits non-zero with the list
+    of attempts — the launcher's plumbing (spawn, collect, fall back, give up) without a GPU"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU suite runs the launcher for real")
+    env = dict(os.environ, SL_BENCH_TRANSPORTS="ipc,rccl", SL_COMM_TIMEOUT_MS="3000")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--rows", "20000", "--steps", "2", "--warmup", "0", "--attempt-timeout", "120"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout[-500:]
+    assert "attempt 0 (transport ipc) failed" in r.stderr and "attempt 1 (transport rccl) failed" in r.stderr and "every transport failed" in r.stderr, r.stderr[-3000:]
