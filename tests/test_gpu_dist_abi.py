@@ -79,3 +79,48 @@ def test_a_rank_that_never_arrives_becomes_an_error_not_a_hang(gpu):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=dict(os.environ, SL_COMM_TIMEOUT_MS="1500"))
     assert r.returncode == 0 and "kind DeviceError" in r.stdout, r.stdout + r.stderr[-1500:]
     assert float(r.stdout.split("after")[1]) < 30.0
+
+
+def test_a_failure_on_one_rank_is_the_verdict_of_all_and_the_communicator_stays_in_step(gpu, tmp_path):
+    """rank 1's rows are not diagonally dominant: NeumannState::new over the partition fails on BOTH ranks with that status (the
+    agreement after the local stage), nobody waits for anybody, and the SAME communicator then builds and solves a valid system —
+    its barrier / exchange counters are still in step on every rank (collective construction must not fall out of step)"""
+    import sys
+    script = tmp_path / "rank.py"
+    script.write_text('''
+import sys, time, numpy as np
+sys.path.insert(0, %r)
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import generators as G
+rank, name = int(sys.argv[1]), sys.argv[2]
+n, k = 40000, 8
+lo, hi = rank * n // 2, (rank + 1) * n // 2
+rp, ci, va, b = G.sdd_rows(n, k, 3, 200, lo, hi)
+comm = S.Communicator(rank, 2, name)
+bad = va.copy()
+if rank == 1:
+    bad[ci[:] == (lo + np.repeat(np.arange(hi - lo), k))] = 1e-3          # diagonal far below the row sums
+mb = S.SparseMatrix.from_csr(rp, ci, bad, hi - lo, n, row_offset=lo)
+t0 = time.time()
+try:
+    S.NeumannSolver().initialize_partitioned(comm, mb, b, S.SolverOptions(tolerance=1e-10))
+    print("NO ERROR")
+except S.SolverError as e:
+    print("first", e.kind, round(time.time() - t0, 2))
+m = S.SparseMatrix.from_csr(rp, ci, va, hi - lo, n, row_offset=lo)
+st = S.NeumannSolver().initialize_partitioned(comm, m, b, S.SolverOptions(tolerance=1e-10))
+r = st.run()
+print("second", r.converged, r.iterations, float(np.abs(r.solution).sum()))
+st.close(); comm.close()
+''' % str(ROOT))
+    name = f"agree_{os.getpid()}"
+    env = dict(os.environ, SL_COMM_TIMEOUT_MS="20000")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in (0, 1)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se[-2000:]
+        assert "first MatrixNotDiagonallyDominant" in so and "NO ERROR" not in so, so + se[-1500:]
+        assert float(so.split("first MatrixNotDiagonallyDominant")[1].split()[0]) < 10.0              # nobody ran into a time limit
+        assert "second True" in so, so + se[-1500:]
+    it = {so.split("second True")[1].split()[0] for so, _ in outs}
+    assert len(it) == 1                                                                               # the same iteration count on both ranks
