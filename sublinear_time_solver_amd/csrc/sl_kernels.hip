@@ -880,7 +880,9 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
 #ifndef SL_PW_SLEEP
 #define SL_PW_SLEEP 4            // s_sleep argument of a paced wave that waits (x 64 cycles)
 #endif
-template <int EPI, bool ANY_ORDER = false>
+// ANY_ORDER / PWV: measurement builds only (SL_PW_ANY, SL_PW_VAR): relaxed accumulation inside this layout; PWV & 8 = no epilogue
+// traffic, PWV & 32 = gathers folded into the first 2 MB of the vector (every gather an L2 hit, no first touches), PWV & 2 = no LDS update
+template <int EPI, bool ANY_ORDER = false, int PWV = 0>
 __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
 {
     extern __shared__ __attribute__((aligned(16))) double pw_acc[];
@@ -942,13 +944,14 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
                 if (fl) sp += mask_count_below(fl) + stepbit;           // a handful of times per tile: the first entry of a super-panel
                 sp_g = __builtin_amdgcn_readfirstlane(sp_g + (real ? (uint32_t)__popcll(fl) : 0u));
                 cc[u] = real ? ((sp << SL_PW_SP_BITS) | (ii[u] & ((1u << SL_PW_SP_BITS) - 1u))) : 0u;
-                gg[u] = g[cc[u]];
+                gg[u] = (PWV & 32) ? g[cc[u] & 0x3ffffu] : g[cc[u]];
             }
         };
         auto accumulate = [&](const uint32_t (&ii)[4], const double (&vv)[4], const double (&gg)[4], const uint32_t (&cc)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                            // row slots < 2^SL_PW_ROW_BITS (SL_PW_MAX_ROWS + the spare slot)
-                if constexpr (ANY_ORDER) (void)__hip_atomic_fetch_add(&acc[ii[u] >> SL_PW_ROW_SHIFT], DMUL(vv[u], gg[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if constexpr (PWV & 2) { if (DMUL(vv[u], gg[u]) == 123.456) acc[0] = 1.0; }
+                else if constexpr (ANY_ORDER) (void)__hip_atomic_fetch_add(&acc[ii[u] >> SL_PW_ROW_SHIFT], DMUL(vv[u], gg[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else sl_ordered_accumulate<SL_PW_ROW_BITS>(acc, lane, ii[u] >> SL_PW_ROW_SHIFT, DMUL(vv[u], gg[u]), cc[u] >> pbits);
             }
         };
@@ -983,6 +986,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
             // groups of SL_PW_GROUP rows are dealt among `deal` tiles: span = tile / deal owns deal * rpw consecutive rows
             const uint64_t i = ((uint64_t)(tile / deal) * deal * (rpw / SL_PW_GROUP) + (uint64_t)(r / SL_PW_GROUP) * deal + tile % deal) * SL_PW_GROUP + (r % SL_PW_GROUP);
             if (i >= a.n_rows || (a.n_long && a.row_len[i] == SL_LONG_SENTINEL)) continue;
+            if constexpr (PWV & 8) { part0 += acc[r]; continue; }
             double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
             if constexpr (EPI == SL_EPI_NEUMANN) { e_t = g[a.row_offset + i]; e_d = a.dinv[i]; e_x = a.x[i]; }
             else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
@@ -1486,6 +1490,13 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
         a.part_stride = *nparts;
 #ifdef SL_PWR_VARIANTS
         static const bool pw_any = [] { const char *e = getenv("SL_PW_ANY"); return e && *e == '1'; }();
+        static const int pw_var = [] { const char *e = getenv("SL_PW_VAR"); return e ? atoi(e) : 0; }();
+        if (pw_var && EPI == SL_EPI_NEUMANN) {
+#define SL_PW_V(v) case v: SL_TRY((set_max_lds_once<sl_pw_kernel<SL_EPI_NEUMANN, false, v>>((int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double))))); \
+                           hipLaunchKernelGGL((sl_pw_kernel<SL_EPI_NEUMANN, false, v>), dim3(a.pw_blocks), dim3(SL_PW_WAVES * 64), lds, s, a); break;
+            switch (pw_var) { SL_PW_V(2) SL_PW_V(8) SL_PW_V(10) SL_PW_V(32) SL_PW_V(40) SL_PW_V(42) default: return sl_fail(SL_INVALID_INPUT, "SL_PW_VAR"); }
+#undef SL_PW_V
+        } else
         if (pw_any && EPI == SL_EPI_NEUMANN) {
             SL_TRY((set_max_lds_once<sl_pw_kernel<SL_EPI_NEUMANN, true>>((int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double)))));
             hipLaunchKernelGGL((sl_pw_kernel<SL_EPI_NEUMANN, true>), dim3(a.pw_blocks), dim3(SL_PW_WAVES * 64), lds, s, a);
