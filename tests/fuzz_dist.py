@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Random campaign over tests/c/dist_smoke.c (the partitioned solve through the C ABI, one process per rank, ranks sharing the box's
+GPU): random world sizes 1..8, sizes, bandwidths on both sides of every halo form (neighbour halo, reach beyond the neighbour, all
+columns), equal and unequal row ranges, the boundary-first step on and off.  dist_smoke itself compares with the one-GPU solve through
+the same ABI (iteration count, convergence flag, solution bit for bit) and checks the exchange with sl_neumann_state_verify_exchange.
+
+usage: python tests/fuzz_dist.py --seconds 300 [--seed0 S]      prints one JSON line; exit status 1 on any failure"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def build(tmp):
+    exe = Path(tmp) / "dist_smoke"
+    pkg = ROOT / "sublinear_time_solver_amd"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c" / "dist_smoke.c"),
+                        "-o", str(exe), f"-L{pkg}", "-lsublinear_hip", "-lm", f"-Wl,-rpath,{pkg}"], capture_output=True, text=True)
+    if r.returncode:
+        raise SystemExit(r.stderr)
+    return exe
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed0", type=int, default=int(time.time()) & 0xFFFFFF)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed0)
+    failures, cases, forms = [], 0, {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build(tmp)
+        t_end = time.time() + args.seconds
+        while time.time() < t_end and len(failures) < 10:
+            world = int(rng.integers(1, 9))
+            n = int(rng.choice([64 * world + 1, 5000, 20011, 90000, 400000, 1200000]))
+            n = max(n, 64 * world)
+            w = int(rng.choice([1, 40, 300, 5000, 15000, n // max(world, 1), 10**9]))
+            uneven = bool(rng.random() < 0.5)
+            overlap = str(rng.choice(["0", "1"]))
+            cmd = [str(exe), str(world), str(n), str(w)] + (["uneven"] if uneven else [])
+            env = dict(os.environ, SL_COMM_TIMEOUT_MS="60000", SL_DIST_OVERLAP=overlap, SL_LOG="1")
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+                ok = r.returncode == 0 and "dist_smoke ok" in r.stdout
+                tail = (r.stdout[-600:] + r.stderr[-1200:]) if not ok else ""
+                form = "edge blocks first" if "runs its edge blocks first" in r.stderr else "exchange after the step"
+            except subprocess.TimeoutExpired:
+                ok, tail, form = False, "timeout", "?"
+            cases += 1
+            key = f"world {world}: {form}"
+            forms[key] = forms.get(key, 0) + 1
+            if not ok:
+                failures.append({"cmd": " ".join(cmd[1:]), "overlap": overlap, "tail": tail})
+                print("FAIL", " ".join(cmd[1:]), "overlap", overlap, "\n", tail, file=sys.stderr)
+    print(json.dumps({"seed0": args.seed0, "cases": cases, "forms_seen": dict(sorted(forms.items())), "failures": failures}))
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
