@@ -216,7 +216,7 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
     a.n_pan_tiles = (uint32_t)m->n_pan_tiles; a.pan_balanced = m->pan_balanced ? 1u : 0u;
     a.pw_idx = m->d_pw_idx; a.pw_val = m->d_pw_val; a.pw_tile_ptr = m->d_pw_tile_ptr;
     a.pw_tiles = (uint32_t)m->n_pw_tiles; a.pw_rpw = m->pw_rpw; a.pw_blocks = m->pw_blocks; a.pw_slack = m->pw_slack;
-    a.pw_deal = m->pw_deal; a.pw_pbits = m->pw_pbits;
+    a.pw_deal = m->pw_deal; a.pw_pbits = m->pw_pbits; a.pw_xcd = m->pw_xcd; a.pw_span_tab = m->d_pw_span_tab;
     a.pwr_idx = m->d_pwr_idx; a.pwr_val = m->d_pwr_val; a.pwr_base = m->d_pwr_base; a.pwr_tile_ptr = m->d_pwr_tile_ptr; a.pwr_diag = m->d_pwr_diag;
     a.pwr_tiles = (uint32_t)m->n_pwr_tiles; a.pwr_rpb = m->pwr_rpb; a.pwr_blocks = m->pwr_blocks;
     return a;
@@ -278,7 +278,7 @@ void sl_matrix_destroy(sl_matrix *m)
     hipFree(m->d_row_ptr); hipFree(m->d_col_idx); hipFree(m->d_values);
     hipFree(m->d_tptr); hipFree(m->d_trow); hipFree(m->d_tval); hipFree(m->d_tent); hipFree(m->d_long_rows);
     hipFree(m->d_pan_tile_ptr); hipFree(m->d_pan_row); hipFree(m->d_pan_col); hipFree(m->d_pan_val);
-    hipFree(m->d_pw_idx); hipFree(m->d_pw_val); hipFree(m->d_pw_tile_ptr);
+    hipFree(m->d_pw_idx); hipFree(m->d_pw_val); hipFree(m->d_pw_tile_ptr); hipFree(m->d_pw_span_tab);
     hipFree(m->d_pwr_idx); hipFree(m->d_pwr_val); hipFree(m->d_pwr_base); hipFree(m->d_pwr_tile_ptr); hipFree(m->d_pwr_diag);
     delete m;
 }
@@ -581,6 +581,7 @@ struct sl_neumann_state {
     // peers pull — run on the side stream with the "halo ready" ticket and the pulls behind them, the interior blocks beside them on
     // the main stream.  ov_edge = 0: off (one launch, then ticket and pulls)
     uint32_t ov_edge = 0, ov_tail = 0, ov_blocks = 0;
+    bool ov_rounds = false;       // the paced layout with edge-first rounds: ov_edge = rounds of the first launch, one launch for the rest
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     ~sl_neumann_state()
     {
@@ -649,7 +650,13 @@ sl_status dist_plan_overlap(sl_neumann_state &st)
     SL_TRY(sl_rows_geometry(sl_matrix_row_args(st.m), (sl_order)st.o.order, SL_EPI_NEUMANN, &R, &NB));
     const uint64_t W = d->max_reach;
     uint64_t edge = 0, real_blocks = 0;
-    bool mine = env != 0 && R != 0 && W > 0 && W < d->n_global && (d->c->world > 1 || env == 2) && sl_side_stream(sl_context());
+    // the paced layout with edge-first rounds (sl_matrix::pw_edge_rounds): what any neighbour pulls lies in the rows its first rounds cover
+    const bool rounds_form = (sl_order)st.o.order == SL_ORDER_CSR_SEQUENTIAL && st.m->d_pw_idx && st.m->pw_edge_rounds && !st.m->n_long;
+    bool mine = env != 0 && (R != 0 || rounds_form) && W > 0 && W < d->n_global && (d->c->world > 1 || env == 2) && sl_side_stream(sl_context());
+    if (mine && rounds_form) {
+        mine = W <= st.m->pw_edge_rows;
+        edge = st.m->pw_edge_rounds;
+    } else
     if (mine) {
         edge = (W + R - 1) / R + 1;                                     // + 1: the last block may be ragged
         real_blocks = (st.n + R - 1) / R;
@@ -661,7 +668,12 @@ sl_status dist_plan_overlap(sl_neumann_state &st)
     const uint64_t flag = mine ? 1 : 0;
     SL_TRY(sl_comm_allgather_blob(d->c, &flag, sizeof(flag), all.data()));
     for (uint64_t f : all) if (!f) mine = false;
-    if (mine) { st.ov_edge = (uint32_t)edge; st.ov_tail = (uint32_t)(real_blocks - edge); st.ov_blocks = NB; }
+    if (mine && rounds_form) { st.ov_edge = (uint32_t)edge; st.ov_rounds = true; }
+    else if (mine) { st.ov_edge = (uint32_t)edge; st.ov_tail = (uint32_t)(real_blocks - edge); st.ov_blocks = NB; }
+    if (mine && rounds_form)
+        sl_log(1, "partition: rank %d runs its edge rounds first, the exchange beside the interior (reach %llu, the first %u rounds of the paced layout cover %llu rows from either end)",
+               d->c->rank, (unsigned long long)W, st.ov_edge, (unsigned long long)st.m->pw_edge_rows);
+    else
     sl_log(1, "partition: rank %d %s (reach %llu, %u rows per block, %llu edge blocks of %llu)", d->c->rank,
            mine ? "runs its edge blocks first, the exchange beside the interior" : "exchanges after the whole step", (unsigned long long)W, R,
            (unsigned long long)(2 * edge), (unsigned long long)real_blocks);
@@ -698,13 +710,15 @@ sl_status dist_step(sl_neumann_state &st, sl_row_args a, sl_dist_vector *vec, do
     sl_row_args e = a;
     e.blk_lo = 0; e.blk_cnt = st.ov_edge;
     SL_TRY(sl_launch_rows(e, order, SL_EPI_NEUMANN, c.side, &nparts));
-    e.blk_lo = st.ov_tail; e.blk_cnt = st.ov_blocks - st.ov_tail;       // to the end of the grid: the padding blocks write their zero partials
-    SL_TRY(sl_launch_rows(e, order, SL_EPI_NEUMANN, c.side));
+    if (!st.ov_rounds) {
+        e.blk_lo = st.ov_tail; e.blk_cnt = st.ov_blocks - st.ov_tail;   // to the end of the grid: the padding blocks write their zero partials
+        SL_TRY(sl_launch_rows(e, order, SL_EPI_NEUMANN, c.side));
+    }
     SL_TRY(sl_comm_launch_ticket(D->c, nullptr, nullptr, ctl, rel, 0, SL_JUDGE_LOCAL, 0.0, c.side, 1));
     SL_TRY(sl_dist_pull(D, vec, c.side));
     SL_HIP(hipEventRecord(st.ev_side, c.side));
     sl_row_args in = a;
-    in.blk_lo = st.ov_edge; in.blk_cnt = st.ov_tail - st.ov_edge;
+    in.blk_lo = st.ov_edge; in.blk_cnt = st.ov_rounds ? 0xffffu : st.ov_tail - st.ov_edge;      // (rounds: to the last one)
     SL_TRY(sl_launch_rows(in, order, SL_EPI_NEUMANN, s));
     SL_HIP(hipStreamWaitEvent(s, st.ev_side, 0));
     SL_TRY(sl_launch_rows_reduce(a, SL_EPI_NEUMANN, nparts, s));

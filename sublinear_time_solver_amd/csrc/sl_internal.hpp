@@ -84,6 +84,20 @@ struct sl_matrix {
     // instead of all tiles), so that a block owns a contiguous range of rows and its waves walk the same narrow panels
     // (2^pw_pbits columns, a few KB of the vector) at the same time: the gathers become hits in the CU's L1
     uint32_t pw_deal = 0, pw_pbits = 16;
+    // XCD-local spans (locality-bounded columns far beyond the L2: |i - j| <= w with w in the 10^5..10^6s): pw_xcd = G > 0 deals a run of
+    // row groups among the tiles of the cus / G blocks that share an L2 (block b runs on XCD b % G), so that an XCD's waves gather from
+    // the columns of ITS rows +- w only — fewer first touches per L2 and more entries per panel; the kernel maps blockIdx.x to the
+    // logical block (b % G) * (blocks / G) + b / G
+    uint32_t pw_xcd = 0;
+    // With pw_xcd the spans are explicit: d_pw_span_tab[2 p], [2 p + 1] = first row group and number of row groups of PHYSICAL span p
+    // (the span that tiles [p * deal, (p + 1) * deal) carry; physical span p runs in round p / G on XCD p % G).  For a rank's rows of
+    // a partition the order is EDGE FIRST: the spans holding the rows within the bandwidth of either end of the range (what the
+    // neighbours pull) — sized to cover exactly that — take the first pw_edge_rounds rounds, the interior spans the rest.  The partitioned
+    // step launches the edge rounds first and exchanges beside the interior rounds (sl_api.hip, dist_step).  pw_edge_rows = rows from
+    // either end that the edge rounds are sure to cover; pw_edge_rounds = 0: row order, no such split.
+    uint32_t *d_pw_span_tab = nullptr;
+    uint32_t pw_edge_rounds = 0;
+    uint64_t pw_edge_rows = 0;
     bool pw_band = false;               // the wide-band form (block-local rows, narrow panels)
     uint32_t pw_slack = 4;              // panels a wave may gather ahead of the slowest wave of its block: about two chunks of its stream
     // ORDER-FREE column stream (SL_MATRIX_ORDER_ANY / SL_ORDER_ANY, round 3): ONE persistent 16-wave block per CU owns a BLOCK tile of
@@ -303,7 +317,9 @@ struct sl_row_args {
     // paced column-panel layout (null unless the matrix carries one)
     const uint32_t *pw_idx; const double *pw_val; const uint32_t *pw_tile_ptr;
     uint32_t pw_tiles, pw_rpw, pw_blocks;
-    uint32_t pw_deal, pw_pbits; // tiles a run of row groups is dealt among (all tiles, or the 16 of a block); log2 of the panel width
+    uint32_t pw_deal, pw_pbits; // tiles a run of row groups is dealt among (all tiles, the tiles of one XCD's blocks, or the 16 of a block); log2 of the panel width
+    uint32_t pw_xcd;          // > 0: blocks b, b + G, b + 2 G, ... (one XCD) are logical neighbours (sl_matrix::pw_xcd)
+    const uint32_t *pw_span_tab;   // explicit spans (sl_matrix::d_pw_span_tab; null: spans of deal * rpw rows in row order); with it blk_lo / blk_cnt select ROUNDS of the paced kernel
     uint32_t pw_slack;        // panels a wave may run ahead of the slowest wave of its block (set by the launcher; >= 2^20: no pacing)
     // order-free column stream (null unless the matrix carries one)
     const uint32_t *pwr_idx, *pwr_base, *pwr_tile_ptr; const double *pwr_val, *pwr_diag;

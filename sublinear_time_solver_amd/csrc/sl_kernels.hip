@@ -902,10 +902,15 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
     __syncthreads();
     const double *__restrict__ g = a.gather;
     const uint32_t nblocks = gridDim.x;
+    // XCD-local spans: the hardware deals workgroups to the XCDs round robin (block b on XCD b % G), the layout deals a span of rows among
+    // nblocks / G consecutive LOGICAL blocks — so blocks b, b + G, b + 2 G, ... become logical neighbours and share their L2's panels
+    const uint32_t lblock = a.pw_xcd ? (blockIdx.x % a.pw_xcd) * (nblocks / a.pw_xcd) + blockIdx.x / a.pw_xcd : blockIdx.x;
     const uint32_t rounds = (a.pw_tiles + nblocks * SL_PW_WAVES - 1) / (nblocks * SL_PW_WAVES);
+    // a range of ROUNDS (blk_cnt != 0; layouts with edge-first rounds): the partitioned step runs the edge rounds first, the exchange beside the rest
+    const uint32_t round_lo = a.blk_cnt ? a.blk_lo : 0u, round_hi = a.blk_cnt ? min(rounds, a.blk_lo + a.blk_cnt) : rounds;
     double part0 = 0.0, part1 = 0.0;
-    for (uint32_t round = 0; round < rounds; ++round) {
-        const uint32_t tile = (round * nblocks + blockIdx.x) * SL_PW_WAVES + wave;
+    for (uint32_t round = round_lo; round < round_hi; ++round) {
+        const uint32_t tile = (round * nblocks + lblock) * SL_PW_WAVES + wave;
         if (tile >= a.pw_tiles) { if (lane == 0) prog_st(wave, 0xffffffffu); continue; }     // nothing to wait for
         for (uint32_t r = lane; r <= rpw; r += 64) acc[r] = 0.0;
         const uint32_t ch0 = a.pw_tile_ptr[tile], chunks = a.pw_tile_ptr[tile + 1] - ch0;
@@ -982,9 +987,15 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         }
         if (lane == 0) prog_st(wave, (round + 1u) << 20);            // as far along as the round's end while the vectors are written
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // groups of SL_PW_GROUP rows are dealt among `deal` tiles: a span owns the row groups [g0, g0 + gcnt) — deal * rpw consecutive rows
+        // in row order, or what the span table says (XCD-local spans, edge-first rounds)
+        const uint32_t ps = tile / deal;
+        const uint64_t g0 = a.pw_span_tab ? a.pw_span_tab[2 * ps] : (uint64_t)ps * deal * (rpw / SL_PW_GROUP);
+        const uint32_t gcnt = a.pw_span_tab ? a.pw_span_tab[2 * ps + 1] : deal * (rpw / SL_PW_GROUP);
         for (uint32_t r = lane; r < rpw; r += 64) {                   // slot r = group r / 16 of the tile, row r % 16 of the group
-            // groups of SL_PW_GROUP rows are dealt among `deal` tiles: span = tile / deal owns deal * rpw consecutive rows
-            const uint64_t i = ((uint64_t)(tile / deal) * deal * (rpw / SL_PW_GROUP) + (uint64_t)(r / SL_PW_GROUP) * deal + tile % deal) * SL_PW_GROUP + (r % SL_PW_GROUP);
+            const uint32_t gl = (r / SL_PW_GROUP) * deal + tile % deal;
+            if (gl >= gcnt) continue;                                 // (a span shorter than its tiles' slots)
+            const uint64_t i = (g0 + gl) * SL_PW_GROUP + (r % SL_PW_GROUP);
             if (i >= a.n_rows || (a.n_long && a.row_len[i] == SL_LONG_SENTINEL)) continue;
             if constexpr (PWV & 8) { part0 += acc[r]; continue; }
             double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
@@ -994,7 +1005,8 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
             sl_row_epilogue<EPI>(a, i, acc[r], e_t, e_d, e_x, dself, part0, part1);
         }
     }
-    sl_block_partials<EPI, SL_PW_WAVES>(a, red, lane, wave, blockIdx.x, a.part_stride, part0, part1);
+    // (a range of rounds that does not start at round 0 = the second of two launches: its own set of partial sums behind the first's)
+    sl_block_partials<EPI, SL_PW_WAVES>(a, red, lane, wave, blockIdx.x + (round_lo ? nblocks : 0u), a.part_stride, part0, part1);
 }
 
 
@@ -1480,13 +1492,14 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
     }
     const band_geom g = pick_band<ORDER, EPI>(a);
     const uint32_t range_cnt = a.blk_cnt;                              // != 0: a range of the blocks (band and general kernel only)
-    if (range_cnt && (a.n_long || (ORDER == 0 && ((a.pw_idx && a.pw_tiles) || (a.pan_tile_ptr && a.n_pan_tiles) || (!g.spw && mpass_eligible(a))))))
+    const bool pw_rounds = ORDER == 0 && a.pw_idx && a.pw_tiles && a.pw_span_tab;       // explicit spans of the paced layout (edge-first rounds): ranges are rounds
+    if (range_cnt && (a.n_long || (ORDER == 0 && !pw_rounds && ((a.pw_idx && a.pw_tiles) || (a.pan_tile_ptr && a.n_pan_tiles) || (!g.spw && mpass_eligible(a))))))
         return sl_fail(SL_UNSUPPORTED_FORMAT, "this matrix layout has no range launches");
     if (ORDER == 0 && a.pw_idx && a.pw_tiles) {
         const uint32_t lds = (uint32_t)(SL_PW_WAVES * ((size_t)a.pw_rpw + 1) * sizeof(double));
         SL_TRY(set_max_lds_once<sl_pw_kernel<EPI>>((int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double))));
         if (knobs().pw_slack) a.pw_slack = knobs().pw_slack;               // A/B knob; 1048576 = no pacing
-        *nparts = a.pw_blocks + a.n_long;
+        *nparts = range_cnt ? 2 * a.pw_blocks : a.pw_blocks + a.n_long;        // two launches (edge rounds, the rest), a set of partial sums each
         a.part_stride = *nparts;
 #ifdef SL_PWR_VARIANTS
         static const bool pw_any = [] { const char *e = getenv("SL_PW_ANY"); return e && *e == '1'; }();

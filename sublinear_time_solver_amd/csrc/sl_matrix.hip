@@ -361,7 +361,7 @@ static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr,
 // keys and per-tile entry counts for the paced layout: groups of SL_PW_GROUP rows dealt round robin to n_tiles tiles
 __global__ __launch_bounds__(256) void sl_pw_keys_kernel(uint64_t n_rows, uint32_t n_panels, uint32_t n_tiles, const uint32_t *row_ptr, const uint32_t *col_idx,
                                                          const uint32_t *row_len, uint32_t *key, uint16_t *rowl, uint32_t *count, uint32_t deal, uint32_t gpt,
-                                                         uint32_t pbits)
+                                                         uint32_t pbits, const uint32_t *span_g0, const uint32_t *span_phys, uint32_t n_spans)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
@@ -370,7 +370,13 @@ __global__ __launch_bounds__(256) void sl_pw_keys_kernel(uint64_t n_rows, uint32
         const bool is_long = row_len[i] == SL_LONG_SENTINEL;
         // group q of SL_PW_GROUP rows: span q / (deal * gpt) owns `deal` tiles (gpt = groups per tile), its groups go round them
         const uint64_t q = i / SL_PW_GROUP;
-        const uint64_t span = q / ((uint64_t)deal * gpt), ql = q % ((uint64_t)deal * gpt);
+        uint64_t span = q / ((uint64_t)deal * gpt), ql = q % ((uint64_t)deal * gpt);
+        if (span_g0) {                                                       // explicit spans (a few dozen): span_g0[s] <= q < span_g0[s + 1]
+            uint32_t sp = 0;
+            while (sp + 1 < n_spans && q >= span_g0[sp + 1]) ++sp;
+            span = span_phys[sp];                                            // its place in the launch (edge-first rounds)
+            ql = q - span_g0[sp];
+        }
         const uint32_t tile = (uint32_t)(span * deal + ql % deal);
         const uint16_t rl = (uint16_t)((ql / deal) * SL_PW_GROUP + i % SL_PW_GROUP);
         for (uint32_t k = s + lane; k < e; k += 64u) {
@@ -452,9 +458,63 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     const uint64_t rounds = (n_groups + waves * max_groups - 1) / (waves * max_groups);
     uint64_t n_tiles = std::min<uint64_t>(rounds * waves, n_groups);                        // every tile of every round carries work
     if (band_pbits) n_tiles = (n_tiles + SL_PW_WAVES - 1) / SL_PW_WAVES * SL_PW_WAVES;       // whole blocks: a block's 16 tiles share its rows
-    const uint32_t gpt = (uint32_t)((n_groups + n_tiles - 1) / n_tiles);                    // groups per tile
+    // XCD-local spans (sl_matrix::pw_xcd): columns bounded by a bandwidth far beyond the L2 but well inside the matrix — a span of rows is
+    // dealt among the tiles of ONE XCD's blocks of one round, and that L2 sees the columns of those rows +- w only.  What it buys is entries
+    // per (tile, panel), not fewer first touches (those get dearer as they get fewer: no other XCD has pulled the line into the memory-side
+    // cache a moment earlier).  Measured at 10^7 x 16, ms per step without / with: ONE RANK'S ROWS of the 8 * 10^7 system at w = 2.5 * 10^6
+    // (15 million columns walked = 229 panels, 85 entries per tile and panel) 1.159 / 1.046; the whole 10^7 system (153 panels, 127 entries)
+    // w = 6 * 10^5 0.944 / 0.962, 10^6 0.946 / 0.959, 2.5 * 10^6 0.953 / 0.936 — so: only where the tiles would meet fewer than ~110 entries
+    // per panel and the span cuts the panels by 40 % or more.  SL_PW_XCD = G: the number of L2s to assume (forced builds: tests on pretended
+    // devices; 0 = never).
+    uint32_t xcd = 0;
+    if (!band_pbits && m->bandwidth != ~0ull && rounds * waves <= n_groups && nnz) {
+        uint32_t G = 8;
+        if (const char *e = getenv("SL_PW_XCD")) G = (uint32_t)atoi(e);
+        if (G >= 2 && cus % G == 0) {
+            const uint64_t span_cols = (waves / G) * (uint64_t)SL_PW_MAX_ROWS + 2 * m->bandwidth, walked = std::min<uint64_t>(m->n_cols, n + 2 * m->bandwidth);
+            const double per_panel = (double)nnz / (double)(rounds * waves) / (double)((walked >> SL_PANEL_COL_BITS) + 1);
+            if (force ? getenv("SL_PW_XCD") != nullptr : (per_panel < 110.0 && 5 * span_cols <= 3 * walked)) xcd = G;
+        }
+    }
+    if (xcd) n_tiles = (n_tiles + waves / xcd - 1) / (waves / xcd) * (waves / xcd);         // whole spans
+    const uint32_t deal = band_pbits ? (uint32_t)SL_PW_WAVES : xcd ? (uint32_t)(waves / xcd) : (uint32_t)n_tiles;
+    uint32_t gpt = (uint32_t)((n_groups + n_tiles - 1) / n_tiles);                          // groups per tile
+    // XCD-local spans are explicit (d_pw_span_tab).  EDGE FIRST where the matrix leaves an interior: E spans at either end sized to cover
+    // the rows within the bandwidth of the range's ends (+ a group: the ends need not fall on group boundaries), the rest shared by the
+    // S - 2 E interior spans; launch order = low edge, high edge, interior, so that the edge takes the first ceil(2 E / G) rounds (the
+    // first interior spans ride along when 2 E is no multiple of G).  Only if that keeps the spans balanced (an edge span >= 90 % of an
+    // interior span: a round is as long as its longest span) and leaves at least one round without edge spans.
+    std::vector<uint32_t> span_g0, phys_of_log, span_tab;
+    uint32_t edge_rounds = 0;
+    uint64_t edge_rows = 0;
+    if (xcd) {
+        const uint64_t S = n_tiles / deal, cap = (uint64_t)deal * max_groups, nominal = (n_groups + S - 1) / S;
+        const uint64_t bwg = (m->bandwidth + SL_PW_GROUP - 1) / SL_PW_GROUP + 1;
+        const uint64_t E = (bwg + nominal - 1) / nominal, edge_g = (bwg + E - 1) / E;
+        uint64_t interior_g = 0;
+        bool edge_first = 2 * E < S && (2 * E + xcd - 1) / xcd < S / xcd && n_groups > 2 * E * edge_g;
+        if (edge_first) {
+            interior_g = (n_groups - 2 * E * edge_g + (S - 2 * E) - 1) / (S - 2 * E);
+            edge_first = interior_g <= cap && edge_g <= cap && 10 * edge_g >= 9 * interior_g && 10 * interior_g >= 9 * edge_g;
+        }
+        span_g0.resize(S + 1); phys_of_log.resize(S); span_tab.resize(2 * S);
+        if (edge_first) {
+            for (uint64_t q = 0; q <= E; ++q) span_g0[q] = (uint32_t)(q * edge_g);
+            for (uint64_t q = 1; q <= S - 2 * E; ++q) span_g0[E + q] = (uint32_t)std::min<uint64_t>(E * edge_g + q * interior_g, n_groups - E * edge_g);
+            for (uint64_t q = 1; q <= E; ++q) span_g0[S - E + q] = (uint32_t)(n_groups - E * edge_g + q * edge_g);
+            for (uint64_t q = 0; q < E; ++q) { phys_of_log[q] = (uint32_t)q; phys_of_log[S - E + q] = (uint32_t)(E + q); }
+            for (uint64_t q = E; q < S - E; ++q) phys_of_log[q] = (uint32_t)(E + q);
+            edge_rounds = (uint32_t)((2 * E + xcd - 1) / xcd);
+            edge_rows = E * edge_g * SL_PW_GROUP - SL_PW_GROUP;             // from either end, whatever the alignment of the last group
+            gpt = (uint32_t)((std::max(edge_g, interior_g) + deal - 1) / deal);
+        } else {
+            for (uint64_t q = 0; q <= S; ++q) span_g0[q] = (uint32_t)std::min<uint64_t>(q * nominal, n_groups);
+            for (uint64_t q = 0; q < S; ++q) phys_of_log[q] = (uint32_t)q;
+            gpt = (uint32_t)((nominal + deal - 1) / deal);
+        }
+        for (uint64_t q = 0; q < S; ++q) { span_tab[2 * phys_of_log[q]] = span_g0[q]; span_tab[2 * phys_of_log[q] + 1] = span_g0[q + 1] - span_g0[q]; }
+    }
     const uint32_t rpw = gpt * SL_PW_GROUP;
-    const uint32_t deal = band_pbits ? (uint32_t)SL_PW_WAVES : (uint32_t)n_tiles;
     // wide band: a block of 16 tiles owns deal * rpw consecutive rows and walks the columns of those rows +- the bandwidth.  The panel
     // width is the smallest (from 2^9 = 4 KB of vector) that gives a tile ~90 entries per panel (tools/ab_band_paced*.sh, n = 10^7 x 16,
     // ms per step 2^9 / 2^10 / 2^11: w = 12 000 0.473 / 0.536 / 0.677, 32 768 0.499 / 0.532 / 0.675, 100 000 0.634 / 0.592 / 0.731);
@@ -477,8 +537,15 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     SL_TRY(rowl.alloc_owned(nnz * 2)); SL_TRY(cnt.alloc_owned((n_tiles + 1) * 4)); SL_TRY(pads.alloc_owned((n_tiles + 1) * 4));
     const uint32_t g = grid_for(nnz, 256) > 8192 ? 8192 : grid_for(nnz, 256);
     SL_HIP(hipMemsetAsync(cnt.p, 0, (n_tiles + 1) * 4, st));
+    DevBuf d_span_g0, d_span_phys;
+    if (xcd) {
+        SL_TRY(d_span_g0.alloc_owned(span_g0.size() * 4)); SL_TRY(d_span_phys.alloc_owned(phys_of_log.size() * 4));
+        SL_HIP(hipMemcpyAsync(d_span_g0.p, span_g0.data(), span_g0.size() * 4, hipMemcpyHostToDevice, st));
+        SL_HIP(hipMemcpyAsync(d_span_phys.p, phys_of_log.data(), phys_of_log.size() * 4, hipMemcpyHostToDevice, st));
+    }
     hipLaunchKernelGGL(sl_pw_keys_kernel, dim3(g), dim3(256), 0, st, n, (uint32_t)n_panels, (uint32_t)n_tiles, d_row_ptr, d_col_idx, m->d_row_len,
-                       key.as<uint32_t>(), rowl.as<uint16_t>(), cnt.as<uint32_t>(), deal, gpt, pbits);
+                       key.as<uint32_t>(), rowl.as<uint16_t>(), cnt.as<uint32_t>(), deal, gpt, pbits, d_span_g0.as<uint32_t>(), d_span_phys.as<uint32_t>(),
+                       (uint32_t)phys_of_log.size());
     std::vector<uint32_t> count(n_tiles + 1), src(n_tiles + 1), dst(n_tiles + 1), hpads(n_tiles + 1);
     SL_HIP(hipMemcpyAsync(count.data(), cnt.p, n_tiles * 4, hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
@@ -526,8 +593,13 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
         const uint32_t cap = std::max<uint32_t>(1u, (2048u >> pbits) ? (2048u >> pbits) - 1u : 1u);
         m->pw_slack = std::min<uint32_t>(cap, std::max<uint32_t>(1u, (uint32_t)(per_chunk + 0.5)));
     }
-    m->pw_deal = deal; m->pw_pbits = pbits; m->pw_band = band_pbits != 0;
-    m->pw_blocks = (uint32_t)std::min<uint64_t>(cus, (n_tiles + SL_PW_WAVES - 1) / SL_PW_WAVES);
+    m->pw_deal = deal; m->pw_pbits = pbits; m->pw_band = band_pbits != 0; m->pw_xcd = xcd;
+    if (xcd) {
+        SL_HIP(hipMalloc(&m->d_pw_span_tab, span_tab.size() * 4));
+        SL_HIP(hipMemcpy(m->d_pw_span_tab, span_tab.data(), span_tab.size() * 4, hipMemcpyHostToDevice));
+        m->pw_edge_rounds = edge_rounds; m->pw_edge_rows = edge_rows;
+    }
+    m->pw_blocks = (uint32_t)std::min<uint64_t>(cus, (n_tiles + SL_PW_WAVES - 1) / SL_PW_WAVES);       // (xcd: n_tiles >= cus * 16, whole spans: = cus)
     m->device_bytes += chunks * 256 * 12 + (n_tiles + 1) * 4;
     return SL_OK;
 }

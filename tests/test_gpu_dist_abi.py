@@ -48,6 +48,25 @@ def test_boundary_first_step_gives_the_same_bits(gpu, dist_exe, world, n, w, ove
     assert ("runs its edge blocks first" in r.stderr) == expect, r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("world,n,w,forced,expect", [(2, 1_200_000, 30_000, True, True),        # pretended 8-CU device with 4 L2 groups: 4 rounds, the first one = the edge
+                                                     (4, 3_000_000, 60_000, True, True),
+                                                     (3, 2_000_000, 25_000, True, False),       # unequal ranges: one rank has a single round, so nobody splits
+                                                     (2, 20_000_000, 2_500_000, False, True)])  # SURVEY 8(e)'s C5 structure at its own size per rank: w = n_local / 4
+def test_paced_layout_runs_its_edge_rounds_first(gpu, dist_exe, world, n, w, forced, expect):
+    """locality-bounded columns far beyond the L2 (the paced layout with XCD-local spans): a rank's rows within w of its range ends sit in
+    the spans of the FIRST rounds; the partitioned step launches those rounds, hands the halo ticket out and pulls beside the remaining
+    rounds.  Same iteration count and solution bits as the one-GPU solve (checked inside dist_smoke), with the split and without it."""
+    env = dict(os.environ, SL_COMM_TIMEOUT_MS="120000", SL_LOG="1")
+    if forced:
+        env.update(SL_COLUMN_PANELS="1", SL_PW_FORCE="1", SL_PW_CUS="8", SL_PW_XCD="4")
+    for overlap in ("1", "0"):
+        r = subprocess.run([str(dist_exe), str(world), str(n), str(w)] + (["uneven"] if world == 3 else []), capture_output=True, text=True, timeout=600,
+                           env=dict(env, SL_DIST_OVERLAP=overlap))
+        assert r.returncode == 0 and "dist_smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        assert "paced column panels" in r.stderr
+        assert ("runs its edge rounds first" in r.stderr) == (expect and overlap == "1"), r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("halo", ["", "allreduce"])
 def test_rccl_transport_of_the_library_at_world_one(gpu, dist_exe, halo):
     """SL_COMM_TRANSPORT=rccl: librccl resolved at run time, ncclCommInitRank with the id passed through the shared block, the

@@ -111,9 +111,11 @@ def test_headline_instances_sampled_rows(gpu, w):
     assert rec["column_panels"] == {4096: 0, 0: 2, 32768: 3}[w]
 
 
-@pytest.mark.parametrize("w", [4096, 0], ids=["band4096", "uniform"])
+@pytest.mark.parametrize("w", [4096, 0, 2_500_000], ids=["band4096", "uniform", "locality_n_over_4P"])
 def test_c5_interior_rank_slice(gpu, w):
-    """Rank 3 of 8 of config 5: 10^7 rows at row offset 3*10^7 of the n = 8*10^7 system, n_cols = 8*10^7."""
+    """Rank 3 of 8 of config 5: 10^7 rows at row offset 3*10^7 of the n = 8*10^7 system, n_cols = 8*10^7.  w = 2.5 * 10^6 is SURVEY
+    8(e)'s halo variant of C5 (locality w = n / (4 P)): gathers spread over 40 MB of the vector — far beyond any cache — but a halo of
+    2 w entries per neighbour instead of every row of every rank."""
     n, r = 80_000_000, 3
     lo, hi = r * 10_000_000, (r + 1) * 10_000_000
     _fused_step_sampled(n, lo, hi, 16, 1, w, (0, 5_000_011, hi - lo - 4096), f"C5 rank {r}/8 w={w}")

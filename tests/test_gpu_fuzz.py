@@ -126,3 +126,32 @@ def test_paced_panels_random_structures_bitwise(gpu, monkeypatch, rows, cols, ki
         g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-11))
         o = O.neumann_solve(rp, ci, va, b, tolerance=1e-11)
         assert (g.iterations, g.converged) == (o["iterations"], o["converged"]) and _bits_equal(g.solution, o["x"])
+
+
+# ---- XCD-local spans of the paced layout (sl_matrix::pw_xcd) ------------------------------------------------------------------------
+@pytest.mark.parametrize("n,k,w,cus,groups,lo,hi", [(40_000, 16, 3_000, 4, 2, 0, 40_000), (50_003, 8, 9_000, 8, 4, 0, 50_003), (30_000, 5, 500, 8, 8, 0, 30_000),
+                                                    (200_000, 16, 20_000, 4, 4, 60_000, 130_000), (66_000, 12, 30_000, 6, 3, 0, 66_000)])
+def test_paced_panels_with_spans_dealt_inside_one_l2_bitwise(gpu, monkeypatch, n, k, w, cus, groups, lo, hi):
+    """locality-bounded columns on the paced layout with a span of rows dealt among the blocks of ONE L2 (blocks b, b + G, ... are logical
+    neighbours): forced on small banded systems on pretended devices of `cus` CUs in `groups` L2 groups, several rounds, also one rank's
+    rows of a larger system — SpMV in the CSR order, the fused solve, the residual, dense push rounds: bit for bit"""
+    from sublinear_time_solver_amd import generators as G
+    monkeypatch.setenv("SL_PW_FORCE", "1")
+    monkeypatch.setenv("SL_PW_CUS", str(cus))
+    monkeypatch.setenv("SL_PW_XCD", str(groups))
+    rp, ci, va, b = G.sdd_rows(n, k, 3, w, lo, hi)
+    m = S.SparseMatrix.from_csr(rp, ci, va, hi - lo, n, row_offset=lo, column_panels=True, with_transpose=(lo == 0 and hi == n))
+    assert m.info().column_panels == 2
+    rng = np.random.default_rng(n + w)
+    for rep in range(2):
+        x = rng.standard_normal(n)
+        assert _bits_equal(m.multiply_vector(x), O.spmv(rp, ci, va, x)), rep
+    if lo == 0 and hi == n:
+        g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-11))
+        o = O.neumann_solve(rp, ci, va, b, tolerance=1e-11)
+        assert (g.iterations, g.converged) == (o["iterations"], o["converged"]) and _bits_equal(g.solution, o["x"])
+        assert abs(g.residual_norm - o["residual_norm"]) <= 1e-12 * o["residual_norm"]
+        bs = b * (np.arange(n) % 3 == 0)
+        p = S.PushSolver(theta=1e-9, dense_switch=1e-12).solve(m, bs)
+        q = O.push_sync_solve(rp, ci, va, bs, theta=1e-9)
+        assert (p["rounds"], p["pushes"]) == (q["rounds"], q["pushes"]) and _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])
