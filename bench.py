@@ -243,18 +243,25 @@ def main_abi(args, world, rank, local_rank, attempt=0):
         transport = ("rccl" + ("+halo-allreduce" if ci_.halo_allreduce else "")) if ci_.transport == 1 else "ipc"
         n_local, k = args.n, args.k
         n_global = n_local * world
-        w_head = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
+        # N = 1: BASELINE configs[2], uniform columns.  N > 1: BASELINE configs[4] in the form north_star and SURVEY 8(e) give it — the halo
+        # only travels: columns within w = n / (4 P) = n_local / 4 of the row (gathers spread over 40 MB of the vector at n_local = 10^7,
+        # far beyond any cache: the same kernel class and, at N = 1, the same time per step as uniform columns — 0.940 against 0.944 ms,
+        # profiles/r03_c5_locality.txt); the uniform-column form (every rank needs every row: an all-gather) and the narrow band are
+        # measured in the same job and reported beside it
+        w_c5 = max(n_local // 4, 1)
+        w_head = args.bandwidth if args.bandwidth >= 0 else (DEFAULT_BANDWIDTH if world == 1 else w_c5)
         m = _abi_measure(args, lib, L, torch, dev, comm, world, rank, w_head)
         if m["pieces_bad"]:
             raise RuntimeError(f"exchange verification failed: {m['pieces_bad']} pieces differ from their owners' copies (transport {transport})")
-        other = None
-        if not args.no_sweep and (world > 1 or w_head != BANDED_BANDWIDTH):      # the other column structure of the recipe in the same job
-            w_other = BANDED_BANDWIDTH if w_head == 0 else 0
-            if world > 1:
+        variants = []
+        if not args.no_sweep and world > 1:                                        # the other column structures of the recipe in the same job
+            for w_other in (0, w_c5, BANDED_BANDWIDTH):
+                if w_other == w_head:
+                    continue
                 mo = _abi_measure(args, lib, L, torch, dev, comm, world, rank, w_other)
                 if mo["pieces_bad"]:
-                    raise RuntimeError(f"exchange verification failed on the second column structure: {mo['pieces_bad']} pieces (transport {transport})")
-                other = (w_other, mo)
+                    raise RuntimeError(f"exchange verification failed on column structure w = {w_other}: {mo['pieces_bad']} pieces (transport {transport})")
+                variants.append((w_other, mo))
         if rank != 0:
             return
         nnz_total = n_global * k
@@ -262,7 +269,8 @@ def main_abi(args, world, rank, local_rank, attempt=0):
         launch_ms = m.get("kern_ms", m["dev_ms"] / args.steps)
         achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
         value = nnz_total * args.steps / m["elapsed"]
-        name_of = lambda w: "uniform columns" if w == 0 else f"band half-width {w}"
+        name_of = lambda w: ("uniform columns" if w == 0 else
+                             f"columns within n/(4P) = {w} of the row (config 5's locality-bounded form, SURVEY 8(e))" if (w == w_c5 and world > 1) else f"band half-width {w}")
         traffic, traffic_source = recorded_traffic(n_local, k, w_head) if world == 1 else (None, None)
         kernel = LAYOUTS.get(m["panels"], "row slices") if m["panels"] else ("LDS-window band kernel" if 0 < w_head <= 9400 else "row-slice general kernel")
         exchange = f"abi: sl_comm, transport {transport}" + (" (one rank: tickets of one, no peers)" if world == 1 else
@@ -296,16 +304,16 @@ def main_abi(args, world, rank, local_rank, attempt=0):
             out["roofline"]["l2_request"] = {"bound": "l2 requests (one 128-byte request per 8-byte gather)", "requests_per_launch": req,
                                             "peak_requests_per_s": L2_REQUEST_RATE, "floor_ms": floor_ms, "frac": floor_ms / launch_ms,
                                             "source": "tools/gather_bench.hip: 265-280 G gathers/s from L2-resident tables = 34.5 TB/s / 128 B (profiles/r01_gather_bench.txt, r02_panel2_prototype.txt)"}
-        if other is not None:
-            w_o, mo = other
-            out["halo_variant" if w_o else "uniform_variant"] = {
-                "half_bandwidth": w_o, "column_structure": name_of(w_o) + (" (config 5's halo variant: only the strips at the range boundaries travel)" if w_o else ""),
+        for w_o, mo in variants:
+            key = "uniform_variant" if w_o == 0 else "halo_variant" if w_o == BANDED_BANDWIDTH else "locality_variant"
+            out[key] = {
+                "half_bandwidth": w_o, "column_structure": name_of(w_o) + (" — only the strips at the range boundaries travel" if w_o else " — every rank needs every row: all-gather"),
                 "value": nnz_total * args.steps / mo["elapsed"], "unit": "nnz*iter/s", "ms_per_step": mo["elapsed"] * 1e3 / args.steps,
                 "device_ms_per_step_slowest_rank": mo["dev_ms"] / args.steps, "exchange_verified": bool(mo["verified"] and not mo["pieces_bad"]),
                 "roofline_frac_per_gpu": per_launch_bytes / (mo["dev_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, "last_term_norm": mo["norm"],
                 "bytes_received_per_rank_per_step": (8 * n_local * (world - 1)) if w_o == 0 else 8 * w_o * min(2, world - 1)}
         if world == 1 and not args.no_sweep:
-            others = [v for v in (0, BANDED_BANDWIDTH, 512, 32768) if v != w_head]
+            others = [v for v in (0, BANDED_BANDWIDTH, 512, 32768, w_c5) if v != w_head]      # w_c5: the per-GPU structure of the N > 1 lines, on one GPU
             sweep = column_structure_sweep(lib, L, torch, dev, n_local, k, args.seed, args.order, others)
             out["config"]["other_column_structures"] = sweep
             bk = f"w{BANDED_BANDWIDTH}"

@@ -482,8 +482,9 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     // XCD-local spans are explicit (d_pw_span_tab).  EDGE FIRST where the matrix leaves an interior: E spans at either end sized to cover
     // the rows within the bandwidth of the range's ends (+ a group: the ends need not fall on group boundaries), the rest shared by the
     // S - 2 E interior spans; launch order = low edge, high edge, interior, so that the edge takes the first ceil(2 E / G) rounds (the
-    // first interior spans ride along when 2 E is no multiple of G).  Only if that keeps the spans balanced (an edge span >= 90 % of an
-    // interior span: a round is as long as its longest span) and leaves at least one round without edge spans.
+    // first interior spans ride along when 2 E is no multiple of G).  Only if the interior spans grow by no more than 5 % for it (a round
+    // is as long as its longest span: edge spans shorter than their share leave the interior more rows) and at least one round has no
+    // edge spans.
     std::vector<uint32_t> span_g0, phys_of_log, span_tab;
     uint32_t edge_rounds = 0;
     uint64_t edge_rows = 0;
@@ -495,7 +496,7 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
         bool edge_first = 2 * E < S && (2 * E + xcd - 1) / xcd < S / xcd && n_groups > 2 * E * edge_g;
         if (edge_first) {
             interior_g = (n_groups - 2 * E * edge_g + (S - 2 * E) - 1) / (S - 2 * E);
-            edge_first = interior_g <= cap && edge_g <= cap && 10 * edge_g >= 9 * interior_g && 10 * interior_g >= 9 * edge_g;
+            edge_first = interior_g <= cap && edge_g <= cap && 20 * interior_g <= 21 * nominal;      // (edge_g <= nominal by construction)
         }
         span_g0.resize(S + 1); phys_of_log.resize(S); span_tab.resize(2 * S);
         if (edge_first) {

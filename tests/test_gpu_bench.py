@@ -81,9 +81,13 @@ def test_bench_starts_its_own_ranks(gpu):
     assert a["n_gpus"] == 2 and a["steps"] == 5 and a["warmup"] == 5 and cfg["n_global"] == 600000 and a["scaling"] == "weak"
     assert cfg["n_ranks_joined"] == 2 and len(cfg["devices"]) == 2 and cfg["transport"] == "ipc" and cfg["exchange_verified"] is True
     assert cfg["launcher"]["self_launched_ranks"] == 2 and cfg["launcher"]["attempts"][-1]["ok"]
-    assert a["halo_variant"]["exchange_verified"] is True and a["halo_variant"]["value"] > 0
+    # N > 1 defaults to config 5's locality-bounded form (columns within n_local / 4 of the row); the all-gather form and the narrow band beside it
+    assert cfg["half_bandwidth"] == 75000 and "locality-bounded" in cfg["workload"]
+    for key in ("halo_variant", "uniform_variant"):
+        assert a[key]["exchange_verified"] is True and a[key]["value"] > 0
+    assert a["uniform_variant"]["bytes_received_per_rank_per_step"] == 8 * 300000 and cfg["bytes_received_per_rank_per_step"] == 8 * 75000
     assert abs(a["value"] - 600000 * 16 * 5 / (a["ms_per_step"] * 5e-3)) <= 1e-6 * a["value"]
-    one = subprocess.run([sys.executable, "bench.py", "--rows", "600000", "--steps", "5", "--no-cpu-baseline", "--no-sweep"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    one = subprocess.run([sys.executable, "bench.py", "--rows", "600000", "--steps", "5", "--bandwidth", "75000", "--no-cpu-baseline", "--no-sweep"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     b = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert b["n_gpus"] == 1 and b["config"]["n_ranks_joined"] == 1 and b["config"]["transport"] == "ipc"      # N = 1 runs the same host path
