@@ -48,11 +48,17 @@ def main():
             overlap = str(rng.choice(["0", "1"]))
             cmd = [str(exe), str(world), str(n), str(w)] + (["uneven"] if uneven else [])
             env = dict(os.environ, SL_COMM_TIMEOUT_MS="60000", SL_DIST_OVERLAP=overlap, SL_LOG="1")
+            if n >= 400000 and rng.random() < 0.5:            # the paced layout with XCD-local spans forced on every rank (a pretended small device)
+                cus = int(rng.choice([4, 8, 12]))
+                env.update(SL_COLUMN_PANELS="1", SL_PW_FORCE="1", SL_PW_CUS=str(cus), SL_PW_XCD=str(int(rng.choice([2, 4]))))
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
                 ok = r.returncode == 0 and "dist_smoke ok" in r.stdout
                 tail = (r.stdout[-600:] + r.stderr[-1200:]) if not ok else ""
-                form = "edge blocks first" if "runs its edge blocks first" in r.stderr else "exchange after the step"
+                form = ("edge blocks first" if "runs its edge blocks first" in r.stderr else
+                        "edge rounds first (paced layout)" if "runs its edge rounds first" in r.stderr else "exchange after the step")
+                if "paced column panels" in r.stderr and "rounds first" not in form:
+                    form += " (paced layout)"
             except subprocess.TimeoutExpired:
                 ok, tail, form = False, "timeout", "?"
             cases += 1
