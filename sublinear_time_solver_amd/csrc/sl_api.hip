@@ -620,7 +620,11 @@ sl_status state_init(sl_neumann_state &st, const sl_matrix *m, const double *b, 
     if (n) SL_HIP(hipMemcpyAsync(st.b.p, b, n * 8, where == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
     unsigned long long hs[4];
     SL_TRY(sl_matrix_diag_pass(m, st.dinv.as<double>(), hs));
-    if (hs[0] & 1ull) return sl_fail(SL_NOT_DIAGONALLY_DOMINANT, "matrix is not row diagonally dominant (first failing row %llu)", hs[1]);
+    if (hs[0] & 1ull) {
+        double dv[2];
+        sl_matrix_row_dominance(m, hs[1], dv);
+        return sl_fail(SL_NOT_DIAGONALLY_DOMINANT, "matrix is not row diagonally dominant (first failing row %llu: |a_ii| = %.17g, sum of |a_ij| = %.17g)", hs[1], dv[0], dv[1]);
+    }
     if (hs[0] & 2ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2]);
     if (hs[0] & 4ull) return sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3]);
     SL_TRY(sl_launch_scale_rows(n, st.b.as<double>(), st.dinv.as<double>(), st.rhs.as<double>(), s));     // rhs = b * dinv  (:191-194)
@@ -749,7 +753,12 @@ sl_status state_init_partitioned(sl_neumann_state &st, sl_comm *c, const sl_matr
         if (n && hipMemcpyAsync(st.b.p, b, n * 8, where == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "upload of b failed"); break; }
         unsigned long long hs[4];
         if ((mine = sl_matrix_diag_pass(m, st.dinv.as<double>(), hs)) != SL_OK) break;
-        if (hs[0] & 1ull) { mine = sl_fail(SL_NOT_DIAGONALLY_DOMINANT, "matrix is not row diagonally dominant (first failing row %llu)", hs[1] + d->lo); break; }
+        if (hs[0] & 1ull) {
+            double dv[2];
+            sl_matrix_row_dominance(m, hs[1], dv);
+            mine = sl_fail(SL_NOT_DIAGONALLY_DOMINANT, "matrix is not row diagonally dominant (first failing row %llu: |a_ii| = %.17g, sum of |a_ij| = %.17g)", hs[1] + d->lo, dv[0], dv[1]);
+            break;
+        }
         if (hs[0] & 2ull) { mine = sl_fail(SL_INVALID_SPARSE_MATRIX, "Missing diagonal element at position %llu", hs[2] + d->lo); break; }
         if (hs[0] & 4ull) { mine = sl_fail(SL_INVALID_SPARSE_MATRIX, "Zero or near-zero diagonal element at position %llu", hs[3] + d->lo); break; }
         if ((mine = sl_launch_scale_rows(n, st.b.as<double>(), st.dinv.as<double>(), st.rhs.as<double>(), s)) != SL_OK) break;

@@ -321,7 +321,14 @@ sl_status sl_dist_vector_create(sl_comm *c, uint64_t n_global, sl_dist_vector *v
     for (int p = 0; p < c->world && mine == SL_OK; ++p) {
         if (p == c->rank) { v->peer[p] = v->mine; continue; }
         void *q = nullptr;
-        const hipError_t e = hipIpcOpenMemHandle(&q, all[p], hipIpcMemLazyEnablePeerAccess);
+        hipError_t e = hipIpcOpenMemHandle(&q, all[p], hipIpcMemLazyEnablePeerAccess);
+        // (seen once in ~1200 many-rank runs on one GPU: "IPC Attach: Invalid IPC handle" for handles that were fine — the runtime's
+        // attach can lose a race with the exporter's other imports; a second try a moment later is cheap and the verdict stays collective)
+        for (int again = 0; e != hipSuccess && again < 3; ++again) {
+            (void)hipGetLastError();
+            usleep(20000);
+            e = hipIpcOpenMemHandle(&q, all[p], hipIpcMemLazyEnablePeerAccess);
+        }
         if (e != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "hipIpcOpenMemHandle of rank %d's vector failed: %s", p, hipGetErrorString(e)); break; }
         v->peer[p] = static_cast<double *>(q);
     }
@@ -477,8 +484,11 @@ static sl_status comm_ipc_selftest(sl_comm *c)
         st = sl_comm_agree(c, mine);
     }
     if (d_bad) (void)hipFree(d_bad);
-    const sl_status bs = st == SL_OK ? sl_comm_host_barrier(c) : st;     // nobody frees its page while a peer still copies from it
+    sl_status bs = st == SL_OK ? sl_comm_host_barrier(c) : st;           // nobody frees its page while a peer still copies from it
     sl_dist_vector_destroy(c, &v);
+    // ... and nobody exports its next allocation (the vectors of a state: quite possibly the address just freed) while a peer still holds
+    // or is closing its mapping of the old one
+    if (bs == SL_OK) bs = sl_comm_host_barrier(c);
     return st != SL_OK ? st : bs;
 }
 

@@ -369,6 +369,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
                                    const double *d_values, bool keep_csr_copy);
 // a6 + a7 pass: h_status[0] bits 1 = not dominant, 2 = missing diagonal, 4 = near-zero diagonal;
 // h_status[1..3] = first offending row of each class.  d_dinv may be null.
+void sl_matrix_row_dominance(const sl_matrix *m, uint64_t row, double out[2]);     // |a_ii|, sum |a_ij| of one row (error messages)
 sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long long h_status[4]);
 // same rules over a plain CSR operator (used for A^T, which has no row-slice layout)
 sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx, const double *val, double *d_dinv,

@@ -76,7 +76,11 @@ def case_paced(seed):
     max_len = int(rng.integers(1, 40))
     dup = bool(rng.random() < 0.5)
     os.environ["SL_PW_FORCE"] = "1"
-    os.environ["SL_PW_CUS"] = str(int(rng.integers(1, 5)))
+    cus = int(rng.integers(1, 5))
+    os.environ["SL_PW_CUS"] = str(cus)
+    xcd = cus in (2, 4) and rng.random() < 0.5                    # spans dealt inside one L2 group (+ edge-first order where an interior is left)
+    if xcd:
+        os.environ["SL_PW_XCD"] = "2"
     try:
         rp, ci, va = F._structured_system(rng, rows, cols, kind, max_len, dup)
         m = S.SparseMatrix.from_csr(rp, ci, va, rows, cols, column_panels=True)
@@ -91,6 +95,7 @@ def case_paced(seed):
             assert (g.iterations, bool(g.converged)) == (o["iterations"], bool(o["converged"])) and bits_equal(g.solution, o["x"]), "neumann"
     finally:
         del os.environ["SL_PW_FORCE"], os.environ["SL_PW_CUS"]
+        os.environ.pop("SL_PW_XCD", None)
 
 
 def case_orderany(seed):

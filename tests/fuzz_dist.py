@@ -65,7 +65,7 @@ def main():
             key = f"world {world}: {form}"
             forms[key] = forms.get(key, 0) + 1
             if not ok:
-                failures.append({"cmd": " ".join(cmd[1:]), "overlap": overlap, "tail": tail})
+                failures.append({"cmd": " ".join(cmd[1:]), "overlap": overlap, "forced": {k: env[k] for k in ("SL_PW_CUS", "SL_PW_XCD") if k in env}, "tail": tail})
                 print("FAIL", " ".join(cmd[1:]), "overlap", overlap, "\n", tail, file=sys.stderr)
     print(json.dumps({"seed0": args.seed0, "cases": cases, "forms_seen": dict(sorted(forms.items())), "failures": failures}))
     return 1 if failures else 0
