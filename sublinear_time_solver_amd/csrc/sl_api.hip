@@ -68,6 +68,21 @@ sl_status sl_fail(sl_status s, const char *fmt, ...)
     sl_log(1, "status %d: %s", (int)s, buf);
     return s;
 }
+static bool poison_on() { static const bool on = [] { const char *e = getenv("SL_POISON_ALLOC"); return e && *e == '1'; }(); return on; }
+void sl_poison(void *p, size_t bytes)
+{
+    if (!poison_on() || !p || !bytes) return;
+    (void)hipDeviceSynchronize();                           // (debug mode: whatever still reads an old block of the cache finishes first)
+    (void)hipMemset(p, 0xA5, bytes);
+    (void)hipDeviceSynchronize();
+}
+hipError_t sl_malloc_checked(void **p, size_t bytes)
+{
+    const hipError_t e = (hipMalloc)(p, bytes);             // (parenthesised: the runtime's function, not the macro of sl_internal.hpp)
+    if (e == hipSuccess) sl_poison(*p, bytes);
+    return e;
+}
+
 void *sl_scratch(size_t bytes)
 {
     sl_ctx &c = sl_context();
@@ -119,7 +134,7 @@ void *sl_ws_alloc(size_t bytes)
         if (b.in_use || b.device != dev || b.bytes < bytes || b.bytes > 4 * bytes + (1u << 20)) continue;
         if (best < 0 || b.bytes < c.ws[best].bytes) best = (int)i;
     }
-    if (best >= 0) { c.ws[best].in_use = true; return c.ws[best].p; }
+    if (best >= 0) { c.ws[best].in_use = true; sl_poison(c.ws[best].p, c.ws[best].bytes); return c.ws[best].p; }
     void *p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {
         sl_release_workspace();                        // give the cache back and try once more

@@ -18,6 +18,14 @@
 #include <vector>
 #include "../../include/sublinear_hip.h"
 
+// Every device allocation of the library goes through here.  SL_POISON_ALLOC=1 (debug): the new block — and every block the workspace
+// cache hands out again — is filled with 0xA5 bytes first: nothing may rely on fresh device memory being zero (it is, on an idle box, and
+// is not once the box has run other work: the kind of fault that shows once in a thousand runs).  The test suite is run under it.
+hipError_t sl_malloc_checked(void **p, size_t bytes);
+void sl_poison(void *p, size_t bytes);                      // no-op unless SL_POISON_ALLOC=1
+template <class T> inline hipError_t sl_malloc_t(T **p, size_t bytes) { return sl_malloc_checked(reinterpret_cast<void **>(p), bytes); }
+#define hipMalloc(p, n) sl_malloc_t((p), (n))
+
 #define SL_SLICE 64
 #ifndef SL_BLOCK
 #define SL_BLOCK 256

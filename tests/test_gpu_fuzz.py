@@ -155,3 +155,18 @@ def test_paced_panels_with_spans_dealt_inside_one_l2_bitwise(gpu, monkeypatch, n
         p = S.PushSolver(theta=1e-9, dense_switch=1e-12).solve(m, bs)
         q = O.push_sync_solve(rp, ci, va, bs, theta=1e-9)
         assert (p["rounds"], p["pushes"]) == (q["rounds"], q["pushes"]) and _bits_equal(p["solution"], q["x"]) and _bits_equal(p["residual"], q["r"])
+
+
+def test_nothing_relies_on_fresh_device_memory_being_zero(gpu):
+    """SL_POISON_ALLOC=1 fills every device allocation of the library (and every block its workspace cache hands out again) with 0xA5
+    bytes before use; the parity and fuzz files must pass under it exactly as they do on an idle box's zero pages"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("SL_POISON_ALLOC") == "1":
+        pytest.skip("already inside the child run")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_fuzz.py"), os.path.join(here, "test_gpu_parity.py"),
+                        os.path.join(here, "test_gpu_panels.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=1500, env=dict(os.environ, SL_POISON_ALLOC="1"))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
