@@ -585,7 +585,12 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     // slowest wave of its block: two thirds of that, at least one panel — since the accumulation got cheaper, waves that stay closer
     // together win (tools/ab_slack.sh, n = 10^7 x 16, lead 1 / 2 / 3 / 4 / 6 panels: 0.950 / 0.966 / 0.966 / 0.985 / 1.000 ms; the same
     // order at 10^6 x 8 .. 5 * 10^6 x 16; at two panels per chunk (10^7 x 8, 2 * 10^7 x 16) leads 1..3 lie within 1 %)
-    m->pw_slack = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (2 * 256 * n_panels * n_tiles + total * 3 / 2) / (total * 3)));
+    // (the panels a tile's entries are spread over: all of them for uniform columns; for a bandwidth well inside the matrix — a rank's rows
+    // of a larger system above all — only those of its rows +- w: taking all n_cols there let the waves drift 5 panels apart where 1 was
+    // meant, n = 10^7 rows of 8 * 10^7, w = 2.5 * 10^6: 1.045 -> see profiles/r03_c5_locality.txt)
+    const uint64_t tile_cols = m->bandwidth == ~0ull ? m->n_cols : std::min<uint64_t>(m->n_cols, (xcd ? (uint64_t)deal * rpw : n) + 2 * m->bandwidth);
+    const uint64_t tile_panels = (tile_cols >> pbits) + 1;
+    m->pw_slack = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (2 * 256 * tile_panels * n_tiles + total * 3 / 2) / (total * 3)));
     if (band_pbits) {
         // a tile walks only the panels of its block's window; the lead = the panels it crosses per chunk of 256 entries, held to
         // what the L1 keeps beside the stream (~16 KB of vector: w = 32 768 at 2^9 lead 1 / 2 / 4 0.533 / 0.499 / 0.513 ms, w = 100 000 at
