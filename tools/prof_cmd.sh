@@ -14,6 +14,6 @@ if not dbs:
 c = sqlite3.connect(dbs[0])
 print(f"{'kernel':<90} {'calls':>7} {'total_ms':>10} {'avg_us':>10} {'pct':>7}")
 for name, calls, tot, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc"):
-    print(f"{name[:90]:<90} {calls:>7} {tot / 1e6:>10.3f} {avg / 1e3:>10.2f} {pct:>7.2f}")
+    print(f"{name[:90]:<90} {calls:>7} {tot / 1e3:>10.3f} {avg:>10.2f} {pct:>7.2f}")
 PY
 cat $R/gpurun_out/${tag}_kernel_stats.txt
