@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""f-3 (Monte-Carlo estimateEntry, src/core/solver.ts:585-601) at size: S-DD(n = 10^7, 16 per row, uniform columns), absorbing walks from a
+few rows — one lane per walk, walk s on its own TS LCG stream — with epsilon = 1e-3 (10^6 walks) and 3e-4 (1.1 * 10^7 walks); device time,
+walks per second, and the deterministic local-push estimate of the same entry beside it.  One JSON line.
+usage: python tools/walk_bench.py [--rows 10000000]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sublinear_time_solver_amd import _lib as L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    args = ap.parse_args()
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    n, k = args.rows, 16
+    rp = torch.empty(n + 1, dtype=torch.int32, device=dev); ci = torch.empty(n * k, dtype=torch.int32, device=dev)
+    va = torch.empty(n * k, dtype=torch.float64, device=dev); b = torch.empty(n, dtype=torch.float64, device=dev)
+    L.check(lib.sl_synth_sdd_device(n, k, 1, 0, 0, n, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), b.data_ptr()))
+    h = C.c_void_p()
+    L.check(lib.sl_matrix_create_csr(n, n, n * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, 0, L.SL_MATRIX_WITH_TRANSPOSE, C.byref(h)))
+    del rp, ci, va
+    out = {"system": f"S-DD(n={n}, k={k}, seed=1, uniform columns)",
+           "note": "absorption probability 1 / a_ii ~ 0.1 per step (solver.ts:366-383): ~10 steps per walk, each a row fetched at random; the value at "
+                   "absorption b_j / a_jj is 0.1 for every j of this recipe, hence the zero variance - the walks are what is timed.  (On a unit-diagonal "
+                   "operator such as PageRank's the reference's rule absorbs every walk at its first step.)",
+           "queries": []}
+    for row in (0, n // 2, n - 1):
+        pe = L.EstimateResult()
+        L.check(lib.sl_estimate_entry(h, C.c_void_p(b.data_ptr()), L.SL_MEM_DEVICE, row, 1e-10, 100000, C.byref(pe)))
+        for eps in (1e-3, 3e-4):
+            best = None
+            for _ in range(3):
+                r = L.WalkResult()
+                L.check(lib.sl_estimate_entry_random_walk(h, C.c_void_p(b.data_ptr()), L.SL_MEM_DEVICE, row, eps, 42, 0, None, C.byref(r)))
+                if best is None or r.device_time_ms < best.device_time_ms:
+                    best = r
+            out["queries"].append({"row": row, "epsilon": eps, "walks": int(best.num_samples), "device_ms": best.device_time_ms,
+                                   "walks_per_s": best.num_samples / (best.device_time_ms * 1e-3), "estimate": best.estimate,
+                                   "std_error": (best.variance / best.num_samples) ** 0.5, "local_push_estimate": pe.estimate,
+                                   "local_push_device_ms": pe.device_time_ms})
+    lib.sl_matrix_destroy(h)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
