@@ -521,6 +521,7 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     // ms per step 2^9 / 2^10 / 2^11: w = 12 000 0.473 / 0.536 / 0.677, 32 768 0.499 / 0.532 / 0.675, 100 000 0.634 / 0.592 / 0.731);
     // SL_PW_BAND_AUTO (0xff): that rule, any other value: the width as given (experiments)
     uint32_t pbits = band_pbits ? band_pbits : (uint32_t)SL_PANEL_COL_BITS;
+    if (!band_pbits) if (const char *e = getenv("SL_PW_PBITS")) { const int v = atoi(e); if (v >= 12 && v <= 20) pbits = (uint32_t)v; }      // experiments: log2 of the panel width
     const uint64_t span_cols = (uint64_t)deal * rpw + 2 * (m->bandwidth == ~0ull ? 0 : m->bandwidth) + 1;
     const double tile_entries = (double)nnz / (double)n_tiles;
     if (band_pbits == SL_PW_BAND_AUTO) {
