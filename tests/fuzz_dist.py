@@ -33,6 +33,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed0", type=int, default=int(time.time()) & 0xFFFFFF)
+    ap.add_argument("--min-world", type=int, default=1)
+    ap.add_argument("--sizes", default="", help="comma-separated n to draw from instead of the default mix")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed0)
     failures, cases, forms = [], 0, {}
@@ -40,8 +42,8 @@ def main():
         exe = build(tmp)
         t_end = time.time() + args.seconds
         while time.time() < t_end and len(failures) < 10:
-            world = int(rng.integers(1, 9))
-            n = int(rng.choice([64 * world + 1, 5000, 20011, 90000, 400000, 1200000]))
+            world = int(rng.integers(max(1, min(args.min_world, 8)), 9))
+            n = int(rng.choice([int(v) for v in args.sizes.split(",")] if args.sizes else [64 * world + 1, 5000, 20011, 90000, 400000, 1200000]))
             n = max(n, 64 * world)
             w = int(rng.choice([1, 40, 300, 5000, 15000, n // max(world, 1), 10**9]))
             uneven = bool(rng.random() < 0.5)
