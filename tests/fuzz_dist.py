@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--sizes", default="", help="comma-separated n to draw from instead of the default mix")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed0)
-    failures, cases, forms = [], 0, {}
+    failures, cases, forms, repaired = [], 0, {}, []
     with tempfile.TemporaryDirectory() as tmp:
         exe = build(tmp)
         t_end = time.time() + args.seconds
@@ -64,12 +64,16 @@ def main():
             except subprocess.TimeoutExpired:
                 ok, tail, form = False, "timeout", "?"
             cases += 1
+            if ok:                                                 # faults the library noticed and repaired by itself: recorded, with its own words
+                for ln in r.stderr.splitlines():
+                    if "did not fit their slices" in ln or "IPC Attach" in ln:
+                        repaired.append({"cmd": " ".join(cmd[1:]), "line": ln[:300]})
             key = f"world {world}: {form}"
             forms[key] = forms.get(key, 0) + 1
             if not ok:
                 failures.append({"cmd": " ".join(cmd[1:]), "overlap": overlap, "forced": {k: env[k] for k in ("SL_PW_CUS", "SL_PW_XCD") if k in env}, "tail": tail})
                 print("FAIL", " ".join(cmd[1:]), "overlap", overlap, "\n", tail, file=sys.stderr)
-    print(json.dumps({"seed0": args.seed0, "cases": cases, "forms_seen": dict(sorted(forms.items())), "failures": failures}))
+    print(json.dumps({"seed0": args.seed0, "cases": cases, "forms_seen": dict(sorted(forms.items())), "failures": failures, "noticed_and_repaired": repaired}))
     return 1 if failures else 0
 
 
