@@ -123,6 +123,146 @@ def cpu_baseline(n_global: int, k: int, seed: int, w: int, threads_all: int, row
                                           "note": "NOT the reference: its vector passes threaded like its SpMV (simd_ops.rs:219 chunks) — what the same cores give once those loops are parallel"}}
 
 
+GATE_BLOCK = 4096          # rows per sampled block of the parity gate
+GATE_STEPS = 2             # fused steps before the blocks are read: the second one gathers what the FIRST one wrote (on a partition: what the exchange moved)
+
+
+def gate_block_starts(n_local):
+    """three blocks of a rank's rows: its first rows, a block in the middle, its last rows (the edges are what gathers from the peers)"""
+    if n_local <= GATE_BLOCK:
+        return [0]
+    starts = {0, n_local - GATE_BLOCK}
+    if n_local >= 3 * GATE_BLOCK:
+        starts.add(n_local // 2 - 37)          # not aligned to slices, tiles or row groups
+    return sorted(starts)
+
+
+def cpu_parity_gate(path):
+    """The checker side of the parity gate (part of bench.py's CPU leg: runs in its own process, never inside the timed region).
+    `path` holds what one rank read back after GATE_STEPS fused steps from t0 = D^-1 b, x0 = t0: the rows of sampled blocks of its
+    current term and of its solution.  Regenerates on the host — from the counter-based generator alone — the sampled rows, the rows
+    those gather from and the rows THOSE gather from, runs the reference's arithmetic over them with the oracle's SpMV (sparse.rs:187-203
+    order: product rounded, then added, left to right; neumann.rs:289-296: tmp *= dinv, term -= tmp; :264-266: x += term), and compares bits."""
+    import numpy as np
+    from oracle import oracle as O
+    from sublinear_time_solver_amd import generators as G
+    z = np.load(path)
+    n_global, k, seed, w, lo, order = (int(z[key]) for key in ("n_global", "k", "seed", "w", "lo", "order"))
+    starts, t_dev, x_dev = z["starts"], z["term"], z["x"]
+    steps = int(z["steps"])
+    assert steps == 2
+
+    def closed_t0(idx):       # t0 = rhs = b * (1 / d), the generator's closed forms of b and the diagonal
+        m = (idx % np.uint64(1000)).astype(np.float64)
+        return (1.0 + 0.001 * m) * (1.0 / (10.0 + 0.01 * m)), 1.0 / (10.0 + 0.01 * m)
+
+    def step_rows(rows, t_of):       # one fused step on `rows` given a function idx -> previous term; returns (new term rows, cols used)
+        rp, ci, va, _ = G.sdd_rows_at(n_global, k, seed, w, rows)
+        cols = np.unique(ci).astype(np.uint64)
+        y = O.spmv(rp, np.searchsorted(cols, ci).astype(np.uint32), va, t_of(cols), order)     # a monotone renumbering keeps every row's order
+        return rp, ci, va, cols, y
+
+    rows_checked, bad, max_rel = 0, 0, 0.0
+    for bi, s0 in enumerate(starts.tolist()):
+        cnt = min(GATE_BLOCK, t_dev.shape[1])
+        R = np.arange(lo + s0, lo + s0 + cnt, dtype=np.uint64)
+        # step 1 on every row the block gathers from (its own rows included: the diagonal)
+        _, ciR, _, U1, _ = step_rows(R, lambda c: closed_t0(c)[0])
+        _, _, _, _, yU = step_rows(U1, lambda c: closed_t0(c)[0])
+        t0U, dinvU = closed_t0(U1)
+        t1U = t0U - yU * dinvU
+        # step 2 on the block itself
+        rpR, ciR, vaR, colsR, yR = step_rows(R, lambda c: t1U[np.searchsorted(U1, c)])
+        pos = np.searchsorted(U1, R)
+        t0R, dinvR = closed_t0(R)
+        t2 = t1U[pos] - yR * dinvR
+        xe = (t0R + t1U[pos]) + t2
+        td, xd = t_dev[bi, :cnt], x_dev[bi, :cnt]
+        bad += int((td.view(np.uint64) != t2.view(np.uint64)).sum()) + int((xd.view(np.uint64) != xe.view(np.uint64)).sum())
+        max_rel = max(max_rel, float(np.max(np.abs(td - t2)) / np.max(np.abs(t2))), float(np.max(np.abs(xd - xe)) / np.max(np.abs(xe))))
+        rows_checked += cnt
+    return {"rows_checked": rows_checked, "bitwise_equal": bad == 0, "values_differing": bad, "max_rel_err": max_rel,
+            "steps": steps, "blocks_at_local_rows": starts.tolist()}
+
+
+def parity_gate(args, lib, L, st, n_local, n_global, lo, w):
+    """BEFORE the timed region: GATE_STEPS fused steps on the instance the bench is about to time, three blocks of GATE_BLOCK rows of the
+    term and of the solution read back through the ABI, checked bit for bit by the CPU checker in a child process; the state is reset
+    afterwards (current_term = rhs), so the timed steps start where they always did."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    if args.order not in (L.SL_ORDER_CSR_SEQUENTIAL, L.SL_ORDER_SIMD4):
+        return {"skipped": "order-relaxed mode: results to rounding, no bitwise gate"}
+    starts = gate_block_starts(n_local)
+    cnt = min(GATE_BLOCK, n_local)
+    nrm, ms = C.c_double(0.0), C.c_float(0.0)
+    L.check(lib.sl_neumann_state_run_steps(st, GATE_STEPS, C.byref(nrm), C.byref(ms)))
+    term, x = np.empty((len(starts), cnt)), np.empty((len(starts), cnt))
+    for i, s0 in enumerate(starts):
+        L.check(lib.sl_neumann_state_current_term(st, s0, cnt, term[i].ctypes.data, L.SL_MEM_HOST))
+        L.check(lib.sl_neumann_state_solution_rows(st, s0, cnt, x[i].ctypes.data, L.SL_MEM_HOST))
+    L.check(lib.sl_neumann_state_reset(st))
+    if os.environ.get("SL_BENCH_GATE_CORRUPT") == "1":        # test of the gate itself: one ulp in one value it read back
+        term.view(np.uint64)[0, 5] ^= 1
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "gate.npz")
+        np.savez(f, n_global=n_global, k=args.k, seed=args.seed, w=w, lo=lo, order=args.order, steps=GATE_STEPS, starts=np.asarray(starts, dtype=np.int64), term=term, x=x)
+        try:
+            r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--parity-gate-only", f], capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                raise RuntimeError(f"checker exited with {r.returncode}: {r.stderr[-400:]}")
+            return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:
+            return {"rows_checked": 0, "bitwise_equal": False, "error": str(e)}
+
+
+def single_rank_reference(args, lib, L, torch, dev, n_global, lo, hi, w, steps):
+    """ms per fused step of ONE process alone on its GPU, no communicator, no peers' traffic: rows [lo, hi) of the n_global-row system
+    against the full-length gathered vector (hi - lo = n_global: the whole system, ping-pong; otherwise one rank's slice of the
+    partition, the gathered vector standing still — what the step costs before any exchange)."""
+    k, rows = args.k, hi - lo
+    rp = torch.empty(rows + 1, dtype=torch.int32, device=dev); ci = torch.empty(rows * k, dtype=torch.int32, device=dev)
+    va = torch.empty(rows * k, dtype=torch.float64, device=dev); b = torch.empty(rows, dtype=torch.float64, device=dev)
+    L.check(lib.sl_synth_sdd_device(n_global, k, args.seed, w, lo, hi, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), b.data_ptr()))
+    h = C.c_void_p()
+    L.check(lib.sl_matrix_create_csr(rows, n_global, rows * k, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), L.SL_MEM_DEVICE, lo, 0, C.byref(h)))
+    del rp, ci, va
+    torch.cuda.empty_cache()
+    try:
+        dinv = torch.empty(rows, dtype=torch.float64, device=dev)
+        L.check(lib.sl_matrix_diagonal_inverse(h, dinv.data_ptr(), L.SL_MEM_DEVICE))
+        nrm = torch.zeros(2, dtype=torch.float64, device=dev)
+        if rows == n_global:
+            ta = b * dinv
+            tb, x = torch.empty_like(ta), ta.clone()
+            ms = C.c_float(0)
+            L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order, 3, C.byref(ms)))
+            L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), tb.data_ptr(), ta.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order, steps, C.byref(ms)))
+            return ms.value / steps
+        idx = torch.arange(n_global, device=dev, dtype=torch.float64)
+        ta = (1.0 + 0.001 * torch.remainder(idx, 1000.0)) * (1.0 / (10.0 + 0.01 * torch.remainder(idx, 1000.0)))
+        del idx
+        tb, x = torch.zeros(rows, dtype=torch.float64, device=dev), ta[lo:hi].clone()
+        stream = torch.cuda.current_stream(dev)
+        L.check(lib.sl_set_stream(C.c_void_p(stream.cuda_stream)))
+        try:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                L.check(lib.sl_neumann_step(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order))
+            e0.record(stream)
+            for _ in range(steps):
+                L.check(lib.sl_neumann_step(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order))
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / steps
+        finally:
+            L.check(lib.sl_set_stream(None))
+    finally:
+        lib.sl_matrix_destroy(h)
+        torch.cuda.empty_cache()
+
+
 def column_structure_sweep(lib, L, torch, dev, n, k, seed, order, bandwidths, steps=30):
     """Secondary, clearly-labelled measurements on ONE GPU: the same fused step on the same S-DD recipe with
     other column structures (half-bandwidth w; 0 = uniform over all columns, the reference generators' recipe).
@@ -186,6 +326,9 @@ def _abi_measure(args, lib, L, torch, dev, comm, world, rank, w, verify=True):
     out = {}
     try:
         nrm, ms = C.c_double(0.0), C.c_float(0.0)
+        gate = None
+        if not args.no_parity_gate:       # every rank checks blocks of ITS rows; the verdicts are gathered below
+            gate = parity_gate(args, lib, L, st, n_local, n_global, lo, w)
         if args.warmup:
             L.check(lib.sl_neumann_state_run_steps(st, args.warmup, C.byref(nrm), C.byref(ms)))
         comm.barrier()
@@ -202,6 +345,17 @@ def _abi_measure(args, lib, L, torch, dev, comm, world, rank, w, verify=True):
         bad_all = sum(comm.allgather_u64(int(bad.value)))
         out = {"elapsed": elapsed, "dev_ms": dev_ms, "norm": float(nrm.value) ** 0.5, "panels": int(info.column_panels), "pieces_bad": bad_all,
                "verified": bool(verify)}
+        if gate is not None and "skipped" not in gate:
+            rows_all = sum(comm.allgather_u64(int(gate.get("rows_checked", 0))))
+            ranks_ok = sum(comm.allgather_u64(1 if gate.get("bitwise_equal") else 0))
+            worst = max(comm.allgather_f64(float(gate.get("max_rel_err", float("inf")))))
+            out["gate"] = {"rows_checked": rows_all, "bitwise_equal": ranks_ok == world, "max_rel_err": worst, "ranks_checked": world, "ranks_equal": ranks_ok,
+                           "steps_before_check": GATE_STEPS, "blocks_per_rank": len(gate_block_starts(n_local)), "block_rows": min(GATE_BLOCK, n_local),
+                           "checker": "oracle SpMV (sparse.rs:187-203 order) over rows regenerated on the host by generators.sdd_rows_at, in a child process before the timed region"}
+            if gate.get("error"):
+                out["gate"]["error"] = gate["error"]
+        elif gate is not None:
+            out["gate"] = gate
         if world == 1:      # kernel-only duration: the same launches (fused step + closing reduction) through the library's HIP-event bracket, no ticket
             dinv = torch.empty(n_local, dtype=torch.float64, device=dev)
             L.check(lib.sl_matrix_diagonal_inverse(h, dinv.data_ptr(), L.SL_MEM_DEVICE))
@@ -253,6 +407,15 @@ def main_abi(args, world, rank, local_rank, attempt=0):
         m = _abi_measure(args, lib, L, torch, dev, comm, world, rank, w_head)
         if m["pieces_bad"]:
             raise RuntimeError(f"exchange verification failed: {m['pieces_bad']} pieces differ from their owners' copies (transport {transport})")
+        if "gate" in m and "skipped" not in m["gate"] and not m["gate"]["bitwise_equal"]:
+            # a fast kernel whose results differ is not measured: the line carries the gate and NO value (every rank sees the same verdict;
+            # not a transport failure, so no fallback is tried)
+            if rank == 0:
+                print(json.dumps({"metric": "push_iterations_x_nnz_per_sec", "value": None, "unit": "nnz*iter/s", "n_gpus": len(set(devices)), "n_ranks": world,
+                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                                  "vs_baseline": None, "dtype": "f64", "data": "synthetic", "error": "parity gate failed: the step's results differ from the CPU checker's; nothing was timed",
+                                  "parity_gate": m["gate"], "config": {"workload": f"S-DD(n={n_local} rows/rank, nnz/row={k}, seed={args.seed}, half-bandwidth {w_head})"}}), flush=True)
+            return
         variants = []
         if not args.no_sweep and world > 1:                                        # the other column structures of the recipe in the same job
             for w_other in (0, w_c5, BANDED_BANDWIDTH):
@@ -260,6 +423,23 @@ def main_abi(args, world, rank, local_rank, attempt=0):
                     continue
                 mo = _abi_measure(args, lib, L, torch, dev, comm, world, rank, w_other)
                 variants.append((w_other, mo))      # (a variant whose exchange does not verify is reported as such — every rank sees the same count — and does not take the headline with it)
+        # N > 1: the like-for-like one-GPU reference, measured in THIS job by rank 0 alone while its peers wait at a barrier: (i) the whole
+        # n_local-row system with the head's column structure — what `--gpus 1 --bandwidth w_head` times — and (ii) rank 0's own rows of the
+        # N * n_local-row system with nobody exchanging.  efficiency = exchange cost; the change of workload between N = 1 and N > 1 is (i) vs (ii)
+        ref = None
+        if world > 1 and not args.no_scaling_reference:
+            comm.barrier()
+            if rank == 0:
+                try:
+                    rs = max(10, min(args.steps, 30))
+                    ref = {"n1_ms_per_step": single_rank_reference(args, lib, L, torch, dev, n_local, 0, n_local, w_head, rs),
+                           "slice_ms_per_step": single_rank_reference(args, lib, L, torch, dev, n_global, 0, n_local, w_head, rs), "steps": rs,
+                           "what": f"rank 0 alone on its device, the other {world - 1} ranks idle at a barrier: n1 = the whole {n_local}-row system, half-bandwidth {w_head} "
+                                   f"(one process, no communicator: sl_neumann_run_steps); slice = rows [0, {n_local}) of the {n_global}-row system against the standing "
+                                   "full-length vector (sl_neumann_step): the step before any exchange"}
+                except Exception as e:      # reported context, never fatal to the line
+                    ref = {"error": str(e)}
+            comm.barrier()
         if rank != 0:
             return
         nnz_total = n_global * k
@@ -273,13 +453,15 @@ def main_abi(args, world, rank, local_rank, attempt=0):
         kernel = LAYOUTS.get(m["panels"], "row slices") if m["panels"] else ("LDS-window band kernel" if 0 < w_head <= 9400 else "row-slice general kernel")
         exchange = f"abi: sl_comm, transport {transport}" + (" (one rank: tickets of one, no peers)" if world == 1 else
                    (" — term all-gathered: every rank needs every row" if w_head == 0 else " — halo strips at the range boundaries only"))
+        n_dev = len(set(devices))
         out = {
-            "metric": "push_iterations_x_nnz_per_sec", "value": value, "unit": "nnz*iter/s", "n_gpus": world,
+            "metric": "push_iterations_x_nnz_per_sec", "value": value, "unit": "nnz*iter/s", "n_gpus": n_dev, "n_ranks": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["elapsed"] * 1e3 / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"S-DD(n={n_local} rows/GPU, nnz/row={k}, seed={args.seed}, {name_of(w_head)}) fused Neumann/push step, fp64, "
+            "config": {"workload": f"S-DD(n={n_local} rows/rank, nnz/row={k}, seed={args.seed}, {name_of(w_head)}) fused Neumann/push step, fp64, "
                                    + ("1xMI355X HBM roofline run (BASELINE configs[2])" if world == 1 else
-                                      f"{world}xMI355X row-partitioned (BASELINE configs[4] per-GPU shape)"),
+                                      f"{world} ranks on {n_dev} device(s)" + (f" = {world}xMI355X" if n_dev == world else " — ranks SHARE a GPU: a functional run of the partitioned path, not a scaling figure")
+                                      + ", row-partitioned (BASELINE configs[4] per-GPU shape)"),
                        "n_per_gpu": n_local, "n_global": n_global, "nnz_per_row": k, "half_bandwidth": w_head,
                        "order": {0: "csr_sequential", 1: "simd4", 2: "any (SL_ORDER_ANY)"}[args.order],
                        "exchange": exchange, "transport": transport, "partition": f"rows{world}",
@@ -296,6 +478,10 @@ def main_abi(args, world, rank, local_rank, attempt=0):
                          "note": ("launch_ms = fused step kernel + closing reduction, HIP events over the same K launches without the ticket" if world == 1 else
                                   "per GPU: one step = fused kernel + all-rank sum + exchange; launch_ms = the slowest rank's device time per step")},
         }
+        if "gate" in m:
+            out["parity_gate"] = m["gate"]
+        if ref is not None:
+            out["scaling_reference"] = ref
         if w_head == 0 and m["panels"]:      # the bound this kernel actually meets: one L2 request per gathered entry
             req = n_local * k
             floor_ms = req / L2_REQUEST_RATE * 1e3
@@ -309,6 +495,7 @@ def main_abi(args, world, rank, local_rank, attempt=0):
                 "value": nnz_total * args.steps / mo["elapsed"], "unit": "nnz*iter/s", "ms_per_step": mo["elapsed"] * 1e3 / args.steps,
                 "device_ms_per_step_slowest_rank": mo["dev_ms"] / args.steps, "exchange_verified": bool(mo["verified"] and not mo["pieces_bad"]),
                 "roofline_frac_per_gpu": per_launch_bytes / (mo["dev_ms"] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, "last_term_norm": mo["norm"],
+                "parity_gate": mo.get("gate"),
                 "bytes_received_per_rank_per_step": (8 * n_local * (world - 1)) if w_o == 0 else 8 * w_o * min(2, world - 1)}
         if world == 1 and not args.no_sweep:
             others = [v for v in (0, BANDED_BANDWIDTH, 512, 32768, w_c5) if v != w_head]      # w_c5: the per-GPU structure of the N > 1 lines, on one GPU
@@ -375,7 +562,15 @@ def launcher(args, argv):
         print(f"[bench launcher] {n} ranks on {ndev} device(s): ranks share GPUs, ipc transport only", file=sys.stderr, flush=True)
         order = [t for t in order if t == "ipc"] or ["ipc"]
     attempts = []
+    t_launch = time.time()
     for att, transport in enumerate(order):
+        left = args.total_timeout - (time.time() - t_launch)
+        if left < 60 and att:      # the whole job stays inside the driver's limit: what is left would not run an attempt
+            attempts.append({"transport": transport, "ok": False, "seconds": 0.0, "why": f"not started: {left:.0f} s of the total budget of {args.total_timeout:.0f} s left"})
+            continue
+        # a later transport always gets its turn: an attempt may take its own limit, and never more than its share of what is left
+        later = len(order) - att - 1
+        limit = max(30.0, min(args.attempt_timeout, left - 90.0 * later))
         port = _free_port()
         job = f"{os.getpid()}_{att}"
         procs, logs = [], []
@@ -388,7 +583,7 @@ def launcher(args, argv):
             logs.append(err)
             procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py")] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                           stderr=err, text=True, start_new_session=True, cwd=str(ROOT)))
-        deadline, failed, why = t0 + args.attempt_timeout, False, ""
+        deadline, failed, why = t0 + limit, False, ""
         out0 = ""
         import threading
         buf = []
@@ -402,7 +597,7 @@ def launcher(args, argv):
             if all(c == 0 for c in codes):
                 break
             if time.time() > deadline:
-                failed, why = True, f"time limit of {args.attempt_timeout} s"
+                failed, why = True, f"time limit of {limit:.0f} s"
                 break
             time.sleep(0.2)
         if failed:
@@ -465,9 +660,17 @@ def main():
                          "or ONE all-reduce over a zero-filled compact strip buffer")
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU (torch path): do not split boundary / interior rows")
     ap.add_argument("--force-split", action="store_true", help="testing (torch path): use the boundary / interior split even on one GPU")
-    ap.add_argument("--attempt-timeout", type=float, default=float(os.environ.get("SL_BENCH_ATTEMPT_TIMEOUT", "900")),
+    ap.add_argument("--attempt-timeout", type=float, default=float(os.environ.get("SL_BENCH_ATTEMPT_TIMEOUT", "420")),
                     help="self-launched N > 1: seconds one transport attempt may take before the parent ends it and tries the next")
+    ap.add_argument("--total-timeout", type=float, default=float(os.environ.get("SL_BENCH_TOTAL_TIMEOUT", "1440")),
+                    help="self-launched N > 1: seconds all attempts together may take (the driver allows a bench run 1800 s)")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the bitwise check of sampled row blocks against the CPU checker before the timed region")
+    ap.add_argument("--parity-gate-only", default=None, help=argparse.SUPPRESS)          # child process of the parity gate (CPU checker)
+    ap.add_argument("--no-scaling-reference", action="store_true", help="N > 1: skip rank 0's one-GPU reference measurements")
     args = ap.parse_args()
+    if args.parity_gate_only:       # the CPU checker of the parity gate, in its own process
+        print(json.dumps(cpu_parity_gate(args.parity_gate_only)), flush=True)
+        return
     if args.cpu_baseline_only:      # runs in its own process: a crash of the CPU checker must not take the GPU line with it
         w0 = args.bandwidth if args.bandwidth >= 0 else DEFAULT_BANDWIDTH
         print(json.dumps(cpu_baseline(args.n, args.k, args.seed, w0, os.cpu_count() or 1)), flush=True)
@@ -660,7 +863,8 @@ def main_torch(args, world, rank, local_rank):
         achieved = per_launch_bytes / (launch_ms * 1e-3) / 1e9
         traffic, traffic_source = recorded_traffic(n_local, k, w)
         out = {
-            "metric": "push_iterations_x_nnz_per_sec", "value": value, "unit": "nnz*iter/s", "n_gpus": world,
+            "metric": "push_iterations_x_nnz_per_sec", "value": value, "unit": "nnz*iter/s",
+            "n_gpus": world if backend == "nccl" else min(world, max(1, torch.cuda.device_count())), "n_ranks": world,      # gloo test mode: ranks share devices
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"S-DD(n={n_local} rows/GPU, nnz/row={k}, seed={args.seed}, "

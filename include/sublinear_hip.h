@@ -236,6 +236,11 @@ sl_status sl_neumann_state_update_rhs(sl_neumann_state *st, uint64_t count, cons
 sl_status sl_neumann_state_run(sl_neumann_state *st, double *term_norms, sl_neumann_result *result);
 sl_status sl_neumann_state_solution(const sl_neumann_state *st, double *x_out, sl_mem where);
 sl_status sl_neumann_state_reset(sl_neumann_state *st);
+/* Rows [first_row, first_row + count) — LOCAL row numbers of the state (a partitioned state: of the rank's range) — of
+ * NeumannState::current_term / NeumannState::solution (neumann.rs:104-107), without moving the whole vector: what a caller samples
+ * to check an iteration against its own CPU arithmetic (bench.py's parity gate).  first_row + count > rows: SL_INDEX_OUT_OF_BOUNDS. */
+sl_status sl_neumann_state_current_term(const sl_neumann_state *st, uint64_t first_row, uint64_t count, double *t_out, sl_mem where);
+sl_status sl_neumann_state_solution_rows(const sl_neumann_state *st, uint64_t first_row, uint64_t count, double *x_out, sl_mem where);
 
 /* ---- (a-P) / a13 / a14: synchronous thresholded residual push ------------------------
  * The data-parallel member of the reference's push family — ForwardPushSolver::push_node

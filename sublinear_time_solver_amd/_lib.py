@@ -131,6 +131,8 @@ SIGNATURES = {
     "sl_neumann_state_update_rhs": (C.c_int, [vp, u64, vp, vp]),
     "sl_neumann_state_run": (C.c_int, [vp, vp, C.POINTER(NeumannResult)]),
     "sl_neumann_state_solution": (C.c_int, [vp, vp, C.c_int]),
+    "sl_neumann_state_current_term": (C.c_int, [vp, u64, u64, vp, C.c_int]),
+    "sl_neumann_state_solution_rows": (C.c_int, [vp, u64, u64, vp, C.c_int]),
     "sl_neumann_state_reset": (C.c_int, [vp]),
     "sl_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]),
     "sl_comm_destroy": (None, [vp]),

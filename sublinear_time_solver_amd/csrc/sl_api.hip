@@ -1183,6 +1183,33 @@ sl_status sl_neumann_state_solution(const sl_neumann_state *st, double *x_out, s
     SL_ABI_END
 }
 
+// rows of current_term / solution (neumann.rs:104-107) without moving the whole vector
+static sl_status state_rows(const sl_neumann_state *st, const double *src, uint64_t first, uint64_t count, double *out, sl_mem where)
+{
+    if (!st || (count && !out)) return sl_fail(SL_INVALID_INPUT, "null argument");
+    if (first > st->n || count > st->n - first)
+        return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "rows [%llu, %llu) of a state of %llu rows", (unsigned long long)first, (unsigned long long)(first + count), (unsigned long long)st->n);
+    if (!count) return SL_OK;
+    hipStream_t s = sl_context().stream;
+    SL_HIP(hipMemcpyAsync(out, src + first, count * 8, where == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+    SL_HIP(hipStreamSynchronize(s));
+    return SL_OK;
+}
+sl_status sl_neumann_state_current_term(const sl_neumann_state *st, uint64_t first_row, uint64_t count, double *t_out, sl_mem where)
+{
+    SL_ABI_BEGIN
+    if (!st) return sl_fail(SL_INVALID_INPUT, "null argument");
+    return state_rows(st, st->t_cur + (st->dist ? st->dist->lo : 0), first_row, count, t_out, where);
+    SL_ABI_END
+}
+sl_status sl_neumann_state_solution_rows(const sl_neumann_state *st, uint64_t first_row, uint64_t count, double *x_out, sl_mem where)
+{
+    SL_ABI_BEGIN
+    if (!st) return sl_fail(SL_INVALID_INPUT, "null argument");
+    return state_rows(st, st->x.as<double>(), first_row, count, x_out, where);
+    SL_ABI_END
+}
+
 sl_status sl_neumann_state_reset(sl_neumann_state *st)                      // SolverState::reset, neumann.rs:367-378
 {
     SL_ABI_BEGIN

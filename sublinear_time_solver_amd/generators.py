@@ -33,6 +33,12 @@ def sdd_rows(n: int, k: int, seed: int, half_bandwidth: int = 0, row_lo: int = 0
     """
     if row_hi is None:
         row_hi = n
+    return sdd_rows_at(n, k, seed, half_bandwidth, np.arange(row_lo, row_hi, dtype=np.uint64))
+
+
+def sdd_rows_at(n: int, k: int, seed: int, half_bandwidth: int, rows_wanted):
+    """The rows `rows_wanted` (any list of global row numbers, in that order) of S-DD(n, k, seed, w) — the generator is counter-based,
+    so a scattered set of rows costs what it holds (bench.py's parity gate regenerates the rows a sampled block gathers from)."""
     if not (2 <= k <= 64):
         raise ValueError("k must be in [2, 64]")
     m = k - 1
@@ -40,7 +46,7 @@ def sdd_rows(n: int, k: int, seed: int, half_bandwidth: int = 0, row_lo: int = 0
     if ((half_bandwidth + 1) if banded else n) // m < 2:
         raise ValueError("column window too narrow for k-1 distinct off-diagonals")
     with np.errstate(over="ignore"):
-        i = np.arange(row_lo, row_hi, dtype=np.uint64)
+        i = np.ascontiguousarray(rows_wanted, dtype=np.uint64)
         rows = i.size
         if not banded:
             lo = np.zeros(rows, dtype=np.uint64)

@@ -26,6 +26,9 @@ def test_bench_line_contract_and_split_equivalence(gpu):
     assert a["n_gpus"] == 1 and a["steps"] == 7 and a["dtype"] == "f64" and a["scaling"] == "weak" and a["vs_baseline"] is None
     assert set(a["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "column_structure"} and a["roofline"]["bound"] == "hbm"
     assert abs(a["roofline"]["frac"] - a["roofline"]["achieved"] / 8000.0) < 1e-12 and "workload" in a["config"]
+    # the parity gate ran before the timed region: three blocks of 4096 rows of the term and the solution after two steps, bit for bit
+    g = a["parity_gate"]
+    assert g["bitwise_equal"] is True and g["rows_checked"] == 3 * 4096 and g["max_rel_err"] == 0.0 and g["ranks_checked"] == 1
     b = _bench("--force-split")
     assert b["config"]["exchange"] == "halo+overlap"
     na, nb = a["config"]["last_term_norm"], b["config"]["last_term_norm"]
@@ -61,7 +64,9 @@ def test_bench_two_ranks_reproduce_the_single_rank_iteration(gpu, w, extra, exch
     assert one.returncode == 0, one.stderr[-2000:]
     a = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     b = _bench_two_ranks(150000, w, *extra)
-    assert b["n_gpus"] == 2 and b["config"]["n_global"] == 300000 and b["scaling"] == "weak"
+    assert b["n_ranks"] == 2 and b["n_gpus"] == 1 and b["config"]["n_global"] == 300000 and b["scaling"] == "weak"       # two ranks SHARING the box's GPU
+    if exchange == "abi":
+        assert b["parity_gate"]["bitwise_equal"] is True and b["parity_gate"]["ranks_checked"] == 2 and b["parity_gate"]["rows_checked"] == 2 * 3 * 4096
     assert b["config"]["exchange"].startswith("abi: sl_comm") if exchange == "abi" else b["config"]["exchange"] == exchange
     na, nb = a["config"]["last_term_norm"], b["config"]["last_term_norm"]
     assert na > 0 and abs(na - nb) <= 1e-12 * na
@@ -78,13 +83,17 @@ def test_bench_starts_its_own_ranks(gpu):
     assert len(lines) == 1, r.stdout[-2000:]
     a = json.loads(lines[0])
     cfg = a["config"]
-    assert a["n_gpus"] == 2 and a["steps"] == 5 and a["warmup"] == 5 and cfg["n_global"] == 600000 and a["scaling"] == "weak"
+    assert a["n_ranks"] == 2 and a["n_gpus"] == len(set(cfg["devices"])) == 1 and "2 ranks on 1 device(s)" in cfg["workload"]
+    assert a["steps"] == 5 and a["warmup"] == 5 and cfg["n_global"] == 600000 and a["scaling"] == "weak"
     assert cfg["n_ranks_joined"] == 2 and len(cfg["devices"]) == 2 and cfg["transport"] == "ipc" and cfg["exchange_verified"] is True
+    assert a["parity_gate"]["bitwise_equal"] is True and a["parity_gate"]["ranks_equal"] == 2
+    ref = a["scaling_reference"]                                      # the like-for-like one-GPU figures, measured in the same job by rank 0 alone
+    assert ref["n1_ms_per_step"] > 0 and ref["slice_ms_per_step"] > 0
     assert cfg["launcher"]["self_launched_ranks"] == 2 and cfg["launcher"]["attempts"][-1]["ok"]
     # N > 1 defaults to config 5's locality-bounded form (columns within n_local / 4 of the row); the all-gather form and the narrow band beside it
     assert cfg["half_bandwidth"] == 75000 and "locality-bounded" in cfg["workload"]
     for key in ("halo_variant", "uniform_variant"):
-        assert a[key]["exchange_verified"] is True and a[key]["value"] > 0
+        assert a[key]["exchange_verified"] is True and a[key]["value"] > 0 and a[key]["parity_gate"]["bitwise_equal"] is True
     assert a["uniform_variant"]["bytes_received_per_rank_per_step"] == 8 * 300000 and cfg["bytes_received_per_rank_per_step"] == 8 * 75000
     assert abs(a["value"] - 600000 * 16 * 5 / (a["ms_per_step"] * 5e-3)) <= 1e-6 * a["value"]
     one = subprocess.run([sys.executable, "bench.py", "--rows", "600000", "--steps", "5", "--bandwidth", "75000", "--no-cpu-baseline", "--no-sweep"], cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -93,6 +102,38 @@ def test_bench_starts_its_own_ranks(gpu):
     assert b["n_gpus"] == 1 and b["config"]["n_ranks_joined"] == 1 and b["config"]["transport"] == "ipc"      # N = 1 runs the same host path
     na, nb = cfg["last_term_norm"], b["config"]["last_term_norm"]
     assert na > 0 and abs(na - nb) <= 1e-12 * na
+
+
+def test_config5_at_its_own_size_eight_ranks_on_this_box(gpu):
+    """BASELINE configs[4] as itself: `python bench.py --gpus 8 --rows 10000000` — 8 ranks x 10^7 rows of the n = 8 * 10^7 system, through the
+    real rendezvous, IPC handles, tickets and pulls (the ranks share this box's one GPU: about 64 GB of its 288).  All eight join; the
+    exchange verifies for the locality-bounded, the all-gather and the narrow-band form; and EVERY rank's sampled blocks (its first, middle
+    and last 4096 rows after two steps — the edge blocks gather what the exchange moved) equal the CPU checker bit for bit."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--rows", "10000000", "--steps", "5", "--warmup", "2"], cwd=ROOT, capture_output=True, text=True, timeout=1700)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    a = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = a["config"]
+    assert a["n_ranks"] == 8 and cfg["n_ranks_joined"] == 8 and len(cfg["devices"]) == 8 and a["n_gpus"] == len(set(cfg["devices"]))
+    assert cfg["n_global"] == 80_000_000 and cfg["half_bandwidth"] == 2_500_000 and cfg["exchange_verified"] is True and a["value"] > 0
+    for g in (a["parity_gate"], a["uniform_variant"]["parity_gate"], a["halo_variant"]["parity_gate"]):
+        assert g["bitwise_equal"] is True and g["ranks_equal"] == 8 and g["rows_checked"] == 8 * 3 * 4096 and g["max_rel_err"] == 0.0
+    assert a["uniform_variant"]["exchange_verified"] is True and a["halo_variant"]["exchange_verified"] is True
+    assert a["uniform_variant"]["bytes_received_per_rank_per_step"] == 7 * 8 * 10_000_000
+    ref = a["scaling_reference"]
+    assert 0 < ref["n1_ms_per_step"] < 5 and 0 < ref["slice_ms_per_step"] < 5
+    out = ROOT / "gpurun_out"
+    if out.is_dir():
+        (out / "bench_8ranks_1gpu.json").write_text(json.dumps(a, indent=1))
+
+
+def test_bench_refuses_a_value_when_the_parity_gate_fails(gpu):
+    """a step whose results differ from the checker's is not timed into a value (SL_BENCH_GATE_CORRUPT flips one bit of what the gate read back)"""
+    import os
+    r = subprocess.run([sys.executable, "bench.py", "--rows", "200000", "--steps", "3", "--warmup", "1", "--no-sweep", "--no-cpu-baseline"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, SL_BENCH_GATE_CORRUPT="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert a["value"] is None and a["parity_gate"]["bitwise_equal"] is False and "parity gate failed" in a["error"]
 
 
 def test_bench_launcher_falls_back_to_the_next_transport(gpu):
