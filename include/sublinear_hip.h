@@ -335,8 +335,9 @@ sl_status sl_neumann_state_verify_exchange(sl_neumann_state *st, uint64_t *piece
  * without out-weight keeps its mass (P_uu = 1, forward_push.rs:210-215; SL_SYSTEM_DANGLING_IDENTITY: it contributes nothing), assembled on the device and returned as an sl_matrix (row diagonally
  * dominant in the backward form, column dominant in the forward one): what sl_push_solve / sl_estimate_entry* / sl_query_session_* and
  * the TS computePageRank path (core/solver.ts:664-722, d = 1 - alpha) run on.
- * sl_forward_push_acl / _with_target / sl_backward_push_acl: ForwardPushSolver::solve_single_source / solve_multi_source
- * (forward_push.rs:67-177), solve_with_target (:233-290) and BackwardPushSolver::solve_single_target (backward_push.rs:67-220) with the
+ * sl_forward_push_acl / _with_target / sl_backward_push_acl / _with_source: ForwardPushSolver::solve_single_source / solve_multi_source
+ * (forward_push.rs:67-177), solve_with_target (:233-290) and BackwardPushSolver::solve_single_target / solve_multi_target /
+ * solve_with_source (backward_push.rs:67-176, 238-293) with the
  * WorkQueue's order (graph/mod.rs:132-213: largest priority first; equal priorities: larger node id — the reference leaves it open):
  * push_count, nodes_visited and every bit of estimate / residual equal the CPU restatement's.  Sequential across pushes by
  * definition: for parity and small graphs; the throughput path is sl_push_solve on the system matrix with theta_rows. */
@@ -374,6 +375,18 @@ sl_status sl_backward_push_acl(const sl_push_graph *g, uint64_t n_targets, const
 sl_status sl_forward_push_acl_with_target(const sl_push_graph *g, uint64_t source, uint64_t target, double target_precision,
                                           const sl_acl_options *o, double *estimate, double *residual, uint32_t *push_log, uint64_t log_cap,
                                           sl_acl_result *res);
+/* BackwardPushSolver::solve_with_source (backward_push.rs:238-293): unit mass at `target`, pushed over the reverse adjacency in the
+ * WorkQueue's order; ends as soon as estimate[source] > source_precision and residual[source] < 0.1 source_precision (:262-264, checked
+ * before every pop: stopped_by = 3); source or target out of range: the empty result (:243-251), not an error. */
+sl_status sl_backward_push_acl_with_source(const sl_push_graph *g, uint64_t source, uint64_t target, double source_precision,
+                                           const sl_acl_options *o, double *estimate, double *residual, uint32_t *push_log, uint64_t log_cap,
+                                           sl_acl_result *res);
+/* {Forward,Backward}PushSolver::extrapolated_solution (forward_push.rs:292-301, backward_push.rs:302-311): solution = estimate, then
+ * solution[i] += alpha * residual[i] (product rounded, then added).  count doubles each, all three in memory space `where`. */
+sl_status sl_acl_extrapolated_solution(uint64_t count, double alpha, const double *estimate, const double *residual, double *solution, sl_mem where);
+/* BackwardPushSolver::reachability_probabilities (backward_push.rs:296-299): solve_single_target(target), then extrapolated_solution
+ * of its result; solution: num_nodes doubles in o->mem; *res = the scalars of the push. */
+sl_status sl_backward_push_acl_reachability(const sl_push_graph *g, uint64_t target, const sl_acl_options *o, double *solution, sl_acl_result *res);
 
 /* ---- a14 in the reference's own visiting order: TS solveForwardPush (src/core/solver.ts:437-522) ----
  * Gauss-Southwell: every step pushes the FIRST index of largest |r_i| (r = b - A x, x0 = 0), p = r_i / a_ii, x_i += p, r_i = 0,

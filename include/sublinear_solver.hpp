@@ -418,7 +418,9 @@ protected:
         const size_t n = graph_.num_nodes();
         out.estimate.assign(n ? n : 1, 0.0); out.residual.assign(n ? n : 1, 0.0);
         sl_acl_result r;
-        if (target) check(sl_forward_push_acl_with_target(graph_.handle(), nodes[0], *target, target_precision, &o, out.estimate.data(), out.residual.data(), nullptr, 0, &r));
+        // with a stop node: forward = solve_with_target(source = nodes[0], target = *target); backward = solve_with_source(source = *target, target = nodes[0])
+        if (target && backward) check(sl_backward_push_acl_with_source(graph_.handle(), *target, nodes[0], target_precision, &o, out.estimate.data(), out.residual.data(), nullptr, 0, &r));
+        else if (target) check(sl_forward_push_acl_with_target(graph_.handle(), nodes[0], *target, target_precision, &o, out.estimate.data(), out.residual.data(), nullptr, 0, &r));
         else if (backward) check(sl_backward_push_acl(graph_.handle(), count, nodes, &o, out.estimate.data(), out.residual.data(), nullptr, 0, &r));
         else check(sl_forward_push_acl(graph_.handle(), count, nodes, &o, out.estimate.data(), out.residual.data(), nullptr, 0, &r));
         out.estimate.resize(n); out.residual.resize(n);
@@ -432,11 +434,41 @@ protected:
 class BackwardPushSolver : private ForwardPushSolver {      // backward_push.rs:67-334
 public:
     BackwardPushSolver(const PushGraph &graph, BackwardPushConfig config = {}) : ForwardPushSolver(graph, config) {}
-    BackwardPushResult solve_single_target(size_t target) const { const uint64_t t = target; return run(true, 1, &t, nullptr, 0.0); }
+    BackwardPushResult solve_single_target(size_t target) const { const uint64_t t = target; return run(true, 1, &t, nullptr, 0.0); }             // :67-122
+    BackwardPushResult solve_multi_target(const std::vector<size_t> &targets) const                                                         // :125-176
+    {
+        std::vector<uint64_t> t(targets.begin(), targets.end());
+        return run(true, t.size(), t.data(), nullptr, 0.0);
+    }
     Precision query_transition_probability(size_t source, size_t target) const                                                              // :228-235
     {
         const BackwardPushResult r = solve_single_target(target);
         return source < r.estimate.size() ? r.estimate[source] : 0.0;
+    }
+    BackwardPushResult solve_with_source(size_t source, size_t target, Precision source_precision) const                                    // :238-293
+    {
+        const uint64_t s = source, t = target;
+        return run(true, 1, &t, &s, source_precision);
+    }
+    std::vector<Precision> reachability_probabilities(size_t target) const                                                                  // :296-299
+    {
+        sl_acl_options o;
+        sl_acl_options_default(&o);
+        o.alpha = config_.alpha; o.epsilon = config_.epsilon; o.queue_threshold = config_.queue_threshold; o.max_pushes = config_.max_pushes;
+        o.adaptive_threshold = config_.adaptive_threshold ? 1 : 0; o.mem = SL_MEM_HOST;
+        const size_t n = graph_.num_nodes();
+        std::vector<Precision> x(n ? n : 1, 0.0);
+        sl_acl_result r;
+        check(sl_backward_push_acl_reachability(graph_.handle(), target, &o, x.data(), &r));
+        x.resize(n);
+        return x;
+    }
+    std::vector<Precision> extrapolated_solution(const BackwardPushResult &r) const                                                         // :302-311
+    {
+        std::vector<Precision> x(r.estimate.size() ? r.estimate.size() : 1, 0.0);
+        check(sl_acl_extrapolated_solution(r.estimate.size(), config_.alpha, r.estimate.data(), r.residual.data(), x.data(), SL_MEM_HOST));
+        x.resize(r.estimate.size());
+        return x;
     }
 };
 

@@ -103,6 +103,9 @@ static int one_system(uint64_t n, uint64_t seed, int hubs)
         if (n) {
             CHECK(orc_acl_forward_push(n, rp, ci, w, 2, src, &ao, x, y, &ar) == ORC_OK);
             CHECK(orc_acl_backward_push(n, rp, ci, w, 1, src, &ao, x, y, &ar) == ORC_OK);
+            orc_acl_extrapolated_solution(n, ao.alpha, x, y, z);
+            CHECK(orc_acl_backward_push_with_source(n, rp, ci, w, src[1], 0, 1e-3, &ao, x, y, &ar, 0, 0) == ORC_OK);
+            CHECK(orc_acl_backward_push_with_source(n, rp, ci, w, n + 3, 0, 1e-3, &ao, x, y, &ar, 0, 0) == ORC_OK && ar.push_count == 0);
         }
     }
     double mean = 0.0, var = 0.0;

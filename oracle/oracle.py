@@ -256,7 +256,9 @@ def push_sync_solve(rp, ci, va, b, theta, max_rounds=100000, order=ORDER_SEQ, x0
 def acl_push(rp, ci, w, sources, *, alpha=0.15, epsilon=1e-6, max_pushes=1_000_000, queue_threshold=1e-8,
              adaptive_threshold=True, backward=False, target=None, target_precision=0.0, log_cap=0):
     """ACL forward / backward push in the spec's visiting order (forward_push.rs:67-216, backward_push.rs:67-220); target != None:
-    solve_with_target (forward_push.rs:233-290; one source); log_cap > 0: also the sequence of pushed nodes ("push_log")"""
+    solve_with_target (forward_push.rs:233-290; one source) — or, with backward=True, solve_with_source (backward_push.rs:238-293):
+    `sources` = [the target node the mass starts at], `target` = the SOURCE node whose precision ends the loop;
+    log_cap > 0: also the sequence of pushed nodes ("push_log")"""
     rp, ci, w = _u32(rp), _u32(ci), _f(w)
     n = rp.size - 1
     src = np.ascontiguousarray(sources, dtype=np.uint64)
@@ -266,7 +268,10 @@ def acl_push(rp, ci, w, sources, *, alpha=0.15, epsilon=1e-6, max_pushes=1_000_0
     out = AclResult()
     log = np.zeros(max(int(log_cap), 1), dtype=np.uint32)
     l = lib()
-    if target is not None:
+    if target is not None and backward:
+        st = l.orc_acl_backward_push_with_source(u64(n), _p(rp), _p(ci), _p(w), u64(int(target)), u64(int(src[0])), C.c_double(target_precision),
+                                                 C.byref(o), _p(est), _p(res), C.byref(out), _p(log), u64(int(log_cap)))
+    elif target is not None:
         st = l.orc_acl_forward_push_with_target(u64(n), _p(rp), _p(ci), _p(w), u64(int(src[0])), u64(int(target)), C.c_double(target_precision),
                                                 C.byref(o), _p(est), _p(res), C.byref(out), _p(log), u64(int(log_cap)))
     else:
@@ -279,6 +284,14 @@ def acl_push(rp, ci, w, sources, *, alpha=0.15, epsilon=1e-6, max_pushes=1_000_0
     if log_cap:
         r["push_log"] = log[: min(int(log_cap), int(out.push_count))].copy()
     return r
+
+
+def acl_extrapolated_solution(alpha, estimate, residual):
+    """{Forward,Backward}PushSolver::extrapolated_solution (forward_push.rs:292-301, backward_push.rs:302-311)"""
+    e, r = _f(estimate), _f(residual)
+    out = np.empty(max(e.size, 1))
+    lib().orc_acl_extrapolated_solution(u64(e.size), C.c_double(alpha), _p(e), _p(r), _p(out))
+    return out[: e.size]
 
 
 def csr_transpose(rp, ci, va, ncols=None):

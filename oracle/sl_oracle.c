@@ -608,7 +608,8 @@ static void row_sums(uint64_t n, const uint32_t *rp, const double *w, double *ou
 }
 
 /* direction 0 = forward (forward_push.rs:67-216), 1 = backward (backward_push.rs:67-220) */
-/* target != NULL: ForwardPushSolver::solve_with_target (forward_push.rs:233-290) — source and target both in range or an empty
+/* target != NULL: ForwardPushSolver::solve_with_target (forward_push.rs:233-290) or, backward, BackwardPushSolver::solve_with_source
+ * (backward_push.rs:238-293; `src` is then the target node and `target` the source whose precision ends the loop) — both in range or an empty
  * result, and the loop ends as soon as estimate[target] > precision and residual[target] < 0.1 precision (checked before every pop).
  * push_log (may be NULL): the nodes pushed, in order, up to log_cap. */
 static int acl_push(uint64_t n, const uint32_t *rp, const uint32_t *ci, const double *w,
@@ -703,6 +704,22 @@ int orc_acl_backward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *c
                           const orc_acl_opts *opts, double *estimate, double *residual, orc_acl_result *res)
 {
     return acl_push(n, row_ptr, col_idx, weights, ntgt, targets, opts, estimate, residual, res, 1, 0, 0.0, 0, 0);
+}
+/* BackwardPushSolver::solve_with_source, backward_push.rs:238-293: unit mass at `target`, pushed over the reverse adjacency; source or
+ * target out of range: empty result (:243-251); the loop ends as soon as estimate[source] > precision and residual[source] < 0.1
+ * precision (:262-264, checked before every pop) */
+int orc_acl_backward_push_with_source(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *weights, uint64_t source,
+                                      uint64_t target, double source_precision, const orc_acl_opts *opts, double *estimate, double *residual,
+                                      orc_acl_result *res, uint32_t *push_log, uint64_t log_cap)
+{
+    return acl_push(n, row_ptr, col_idx, weights, 1, &target, opts, estimate, residual, res, 1, &source, source_precision, push_log, log_cap);
+}
+/* ForwardPushSolver::extrapolated_solution (forward_push.rs:292-301) = BackwardPushSolver::extrapolated_solution (backward_push.rs:302-311):
+ * solution = estimate.clone(); solution[i] += alpha * residual[i] */
+void orc_acl_extrapolated_solution(uint64_t n, double alpha, const double *estimate, const double *residual, double *solution)
+{
+    for (uint64_t i = 0; i < n; ++i) solution[i] = estimate[i];
+    for (uint64_t i = 0; i < n; ++i) solution[i] = solution[i] + alpha * residual[i];
 }
 
 /* ------------------------------------------------------------------ a14 -- */

@@ -173,6 +173,12 @@ int orc_acl_forward_push_logged(uint64_t n, const uint32_t *row_ptr, const uint3
 int orc_acl_forward_push_with_target(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *weights, uint64_t source,
                                      uint64_t target, double target_precision, const orc_acl_opts *opts, double *estimate, double *residual,
                                      orc_acl_result *res, uint32_t *push_log, uint64_t log_cap);
+/* BackwardPushSolver::solve_with_source, backward_push.rs:238-293 */
+int orc_acl_backward_push_with_source(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *weights, uint64_t source,
+                                      uint64_t target, double source_precision, const orc_acl_opts *opts, double *estimate, double *residual,
+                                      orc_acl_result *res, uint32_t *push_log, uint64_t log_cap);
+/* {Forward,Backward}PushSolver::extrapolated_solution, forward_push.rs:292-301 / backward_push.rs:302-311 */
+void orc_acl_extrapolated_solution(uint64_t n, double alpha, const double *estimate, const double *residual, double *solution);
 /* CompressedSparseRow::transpose, graph/mod.rs:92-130 */
 void orc_csr_transpose(uint64_t nrows, uint64_t ncols, const uint32_t *row_ptr, const uint32_t *col_idx,
                        const double *values, uint32_t *t_row_ptr, uint32_t *t_col_idx, double *t_values);

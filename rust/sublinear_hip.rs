@@ -1,0 +1,378 @@
+//! rust/sublinear_hip.rs — the reference-side binding of libsublinear_hip.so (MI355X): what a maintainer of ruvnet/sublinear-time-solver
+//! adds as `src/solver/hip.rs` behind `feature = "hip"` (declared in src/solver/mod.rs next to `pub mod neumann;`, mod.rs:14, and
+//! re-exported from lib.rs like `NeumannSolver`, lib.rs:70-97).  SOURCE ONLY: the build image has no rustc / cargo, so this file is
+//! not compiled here; what IS checked here (tests/test_rust_shim.py, no GPU needed) is that every `extern "C"` declaration and every
+//! `#[repr(C)]` struct below agrees with include/sublinear_hip.h — names, argument counts, pointer / scalar kinds and widths, field
+//! order — so the shim cannot drift from the ABI it binds.
+//!
+//! Interfaces it implements: `trait SolverAlgorithm` / `trait SolverState` (src/solver/mod.rs:223-351) over `&dyn Matrix`
+//! (src/matrix/mod.rs:25-104); `ForwardPushSolver` / `BackwardPushSolver` over `PushGraph` (src/solver/forward_push.rs:52-301,
+//! src/solver/backward_push.rs:60-311, src/graph/adjacency.rs:199-277).
+//! build.rs: `println!("cargo:rustc-link-lib=dylib=sublinear_hip")` + a `rustc-link-search` for the directory holding the `.so`.
+
+use crate::error::{Result, SolverError};
+use crate::matrix::Matrix;
+use crate::solver::{SolverAlgorithm, SolverOptions, SolverResult, SolverState, StepResult};
+use crate::types::{ErrorBounds, MemoryInfo, NodeId, Precision};
+use crate::graph::PushGraph;
+use crate::solver::forward_push::{ForwardPushConfig, ForwardPushResult};
+use crate::solver::backward_push::{BackwardPushConfig, BackwardPushResult};
+use core::ffi::{c_char, c_int, c_void};
+
+#[repr(C)] pub struct SlMatrix { _private: [u8; 0] }
+
+#[repr(C)] #[derive(Default)]
+pub struct SlNeumannOptions {
+    tolerance: f64, max_iterations: u64, max_terms: u64, series_tolerance: f64,
+    order: i32, start: i32, residual: i32, mem: i32, collect_stats: i32, compute_error_bounds: i32,
+}
+#[repr(C)] #[derive(Default)]
+pub struct SlNeumannResult {
+    iterations: u64, terms_computed: u64, matvec_count: u64, residual_norm: f64, last_term_norm: f64,
+    error_bound: f64, total_time_ms: f64, device_time_ms: f64, bytes_moved: u64,
+    converged: i32, series_converged: i32,
+}
+
+#[repr(C)] pub struct SlNeumannState { _private: [u8; 0] }
+
+#[link(name = "sublinear_hip")]
+extern "C" {
+    fn sl_last_error_message() -> *const c_char;
+    fn sl_matrix_create_from_triplets(n: u64, rows: *const u64, cols: *const u64, vals: *const f64,
+                                      n_rows: u64, n_cols: u64, flags: u32, out: *mut *mut SlMatrix) -> c_int;
+    fn sl_matrix_destroy(m: *mut SlMatrix);
+    fn sl_neumann_options_default(o: *mut SlNeumannOptions);
+    fn sl_neumann_solve(m: *const SlMatrix, b: *const f64, initial_guess: *const f64,
+                        opts: *const SlNeumannOptions, x_out: *mut f64, term_norms: *mut f64,
+                        result: *mut SlNeumannResult) -> c_int;
+    // NeumannState as an object (initialize / update_rhs / extract_solution / reset)
+    fn sl_neumann_state_create(m: *const SlMatrix, b: *const f64, initial_guess: *const f64, opts: *const SlNeumannOptions,
+                               out: *mut *mut SlNeumannState) -> c_int;
+    fn sl_neumann_state_destroy(s: *mut SlNeumannState);
+    fn sl_neumann_state_update_rhs(s: *mut SlNeumannState, count: u64, indices: *const u64, deltas: *const f64) -> c_int;
+    fn sl_neumann_state_run(s: *mut SlNeumannState, term_norms: *mut f64, result: *mut SlNeumannResult) -> c_int;
+    fn sl_neumann_state_solution(s: *const SlNeumannState, x_out: *mut f64, mem: c_int) -> c_int;
+    fn sl_neumann_state_reset(s: *mut SlNeumannState) -> c_int;
+}
+
+fn to_error(status: c_int, iterations: usize, residual: f64, tol: f64) -> SolverError {
+    let msg = unsafe { std::ffi::CStr::from_ptr(sl_last_error_message()) }.to_string_lossy().into_owned();
+    match status {                                            // 1:1 with error.rs:16-140
+        1 => SolverError::MatrixNotDiagonallyDominant { row: 0, diagonal: 0.0, off_diagonal_sum: 0.0 },
+        2 => SolverError::NumericalInstability { reason: msg, iteration: iterations, residual_norm: residual },
+        3 => SolverError::ConvergenceFailure { iterations, residual_norm: residual, tolerance: tol, algorithm: "neumann".into() },
+        4 => SolverError::InvalidInput { message: msg, parameter: None },
+        5 => SolverError::DimensionMismatch { expected: 0, actual: 0, operation: msg },
+        8 => SolverError::IndexOutOfBounds { index: 0, max_index: 0, context: msg },
+        9 => SolverError::InvalidSparseMatrix { reason: msg, position: None },
+        _ => SolverError::AlgorithmError { algorithm: "neumann-hip".into(), message: msg, context: vec![] },
+    }
+}
+
+/// Device copy of a `&dyn Matrix`, built ONCE (upload + row-slice layout) and kept for every later solve on the same matrix.
+/// Key = the address and shape of the borrowed matrix plus its nnz: the crate's matrices are immutable behind `&dyn Matrix`.
+pub struct HipMatrix { handle: *mut SlMatrix, key: (usize, usize, usize, usize) }
+unsafe impl Send for HipMatrix {}            // sl_matrix is immutable after create and shareable across threads (header, "Threading")
+unsafe impl Sync for HipMatrix {}
+impl HipMatrix {
+    fn key_of(m: &dyn Matrix) -> (usize, usize, usize, usize) { (m as *const dyn Matrix as *const () as usize, m.rows(), m.cols(), m.nnz()) }
+    pub fn upload(matrix: &dyn Matrix) -> Result<Self> {
+        // CSR arrays via the trait: to_triplets (matrix/mod.rs:298-305) keeps the builder rules in ONE place
+        let t = matrix.to_triplets()?;                                  // Vec<(usize, usize, Precision)>
+        let (r, c, v): (Vec<u64>, Vec<u64>, Vec<f64>) =
+            t.iter().fold((vec![], vec![], vec![]), |mut a, &(i, j, x)| { a.0.push(i as u64); a.1.push(j as u64); a.2.push(x); a });
+        let mut h: *mut SlMatrix = core::ptr::null_mut();
+        let st = unsafe { sl_matrix_create_from_triplets(v.len() as u64, r.as_ptr(), c.as_ptr(), v.as_ptr(),
+                                                         matrix.rows() as u64, matrix.cols() as u64, 0, &mut h) };
+        if st != 0 { return Err(to_error(st, 0, f64::INFINITY, 0.0)); }
+        Ok(Self { handle: h, key: Self::key_of(matrix) })
+    }
+}
+impl Drop for HipMatrix { fn drop(&mut self) { unsafe { sl_matrix_destroy(self.handle) } } }
+
+/// Same constructor surface as NeumannSolver (neumann.rs:48-92).  The solver caches the device matrix of the last system it saw.
+pub struct HipNeumannSolver { pub max_terms: usize, pub series_tolerance: Precision, cache: std::sync::Mutex<Option<std::sync::Arc<HipMatrix>>> }
+impl Default for HipNeumannSolver { fn default() -> Self { Self { max_terms: 50, series_tolerance: 1e-8, cache: Default::default() } } }
+impl HipNeumannSolver {
+    fn device_matrix(&self, matrix: &dyn Matrix) -> Result<std::sync::Arc<HipMatrix>> {
+        let mut slot = self.cache.lock().unwrap();
+        if let Some(m) = slot.as_ref() { if m.key == HipMatrix::key_of(matrix) { return Ok(m.clone()); } }
+        let m = std::sync::Arc::new(HipMatrix::upload(matrix)?);
+        *slot = Some(m.clone());
+        Ok(m)
+    }
+    fn options(&self, options: &SolverOptions) -> (SlNeumannOptions, *const f64) {
+        // SolverOptions (mod.rs:22-45) + solver fields (neumann.rs:24-33)
+        let mut o = SlNeumannOptions::default();
+        unsafe { sl_neumann_options_default(&mut o) };
+        o.tolerance = options.tolerance; o.max_iterations = options.max_iterations as u64;
+        o.max_terms = self.max_terms as u64; o.series_tolerance = self.series_tolerance;
+        o.collect_stats = options.collect_stats as i32; o.compute_error_bounds = options.compute_error_bounds as i32;
+        let guess = options.initial_guess.as_ref().map(|g| { o.start = 2; g.as_ptr() }).unwrap_or(core::ptr::null());
+        // o.start = 1; o.residual = 1;   // opt in to the reference's x0 = D^-1 b / scaled-residual behaviour
+        (o, guess)
+    }
+}
+
+/// NeumannState (neumann.rs:95-137) living on the device: the ABI's state object + the matrix it borrows.
+pub struct HipState { raw: *mut SlNeumannState, _matrix: std::sync::Arc<HipMatrix>, n: usize, last: SlNeumannResult, tolerance: Precision }
+impl Drop for HipState { fn drop(&mut self) { unsafe { sl_neumann_state_destroy(self.raw) } } }
+impl SolverState for HipState {
+    fn residual_norm(&self) -> Precision { if self.last.iterations == 0 && self.last.matvec_count == 0 { Precision::INFINITY } else { self.last.residual_norm } }
+    fn matvec_count(&self) -> usize { self.last.matvec_count as usize }
+    fn error_bounds(&self) -> Option<ErrorBounds> { None }
+    fn memory_usage(&self) -> MemoryInfo { MemoryInfo::default() }
+    fn reset(&mut self) { unsafe { sl_neumann_state_reset(self.raw) }; self.last = SlNeumannResult::default(); }     // neumann.rs:367-378
+}
+
+impl SolverAlgorithm for HipNeumannSolver {
+    type State = HipState;
+    fn initialize(&self, matrix: &dyn Matrix, b: &[Precision], options: &SolverOptions) -> Result<HipState> {          // NeumannState::new
+        if b.len() != matrix.rows() {                                   // neumann.rs:154-160
+            return Err(SolverError::DimensionMismatch { expected: matrix.rows(), actual: b.len(), operation: "neumann_initialization".into() });
+        }
+        let dm = self.device_matrix(matrix)?;
+        let (o, guess) = self.options(options);
+        let mut raw = core::ptr::null_mut();
+        let st = unsafe { sl_neumann_state_create(dm.handle, b.as_ptr(), guess, &o, &mut raw) };
+        if st != 0 { return Err(to_error(st, 0, f64::INFINITY, options.tolerance)); }
+        Ok(HipState { raw, _matrix: dm, n: matrix.rows(), last: SlNeumannResult::default(), tolerance: options.tolerance })
+    }
+    /// One call runs the whole loop of neumann.rs:477-555 on the device (the reference's own `step` cannot iterate at all,
+    /// neumann.rs:393-419); it reports Converged / Failed like a last step would.
+    fn step(&self, s: &mut HipState) -> Result<StepResult> {
+        let st = unsafe { sl_neumann_state_run(s.raw, core::ptr::null_mut(), &mut s.last) };
+        match st { 0 => Ok(StepResult::Converged),
+                   3 => Ok(StepResult::Failed("convergence failure".into())),
+                   _ => Err(to_error(st, s.last.iterations as usize, s.last.residual_norm, s.tolerance)) }
+    }
+    fn is_converged(&self, s: &HipState) -> bool { s.last.converged != 0 }
+    fn extract_solution(&self, s: &HipState) -> Vec<Precision> {
+        let mut x = vec![0.0; s.n];
+        unsafe { sl_neumann_state_solution(s.raw, x.as_mut_ptr(), 0 /* SL_MEM_HOST */) };
+        x
+    }
+    /// neumann.rs:436-462 on the device state, statement for statement (rhs and solution += delta * dinv, series state reset;
+    /// IndexOutOfBounds for an index >= n).  An update is never dropped: any other failure comes back as an error.
+    fn update_rhs(&self, s: &mut HipState, d: &[(usize, Precision)]) -> Result<()> {
+        let (i, v): (Vec<u64>, Vec<f64>) = d.iter().map(|&(i, v)| (i as u64, v)).unzip();
+        let st = unsafe { sl_neumann_state_update_rhs(s.raw, d.len() as u64, i.as_ptr(), v.as_ptr()) };
+        if st != 0 { return Err(to_error(st, 0, s.last.residual_norm, s.tolerance)); }
+        s.last.converged = 0;
+        Ok(())
+    }
+    fn algorithm_name(&self) -> &'static str { "neumann-hip" }
+
+    fn solve(&self, matrix: &dyn Matrix, b: &[Precision], options: &SolverOptions) -> Result<SolverResult> {
+        if b.len() != matrix.rows() {                                   // neumann.rs:154-160
+            return Err(SolverError::DimensionMismatch { expected: matrix.rows(), actual: b.len(), operation: "neumann_initialization".into() });
+        }
+        let dm = self.device_matrix(matrix)?;                           // (i) uploaded and laid out once per matrix, reused by later solves
+        let (o, guess) = self.options(options);                         // (ii)
+        let mut x = vec![0.0; matrix.rows()];
+        let mut res = SlNeumannResult::default();
+        let st = unsafe { sl_neumann_solve(dm.handle, b.as_ptr(), guess, &o, x.as_mut_ptr(), core::ptr::null_mut(), &mut res) };
+        // (iii) status -> SolverError / SolverResult (mod.rs:118-195)
+        if st != 0 { return Err(to_error(st, res.iterations as usize, res.residual_norm, options.tolerance)); }
+        let mut out = if res.converged != 0 { SolverResult::success(x, res.residual_norm, res.iterations as usize) }
+                      else { SolverResult::failure(x, res.residual_norm, res.iterations as usize) };
+        if options.collect_stats {
+            let mut s = crate::types::SolverStats::new();
+            s.total_time_ms = res.total_time_ms; s.matvec_count = res.matvec_count as usize;
+            out.stats = Some(s);
+        }
+        Ok(out)
+    }
+}
+
+// ---- single-entry queries: ForwardPushSolver over a query session ---------------------------------------------------------------
+#[repr(C)] pub struct SlQuerySession { _private: [u8; 0] }
+#[repr(C)] #[derive(Default)]
+pub struct SlEstimateResult { estimate: f64, residual_l1: f64, rounds: u64, pushes: u64, rows_touched: u64,
+                              device_time_ms: f64, converged: i32, reserved: i32 }
+#[link(name = "sublinear_hip")]
+extern "C" {
+    fn sl_query_session_create(m: *const SlMatrix, matrix_is_transpose: c_int, b: *const f64, mem: c_int,
+                               out: *mut *mut SlQuerySession) -> c_int;
+    fn sl_query_session_estimate(q: *mut SlQuerySession, row: u64, theta: f64, max_rounds: u64,
+                                 res: *mut SlEstimateResult) -> c_int;
+    fn sl_query_session_destroy(q: *mut SlQuerySession);
+}
+
+/// ForwardPushSolver::new + query_single_entry (src/solver/forward_push.rs:52-66, 224-231): the session is created once per
+/// (graph, rhs); every query then costs the rows its push touches.  `matrix` is a handle made with flag 1
+/// (SL_MATRIX_WITH_TRANSPOSE) by sl_matrix_create_from_triplets, as in `solve` above; it is owned here.
+pub struct HipForwardPush { matrix: *mut SlMatrix, session: *mut SlQuerySession, epsilon: Precision, max_pushes: u64 }
+
+impl HipForwardPush {
+    pub fn new(matrix: *mut SlMatrix, b: &[Precision], config: &ForwardPushConfig) -> Result<Self> {
+        let mut session = core::ptr::null_mut();
+        let st = unsafe { sl_query_session_create(matrix, 0, b.as_ptr(), 0 /* SL_MEM_HOST */, &mut session) };
+        if st != 0 { return Err(to_error(st, 0, f64::INFINITY, config.epsilon)); }
+        Ok(Self { matrix, session, epsilon: config.epsilon, max_pushes: config.max_pushes as u64 })
+    }
+    pub fn query_single_entry(&mut self, row: NodeId) -> Result<(Precision, Precision)> {      // (estimate, ||r||_1)
+        let mut r = SlEstimateResult::default();
+        let st = unsafe { sl_query_session_estimate(self.session, row as u64, self.epsilon, self.max_pushes, &mut r) };
+        if st != 0 { return Err(to_error(st, r.rounds as usize, r.residual_l1, self.epsilon)); }
+        Ok((r.estimate, r.residual_l1))
+    }
+}
+impl Drop for HipForwardPush { fn drop(&mut self) { unsafe { sl_query_session_destroy(self.session); sl_matrix_destroy(self.matrix) } } }
+
+// ---- the graph side: ForwardPushSolver / BackwardPushSolver::new(graph, config) served from the header alone -------------------------
+#[repr(C)] pub struct SlPushGraph { _private: [u8; 0] }
+#[repr(C)] pub struct SlAclOptions { alpha: f64, epsilon: f64, queue_threshold: f64, max_pushes: u64, adaptive_threshold: i32, mem: i32 }
+#[repr(C)] #[derive(Default)]
+pub struct SlAclResult { push_count: u64, nodes_visited: u64, residual_norm: f64, device_time_ms: f64, stopped_by: i32, reserved: i32 }
+#[link(name = "sublinear_hip")]
+extern "C" {
+    fn sl_push_graph_create(n: u64, row_ptr: *const u32, col_idx: *const u32, weights: *const f64, mem: c_int, out: *mut *mut SlPushGraph) -> c_int;
+    fn sl_push_graph_destroy(g: *mut SlPushGraph);
+    fn sl_push_graph_degrees(g: *const SlPushGraph, out_deg: *mut f64, in_deg: *mut f64, mem: c_int) -> c_int;
+    fn sl_push_graph_system(g: *const SlPushGraph, alpha: f64, system_flags: u32, matrix_flags: u32, out: *mut *mut SlMatrix) -> c_int;
+    fn sl_forward_push_acl(g: *const SlPushGraph, n_sources: u64, sources: *const u64, o: *const SlAclOptions, estimate: *mut f64,
+                           residual: *mut f64, push_log: *mut u32, log_cap: u64, res: *mut SlAclResult) -> c_int;
+    fn sl_forward_push_acl_with_target(g: *const SlPushGraph, source: u64, target: u64, target_precision: f64, o: *const SlAclOptions,
+                                       estimate: *mut f64, residual: *mut f64, push_log: *mut u32, log_cap: u64, res: *mut SlAclResult) -> c_int;
+    fn sl_backward_push_acl(g: *const SlPushGraph, n_targets: u64, targets: *const u64, o: *const SlAclOptions, estimate: *mut f64,
+                            residual: *mut f64, push_log: *mut u32, log_cap: u64, res: *mut SlAclResult) -> c_int;
+    fn sl_backward_push_acl_with_source(g: *const SlPushGraph, source: u64, target: u64, source_precision: f64, o: *const SlAclOptions,
+                                        estimate: *mut f64, residual: *mut f64, push_log: *mut u32, log_cap: u64, res: *mut SlAclResult) -> c_int;
+    fn sl_acl_extrapolated_solution(count: u64, alpha: f64, estimate: *const f64, residual: *const f64, solution: *mut f64, mem: c_int) -> c_int;
+    fn sl_backward_push_acl_reachability(g: *const SlPushGraph, target: u64, o: *const SlAclOptions, solution: *mut f64, res: *mut SlAclResult) -> c_int;
+    fn sl_acl_options_default(o: *mut SlAclOptions);
+}
+
+fn acl_options(alpha: f64, epsilon: f64, queue_threshold: f64, max_pushes: usize, adaptive: bool) -> SlAclOptions {
+    SlAclOptions { alpha, epsilon, queue_threshold, max_pushes: max_pushes as u64, adaptive_threshold: adaptive as i32, mem: 0 /* SL_MEM_HOST */ }
+}
+
+/// ForwardPushSolver over PushGraph (src/solver/forward_push.rs:52-301, src/graph/adjacency.rs:199-277).  The graph lives on the device;
+/// `solve_single_source` is the data-parallel push on the system sl_push_graph_system assembles (SL_SYSTEM_FORWARD, WITH_TRANSPOSE),
+/// with the spec's skip rule as per-row thresholds theta_u = alpha * epsilon * max(deg_u, 1); `solve_single_source_exact` and
+/// `solve_with_target` run the spec's OWN visiting order (WorkQueue pops) — push_count / nodes_visited / bits as the reference's loop.
+pub struct HipForwardPushSolver { graph: *mut SlPushGraph, system: *mut SlMatrix, config: ForwardPushConfig, n: usize }
+impl HipForwardPushSolver {
+    pub fn new(graph: &PushGraph, config: ForwardPushConfig) -> Result<Self> {
+        let a = &graph.adjacency;                                  // CompressedSparseRow { row_ptr, col_indices, values }
+        let (rp, ci): (Vec<u32>, Vec<u32>) = (a.row_ptr.iter().map(|&v| v as u32).collect(), a.col_indices.iter().map(|&v| v as u32).collect());
+        let (mut g, mut m) = (core::ptr::null_mut(), core::ptr::null_mut());
+        let st = unsafe { sl_push_graph_create(a.nrows as u64, rp.as_ptr(), ci.as_ptr(), a.values.as_ptr(), 0, &mut g) };
+        if st != 0 { return Err(to_error(st, 0, f64::INFINITY, config.epsilon)); }
+        let st = unsafe { sl_push_graph_system(g, config.alpha, 0 /* SL_SYSTEM_FORWARD */, 1 /* WITH_TRANSPOSE */, &mut m) };
+        if st != 0 { unsafe { sl_push_graph_destroy(g) }; return Err(to_error(st, 0, f64::INFINITY, config.epsilon)); }
+        Ok(Self { graph: g, system: m, config, n: a.nrows })
+    }
+    pub fn solve_with_target(&self, source: usize, target: usize, target_precision: f64) -> ForwardPushResult {    // forward_push.rs:233-290
+        let o = acl_options(self.config.alpha, self.config.epsilon, self.config.queue_threshold, self.config.max_pushes, self.config.adaptive_threshold);
+        let (mut est, mut res, mut r) = (vec![0.0; self.n], vec![0.0; self.n], SlAclResult::default());
+        unsafe { sl_forward_push_acl_with_target(self.graph, source as u64, target as u64, target_precision, &o, est.as_mut_ptr(),
+                                                 res.as_mut_ptr(), core::ptr::null_mut(), 0, &mut r) };
+        ForwardPushResult { estimate: est, residual: res, push_count: r.push_count as usize, nodes_visited: r.nodes_visited as usize, residual_norm: r.residual_norm }
+    }
+}
+impl HipForwardPushSolver {
+    /// solve_single_source / solve_multi_source in the spec's own order (forward_push.rs:67-177)
+    pub fn solve_multi_source_exact(&self, sources: &[usize]) -> ForwardPushResult {
+        let s: Vec<u64> = sources.iter().map(|&v| v as u64).collect();
+        let o = acl_options(self.config.alpha, self.config.epsilon, self.config.queue_threshold, self.config.max_pushes, self.config.adaptive_threshold);
+        let (mut est, mut res, mut r) = (vec![0.0; self.n], vec![0.0; self.n], SlAclResult::default());
+        unsafe { sl_forward_push_acl(self.graph, s.len() as u64, s.as_ptr(), &o, est.as_mut_ptr(), res.as_mut_ptr(), core::ptr::null_mut(), 0, &mut r) };
+        ForwardPushResult { estimate: est, residual: res, push_count: r.push_count as usize, nodes_visited: r.nodes_visited as usize, residual_norm: r.residual_norm }
+    }
+    pub fn solve_single_source_exact(&self, source: usize) -> ForwardPushResult { self.solve_multi_source_exact(&[source]) }
+    pub fn extrapolated_solution(&self, result: &ForwardPushResult) -> Vec<f64> {                                        // forward_push.rs:292-301
+        let mut x = vec![0.0; result.estimate.len()];
+        unsafe { sl_acl_extrapolated_solution(x.len() as u64, self.config.alpha, result.estimate.as_ptr(), result.residual.as_ptr(), x.as_mut_ptr(), 0) };
+        x
+    }
+}
+impl Drop for HipForwardPushSolver { fn drop(&mut self) { unsafe { sl_matrix_destroy(self.system); sl_push_graph_destroy(self.graph) } } }
+
+/// BackwardPushSolver over PushGraph (src/solver/backward_push.rs:60-311) in the spec's OWN visiting order: the WorkQueue's pops over the
+/// reverse adjacency, in-degrees in the admission rule — push_count / nodes_visited / every bit of estimate and residual as the
+/// reference's loop.  The reverse adjacency and both degree vectors live on the device (built once by sl_push_graph_create).
+pub struct HipBackwardPushSolver { graph: *mut SlPushGraph, config: BackwardPushConfig, n: usize }
+impl HipBackwardPushSolver {
+    pub fn new(graph: &PushGraph, config: BackwardPushConfig) -> Result<Self> {                                          // backward_push.rs:62-64
+        let a = &graph.adjacency;
+        let (rp, ci): (Vec<u32>, Vec<u32>) = (a.row_ptr.iter().map(|&v| v as u32).collect(), a.col_indices.iter().map(|&v| v as u32).collect());
+        let mut g = core::ptr::null_mut();
+        let st = unsafe { sl_push_graph_create(a.nrows as u64, rp.as_ptr(), ci.as_ptr(), a.values.as_ptr(), 0, &mut g) };
+        if st != 0 { return Err(to_error(st, 0, f64::INFINITY, config.epsilon)); }
+        Ok(Self { graph: g, config, n: a.nrows })
+    }
+    fn options(&self) -> SlAclOptions {
+        acl_options(self.config.alpha, self.config.epsilon, self.config.queue_threshold, self.config.max_pushes, self.config.adaptive_threshold)
+    }
+    fn result(est: Vec<f64>, res: Vec<f64>, r: SlAclResult) -> BackwardPushResult {
+        BackwardPushResult { estimate: est, residual: res, push_count: r.push_count as usize, nodes_visited: r.nodes_visited as usize, residual_norm: r.residual_norm }
+    }
+    pub fn solve_single_target(&self, target: usize) -> BackwardPushResult { self.solve_multi_target(&[target]) }         // :67-122 (one target: unit mass)
+    pub fn solve_multi_target(&self, targets: &[usize]) -> BackwardPushResult {                                          // :125-176
+        let t: Vec<u64> = targets.iter().map(|&v| v as u64).collect();
+        let (o, mut est, mut res, mut r) = (self.options(), vec![0.0; self.n], vec![0.0; self.n], SlAclResult::default());
+        unsafe { sl_backward_push_acl(self.graph, t.len() as u64, t.as_ptr(), &o, est.as_mut_ptr(), res.as_mut_ptr(), core::ptr::null_mut(), 0, &mut r) };
+        Self::result(est, res, r)
+    }
+    pub fn query_transition_probability(&self, source: usize, target: usize) -> f64 {                                    // :228-235
+        let r = self.solve_single_target(target);
+        if source < r.estimate.len() { r.estimate[source] } else { 0.0 }
+    }
+    /// :238-293 — ends once estimate[source] > source_precision && residual[source] < 0.1 source_precision (:262-264); source or target
+    /// out of range: the empty result (:243-251)
+    pub fn solve_with_source(&self, source: usize, target: usize, source_precision: f64) -> BackwardPushResult {
+        let (o, mut est, mut res, mut r) = (self.options(), vec![0.0; self.n], vec![0.0; self.n], SlAclResult::default());
+        unsafe { sl_backward_push_acl_with_source(self.graph, source as u64, target as u64, source_precision, &o, est.as_mut_ptr(),
+                                                  res.as_mut_ptr(), core::ptr::null_mut(), 0, &mut r) };
+        Self::result(est, res, r)
+    }
+    pub fn reachability_probabilities(&self, target: usize) -> Vec<f64> {                                                // :296-299, one call on the device
+        let (o, mut x, mut r) = (self.options(), vec![0.0; self.n], SlAclResult::default());
+        unsafe { sl_backward_push_acl_reachability(self.graph, target as u64, &o, x.as_mut_ptr(), &mut r) };
+        x
+    }
+    pub fn extrapolated_solution(&self, result: &BackwardPushResult) -> Vec<f64> {                                       // :302-311
+        let mut x = vec![0.0; result.estimate.len()];
+        unsafe { sl_acl_extrapolated_solution(x.len() as u64, self.config.alpha, result.estimate.as_ptr(), result.residual.as_ptr(), x.as_mut_ptr(), 0) };
+        x
+    }
+}
+impl Drop for HipBackwardPushSolver { fn drop(&mut self) { unsafe { sl_push_graph_destroy(self.graph) } } }
+
+// ---- one process per GPU: the communicator and the partitioned NeumannState (src/simd_ops.rs:201-239 is the crate's precedent: row
+// chunks behind one call).  A host that starts N processes drives N GPUs through these alone. -------------------------------------------
+#[repr(C)] pub struct SlComm { _private: [u8; 0] }
+#[repr(C)] #[derive(Default)]
+pub struct SlCommInfoT { rank: i32, world: i32, device: i32, transport: i32, halo_allreduce: i32, ranks_joined: i32, failed: i32, reserved: i32 }
+#[link(name = "sublinear_hip")]
+extern "C" {
+    fn sl_comm_create(rank: c_int, world: c_int, rendezvous_name: *const c_char, out: *mut *mut SlComm) -> c_int;
+    fn sl_comm_destroy(c: *mut SlComm);
+    fn sl_comm_barrier(c: *mut SlComm) -> c_int;
+    fn sl_comm_info(c: *const SlComm, info: *mut SlCommInfoT) -> c_int;
+    fn sl_matrix_create_csr(n_rows: u64, n_cols: u64, nnz: u64, row_ptr: *const u32, col_idx: *const u32, values: *const f64,
+                            mem: c_int, row_offset: u64, flags: u32, out: *mut *mut SlMatrix) -> c_int;
+    fn sl_neumann_state_create_partitioned(c: *mut SlComm, local_rows: *const SlMatrix, b_local: *const f64, initial_guess_local: *const f64,
+                                           opts: *const SlNeumannOptions, out: *mut *mut SlNeumannState) -> c_int;
+    fn sl_neumann_state_run_steps(s: *mut SlNeumannState, steps: u64, last_norm2: *mut f64, elapsed_ms: *mut f32) -> c_int;
+    fn sl_neumann_state_verify_exchange(s: *mut SlNeumannState, pieces_bad: *mut u64) -> c_int;
+    fn sl_neumann_state_current_term(s: *const SlNeumannState, first_row: u64, count: u64, t_out: *mut f64, mem: c_int) -> c_int;
+    fn sl_neumann_state_solution_rows(s: *const SlNeumannState, first_row: u64, count: u64, x_out: *mut f64, mem: c_int) -> c_int;
+}
+
+/// This rank's rows [lo, hi) of a system of n_global rows (CSR with GLOBAL column ids) as a NeumannState over the communicator: the
+/// SolverAlgorithm calls above then act collectively (every rank makes the same calls in the same order); `extract_solution` returns
+/// the rank's rows.
+pub fn initialize_partitioned(comm: *mut SlComm, n_global: usize, lo: usize, row_ptr: &[u32], col_idx: &[u32], values: &[f64],
+                              b_local: &[Precision], o: &SlNeumannOptions) -> Result<(*mut SlMatrix, *mut SlNeumannState)> {
+    let (mut m, mut s) = (core::ptr::null_mut(), core::ptr::null_mut());
+    let rows = row_ptr.len() - 1;
+    let st = unsafe { sl_matrix_create_csr(rows as u64, n_global as u64, values.len() as u64, row_ptr.as_ptr(), col_idx.as_ptr(), values.as_ptr(),
+                                           0 /* SL_MEM_HOST */, lo as u64, 0, &mut m) };
+    if st != 0 { return Err(to_error(st, 0, f64::INFINITY, o.tolerance)); }
+    let st = unsafe { sl_neumann_state_create_partitioned(comm, m, b_local.as_ptr(), core::ptr::null(), o, &mut s) };
+    if st != 0 { unsafe { sl_matrix_destroy(m) }; return Err(to_error(st, 0, f64::INFINITY, o.tolerance)); }
+    Ok((m, s))
+}

@@ -156,6 +156,9 @@ SIGNATURES = {
     "sl_forward_push_acl": (C.c_int, [vp, u64, vp, C.POINTER(AclOptions), vp, vp, vp, u64, C.POINTER(AclResult)]),
     "sl_backward_push_acl": (C.c_int, [vp, u64, vp, C.POINTER(AclOptions), vp, vp, vp, u64, C.POINTER(AclResult)]),
     "sl_forward_push_acl_with_target": (C.c_int, [vp, u64, u64, f64, C.POINTER(AclOptions), vp, vp, vp, u64, C.POINTER(AclResult)]),
+    "sl_backward_push_acl_with_source": (C.c_int, [vp, u64, u64, f64, C.POINTER(AclOptions), vp, vp, vp, u64, C.POINTER(AclResult)]),
+    "sl_acl_extrapolated_solution": (C.c_int, [u64, f64, vp, vp, vp, C.c_int]),
+    "sl_backward_push_acl_reachability": (C.c_int, [vp, u64, C.POINTER(AclOptions), vp, C.POINTER(AclResult)]),
     "sl_southwell_options_default": (None, [C.POINTER(SouthwellOptions)]),
     "sl_forward_push_southwell": (C.c_int, [vp, vp, C.POINTER(SouthwellOptions), vp, vp, vp, u64, C.POINTER(SouthwellResult)]),
     "sl_estimate_entry": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),

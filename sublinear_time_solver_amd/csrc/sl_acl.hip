@@ -540,4 +540,49 @@ sl_status sl_forward_push_acl_with_target(const sl_push_graph *g, uint64_t sourc
     SL_ABI_END
 }
 
+// BackwardPushSolver::solve_with_source, backward_push.rs:238-293: the same queue kernel over the reverse adjacency; the mass starts at
+// `target`, the node whose precision ends the loop is `source` (:262-264); either out of range: the empty result (:243-251)
+sl_status sl_backward_push_acl_with_source(const sl_push_graph *g, uint64_t source, uint64_t target, double source_precision, const sl_acl_options *o,
+                                           double *estimate, double *residual, uint32_t *push_log, uint64_t log_cap, sl_acl_result *res)
+{
+    SL_ABI_BEGIN
+    return acl_run(g, 1, 1, &target, o, 1, source, source_precision, estimate, residual, push_log, log_cap, res);
+    SL_ABI_END
+}
+
+// {Forward,Backward}PushSolver::extrapolated_solution, forward_push.rs:292-301 / backward_push.rs:302-311
+sl_status sl_acl_extrapolated_solution(uint64_t count, double alpha, const double *estimate, const double *residual, double *solution, sl_mem where)
+{
+    SL_ABI_BEGIN
+    if (count && (!estimate || !residual || !solution)) return sl_fail(SL_INVALID_INPUT, "null argument");
+    if (!count) return SL_OK;
+    if (where == SL_MEM_HOST) memcpy(solution, estimate, count * 8);                       // solution = estimate.clone()
+    else {
+        hipStream_t s = sl_context().stream;
+        SL_HIP(hipMemcpyAsync(solution, estimate, count * 8, hipMemcpyDeviceToDevice, s));
+    }
+    return sl_axpy(count, alpha, residual, solution, where);                               // solution[i] += alpha * res   (device; mul, then add)
+    SL_ABI_END
+}
+
+// BackwardPushSolver::reachability_probabilities, backward_push.rs:296-299
+sl_status sl_backward_push_acl_reachability(const sl_push_graph *g, uint64_t target, const sl_acl_options *o, double *solution, sl_acl_result *res)
+{
+    SL_ABI_BEGIN
+    if (!g || !o || !solution || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
+    const uint64_t n = g->n;
+    DevBuf est, rsd;
+    SL_TRY(est.alloc((n ? n : 1) * 8)); SL_TRY(rsd.alloc((n ? n : 1) * 8));
+    sl_acl_options od = *o;
+    od.mem = SL_MEM_DEVICE;
+    SL_TRY(acl_run(g, 1, 1, &target, &od, 0, 0, 0.0, est.as<double>(), rsd.as<double>(), nullptr, 0, res));
+    if (!n) return SL_OK;
+    hipStream_t s = sl_context().stream;
+    SL_TRY(sl_launch_axpy(n, o->alpha, rsd.as<double>(), est.as<double>(), s));
+    SL_HIP(hipMemcpyAsync(solution, est.p, n * 8, o->mem == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+    SL_HIP(hipStreamSynchronize(s));
+    return SL_OK;
+    SL_ABI_END
+}
+
 } // extern "C"

@@ -5,8 +5,9 @@
   ForwardPushConfig {alpha, epsilon, max_pushes, ...}            ForwardPushConfig  src/solver/forward_push.rs:26-49
   ForwardPushSolver::{solve_single_source, solve_multi_source,
       query_single_entry, extrapolated_solution}                 ForwardPushSolver  forward_push.rs:67-301
-  BackwardPushSolver::{solve_single_target, query_transition_probability,
-      combine_with_forward}                                      BackwardPushSolver src/solver/backward_push.rs:67-334
+  BackwardPushSolver::{solve_single_target, solve_multi_target, solve_with_source,
+      query_transition_probability, reachability_probabilities,
+      extrapolated_solution, combine_with_forward}                                      BackwardPushSolver src/solver/backward_push.rs:67-334
 
 The reference pushes one node at a time from a priority queue (inherently sequential).  The device runs the
 synchronous form of the same push: personalised PageRank pi_s = alpha e_s^T (I - (1-alpha) P)^-1 is the solution
@@ -143,6 +144,18 @@ class PushGraph:
     def acl_forward_with_target(self, source: int, target: int, target_precision: float, config, log_cap: int = 0):
         return self._acl(L.load().sl_forward_push_acl_with_target, (int(source), int(target), float(target_precision)), config, log_cap)
 
+    def acl_backward_with_source(self, source: int, target: int, source_precision: float, config, log_cap: int = 0):
+        return self._acl(L.load().sl_backward_push_acl_with_source, (int(source), int(target), float(source_precision)), config, log_cap)
+
+    def acl_reachability(self, target: int, config) -> np.ndarray:
+        o = L.AclOptions()
+        L.load().sl_acl_options_default(C.byref(o))
+        o.alpha, o.epsilon, o.queue_threshold, o.max_pushes = config.alpha, config.epsilon, config.queue_threshold, int(config.max_pushes)
+        o.adaptive_threshold, o.mem = (1 if config.adaptive_threshold else 0), L.SL_MEM_HOST
+        out, r = np.zeros(max(self.n, 1)), L.AclResult()
+        L.check(L.load().sl_backward_push_acl_reachability(self._h, int(target), C.byref(o), L.ptr(out), C.byref(r)))
+        return out[: self.n]
+
 
 class _PushBase:
     backward = False
@@ -168,8 +181,11 @@ class _PushBase:
         return PushResult(est, residual, out["pushes"], int(np.count_nonzero(est)), float(np.linalg.norm(residual)))
 
     def extrapolated_solution(self, result: PushResult) -> np.ndarray:
-        """estimate + alpha * residual, forward_push.rs:292-301"""
-        return result.estimate + self.config.alpha * result.residual
+        """estimate + alpha * residual, forward_push.rs:292-301 / backward_push.rs:302-311 (sl_acl_extrapolated_solution: on the device)"""
+        e, r = np.ascontiguousarray(result.estimate, dtype=np.float64), np.ascontiguousarray(result.residual, dtype=np.float64)
+        out = np.empty(max(e.size, 1))
+        L.check(L.load().sl_acl_extrapolated_solution(int(e.size), float(self.config.alpha), L.ptr(e), L.ptr(r), L.ptr(out), L.SL_MEM_HOST))
+        return out[: e.size]
 
 
 class ForwardPushSolver(_PushBase):
@@ -216,8 +232,19 @@ class BackwardPushSolver(_PushBase):
             return self.graph.acl_backward([target], self.config, log_cap)
         return self._solve([target])
 
-    def solve_multi_target(self, targets: Sequence[int]) -> PushResult:
+    def solve_multi_target(self, targets: Sequence[int], order: str = "synchronous", log_cap: int = 0) -> PushResult:   # backward_push.rs:125-176
+        if order == "reference":
+            return self.graph.acl_backward(list(targets), self.config, log_cap)
         return self._solve(list(targets))
+
+    def solve_with_source(self, source: int, target: int, source_precision: float, log_cap: int = 0) -> PushResult:     # backward_push.rs:238-293
+        """early termination once estimate[source] > source_precision and residual[source] < 0.1 source_precision (:262-264) — defined by
+        the visiting order, so it always runs the spec's own; source or target out of range: the empty result (:243-251)"""
+        return self.graph.acl_backward_with_source(source, target, source_precision, self.config, log_cap)
+
+    def reachability_probabilities(self, target: int) -> np.ndarray:                                                    # backward_push.rs:296-299
+        """solve_single_target(target) in the spec's order, then extrapolated_solution of its result — one call, on the device"""
+        return self.graph.acl_reachability(target, self.config)
 
     def query_transition_probability(self, source: int, target: int) -> float:   # :228-235
         r = self.solve_single_target(target)

@@ -74,6 +74,15 @@ int main()
         EXPECT(std::fabs(mm - 1.0) < 0.01);
         BackwardPushSolver bps(g);
         EXPECT(bps.solve_single_target(1).push_count > 0 && bps.query_transition_probability(0, 1) > 0.0);
+        // solve_with_source / reachability_probabilities / extrapolated_solution (backward_push.rs:238-311): the oracle's run of the fixture
+        // from target 3 takes 305 pushes; stopping once node 1 holds half of its final estimate takes 12
+        const BackwardPushResult bfull = bps.solve_single_target(3);
+        const BackwardPushResult bsrc = bps.solve_with_source(1, 3, 0.5 * bfull.estimate[1]);
+        EXPECT(bfull.push_count == 305 && bsrc.push_count == 12 && bsrc.estimate[1] > 0.5 * bfull.estimate[1]);
+        EXPECT(bps.solve_with_source(9, 3, 0.1).push_count == 0 && bps.solve_with_source(1, 9, 0.1).push_count == 0);   // :243-251
+        const std::vector<double> reach = bps.reachability_probabilities(3), extra = bps.extrapolated_solution(bfull);
+        for (int i = 0; i < 4; ++i) EXPECT(reach[i] == extra[i] && reach[i] == bfull.estimate[i] + 0.15 * bfull.residual[i]);
+        EXPECT(bps.solve_multi_target({3, 1}).push_count > 0);
         auto e = PushGraph::from_edges(5, {{0, 1, 1.0}, {1, 2, 1.0}, {2, 3, 1.0}, {7, 1, 1.0}});     // the invalid edge is skipped
         EXPECT(e.num_edges() == 3 && ForwardPushSolver(e).solve_single_source(0).estimate[4] == 0.0);
     }

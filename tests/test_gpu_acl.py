@@ -187,3 +187,45 @@ def test_pagerank_through_the_device_assembled_system(gpu):
         out = S.PushSolver(theta=1e-18).solve(m, np.full(n, (1.0 - d) / n))
         ref = z[f"{key}__pagerank"]
         assert out["converged"] and np.abs(out["solution"] - ref).max() <= 1e-13, key
+
+
+def test_backward_solve_with_source_multi_target_and_reachability(gpu):
+    """BackwardPushSolver::{solve_with_source, solve_multi_target, reachability_probabilities, extrapolated_solution}
+    (backward_push.rs:125-176, 238-311) in the spec's order: sequence, counts and bits against the CPU restatement, on the messy graph and
+    on the 4-node fixture of tests/rust/push_tests.rs:15-22"""
+    for g, cfg, tgt, src0 in ((messy_graph(900, 13), ForwardPushConfig(alpha=0.15, epsilon=1e-7, max_pushes=60_000), 4, None),
+                              (simple_graph(), ForwardPushConfig(alpha=0.15, epsilon=1e-6), 3, None)):
+        kw = dict(alpha=cfg.alpha, epsilon=cfg.epsilon, max_pushes=cfg.max_pushes)
+        b = BackwardPushSolver(g, cfg)
+        full = b.solve_single_target(tgt, order="reference", log_cap=60_000)
+        src = int(np.argsort(full.estimate)[-2])                             # a node that does reach the target
+        prec = float(full.estimate[src]) * 0.5
+        r = b.solve_with_source(src, tgt, prec, log_cap=60_000)
+        o = O.acl_push(g.row_ptr, g.col_idx, g.weights, [tgt], backward=True, target=src, target_precision=prec, log_cap=60_000, **kw)
+        same_as_oracle(r, o, "backward with source")
+        assert r.stopped_by == 3 and r.push_count < full.push_count and r.estimate[src] > prec and r.residual[src] < 0.1 * prec   # :262-264
+        # a precision the source never reaches: the loop runs to its end, the single-target result
+        never = b.solve_with_source(src, tgt, 10.0, log_cap=60_000)
+        same_as_oracle(never, O.acl_push(g.row_ptr, g.col_idx, g.weights, [tgt], backward=True, log_cap=60_000, **kw), "backward with source, precision out of reach")
+        assert never.stopped_by == 1 and (bits(never.estimate) == bits(full.estimate)).all()
+        # source or target out of range: the empty result (:243-251)
+        for s, t in ((g.n + 7, 1), (1, g.n + 7), (g.n, g.n)):
+            e = b.solve_with_source(s, t, 1e-3)
+            assert e.push_count == 0 and e.nodes_visited == 0 and e.estimate.sum() == 0.0 and e.residual.sum() == 0.0 and e.residual_norm == 0.0 and e.stopped_by == 0
+        # several targets (one repeated, one out of range), :125-176
+        tg = [tgt, 1, tgt, g.n + 3]
+        same_as_oracle(b.solve_multi_target(tg, order="reference", log_cap=60_000),
+                       O.acl_push(g.row_ptr, g.col_idx, g.weights, tg, backward=True, log_cap=60_000, **kw), "backward multi target")
+        # reachability_probabilities = solve_single_target + extrapolated_solution (:296-311), one call on the device
+        want = O.acl_extrapolated_solution(cfg.alpha, full.estimate, full.residual)
+        assert (bits(b.reachability_probabilities(tgt)) == bits(want)).all()
+        assert (bits(b.extrapolated_solution(full)) == bits(want)).all()
+        assert b.reachability_probabilities(g.n + 1).sum() == 0.0            # target out of range: zeros
+        f = ForwardPushSolver(g, cfg)
+        fr = f.solve_single_source(1, order="reference")
+        assert (bits(f.extrapolated_solution(fr)) == bits(O.acl_extrapolated_solution(cfg.alpha, fr.estimate, fr.residual))).all()   # forward_push.rs:292-301
+    # max_pushes ends solve_with_source like every other loop of the spec
+    g = messy_graph(900, 13)
+    cut = ForwardPushConfig(alpha=0.15, epsilon=1e-7, max_pushes=91)
+    r = BackwardPushSolver(g, cut).solve_with_source(5, 4, 1e-30, log_cap=200)
+    same_as_oracle(r, O.acl_push(g.row_ptr, g.col_idx, g.weights, [4], alpha=0.15, epsilon=1e-7, max_pushes=91, backward=True, target=5, target_precision=1e-30, log_cap=200), "with source, max_pushes")

@@ -210,6 +210,33 @@ def test_g5_monotone_and_edge_cases():
     assert (b["estimate"] >= 0).all() and b["estimate"][3] > 0
 
 
+def test_g5_backward_push_reference_tests():
+    """tests/rust/push_tests.rs:255-302 — query_transition_probability, solve_multi_target, reachability_probabilities on the reference's
+    own fixtures — plus solve_with_source's stop rule and empty results (backward_push.rs:238-293), which the reference leaves untested"""
+    rp, ci, w = _four_node()
+    q = lambda s, t: O.acl_push(rp, ci, w, [t], backward=True)["estimate"][s]
+    assert 0.0 <= q(0, 3) <= 1.0 and q(0, 0) > 0.0                                # :256-267
+    m = O.acl_push(rp, ci, w, [1, 3], backward=True)
+    assert m["push_count"] > 0 and m["nodes_visited"] > 0 and m["estimate"][1] > 0 and m["estimate"][3] > 0      # :270-284
+    prp, pci, pw = O.csr_from_triplets([0, 1, 2, 3], [1, 2, 3, 4], [1.0, 1.0, 1.0, 1.0], 5, 5)                   # create_path_graph(5), :49-58
+    r = O.acl_push(prp, pci, pw, [4], backward=True)
+    reach = O.acl_extrapolated_solution(0.15, r["estimate"], r["residual"])       # reachability_probabilities(4), :287-301
+    assert reach[4] > reach[3] > reach[2] > reach[1]
+    # The reference test's LAST inequality (reach[1] > reach[0] || reach[0] < 1e-6, :300) contradicts the code it tests: node 0 has no
+    # in-edges, so backward_push_node keeps its mass on it (self loop, backward_push.rs:210-215) and every re-push adds alpha of it to the
+    # estimate — 0.85^4 = 0.522 ends up on node 0.  The push files were never compiled (SURVEY 0.1), so the test never ran; the
+    # restatement follows the CODE, and this pins what the code gives.
+    assert abs(reach[0] - 0.85 ** 4) < 1e-5 and abs(reach[1] - 0.15 * 0.85 ** 3) < 1e-12
+    full = O.acl_push(rp, ci, w, [3], backward=True)
+    prec = 0.5 * full["estimate"][1]
+    ws = O.acl_push(rp, ci, w, [3], backward=True, target=1, target_precision=prec)
+    assert ws["push_count"] == 12 and full["push_count"] == 305                   # the loop ends at the first pop after the rule holds
+    assert ws["estimate"][1] > prec and ws["residual"][1] < 0.1 * prec            # backward_push.rs:262-264
+    for s, t in ((9, 3), (1, 9)):                                                 # :243-251
+        e = O.acl_push(rp, ci, w, [t], backward=True, target=s, target_precision=0.1)
+        assert e["push_count"] == 0 and e["estimate"].sum() == 0.0 and e["residual"].sum() == 0.0 and e["residual_norm"] == 0.0
+
+
 # ---- G6: TS forward push (tests/mcp/mcp-tool-tests.js:27-52) ---------------------------------------
 def _tridiag10():
     tr, tc, tv = [], [], []
