@@ -403,11 +403,11 @@ sl_status sl_push_graph_create(uint64_t n, const uint32_t *row_ptr, const uint32
         hipLaunchKernelGGL(pg_count_kernel, dim3(grid_of(nnz)), dim3(256), 0, s, nnz, g->d_ci, g->d_trp);
         // the column histogram -> row pointers of the reverse adjacency (host prefix sum: one-off, n + 1 words)
         std::vector<uint32_t> tp(n + 1);
-        SL_HIP(hipMemcpyAsync(tp.data(), g->d_trp, (n + 1) * 4, hipMemcpyDeviceToHost, s));
-        SL_HIP(hipStreamSynchronize(s));
+        SL_TRY(sl_read_back(tp.data(), g->d_trp, (n + 1) * 4, s));                                   // (control-plane transfers: the library's pinned staging)
         uint64_t run = 0;
         for (uint64_t j = 0; j <= n; ++j) { run += tp[j]; tp[j] = (uint32_t)run; }
-        SL_HIP(hipMemcpyAsync(g->d_trp, tp.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
+        if (run != nnz) return sl_fail(SL_DEVICE_ERROR, "push graph: the in-degree histogram as read back sums to %llu, the graph holds %llu edges", (unsigned long long)run, (unsigned long long)nnz);
+        SL_TRY(sl_upload(g->d_trp, tp.data(), (n + 1) * 4, s));
         hipLaunchKernelGGL(pg_iota_kernel, dim3(grid_of(nnz)), dim3(256), 0, s, nnz, iota.as<uint32_t>());
         int bits = 1;
         while (bits < 32 && (1ull << bits) < n) ++bits;
@@ -495,12 +495,11 @@ sl_status sl_push_graph_system(const sl_push_graph *g, double alpha, uint32_t sy
     if (n) hipLaunchKernelGGL((pg_system_kernel<true>), dim3(grid), dim3(256), 0, s, n, backward, dangling_identity, alpha, srp, sci, sw, g->d_deg, (const uint32_t *)nullptr, orp.as<uint32_t>(),
                               (uint32_t *)nullptr, (double *)nullptr);
     std::vector<uint32_t> hp(n + 1);
-    SL_HIP(hipMemcpyAsync(hp.data(), orp.p, (n + 1) * 4, hipMemcpyDeviceToHost, s));
-    SL_HIP(hipStreamSynchronize(s));
+    SL_TRY(sl_read_back(hp.data(), orp.p, (n + 1) * 4, s));
     uint64_t run = 0;
     for (uint64_t i = 0; i <= n; ++i) { run += hp[i]; if (run > 0xfffffff0ull) return sl_fail(SL_ALLOCATION, "system too large for 32-bit entry counts"); hp[i] = (uint32_t)run; }
     const uint64_t onnz = run;
-    SL_HIP(hipMemcpyAsync(orp.p, hp.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
+    SL_TRY(sl_upload(orp.p, hp.data(), (n + 1) * 4, s));
     SL_TRY(oci.alloc((onnz ? onnz : 1) * 4)); SL_TRY(ova.alloc((onnz ? onnz : 1) * 8));
     if (n) hipLaunchKernelGGL((pg_system_kernel<false>), dim3(grid), dim3(256), 0, s, n, backward, dangling_identity, alpha, srp, sci, sw, g->d_deg, orp.as<uint32_t>(), (uint32_t *)nullptr,
                               oci.as<uint32_t>(), ova.as<double>());

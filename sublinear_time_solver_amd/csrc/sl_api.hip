@@ -97,6 +97,54 @@ void *sl_scratch(size_t bytes)
     return c.scratch;
 }
 
+static bool staging_pageable() { static const bool on = [] { const char *e = getenv("SL_STAGING"); return e && !strcmp(e, "pageable"); }(); return on; }
+static void *pinned_staging(size_t *cap)
+{
+    sl_ctx &c = sl_context();
+    const size_t want = 4u << 20;
+    if (!c.pinned) {
+        if (hipHostMalloc(&c.pinned, want, hipHostMallocDefault) != hipSuccess) { c.pinned = nullptr; return nullptr; }
+        c.pinned_bytes = want;
+    }
+    *cap = c.pinned_bytes;
+    return c.pinned;
+}
+sl_status sl_read_back(void *host_dst, const void *dev_src, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return SL_OK;
+    size_t cap = 0;
+    void *pin = staging_pageable() ? nullptr : pinned_staging(&cap);
+    if (!pin) {                                                    // SL_STAGING=pageable, or no page-locked memory to be had
+        SL_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st));
+        SL_HIP(hipStreamSynchronize(st));
+        return SL_OK;
+    }
+    for (size_t off = 0; off < bytes; off += cap) {
+        const size_t len = bytes - off < cap ? bytes - off : cap;
+        SL_HIP(hipMemcpyAsync(pin, static_cast<const char *>(dev_src) + off, len, hipMemcpyDeviceToHost, st));
+        SL_HIP(hipStreamSynchronize(st));
+        memcpy(static_cast<char *>(host_dst) + off, pin, len);
+    }
+    return SL_OK;
+}
+sl_status sl_upload(void *dev_dst, const void *host_src, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return SL_OK;
+    size_t cap = 0;
+    void *pin = staging_pageable() ? nullptr : pinned_staging(&cap);
+    if (!pin) {
+        SL_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st));
+        return SL_OK;
+    }
+    for (size_t off = 0; off < bytes; off += cap) {
+        const size_t len = bytes - off < cap ? bytes - off : cap;
+        memcpy(pin, static_cast<const char *>(host_src) + off, len);
+        SL_HIP(hipMemcpyAsync(static_cast<char *>(dev_dst) + off, pin, len, hipMemcpyHostToDevice, st));
+        SL_HIP(hipStreamSynchronize(st));                           // the staging buffer is free again, the table is on the device
+    }
+    return SL_OK;
+}
+
 bool sl_side_stream(sl_ctx &c)
 {
     int dev = -1;
@@ -314,6 +362,7 @@ sl_status sl_matrix_create_csr(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, c
     SL_ABI_BEGIN
     sl_matrix *m = new sl_matrix();
     m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz; m->row_offset = row_offset; m->flags = flags;
+    m->caller_device_arrays = where != SL_MEM_HOST;
     hipGetDevice(&m->device);
     const bool keep = (flags & (SL_MATRIX_KEEP_CSR | SL_MATRIX_WITH_TRANSPOSE)) != 0;
     sl_status st;

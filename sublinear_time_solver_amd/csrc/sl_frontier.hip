@@ -1149,6 +1149,11 @@ static void query_lane_main(sl_query_session *q, sl_query_pool *p)
     {
         std::unique_lock<std::mutex> lk(p->mu);
         if (init != SL_OK && p->first_error == SL_OK) { p->first_error = init; p->first_msg = sl_context().last_error; }
+        // a lane that joins a pool which has already run jobs starts at the pool's CURRENT generation: the jobs before it were never
+        // published to it (with seen = 0 its first wait returned at once, for a job it had no part in, and it then took `active` down a
+        // second time — the caller could return while another lane still wrote its results).  The creator publishes the next job only
+        // after it has seen `ready` rise, so the generation read here is the last one this lane did NOT take part in.
+        seen = p->generation;
         ++p->ready;
         p->cv_done.notify_all();
     }
@@ -1171,12 +1176,13 @@ static void query_lane_main(sl_query_session *q, sl_query_pool *p)
             }
         }
         std::unique_lock<std::mutex> lk(p->mu);
-        if (--p->active == 0) p->cv_done.notify_all();
+        if (p->active > 0 && --p->active == 0) p->cv_done.notify_all();      // one decrement per lane and generation (seen == generation here)
     }
     delete sub;
     sl_release_workspace();
     sl_ctx &c = sl_context();
     if (c.scratch) { (void)hipFree(c.scratch); c.scratch = nullptr; c.scratch_bytes = 0; }
+    if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_bytes = 0; }
     if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 }
 

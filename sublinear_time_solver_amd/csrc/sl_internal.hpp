@@ -123,6 +123,7 @@ struct sl_matrix {
     uint32_t pwr_rpb = 0, pwr_blocks = 0;
 
     uint64_t device_bytes = 0;
+    bool caller_device_arrays = false;  // sl_matrix_create_csr was handed device pointers (diagnostics of the layout build)
 };
 #ifndef SL_PANEL_TILE
 #define SL_PANEL_TILE 2048u          // rows per tile = per wave: their running sums live in LDS (16 KiB)
@@ -168,6 +169,9 @@ struct sl_ctx {
     // workspace pool (sl_ws_alloc / sl_ws_free)
     struct ws_block { void *p; size_t bytes; int device; bool in_use; };
     std::vector<ws_block> ws;
+    // pinned staging of the control-plane transfers (sl_read_back / sl_upload): page-locked host memory of the library's own
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
     // side stream + fork / join events: the long-row kernel of a launch runs beside the slice kernel (sl_kernels.hip)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -182,6 +186,15 @@ int sl_log_level();
 void sl_log(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 struct sl_range { explicit sl_range(const char *n) { sl_range_push(n); } ~sl_range() { sl_range_pop(); } sl_range(const sl_range &) = delete; sl_range &operator=(const sl_range &) = delete; };
 
+// Control-plane transfers — every word the HOST computes a layout from (slice widths, per-tile counts, column histograms) and every
+// table it sends back (slice pointers, tile pointers): through the library's own page-locked staging buffer, chunk by chunk, each chunk
+// complete (stream synchronised) before the host touches it.  No asynchronous copy ever targets pageable memory of a std::vector: in the
+// many-process campaigns of round 3 a row twice lost its diagonal because the slice pointers on the device did not match the row lengths
+// there, and the pageable paths of the runtime (staging rings shared by a process's copies, on-the-fly pinning) were the one part of that
+// chain the library did not control.  SL_STAGING=pageable restores the old calls (A/B in tests/fuzz_dist.py).
+// sl_read_back returns with the data in host_dst; sl_upload returns when host_src may be reused AND the data is on the device.
+sl_status sl_read_back(void *host_dst, const void *dev_src, size_t bytes, hipStream_t st);
+sl_status sl_upload(void *dev_dst, const void *host_src, size_t bytes, hipStream_t st);
 bool sl_side_stream(sl_ctx &c);      // lazily creates the side stream / events for the current device; false if that failed
 sl_ctx &sl_context();
 sl_status sl_fail(sl_status s, const char *fmt, ...);

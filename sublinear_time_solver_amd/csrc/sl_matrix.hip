@@ -31,9 +31,11 @@ __global__ __launch_bounds__(256) void sl_row_len_kernel(uint64_t n_rows, uint64
     uint32_t len = 0;
     if (i < n_rows) {
         len = row_ptr[i + 1] - row_ptr[i];
-        atomicMin(&minmax[0], len);
-        atomicMax(&minmax[1], len);
-        if (len > long_row) atomicAdd(&minmax[2], 1u);
+        if (minmax) {
+            atomicMin(&minmax[0], len);
+            atomicMax(&minmax[1], len);
+            if (len > long_row) atomicAdd(&minmax[2], 1u);
+        }
     }
     const bool is_long = len > long_row;             // leaves the slice layout (sl_long_rows_kernel owns it)
     row_len[i] = is_long ? SL_LONG_SENTINEL : len;
@@ -327,7 +329,7 @@ static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr,
     hipLaunchKernelGGL(sl_iota_kernel, dim3(g), dim3(256), 0, st, nnz, ent_in.as<uint32_t>());
     hipLaunchKernelGGL(sl_panel_tile_count_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, n, n_tiles, (uint32_t)SL_PANEL_TILE, d_row_ptr, m->d_row_len, cnt.as<uint32_t>());
     std::vector<uint32_t> count(n_tiles + 1), src(n_tiles + 1), dst(n_tiles + 1);
-    SL_HIP(hipMemcpyAsync(count.data(), cnt.p, n_tiles * 4, hipMemcpyDeviceToHost, st));
+    SL_TRY(sl_read_back(count.data(), cnt.p, n_tiles * 4, st));
     int bits = 32;                                                             // long rows carry the key 0xffffffff
     if (!m->n_long) { bits = 1; while (bits < 32 && (1ull << bits) < n_tiles * n_panels) ++bits; }
     SL_TRY(sl_sort_pairs_u32(key.as<uint32_t>(), key_out.as<uint32_t>(), ent_in.as<uint32_t>(), perm.as<uint32_t>(), nnz, bits, st));   // synchronises
@@ -337,6 +339,8 @@ static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr,
         run_s += count[t];
         run_d += (count[t] + SL_PANEL_CHUNK - 1) / SL_PANEL_CHUNK * SL_PANEL_CHUNK;
     }
+    if (run_s > nnz || (!m->n_long && run_s != nnz))                          // the tiles' counts are the entries of the slice layout: all of them, or all but the long rows'
+        return sl_fail(SL_DEVICE_ERROR, "column panels: the tiles' entry counts as read back sum to %llu, the matrix holds %llu entries", (unsigned long long)run_s, (unsigned long long)nnz);
     if (run_d > 0xfffffff0ull) return SL_OK;                                   // would not fit 32-bit stream offsets: stay without panels
     src[n_tiles] = (uint32_t)run_s; dst[n_tiles] = (uint32_t)run_d;
     DevBuf dsrc;
@@ -345,8 +349,8 @@ static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr,
     SL_HIP(hipMalloc(&m->d_pan_row, (run_d ? run_d : 1) * 2));
     SL_HIP(hipMalloc(&m->d_pan_col, (run_d ? run_d : 1) * 4));
     SL_HIP(hipMalloc(&m->d_pan_val, (run_d ? run_d : 1) * 8));
-    SL_HIP(hipMemcpyAsync(dsrc.p, src.data(), (n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
-    SL_HIP(hipMemcpyAsync(m->d_pan_tile_ptr, dst.data(), (n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
+    SL_TRY(sl_upload(dsrc.p, src.data(), (n_tiles + 1) * 4, st));
+    SL_TRY(sl_upload(m->d_pan_tile_ptr, dst.data(), (n_tiles + 1) * 4, st));
     hipLaunchKernelGGL(sl_panel_fill_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, n_tiles, dsrc.as<uint32_t>(), m->d_pan_tile_ptr, perm.as<uint32_t>(),
                        rowl.as<uint16_t>(), d_col_idx, d_values, m->d_pan_row, m->d_pan_col, m->d_pan_val);
     SL_HIP(hipGetLastError());
@@ -543,18 +547,19 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     DevBuf d_span_g0, d_span_phys;
     if (xcd) {
         SL_TRY(d_span_g0.alloc_owned(span_g0.size() * 4)); SL_TRY(d_span_phys.alloc_owned(phys_of_log.size() * 4));
-        SL_HIP(hipMemcpyAsync(d_span_g0.p, span_g0.data(), span_g0.size() * 4, hipMemcpyHostToDevice, st));
-        SL_HIP(hipMemcpyAsync(d_span_phys.p, phys_of_log.data(), phys_of_log.size() * 4, hipMemcpyHostToDevice, st));
+        SL_TRY(sl_upload(d_span_g0.p, span_g0.data(), span_g0.size() * 4, st));
+        SL_TRY(sl_upload(d_span_phys.p, phys_of_log.data(), phys_of_log.size() * 4, st));
     }
     hipLaunchKernelGGL(sl_pw_keys_kernel, dim3(g), dim3(256), 0, st, n, (uint32_t)n_panels, (uint32_t)n_tiles, d_row_ptr, d_col_idx, m->d_row_len,
                        key.as<uint32_t>(), rowl.as<uint16_t>(), cnt.as<uint32_t>(), deal, gpt, pbits, d_span_g0.as<uint32_t>(), d_span_phys.as<uint32_t>(),
                        (uint32_t)phys_of_log.size());
     std::vector<uint32_t> count(n_tiles + 1), src(n_tiles + 1), dst(n_tiles + 1), hpads(n_tiles + 1);
-    SL_HIP(hipMemcpyAsync(count.data(), cnt.p, n_tiles * 4, hipMemcpyDeviceToHost, st));
-    SL_HIP(hipStreamSynchronize(st));
+    SL_TRY(sl_read_back(count.data(), cnt.p, n_tiles * 4, st));
     uint64_t total = 0; uint32_t longest = 0;
     for (uint64_t t = 0; t < n_tiles; ++t) { src[t] = (uint32_t)total; total += count[t]; longest = std::max(longest, count[t]); }
     src[n_tiles] = (uint32_t)total;
+    if (total > nnz || (!m->n_long && total != nnz))
+        return sl_fail(SL_DEVICE_ERROR, "paced panels: the tiles' entry counts as read back sum to %llu, the matrix holds %llu entries", (unsigned long long)total, (unsigned long long)nnz);
     // persistent blocks with a fixed deal of tiles: only for matrices whose tiles carry (nearly) equal work
     if (total == 0 || (!force && (double)longest * (double)n_tiles > 1.1 * (double)total)) return SL_OK;
     hipLaunchKernelGGL(sl_iota_kernel, dim3(g), dim3(256), 0, st, nnz, ent_in.as<uint32_t>());
@@ -564,12 +569,11 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     SL_TRY(sl_sort_pairs_u32(key.as<uint32_t>(), key_out.as<uint32_t>(), ent_in.as<uint32_t>(), perm.as<uint32_t>(), nnz, bits, st));   // synchronises
     DevBuf dsrc, ddst;
     SL_TRY(dsrc.alloc_owned((n_tiles + 1) * 4));
-    SL_HIP(hipMemcpyAsync(dsrc.p, src.data(), (n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
+    SL_TRY(sl_upload(dsrc.p, src.data(), (n_tiles + 1) * 4, st));
     const uint32_t fg = (uint32_t)((n_tiles + 3) / 4);
     hipLaunchKernelGGL((sl_pw_fill_kernel<false>), dim3(fg), dim3(256), 0, st, n_tiles, rpw, dsrc.as<uint32_t>(), (const uint32_t *)nullptr, perm.as<uint32_t>(),
                        rowl.as<uint16_t>(), d_col_idx, d_values, pads.as<uint32_t>(), (uint32_t *)nullptr, (double *)nullptr);
-    SL_HIP(hipMemcpyAsync(hpads.data(), pads.p, n_tiles * 4, hipMemcpyDeviceToHost, st));
-    SL_HIP(hipStreamSynchronize(st));
+    SL_TRY(sl_read_back(hpads.data(), pads.p, n_tiles * 4, st));
     uint64_t chunks = 0;
     for (uint64_t t = 0; t < n_tiles; ++t) { dst[t] = (uint32_t)chunks; chunks += ((uint64_t)count[t] + hpads[t] + SL_PANEL_CHUNK - 1) / SL_PANEL_CHUNK; }
     dst[n_tiles] = (uint32_t)chunks;
@@ -577,7 +581,7 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     SL_HIP(hipMalloc(&m->d_pw_tile_ptr, (n_tiles + 1) * 4));
     SL_HIP(hipMalloc(&m->d_pw_idx, (chunks ? chunks : 1) * 256 * 4));
     SL_HIP(hipMalloc(&m->d_pw_val, (chunks ? chunks : 1) * 256 * 8));
-    SL_HIP(hipMemcpyAsync(m->d_pw_tile_ptr, dst.data(), (n_tiles + 1) * 4, hipMemcpyHostToDevice, st));
+    SL_TRY(sl_upload(m->d_pw_tile_ptr, dst.data(), (n_tiles + 1) * 4, st));
     hipLaunchKernelGGL((sl_pw_fill_kernel<true>), dim3(fg), dim3(256), 0, st, n_tiles, rpw, dsrc.as<uint32_t>(), m->d_pw_tile_ptr, perm.as<uint32_t>(),
                        rowl.as<uint16_t>(), d_col_idx, d_values, (uint32_t *)nullptr, m->d_pw_idx, m->d_pw_val);
     SL_HIP(hipGetLastError());
@@ -716,11 +720,11 @@ static sl_status sl_build_order_free_stream(sl_matrix *m, const uint32_t *d_row_
     hipLaunchKernelGGL(sl_pwr_keys_kernel, dim3(g), dim3(256), 0, st, n, (uint32_t)n_btiles, m->row_offset, d_row_ptr, d_col_idx, d_values,
                        key.as<unsigned long long>(), slot.as<uint16_t>(), cnt.as<uint32_t>(), diag.as<double>());
     std::vector<uint32_t> count(n_btiles + 1), src(n_btiles + 1), dst(n_btiles + 1), hch(n_btiles + 1);
-    SL_HIP(hipMemcpyAsync(count.data(), cnt.p, n_btiles * 4, hipMemcpyDeviceToHost, st));
-    SL_HIP(hipStreamSynchronize(st));
+    SL_TRY(sl_read_back(count.data(), cnt.p, n_btiles * 4, st));
     uint64_t total = 0; uint32_t longest = 0;
     for (uint64_t t = 0; t < n_btiles; ++t) { src[t] = (uint32_t)total; total += count[t]; longest = std::max(longest, count[t]); }
     src[n_btiles] = (uint32_t)total;
+    if (total > nnz) return sl_fail(SL_DEVICE_ERROR, "column stream: the tiles' entry counts as read back sum to %llu, the matrix holds %llu entries", (unsigned long long)total, (unsigned long long)nnz);
     // persistent blocks with a fixed deal of block tiles: only for matrices whose tiles carry (nearly) equal work
     if (total == 0 || (!force && (double)longest * (double)n_btiles > 1.1 * (double)total)) return SL_OK;
     hipLaunchKernelGGL(sl_iota_kernel, dim3(g), dim3(256), 0, st, nnz, ent_in.as<uint32_t>());
@@ -730,12 +734,11 @@ static sl_status sl_build_order_free_stream(sl_matrix *m, const uint32_t *d_row_
     key.reset(); key_out.reset(); ent_in.reset();
     DevBuf dsrc;
     SL_TRY(dsrc.alloc_owned((n_btiles + 1) * 4));
-    SL_HIP(hipMemcpyAsync(dsrc.p, src.data(), (n_btiles + 1) * 4, hipMemcpyHostToDevice, st));
+    SL_TRY(sl_upload(dsrc.p, src.data(), (n_btiles + 1) * 4, st));
     const uint32_t fg = (uint32_t)((n_btiles + 3) / 4);
     hipLaunchKernelGGL((sl_pwr_fill_kernel<false>), dim3(fg), dim3(256), 0, st, n_btiles, dsrc.as<uint32_t>(), (const uint32_t *)nullptr, perm.as<uint32_t>(), slot.as<uint16_t>(),
                        d_col_idx, d_values, nch.as<uint32_t>(), (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
-    SL_HIP(hipMemcpyAsync(hch.data(), nch.p, n_btiles * 4, hipMemcpyDeviceToHost, st));
-    SL_HIP(hipStreamSynchronize(st));
+    SL_TRY(sl_read_back(hch.data(), nch.p, n_btiles * 4, st));
     uint64_t chunks = 0;
     for (uint64_t t = 0; t < n_btiles; ++t) { dst[t] = (uint32_t)chunks; chunks += hch[t]; }
     dst[n_btiles] = (uint32_t)chunks;
@@ -745,7 +748,7 @@ static sl_status sl_build_order_free_stream(sl_matrix *m, const uint32_t *d_row_
     SL_HIP(hipMalloc(&m->d_pwr_idx, (chunks ? chunks : 1) * SL_PWR_CHUNK * 4));
     SL_HIP(hipMalloc(&m->d_pwr_val, (chunks ? chunks : 1) * SL_PWR_CHUNK * 8));
     SL_HIP(hipMalloc(&m->d_pwr_base, (chunks ? chunks : 1) * 4));
-    SL_HIP(hipMemcpyAsync(m->d_pwr_tile_ptr, dst.data(), (n_btiles + 1) * 4, hipMemcpyHostToDevice, st));
+    SL_TRY(sl_upload(m->d_pwr_tile_ptr, dst.data(), (n_btiles + 1) * 4, st));
     hipLaunchKernelGGL((sl_pwr_fill_kernel<true>), dim3(fg), dim3(256), 0, st, n_btiles, dsrc.as<uint32_t>(), m->d_pwr_tile_ptr, perm.as<uint32_t>(), slot.as<uint16_t>(),
                        d_col_idx, d_values, (uint32_t *)nullptr, m->d_pwr_idx, m->d_pwr_val, m->d_pwr_base);
     SL_HIP(hipGetLastError());
@@ -773,8 +776,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     hipLaunchKernelGGL(sl_validate_csr_kernel, dim3(grid_for(nnz > n ? nnz : n, 256) > 4096 ? 4096 : grid_for(nnz > n ? nnz : n, 256)),
                        dim3(256), 0, st, n, m->n_cols, nnz, d_row_ptr, d_col_idx, d_err);
     uint32_t h_err = 0;
-    SL_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    SL_HIP(hipStreamSynchronize(st));
+    SL_TRY(sl_read_back(&h_err, d_err, sizeof(uint32_t), st));
     if (h_err & 1u) { hipFree(d_err); return sl_fail(SL_INVALID_SPARSE_MATRIX, "row_ptr is not a monotone 0..nnz prefix array"); }
     if (h_err & 2u) { hipFree(d_err); return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "column index >= n_cols (%llu)", (unsigned long long)m->n_cols); }
 
@@ -792,16 +794,14 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     SL_HIP(hipMalloc(&m->d_row_len, (padded_rows ? padded_rows : 1) * sizeof(uint32_t)));
     SL_HIP(hipMalloc(&d_slice_w, (m->n_slices ? m->n_slices : 1) * sizeof(uint32_t)));
     const uint32_t mm_init[4] = {0xffffffffu, 0u, 0u, 0u};
-    SL_HIP(hipMemcpyAsync(d_err, mm_init, sizeof(mm_init), hipMemcpyHostToDevice, st));
+    SL_TRY(sl_upload(d_err, mm_init, sizeof(mm_init), st));
     if (m->n_slices)
         hipLaunchKernelGGL(sl_row_len_kernel, dim3((uint32_t)((padded_rows + 255) / 256)), dim3(256), 0, st, n, m->n_slices, m->long_row,
                            d_row_ptr, m->d_row_len, d_slice_w, d_err);
     std::vector<uint32_t> slice_w(m->n_slices), slice_ptr(m->n_slices + 1);
     uint32_t mm[4];
-    SL_HIP(hipMemcpyAsync(mm, d_err, sizeof(mm), hipMemcpyDeviceToHost, st));
-    if (m->n_slices)
-        SL_HIP(hipMemcpyAsync(slice_w.data(), d_slice_w, m->n_slices * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    SL_HIP(hipStreamSynchronize(st));
+    SL_TRY(sl_read_back(mm, d_err, sizeof(mm), st));
+    if (m->n_slices) SL_TRY(sl_read_back(slice_w.data(), d_slice_w, m->n_slices * sizeof(uint32_t), st));
     DevBuf slice_w_keep;                                          // (freed at the end of the build: the fill below may want the widths again)
     slice_w_keep.p = d_slice_w; slice_w_keep.pooled = false;
     m->min_row_nnz = n ? mm[0] : 0;
@@ -818,8 +818,10 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         if (ss != SL_OK) { hipFree(d_err); return ss; }
     }
     hipFree(d_err);
-    if (getenv("SL_DEBUG_STALE_SLICE_WIDTHS"))                    // tests: what a stale read-back would look like — every third width one pair block short
+#ifdef SL_DEBUG_HOOKS                                            // test builds only (make EXTRA=-DSL_DEBUG_HOOKS): what a stale read-back would look like
+    if (getenv("SL_DEBUG_STALE_SLICE_WIDTHS"))                    // every third width one pair block short
         for (uint64_t s = 0; s < m->n_slices; s += 3) if (slice_w[s]) --slice_w[s];
+#endif
     uint64_t acc = 0;
     for (uint64_t s = 0; s < m->n_slices; ++s) { slice_ptr[s] = (uint32_t)acc; acc += slice_w[s]; }
     if (acc > 0xffffffffull) return sl_fail(SL_ALLOCATION, "matrix too large for 32-bit slice pointers");
@@ -829,7 +831,14 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     if (getenv("SL_NO_UNROLLED")) m->uniform_width = 0;          // experiments: send uniform-width matrices through the batched path
 
     SL_HIP(hipMalloc(&m->d_slice_ptr, (m->n_slices + 1) * sizeof(uint32_t)));
-    SL_HIP(hipMemcpyAsync(m->d_slice_ptr, slice_ptr.data(), (m->n_slices + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    SL_TRY(sl_upload(m->d_slice_ptr, slice_ptr.data(), (m->n_slices + 1) * sizeof(uint32_t), st));
+#ifdef SL_DEBUG_HOOKS
+    if (const char *e = getenv("SL_DEBUG_STALE_SLICE_PTRS")) if (*e == '1' && m->n_slices > 4) {     // what a stale host-to-device copy would look like
+        std::vector<uint32_t> bad(slice_ptr);
+        for (uint64_t q = 3; q <= m->n_slices; ++q) bad[q] -= 1;                                       // slice 2 one pair block short, the rest shifted
+        SL_TRY(sl_upload(m->d_slice_ptr, bad.data(), (m->n_slices + 1) * sizeof(uint32_t), st));
+    }
+#endif
     SL_HIP(hipMalloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
     SL_HIP(hipMalloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
     unsigned long long *d_band = nullptr;
@@ -840,23 +849,39 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
                            m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_band);
     SL_HIP(hipGetLastError());
     unsigned long long h_band[5] = {0, 0, 0, 0, 0};
-    SL_HIP(hipMemcpyAsync(h_band, d_band, sizeof(h_band), hipMemcpyDeviceToHost, st));
-    SL_HIP(hipStreamSynchronize(st));
+    SL_TRY(sl_read_back(h_band, d_band, sizeof(h_band), st));
     hipFree(d_band);
     if (h_band[4]) {
-        // Rows that do not fit the slice the host's pointers give them: the slice widths the host summed were not the ones the device
-        // computed.  Seen twice in ~2200 many-process runs on one GPU and never otherwise — a row lost its last entries (the diagonal)
-        // and the dominance check refused a dominant matrix; the mechanism is not understood (the widths are read back with an
-        // asynchronous copy into pageable memory and a stream synchronisation, as everywhere).  Said aloud, repaired once: the widths are
-        // read again with a blocking copy, the pointers rebuilt, the slices filled again; a second misfit is an error.
-        std::vector<uint32_t> again(m->n_slices);
+        // Rows that do not fit the slice the host's pointers give them: somewhere between sl_row_len_kernel and sl_fill_slices_kernel the
+        // widths changed hands wrongly.  Seen twice in ~2200 many-process runs on one GPU in round 3 (a row lost its diagonal, the dominance
+        // check refused a dominant matrix) and never with the control-plane transfers on the library's own pinned staging (round 4).  The
+        // repair is also the diagnosis — every link of the chain is checked apart and the counts are logged (level 0: always):
+        //   (a) the widths the host summed against a second, blocking read of the SAME device buffer    -> a stale device-to-host copy
+        //   (b) that buffer against a re-run of sl_row_len_kernel on the same inputs                    -> inputs not complete when the kernel ran
+        //   (c) the slice pointers ON THE DEVICE against the ones the host uploaded                     -> a stale host-to-device copy
+        std::vector<uint32_t> again(m->n_slices), rerun(m->n_slices), ptr_dev(m->n_slices + 1);
+        SL_HIP(hipDeviceSynchronize());
         SL_HIP(hipMemcpy(again.data(), slice_w_keep.p, m->n_slices * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        uint64_t differ = 0;
-        for (uint64_t q = 0; q < m->n_slices; ++q) differ += again[q] != slice_w[q];
-        sl_log(0, "matrix layout: %llu rows did not fit their slices; %llu of %llu slice widths differ between the first read-back and a second, blocking one — rebuilding",
-               h_band[4], (unsigned long long)differ, (unsigned long long)m->n_slices);
+        SL_HIP(hipMemcpy(ptr_dev.data(), m->d_slice_ptr, (m->n_slices + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t differ_a = 0, differ_b = 0, differ_c = 0;
+        {
+            DevBuf w2, len2, mm2;
+            SL_TRY(w2.alloc_owned(m->n_slices * 4)); SL_TRY(len2.alloc_owned((padded_rows ? padded_rows : 1) * 4)); SL_TRY(mm2.alloc_owned(16));
+            SL_HIP(hipMemcpy(mm2.p, mm_init, sizeof(mm_init), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(sl_row_len_kernel, dim3((uint32_t)((padded_rows + 255) / 256)), dim3(256), 0, st, n, m->n_slices, m->long_row,
+                               d_row_ptr, len2.as<uint32_t>(), w2.as<uint32_t>(), mm2.as<uint32_t>());
+            SL_HIP(hipDeviceSynchronize());
+            SL_HIP(hipMemcpy(rerun.data(), w2.p, m->n_slices * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
+        for (uint64_t q = 0; q < m->n_slices; ++q) { differ_a += again[q] != slice_w[q]; differ_b += rerun[q] != again[q]; }
+        for (uint64_t q = 0; q <= m->n_slices; ++q) differ_c += ptr_dev[q] != slice_ptr[q];
+        sl_log(0, "matrix layout: %llu rows did not fit their slices (%llu slices).  (a) host copy of the widths vs a blocking re-read of the same buffer: %llu differ; "
+                  "(b) that buffer vs a re-run of the row-length kernel: %llu differ; (c) slice pointers on the device vs the ones uploaded: %llu differ.  "
+                  "Library stream %p, staging %s, caller's CSR arrays %s — rebuilding from the re-run",
+               h_band[4], (unsigned long long)m->n_slices, (unsigned long long)differ_a, (unsigned long long)differ_b, (unsigned long long)differ_c, (void *)st,
+               getenv("SL_STAGING") ? getenv("SL_STAGING") : "pinned", m->caller_device_arrays ? "in device memory (SL_MEM_DEVICE)" : "uploaded by the library (SL_MEM_HOST)");
         acc = 0;
-        for (uint64_t q = 0; q < m->n_slices; ++q) { slice_ptr[q] = (uint32_t)acc; acc += again[q]; }
+        for (uint64_t q = 0; q < m->n_slices; ++q) { slice_ptr[q] = (uint32_t)acc; acc += rerun[q]; }
         if (acc > 0xffffffffull) return sl_fail(SL_ALLOCATION, "matrix too large for 32-bit slice pointers");
         slice_ptr[m->n_slices] = (uint32_t)acc;
         m->padded_nnz = acc * 2 * SL_SLICE;
@@ -864,6 +889,9 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         SL_HIP(hipMalloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
         SL_HIP(hipMalloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
         SL_HIP(hipMemcpy(m->d_slice_ptr, slice_ptr.data(), (m->n_slices + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // the row lengths the fill walks must be the re-run's too (case b)
+        hipLaunchKernelGGL(sl_row_len_kernel, dim3((uint32_t)((padded_rows + 255) / 256)), dim3(256), 0, st, n, m->n_slices, m->long_row,
+                           d_row_ptr, m->d_row_len, static_cast<uint32_t *>(slice_w_keep.p), static_cast<uint32_t *>(nullptr));
         SL_HIP(hipMalloc(&d_band, 5 * sizeof(unsigned long long)));
         SL_HIP(hipMemsetAsync(d_band, 0, 5 * sizeof(unsigned long long), st));
         hipLaunchKernelGGL(sl_fill_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_cols,
@@ -953,11 +981,11 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         const uint32_t g = grid_for(nnz, 256) > 8192 ? 8192 : grid_for(nnz, 256);
         if (nnz) hipLaunchKernelGGL(sl_col_count_kernel, dim3(g), dim3(256), 0, st, nnz, d_col_idx, m->d_tptr);
         std::vector<uint32_t> tptr(m->n_cols + 1);
-        SL_HIP(hipMemcpyAsync(tptr.data(), m->d_tptr, (m->n_cols + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        SL_HIP(hipStreamSynchronize(st));
+        SL_TRY(sl_read_back(tptr.data(), m->d_tptr, (m->n_cols + 1) * sizeof(uint32_t), st));
         uint64_t run = 0;
         for (uint64_t j = 0; j <= m->n_cols; ++j) { run += tptr[j]; tptr[j] = (uint32_t)run; }
-        SL_HIP(hipMemcpyAsync(m->d_tptr, tptr.data(), (m->n_cols + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        if (run != nnz) return sl_fail(SL_DEVICE_ERROR, "transpose: the column histogram as read back sums to %llu, the matrix holds %llu entries", (unsigned long long)run, (unsigned long long)nnz);
+        SL_TRY(sl_upload(m->d_tptr, tptr.data(), (m->n_cols + 1) * sizeof(uint32_t), st));
         if (nnz) {
             uint32_t *d_keys = nullptr, *d_ent_in = nullptr, *d_ent = nullptr;
             SL_HIP(hipMalloc(&d_keys, nnz * sizeof(uint32_t)));

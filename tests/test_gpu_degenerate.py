@@ -78,23 +78,44 @@ def test_empty_system(gpu):
     assert p["solution"].size == 0 and p["converged"] and p["rounds"] == 0
 
 
-def test_slice_pointers_that_do_not_match_the_row_lengths_are_noticed_and_rebuilt(gpu, monkeypatch, capfd):
-    """the layout build sums slice widths on the host; were the read-back stale (seen twice in ~2200 many-process runs, never explained),
-    rows would lose their last entries.  The fill kernel counts rows that do not fit, the build says so, reads the widths again and fills
-    again: forced here by shortening every third width — results bit for bit as without the fault."""
-    import numpy as np
-    import sublinear_time_solver_amd as S
-    from sublinear_time_solver_amd import generators as G
-    from oracle import oracle as O
-    n = 20_000
-    rp, ci, va, b = G.sdd_rows(n, 9, seed=4, half_bandwidth=300)
-    x = np.cos(np.arange(n) * 0.3)
-    ref = O.spmv(rp, ci, va, x)
-    monkeypatch.setenv("SL_DEBUG_STALE_SLICE_WIDTHS", "1")
-    m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
-    err = capfd.readouterr().err
-    assert "did not fit their slices" in err and "rebuilding" in err
-    assert (m.multiply_vector(x).view(np.uint64) == ref.view(np.uint64)).all()
-    g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-10))
-    o = O.neumann_solve(rp, ci, va, b, tolerance=1e-10)
-    assert g.iterations == o["iterations"] and (g.solution.view(np.uint64) == o["x"].view(np.uint64)).all()
+def test_slice_pointers_that_do_not_match_the_row_lengths_are_noticed_and_rebuilt(gpu):
+    """the layout build sums slice widths on the host and sends the pointers back; were either copy stale (a row twice lost its diagonal in
+    ~2200 many-process runs of round 3), rows would lose their last entries.  The fill kernel counts rows that do not fit, the build says
+    which link of the chain was off — (a) the widths' read-back, (b) the row-length kernel's result, (c) the pointers on the device — and
+    rebuilds: forced here in the hooked build of the library (libsublinear_hip_hooks.so, -DSL_DEBUG_HOOKS: the product has no such switch),
+    once per link that can be forced; results bit for bit as without the fault."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    hooked = root / "sublinear_time_solver_amd" / "libsublinear_hip_hooks.so"
+    assert hooked.exists(), "make -C sublinear_time_solver_amd/csrc builds it"
+    prog = """
+import sys, numpy as np
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import generators as G
+from oracle import oracle as O
+n = 20_000
+rp, ci, va, b = G.sdd_rows(n, 9, seed=4, half_bandwidth=300)
+x = np.cos(np.arange(n) * 0.3)
+ref = O.spmv(rp, ci, va, x)
+m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+assert (m.multiply_vector(x).view(np.uint64) == ref.view(np.uint64)).all()
+g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-10))
+o = O.neumann_solve(rp, ci, va, b, tolerance=1e-10)
+assert g.iterations == o["iterations"] and (g.solution.view(np.uint64) == o["x"].view(np.uint64)).all()
+print("bits equal")
+"""
+    for var, which in (("SL_DEBUG_STALE_SLICE_WIDTHS", "(a)"), ("SL_DEBUG_STALE_SLICE_PTRS", "(c)")):
+        env = dict(os.environ, SUBLINEAR_HIP_LIB=str(hooked), **{var: "1"})
+        r = subprocess.run([sys.executable, "-c", prog], cwd=root, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "bits equal" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+        line = [ln for ln in r.stderr.splitlines() if "did not fit their slices" in ln]
+        assert line and "rebuilding" in line[0], r.stderr[-2000:]
+        counts = dict(zip("abc", (int(v) for v in __import__("re").findall(r": (\d+) differ", line[0]))))
+        assert counts[which[1]] > 0 and all(v == 0 for k, v in counts.items() if k != which[1]), (which, line[0])
+    # the product library carries no such switch: the same variables change nothing
+    env = dict(os.environ, SL_DEBUG_STALE_SLICE_WIDTHS="1", SL_DEBUG_STALE_SLICE_PTRS="1")
+    r = subprocess.run([sys.executable, "-c", prog], cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "did not fit" not in r.stderr
