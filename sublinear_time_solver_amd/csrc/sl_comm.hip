@@ -311,7 +311,21 @@ sl_status sl_dist_vector_create(sl_comm *c, uint64_t n_global, sl_dist_vector *v
     hipIpcMemHandle_t h;
     memset(&h, 0, sizeof(h));
     if (mine == SL_OK && c->world > 1) {
-        const hipError_t e = hipIpcGetMemHandle(&h, v->mine);
+        // (round 4: with TWO jobs of 5-8 processes each building communicators on one GPU at the same time, the export failed with "invalid
+        // argument" in 9 of 182 cases for allocations that were fine — never with one job at a time.  A second try a moment later, then
+        // once more on a fresh allocation; the verdict stays collective either way)
+        hipError_t e = hipIpcGetMemHandle(&h, v->mine);
+        for (int again = 0; e != hipSuccess && again < 4; ++again) {
+            (void)hipGetLastError();
+            usleep(20000 << again);
+            if (again == 2) {
+                void *fresh = nullptr;
+                if ((hipMalloc)(&fresh, bytes) == hipSuccess && hipMemset(fresh, 0, bytes) == hipSuccess) { (void)hipFree(v->mine); v->mine = static_cast<double *>(fresh); }
+                else if (fresh) (void)hipFree(fresh);
+            }
+            e = hipIpcGetMemHandle(&h, v->mine);
+            if (e == hipSuccess) sl_log(0, "ipc transport: hipIpcGetMemHandle succeeded on try %d", again + 2);
+        }
         if (e != hipSuccess) mine = sl_fail(SL_DEVICE_ERROR, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
     }
     std::vector<hipIpcMemHandle_t> all((size_t)c->world);
