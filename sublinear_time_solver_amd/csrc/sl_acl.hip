@@ -285,7 +285,7 @@ __global__ __launch_bounds__(SL_ACL_THREADS) void acl_kernel(uint32_t n, int bac
 
 sl_status upload(const void *src, size_t bytes, sl_mem where, void **out, hipStream_t s)
 {
-    SL_HIP(hipMalloc(out, bytes ? bytes : 8));
+    SL_HIP(sl_malloc(out, bytes ? bytes : 8));
     if (bytes) SL_HIP(hipMemcpyAsync(*out, src, bytes, where == SL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
     return SL_OK;
 }
@@ -391,9 +391,9 @@ sl_status sl_push_graph_create(uint64_t n, const uint32_t *row_ptr, const uint32
     if (herr & 1u) return sl_fail(SL_INVALID_SPARSE_MATRIX, "row_ptr is not a monotone 0..nnz prefix array");
     if (herr & 2u) return sl_fail(SL_INDEX_OUT_OF_BOUNDS, "edge endpoint >= num_nodes (%llu)", (unsigned long long)n);
     if (herr & 4u) return sl_fail(SL_INVALID_INPUT, "non-finite edge weight");
-    SL_HIP(hipMalloc(&g->d_deg, (n ? n : 1) * 8)); SL_HIP(hipMalloc(&g->d_rdeg, (n ? n : 1) * 8));
-    SL_HIP(hipMalloc(&g->d_dup, n ? n : 1)); SL_HIP(hipMalloc(&g->d_tdup, n ? n : 1));
-    SL_HIP(hipMalloc(&g->d_trp, (n + 1) * 4)); SL_HIP(hipMalloc(&g->d_tci, (nnz ? nnz : 1) * 4)); SL_HIP(hipMalloc(&g->d_tw, (nnz ? nnz : 1) * 8));
+    SL_HIP(sl_malloc(&g->d_deg, (n ? n : 1) * 8)); SL_HIP(sl_malloc(&g->d_rdeg, (n ? n : 1) * 8));
+    SL_HIP(sl_malloc(&g->d_dup, n ? n : 1)); SL_HIP(sl_malloc(&g->d_tdup, n ? n : 1));
+    SL_HIP(sl_malloc(&g->d_trp, (n + 1) * 4)); SL_HIP(sl_malloc(&g->d_tci, (nnz ? nnz : 1) * 4)); SL_HIP(sl_malloc(&g->d_tw, (nnz ? nnz : 1) * 8));
     SL_HIP(hipMemsetAsync(g->d_dup, 0, n ? n : 1, s));
     SL_HIP(hipMemsetAsync(g->d_trp, 0, (n + 1) * 4, s));
     if (n) hipLaunchKernelGGL(pg_row_sums_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, n, g->d_rp, g->d_w, g->d_deg);

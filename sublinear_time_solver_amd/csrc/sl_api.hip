@@ -78,7 +78,7 @@ void sl_poison(void *p, size_t bytes)
 }
 hipError_t sl_malloc_checked(void **p, size_t bytes)
 {
-    const hipError_t e = (hipMalloc)(p, bytes);             // (parenthesised: the runtime's function, not the macro of sl_internal.hpp)
+    const hipError_t e = hipMalloc(p, bytes);
     if (e == hipSuccess) sl_poison(*p, bytes);
     return e;
 }
@@ -91,7 +91,7 @@ void *sl_scratch(size_t bytes)
     if (c.scratch && c.scratch_device == dev && c.scratch_bytes >= bytes) return c.scratch;
     if (c.scratch) { hipFree(c.scratch); c.scratch = nullptr; c.scratch_bytes = 0; }
     size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-    if (hipMalloc(&c.scratch, want) != hipSuccess) return nullptr;
+    if (sl_malloc(&c.scratch, want) != hipSuccess) return nullptr;
     c.scratch_bytes = want;
     c.scratch_device = dev;
     return c.scratch;
@@ -184,9 +184,9 @@ void *sl_ws_alloc(size_t bytes)
     }
     if (best >= 0) { c.ws[best].in_use = true; sl_poison(c.ws[best].p, c.ws[best].bytes); return c.ws[best].p; }
     void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {
+    if (sl_malloc(&p, bytes) != hipSuccess) {
         sl_release_workspace();                        // give the cache back and try once more
-        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        if (sl_malloc(&p, bytes) != hipSuccess) return nullptr;
     }
     c.ws.push_back({p, bytes, dev, true});
     return p;

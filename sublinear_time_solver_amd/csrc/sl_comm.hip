@@ -40,7 +40,21 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <fcntl.h>
+// librccl is resolved at run time (dlopen below); of its header only a handful of types and constants are needed.  With rccl-dev
+// installed the real header is used and the constants the other branch assumes are checked against it; a ROCm installation WITHOUT the
+// RCCL headers still builds the library (the IPC transport needs neither RCCL nor torch), with the stable values of the NCCL ABI.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+static_assert(ncclSuccess == 0 && ncclInProgress == 7 && ncclSum == 0 && ncclDouble == 8 && sizeof(ncclUniqueId) == 128,
+              "the local declarations of the #else branch below describe another RCCL");
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5,
+               ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;
+#endif
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
@@ -305,7 +319,7 @@ sl_status sl_dist_vector_create(sl_comm *c, uint64_t n_global, sl_dist_vector *v
     v->peer.assign((size_t)c->world, nullptr);
     const size_t bytes = (n_global ? n_global : 1) * sizeof(double);
     sl_status mine = SL_OK;
-    if (hipMalloc(&v->mine, bytes) != hipSuccess) { v->mine = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc(%zu) for a gathered vector failed", bytes); }
+    if (sl_malloc(&v->mine, bytes) != hipSuccess) { v->mine = nullptr; mine = sl_fail(SL_ALLOCATION, "sl_malloc(%zu) for a gathered vector failed", bytes); }
     if (mine == SL_OK && hipMemset(v->mine, 0, bytes) != hipSuccess) mine = sl_fail(SL_DEVICE_ERROR, "hipMemset of a gathered vector failed");
     if (c->transport != SL_TRANSPORT_IPC) { if (v->mine) v->peer[c->rank] = v->mine; return sl_comm_agree(c, mine); }
     hipIpcMemHandle_t h;
@@ -320,7 +334,7 @@ sl_status sl_dist_vector_create(sl_comm *c, uint64_t n_global, sl_dist_vector *v
             usleep(20000 << again);
             if (again == 2) {
                 void *fresh = nullptr;
-                if ((hipMalloc)(&fresh, bytes) == hipSuccess && hipMemset(fresh, 0, bytes) == hipSuccess) { (void)hipFree(v->mine); v->mine = static_cast<double *>(fresh); }
+                if (sl_malloc(&fresh, bytes) == hipSuccess && hipMemset(fresh, 0, bytes) == hipSuccess) { (void)hipFree(v->mine); v->mine = static_cast<double *>(fresh); }
                 else if (fresh) (void)hipFree(fresh);
             }
             e = hipIpcGetMemHandle(&h, v->mine);
@@ -473,7 +487,7 @@ static sl_status comm_ipc_selftest(sl_comm *c)
     uint32_t *d_bad = nullptr;
     const unsigned long long nonce = (unsigned long long)c->h_shm->generation;
     do {
-        if (hipMalloc(&d_bad, 4) != hipSuccess) { d_bad = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); break; }
+        if (sl_malloc(&d_bad, 4) != hipSuccess) { d_bad = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); break; }
         if (hipMemsetAsync(d_bad, 0, 4, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "memset failed"); break; }
         hipLaunchKernelGGL(sl_comm_pattern_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<unsigned long long *>(v.mine) + (size_t)c->rank * WORDS, WORDS,
                            nonce + (unsigned long long)c->rank);
@@ -525,7 +539,7 @@ sl_status sl_dist_verify(sl_dist *d, sl_dist_vector *v, uint64_t *n_bad)
     sl_status mine = SL_OK;
     std::vector<uint64_t> sums((size_t)2 * SL_COMM_MAX_RANKS, 0);       // [0, W): what I give to rank q (my own copy); [16, 16 + W): what I hold of rank p
     do {
-        if (!d->d_check && hipMalloc(&d->d_check, 2 * SL_COMM_MAX_RANKS * sizeof(uint64_t)) != hipSuccess) { d->d_check = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); break; }
+        if (!d->d_check && sl_malloc(&d->d_check, 2 * SL_COMM_MAX_RANKS * sizeof(uint64_t)) != hipSuccess) { d->d_check = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); break; }
         if (hipMemsetAsync(d->d_check, 0, 2 * SL_COMM_MAX_RANKS * sizeof(uint64_t), s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "memset failed"); break; }
         auto launch = [&](const sl_dist::piece &pc, uint64_t *out) {
             const uint64_t n = pc.hi - pc.lo;
@@ -646,8 +660,15 @@ sl_status sl_comm_create(int rank, int world, const char *rendezvous, sl_comm **
             while (!expired()) {
                 if (ld_acq(&h->confirmed) == gen && gen) { joined = true; break; }
                 struct stat cur;
-                const bool all = [&] { for (int p = 0; p < world; ++p) if (ld_acq(&h->arrive[p]) < 1) return false; return true; }();
-                if (!all && stat(c->path.c_str(), &cur) == 0 && cur.st_ino != ino) { stale = true; break; }    // a new rank 0 published its block: this one is a leftover
+                // a new rank 0 published ITS block under the name: this one is a leftover — also when all of its slots are taken (a dead
+                // job's slots filled up by ranks of the new one: it will never confirm).  A live job's rank 0 removes the name
+                // and confirms microseconds later, so a name that changed hands is looked at once more before this block is given up
+                if (stat(c->path.c_str(), &cur) == 0 && cur.st_ino != ino) {
+                    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                    if (ld_acq(&h->confirmed) == gen && gen) { joined = true; break; }
+                    stale = true;
+                    break;
+                }
                 std::this_thread::sleep_for(std::chrono::microseconds(100));
             }
             if (joined) { c->fd = fd; c->h_shm = h; c->shm_bytes = bytes; c->barrier_count = 1; break; }
@@ -692,7 +713,7 @@ sl_status sl_comm_create(int rank, int world, const char *rendezvous, sl_comm **
         const ncclResult_t r = rccl().CommInitRank(&nc, world, ids[0], rank);
         if (r != ncclSuccess) mine = sl_fail(SL_DEVICE_ERROR, "ncclCommInitRank failed on rank %d (device %d): %s — RCCL needs one rank per GPU", rank, c->device, rccl().GetErrorString(r));
         else c->nccl = nc;
-        if (mine == SL_OK && hipMalloc(&c->d_sums, (size_t)SL_COMM_RING * (size_t)world * sizeof(double)) != hipSuccess) { c->d_sums = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); }
+        if (mine == SL_OK && sl_malloc(&c->d_sums, (size_t)SL_COMM_RING * (size_t)world * sizeof(double)) != hipSuccess) { c->d_sums = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); }
         if ((st = sl_comm_agree(c, mine)) != SL_OK) return fail(st);
     }
     if (transport == SL_TRANSPORT_IPC && !(getenv("SL_COMM_SELFTEST") && getenv("SL_COMM_SELFTEST")[0] == '0')) {
@@ -846,7 +867,7 @@ sl_status sl_dist_create(sl_comm *c, const sl_matrix *local, sl_dist **out)
         }
         d->halo_len = off;
         sl_status mine = SL_OK;
-        if (off && hipMalloc(&d->d_halo, off * sizeof(double)) != hipSuccess) { d->d_halo = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc of the halo buffer failed"); }
+        if (off && sl_malloc(&d->d_halo, off * sizeof(double)) != hipSuccess) { d->d_halo = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc of the halo buffer failed"); }
         if ((st = sl_comm_agree(c, mine)) != SL_OK) { sl_dist_destroy(d); return st; }
     }
     sl_log(1, "partition: rank %d holds rows [%llu, %llu) of %llu, reach %llu columns, receives %.1f KB from %zu peers per exchange (%s)", c->rank,

@@ -23,8 +23,7 @@
 // is not once the box has run other work: the kind of fault that shows once in a thousand runs).  The test suite is run under it.
 hipError_t sl_malloc_checked(void **p, size_t bytes);
 void sl_poison(void *p, size_t bytes);                      // no-op unless SL_POISON_ALLOC=1
-template <class T> inline hipError_t sl_malloc_t(T **p, size_t bytes) { return sl_malloc_checked(reinterpret_cast<void **>(p), bytes); }
-#define hipMalloc(p, n) sl_malloc_t((p), (n))
+template <class T> inline hipError_t sl_malloc(T **p, size_t bytes) { return sl_malloc_checked(reinterpret_cast<void **>(p), bytes); }   // (an explicit wrapper: no runtime name is redefined)
 
 #define SL_SLICE 64
 #ifndef SL_BLOCK
@@ -262,7 +261,7 @@ struct DevBuf {
     {
         reset();
         pooled = false;
-        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { p = nullptr; return sl_fail(SL_ALLOCATION, "hipMalloc(%zu) failed", bytes); }
+        if (sl_malloc(&p, bytes ? bytes : 8) != hipSuccess) { p = nullptr; return sl_fail(SL_ALLOCATION, "sl_malloc(%zu) failed", bytes); }
         return SL_OK;
     }
     void *release() { void *q = p; p = nullptr; return q; }   // alloc_owned buffers only

@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pwr_kernel(sl_row_args a)
     const uint32_t rpb = a.pwr_rpb, nblocks = gridDim.x, ntiles = a.pwr_tiles;
     const double *__restrict__ g = a.gather;
     const uint32_t rounds = (ntiles + nblocks - 1) / nblocks;
-    for (uint32_t r = threadIdx.x; r < rpb; r += SL_PW_WAVES * 64) pwr_acc[r] = 0.0;
+    for (uint32_t r = threadIdx.x; r <= rpb; r += SL_PW_WAVES * 64) pwr_acc[r] = 0.0;      // rpb rows + the spare slot of the padding entries
     __syncthreads();
     double part0 = 0.0, part1 = 0.0;
     for (uint32_t round = 0; round < rounds; ++round) {
@@ -1609,15 +1609,15 @@ static bool order_free_launch(const sl_row_args &a, sl_order order, sl_epilogue 
 template <int EPI>
 static sl_status launch_pwr(sl_row_args a, hipStream_t s, uint32_t *nparts)
 {
-    SL_TRY(set_max_lds_once<sl_pwr_kernel<EPI>>((int)((size_t)SL_PWR_MAX_ROWS * sizeof(double))));
+    SL_TRY(set_max_lds_once<sl_pwr_kernel<EPI>>((int)(((size_t)SL_PWR_MAX_ROWS + 1) * sizeof(double))));
     *nparts = a.pwr_blocks;
     a.part_stride = *nparts;
     a.n_long = 0;                                                    // hub rows are in the stream like every other row
-    const uint32_t lds = (uint32_t)((size_t)a.pwr_rpb * sizeof(double));
+    const uint32_t lds = (uint32_t)(((size_t)a.pwr_rpb + 1) * sizeof(double));      // + the spare slot padding entries add their products to
 #ifdef SL_PWR_VARIANTS
     static const int var = [] { const char *e = getenv("SL_PWR_VAR"); return e ? atoi(e) : 0; }();
     if (EPI == SL_EPI_NEUMANN && var) {
-#define SL_PWR_V(v) case v: SL_TRY((set_max_lds_once<sl_pwr_kernel<SL_EPI_NEUMANN, v>>((int)((size_t)SL_PWR_MAX_ROWS * sizeof(double))))); \
+#define SL_PWR_V(v) case v: SL_TRY((set_max_lds_once<sl_pwr_kernel<SL_EPI_NEUMANN, v>>((int)(((size_t)SL_PWR_MAX_ROWS + 1) * sizeof(double))))); \
                             hipLaunchKernelGGL((sl_pwr_kernel<SL_EPI_NEUMANN, v>), dim3(a.pwr_blocks), dim3(SL_PW_WAVES * 64), lds, s, a); break;
         switch (var) { SL_PWR_V(1) SL_PWR_V(2) SL_PWR_V(4) SL_PWR_V(6) SL_PWR_V(10) SL_PWR_V(14) SL_PWR_V(32) SL_PWR_V(42) default: return sl_fail(SL_INVALID_INPUT, "SL_PWR_VAR"); }
 #undef SL_PWR_V

@@ -345,10 +345,10 @@ static sl_status sl_build_column_panels(sl_matrix *m, const uint32_t *d_row_ptr,
     src[n_tiles] = (uint32_t)run_s; dst[n_tiles] = (uint32_t)run_d;
     DevBuf dsrc;
     SL_TRY(dsrc.alloc_owned((n_tiles + 1) * 4));
-    SL_HIP(hipMalloc(&m->d_pan_tile_ptr, (n_tiles + 1) * 4));
-    SL_HIP(hipMalloc(&m->d_pan_row, (run_d ? run_d : 1) * 2));
-    SL_HIP(hipMalloc(&m->d_pan_col, (run_d ? run_d : 1) * 4));
-    SL_HIP(hipMalloc(&m->d_pan_val, (run_d ? run_d : 1) * 8));
+    SL_HIP(sl_malloc(&m->d_pan_tile_ptr, (n_tiles + 1) * 4));
+    SL_HIP(sl_malloc(&m->d_pan_row, (run_d ? run_d : 1) * 2));
+    SL_HIP(sl_malloc(&m->d_pan_col, (run_d ? run_d : 1) * 4));
+    SL_HIP(sl_malloc(&m->d_pan_val, (run_d ? run_d : 1) * 8));
     SL_TRY(sl_upload(dsrc.p, src.data(), (n_tiles + 1) * 4, st));
     SL_TRY(sl_upload(m->d_pan_tile_ptr, dst.data(), (n_tiles + 1) * 4, st));
     hipLaunchKernelGGL(sl_panel_fill_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, st, n_tiles, dsrc.as<uint32_t>(), m->d_pan_tile_ptr, perm.as<uint32_t>(),
@@ -578,9 +578,9 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     for (uint64_t t = 0; t < n_tiles; ++t) { dst[t] = (uint32_t)chunks; chunks += ((uint64_t)count[t] + hpads[t] + SL_PANEL_CHUNK - 1) / SL_PANEL_CHUNK; }
     dst[n_tiles] = (uint32_t)chunks;
     if (chunks * 256 > 0xfffffff0ull) return SL_OK;
-    SL_HIP(hipMalloc(&m->d_pw_tile_ptr, (n_tiles + 1) * 4));
-    SL_HIP(hipMalloc(&m->d_pw_idx, (chunks ? chunks : 1) * 256 * 4));
-    SL_HIP(hipMalloc(&m->d_pw_val, (chunks ? chunks : 1) * 256 * 8));
+    SL_HIP(sl_malloc(&m->d_pw_tile_ptr, (n_tiles + 1) * 4));
+    SL_HIP(sl_malloc(&m->d_pw_idx, (chunks ? chunks : 1) * 256 * 4));
+    SL_HIP(sl_malloc(&m->d_pw_val, (chunks ? chunks : 1) * 256 * 8));
     SL_TRY(sl_upload(m->d_pw_tile_ptr, dst.data(), (n_tiles + 1) * 4, st));
     hipLaunchKernelGGL((sl_pw_fill_kernel<true>), dim3(fg), dim3(256), 0, st, n_tiles, rpw, dsrc.as<uint32_t>(), m->d_pw_tile_ptr, perm.as<uint32_t>(),
                        rowl.as<uint16_t>(), d_col_idx, d_values, (uint32_t *)nullptr, m->d_pw_idx, m->d_pw_val);
@@ -607,7 +607,7 @@ static sl_status sl_build_paced_panels(sl_matrix *m, const uint32_t *d_row_ptr, 
     }
     m->pw_deal = deal; m->pw_pbits = pbits; m->pw_band = band_pbits != 0; m->pw_xcd = xcd;
     if (xcd) {
-        SL_HIP(hipMalloc(&m->d_pw_span_tab, span_tab.size() * 4));
+        SL_HIP(sl_malloc(&m->d_pw_span_tab, span_tab.size() * 4));
         SL_HIP(hipMemcpy(m->d_pw_span_tab, span_tab.data(), span_tab.size() * 4, hipMemcpyHostToDevice));
         m->pw_edge_rounds = edge_rounds; m->pw_edge_rows = edge_rows;
     }
@@ -654,7 +654,8 @@ __global__ __launch_bounds__(256) void sl_pwr_keys_kernel(uint64_t n_rows, uint3
 // entry l of a chunk in lane l's place, each padded to 64 entries with {slot 0, the base column, 0.0}.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void sl_pwr_fill_kernel(uint64_t n_btiles, const uint32_t *src, const uint32_t *dst_chunks, const uint32_t *perm, const uint16_t *slot,
-                                                          const uint32_t *col_idx, const double *values, uint32_t *nchunks, uint32_t *idx, double *val, uint32_t *base)
+                                                          const uint32_t *col_idx, const double *values, uint32_t *nchunks, uint32_t *idx, double *val, uint32_t *base,
+                                                          uint32_t spare_slot)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -663,7 +664,9 @@ __global__ __launch_bounds__(256) void sl_pwr_fill_kernel(uint64_t n_btiles, con
     const uint64_t c0 = WRITE ? dst_chunks[t] : 0;
     uint32_t chunk = 0, fill = 0, B = 0;
     auto close_chunk = [&]() {
-        if (WRITE) for (uint32_t p = fill + lane; p < SL_PWR_CHUNK; p += 64u) { idx[(c0 + chunk) * SL_PWR_CHUNK + p] = 0u; val[(c0 + chunk) * SL_PWR_CHUNK + p] = 0.0; }
+        // padding: value 0, column = the chunk's base, and the tile's SPARE slot (one double behind its rows) — its product 0 * g[base] is
+        // NaN when the vector holds an Inf there (a diverging iterate), and must not reach a row that never referenced that column
+        if (WRITE) for (uint32_t p = fill + lane; p < SL_PWR_CHUNK; p += 64u) { idx[(c0 + chunk) * SL_PWR_CHUNK + p] = spare_slot << SL_PWR_OFF_BITS; val[(c0 + chunk) * SL_PWR_CHUNK + p] = 0.0; }
         ++chunk; fill = 0;
     };
     for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
@@ -737,20 +740,20 @@ static sl_status sl_build_order_free_stream(sl_matrix *m, const uint32_t *d_row_
     SL_TRY(sl_upload(dsrc.p, src.data(), (n_btiles + 1) * 4, st));
     const uint32_t fg = (uint32_t)((n_btiles + 3) / 4);
     hipLaunchKernelGGL((sl_pwr_fill_kernel<false>), dim3(fg), dim3(256), 0, st, n_btiles, dsrc.as<uint32_t>(), (const uint32_t *)nullptr, perm.as<uint32_t>(), slot.as<uint16_t>(),
-                       d_col_idx, d_values, nch.as<uint32_t>(), (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
+                       d_col_idx, d_values, nch.as<uint32_t>(), (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr, rpb);
     SL_TRY(sl_read_back(hch.data(), nch.p, n_btiles * 4, st));
     uint64_t chunks = 0;
     for (uint64_t t = 0; t < n_btiles; ++t) { dst[t] = (uint32_t)chunks; chunks += hch[t]; }
     dst[n_btiles] = (uint32_t)chunks;
     // columns too sparse for the offsets (chunks cut early) or streams too short: more than 12 % padding — not a matrix for this layout
     if (chunks * SL_PWR_CHUNK > 0xfffffff0ull || (!force && (double)chunks * SL_PWR_CHUNK > 1.12 * (double)total + (double)SL_PWR_CHUNK * (double)n_btiles)) return SL_OK;
-    SL_HIP(hipMalloc(&m->d_pwr_tile_ptr, (n_btiles + 1) * 4));
-    SL_HIP(hipMalloc(&m->d_pwr_idx, (chunks ? chunks : 1) * SL_PWR_CHUNK * 4));
-    SL_HIP(hipMalloc(&m->d_pwr_val, (chunks ? chunks : 1) * SL_PWR_CHUNK * 8));
-    SL_HIP(hipMalloc(&m->d_pwr_base, (chunks ? chunks : 1) * 4));
+    SL_HIP(sl_malloc(&m->d_pwr_tile_ptr, (n_btiles + 1) * 4));
+    SL_HIP(sl_malloc(&m->d_pwr_idx, (chunks ? chunks : 1) * SL_PWR_CHUNK * 4));
+    SL_HIP(sl_malloc(&m->d_pwr_val, (chunks ? chunks : 1) * SL_PWR_CHUNK * 8));
+    SL_HIP(sl_malloc(&m->d_pwr_base, (chunks ? chunks : 1) * 4));
     SL_TRY(sl_upload(m->d_pwr_tile_ptr, dst.data(), (n_btiles + 1) * 4, st));
     hipLaunchKernelGGL((sl_pwr_fill_kernel<true>), dim3(fg), dim3(256), 0, st, n_btiles, dsrc.as<uint32_t>(), m->d_pwr_tile_ptr, perm.as<uint32_t>(), slot.as<uint16_t>(),
-                       d_col_idx, d_values, (uint32_t *)nullptr, m->d_pwr_idx, m->d_pwr_val, m->d_pwr_base);
+                       d_col_idx, d_values, (uint32_t *)nullptr, m->d_pwr_idx, m->d_pwr_val, m->d_pwr_base, rpb);
     SL_HIP(hipGetLastError());
     SL_HIP(hipStreamSynchronize(st));
     m->d_pwr_diag = static_cast<double *>(diag.release());
@@ -771,7 +774,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
 
     // 1. validate
     uint32_t *d_err = nullptr;
-    SL_HIP(hipMalloc(&d_err, 4 * sizeof(uint32_t)));
+    SL_HIP(sl_malloc(&d_err, 4 * sizeof(uint32_t)));
     SL_HIP(hipMemsetAsync(d_err, 0, 4 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(sl_validate_csr_kernel, dim3(grid_for(nnz > n ? nnz : n, 256) > 4096 ? 4096 : grid_for(nnz > n ? nnz : n, 256)),
                        dim3(256), 0, st, n, m->n_cols, nnz, d_row_ptr, d_col_idx, d_err);
@@ -791,8 +794,8 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     // 2. row lengths, slice widths
     const uint64_t padded_rows = m->n_slices * SL_SLICE;
     uint32_t *d_slice_w = nullptr;
-    SL_HIP(hipMalloc(&m->d_row_len, (padded_rows ? padded_rows : 1) * sizeof(uint32_t)));
-    SL_HIP(hipMalloc(&d_slice_w, (m->n_slices ? m->n_slices : 1) * sizeof(uint32_t)));
+    SL_HIP(sl_malloc(&m->d_row_len, (padded_rows ? padded_rows : 1) * sizeof(uint32_t)));
+    SL_HIP(sl_malloc(&d_slice_w, (m->n_slices ? m->n_slices : 1) * sizeof(uint32_t)));
     const uint32_t mm_init[4] = {0xffffffffu, 0u, 0u, 0u};
     SL_TRY(sl_upload(d_err, mm_init, sizeof(mm_init), st));
     if (m->n_slices)
@@ -809,8 +812,8 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     m->n_long = n ? mm[2] : 0;
     if (m->n_long) {                                 // ascending list of the long rows (deterministic partial slots)
         uint32_t *d_tmp = nullptr;
-        SL_HIP(hipMalloc(&d_tmp, m->n_long * sizeof(uint32_t)));
-        SL_HIP(hipMalloc(&m->d_long_rows, m->n_long * sizeof(uint32_t)));
+        SL_HIP(sl_malloc(&d_tmp, m->n_long * sizeof(uint32_t)));
+        SL_HIP(sl_malloc(&m->d_long_rows, m->n_long * sizeof(uint32_t)));
         SL_HIP(hipMemsetAsync(d_err, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(sl_long_collect_kernel, dim3(1024), dim3(256), 0, st, n, m->d_row_len, d_tmp, d_err);
         sl_status ss = sl_sort_keys_u32(d_tmp, m->d_long_rows, m->n_long, st);
@@ -830,7 +833,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     m->uniform_width = (n && m->min_row_nnz == m->max_row_nnz && (m->max_row_nnz % 4u) == 0u) ? m->max_row_nnz : 0u;
     if (getenv("SL_NO_UNROLLED")) m->uniform_width = 0;          // experiments: send uniform-width matrices through the batched path
 
-    SL_HIP(hipMalloc(&m->d_slice_ptr, (m->n_slices + 1) * sizeof(uint32_t)));
+    SL_HIP(sl_malloc(&m->d_slice_ptr, (m->n_slices + 1) * sizeof(uint32_t)));
     SL_TRY(sl_upload(m->d_slice_ptr, slice_ptr.data(), (m->n_slices + 1) * sizeof(uint32_t), st));
 #ifdef SL_DEBUG_HOOKS
     if (const char *e = getenv("SL_DEBUG_STALE_SLICE_PTRS")) if (*e == '1' && m->n_slices > 4) {     // what a stale host-to-device copy would look like
@@ -839,10 +842,10 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         SL_TRY(sl_upload(m->d_slice_ptr, bad.data(), (m->n_slices + 1) * sizeof(uint32_t), st));
     }
 #endif
-    SL_HIP(hipMalloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
-    SL_HIP(hipMalloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
+    SL_HIP(sl_malloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
+    SL_HIP(sl_malloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
     unsigned long long *d_band = nullptr;
-    SL_HIP(hipMalloc(&d_band, 5 * sizeof(unsigned long long)));
+    SL_HIP(sl_malloc(&d_band, 5 * sizeof(unsigned long long)));
     SL_HIP(hipMemsetAsync(d_band, 0, 5 * sizeof(unsigned long long), st));
     if (m->n_slices)
         hipLaunchKernelGGL(sl_fill_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_cols,
@@ -886,13 +889,13 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         slice_ptr[m->n_slices] = (uint32_t)acc;
         m->padded_nnz = acc * 2 * SL_SLICE;
         hipFree(m->d_cols); hipFree(m->d_vals); m->d_cols = nullptr; m->d_vals = nullptr;
-        SL_HIP(hipMalloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
-        SL_HIP(hipMalloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
+        SL_HIP(sl_malloc(&m->d_cols, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(uint32_t)));
+        SL_HIP(sl_malloc(&m->d_vals, (m->padded_nnz ? m->padded_nnz : 4) * sizeof(double)));
         SL_HIP(hipMemcpy(m->d_slice_ptr, slice_ptr.data(), (m->n_slices + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
         // the row lengths the fill walks must be the re-run's too (case b)
         hipLaunchKernelGGL(sl_row_len_kernel, dim3((uint32_t)((padded_rows + 255) / 256)), dim3(256), 0, st, n, m->n_slices, m->long_row,
                            d_row_ptr, m->d_row_len, static_cast<uint32_t *>(slice_w_keep.p), static_cast<uint32_t *>(nullptr));
-        SL_HIP(hipMalloc(&d_band, 5 * sizeof(unsigned long long)));
+        SL_HIP(sl_malloc(&d_band, 5 * sizeof(unsigned long long)));
         SL_HIP(hipMemsetAsync(d_band, 0, 5 * sizeof(unsigned long long), st));
         hipLaunchKernelGGL(sl_fill_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_cols,
                            m->n_slices, m->row_offset, d_row_ptr, d_col_idx, d_values, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_band);
@@ -908,7 +911,7 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     if (m->row_offset + n > m->n_cols) m->bandwidth = ~0ull;
     const uint64_t far_entries = h_band[1], slice_entries = h_band[2], diagonal_entries = h_band[3];
     if (m->bandwidth < 32768 && m->n_slices && m->padded_nnz) {
-        SL_HIP(hipMalloc(&m->d_cols16, m->padded_nnz * sizeof(uint16_t)));
+        SL_HIP(sl_malloc(&m->d_cols16, m->padded_nnz * sizeof(uint16_t)));
         if (m->uniform_width == 8 || m->uniform_width == 16)      // octet layout of the unrolled uniform path
             hipLaunchKernelGGL(sl_fill_cols16_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, n, m->n_slices, m->row_offset,
                                m->uniform_width, m->d_cols, m->d_cols16);
@@ -974,9 +977,9 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
 
     // 3. transpose
     if (m->flags & SL_MATRIX_WITH_TRANSPOSE) {
-        SL_HIP(hipMalloc(&m->d_tptr, (m->n_cols + 1) * sizeof(uint32_t)));
-        SL_HIP(hipMalloc(&m->d_trow, (nnz ? nnz : 1) * sizeof(uint32_t)));
-        SL_HIP(hipMalloc(&m->d_tval, (nnz ? nnz : 1) * sizeof(double)));
+        SL_HIP(sl_malloc(&m->d_tptr, (m->n_cols + 1) * sizeof(uint32_t)));
+        SL_HIP(sl_malloc(&m->d_trow, (nnz ? nnz : 1) * sizeof(uint32_t)));
+        SL_HIP(sl_malloc(&m->d_tval, (nnz ? nnz : 1) * sizeof(double)));
         SL_HIP(hipMemsetAsync(m->d_tptr, 0, (m->n_cols + 1) * sizeof(uint32_t), st));
         const uint32_t g = grid_for(nnz, 256) > 8192 ? 8192 : grid_for(nnz, 256);
         if (nnz) hipLaunchKernelGGL(sl_col_count_kernel, dim3(g), dim3(256), 0, st, nnz, d_col_idx, m->d_tptr);
@@ -988,9 +991,9 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
         SL_TRY(sl_upload(m->d_tptr, tptr.data(), (m->n_cols + 1) * sizeof(uint32_t), st));
         if (nnz) {
             uint32_t *d_keys = nullptr, *d_ent_in = nullptr, *d_ent = nullptr;
-            SL_HIP(hipMalloc(&d_keys, nnz * sizeof(uint32_t)));
-            SL_HIP(hipMalloc(&d_ent_in, nnz * sizeof(uint32_t)));
-            SL_HIP(hipMalloc(&d_ent, nnz * sizeof(uint32_t)));
+            SL_HIP(sl_malloc(&d_keys, nnz * sizeof(uint32_t)));
+            SL_HIP(sl_malloc(&d_ent_in, nnz * sizeof(uint32_t)));
+            SL_HIP(sl_malloc(&d_ent, nnz * sizeof(uint32_t)));
             hipLaunchKernelGGL(sl_iota_kernel, dim3(g), dim3(256), 0, st, nnz, d_ent_in);
             int bits = 1;
             while (bits < 32 && (1ull << bits) < m->n_cols) ++bits;
@@ -1009,9 +1012,9 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
 
     // 4. raw CSR copy (also needed by the long-row kernel)
     if (keep_csr_copy || (m->n_long && !m->d_row_ptr)) {
-        SL_HIP(hipMalloc(&m->d_row_ptr, (n + 1) * sizeof(uint32_t)));
-        SL_HIP(hipMalloc(&m->d_col_idx, (nnz ? nnz : 1) * sizeof(uint32_t)));
-        SL_HIP(hipMalloc(&m->d_values, (nnz ? nnz : 1) * sizeof(double)));
+        SL_HIP(sl_malloc(&m->d_row_ptr, (n + 1) * sizeof(uint32_t)));
+        SL_HIP(sl_malloc(&m->d_col_idx, (nnz ? nnz : 1) * sizeof(uint32_t)));
+        SL_HIP(sl_malloc(&m->d_values, (nnz ? nnz : 1) * sizeof(double)));
         SL_HIP(hipMemcpyAsync(m->d_row_ptr, d_row_ptr, (n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         if (nnz) {
             SL_HIP(hipMemcpyAsync(m->d_col_idx, d_col_idx, nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));

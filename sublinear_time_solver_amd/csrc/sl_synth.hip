@@ -137,7 +137,7 @@ extern "C" sl_status sl_synth_pagerank_device(uint64_t n, uint64_t seed, double 
     if (!col_idx) {
         hipLaunchKernelGGL(sl_pr_degree_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, seed, dmin, dmax, row_ptr);
         unsigned long long *d_total = nullptr;
-        SL_HIP(hipMalloc(&d_total, 8));
+        SL_HIP(sl_malloc(&d_total, 8));
         hipLaunchKernelGGL(sl_scan_u32_inplace_kernel, dim3(1), dim3(1024), 0, st, n + 1, row_ptr, d_total);
         unsigned long long h = 0;
         SL_HIP(hipMemcpyAsync(&h, d_total, 8, hipMemcpyDeviceToHost, st));
