@@ -178,6 +178,7 @@ sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *
     sl_solve_ctl *d_ctl = ctlbuf.as<sl_solve_ctl>();
     sl_cg_scalars *d_sc = scbuf.as<sl_cg_scalars>();
     hipLaunchKernelGGL(sl_cg_set_rsold_kernel, dim3(1), dim3(1), 0, s, d_sc, rsold);
+    static const bool fused_dot = [] { const char *e = getenv("SL_CG_FUSED_DOT"); return e && *e == '1'; }();      // TODO(after the GPU run of tests/test_gpu_cg.py with it): on by default
     static const int batch_env = [] { const char *e = getenv("SL_SOLVE_BATCH"); const int v = e ? atoi(e) : 10; return v < 1 ? 1 : (v > 25 ? 25 : v); }();
     sl_timer timer;
     SL_TRY(timer.start(s));
@@ -193,10 +194,20 @@ sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *
             sl_row_args a = sl_matrix_row_args(m);
             a.gather = p.as<double>(); a.out = ap.as<double>();
             a.ctl = d_ctl; a.gate_it = ga;
-            st = sl_launch_rows(a, (sl_order)o->order, SL_EPI_SPMV, s);      // ap = A p  (:227)
-            if (st != SL_OK) break;
-            hipLaunchKernelGGL(sl_cg_dot_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, ga, n, p.as<double>(), ap.as<double>(), scr);
-            hipLaunchKernelGGL(sl_cg_pap_kernel, dim3(1), dim3(1024), 0, s, d_ctl, ga, scr, vgrid, d_sc);
+            if (fused_dot) {
+                // ap = A p and p . Ap in one launch (:227-233): the residual epilogue in its "product + dot" form, gated like the rest;
+                // its closing reduction leaves the sum in d_res (SL_JUDGE_LOCAL: no log entry, no stop rule — sl_cg_pap_kernel owns both)
+                a.aux = p.as<double>(); a.aux_dot = 1u;
+                a.partials = scr; a.partials_slack = 8192; a.result = d_res; a.ctl_mode = SL_JUDGE_LOCAL;
+                st = sl_launch_rows(a, (sl_order)o->order, SL_EPI_RESIDUAL, s);
+                if (st != SL_OK) break;
+                hipLaunchKernelGGL(sl_cg_pap_kernel, dim3(1), dim3(1024), 0, s, d_ctl, ga, d_res, 1u, d_sc);
+            } else {
+                st = sl_launch_rows(a, (sl_order)o->order, SL_EPI_SPMV, s);      // ap = A p  (:227)
+                if (st != SL_OK) break;
+                hipLaunchKernelGGL(sl_cg_dot_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, ga, n, p.as<double>(), ap.as<double>(), scr);
+                hipLaunchKernelGGL(sl_cg_pap_kernel, dim3(1), dim3(1024), 0, s, d_ctl, ga, scr, vgrid, d_sc);
+            }
             hipLaunchKernelGGL(sl_cg_update_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, gb, n, d_sc, p.as<double>(), ap.as<double>(), x.as<double>(),
                                r.as<double>(), scr);
             hipLaunchKernelGGL(sl_cg_rs_kernel, dim3(1), dim3(1024), 0, s, d_ctl, gb, scr, vgrid, d_sc, tol_sq);

@@ -348,6 +348,7 @@ struct sl_row_args {
     const double *gather; // gathered vector (n_cols)
     const double *dinv;   // n_rows
     const double *aux;    // RESIDUAL: rhs (n_rows); PUSH: unused
+    uint32_t aux_dot;     // RESIDUAL epilogue as "product + dot": out = A g, sum of aux_i * (A g)_i instead of the residual's sum of squares (CG: p . Ap in the SpMV's launch)
     double *out;          // SPMV: y; NEUMANN: t_out; RESIDUAL: r (may be null); PUSH: delta_out
     double *x;            // NEUMANN / PUSH: x in/out
     double *r;            // PUSH: r in/out

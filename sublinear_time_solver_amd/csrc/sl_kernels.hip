@@ -129,6 +129,11 @@ __device__ __forceinline__ void sl_row_epilogue(const sl_row_args &a, uint64_t i
         __builtin_nontemporal_store(DADD(e_x, tn), &a.x[i]);
         part0 = DADD(part0, DMUL(tn, tn));
     } else if constexpr (EPI == SL_EPI_RESIDUAL) {
+        if (a.aux_dot) {            // (wave-uniform) CG: A p with p . Ap in the same launch, optimized_solver.rs:227-233 — e_t = p_i
+            a.out[i] = sum;
+            part0 = DADD(part0, DMUL(e_t, sum));
+            return;
+        }
         // neumann.rs:303-309: residual = A x - rhs
         const double rr = DSUB(sum, e_t);
         if (a.out) a.out[i] = rr;
