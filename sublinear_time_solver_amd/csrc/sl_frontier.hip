@@ -559,6 +559,55 @@ __global__ __launch_bounds__(256) void sl_pull_heavy_kernel(const sl_round_io *i
     c->done_blocks = 0;
     sl_close_round(io, nf);
 }
+// SMALL rounds, several of them, in ONE launch of ONE workgroup (round 4, SL_PUSH_SMALL=1).  A local query starts — and ends — with
+// frontiers of a few columns: each such round is microseconds of work behind four kernel boundaries of ~4.5 us.  Here one 8-wave
+// workgroup runs the four phases of a round back to back behind block barriers, round after round, for as long as the round at hand is
+// small (|F| <= max_nf and column entries under it <= max_hits) and the batch's round limit allows; a round that is too large — it
+// wants the whole machine — is left untouched for the launch train behind this kernel, which is followed by this kernel again.
+// The phases are the SAME device functions as the launch train's (written against sl_worker, not against the grid), so every value —
+// records, hit order, sums, frontier SETS — is the same; the order of a frontier LIST differs as it does between two runs of the train
+// (slots are reserved by atomics), which nothing downstream depends on.  Between phases: block barrier (workgroup release: the waves'
+// stores and atomics have left) + an agent-scope ACQUIRE fence in every wave (its CU's L1 forgets what it held: lists and heads that
+// another wave changed through an L2 atomic are re-read) — no release at agent scope, no other workgroup takes part.
+#define SL_SMALL_THREADS 512      // 8 waves, up to 256 VGPRs each: the phases' register arrays do not spill; a small round is latency, not throughput
+__global__ __launch_bounds__(SL_SMALL_THREADS) void sl_small_rounds_kernel(const sl_round_io *iop, uint32_t max_nf, unsigned long long max_hits)
+{
+    __shared__ uint32_t s_go, s_par, s_nf, s_prev, s_cnt;
+    const sl_round_io io = *iop;
+    sl_push_ctl *c = io.c;
+    sl_worker w;
+    w.tid = threadIdx.x; w.nthreads = SL_SMALL_THREADS; w.wave = threadIdx.x >> 6; w.nwaves = SL_SMALL_THREADS / 64u; w.lane = threadIdx.x & 63u;
+    auto phase_sync = [&]() { __syncthreads(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); };
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const uint32_t stop = sl_ld(&c->stop), rounds = sl_ld(&c->rounds), nf = sl_ld(&c->nf);
+            const unsigned long long hits = sl_ld(&c->hits);
+            s_go = (!stop && rounds < io.round_limit && nf <= max_nf && hits <= max_hits) ? 1u : 0u;
+            s_par = rounds & 1u; s_nf = nf; s_prev = rounds ? sl_ld(&c->nf_prev) : 0u;
+        }
+        __syncthreads();
+        if (!s_go) return;                                                      // block-uniform
+        const uint32_t par = s_par, nf = s_nf;
+        if (s_prev) sl_clear_frontier(SL_PICK(io.frontier, 1u - par), SL_PICK(io.delta, 1u - par), s_prev, w);
+        sl_phase_expand(io, par, nf, w);
+        phase_sync();
+        if (threadIdx.x == 0) s_cnt = sl_ld(&c->n_long_cols);
+        __syncthreads();
+        if (s_cnt) sl_phase_expand_long(io, par, s_cnt, w);
+        phase_sync();
+        if (threadIdx.x == 0) s_cnt = sl_ld(&c->nc);
+        __syncthreads();
+        sl_phase_pull_hits(io, par, s_cnt, w);
+        phase_sync();
+        if (threadIdx.x == 0) s_cnt = sl_ld(&c->n_heavy);
+        __syncthreads();
+        if (s_cnt) sl_phase_pull_heavy(io, par, s_cnt, w);
+        phase_sync();
+        if (threadIdx.x == 0) sl_close_round(io, nf);
+        phase_sync();
+    }
+}
+
 // after the last round of a batch: the frontier that round consumed is still marked in its delta buffer
 __global__ __launch_bounds__(256) void sl_batch_end_kernel(const sl_round_io *iop)
 {
@@ -733,6 +782,16 @@ sl_status run_push(push_state &ps, const sl_matrix *m, sl_theta theta, uint64_t 
             uint64_t batch = plog.log ? 1 : (uint64_t)(sparse_batches_done == 0 ? cfg_batch : std::max(cfg_batch / 2, 1));
             ++sparse_batches_done;
             if (batch > max_rounds - rs.rounds) batch = max_rounds - rs.rounds;
+            // SL_PUSH_SMALL=1 (round 4; not with a frontier log, which wants every round's list on the host): a one-workgroup kernel that runs
+            // small rounds back to back stands before every launch train; a batch then enqueues fewer trains (SL_PUSH_SMALL_TRAINS, 6) and
+            // allows more rounds (each small kernel may run many)
+            static const int small_on = [] { const char *e = getenv("SL_PUSH_SMALL"); return e && *e == '1' ? 1 : 0; }();
+            static const uint32_t small_nf = [] { const char *e = getenv("SL_PUSH_SMALL_NF"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 256u; }();
+            static const unsigned long long small_hits = [] { const char *e = getenv("SL_PUSH_SMALL_HITS"); return e ? strtoull(e, nullptr, 10) : 8192ull; }();
+            static const uint64_t small_trains = [] { const char *e = getenv("SL_PUSH_SMALL_TRAINS"); const long v = e ? atol(e) : 6; return (uint64_t)(v < 1 ? 1 : v); }();
+            const bool small = small_on && !plog.log;
+            uint64_t trains = batch;
+            if (small) { trains = std::min<uint64_t>(batch, small_trains); batch = std::min<uint64_t>(max_rounds - rs.rounds, 64); }
             sl_round_io io{};
             io.c = ps.ctl;
             io.frontier[0] = ps.frontier[0]; io.frontier[1] = ps.frontier[1];
@@ -746,11 +805,13 @@ sl_status run_push(push_state &ps, const sl_matrix *m, sl_theta theta, uint64_t 
             hipLaunchKernelGGL(sl_push_ctl_reset_kernel, dim3(1), dim3(1), 0, s, iop);
             hipLaunchKernelGGL(sl_frontier_hits_kernel, dim3((uint32_t)std::min<uint64_t>((nf + 255) / 256, 512)), dim3(256), 0, s, iop);
             hipLaunchKernelGGL(sl_hits_gate_kernel, dim3(1), dim3(1), 0, s, iop);              // hard limit: the record buffer
-            for (uint64_t b = 0; b < batch; ++b) {
+            if (small) hipLaunchKernelGGL(sl_small_rounds_kernel, dim3(1), dim3(SL_SMALL_THREADS), 0, s, iop, small_nf, small_hits);
+            for (uint64_t b = 0; b < trains; ++b) {
                 hipLaunchKernelGGL(sl_expand_kernel, dim3(1024), dim3(256), 0, s, iop);
                 hipLaunchKernelGGL(sl_expand_long_kernel, dim3(512), dim3(256), 0, s, iop);
                 hipLaunchKernelGGL(sl_pull_hits_kernel, dim3(512), dim3(256), 0, s, iop);
                 hipLaunchKernelGGL(sl_pull_heavy_kernel, dim3(128), dim3(256), 0, s, iop);
+                if (small) hipLaunchKernelGGL(sl_small_rounds_kernel, dim3(1), dim3(SL_SMALL_THREADS), 0, s, iop, small_nf, small_hits);
             }
             hipLaunchKernelGGL(sl_batch_end_kernel, dim3(128), dim3(256), 0, s, iop);
             if (tail && !ps.flooded) (*tail)(s, rs.rounds + batch >= max_rounds, (uint32_t)batch);

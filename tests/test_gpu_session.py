@@ -116,3 +116,51 @@ def test_batch_of_queries_on_lanes_equals_one_at_a_time(gpu):
         assert np.float64(again.estimate).view(np.uint64) == np.float64(one[2].estimate).view(np.uint64)
         with pytest.raises(S.SolverError):
             sess.estimate_batch([0, n + 7], theta=1e-7)
+
+
+def test_small_rounds_in_one_workgroup_give_the_same_answers(gpu):
+    """SL_PUSH_SMALL=1: rounds with small frontiers run back to back in ONE workgroup (sl_small_rounds_kernel) instead of four launches
+    each.  Same phases, same records, same ordered sums: every query answers with the same bits — estimate, residual, rounds, pushes, rows
+    touched — as without it, for queries that stay small, queries whose middle rounds need the launch train, queries that flood, queries cut
+    off by the round limit, on a graph with hub columns (long-column pieces, heavy rows) and on S-DD; and push solves give the same x / r."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    prog = r"""
+import json, numpy as np
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import generators as G
+out = []
+def bits(v): return int(np.float64(v).view(np.uint64))
+n = 60_000
+rp, ci, va, b = G.sdd_rows(n, 11, seed=9, half_bandwidth=0)
+m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+with S.QuerySession(m, b) as q:
+    for row, theta, mr in [(0, 1e-3, 100000), (n // 3, 1e-5, 100000), (n - 1, 1e-7, 100000), (17, 1e-9, 100000), (5, 1e-6, 3), (n // 2, 1e-12, 100000), (0, 1e-3, 100000)]:
+        e = q.estimate(row, theta=theta, max_rounds=mr)
+        out.append([bits(e.estimate), bits(e.residual_l1), int(e.rounds), int(e.pushes), int(e.rows_touched), int(bool(e.converged))])
+    for e in q.estimate_batch([3, 99, 4242, n - 7], theta=1e-5, lanes=3):
+        out.append([bits(e.estimate), bits(e.residual_l1), int(e.rounds), int(e.pushes), int(e.rows_touched)])
+# a power-law graph: hub columns (pieces), heavy rows
+adj = G.pagerank_graph(20_000, 3)
+prp, pci, pva, pb = G.pagerank_system(20_000, *adj, damping=0.85)
+pm = S.SparseMatrix.from_csr(prp, pci, pva, 20_000, 20_000, with_transpose=True)
+with S.QuerySession(pm, pb) as q:
+    for row, theta in [(0, 1e-4), (7, 1e-6), (19_999, 1e-5), (123, 1e-8)]:
+        e = q.estimate(row, theta=theta)
+        out.append([bits(e.estimate), bits(e.residual_l1), int(e.rounds), int(e.pushes), int(e.rows_touched)])
+bs = pb * (np.arange(20_000) % 97 == 0)
+p = S.PushSolver(theta=1e-7).solve(pm, bs)
+out.append([int(p["rounds"]), int(p["pushes"]), int(p["solution"].view(np.uint64).sum() % (1 << 61)), int(p["residual"].view(np.uint64).sum() % (1 << 61))])
+print("RESULT " + json.dumps(out))
+"""
+    res = {}
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", prog], cwd=root, capture_output=True, text=True, timeout=900, env=dict(os.environ, SL_PUSH_SMALL=mode))
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res["0"] == res["1"], [(a, b) for a, b in zip(res["0"], res["1"]) if a != b][:3]
+    assert any(row[2] >= 6 for row in res["0"][:7])             # several rounds did run
