@@ -182,10 +182,13 @@ __device__ __forceinline__ sl_worker sl_worker_here()
     return w;
 }
 template <typename T> __device__ __forceinline__ T sl_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool sl_round_open(const sl_round_io &io, uint32_t &par)
+// The control block and the round limit are kernel ARGUMENTS of their own (round 4): the gate words and the argument block are then
+// fetched side by side — one round trip to memory at the head of every launch of a train instead of two (block, then block->c->...).
+__device__ __forceinline__ bool sl_round_open(const sl_push_ctl *c, uint32_t round_limit, uint32_t &par)
 {
-    if (io.c->stop || io.c->rounds >= io.round_limit) return false;
-    par = io.c->rounds & 1u;
+    const uint32_t stop = c->stop, rounds = c->rounds;
+    if (stop || rounds >= round_limit) return false;
+    par = rounds & 1u;
     return true;
 }
 
@@ -520,35 +523,35 @@ __device__ __forceinline__ void sl_close_round(const sl_round_io &io, uint32_t n
 
 // A round is four launches: expansion of the short columns (+ clearing the previous frontier), the pieces of the long
 // columns, the pull over hit lists, and the whole-row pull of heavy rows, whose last block closes the round.
-__global__ __launch_bounds__(256) void sl_expand_kernel(const sl_round_io *iop)
+__global__ __launch_bounds__(256) void sl_expand_kernel(const sl_round_io *iop, const sl_push_ctl *cg, uint32_t round_limit)
 {
     const sl_round_io io = *iop;
     uint32_t par;
-    if (!sl_round_open(io, par)) return;
+    if (!sl_round_open(cg, round_limit, par)) return;
     const sl_worker w = sl_worker_here();
     if (io.c->rounds) sl_clear_frontier(SL_PICK(io.frontier, 1u - par), SL_PICK(io.delta, 1u - par), io.c->nf_prev, w);
     sl_phase_expand(io, par, io.c->nf, w);
 }
-__global__ __launch_bounds__(256) void sl_expand_long_kernel(const sl_round_io *iop)
+__global__ __launch_bounds__(256) void sl_expand_long_kernel(const sl_round_io *iop, const sl_push_ctl *cg, uint32_t round_limit)
 {
     const sl_round_io io = *iop;
     uint32_t par;
-    if (!sl_round_open(io, par)) return;
+    if (!sl_round_open(cg, round_limit, par)) return;
     sl_phase_expand_long(io, par, io.c->n_long_cols, sl_worker_here());
 }
-__global__ __launch_bounds__(256) void sl_pull_hits_kernel(const sl_round_io *iop)
+__global__ __launch_bounds__(256) void sl_pull_hits_kernel(const sl_round_io *iop, const sl_push_ctl *cg, uint32_t round_limit)
 {
     const sl_round_io io = *iop;
     uint32_t par;
-    if (!sl_round_open(io, par)) return;
+    if (!sl_round_open(cg, round_limit, par)) return;
     sl_phase_pull_hits(io, par, io.c->nc, sl_worker_here());
 }
 // the block that finishes last closes the round (a small grid: every block pays an agent-scope fence on the way out)
-__global__ __launch_bounds__(256) void sl_pull_heavy_kernel(const sl_round_io *iop)
+__global__ __launch_bounds__(256) void sl_pull_heavy_kernel(const sl_round_io *iop, const sl_push_ctl *cg, uint32_t round_limit)
 {
     const sl_round_io io = *iop;
     uint32_t par;
-    if (!sl_round_open(io, par)) return;
+    if (!sl_round_open(cg, round_limit, par)) return;
     sl_push_ctl *c = io.c;
     const uint32_t nf = c->nf;
     sl_phase_pull_heavy(io, par, c->n_heavy, sl_worker_here());
@@ -807,10 +810,10 @@ sl_status run_push(push_state &ps, const sl_matrix *m, sl_theta theta, uint64_t 
             hipLaunchKernelGGL(sl_hits_gate_kernel, dim3(1), dim3(1), 0, s, iop);              // hard limit: the record buffer
             if (small) hipLaunchKernelGGL(sl_small_rounds_kernel, dim3(1), dim3(SL_SMALL_THREADS), 0, s, iop, small_nf, small_hits);
             for (uint64_t b = 0; b < trains; ++b) {
-                hipLaunchKernelGGL(sl_expand_kernel, dim3(1024), dim3(256), 0, s, iop);
-                hipLaunchKernelGGL(sl_expand_long_kernel, dim3(512), dim3(256), 0, s, iop);
-                hipLaunchKernelGGL(sl_pull_hits_kernel, dim3(512), dim3(256), 0, s, iop);
-                hipLaunchKernelGGL(sl_pull_heavy_kernel, dim3(128), dim3(256), 0, s, iop);
+                hipLaunchKernelGGL(sl_expand_kernel, dim3(1024), dim3(256), 0, s, iop, ps.ctl, io.round_limit);
+                hipLaunchKernelGGL(sl_expand_long_kernel, dim3(512), dim3(256), 0, s, iop, ps.ctl, io.round_limit);
+                hipLaunchKernelGGL(sl_pull_hits_kernel, dim3(512), dim3(256), 0, s, iop, ps.ctl, io.round_limit);
+                hipLaunchKernelGGL(sl_pull_heavy_kernel, dim3(128), dim3(256), 0, s, iop, ps.ctl, io.round_limit);
                 if (small) hipLaunchKernelGGL(sl_small_rounds_kernel, dim3(1), dim3(SL_SMALL_THREADS), 0, s, iop, small_nf, small_hits);
             }
             hipLaunchKernelGGL(sl_batch_end_kernel, dim3(128), dim3(256), 0, s, iop);
