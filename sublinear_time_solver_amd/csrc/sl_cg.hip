@@ -115,6 +115,39 @@ __global__ __launch_bounds__(1024) void sl_cg_rs_kernel(sl_solve_ctl *c, uint32_
     if (rsnew <= tol_sq && g < c->stop_after) c->stop_after = g;
 }
 
+// The fused form of the two vector passes (round 4, SL_CG_FUSED_DOT=1): p is read ONCE per iteration — the first pass keeps to the
+// residual (r -= alpha Ap, r.r: 24 n bytes), the second does both updates that read the old direction (x += alpha p, then p = r + beta p:
+// 40 n bytes) — 64 n instead of 72 n bytes, element-wise the same operations on the same values.  The second pass runs in every
+// iteration whose r.r was finite (gate g), also the one the tolerance rule ends: x has its update as in the reference (:244-246).
+__global__ __launch_bounds__(256) void sl_cg_residual_kernel(const sl_solve_ctl *c, uint32_t g, uint64_t n, const sl_cg_scalars *sc,
+                                                             const double *__restrict__ ap, double *r, double *partials)
+{
+    __shared__ double red[4];
+    if (cg_gated(c, g)) return;
+    const double alpha = sc->alpha;
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const double rn = DSUB(r[i], DMUL(alpha, ap[i]));
+        r[i] = rn;
+        acc = DADD(acc, DMUL(rn, rn));
+    }
+    acc = cg_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(256) void sl_cg_x_direction_kernel(const sl_solve_ctl *c, uint32_t g, uint64_t n, const sl_cg_scalars *sc,
+                                                                const double *__restrict__ r, double *x, double *p)
+{
+    if (cg_gated(c, g)) return;
+    const double alpha = sc->alpha, beta = sc->beta;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const double pi = p[i];
+        x[i] = DADD(x[i], DMUL(alpha, pi));
+        p[i] = DADD(r[i], DMUL(beta, pi));
+    }
+}
+
 // p = r + beta p   (optimized_solver.rs:261-263)
 __global__ __launch_bounds__(256) void sl_cg_direction_kernel(const sl_solve_ctl *c, uint32_t g, uint64_t n, const sl_cg_scalars *sc,
                                                               const double *__restrict__ r, double *p)
@@ -208,10 +241,16 @@ sl_status sl_cg_solve(const sl_matrix *m, const double *b, const sl_cg_options *
                 hipLaunchKernelGGL(sl_cg_dot_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, ga, n, p.as<double>(), ap.as<double>(), scr);
                 hipLaunchKernelGGL(sl_cg_pap_kernel, dim3(1), dim3(1024), 0, s, d_ctl, ga, scr, vgrid, d_sc);
             }
-            hipLaunchKernelGGL(sl_cg_update_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, gb, n, d_sc, p.as<double>(), ap.as<double>(), x.as<double>(),
-                               r.as<double>(), scr);
-            hipLaunchKernelGGL(sl_cg_rs_kernel, dim3(1), dim3(1024), 0, s, d_ctl, gb, scr, vgrid, d_sc, tol_sq);
-            hipLaunchKernelGGL(sl_cg_direction_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, gb, n, d_sc, r.as<double>(), p.as<double>());
+            if (fused_dot) {
+                hipLaunchKernelGGL(sl_cg_residual_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, gb, n, d_sc, ap.as<double>(), r.as<double>(), scr);
+                hipLaunchKernelGGL(sl_cg_rs_kernel, dim3(1), dim3(1024), 0, s, d_ctl, gb, scr, vgrid, d_sc, tol_sq);
+                hipLaunchKernelGGL(sl_cg_x_direction_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, gb, n, d_sc, r.as<double>(), x.as<double>(), p.as<double>());
+            } else {
+                hipLaunchKernelGGL(sl_cg_update_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, gb, n, d_sc, p.as<double>(), ap.as<double>(), x.as<double>(),
+                                   r.as<double>(), scr);
+                hipLaunchKernelGGL(sl_cg_rs_kernel, dim3(1), dim3(1024), 0, s, d_ctl, gb, scr, vgrid, d_sc, tol_sq);
+                hipLaunchKernelGGL(sl_cg_direction_kernel, dim3(vgrid), dim3(256), 0, s, d_ctl, gb, n, d_sc, r.as<double>(), p.as<double>());
+            }
         }
         if (st != SL_OK) break;
         sl_solve_ctl h_ctl;
