@@ -237,9 +237,12 @@ def single_rank_reference(args, lib, L, torch, dev, n_global, lo, hi, w, steps):
             ta = b * dinv
             tb, x = torch.empty_like(ta), ta.clone()
             ms = C.c_float(0)
-            L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order, 3, C.byref(ms)))
-            L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), tb.data_ptr(), ta.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order, steps, C.byref(ms)))
-            return ms.value / steps
+            L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order, 5, C.byref(ms)))
+            reps = []
+            for _ in range(2):      # twice, the smaller figure: the peers' last state is still being unmapped when this starts (seen with ranks sharing a device)
+                L.check(lib.sl_neumann_run_steps(h, dinv.data_ptr(), tb.data_ptr(), ta.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order, steps, C.byref(ms)))
+                reps.append(ms.value / steps)
+            return min(reps)
         idx = torch.arange(n_global, device=dev, dtype=torch.float64)
         ta = (1.0 + 0.001 * torch.remainder(idx, 1000.0)) * (1.0 / (10.0 + 0.01 * torch.remainder(idx, 1000.0)))
         del idx
@@ -247,15 +250,18 @@ def single_rank_reference(args, lib, L, torch, dev, n_global, lo, hi, w, steps):
         stream = torch.cuda.current_stream(dev)
         L.check(lib.sl_set_stream(C.c_void_p(stream.cuda_stream)))
         try:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for _ in range(3):
+            for _ in range(5):
                 L.check(lib.sl_neumann_step(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order))
-            e0.record(stream)
-            for _ in range(steps):
-                L.check(lib.sl_neumann_step(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order))
-            e1.record(stream)
-            torch.cuda.synchronize(dev)
-            return e0.elapsed_time(e1) / steps
+            reps = []
+            for _ in range(2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(steps):
+                    L.check(lib.sl_neumann_step(h, dinv.data_ptr(), ta.data_ptr(), tb.data_ptr(), x.data_ptr(), nrm.data_ptr(), args.order))
+                e1.record(stream)
+                torch.cuda.synchronize(dev)
+                reps.append(e0.elapsed_time(e1) / steps)
+            return min(reps)
         finally:
             L.check(lib.sl_set_stream(None))
     finally:
@@ -429,8 +435,10 @@ def main_abi(args, world, rank, local_rank, attempt=0):
         ref = None
         if world > 1 and not args.no_scaling_reference:
             comm.barrier()
+            torch.cuda.synchronize(dev)
             if rank == 0:
                 try:
+                    time.sleep(0.5)      # the peers have just released their vectors and mappings
                     rs = max(10, min(args.steps, 30))
                     ref = {"n1_ms_per_step": single_rank_reference(args, lib, L, torch, dev, n_local, 0, n_local, w_head, rs),
                            "slice_ms_per_step": single_rank_reference(args, lib, L, torch, dev, n_global, 0, n_local, w_head, rs), "steps": rs,
