@@ -192,15 +192,20 @@ __device__ __forceinline__ bool sl_round_open(const sl_push_ctl *c, uint32_t rou
     return true;
 }
 
+// (every kernel of a batch takes its argument block at iop[blockIdx.y]: one launch serves one query — grid.y = 1 — or the W queries of a
+// wide batch, each with a state of its own)
 __global__ void sl_push_ctl_reset_kernel(const sl_round_io *iop)
 {
+    iop += blockIdx.y;
     sl_push_ctl *c = iop->c;
-    c->nf = iop->nf0; c->nn = 0; c->n_long_cols = 0; c->nrec = 0; c->nc = 0; c->n_heavy = 0; c->stop = 0; c->rounds = 0; c->done_blocks = 0; c->nf_prev = 0;
+    // (an empty first frontier — the seed below its threshold — is a query that is over before its first round: only a wide batch asks)
+    c->nf = iop->nf0; c->nn = 0; c->n_long_cols = 0; c->nrec = 0; c->nc = 0; c->n_heavy = 0; c->stop = iop->nf0 ? 0u : 1u; c->rounds = 0; c->done_blocks = 0; c->nf_prev = 0;
     c->hits = 0; c->next_hits = 0; c->pushes = 0; c->rows_touched = 0;
 }
 // column entries under the first frontier of a batch (later rounds accumulate the figure as their frontier forms)
 __global__ __launch_bounds__(256) void sl_frontier_hits_kernel(const sl_round_io *iop)
 {
+    iop += blockIdx.y;
     sl_push_ctl *c = iop->c;
     const uint32_t *frontier = iop->frontier[0], *tptr = iop->op.tptr;
     const uint32_t nf = iop->nf0;
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(256) void sl_frontier_hits_kernel(const sl_round_io
 }
 __global__ void sl_hits_gate_kernel(const sl_round_io *iop)
 {
+    iop += blockIdx.y;
     if (iop->c->hits > iop->rec_cap) iop->c->stop = 2u;
 }
 
@@ -525,33 +531,33 @@ __device__ __forceinline__ void sl_close_round(const sl_round_io &io, uint32_t n
 // columns, the pull over hit lists, and the whole-row pull of heavy rows, whose last block closes the round.
 __global__ __launch_bounds__(256) void sl_expand_kernel(const sl_round_io *iop, const sl_push_ctl *cg, uint32_t round_limit)
 {
-    const sl_round_io io = *iop;
+    const sl_round_io io = iop[blockIdx.y];
     uint32_t par;
-    if (!sl_round_open(cg, round_limit, par)) return;
+    if (!sl_round_open(cg ? cg : io.c, round_limit, par)) return;      // (cg: the one query's control block as an argument of its own; a wide batch passes null)
     const sl_worker w = sl_worker_here();
     if (io.c->rounds) sl_clear_frontier(SL_PICK(io.frontier, 1u - par), SL_PICK(io.delta, 1u - par), io.c->nf_prev, w);
     sl_phase_expand(io, par, io.c->nf, w);
 }
 __global__ __launch_bounds__(256) void sl_expand_long_kernel(const sl_round_io *iop, const sl_push_ctl *cg, uint32_t round_limit)
 {
-    const sl_round_io io = *iop;
+    const sl_round_io io = iop[blockIdx.y];
     uint32_t par;
-    if (!sl_round_open(cg, round_limit, par)) return;
+    if (!sl_round_open(cg ? cg : io.c, round_limit, par)) return;      // (cg: the one query's control block as an argument of its own; a wide batch passes null)
     sl_phase_expand_long(io, par, io.c->n_long_cols, sl_worker_here());
 }
 __global__ __launch_bounds__(256) void sl_pull_hits_kernel(const sl_round_io *iop, const sl_push_ctl *cg, uint32_t round_limit)
 {
-    const sl_round_io io = *iop;
+    const sl_round_io io = iop[blockIdx.y];
     uint32_t par;
-    if (!sl_round_open(cg, round_limit, par)) return;
+    if (!sl_round_open(cg ? cg : io.c, round_limit, par)) return;      // (cg: the one query's control block as an argument of its own; a wide batch passes null)
     sl_phase_pull_hits(io, par, io.c->nc, sl_worker_here());
 }
 // the block that finishes last closes the round (a small grid: every block pays an agent-scope fence on the way out)
 __global__ __launch_bounds__(256) void sl_pull_heavy_kernel(const sl_round_io *iop, const sl_push_ctl *cg, uint32_t round_limit)
 {
-    const sl_round_io io = *iop;
+    const sl_round_io io = iop[blockIdx.y];
     uint32_t par;
-    if (!sl_round_open(cg, round_limit, par)) return;
+    if (!sl_round_open(cg ? cg : io.c, round_limit, par)) return;      // (cg: the one query's control block as an argument of its own; a wide batch passes null)
     sl_push_ctl *c = io.c;
     const uint32_t nf = c->nf;
     sl_phase_pull_heavy(io, par, c->n_heavy, sl_worker_here());
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(256) void sl_pull_heavy_kernel(const sl_round_io *i
 __global__ __launch_bounds__(SL_SMALL_THREADS) void sl_small_rounds_kernel(const sl_round_io *iop, uint32_t max_nf, unsigned long long max_hits)
 {
     __shared__ uint32_t s_go, s_par, s_nf, s_prev, s_cnt;
-    const sl_round_io io = *iop;
+    const sl_round_io io = iop[blockIdx.y];
     sl_push_ctl *c = io.c;
     sl_worker w;
     w.tid = threadIdx.x; w.nthreads = SL_SMALL_THREADS; w.wave = threadIdx.x >> 6; w.nwaves = SL_SMALL_THREADS / 64u; w.lane = threadIdx.x & 63u;
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(SL_SMALL_THREADS) void sl_small_rounds_kernel(const
 // after the last round of a batch: the frontier that round consumed is still marked in its delta buffer
 __global__ __launch_bounds__(256) void sl_batch_end_kernel(const sl_round_io *iop)
 {
-    const sl_round_io io = *iop;
+    const sl_round_io io = iop[blockIdx.y];
     const uint32_t rounds = io.c->rounds;
     if (rounds == 0) return;
     const uint32_t par = (rounds - 1u) & 1u;                                   // parity of the last round run
@@ -970,6 +976,7 @@ struct sl_query_session {
     std::vector<double> h_dinv;           // host copy: the seed's threshold test needs dinv[row] only
     double dense_switch = 0.25;
     sl_query_pool *pool = nullptr;        // lanes of sl_query_session_estimate_batch (created on first use)
+    struct sl_query_wide *wide = nullptr; // slots of the wide batch (SL_QUERY_WIDE; created on first use)
     ~sl_query_session();
 };
 
@@ -1011,8 +1018,8 @@ __device__ __forceinline__ bool sl_tail_open(const sl_push_ctl *c, int gate, uin
     if (gate == 0) return true;
     return c->stop == 1u || (gate == 2 && c->rounds >= round_limit);
 }
-__global__ __launch_bounds__(256) void sl_touched_max_kernel(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, const double *x,
-                                                             const double *b, const double *r, unsigned long long *mx)
+__device__ __forceinline__ void sl_touched_max_body(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, const double *x,
+                                                    const double *b, const double *r, unsigned long long *mx)
 {
     uint32_t nt;
     if (!sl_tail_open(c, gate, round_limit, nt)) return;
@@ -1053,8 +1060,13 @@ __device__ __forceinline__ int sl_top_exponent(unsigned long long bits)
     (void)frexp(__longlong_as_double((long long)bits), &e);     // value = m 2^e, 0.5 <= m < 1
     return e < -900 ? -900 : e;                                   // keep every quantum a normal number
 }
-__global__ __launch_bounds__(256) void sl_touched_bins_kernel(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, const double *x,
-                                                              const double *b, const double *r, const unsigned long long *mx, double *bins)
+__global__ __launch_bounds__(256) void sl_touched_max_kernel(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, const double *x,
+                                                             const double *b, const double *r, unsigned long long *mx)
+{
+    sl_touched_max_body(c, gate, round_limit, touched, x, b, r, mx);
+}
+__device__ __forceinline__ void sl_touched_bins_body(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, const double *x,
+                                                     const double *b, const double *r, const unsigned long long *mx, double *bins)
 {
     uint32_t nt;
     if (!sl_tail_open(c, gate, round_limit, nt)) return;
@@ -1085,8 +1097,13 @@ __global__ __launch_bounds__(256) void sl_touched_bins_kernel(const sl_push_ctl 
         if (v != 0.0) atomicAdd(&bins[threadIdx.x * SL_SUM_STRIDE], v);
     }
 }
-__global__ __launch_bounds__(256) void sl_touched_cleanup_kernel(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, double *x, double *r,
-                                                                 double *d0, double *d1, uint32_t *flag)
+__global__ __launch_bounds__(256) void sl_touched_bins_kernel(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, const double *x,
+                                                              const double *b, const double *r, const unsigned long long *mx, double *bins)
+{
+    sl_touched_bins_body(c, gate, round_limit, touched, x, b, r, mx, bins);
+}
+__device__ __forceinline__ void sl_touched_cleanup_body(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, double *x, double *r,
+                                                        double *d0, double *d1, uint32_t *flag)
 {
     uint32_t nt;
     if (!sl_tail_open(c, gate, round_limit, nt)) return;
@@ -1095,6 +1112,48 @@ __global__ __launch_bounds__(256) void sl_touched_cleanup_kernel(const sl_push_c
         const uint32_t i = touched[t];
         x[i] = 0.0; r[i] = 0.0; d0[i] = 0.0; d1[i] = 0.0; flag[i] = 0u;
     }
+}
+__global__ __launch_bounds__(256) void sl_touched_cleanup_kernel(const sl_push_ctl *c, int gate, uint32_t round_limit, const uint32_t *touched, double *x, double *r,
+                                                                 double *d0, double *d1, uint32_t *flag)
+{
+    sl_touched_cleanup_body(c, gate, round_limit, touched, x, r, d0, d1, flag);
+}
+
+// ---- the same tail for the W queries of a WIDE batch (one launch each, slot = blockIdx.y) ---------------------------------------------
+#define SL_WIDE_STATS 8                                     // u64 per slot: rounds, pushes, rows_touched, stop, nf, n_touched, marker, -
+#define SL_WIDE_OUT ((size_t)SL_WIDE_STATS + (2 + 2 * SL_BINS) * SL_SUM_STRIDE)     // 8-byte words a slot leaves for the host: stats, then the sums block
+struct sl_wide_aux { unsigned long long *out; uint32_t row; int32_t in_frontier; double p; };
+__global__ void sl_seed_wide_kernel(const sl_round_io *iov, const sl_wide_aux *aux)
+{
+    const sl_round_io &io = iov[blockIdx.x];
+    const sl_wide_aux a = aux[blockIdx.x];
+    io.r[a.row] = 1.0;
+    if (a.in_frontier) { io.delta[0][a.row] = a.p; io.frontier[0][0] = a.row; }
+    io.flag[a.row] = SL_FLAG_TOUCHED;
+    io.touched[0] = a.row;
+    io.c->n_touched = 1;
+}
+__global__ __launch_bounds__(256) void sl_touched_max_wide_kernel(const sl_round_io *iov, const sl_wide_aux *aux, int gate, uint32_t round_limit, const double *b)
+{
+    const sl_round_io &io = iov[blockIdx.y];
+    sl_touched_max_body(io.c, gate, round_limit, io.touched, io.x, b, io.r, aux[blockIdx.y].out + SL_WIDE_STATS);
+}
+__global__ __launch_bounds__(256) void sl_touched_bins_wide_kernel(const sl_round_io *iov, const sl_wide_aux *aux, int gate, uint32_t round_limit, const double *b)
+{
+    const sl_round_io &io = iov[blockIdx.y];
+    unsigned long long *mx = aux[blockIdx.y].out + SL_WIDE_STATS;
+    sl_touched_bins_body(io.c, gate, round_limit, io.touched, io.x, b, io.r, mx, reinterpret_cast<double *>(mx) + 2 * SL_SUM_STRIDE);
+}
+__global__ __launch_bounds__(256) void sl_touched_cleanup_wide_kernel(const sl_round_io *iov, int gate, uint32_t round_limit)
+{
+    const sl_round_io &io = iov[blockIdx.y];
+    sl_touched_cleanup_body(io.c, gate, round_limit, io.touched, io.x, io.r, io.delta[0], io.delta[1], io.flag);
+}
+__global__ void sl_wide_stats_kernel(const sl_round_io *iov, const sl_wide_aux *aux)
+{
+    const sl_push_ctl *c = iov[blockIdx.x].c;
+    unsigned long long *o = aux[blockIdx.x].out;
+    o[0] = c->rounds; o[1] = c->pushes; o[2] = c->rows_touched; o[3] = c->stop; o[4] = c->nf; o[5] = c->n_touched;
 }
 
 extern "C" {
@@ -1250,12 +1309,137 @@ static void query_lane_main(sl_query_session *q, sl_query_pool *p)
     if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
 }
 
+// ---- many independent queries at once: a WIDE batch (round 4, SL_QUERY_WIDE=W; opt-in until measured) --------------------------------------
+// The lanes above overlap the launch trains of different queries; every query still pays its own ~56 launches.  A wide batch runs W
+// queries through ONE launch train: W slots — a state of its own each, like a lane's — and every kernel of the batch launched once with
+// grid.y = W, slot = blockIdx.y (argument blocks iop[blockIdx.y]); the rounds of the W queries proceed in lockstep, a query that is done
+// gates its blocks off through its own control block.  Seeds, argument blocks and results travel as ONE upload and ONE read-back per
+// group of W.  Every query runs the same phases on the same kind of state as sl_query_session_estimate: the same bits.  A query that the
+// first batch does not finish (a frontier that wants dense rounds, more rounds than the batch holds) has its slot cleaned and is answered
+// again by the ordinary path on that slot — a deterministic function of the query, so the answer is the one it would have had.
+struct sl_query_wide {
+    std::vector<sl_query_session *> slot;
+    DevBuf io_dev, aux_dev, out_dev;
+    std::vector<sl_round_io> h_io;
+    std::vector<sl_wide_aux> h_aux;
+    std::vector<unsigned long long> h_out;
+    ~sl_query_wide() { for (sl_query_session *q : slot) delete q; }
+};
+
 sl_query_session::~sl_query_session()
 {
+    delete wide;
     if (!pool) return;
     { std::unique_lock<std::mutex> lk(pool->mu); pool->quit = true; pool->cv_job.notify_all(); }
     for (std::thread &t : pool->threads) if (t.joinable()) t.join();
     delete pool;
+}
+
+static sl_status wide_batch(sl_query_session *q, uint64_t count, const uint64_t *rows, double theta, uint64_t max_rounds, uint32_t W, sl_estimate_result *results)
+{
+    hipStream_t s = sl_context().stream;
+    if (!q->wide) q->wide = new sl_query_wide();
+    sl_query_wide *wd = q->wide;
+    while (wd->slot.size() < W) {
+        sl_query_session *sub = nullptr;
+        SL_TRY(session_create(q->m, q->given_is_transpose ? 1 : 0, q->db, SL_MEM_DEVICE, true, &sub));     // shares b (device) and the matrix; own state vectors
+        wd->slot.push_back(sub);
+    }
+    if (wd->h_io.size() < W) {
+        wd->h_io.resize(W); wd->h_aux.resize(W); wd->h_out.resize((size_t)W * SL_WIDE_OUT);
+        SL_TRY(wd->io_dev.alloc_owned(W * sizeof(sl_round_io))); SL_TRY(wd->aux_dev.alloc_owned(W * sizeof(sl_wide_aux)));
+        SL_TRY(wd->out_dev.alloc_owned((size_t)W * SL_WIDE_OUT * 8));
+    }
+    static const int cfg_batch = [] { const char *e = getenv("SL_PUSH_BATCH"); const int v = e ? atoi(e) : 12; return v < 1 ? 1 : v; }();
+    static const unsigned long long hit_div = [] { const char *e = getenv("SL_PUSH_HIT_DIV"); const unsigned long long v = e ? strtoull(e, nullptr, 10) : 64; return v ? v : 64ull; }();
+    static const int small_on = [] { const char *e = getenv("SL_PUSH_SMALL"); return e && *e == '1' ? 1 : 0; }();
+    static const uint32_t small_nf = [] { const char *e = getenv("SL_PUSH_SMALL_NF"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 256u; }();
+    static const unsigned long long small_hits = [] { const char *e = getenv("SL_PUSH_SMALL_HITS"); return e ? strtoull(e, nullptr, 10) : 8192ull; }();
+    const uint64_t n = q->n;
+    const uint64_t batch = std::min<uint64_t>((uint64_t)cfg_batch, max_rounds);
+    const int gate = batch >= max_rounds ? 2 : 1;                           // the round limit of the caller falls inside this batch
+    const double dense_limit = q->dense_switch * (double)n;
+    const uint32_t dense_threshold = dense_limit >= 4294967295.0 ? 0xffffffffu : (dense_limit > 0.0 ? (uint32_t)dense_limit : 0u);
+    const sl_round_io *iov = wd->io_dev.as<sl_round_io>();
+    const sl_wide_aux *auxv = wd->aux_dev.as<sl_wide_aux>();
+    for (uint64_t g0 = 0; g0 < count; g0 += W) {
+        const uint32_t G = (uint32_t)std::min<uint64_t>(W, count - g0);
+        if (batch == 0) {                                                   // max_rounds = 0: nothing runs; the ordinary path says what that means
+            for (uint32_t j = 0; j < G; ++j) SL_TRY(sl_query_session_estimate(wd->slot[j], rows[g0 + j], theta, max_rounds, &results[g0 + j]));
+            continue;
+        }
+        for (uint32_t j = 0; j < G; ++j) {
+            push_state &ps = wd->slot[j]->ps;
+            ps.flooded = false;
+            sl_round_io io{};
+            io.c = ps.ctl;
+            io.frontier[0] = ps.frontier[0]; io.frontier[1] = ps.frontier[1];
+            io.delta[0] = ps.delta[0]; io.delta[1] = ps.delta[1];
+            io.op = ps.op; io.x = ps.x; io.r = ps.r; io.dinv = ps.dinv; io.recs = ps.recs; io.head = ps.head; io.cand = ps.cand;
+            io.flag = ps.cand_flag; io.long_cols = ps.long_list; io.touched = ps.touched; io.heavy = ps.heavy;
+            io.theta = sl_theta{theta, nullptr}; io.order = SL_ORDER_CSR_SEQUENTIAL; io.dense_threshold = dense_threshold; io.round_limit = (uint32_t)batch;
+            io.hit_limit = q->dense_switch >= 1.0 ? ps.rec_cap : std::min<unsigned long long>(ps.rec_cap, std::max<unsigned long long>(ps.op_nnz / hit_div, 4096));
+            io.rec_cap = ps.rec_cap;
+            const double p = q->h_dinv[rows[g0 + j]];
+            const int in_frontier = std::fabs(p) >= theta ? 1 : 0;
+            io.nf0 = (uint32_t)in_frontier;
+            wd->h_io[j] = io;
+            wd->h_aux[j] = sl_wide_aux{wd->out_dev.as<unsigned long long>() + (size_t)j * SL_WIDE_OUT, (uint32_t)rows[g0 + j], in_frontier, p};
+        }
+        SL_TRY(sl_upload(wd->io_dev.p, wd->h_io.data(), G * sizeof(sl_round_io), s));
+        SL_TRY(sl_upload(wd->aux_dev.p, wd->h_aux.data(), G * sizeof(sl_wide_aux), s));
+        SL_HIP(hipMemsetAsync(wd->out_dev.p, 0, (size_t)G * SL_WIDE_OUT * 8, s));
+        sl_timer timer;
+        SL_TRY(timer.start(s));
+        hipLaunchKernelGGL(sl_seed_wide_kernel, dim3(G), dim3(1), 0, s, iov, auxv);
+        hipLaunchKernelGGL(sl_push_ctl_reset_kernel, dim3(1, G), dim3(1), 0, s, iov);
+        hipLaunchKernelGGL(sl_frontier_hits_kernel, dim3(1, G), dim3(256), 0, s, iov);
+        hipLaunchKernelGGL(sl_hits_gate_kernel, dim3(1, G), dim3(1), 0, s, iov);
+        if (small_on) hipLaunchKernelGGL(sl_small_rounds_kernel, dim3(1, G), dim3(SL_SMALL_THREADS), 0, s, iov, small_nf, small_hits);
+        for (uint64_t b = 0; b < batch; ++b) {                              // a quarter of a single query's grids per slot: W of them share the machine
+            hipLaunchKernelGGL(sl_expand_kernel, dim3(256, G), dim3(256), 0, s, iov, (const sl_push_ctl *)nullptr, (uint32_t)batch);
+            hipLaunchKernelGGL(sl_expand_long_kernel, dim3(128, G), dim3(256), 0, s, iov, (const sl_push_ctl *)nullptr, (uint32_t)batch);
+            hipLaunchKernelGGL(sl_pull_hits_kernel, dim3(128, G), dim3(256), 0, s, iov, (const sl_push_ctl *)nullptr, (uint32_t)batch);
+            hipLaunchKernelGGL(sl_pull_heavy_kernel, dim3(32, G), dim3(256), 0, s, iov, (const sl_push_ctl *)nullptr, (uint32_t)batch);
+            if (small_on) hipLaunchKernelGGL(sl_small_rounds_kernel, dim3(1, G), dim3(SL_SMALL_THREADS), 0, s, iov, small_nf, small_hits);
+        }
+        hipLaunchKernelGGL(sl_batch_end_kernel, dim3(32, G), dim3(256), 0, s, iov);
+        hipLaunchKernelGGL(sl_touched_max_wide_kernel, dim3(32, G), dim3(256), 0, s, iov, auxv, gate, (uint32_t)batch, q->db);
+        hipLaunchKernelGGL(sl_touched_bins_wide_kernel, dim3(32, G), dim3(256), 0, s, iov, auxv, gate, (uint32_t)batch, q->db);
+        hipLaunchKernelGGL(sl_wide_stats_kernel, dim3(G), dim3(1), 0, s, iov, auxv);              // before the cleanup: n_touched and the counters as the query left them
+        hipLaunchKernelGGL(sl_touched_cleanup_wide_kernel, dim3(64, G), dim3(256), 0, s, iov, gate, (uint32_t)batch);
+        SL_HIP(hipGetLastError());
+        SL_TRY(sl_read_back(wd->h_out.data(), wd->out_dev.p, (size_t)G * SL_WIDE_OUT * 8, s));
+        const float ms = timer.stop();
+        for (uint32_t j = 0; j < G; ++j) {
+            const unsigned long long *o = wd->h_out.data() + (size_t)j * SL_WIDE_OUT;
+            const double *hs = reinterpret_cast<const double *>(o + SL_WIDE_STATS);
+            unsigned long long marker = 0;
+            memcpy(&marker, &hs[2 * SL_SUM_STRIDE - 1], 8);
+            sl_estimate_result *res = &results[g0 + j];
+            memset(res, 0, sizeof(*res));
+            if (marker == 1ull) {                                           // the batch finished the query on the device's terms: sums taken, slot clean
+                double h[2] = {0.0, 0.0};
+                for (int v = 0; v < 2; ++v) {
+                    const double m = hs[v * SL_SUM_STRIDE];                  // bit pattern of a non-negative double
+                    double sum = 0.0;
+                    if (!std::isfinite(m)) sum = m;
+                    else for (int k = SL_BINS - 1; k >= 0; --k) sum += hs[(2 + v * SL_BINS + k) * SL_SUM_STRIDE];
+                    h[v] = sum;
+                }
+                res->estimate = h[0]; res->residual_l1 = h[1];
+                res->rounds = o[0]; res->pushes = o[1]; res->rows_touched = o[2];
+                res->device_time_ms = ms; res->converged = o[4] == 0 ? 1 : 0;
+            } else {
+                // not finished inside the batch: clean the slot (everything the query touched is on its list), answer it the ordinary way
+                push_state &ps = wd->slot[j]->ps;
+                hipLaunchKernelGGL(sl_touched_cleanup_kernel, dim3(256), dim3(256), 0, s, ps.ctl, 0, 0u, ps.touched, ps.x, ps.r, ps.delta[0], ps.delta[1], ps.cand_flag);
+                SL_HIP(hipGetLastError());
+                SL_TRY(sl_query_session_estimate(wd->slot[j], rows[g0 + j], theta, max_rounds, res));
+            }
+        }
+    }
+    return SL_OK;
 }
 
 extern "C" {
@@ -1268,6 +1452,8 @@ sl_status sl_query_session_estimate_batch(sl_query_session *q, uint64_t count, c
     if (count == 0) return SL_OK;
     for (uint64_t i = 0; i < count; ++i)
         if (rows[i] >= q->n) return sl_fail(SL_INVALID_INPUT, "Row index %llu out of bounds. Matrix has %llu rows", (unsigned long long)rows[i], (unsigned long long)q->n);
+    static const uint32_t wide_env = [] { const char *e = getenv("SL_QUERY_WIDE"); const long v = e ? atol(e) : 0; return (uint32_t)(v < 0 ? 0 : (v > 256 ? 256 : v)); }();
+    if (wide_env >= 2 && count >= 2) return wide_batch(q, count, rows, theta, max_rounds, (uint32_t)std::min<uint64_t>(wide_env, count), results);
     if (lanes == 0) lanes = 8;
     lanes = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(lanes, 64u), count);
     if (!q->pool) q->pool = new sl_query_pool();

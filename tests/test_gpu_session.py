@@ -164,3 +164,52 @@ print("RESULT " + json.dumps(out))
         res[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert res["0"] == res["1"], [(a, b) for a, b in zip(res["0"], res["1"]) if a != b][:3]
     assert any(row[2] >= 6 for row in res["0"][:7])             # several rounds did run
+
+
+def test_wide_batch_answers_equal_single_queries(gpu):
+    """SL_QUERY_WIDE=W: W queries share ONE launch train (grid.y = slot).  Every answer — estimate, residual, rounds, pushes, rows touched,
+    converged — equals the one-at-a-time answer bit for bit: local queries, a seed below its threshold (no round at all), queries the batch
+    does not finish (they flood, or need more rounds than a batch holds: the slot is cleaned and the ordinary path answers), a round limit
+    inside the batch, a count that is not a multiple of W, the same row twice; with and without the one-workgroup small rounds."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    prog = r"""
+import json, numpy as np
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import generators as G
+def bits(v): return int(np.float64(v).view(np.uint64))
+def rec(e): return [bits(e.estimate), bits(e.residual_l1), int(e.rounds), int(e.pushes), int(e.rows_touched), int(bool(e.converged))]
+out = {}
+n = 50_000
+rp, ci, va, b = G.sdd_rows(n, 9, seed=12, half_bandwidth=0)
+m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+rows = [0, 17, n - 1, 4242, 17, 31337, 9, 25_000, 40_001, 3, 12_345]
+with S.QuerySession(m, b) as q:
+    for theta, mr in [(1e-4, 100000), (1e-6, 100000), (10.0, 100000), (1e-7, 3), (1e-13, 100000)]:
+        out[f"batch {theta} {mr}"] = [rec(e) for e in q.estimate_batch(rows, theta=theta, max_rounds=mr)]
+        out[f"single {theta} {mr}"] = [rec(q.estimate(r, theta=theta, max_rounds=mr)) for r in rows]
+adj = G.pagerank_graph(20_000, 5)
+prp, pci, pva, pb = G.pagerank_system(20_000, *adj, damping=0.85)
+pm = S.SparseMatrix.from_csr(prp, pci, pva, 20_000, 20_000, with_transpose=True)
+prow = [0, 5, 19_999, 777, 10_000, 64, 1]
+with S.QuerySession(pm, pb) as q:
+    out["pr batch"] = [rec(e) for e in q.estimate_batch(prow, theta=1e-5)]
+    out["pr single"] = [rec(q.estimate(r, theta=1e-5)) for r in prow]
+print("RESULT " + json.dumps(out))
+"""
+    for extra in ({}, {"SL_PUSH_SMALL": "1"}):
+        r = subprocess.run([sys.executable, "-c", prog], cwd=root, capture_output=True, text=True, timeout=900, env=dict(os.environ, SL_QUERY_WIDE="4", **extra))
+        assert r.returncode == 0, r.stderr[-3000:]
+        res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        for key in res:
+            if key.startswith("batch") or key == "pr batch":
+                other = key.replace("batch", "single")
+                # device_time aside, the records must be identical
+                assert res[key] == res[other], (extra, key, [(a, b) for a, b in zip(res[key], res[other]) if a != b][:2])
+        assert all(rr[2] == 0 and rr[0] == 0 for rr in res["batch 10.0 100000"])          # seeds below the threshold: no round, estimate 0
+        assert all(rr[2] == 3 and rr[5] == 0 for rr in res["batch 1e-07 3"])               # cut off by the round limit inside the batch
+        assert any(rr[2] > 12 for rr in res["batch 1e-13 100000"])                         # more rounds than a batch holds: answered by the ordinary path
