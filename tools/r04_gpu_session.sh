@@ -21,8 +21,9 @@ micro)
 optin)
     for f in 0 1; do SL_CG_FUSED_DOT=$f timeout 300 python tools/cg_bench.py > $O/r04_cg_bench_fused$f.json 2>$O/r04_cg_fused$f.err; cat $O/r04_cg_bench_fused$f.json; done
     SL_CG_FUSED_DOT=1 timeout 600 python -m pytest tests/test_gpu_cg.py -q 2>&1 | tail -3
-    timeout 600 python -m pytest tests/test_gpu_session.py -q -k small_rounds 2>&1 | tail -3
-    for f in 0 1; do SL_PUSH_SMALL=$f timeout 600 python tools/pagerank_query.py --no-full-solve > $O/r04_pagerank_small$f.json 2>$O/r04_pagerank_small$f.err; tail -c 2500 $O/r04_pagerank_small$f.json; echo; done ;;
+    timeout 900 python -m pytest tests/test_gpu_session.py -q -k "small_rounds or wide_batch" 2>&1 | tail -3
+    for f in 0 1; do SL_PUSH_SMALL=$f timeout 600 python tools/pagerank_query.py --no-full-solve > $O/r04_pagerank_small$f.json 2>$O/r04_pagerank_small$f.err; tail -c 2500 $O/r04_pagerank_small$f.json; echo; done
+    for w in 8 16 32; do SL_QUERY_WIDE=$w timeout 600 python tools/pagerank_query.py --no-full-solve > $O/r04_pagerank_wide$w.json 2>$O/r04_pagerank_wide$w.err; tail -c 1500 $O/r04_pagerank_wide$w.json; echo; done ;;
 bench)
     timeout 900 python bench.py > $O/r04_bench_default.json 2>$O/r04_bench_default.err; cat $O/r04_bench_default.json | cut -c1-1500
     timeout 600 python bench.py --gpus 2 --steps 20 > $O/r04_bench_2ranks_1gpu.json 2>$O/r04_bench_2ranks.err; cut -c1-600 $O/r04_bench_2ranks_1gpu.json ;;
