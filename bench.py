@@ -14,7 +14,12 @@ N > 1 runs through the library's own communicator by default (`--exchange abi`: 
 IPC-mapped vectors pulled over xGMI, the norm summed over all ranks every step); `--exchange p2p | allreduce` runs the exchange over
 torch.distributed / RCCL instead (grouped send/recv of the halo strips, or the all-reduce form; all-gather for uniform columns).
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+Before the timed region every rank passes a PARITY GATE: two fused steps on the instance it is about to time, sampled
+4096-row blocks of the term and the solution read back through the ABI and compared bit for bit, in a CPU child process, with the
+reference's arithmetic over rows regenerated from the counter-based generator (`parity_gate` in the line; a gate that fails prints
+`value: null`).  N > 1 lines also carry `scaling_reference`: rank 0 alone on the whole one-GPU system and on its own slice, same job.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline`, `cpu_baseline` (N = 1) and `parity_gate`.
 """
 import argparse
 import ctypes as C

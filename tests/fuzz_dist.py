@@ -56,43 +56,43 @@ def main():
                 one_case(rng)
 
         def one_case(rng):
-                world = int(rng.integers(max(1, min(args.min_world, 8)), 9))
-                n = int(rng.choice([int(v) for v in args.sizes.split(",")] if args.sizes else [64 * world + 1, 5000, 20011, 90000, 400000, 1200000]))
-                n = max(n, 64 * world)
-                w = int(rng.choice([1, 40, 300, 5000, 15000, n // max(world, 1), 10**9]))
-                uneven = bool(rng.random() < 0.5)
-                overlap = str(rng.choice(["0", "1"]))
-                cmd = [str(exe), str(world), str(n), str(w)] + (["uneven"] if uneven else [])
-                staging = "pageable" if rng.random() < 0.5 else "pinned"
-                env = dict(os.environ, SL_COMM_TIMEOUT_MS="60000", SL_DIST_OVERLAP=overlap, SL_LOG="1")
-                if staging == "pageable":
-                    env["SL_STAGING"] = "pageable"
-                if n >= 400000 and rng.random() < 0.5:            # the paced layout with XCD-local spans forced on every rank (a pretended small device)
-                    cus = int(rng.choice([4, 8, 12]))
-                    env.update(SL_COLUMN_PANELS="1", SL_PW_FORCE="1", SL_PW_CUS=str(cus), SL_PW_XCD=str(int(rng.choice([2, 4]))))
-                try:
-                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
-                    ok = r.returncode == 0 and "dist_smoke ok" in r.stdout
-                    tail = (r.stdout[-600:] + r.stderr[-1200:]) if not ok else ""
-                    form = ("edge blocks first" if "runs its edge blocks first" in r.stderr else
-                            "edge rounds first (paced layout)" if "runs its edge rounds first" in r.stderr else "exchange after the step")
-                    if "paced column panels" in r.stderr and "rounds first" not in form:
-                        form += " (paced layout)"
-                except subprocess.TimeoutExpired:
-                    ok, tail, form, r = False, "timeout", "?", None
-                lock.acquire()
-                counter[0] += 1
-                by_staging[staging] += 1
-                if r is not None:      # faults the library noticed and repaired by itself: recorded with its own words, whether or not the case then passed
-                    for ln in r.stderr.splitlines():
-                        if "did not fit their slices" in ln or "IPC Attach" in ln or "succeeded on try" in ln:
-                            repaired.append({"cmd": " ".join(cmd[1:]), "staging": staging, "line": ln[:700]})
-                key = f"world {world}: {form}"
-                forms[key] = forms.get(key, 0) + 1
-                if not ok:
-                    failures.append({"cmd": " ".join(cmd[1:]), "overlap": overlap, "staging": staging, "forced": {k: env[k] for k in ("SL_PW_CUS", "SL_PW_XCD") if k in env}, "tail": tail})
-                    print("FAIL", " ".join(cmd[1:]), "overlap", overlap, "staging", staging, "\n", tail, file=sys.stderr)
-                lock.release()
+            world = int(rng.integers(max(1, min(args.min_world, 8)), 9))
+            n = int(rng.choice([int(v) for v in args.sizes.split(",")] if args.sizes else [64 * world + 1, 5000, 20011, 90000, 400000, 1200000]))
+            n = max(n, 64 * world)
+            w = int(rng.choice([1, 40, 300, 5000, 15000, n // max(world, 1), 10**9]))
+            uneven = bool(rng.random() < 0.5)
+            overlap = str(rng.choice(["0", "1"]))
+            cmd = [str(exe), str(world), str(n), str(w)] + (["uneven"] if uneven else [])
+            staging = "pageable" if rng.random() < 0.5 else "pinned"
+            env = dict(os.environ, SL_COMM_TIMEOUT_MS="60000", SL_DIST_OVERLAP=overlap, SL_LOG="1")
+            if staging == "pageable":
+                env["SL_STAGING"] = "pageable"
+            if n >= 400000 and rng.random() < 0.5:            # the paced layout with XCD-local spans forced on every rank (a pretended small device)
+                cus = int(rng.choice([4, 8, 12]))
+                env.update(SL_COLUMN_PANELS="1", SL_PW_FORCE="1", SL_PW_CUS=str(cus), SL_PW_XCD=str(int(rng.choice([2, 4]))))
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env)
+                ok = r.returncode == 0 and "dist_smoke ok" in r.stdout
+                tail = (r.stdout[-600:] + r.stderr[-1200:]) if not ok else ""
+                form = ("edge blocks first" if "runs its edge blocks first" in r.stderr else
+                        "edge rounds first (paced layout)" if "runs its edge rounds first" in r.stderr else "exchange after the step")
+                if "paced column panels" in r.stderr and "rounds first" not in form:
+                    form += " (paced layout)"
+            except subprocess.TimeoutExpired:
+                ok, tail, form, r = False, "timeout", "?", None
+            lock.acquire()
+            counter[0] += 1
+            by_staging[staging] += 1
+            if r is not None:      # faults the library noticed and repaired by itself: recorded with its own words, whether or not the case then passed
+                for ln in r.stderr.splitlines():
+                    if "did not fit their slices" in ln or "IPC Attach" in ln or "succeeded on try" in ln:
+                        repaired.append({"cmd": " ".join(cmd[1:]), "staging": staging, "line": ln[:700]})
+            key = f"world {world}: {form}"
+            forms[key] = forms.get(key, 0) + 1
+            if not ok:
+                failures.append({"cmd": " ".join(cmd[1:]), "overlap": overlap, "staging": staging, "forced": {k: env[k] for k in ("SL_PW_CUS", "SL_PW_XCD") if k in env}, "tail": tail})
+                print("FAIL", " ".join(cmd[1:]), "overlap", overlap, "staging", staging, "\n", tail, file=sys.stderr)
+            lock.release()
 
         threads = [threading.Thread(target=worker, args=(w,)) for w in range(max(1, args.parallel))]
         for t in threads:
