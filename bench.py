@@ -208,6 +208,14 @@ def parity_gate(args, lib, L, st, n_local, n_global, lo, w):
         L.check(lib.sl_neumann_state_current_term(st, s0, cnt, term[i].ctypes.data, L.SL_MEM_HOST))
         L.check(lib.sl_neumann_state_solution_rows(st, s0, cnt, x[i].ctypes.data, L.SL_MEM_HOST))
     L.check(lib.sl_neumann_state_reset(st))
+    return run_gate_checker(args, n_global, lo, w, starts, term, x)
+
+
+def run_gate_checker(args, n_global, lo, w, starts, term, x):
+    """the blocks a rank read back -> the CPU checker in a child process -> its verdict"""
+    import subprocess
+    import tempfile
+    import numpy as np
     if os.environ.get("SL_BENCH_GATE_CORRUPT") == "1":        # test of the gate itself: one ulp in one value it read back
         term.view(np.uint64)[0, 5] ^= 1
     with tempfile.TemporaryDirectory() as td:
@@ -220,6 +228,27 @@ def parity_gate(args, lib, L, st, n_local, n_global, lo, w):
             return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         except Exception as e:
             return {"rows_checked": 0, "bitwise_equal": False, "error": str(e)}
+
+
+def parity_gate_torch(args, torch, drv, part, n_global, w, t0_full, reduce_norm):
+    """the same gate for the exchange ABOVE the ABI (main_torch: --exchange p2p | allreduce, the last fallback of N > 1): two steps of the
+    torch.distributed driver, the same blocks read from its tensors, the same checker; then the driver starts over from t0"""
+    import numpy as np
+    if args.order not in (0, 1):
+        return {"skipped": "order-relaxed mode: results to rounding, no bitwise gate"}
+    n_local = part.n_local
+    starts = gate_block_starts(n_local)
+    cnt = min(GATE_BLOCK, n_local)
+    t_start = t0_full.clone()
+    for _ in range(GATE_STEPS):
+        drv.step(reduce_norm)
+    torch.cuda.synchronize()
+    tc = drv.t[drv.cur]
+    term = np.stack([tc[part.lo + s0:part.lo + s0 + cnt].cpu().numpy() for s0 in starts])
+    x = np.stack([drv.x[s0:s0 + cnt].cpu().numpy() for s0 in starts])
+    drv.restart(t_start, t_start[part.lo:part.hi])
+    del t_start
+    return run_gate_checker(args, n_global, part.lo, w, starts, term, x)
 
 
 def single_rank_reference(args, lib, L, torch, dev, n_global, lo, hi, w, steps):
@@ -839,6 +868,16 @@ def main_torch(args, world, rank, local_rank):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    gate = None
+    if not args.no_parity_gate:
+        gate = parity_gate_torch(args, torch, drv, part, n_global, w, t0, reduce_norm)
+        if "skipped" not in gate:
+            agg = torch.tensor([float(gate.get("rows_checked", 0)), 1.0 if gate.get("bitwise_equal") else 0.0, float(gate.get("max_rel_err", float("inf")))], dtype=torch.float64, device=dev)
+            lo_ok = agg[1:2].clone()
+            if world > 1 or force_dist:
+                D.all_reduce_scalar(agg[0:1], dist.ReduceOp.SUM); D.all_reduce_scalar(lo_ok, dist.ReduceOp.MIN); D.all_reduce_scalar(agg[2:3], dist.ReduceOp.MAX)
+            gate = {"rows_checked": int(agg[0]), "bitwise_equal": bool(lo_ok[0] > 0.5), "max_rel_err": float(agg[2]), "ranks_checked": world,
+                    "steps_before_check": GATE_STEPS, "checker": "oracle SpMV over rows regenerated on the host, in a child process before the timed region (exchange over torch.distributed)"}
     for _ in range(args.warmup):
         drv.step(reduce_norm)
     barrier()
@@ -898,6 +937,10 @@ def main_torch(args, world, rank, local_rank):
                          # algorithmic bytes count 12 B per entry; 16-bit column offsets move 10, so this ratio can exceed 1 on banded inputs
                          "algorithmic_over_copy_ceiling_6290": achieved / 6290.0},
         }
+        if gate is not None:
+            out["parity_gate"] = gate
+            if "skipped" not in gate and not gate["bitwise_equal"]:      # a step whose results differ is not reported as a measurement
+                out["value"], out["ms_per_step"], out["error"] = None, None, "parity gate failed: the step's results differ from the CPU checker's"
         if world == 1 and not args.no_sweep:
             others = [v for v in (0, BANDED_BANDWIDTH, 512, 32768) if v != w]
             sweep = column_structure_sweep(lib, L, torch, dev, n_local, k, args.seed, args.order, others)

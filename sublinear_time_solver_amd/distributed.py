@@ -422,6 +422,19 @@ class PartitionedNeumann:
         self.steps_done = 0
         self.reduce_always = False                     # measurement mode: issue the norm all-reduce even at world size 1
 
+    def restart(self, t0_full: torch.Tensor, x_local: torch.Tensor) -> None:
+        """back to the start of the series (current term = t0, solution = x_local, no step taken): pending all-reduces are waited
+        for, the logs start over.  bench.py's parity gate runs two steps, reads them, and restarts."""
+        for k in (0, 1):
+            if self._pending[k] is not None:
+                self._pending[k].wait()
+                self._pending[k] = None
+        self.t[0].copy_(t0_full)
+        self.t[1].zero_()
+        self.x.copy_(x_local)
+        self.cur = 0
+        self._log, self._fill, self._last, self.steps_done = 0, 0, (0, 0), 0
+
     @property
     def norm2(self) -> torch.Tensor:
         """log row of the most recent step (globally summed after term_norm())"""
