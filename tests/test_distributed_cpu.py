@@ -64,6 +64,11 @@ def _worker(rank, world, port, n, k, w, steps, out_dir, split=False):
             local = D.SplitStep([piece(a, b) for a, b in bnd if b > a], [piece(a, b) for a, b in inter if b > a], torch.device("cpu"))
         every = int(os.environ.get("SL_TEST_REDUCE_EVERY", "1"))
         drv = D.PartitionedNeumann(part, local, ex, t0, x, reduce_every=every)
+        if os.environ.get("SL_TEST_RESTART") == "1":      # bench.py's parity gate: a few steps, a look, back to the start
+            t_start = t0.clone()
+            for _ in range(3):
+                drv.step()
+            drv.restart(t_start, t_start[part.lo:part.hi])
         norms = []
         for s in range(steps):
             drv.step()
@@ -112,6 +117,26 @@ def test_halo_as_one_allreduce(tmp_path, monkeypatch, split):
         assert int(z["sent"]) == 8 * 2 * w * (world - 1)
     assert (xs.view(np.uint64) == o["x"].view(np.uint64)).all()
     assert (ts.view(np.uint64) == o["term"].view(np.uint64)).all()
+
+
+@pytest.mark.parametrize("every", ["1", "4"])
+def test_restart_puts_the_driver_back_at_the_start(tmp_path, monkeypatch, every):
+    """PartitionedNeumann.restart (bench.py's parity gate on the torch.distributed path runs steps, reads them and starts over): the
+    iteration after a restart is the iteration of a fresh driver — bits of x and t, every norm — with the split step and a batched log"""
+    monkeypatch.setenv("SL_TEST_RESTART", "1")
+    monkeypatch.setenv("SL_TEST_REDUCE_EVERY", every)
+    n, k, w, world, steps = 6000, 12, 300, 2, 6
+    mp.spawn(_worker, args=(world, _free_port(), n, k, w, steps, str(tmp_path), True), nprocs=world, join=True)
+    rp, ci, va, b = G.sdd_rows(n, k, 3, w)
+    o = O.neumann_solve(rp, ci, va, b, max_terms=steps + 1, series_tolerance=0.0, max_iterations=steps + 1, tolerance=0.0)
+    xs, ts = np.zeros(n), np.zeros(n)
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        xs[int(z["lo"]):int(z["hi"])] = z["x"]
+        ts[int(z["lo"]):int(z["hi"])] = z["t"]
+        assert len(z["norms"]) == steps
+        np.testing.assert_allclose(z["norms"], o["term_norms"][1:], rtol=1e-12)
+    assert (xs.view(np.uint64) == o["x"].view(np.uint64)).all() and (ts.view(np.uint64) == o["term"].view(np.uint64)).all()
 
 
 def test_partitioned_iteration_batched_norm_log(tmp_path, monkeypatch):
