@@ -343,6 +343,7 @@ void sl_matrix_destroy(sl_matrix *m)
     hipFree(m->d_pan_tile_ptr); hipFree(m->d_pan_row); hipFree(m->d_pan_col); hipFree(m->d_pan_val);
     hipFree(m->d_pw_idx); hipFree(m->d_pw_val); hipFree(m->d_pw_tile_ptr); hipFree(m->d_pw_span_tab);
     hipFree(m->d_pwr_idx); hipFree(m->d_pwr_val); hipFree(m->d_pwr_base); hipFree(m->d_pwr_tile_ptr); hipFree(m->d_pwr_diag);
+    hipFree(m->d_colval);
     delete m;
 }
 

@@ -748,6 +748,9 @@ sl_status run_push(push_state &ps, const sl_matrix *m, sl_theta theta, uint64_t 
                                          : std::min<unsigned long long>(ps.rec_cap, std::max<unsigned long long>(ps.op_nnz / hit_div, 4096));
     bool force_dense = false, need_log = true;
     int sparse_batches_done = 0;
+    static const bool idx_only = [] { const char *e = getenv("SL_PW_INDEX_ONLY"); return e && *e == '1'; }();
+    DevBuf zbuf[2];
+    bool z_valid = false;
     const double mean_col = n ? (double)ps.op_nnz / (double)n : 0.0;
 
     sl_status st = SL_OK;
@@ -764,6 +767,15 @@ sl_status run_push(push_state &ps, const sl_matrix *m, sl_theta theta, uint64_t 
                 sl_row_args a = sl_matrix_row_args(m);
                 a.gather = ps.delta[cur]; a.dinv = ps.dinv; a.out = ps.delta[1 - cur]; a.x = ps.x; a.r = ps.r; a.theta = theta.s; a.theta_rows = theta.rows;
                 a.partials = scr; a.partials_slack = 4096; a.result = resbuf.as<double>();
+                // column-constant operator (sl_matrix::d_colval; SL_PW_INDEX_ONLY=1): the paced kernel reads the index words of its stream alone
+                // and gathers ready-made products from z = colval (.) delta; the epilogue leaves the next round's z beside the next delta.
+                // z follows delta's parity; a sparse batch or a fresh frontier invalidates it (one elementwise pass brings it back).
+                if (idx_only && m->d_colval && m->d_pw_idx && order == SL_ORDER_CSR_SEQUENTIAL) {
+                    if (!zbuf[0].p) { st = zbuf[0].alloc(n * 8); if (st == SL_OK) st = zbuf[1].alloc(n * 8); if (st != SL_OK) break; }
+                    if (!z_valid) { st = sl_launch_scale_rows(n, m->d_colval, ps.delta[cur], zbuf[cur].as<double>(), s); if (st != SL_OK) break; }
+                    a.zgather = zbuf[cur].as<double>(); a.zcol = m->d_colval; a.zout = zbuf[1 - cur].as<double>();
+                    z_valid = true;
+                }
                 st = sl_launch_rows(a, (sl_order)order, SL_EPI_PUSH, s);
                 if (st != SL_OK) break;
                 double h[2];
@@ -783,6 +795,7 @@ sl_status run_push(push_state &ps, const sl_matrix *m, sl_theta theta, uint64_t 
             SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s));
             list_valid = true; list_sorted = true; need_log = true;
         } else {
+            z_valid = false;                                             // sparse rounds write delta without its pre-multiplied twin
             if (!list_valid) { SL_TRY(compact(ps, ps.delta[cur], theta, ps.frontier[0], &nf, s)); list_valid = true; list_sorted = true; need_log = true;
                                SL_HIP(hipMemsetAsync(ps.delta[1 - cur], 0, n * 8, s)); }
             // a batch of device-driven sparse rounds (one round when the frontier lists are being logged); the first batch is the

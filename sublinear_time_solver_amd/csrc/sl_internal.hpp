@@ -121,6 +121,12 @@ struct sl_matrix {
     uint64_t n_pwr_tiles = 0, pwr_chunks = 0;
     uint32_t pwr_rpb = 0, pwr_blocks = 0;
 
+    // COLUMN-CONSTANT operators (round 4): every off-diagonal entry of a column holds the same value and every diagonal entry is exactly
+    // 1 — the PageRank / PPR systems I - (1 - alpha) P^T of an unweighted graph, a_iu = -(1 - alpha) / deg_u.  d_colval[u] = that value
+    // (0 for a column nobody references).  A dense push round may then run the paced kernel on the INDEX words of its stream alone
+    // (4 instead of 12 bytes per entry), gathering from the pre-multiplied vector z_u = colval_u * delta_u: the product of every entry of
+    // column u is that one rounded product, so the row sums keep their bits (sl_pw_kernel<.., IDX>).
+    double *d_colval = nullptr;
     uint64_t device_bytes = 0;
     bool caller_device_arrays = false;  // sl_matrix_create_csr was handed device pointers (diagnostics of the layout build)
 };
@@ -348,6 +354,10 @@ struct sl_row_args {
     const double *gather; // gathered vector (n_cols)
     const double *dinv;   // n_rows
     const double *aux;    // RESIDUAL: rhs (n_rows); PUSH: unused
+    // index-only stream of a column-constant operator (PUSH epilogue on the paced layout; all three null otherwise): zgather = the
+    // pre-multiplied gathered vector colval (.) gather, zcol = colval, zout = where the epilogue leaves colval_i * delta'_i for the next round
+    const double *zgather, *zcol;
+    double *zout;
     uint32_t aux_dot;     // RESIDUAL epilogue as "product + dot": out = A g, sum of aux_i * (A g)_i instead of the residual's sum of squares (CG: p . Ap in the SpMV's launch)
     double *out;          // SPMV: y; NEUMANN: t_out; RESIDUAL: r (may be null); PUSH: delta_out
     double *x;            // NEUMANN / PUSH: x in/out

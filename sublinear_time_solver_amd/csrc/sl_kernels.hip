@@ -146,7 +146,9 @@ __device__ __forceinline__ void sl_row_epilogue(const sl_row_args &a, uint64_t i
         a.r[i] = rn;
         const double p = DMUL(rn, e_d);
         const bool f = fabs(p) >= (a.theta_rows ? a.theta_rows[i] : a.theta);
-        a.out[i] = f ? p : 0.0;
+        const double dn = f ? p : 0.0;
+        a.out[i] = dn;
+        if (a.zout) a.zout[i] = DMUL(a.zcol[i], dn);       // column-constant operator: the one product every entry of column i will contribute next round
         part0 = DADD(part0, DMUL(rn, rn));
         part1 += f ? 1.0 : 0.0;
     }
@@ -887,7 +889,11 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
 #endif
 // ANY_ORDER / PWV: measurement builds only (SL_PW_ANY, SL_PW_VAR): relaxed accumulation inside this layout; PWV & 8 = no epilogue
 // traffic, PWV & 32 = gathers folded into the first 2 MB of the vector (every gather an L2 hit, no first touches), PWV & 2 = no LDS update
-template <int EPI, bool ANY_ORDER = false, int PWV = 0>
+// IDX (round 4): the index-only form for column-constant operators (sl_matrix::d_colval) — only the index words of the stream are
+// loaded (4 of its 12 bytes per entry); an off-diagonal entry's product is gathered ready-made from a.zgather (= colval_u * gather_u,
+// rounded once: the same double DMUL(value, gather) gives for every entry of column u), the diagonal entry's — value exactly 1 — is the
+// gathered vector's own entry; which of the two an entry is follows from its row slot (the row's global index against its column).
+template <int EPI, bool ANY_ORDER = false, int PWV = 0, bool IDX = false>
 __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
 {
     extern __shared__ __attribute__((aligned(16))) double pw_acc[];
@@ -919,6 +925,11 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         if (tile >= a.pw_tiles) { if (lane == 0) prog_st(wave, 0xffffffffu); continue; }     // nothing to wait for
         for (uint32_t r = lane; r <= rpw; r += 64) acc[r] = 0.0;
         const uint32_t ch0 = a.pw_tile_ptr[tile], chunks = a.pw_tile_ptr[tile + 1] - ch0;
+        // groups of SL_PW_GROUP rows are dealt among `deal` tiles: a span owns the row groups [g0, g0 + gcnt) — deal * rpw consecutive rows
+        // in row order, or what the span table says (XCD-local spans, edge-first rounds)
+        const uint32_t ps = tile / deal, tdeal = tile % deal;
+        const uint64_t g0 = a.pw_span_tab ? a.pw_span_tab[2 * ps] : (uint64_t)ps * deal * (rpw / SL_PW_GROUP);
+        const uint32_t gcnt = a.pw_span_tab ? a.pw_span_tab[2 * ps + 1] : deal * (rpw / SL_PW_GROUP);
         const u32x4 *__restrict__ idxq = reinterpret_cast<const u32x4 *>(a.pw_idx) + (uint64_t)ch0 * 64;
         const f64x2 *__restrict__ valq = reinterpret_cast<const f64x2 *>(a.pw_val) + (uint64_t)ch0 * 128;
         uint32_t sp_g = 0;                                          // super-panel at the gather stage (wave-uniform)
@@ -926,9 +937,10 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         double SV[3][4], GG[3][4];
         auto load_stream = [&](uint32_t ch, uint32_t (&ii)[4], double (&vv)[4]) {
             const u32x4 q = __builtin_nontemporal_load(idxq + (uint64_t)ch * 64 + lane);
+            ii[0] = q.x; ii[1] = q.y; ii[2] = q.z; ii[3] = q.w;
+            if constexpr (IDX) { vv[0] = vv[1] = vv[2] = vv[3] = 1.0; return; }        // (never multiplied: the products come ready-made)
             const f64x2 va = __builtin_nontemporal_load(valq + (uint64_t)ch * 128 + lane);
             const f64x2 vb = __builtin_nontemporal_load(valq + (uint64_t)ch * 128 + 64 + lane);
-            ii[0] = q.x; ii[1] = q.y; ii[2] = q.z; ii[3] = q.w;
             vv[0] = va.x; vv[1] = va.y; vv[2] = vb.x; vv[3] = vb.y;
         };
         auto pace = [&](uint32_t pan) {
@@ -954,6 +966,13 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
                 if (fl) sp += mask_count_below(fl) + stepbit;           // a handful of times per tile: the first entry of a super-panel
                 sp_g = __builtin_amdgcn_readfirstlane(sp_g + (real ? (uint32_t)__popcll(fl) : 0u));
                 cc[u] = real ? ((sp << SL_PW_SP_BITS) | (ii[u] & ((1u << SL_PW_SP_BITS) - 1u))) : 0u;
+                if constexpr (IDX) {
+                    // the row this entry belongs to (slot -> group of the span -> global row); its diagonal entry is the one at its own column
+                    const uint32_t r = ii[u] >> SL_PW_ROW_SHIFT;
+                    const uint64_t irow = (g0 + (uint64_t)(r / SL_PW_GROUP) * deal + tdeal) * SL_PW_GROUP + (r % SL_PW_GROUP);
+                    const double *__restrict__ base = ((uint64_t)cc[u] == a.row_offset + irow && r < rpw) ? g : a.zgather;
+                    gg[u] = base[cc[u]];
+                } else
                 gg[u] = (PWV & 32) ? g[cc[u] & 0x3ffffu] : g[cc[u]];
             }
         };
@@ -962,7 +981,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
             for (int u = 0; u < 4; ++u) {                            // row slots < 2^SL_PW_ROW_BITS (SL_PW_MAX_ROWS + the spare slot)
                 if constexpr (PWV & 2) { if (DMUL(vv[u], gg[u]) == 123.456) acc[0] = 1.0; }
                 else if constexpr (ANY_ORDER) (void)__hip_atomic_fetch_add(&acc[ii[u] >> SL_PW_ROW_SHIFT], DMUL(vv[u], gg[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else sl_ordered_accumulate<SL_PW_ROW_BITS>(acc, lane, ii[u] >> SL_PW_ROW_SHIFT, DMUL(vv[u], gg[u]), cc[u] >> pbits);
+                else sl_ordered_accumulate<SL_PW_ROW_BITS>(acc, lane, ii[u] >> SL_PW_ROW_SHIFT, IDX ? gg[u] : DMUL(vv[u], gg[u]), cc[u] >> pbits);
             }
         };
         if (chunks) {
@@ -992,13 +1011,8 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         }
         if (lane == 0) prog_st(wave, (round + 1u) << 20);            // as far along as the round's end while the vectors are written
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // groups of SL_PW_GROUP rows are dealt among `deal` tiles: a span owns the row groups [g0, g0 + gcnt) — deal * rpw consecutive rows
-        // in row order, or what the span table says (XCD-local spans, edge-first rounds)
-        const uint32_t ps = tile / deal;
-        const uint64_t g0 = a.pw_span_tab ? a.pw_span_tab[2 * ps] : (uint64_t)ps * deal * (rpw / SL_PW_GROUP);
-        const uint32_t gcnt = a.pw_span_tab ? a.pw_span_tab[2 * ps + 1] : deal * (rpw / SL_PW_GROUP);
         for (uint32_t r = lane; r < rpw; r += 64) {                   // slot r = group r / 16 of the tile, row r % 16 of the group
-            const uint32_t gl = (r / SL_PW_GROUP) * deal + tile % deal;
+            const uint32_t gl = (r / SL_PW_GROUP) * deal + tdeal;
             if (gl >= gcnt) continue;                                 // (a span shorter than its tiles' slots)
             const uint64_t i = (g0 + gl) * SL_PW_GROUP + (r % SL_PW_GROUP);
             if (i >= a.n_rows || (a.n_long && a.row_len[i] == SL_LONG_SENTINEL)) continue;
@@ -1520,6 +1534,10 @@ static sl_status launch_rows_t(const sl_row_args &a_in, hipStream_t s, uint32_t 
             hipLaunchKernelGGL((sl_pw_kernel<SL_EPI_NEUMANN, true>), dim3(a.pw_blocks), dim3(SL_PW_WAVES * 64), lds, s, a);
         } else
 #endif
+        if (EPI == SL_EPI_PUSH && a.zgather) {                             // column-constant operator: the index words of the stream alone
+            SL_TRY((set_max_lds_once<sl_pw_kernel<SL_EPI_PUSH, false, 0, true>>((int)(SL_PW_WAVES * ((size_t)SL_PW_MAX_ROWS + 1) * sizeof(double)))));
+            hipLaunchKernelGGL((sl_pw_kernel<SL_EPI_PUSH, false, 0, true>), dim3(a.pw_blocks), dim3(SL_PW_WAVES * 64), lds, s, a);
+        } else
         hipLaunchKernelGGL((sl_pw_kernel<EPI>), dim3(a.pw_blocks), dim3(SL_PW_WAVES * 64), lds, s, a);
     } else if (ORDER == 0 && a.pan_tile_ptr && a.n_pan_tiles) {
         const uint32_t grid = (a.n_pan_tiles + SL_PANEL_WAVES - 1) / SL_PANEL_WAVES;

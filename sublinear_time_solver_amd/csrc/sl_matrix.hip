@@ -764,6 +764,59 @@ static sl_status sl_build_order_free_stream(sl_matrix *m, const uint32_t *d_row_
     return SL_OK;
 }
 
+// ---- column-constant operators (sl_matrix::d_colval) ----------------------------------------------------------------------------------
+// One pass over the rows: the first off-diagonal entry seen of a column leaves its value (bit pattern) in colbits[column], every other
+// one compares with it; a diagonal entry must be exactly 1.  *bad != 0: not such an operator (threads leave as soon as they see it).
+#define SL_COLVAL_UNSET 0xfff8c01dc01dc01dull              // a NaN payload no stored value carries
+__global__ __launch_bounds__(256) void sl_fill_u64_kernel(uint64_t n, unsigned long long *p, unsigned long long v)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < n) p[j] = v;
+}
+__global__ __launch_bounds__(256) void sl_colval_detect_kernel(uint64_t n, uint64_t row_offset, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values,
+                                                               unsigned long long *colbits, uint32_t *bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const uint32_t s = row_ptr[i], e = row_ptr[i + 1];
+    for (uint32_t k = s; k < e; ++k) {
+        const uint32_t c = col_idx[k];
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(values[k]);
+        if ((uint64_t)c == row_offset + i) { if (values[k] != 1.0) { *bad = 1u; return; } continue; }
+        const unsigned long long old = atomicCAS(&colbits[c], SL_COLVAL_UNSET, vb);
+        if (old != SL_COLVAL_UNSET && old != vb) { *bad = 1u; return; }
+        if ((k & 63u) == 63u && __hip_atomic_load(bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+}
+__global__ __launch_bounds__(256) void sl_colval_finish_kernel(uint64_t n_cols, unsigned long long *colbits)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < n_cols && colbits[j] == SL_COLVAL_UNSET) colbits[j] = 0ull;          // a column nobody references: +0.0
+}
+static sl_status sl_detect_column_constant(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx, const double *d_values, hipStream_t st)
+{
+    const uint64_t n = m->n_rows;
+    if (!n || !m->nnz || m->n_rows != m->n_cols || m->row_offset) return SL_OK;
+    DevBuf bits, bad;
+    SL_TRY(bits.alloc_owned(m->n_cols * 8)); SL_TRY(bad.alloc(16));
+    SL_HIP(hipMemsetAsync(bad.p, 0, 16, st));
+    // fill with the sentinel: its eight bytes are not all equal, so no memset — a tiny kernel would do; reuse the finish kernel's shape
+    hipLaunchKernelGGL(sl_fill_u64_kernel, dim3((uint32_t)((m->n_cols + 255) / 256)), dim3(256), 0, st, m->n_cols, bits.as<unsigned long long>(), SL_COLVAL_UNSET);
+    hipLaunchKernelGGL(sl_colval_detect_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, m->row_offset, d_row_ptr, d_col_idx, d_values,
+                       bits.as<unsigned long long>(), bad.as<uint32_t>());
+    uint32_t h_bad = 0;
+    SL_TRY(sl_read_back(&h_bad, bad.p, 4, st));
+    if (h_bad) return SL_OK;
+    hipLaunchKernelGGL(sl_colval_finish_kernel, dim3((uint32_t)((m->n_cols + 255) / 256)), dim3(256), 0, st, m->n_cols, bits.as<unsigned long long>());
+    SL_HIP(hipGetLastError());
+    SL_HIP(hipStreamSynchronize(st));
+    m->d_colval = static_cast<double *>(bits.release());
+    m->device_bytes += m->n_cols * 8;
+    sl_log(1, "matrix layout: column-constant operator with a unit diagonal (one value per column: %llu columns) — dense push rounds may run on the index words of the paced stream alone",
+           (unsigned long long)m->n_cols);
+    return SL_OK;
+}
+
 sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx,
                                    const double *d_values, bool keep_csr_copy)
 {
@@ -973,6 +1026,13 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
             if (ps == SL_OK && !m->d_pw_idx && (forced || pays)) ps = sl_build_column_panels(m, d_row_ptr, d_col_idx, d_values, n_tiles, (uint32_t)n_panels, st);
             if (ps != SL_OK) return ps;
         }
+    }
+
+    // 2c. column-constant operators with a unit diagonal (PageRank / PPR systems of unweighted graphs) on the uniform-column paced layout:
+    //     opt-in for now (SL_PW_INDEX_ONLY=1, read when the matrix is built and when a push runs on it)
+    {
+        static const bool idx_only = [] { const char *e = getenv("SL_PW_INDEX_ONLY"); return e && *e == '1'; }();
+        if (idx_only && m->d_pw_idx && !m->pw_band) SL_TRY(sl_detect_column_constant(m, d_row_ptr, d_col_idx, d_values, st));
     }
 
     // 3. transpose

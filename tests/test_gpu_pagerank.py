@@ -141,3 +141,46 @@ def test_g9_gpu_pagerank_matches_the_reference_power_iteration(gpu):
         top = int(np.argmax(ref))
         e = S.estimate_entry(m, b, top, theta=1e-16)
         assert abs(e.estimate - ref[top]) <= 1e-12
+
+
+def test_index_only_stream_of_column_constant_operators_keeps_the_bits(gpu):
+    """SL_PW_INDEX_ONLY=1: for I - (1 - alpha) P^T of an UNWEIGHTED graph every off-diagonal entry of column u is -(1 - alpha) / deg_u and
+    the diagonal is exactly 1; the dense push rounds then run the paced kernel on the index words of its stream alone and gather the
+    ready-made products colval_u * delta_u.  Same product per entry, same order: x, r, rounds, pushes bit for bit as with the full stream —
+    on a forced paced layout with several rounds of tiles, hub rows (long-row kernel) and dangling columns; a WEIGHTED graph is not such an
+    operator and must not be taken for one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    prog = r"""
+import json, numpy as np
+import sublinear_time_solver_amd as S
+from sublinear_time_solver_amd import generators as G
+out = {}
+n = 40_000
+for tag, weighted in (("unit", False), ("weighted", True)):
+    rp, ci, w = G.pagerank_graph(n, 11)
+    if weighted:
+        w = 0.5 + (np.arange(w.size) % 7) * 0.25
+    arp, aci, ava, b = G.pagerank_system(n, rp, ci, w, damping=0.85)
+    m = S.SparseMatrix.from_csr(arp, aci, ava, n, n, with_transpose=True)
+    out[tag + " layout"] = int(m.info().column_panels)
+    for theta in (1e-9, 1e-6):
+        p = S.PushSolver(theta=theta, dense_switch=1.0 / 64.0).solve(m, b)
+        out[f"{tag} {theta}"] = [int(p["rounds"]), int(p["pushes"]), int(p["dense_rounds"]), int(p["solution"].view(np.uint64).sum() % (1 << 61)),
+                                 int(p["residual"].view(np.uint64).sum() % (1 << 61)), int(np.float64(p["solution"][17]).view(np.uint64))]
+print("RESULT " + json.dumps(out))
+"""
+    base = dict(os.environ, SL_COLUMN_PANELS="1", SL_PW_FORCE="1", SL_PW_CUS="4", SL_LOG="1")
+    res, logs = {}, {}
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", prog], cwd=root, capture_output=True, text=True, timeout=900, env=dict(base, SL_PW_INDEX_ONLY=mode))
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+        logs[mode] = r.stderr
+    assert res["0"] == res["1"], {k: (res["0"][k], res["1"][k]) for k in res["0"] if res["0"][k] != res["1"][k]}
+    assert res["1"]["unit layout"] == 2 and res["1"]["unit 1e-09"][2] > 3                       # paced layout, several dense rounds
+    assert logs["1"].count("column-constant operator") == 1 and "column-constant operator" not in logs["0"]   # the unit graph only, and only when asked

@@ -23,6 +23,8 @@ optin)
     SL_CG_FUSED_DOT=1 timeout 600 python -m pytest tests/test_gpu_cg.py -q 2>&1 | tail -3
     timeout 900 python -m pytest tests/test_gpu_session.py -q -k "small_rounds or wide_batch" 2>&1 | tail -3
     for f in 0 1; do SL_PUSH_SMALL=$f timeout 600 python tools/pagerank_query.py --no-full-solve > $O/r04_pagerank_small$f.json 2>$O/r04_pagerank_small$f.err; tail -c 2500 $O/r04_pagerank_small$f.json; echo; done
+    timeout 900 python -m pytest tests/test_gpu_pagerank.py -q -k index_only 2>&1 | tail -3
+    for f in 0 1; do SL_PW_INDEX_ONLY=$f timeout 900 python tools/pagerank_query.py --thetas 1e-5 > $O/r04_pagerank_idx$f.json 2>$O/r04_pagerank_idx$f.err; head -c 900 $O/r04_pagerank_idx$f.json; echo; done
     for w in 8 16 32; do SL_QUERY_WIDE=$w timeout 600 python tools/pagerank_query.py --no-full-solve > $O/r04_pagerank_wide$w.json 2>$O/r04_pagerank_wide$w.err; tail -c 1500 $O/r04_pagerank_wide$w.json; echo; done ;;
 bench)
     timeout 900 python bench.py > $O/r04_bench_default.json 2>$O/r04_bench_default.err; cat $O/r04_bench_default.json | cut -c1-1500
