@@ -14,6 +14,7 @@ tests)
     timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -15 ;;
 micro)
     timeout 200 tools/ldsdma_bench 20 > $O/r04_ldsdma_bench.txt 2>&1; cat $O/r04_ldsdma_bench.txt
+    timeout 100 tools/launch_floor > $O/r04_launch_floor.txt 2>&1; cat $O/r04_launch_floor.txt
     for p in 8 7; do
         timeout 300 tools/layout_stress $p 1500 400000 2 > $O/r04_layout_stress_$p.json 2> $O/r04_layout_stress_$p.err
         cat $O/r04_layout_stress_$p.json; echo "misfits reported: $(grep -c 'did not fit' $O/r04_layout_stress_$p.err)"; head -c 1200 $O/r04_layout_stress_$p.err
