@@ -5,6 +5,7 @@
 #   bash tools/r04_gpu_session.sh optin        the opt-in paths against their defaults: CG with p.Ap fused, push rounds in one workgroup
 #   bash tools/r04_gpu_session.sh bench        default bench line + N = 2 / 8 self-started ranks
 #   bash tools/r04_gpu_session.sh profile      rocprofv3 stats + counters of the headline (tools/profile.sh)
+#   bash tools/r04_gpu_session.sh optin_fuzz [s]   tests/fuzz_campaign.py with every opt-in path on
 #   bash tools/r04_gpu_session.sh fuzz [s]     tests/fuzz_dist.py, one job at a time, s seconds (default 600)
 cd /root/repo
 O=gpurun_out
@@ -32,6 +33,8 @@ bench)
     timeout 600 python bench.py --gpus 2 --steps 20 > $O/r04_bench_2ranks_1gpu.json 2>$O/r04_bench_2ranks.err; cut -c1-600 $O/r04_bench_2ranks_1gpu.json ;;
 profile)
     bash tools/profile.sh r04_uniform --bandwidth 0 2>&1 | tail -12 ;;
+optin_fuzz)      # the random parity campaign with every opt-in path of the round switched on: whatever runs must still equal the oracle
+    SL_PUSH_SMALL=1 SL_QUERY_WIDE=4 SL_CG_FUSED_DOT=1 SL_PW_INDEX_ONLY=1 timeout $(( ${2:-240} + 120 )) python tests/fuzz_campaign.py --seconds ${2:-240} > $O/r04_fuzz_optin.json 2> $O/r04_fuzz_optin.err; tail -c 1200 $O/r04_fuzz_optin.json ;;
 fuzz)
     timeout $(( ${2:-600} + 120 )) python tests/fuzz_dist.py --seconds ${2:-600} --min-world 5 --seed0 ${3:-4410} > $O/r04_fuzz_dist_seq_${3:-4410}.json 2> $O/r04_fuzz_dist_seq.err; tail -c 800 $O/r04_fuzz_dist_seq_${3:-4410}.json ;;
 *)
