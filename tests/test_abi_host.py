@@ -190,3 +190,15 @@ def test_every_abi_entry_is_documented_with_its_reference_counterpart():
     names = set(re.findall(r"\b(sl_[a-z0-9_]+)\s*\(", header))
     missing = sorted(n for n in names if n not in doc)
     assert not missing, missing
+
+
+def test_layout_stress_tool_builds_as_strict_c99_against_the_header(tmp_path):
+    """tools/layout_stress.c (the layout build alone under many-process contention) is a C99 program over the ABI: it must keep building"""
+    import subprocess
+    root = Path(__file__).resolve().parent.parent
+    pkg = root / "sublinear_time_solver_amd"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-O2", f"-I{root / 'include'}", str(root / "tools" / "layout_stress.c"), "-o",
+                        str(tmp_path / "layout_stress"), f"-L{pkg}", "-lsublinear_hip", "-lm", f"-Wl,-rpath,{pkg}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(tmp_path / "layout_stress")], capture_output=True, text=True)       # no arguments: the usage line, exit status 2
+    assert r.returncode == 2 and "usage" in r.stderr
