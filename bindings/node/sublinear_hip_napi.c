@@ -443,6 +443,10 @@ static napi_value Init(napi_env env, napi_value exports)
         {"cgSolve", NULL, CgSolve, NULL, NULL, NULL, napi_default, NULL},
         {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
     };
+    if (sl_abi_version() != SL_ABI_VERSION) {       /* a stale libsublinear_hip.so: refuse at load, not at the first missing symbol */
+        napi_throw_error(env, NULL, "libsublinear_hip.so ABI version differs from the header this addon was built against");
+        return NULL;
+    }
     if (napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props) != napi_ok) return NULL;
     return exports;
 }

@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define SL_ABI_VERSION 2
+/* 3 (round 5): + sl_spmv_add, sl_matrix_diagonal_dominance_factor, sl_matrix_spectral_radius_estimate, and the round-4 additions
+ * (sl_neumann_state_current_term / _solution_rows, sl_backward_push_acl_with_source / _reachability, sl_acl_extrapolated_solution):
+ * a library that lacks any of them answers 2 and is refused by the bindings before a symbol lookup can fail. */
+#define SL_ABI_VERSION 3
 
 /* ---- status codes: 1:1 with SolverError variants (src/error.rs:16-140) ---------- */
 typedef enum {
@@ -138,6 +141,13 @@ sl_status sl_matrix_download_csr(const sl_matrix *m, uint32_t *row_ptr, uint32_t
 
 /* a6: SparseMatrix::is_diagonally_dominant (matrix/mod.rs:467-485), weak ROW dominance */
 sl_status sl_matrix_is_diagonally_dominant(const sl_matrix *m, int *is_dd);
+/* Matrix::diagonal_dominance_factor (matrix/mod.rs:487-514): min over the rows that have off-diagonal weight of |a_ii| / sum_j |a_ij|
+ * (per row exactly as a6: last diagonal entry seen, |.| summed left to right).  *has_factor = 0 is the reference's None (no row has
+ * off-diagonal entries, or the minimum is not finite), then *factor = 0.  The minimum of exactly computed row ratios: bit-exact. */
+sl_status sl_matrix_diagonal_dominance_factor(const sl_matrix *m, int *has_factor, double *factor);
+/* Matrix::spectral_radius_estimate (matrix/mod.rs:83-100): Gershgorin, max over rows of |a_ii| + sum_j |a_ij|; bit-exact.
+ * With the two calls above it fills ConditioningInfo (matrix/mod.rs:548-556). */
+sl_status sl_matrix_spectral_radius_estimate(const sl_matrix *m, double *radius);
 /* a7 (first half): D^-1 with the reference's rejection rules (neumann.rs:172-188):
  * missing diagonal or |d| < 1e-14 -> SL_INVALID_SPARSE_MATRIX.  dinv: n_rows doubles. */
 sl_status sl_matrix_diagonal_inverse(const sl_matrix *m, double *dinv, sl_mem where);
@@ -145,6 +155,11 @@ sl_status sl_matrix_diagonal_inverse(const sl_matrix *m, double *dinv, sl_mem wh
 /* ---- a2 / a3 / a5: primitives ----------------------------------------------------
  * y = A x — Matrix::multiply_vector (matrix/mod.rs:415-439) in either summation order. */
 sl_status sl_spmv(const sl_matrix *m, const double *x, double *y, sl_order order, sl_mem where);
+/* y += A x — Matrix::multiply_vector_add (matrix/mod.rs:47, 441-465) over CSRStorage::multiply_vector_add (sparse.rs:192-203): the
+ * running sum of row i starts from y_i, (y_i + a_0 x_0) + a_1 x_1 + ..., so the bits differ from sl_spmv followed by an add.
+ * SL_ORDER_CSR_SEQUENTIAL (SL_ORDER_ANY runs the same order); SL_ORDER_SIMD4: SL_INVALID_INPUT — simd_ops.rs has no accumulating
+ * form.  x (n_cols) and y (n_rows) must not alias. */
+sl_status sl_spmv_add(const sl_matrix *m, const double *x, double *y, sl_order order, sl_mem where);
 /* simd_ops::dot_product_simd / axpy_simd (simd_ops.rs:116-189), solver::utils::l2_norm
  * (solver/mod.rs:369-371).  Device reductions use a fixed tree: run-to-run
  * deterministic, equal to the sequential CPU sum to rounding (not bitwise). */
@@ -202,7 +217,9 @@ typedef struct {
     uint64_t matvec_count;   /* SolverStats.matvec_count */
     double residual_norm;    /* SolverResult.residual_norm */
     double last_term_norm;
-    double error_bound;      /* ErrorBounds::upper_bound_only, < 0 when not computed */
+    double error_bound;      /* ErrorBounds::upper_bound_only of estimate_error_bounds (neumann.rs:321-347): needs compute_error_bounds and a
+                                converged series; < 0 = the reference's None (also when the norm estimate is >= 1 or NaN).  One term
+                                computed gives 0.0 as in the reference; est^terms is f64::powi's square-and-multiply. */
     double total_time_ms;    /* SolverStats.total_time_ms (host wall) */
     double device_time_ms;   /* HIP-event time of the iteration loop */
     uint64_t bytes_moved;    /* algorithmic HBM bytes of the loop */

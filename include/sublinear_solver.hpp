@@ -6,7 +6,9 @@
 //   reference                                         here
 //   SparseMatrix::from_triplets  matrix/mod.rs:160    sublinear::SparseMatrix::from_triplets
 //   Matrix::{rows,cols,nnz,is_diagonally_dominant,
-//            multiply_vector}    matrix/mod.rs:25-104 same names
+//            multiply_vector,multiply_vector_add,
+//            diagonal_dominance_factor,
+//            spectral_radius_estimate} matrix/mod.rs:25-104 same names
 //   SolverOptions (+presets)     solver/mod.rs:20-116 sublinear::SolverOptions
 //   SolverResult / SolverStats   solver/mod.rs:118-195, types.rs:88-109
 //   NeumannSolver::{new,default,high_precision,fast,solve}  solver/neumann.rs:24-92,469-555
@@ -111,6 +113,21 @@ public:
         if (result.size() != rows_) throw SolverError(SL_DIMENSION_MISMATCH, "matrix_vector_multiply: result");
         check(sl_spmv(h_, x.data(), result.data(), order, SL_MEM_HOST));
     }
+    // Matrix::multiply_vector_add (matrix/mod.rs:441-465): result += A x, the running sum of row i seeded with result[i] (sparse.rs:192-203)
+    void multiply_vector_add(const std::vector<Precision> &x, std::vector<Precision> &result) const
+    {
+        if (x.size() != cols_) throw SolverError(SL_DIMENSION_MISMATCH, "matrix_vector_multiply_add: x");
+        if (result.size() != rows_) throw SolverError(SL_DIMENSION_MISMATCH, "matrix_vector_multiply_add: result");
+        check(sl_spmv_add(h_, x.data(), result.data(), SL_ORDER_CSR_SEQUENTIAL, SL_MEM_HOST));
+    }
+    // Matrix::diagonal_dominance_factor (matrix/mod.rs:487-514) / spectral_radius_estimate (:83-100)
+    std::optional<Precision> diagonal_dominance_factor() const
+    {
+        int has = 0; double f = 0.0;
+        check(sl_matrix_diagonal_dominance_factor(h_, &has, &f));
+        return has ? std::optional<Precision>(f) : std::nullopt;
+    }
+    Precision spectral_radius_estimate() const { double r = 0.0; check(sl_matrix_spectral_radius_estimate(h_, &r)); return r; }
     const sl_matrix *handle() const { return h_; }
 
 private:

@@ -49,6 +49,9 @@ static int one_system(uint64_t n, uint64_t seed, int hubs)
     orc_spmv_csr_sequential(n, rp, ci, va, x, y);
     orc_spmv_simd4(n, rp, ci, va, x, z);
     for (int t = 0; t <= 5; t += 5) { orc_spmv_parallel(n, rp, ci, va, x, z, t); CHECK(n == 0 || memcmp(y, z, n * sizeof *y) == 0); }
+    orc_spmv_add_csr_sequential(n, rp, ci, va, x, z);                      /* z = y + A x, the seeded chain */
+    { double f = -1.0; int has = orc_diagonal_dominance_factor(n, rp, ci, va, &f); CHECK(!has || f >= 1.0); }
+    CHECK(orc_spectral_radius_estimate(n, rp, ci, va) >= 0.0 && orc_powi(0.5, 3) == 0.125);
     (void)orc_dot_simd4(n, x, y); (void)orc_dot_sequential(n, x, y); orc_axpy(n, 0.5, x, y);
     (void)orc_l2_norm(n, y); (void)orc_l1_norm(n, y); (void)orc_linf_norm(n, y);
 
@@ -67,6 +70,7 @@ static int one_system(uint64_t n, uint64_t seed, int hubs)
             st = orc_neumann_solve(n, n, rp, ci, va, n, b, x, &o, y, term, NULL, &res);
             CHECK(st == ORC_OK || st == ORC_CONVERGENCE_FAILURE);
         }
+    { double eb = -1.0; (void)orc_neumann_error_bound(n, term, rhs, 7, 1, &eb); (void)orc_neumann_error_bound(n, term, rhs, 1, 1, &eb); CHECK(eb == 0.0); }
     for (uint64_t i = 0; i < n; ++i) { x[i] = 0.0; y[i] = rhs[i]; }
     (void)orc_neumann_steps(n, rp, ci, va, dinv, y, x, z, 3, 0, 2);
 

@@ -77,6 +77,8 @@ def lib(fast: bool = False) -> C.CDLL:
         l.orc_l2_norm.restype = f64
         l.orc_l1_norm.restype = f64
         l.orc_linf_norm.restype = f64
+        l.orc_spectral_radius_estimate.restype = f64
+        l.orc_powi.restype = f64
         _libs[key] = l
     return _libs[key]
 
@@ -136,6 +138,14 @@ def spmv(rp, ci, va, x, order=ORDER_SEQ, threads=1, fast=False):
     return y
 
 
+def spmv_add(rp, ci, va, x, y):
+    """CSRStorage::multiply_vector_add (sparse.rs:192-203): returns y + A x with the running sum seeded by y_i"""
+    rp, ci, va, x = _u32(rp), _u32(ci), _f(va), _f(x)
+    y = _f(y).copy()
+    lib().orc_spmv_add_csr_sequential(u64(rp.size - 1), _p(rp), _p(ci), _p(va), _p(x), _p(y))
+    return y
+
+
 def dot_simd4(x, y):
     x, y = _f(x), _f(y)
     return lib().orc_dot_simd4(u64(x.size), _p(x), _p(y))
@@ -173,6 +183,31 @@ def is_diagonally_dominant(rp, ci, va):
     return bool(lib().orc_is_diagonally_dominant(u64(rp.size - 1), _p(rp), _p(ci), _p(va)))
 
 
+def diagonal_dominance_factor(rp, ci, va):
+    """Matrix::diagonal_dominance_factor (matrix/mod.rs:487-514): the factor, or None"""
+    rp, ci, va = _u32(rp), _u32(ci), _f(va)
+    out = f64(0)
+    ok = lib().orc_diagonal_dominance_factor(u64(rp.size - 1), _p(rp), _p(ci), _p(va), C.byref(out))
+    return out.value if ok else None
+
+
+def spectral_radius_estimate(rp, ci, va):
+    rp, ci, va = _u32(rp), _u32(ci), _f(va)
+    return lib().orc_spectral_radius_estimate(u64(rp.size - 1), _p(rp), _p(ci), _p(va))
+
+
+def powi(a, b):
+    return lib().orc_powi(f64(a), C.c_int(b))
+
+
+def neumann_error_bound(term, rhs, terms_computed, series_converged):
+    """NeumannState::estimate_error_bounds (neumann.rs:321-347) on a final state: the upper bound, or None"""
+    term, rhs = _f(term), _f(rhs)
+    out = f64(0)
+    ok = lib().orc_neumann_error_bound(u64(rhs.size), _p(term), _p(rhs), u64(terms_computed), C.c_int(int(series_converged)), C.byref(out))
+    return out.value if ok else None
+
+
 def neumann_init(rp, ci, va, b, cols=None):
     rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
     rows = rp.size - 1
@@ -208,6 +243,8 @@ def neumann_solve(rp, ci, va, b, *, tolerance=1e-6, max_iterations=1000, max_ter
            "series_converged": bool(res.series_converged)}
     if st and raise_on_error and st != 3:
         raise OracleError(st)
+    if st == 0:         # SolverResult.error_bounds = state.error_bounds() (neumann.rs:549-551) — Ok results only
+        out["error_bound"] = neumann_error_bound(term, neumann_init(rp, ci, va, b, cols)[1], res.terms_computed, res.series_converged)
     return out
 
 

@@ -104,6 +104,22 @@ void orc_spmv_csr_sequential(uint64_t rows, const uint32_t *row_ptr, const uint3
     }
 }
 
+/* CSRStorage::multiply_vector_add (sparse.rs:192-203; trait method matrix/mod.rs:47, dispatch :441-465):
+ * `*row_sum += values[i] * x[col]` directly into result[row] — the running sum STARTS FROM y_i, so the
+ * rounding differs from multiply_vector followed by an add. */
+void orc_spmv_add_csr_sequential(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
+                                 const double *values, const double *x, double *y)
+{
+    for (uint64_t i = 0; i < rows; ++i) {
+        double s = y[i];
+        for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+            double p = values[k] * x[col_idx[k]];
+            s = s + p;
+        }
+        y[i] = s;
+    }
+}
+
 /* simd_ops::matrix_vector_multiply_simd with feature "simd" (simd_ops.rs:20-88):
  * rows with nnz >= 8 use four lane accumulators over chunks of 4 (wide::f64x4 mul
  * then add, lane-wise IEEE), horizontal ((l0+l1)+l2)+l3, tail sequential;
@@ -286,6 +302,81 @@ int orc_is_diagonally_dominant(uint64_t rows, const uint32_t *row_ptr, const uin
         if (diag < off) return 0;
     }
     return 1;
+}
+
+/* Matrix::diagonal_dominance_factor (matrix/mod.rs:487-514): min over rows WITH off-diagonal weight of
+ * |a_ii| / sum |a_ij|; f64::min ignores a NaN operand; returns 1 and *factor when the minimum is finite
+ * (Some), 0 for None (no row has off-diagonal entries, or every ratio was +inf / NaN). */
+int orc_diagonal_dominance_factor(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
+                                  const double *values, double *factor)
+{
+    double min_factor = INFINITY;
+    for (uint64_t i = 0; i < rows; ++i) {
+        double diag = 0.0, off = 0.0;
+        for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+            if ((uint64_t)col_idx[k] == i) diag = fabs(values[k]);
+            else off = off + fabs(values[k]);
+        }
+        if (off > 0.0) {
+            double f = diag / off;
+            if (!(f != f) && f < min_factor) min_factor = f;          /* f64::min: a NaN operand loses */
+        }
+    }
+    if (isfinite(min_factor)) { *factor = min_factor; return 1; }
+    return 0;
+}
+
+/* Matrix::spectral_radius_estimate (matrix/mod.rs:83-100), Gershgorin: max over rows of |a_ii| + sum |a_ij|,
+ * folded with f64::max from 0.0 (a NaN row sum loses). */
+double orc_spectral_radius_estimate(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values)
+{
+    double max_radius = 0.0;
+    for (uint64_t i = 0; i < rows; ++i) {
+        double diag = 0.0, off = 0.0;
+        for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+            if ((uint64_t)col_idx[k] == i) diag = fabs(values[k]);
+            else off = off + fabs(values[k]);
+        }
+        double r = diag + off;
+        if (!(r != r) && r > max_radius) max_radius = r;
+    }
+    return max_radius;
+}
+
+/* f64::powi (neumann.rs:336): rustc lowers it to llvm.powi.f64, which for a run-time exponent calls compiler-rt's
+ * __powidf2 — square and multiply, NOT libm pow (third-party arithmetic outside /root/reference: LLVM compiler-rt
+ * lib/builtins/powidf2.c, unchanged across the LLVM versions rustc 1.7x ships; restated from its published algorithm). */
+double orc_powi(double a, int b)
+{
+    const int recip = b < 0;
+    double r = 1.0;
+    while (1) {
+        if (b & 1) r = r * a;
+        b /= 2;
+        if (b == 0) break;
+        a = a * a;
+    }
+    return recip ? 1.0 / r : r;
+}
+
+/* NeumannState::estimate_error_bounds (neumann.rs:321-347) on the state a solve ends in: returns 1 and *bound for
+ * Some(ErrorBounds::upper_bound_only(bound)), 0 when the state keeps error_bounds = None.
+ * terms_computed == 1 leaves matrix_norm_estimate = 0.0 => Some(0^1 / (1 - 0) * ||rhs||) = Some(0.0). */
+int orc_neumann_error_bound(uint64_t n, const double *current_term, const double *rhs, uint64_t terms_computed,
+                            int series_converged, double *bound)
+{
+    if (!series_converged || terms_computed == 0) return 0;                          /* :322-324 */
+    double est = 0.0;
+    if (terms_computed > 1) {                                                        /* :328-332 */
+        double ratio = orc_l2_norm(n, current_term) / orc_l2_norm(n, rhs);
+        est = pow(ratio, 1.0 / (double)(terms_computed - 1));
+    }
+    if (est < 1.0) {                                                                 /* :334-344 */
+        double remaining = orc_powi(est, (int)terms_computed) / (1.0 - est);
+        *bound = remaining * orc_l2_norm(n, rhs);
+        return 1;
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------- a7..a11 -- */

@@ -86,6 +86,10 @@ void orc_spmv_simd4(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_
 void orc_spmv_parallel(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
                        const double *values, const double *x, double *y, int threads);
 
+/* CSRStorage::multiply_vector_add, sparse.rs:192-203 (y += A x, the running sum seeded with y_i) */
+void orc_spmv_add_csr_sequential(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
+                                 const double *values, const double *x, double *y);
+
 /* ---- a5: vector primitives ---- */
 double orc_dot_simd4(uint64_t n, const double *x, const double *y);
 double orc_dot_sequential(uint64_t n, const double *x, const double *y);
@@ -97,6 +101,17 @@ double orc_linf_norm(uint64_t n, const double *v);
 /* ---- a6: diagonal dominance (matrix/mod.rs:467-485) ---- */
 int orc_is_diagonally_dominant(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
                                const double *values);
+
+/* Matrix::diagonal_dominance_factor (matrix/mod.rs:487-514): 1 + *factor for Some, 0 for None */
+int orc_diagonal_dominance_factor(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx,
+                                  const double *values, double *factor);
+/* Matrix::spectral_radius_estimate (matrix/mod.rs:83-100) */
+double orc_spectral_radius_estimate(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values);
+/* f64::powi as rustc emits it (compiler-rt __powidf2: square and multiply) */
+double orc_powi(double a, int b);
+/* NeumannState::estimate_error_bounds (neumann.rs:321-347): 1 + *bound for Some, 0 for None */
+int orc_neumann_error_bound(uint64_t n, const double *current_term, const double *rhs, uint64_t terms_computed,
+                            int series_converged, double *bound);
 
 /* ---- a7..a11: NeumannState::new + NeumannSolver::solve ---- */
 int orc_neumann_init(uint64_t rows, uint64_t cols, const uint32_t *row_ptr, const uint32_t *col_idx,

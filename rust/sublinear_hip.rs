@@ -41,6 +41,12 @@ extern "C" {
     fn sl_matrix_create_from_triplets(n: u64, rows: *const u64, cols: *const u64, vals: *const f64,
                                       n_rows: u64, n_cols: u64, flags: u32, out: *mut *mut SlMatrix) -> c_int;
     fn sl_matrix_destroy(m: *mut SlMatrix);
+    // the device-served half of `trait Matrix` (matrix/mod.rs:25-104)
+    fn sl_spmv(m: *const SlMatrix, x: *const f64, y: *mut f64, order: c_int, mem: c_int) -> c_int;
+    fn sl_spmv_add(m: *const SlMatrix, x: *const f64, y: *mut f64, order: c_int, mem: c_int) -> c_int;
+    fn sl_matrix_is_diagonally_dominant(m: *const SlMatrix, is_dd: *mut c_int) -> c_int;
+    fn sl_matrix_diagonal_dominance_factor(m: *const SlMatrix, has_factor: *mut c_int, factor: *mut f64) -> c_int;
+    fn sl_matrix_spectral_radius_estimate(m: *const SlMatrix, radius: *mut f64) -> c_int;
     fn sl_neumann_options_default(o: *mut SlNeumannOptions);
     fn sl_neumann_solve(m: *const SlMatrix, b: *const f64, initial_guess: *const f64,
                         opts: *const SlNeumannOptions, x_out: *mut f64, term_norms: *mut f64,
@@ -88,6 +94,45 @@ impl HipMatrix {
         Ok(Self { handle: h, key: Self::key_of(matrix) })
     }
 }
+/// The methods of `trait Matrix` (matrix/mod.rs:25-104) that are arithmetic over the stored entries, served from the device copy with the
+/// reference's rounding: multiply_vector (:415-439), multiply_vector_add (:441-465, running sums seeded with `result`, sparse.rs:192-203),
+/// is_diagonally_dominant (:467-485), diagonal_dominance_factor (:487-514), spectral_radius_estimate (:83-100), conditioning_info (:548-556).
+/// (`get` / `row_iter` / `col_iter` stay with the host matrix the device copy was made from.)
+impl HipMatrix {
+    fn dims(&self) -> (usize, usize) { (self.key.1, self.key.2) }
+    pub fn multiply_vector(&self, x: &[Precision], result: &mut [Precision]) -> Result<()> {
+        let (rows, cols) = self.dims();
+        if x.len() != cols { return Err(SolverError::DimensionMismatch { expected: cols, actual: x.len(), operation: "matrix_vector_multiply".into() }); }
+        if result.len() != rows { return Err(SolverError::DimensionMismatch { expected: rows, actual: result.len(), operation: "matrix_vector_multiply".into() }); }
+        let st = unsafe { sl_spmv(self.handle, x.as_ptr(), result.as_mut_ptr(), 0 /* SL_ORDER_CSR_SEQUENTIAL */, 0 /* SL_MEM_HOST */) };
+        if st != 0 { Err(to_error(st, 0, f64::INFINITY, 0.0)) } else { Ok(()) }
+    }
+    pub fn multiply_vector_add(&self, x: &[Precision], result: &mut [Precision]) -> Result<()> {
+        let (rows, cols) = self.dims();
+        if x.len() != cols { return Err(SolverError::DimensionMismatch { expected: cols, actual: x.len(), operation: "matrix_vector_multiply_add".into() }); }
+        if result.len() != rows { return Err(SolverError::DimensionMismatch { expected: rows, actual: result.len(), operation: "matrix_vector_multiply_add".into() }); }
+        let st = unsafe { sl_spmv_add(self.handle, x.as_ptr(), result.as_mut_ptr(), 0 /* SL_ORDER_CSR_SEQUENTIAL */, 0 /* SL_MEM_HOST */) };
+        if st != 0 { Err(to_error(st, 0, f64::INFINITY, 0.0)) } else { Ok(()) }
+    }
+    pub fn is_diagonally_dominant(&self) -> bool {
+        let mut f: c_int = 0;
+        unsafe { sl_matrix_is_diagonally_dominant(self.handle, &mut f) == 0 && f != 0 }
+    }
+    pub fn diagonal_dominance_factor(&self) -> Option<Precision> {
+        let (mut has, mut f): (c_int, f64) = (0, 0.0);
+        if unsafe { sl_matrix_diagonal_dominance_factor(self.handle, &mut has, &mut f) } == 0 && has != 0 { Some(f) } else { None }
+    }
+    pub fn spectral_radius_estimate(&self) -> Precision {
+        let mut r = 0.0;
+        unsafe { sl_matrix_spectral_radius_estimate(self.handle, &mut r) };
+        r
+    }
+    pub fn conditioning_info(&self) -> crate::matrix::ConditioningInfo {
+        crate::matrix::ConditioningInfo { condition_number: None, is_diagonally_dominant: self.is_diagonally_dominant(),
+                                          diagonal_dominance_factor: self.diagonal_dominance_factor(),
+                                          spectral_radius: Some(self.spectral_radius_estimate()), is_positive_definite: None }
+    }
+}
 impl Drop for HipMatrix { fn drop(&mut self) { unsafe { sl_matrix_destroy(self.handle) } } }
 
 /// Same constructor surface as NeumannSolver (neumann.rs:48-92).  The solver caches the device matrix of the last system it saw.
@@ -120,7 +165,10 @@ impl Drop for HipState { fn drop(&mut self) { unsafe { sl_neumann_state_destroy(
 impl SolverState for HipState {
     fn residual_norm(&self) -> Precision { if self.last.iterations == 0 && self.last.matvec_count == 0 { Precision::INFINITY } else { self.last.residual_norm } }
     fn matvec_count(&self) -> usize { self.last.matvec_count as usize }
-    fn error_bounds(&self) -> Option<ErrorBounds> { None }
+    /// estimate_error_bounds (neumann.rs:321-347) of the state the last run ended in; the ABI reports None as a negative bound
+    fn error_bounds(&self) -> Option<ErrorBounds> {
+        if self.last.error_bound >= 0.0 { Some(ErrorBounds::upper_bound_only(self.last.error_bound, crate::types::ErrorBoundMethod::NeumannTruncation)) } else { None }
+    }
     fn memory_usage(&self) -> MemoryInfo { MemoryInfo::default() }
     fn reset(&mut self) { unsafe { sl_neumann_state_reset(self.raw) }; self.last = SlNeumannResult::default(); }     // neumann.rs:367-378
 }
@@ -180,6 +228,9 @@ impl SolverAlgorithm for HipNeumannSolver {
             let mut s = crate::types::SolverStats::new();
             s.total_time_ms = res.total_time_ms; s.matvec_count = res.matvec_count as usize;
             out.stats = Some(s);
+        }
+        if options.compute_error_bounds && res.error_bound >= 0.0 {      // neumann.rs:549-551
+            out.error_bounds = Some(ErrorBounds::upper_bound_only(res.error_bound, crate::types::ErrorBoundMethod::NeumannTruncation));
         }
         Ok(out)
     }

@@ -97,6 +97,8 @@ class CgResult(C.Structure):
                 ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
 
 
+ABI_VERSION = 3      # SL_ABI_VERSION of include/sublinear_hip.h
+
 # every symbol include/sublinear_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "sl_abi_version": (C.c_int, []),
@@ -114,7 +116,10 @@ SIGNATURES = {
     "sl_matrix_download_csr": (C.c_int, [vp, vp, vp, vp]),
     "sl_matrix_is_diagonally_dominant": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "sl_matrix_diagonal_inverse": (C.c_int, [vp, vp, C.c_int]),
+    "sl_matrix_diagonal_dominance_factor": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(f64)]),
+    "sl_matrix_spectral_radius_estimate": (C.c_int, [vp, C.POINTER(f64)]),
     "sl_spmv": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+    "sl_spmv_add": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
     "sl_dot": (C.c_int, [u64, vp, vp, C.POINTER(f64), C.c_int]),
     "sl_axpy": (C.c_int, [u64, f64, vp, vp, C.c_int]),
     "sl_l2_norm": (C.c_int, [u64, vp, C.POINTER(f64), C.c_int]),
@@ -228,8 +233,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.sl_abi_version() != 2:
-        raise ImportError("libsublinear_hip ABI version mismatch")
+    if lib.sl_abi_version() != ABI_VERSION:
+        raise ImportError(f"libsublinear_hip ABI version {lib.sl_abi_version()}, this package binds {ABI_VERSION}: rebuild csrc/")
     _lib = lib
     return lib
 

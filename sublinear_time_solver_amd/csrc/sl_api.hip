@@ -285,6 +285,21 @@ sl_row_args sl_matrix_row_args(const sl_matrix *m)
     return a;
 }
 
+// f64::powi as rustc emits it for a run-time exponent (llvm.powi.f64 -> compiler-rt __powidf2): square and multiply, not libm pow —
+// its rounding sequence is part of estimate_error_bounds' result (neumann.rs:336)
+static double sl_powi(double a, int b)
+{
+    const bool recip = b < 0;
+    double r = 1.0;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0 / r : r;
+}
+
 // ---- library -----------------------------------------------------------------------------------
 extern "C" {
 
@@ -475,6 +490,25 @@ sl_status sl_matrix_is_diagonally_dominant(const sl_matrix *m, int *is_dd)
     return SL_OK;
 }
 
+sl_status sl_matrix_diagonal_dominance_factor(const sl_matrix *m, int *has_factor, double *factor)
+{
+    if (!m || !has_factor || !factor) return sl_fail(SL_INVALID_INPUT, "null argument");
+    double h[2];
+    SL_TRY(sl_matrix_cond_pass(m, h));
+    *has_factor = std::isfinite(h[0]) ? 1 : 0;                          // matrix/mod.rs:508-512: Some(min) only when finite
+    *factor = *has_factor ? h[0] : 0.0;
+    return SL_OK;
+}
+
+sl_status sl_matrix_spectral_radius_estimate(const sl_matrix *m, double *radius)
+{
+    if (!m || !radius) return sl_fail(SL_INVALID_INPUT, "null argument");
+    double h[2];
+    SL_TRY(sl_matrix_cond_pass(m, h));
+    *radius = h[1];
+    return SL_OK;
+}
+
 sl_status sl_matrix_diagonal_inverse(const sl_matrix *m, double *dinv, sl_mem where)
 {
     if (!m || !dinv) return sl_fail(SL_INVALID_INPUT, "null argument");
@@ -506,6 +540,32 @@ sl_status sl_spmv(const sl_matrix *m, const double *x, double *y, sl_order order
     a.gather = dx; a.out = dy;
     SL_TRY(sl_launch_rows(a, order, SL_EPI_SPMV, s));
     if (where == SL_MEM_HOST) SL_HIP(hipMemcpyAsync(y, dy, m->n_rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    return SL_OK;
+}
+
+// Matrix::multiply_vector_add (matrix/mod.rs:441-465) over CSRStorage::multiply_vector_add (sparse.rs:192-203): y += A x with the
+// running sum of row i STARTING FROM y_i — (y_i + a_0 x_0) + a_1 x_1 ..., every product rounded before it is added.
+sl_status sl_spmv_add(const sl_matrix *m, const double *x, double *y, sl_order order, sl_mem where)
+{
+    if (!m || !x || !y) return sl_fail(SL_INVALID_INPUT, "null argument");
+    if (order == SL_ORDER_SIMD4)
+        return sl_fail(SL_INVALID_INPUT, "multiply_vector_add exists in the CSR order only (sparse.rs:192-203); simd_ops.rs has no accumulating form");
+    if (x == y) return sl_fail(SL_INVALID_INPUT, "x and y must not alias");
+    hipStream_t s = sl_context().stream;
+    DevBuf xin, yio;
+    const double *dx;
+    SL_TRY(stage_in(x, m->n_cols, where, xin, &dx));
+    double *dy = y;
+    if (where == SL_MEM_HOST) {
+        SL_TRY(yio.alloc((m->n_rows ? m->n_rows : 1) * sizeof(double)));
+        dy = yio.as<double>();
+        if (m->n_rows) SL_HIP(hipMemcpyAsync(dy, y, m->n_rows * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    sl_row_args a = row_args(m);
+    a.gather = dx; a.out = dy;
+    SL_TRY(sl_launch_rows_add(a, s));
+    if (where == SL_MEM_HOST && m->n_rows) SL_HIP(hipMemcpyAsync(y, dy, m->n_rows * sizeof(double), hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
     return SL_OK;
 }
@@ -1007,13 +1067,13 @@ sl_status state_run(sl_neumann_state &st, double *term_norms, sl_neumann_result 
     }
     // estimate_error_bounds, neumann.rs:321-347
     if (D && status == SL_OK && sl_comm_failed(D->c)) status = sl_fail(SL_DEVICE_ERROR, "a rank of the communicator did not arrive within the time limit");
-    if (o->compute_error_bounds && series_conv && terms > 1 && status == SL_OK && !D) {      // (needs ||rhs|| over all ranks: not offered for partitions)
+    if (o->compute_error_bounds && series_conv && terms > 0 && status == SL_OK && !D) {      // (needs ||rhs|| over all ranks: not offered for partitions)
         double h;
         if (sl_launch_sumsq(n, rhs.as<double>(), scr, d_res, s) == SL_OK && read_scalars(d_res, &h, 1) == SL_OK) {
             const double rhs_norm = std::sqrt(h);
-            const double ratio = tn / rhs_norm;
-            const double est = std::pow(ratio, 1.0 / (double)(terms - 1));
-            if (est < 1.0) res->error_bound = std::pow(est, (double)(int)terms) / (1.0 - est) * rhs_norm;
+            double est = 0.0;                                                                // one term: the estimate stays 0.0 => Some(0.0), :327-332
+            if (terms > 1) est = std::pow(tn / rhs_norm, 1.0 / (double)(terms - 1));         // f64::powf
+            if (est < 1.0) res->error_bound = sl_powi(est, (int)terms) / (1.0 - est) * rhs_norm;   // :334-344 (a NaN estimate keeps None)
         }
     }
     res->iterations = it; res->terms_computed = terms; res->matvec_count = matvec;

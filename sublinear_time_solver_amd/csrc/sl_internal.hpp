@@ -382,6 +382,7 @@ sl_status sl_rows_geometry(const sl_row_args &a, sl_order order, sl_epilogue epi
 // the closing reduction of a launch made in ranges (n_partials as sl_launch_rows reports it for the whole launch)
 sl_status sl_launch_rows_reduce(const sl_row_args &a, sl_epilogue epi, uint32_t n_partials, hipStream_t s);
 sl_status sl_launch_final_reduce(const double *partials, uint32_t n, double *result, hipStream_t s);
+sl_status sl_launch_rows_add(const sl_row_args &a, hipStream_t s);   // a.out += A a.gather, running sums seeded with a.out (sparse.rs:192-203)
 sl_row_args sl_matrix_row_args(const sl_matrix *m);   // matrix part filled, vectors null
 uint32_t sl_row_grid(uint64_t n_slices);
 
@@ -402,6 +403,9 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
 // h_status[1..3] = first offending row of each class.  d_dinv may be null.
 void sl_matrix_row_dominance(const sl_matrix *m, uint64_t row, double out[2]);     // |a_ii|, sum |a_ij| of one row (error messages)
 sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long long h_status[4]);
+// ConditioningInfo's row statistics (matrix/mod.rs:487-514, 83-100): h_out[0] = min |a_ii| / sum |a_ij| over rows with off-diagonal
+// weight (+inf when there is none), h_out[1] = max |a_ii| + sum |a_ij|
+sl_status sl_matrix_cond_pass(const sl_matrix *m, double h_out[2]);
 // same rules over a plain CSR operator (used for A^T, which has no row-slice layout)
 sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx, const double *val, double *d_dinv,
                            unsigned long long h_status[4]);

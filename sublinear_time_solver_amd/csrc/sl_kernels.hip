@@ -34,12 +34,14 @@ __device__ __forceinline__ double wave_sum(double v)
 // from HBM/L2 (global variant) or from the LDS-staged window (band variant).
 // ORDER 0: sequential, 1: simd4 lanes.  UW > 0: every row has exactly UW entries (UW % 4 == 0):
 // no slice_ptr / row_len reads, fully unrolled, all loads issued before the dependent add chain.
+// `seed` = the value the running sum starts from: 0.0 everywhere except the accumulating product y += A x
+// (CSRStorage::multiply_vector_add, sparse.rs:192-203, which adds into result[row] itself; ORDER 0 only).
 template <int ORDER, int UW, class GATHER>
-__device__ __forceinline__ double sl_row_walk(const sl_row_args &a, uint64_t s, uint32_t lane, uint64_t i, GATHER gather)
+__device__ __forceinline__ double sl_row_walk(const sl_row_args &a, uint64_t s, uint32_t lane, uint64_t i, GATHER gather, double seed = 0.0)
 {
     const u32x4 *__restrict__ cq = reinterpret_cast<const u32x4 *>(a.cols);
     const f64x2 *__restrict__ vq = reinterpret_cast<const f64x2 *>(a.vals);
-    double sum = 0.0;
+    double sum = seed;
     if constexpr (UW > 0) {
         constexpr int NQ = UW / 4;
         const uint64_t qb = s * NQ;
@@ -206,6 +208,25 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32
     double part0 = 0.0, part1 = 0.0;
     if (live) sl_row_epilogue<EPI>(a, i, sum, e_t, e_d, e_x, dself, part0, part1);
     sl_block_partials<EPI>(a, red, lane, wave, lb, a.part_stride, part0, part1);
+}
+
+// y += A x, the running sum of row i seeded with y_i: CSRStorage::multiply_vector_add (sparse.rs:192-203; Matrix::multiply_vector_add,
+// matrix/mod.rs:441-465).  (y_i + p_0) + p_1 ... rounds differently from y_i + ((p_0 + p_1) + ...): a launch of its own over the
+// row-slice layout (every matrix carries it), whatever other layouts the matrix has; hub rows by sl_long_rows_kernel<0, SPMV, true>.
+__global__ __launch_bounds__(SL_BLOCK) void sl_rows_add_kernel(sl_row_args a, uint32_t nb8)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
+    const uint64_t s = (uint64_t)lb * SL_WAVES_PER_BLOCK + wave;
+    if (s >= a.n_slices) return;                                       // whole waves; no block barrier below
+    const uint64_t i = s * SL_SLICE + lane;
+    bool live = i < a.n_rows;
+    if (live && a.n_long && a.row_len[i] == SL_LONG_SENTINEL) live = false;
+    const double *__restrict__ g = a.gather;
+    const double seed = live ? a.out[i] : 0.0;
+    const double sum = sl_row_walk<0, 0>(a, s, lane, i, [g](uint32_t c) { return g[c]; }, seed);
+    if (live) a.out[i] = sum;
 }
 
 // ---- band kernel: gathers served by an LDS-staged window of the gathered vector -----------------
@@ -1166,7 +1187,7 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pwr_kernel(sl_row_args a)
 // or two batches of 64 entries, i.e. a chain of load latencies (row pointers -> entries -> gather -> 64 adds -> store) — what
 // counts is how many rows are in flight per CU (round 2: a 256-thread block per row took 1.27 ms per dense PageRank round, more
 // than the panel kernel beside it).  Longer rows keep the next batch's loads in flight under the add chain of the current one.
-template <int ORDER, int EPI>
+template <int ORDER, int EPI, bool SEED = false>
 __global__ __launch_bounds__(SL_BLOCK) void sl_long_rows_kernel(sl_row_args a, uint32_t slot0)
 {
     __shared__ double prod_lds[SL_BLOCK];
@@ -1187,6 +1208,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_long_rows_kernel(sl_row_args a, u
     }
     const uint32_t chunks4 = (ORDER == 1) ? ((len >> 2) << 2) : 0u;     // entries covered by full simd chunks (len >= 8 here)
     double sum = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+    if constexpr (SEED) sum = a.out[i];                                 // y += A x: the chain starts from y_i (sparse.rs:192-203)
     bool merged = false;
     // pipeline: entries (value, column) one batch ahead of their gather, the gather one batch ahead of the add chain
     uint32_t k = s + lane;
@@ -1684,6 +1706,18 @@ sl_status sl_launch_rows(const sl_row_args &a, sl_order order, sl_epilogue epi, 
     if (n_partials) *n_partials = nparts;
     if (a.blk_cnt) return SL_OK;                                        // a range: the caller closes with sl_launch_rows_reduce
     return sl_launch_rows_reduce(a, epi, nparts, s);
+}
+
+// y += A x in the CSR order with the running sums seeded by y (a.out = y in / out, a.gather = x)
+sl_status sl_launch_rows_add(const sl_row_args &a, hipStream_t s)
+{
+    if (a.n_slices == 0) return SL_OK;
+    const uint32_t grid = sl_row_grid(a.n_slices), nb8 = grid / 8;
+    hipLaunchKernelGGL(sl_rows_add_kernel, dim3(grid), dim3(SL_BLOCK), 0, s, a, nb8);
+    if (a.n_long)      // disjoint rows: order against the slice kernel does not matter, the same stream keeps it simple
+        hipLaunchKernelGGL((sl_long_rows_kernel<0, SL_EPI_SPMV, true>), dim3((a.n_long + SL_BLOCK / 64 - 1) / (SL_BLOCK / 64)), dim3(SL_BLOCK), 0, s, a, 0u);
+    SL_HIP(hipGetLastError());
+    return SL_OK;
 }
 
 sl_status sl_rows_geometry(const sl_row_args &a, sl_order order, sl_epilogue epi, uint32_t *rows_per_block, uint32_t *n_blocks)

@@ -3,6 +3,7 @@
 // One-off work per matrix (not in the per-iteration metric).
 #include "sl_internal.hpp"
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 // ---- validation ---------------------------------------------------------------------------
@@ -210,6 +211,55 @@ __global__ void sl_long_diag_kernel(uint32_t n_long, const uint32_t *long_rows, 
     if (!found) { atomicOr(&status[0], 2ull); atomicMin(&status[2], (unsigned long long)i); }
     else if (fabs(d) < 1e-14) { atomicOr(&status[0], 4ull); atomicMin(&status[3], (unsigned long long)i); }
     if (dinv) dinv[i] = (found && fabs(d) >= 1e-14) ? 1.0 / d : 0.0;
+}
+// ConditioningInfo's two row statistics (matrix/mod.rs:548-556) in one pass over the slice layout, per row in stored order as a6:
+//   factor = min over rows with off > 0 of |a_ii| / off      Matrix::diagonal_dominance_factor, matrix/mod.rs:487-514
+//   radius = max over rows of |a_ii| + off                    Matrix::spectral_radius_estimate (Gershgorin), matrix/mod.rs:83-100
+// Both are folds with f64::min / f64::max (a NaN operand loses) over values >= +0.0, whose IEEE bit patterns order like the numbers:
+// integer atomicMin / atomicMax on the bits give the same result whatever the order the rows arrive in — exact, not "to rounding".
+// out[0] starts as the bits of +inf, out[1] as the bits of 0.0.
+__device__ __forceinline__ void sl_cond_fold(double diag_abs, double off, unsigned long long *out)
+{
+    if (off > 0.0) {
+        const double f = diag_abs / off;
+        if (f == f) atomicMin(&out[0], (unsigned long long)__double_as_longlong(f));
+    }
+    const double r = __dadd_rn(diag_abs, off);
+    if (r == r) atomicMax(&out[1], (unsigned long long)__double_as_longlong(r));
+}
+__global__ __launch_bounds__(256) void sl_cond_kernel(uint64_t n_rows, uint64_t n_slices, uint64_t row_offset, const uint32_t *slice_ptr,
+                                                      const uint32_t *row_len, const uint32_t *cols, const double *vals, unsigned long long *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const uint64_t i = s * 64 + lane;
+    if (i >= n_rows) return;
+    const uint32_t len = row_len[i];
+    if (len == SL_LONG_SENTINEL) return;            // sl_long_cond_kernel
+    const uint32_t q0 = slice_ptr[s], q1 = slice_ptr[s + 1];
+    const uint32_t gi = (uint32_t)(row_offset + i);
+    double diag_abs = 0.0, off = 0.0;
+    for (uint32_t k = 0; k < len; ++k) {
+        const uint32_t c = cols[sl_col_slot(q0, q1, k, lane)];
+        const double v = vals[sl_val_slot(q0, k, lane)];
+        if (c == gi) diag_abs = fabs(v); else off = __dadd_rn(off, fabs(v));
+    }
+    sl_cond_fold(diag_abs, off, out);
+}
+__global__ void sl_long_cond_kernel(uint32_t n_long, const uint32_t *long_rows, uint64_t row_offset, const uint32_t *row_ptr,
+                                    const uint32_t *col_idx, const double *values, unsigned long long *out)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_long) return;
+    const uint32_t i = long_rows[t];
+    const uint32_t gi = (uint32_t)(row_offset + i);
+    double diag_abs = 0.0, off = 0.0;
+    for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+        const double v = values[k];
+        if (col_idx[k] == gi) diag_abs = fabs(v); else off = __dadd_rn(off, fabs(v));
+    }
+    sl_cond_fold(diag_abs, off, out);
 }
 __global__ void sl_long_collect_kernel(uint64_t n_rows, const uint32_t *row_len, uint32_t *list, uint32_t *count)
 {
@@ -1108,6 +1158,29 @@ sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long 
                            m->row_offset, m->d_row_ptr, m->d_col_idx, m->d_values, d_dinv, d_status);
     SL_HIP(hipMemcpyAsync(h_status, d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SL_HIP(hipStreamSynchronize(st));
+    return SL_OK;
+}
+
+// the conditioning pass: h_out[0] = diagonal dominance factor (+inf: no row has off-diagonal weight), h_out[1] = Gershgorin radius
+sl_status sl_matrix_cond_pass(const sl_matrix *m, double h_out[2])
+{
+    hipStream_t st = sl_context().stream;
+    DevBuf buf;
+    SL_TRY(buf.alloc(2 * sizeof(unsigned long long)));
+    unsigned long long *d_out = buf.as<unsigned long long>();
+    const unsigned long long init[2] = {0x7ff0000000000000ull, 0ull};
+    unsigned long long bits[2];
+    SL_HIP(hipMemcpyAsync(d_out, init, sizeof(init), hipMemcpyHostToDevice, st));
+    if (m->n_slices)
+        hipLaunchKernelGGL(sl_cond_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, m->n_rows, m->n_slices, m->row_offset,
+                           m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_out);
+    if (m->n_long)
+        hipLaunchKernelGGL(sl_long_cond_kernel, dim3((uint32_t)((m->n_long + 63) / 64)), dim3(64), 0, st, (uint32_t)m->n_long, m->d_long_rows,
+                           m->row_offset, m->d_row_ptr, m->d_col_idx, m->d_values, d_out);
+    SL_HIP(hipGetLastError());
+    SL_HIP(hipMemcpyAsync(bits, d_out, sizeof(bits), hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    memcpy(h_out, bits, sizeof(bits));
     return SL_OK;
 }
 

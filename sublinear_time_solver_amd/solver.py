@@ -157,6 +157,37 @@ class SparseMatrix:
         L.check(L.load().sl_spmv(self._h, L.ptr(x), L.ptr(y), order, L.SL_MEM_HOST))
         return y
 
+    def multiply_vector_add(self, x, result) -> np.ndarray:
+        """Matrix::multiply_vector_add, matrix/mod.rs:441-465: result += A x IN PLACE (a float64 numpy array), the running sum of row i
+        seeded with result[i] (sparse.rs:192-203); DimensionMismatch on bad lengths, as the reference checks x first, then result."""
+        x = _f64(x)
+        if x.size != self._cols:
+            raise SolverError(5, f"expected {self._cols}, actual {x.size} in matrix_vector_multiply_add")
+        if not (isinstance(result, np.ndarray) and result.dtype == np.float64 and result.flags.c_contiguous):
+            raise SolverError(4, "result must be a contiguous float64 numpy array (it is updated in place)")
+        if result.size != self._rows:
+            raise SolverError(5, f"expected {self._rows}, actual {result.size} in matrix_vector_multiply_add")
+        L.check(L.load().sl_spmv_add(self._h, L.ptr(x), L.ptr(result), L.SL_ORDER_CSR_SEQUENTIAL, L.SL_MEM_HOST))
+        return result
+
+    def diagonal_dominance_factor(self) -> Optional[float]:
+        """Matrix::diagonal_dominance_factor, matrix/mod.rs:487-514: min |a_ii| / sum |a_ij| over rows with off-diagonal weight, or None"""
+        has, f = C.c_int(0), C.c_double(0.0)
+        L.check(L.load().sl_matrix_diagonal_dominance_factor(self._h, C.byref(has), C.byref(f)))
+        return f.value if has.value else None
+
+    def spectral_radius_estimate(self) -> float:
+        """Matrix::spectral_radius_estimate, matrix/mod.rs:83-100 (Gershgorin)"""
+        r = C.c_double(0.0)
+        L.check(L.load().sl_matrix_spectral_radius_estimate(self._h, C.byref(r)))
+        return r.value
+
+    def conditioning_info(self) -> dict:
+        """Matrix::conditioning_info, matrix/mod.rs:548-556 (condition_number / is_positive_definite stay None there too)"""
+        return {"condition_number": None, "is_diagonally_dominant": self.is_diagonally_dominant(),
+                "diagonal_dominance_factor": self.diagonal_dominance_factor(), "spectral_radius": self.spectral_radius_estimate(),
+                "is_positive_definite": None}
+
     def to_csr(self):
         i = self.info()
         rp = np.empty(i.n_rows + 1, dtype=np.uint32)

@@ -18,11 +18,24 @@ int main()
     m.multiply_vector({1.0, 2.0}, y);
     EXPECT(y[0] == 4.0 && y[1] == 7.0);
     EXPECT(m.nnz() == 4 && m.is_diagonally_dominant());
+    // Matrix::multiply_vector_add (matrix/mod.rs:441-465): result += A x; dominance factor min(2/1, 3/1) and Gershgorin max(3, 4) (:487-514, :83-100)
+    std::vector<double> acc = {0.5, -1.0};
+    m.multiply_vector_add({1.0, 2.0}, acc);
+    EXPECT(acc[0] == 4.5 && acc[1] == 6.0);
+    EXPECT(m.diagonal_dominance_factor().has_value() && *m.diagonal_dominance_factor() == 2.0 && m.spectral_radius_estimate() == 4.0);
+    EXPECT(!SparseMatrix::from_triplets({{0, 0, 2.0}, {1, 1, 3.0}}, 2, 2).diagonal_dominance_factor().has_value());     // no off-diagonal weight: None
 
     // neumann.rs:572-590 (test_neumann_solver_simple): diagonally dominant 2x2
     auto a = SparseMatrix::from_triplets({{0, 0, 4.0}, {0, 1, 1.0}, {1, 0, 1.0}, {1, 1, 3.0}}, 2, 2, true);
     auto r = NeumannSolver(20, 1e-8).solve(a, {5.0, 4.0}, SolverOptions());
     EXPECT(r.converged && r.iterations == 16);
+    {   // estimate_error_bounds (neumann.rs:321-347): the series ends the solve => Some(bound); one term => Some(0.0)
+        SolverOptions eb; eb.tolerance = 1e-30; eb.compute_error_bounds = true;
+        auto e = NeumannSolver(20, 1e-8).solve(a, {5.0, 4.0}, eb);
+        EXPECT(e.iterations == 17 && e.error_bound.has_value() && std::fabs(*e.error_bound - 1.724974623182487e-09) < 1e-20);
+        auto one = NeumannSolver(20, 1e9).solve(a, {5.0, 4.0}, eb);
+        EXPECT(one.iterations == 1 && one.error_bound.has_value() && *one.error_bound == 0.0);
+    }
     EXPECT(std::fabs(r.solution[0] - 1.0) < 1e-7 && std::fabs(r.solution[1] - 1.0) < 1e-7);
     auto q = NeumannSolver(20, 1e-8).with_reference_quirks(true).solve(a, {5.0, 4.0});
     EXPECT(std::fabs(q.solution[0] - 2.25) < 1e-7);          // reference default start: x_true + D^-1 b
