@@ -86,9 +86,10 @@ def parse_asm(path: Path):
         body = bodies.get(k[".name"], "")
         ins = [ln.split()[0] for ln in body.split("\n") if ln.startswith("\t") and not ln.startswith("\t.") and not ln.strip().startswith(";")]
         vg, ag = int(k.get(".vgpr_count", 0)), int(k.get(".agpr_count", 0))
-        if not short_name(full).startswith("sl_"):      # rocPRIM's sort / scan kernels (sl_sort.hip, sl_matrix.hip): the library's, not ours
+        name = short_name(full.replace("(anonymous namespace)::", ""))
+        if "rocprim" in name or "hipcub" in name or name == "":      # rocPRIM's sort / scan kernels (sl_sort.hip, sl_matrix.hip, sl_acl.hip): the library's, not ours
             continue
-        res[short_name(full)] = {
+        res[name] = {
             "file": path.stem + ".hip",
             "vgpr": vg, "agpr": ag, "sgpr": int(k.get(".sgpr_count", 0)),
             "vgpr_spills": int(k.get(".vgpr_spill_count", 0)), "sgpr_spills": int(k.get(".sgpr_spill_count", 0)),
@@ -98,6 +99,7 @@ def parse_asm(path: Path):
             "waves_per_simd": waves_per_simd(vg, ag),
             "instructions": len(ins),
             "v_fma_f64": sum(1 for i in ins if i.startswith("v_fma_f64") or i.startswith("v_fmac_f64")),
+            "f64_divisions": sum(1 for i in ins if i.startswith("v_div_fixup_f64")),      # each IEEE division expands to 5 v_fma_f64 of its own
             "scratch_ops": sum(1 for i in ins if i.startswith("scratch_") or i.startswith("buffer_store") and "offen" in i),
             "lds_dma_loads": sum(1 for ln in body.split("\n") if re.search(r"\b(global|buffer)_load_(lds_)?dword.*\blds\b|global_load_lds", ln)),
         }
