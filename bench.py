@@ -193,7 +193,9 @@ def cpu_parity_gate(path):
 def parity_gate(args, lib, L, st, n_local, n_global, lo, w):
     """BEFORE the timed region: GATE_STEPS fused steps on the instance the bench is about to time, three blocks of GATE_BLOCK rows of the
     term and of the solution read back through the ABI, checked bit for bit by the CPU checker in a child process; the state is reset
-    afterwards (current_term = rhs), so the timed steps start where they always did."""
+    afterwards (SolverState::reset, neumann.rs:367-378: current_term = rhs, solution = 0, counters 0): the timed steps start from the
+    first term as they always did.  The solution then starts from 0 instead of the state's x0 — its VALUES do not enter the timing
+    (x is read and written once per step whatever it holds) and the gate has already compared them."""
     import subprocess
     import tempfile
     import numpy as np

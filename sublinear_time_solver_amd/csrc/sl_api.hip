@@ -103,7 +103,12 @@ static void *pinned_staging(size_t *cap)
     sl_ctx &c = sl_context();
     const size_t want = 4u << 20;
     if (!c.pinned) {
-        if (hipHostMalloc(&c.pinned, want, hipHostMallocDefault) != hipSuccess) { c.pinned = nullptr; return nullptr; }
+        if (c.pinned_failed) return nullptr;                         // asked once, refused: the pageable calls from here on, no retry per transfer
+        if (hipHostMalloc(&c.pinned, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();                                 // the fallback below works: do not leave this failure for the next SL_HIP(hipGetLastError()) to report
+            c.pinned = nullptr; c.pinned_failed = true;
+            return nullptr;
+        }
         c.pinned_bytes = want;
     }
     *cap = c.pinned_bytes;
@@ -134,6 +139,7 @@ sl_status sl_upload(void *dev_dst, const void *host_src, size_t bytes, hipStream
     void *pin = staging_pageable() ? nullptr : pinned_staging(&cap);
     if (!pin) {
         SL_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st));
+        SL_HIP(hipStreamSynchronize(st));                               // the contract of sl_upload: host_src is reusable and the data is on the device on return
         return SL_OK;
     }
     for (size_t off = 0; off < bytes; off += cap) {
@@ -207,6 +213,9 @@ void sl_ws_free(void *p)
 extern "C" void sl_release_workspace(void)
 {
     sl_ctx &c = sl_context();
+    // the thread's page-locked staging buffer goes with its workspace: a thread that built a matrix and calls this before it ends leaks nothing
+    if (c.pinned) { (void)hipHostFree(c.pinned); c.pinned = nullptr; c.pinned_bytes = 0; }
+    c.pinned_failed = false;
     for (size_t i = 0; i < c.ws.size();) {
         if (!c.ws[i].in_use) { hipFree(c.ws[i].p); c.ws.erase(c.ws.begin() + i); }
         else ++i;

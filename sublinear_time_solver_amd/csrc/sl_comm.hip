@@ -468,13 +468,53 @@ sl_status sl_dist_pull(sl_dist *d, sl_dist_vector *v, hipStream_t s)
 // every rank alike, with a status — the caller (bench.py's parent, a host's own retry) then takes the rccl transport.
 __global__ void sl_comm_pattern_kernel(unsigned long long *p, uint32_t words, unsigned long long seed)
 {
-    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) p[i] = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)i * 0xBF58476D1CE4E5B9ull;
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) p[i] = seed * 0x9E3779B97F4A7C15ull + (unsigned long long)i * 0xBF58476D1CE4E5B9ull;      // = SL_PAT_K1, SL_PAT_K2 below
 }
 __global__ void sl_comm_pattern_check_kernel(const unsigned long long *p, uint32_t words, unsigned long long seed, uint32_t *bad)
 {
     for (uint32_t i = threadIdx.x; i < words; i += blockDim.x)
         if (p[i] != seed * 0x9E3779B97F4A7C15ull + (unsigned long long)i * 0xBF58476D1CE4E5B9ull) atomicAdd(bad, 1u);
 }
+// What a wrong page IS ("wrong pages over IPC, unexplained").  The pattern is affine in the word index with an odd
+// multiplier of the seed, so the first word names the seed the page was written with: seed = w[0] * K1^-1 (mod 2^64), confirmed by the
+// next seven words.  seed - peer = the nonce of the job that wrote it.  One line says which of the four stories it is:
+//   zeros                         the owner's kernel had not written (or its write was not visible) when the copy ran: ORDERING
+//   this job's nonce, other rank  the handle of rank q was opened where rank p's was meant: a mix-up INSIDE the job's own exchange
+//   another nonce, any rank       a page of a DIFFERENT job (or of this process tree's earlier communicator) came back through the handle:
+//                                 the runtime resolved the IPC handle to someone else's allocation — not this library's rendezvous
+//   no seed fits                  neither: partially written / torn page (words listed)
+#define SL_PAT_K1 0x9E3779B97F4A7C15ull
+#define SL_PAT_K2 0xBF58476D1CE4E5B9ull
+static void comm_classify_page(const unsigned long long w[8], unsigned long long nonce, int world, int peer, char *out, size_t cap)
+{
+    bool zeros = true;
+    for (int i = 0; i < 8; ++i) zeros = zeros && w[i] == 0ull;
+    if (zeros) { snprintf(out, cap, "zeros: rank %d's page was not written (or not visible) when it was copied — ordering", peer); return; }
+    unsigned long long inv = SL_PAT_K1;                               // Newton: inverse of an odd number mod 2^64, 5 steps double the correct bits 3 -> 96
+    for (int i = 0; i < 5; ++i) inv *= 2ull - SL_PAT_K1 * inv;
+    const unsigned long long seed = w[0] * inv;
+    bool fits = true;
+    for (int i = 0; i < 8; ++i) fits = fits && w[i] == seed * SL_PAT_K1 + (unsigned long long)i * SL_PAT_K2;
+    if (!fits) {
+        snprintf(out, cap, "no rank's pattern: torn or foreign data, words %016llx %016llx %016llx %016llx (expected %016llx ...)", w[0], w[1], w[2], w[3],
+                 (nonce + (unsigned long long)peer) * SL_PAT_K1);
+        return;
+    }
+    if (seed >= nonce && seed < nonce + (unsigned long long)world) {
+        const int q = (int)(seed - nonce);
+        if (q == peer) snprintf(out, cap, "rank %d's own pattern in the first words: only part of the page is wrong (a torn copy)", peer);
+        else snprintf(out, cap, "the page of rank %d of THIS job (nonce %016llx) where rank %d's was meant: handle mix-up inside the job's exchange", q, nonce, peer);
+        return;
+    }
+    // a foreign nonce: which rank slot it would be under that job cannot be told apart from the nonce itself (seed = nonce' + rank'), report the seed
+    snprintf(out, cap, "the pattern of ANOTHER communicator (seed %016llx = its nonce + rank; this job's nonce %016llx): the runtime resolved rank %d's IPC handle to "
+             "a different job's (or an earlier communicator's) allocation", seed, nonce, peer);
+}
+#ifdef SL_DEBUG_HOOKS
+extern "C" void sl_hook_classify_ipc_page(const unsigned long long *w, unsigned long long nonce, int world, int peer, char *out, size_t cap) { comm_classify_page(w, nonce, world, peer, out, cap); }
+extern "C" void sl_hook_ipc_pattern(unsigned long long seed, uint32_t words, unsigned long long *out) { for (uint32_t i = 0; i < words; ++i) out[i] = seed * SL_PAT_K1 + (unsigned long long)i * SL_PAT_K2; }
+#endif
+
 static sl_status comm_ipc_selftest(sl_comm *c)
 {
     if (c->world < 2) return SL_OK;
@@ -487,27 +527,46 @@ static sl_status comm_ipc_selftest(sl_comm *c)
     uint32_t *d_bad = nullptr;
     const unsigned long long nonce = (unsigned long long)c->h_shm->generation;
     do {
-        if (sl_malloc(&d_bad, 4) != hipSuccess) { d_bad = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); break; }
-        if (hipMemsetAsync(d_bad, 0, 4, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "memset failed"); break; }
+        if (sl_malloc(&d_bad, SL_COMM_MAX_RANKS * 4) != hipSuccess) { d_bad = nullptr; mine = sl_fail(SL_ALLOCATION, "hipMalloc failed"); break; }      // one counter per peer
+        if (hipMemsetAsync(d_bad, 0, SL_COMM_MAX_RANKS * 4, s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "memset failed"); break; }
         hipLaunchKernelGGL(sl_comm_pattern_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<unsigned long long *>(v.mine) + (size_t)c->rank * WORDS, WORDS,
                            nonce + (unsigned long long)c->rank);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "self-test: pattern kernel failed"); break; }
     } while (0);
     sl_status st = sl_comm_agree(c, mine);               // every rank's page is written (and visible: the stream was drained)
     if (st == SL_OK) {
-        uint32_t bad = 0;
+        uint32_t bad[SL_COMM_MAX_RANKS] = {0};
         do {
             for (int p = 0; p < c->world && mine == SL_OK; ++p) {
                 if (p == c->rank) continue;
                 if (hipMemcpyAsync(v.mine + (size_t)p * WORDS, v.peer[p] + (size_t)p * WORDS, WORDS * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
                     { mine = sl_fail(SL_DEVICE_ERROR, "self-test: device copy from rank %d's mapped buffer failed", p); break; }
                 hipLaunchKernelGGL(sl_comm_pattern_check_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<const unsigned long long *>(v.mine) + (size_t)p * WORDS, WORDS,
-                                   nonce + (unsigned long long)p, d_bad);
+                                   nonce + (unsigned long long)p, d_bad + p);
             }
             if (mine != SL_OK) break;
-            if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "self-test: readback failed"); break; }
-            if (bad) mine = sl_fail(SL_DEVICE_ERROR, "self-test of the ipc transport: %u of %u words pulled from the peers differ from what they wrote (rank %d)", bad,
-                                    WORDS * (uint32_t)(c->world - 1), c->rank);
+            if (hipMemcpyAsync(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { mine = sl_fail(SL_DEVICE_ERROR, "self-test: readback failed"); break; }
+            // a wrong page names its cause: per peer, the first words of what arrived, and of a SECOND read of the same mapping (does it persist?)
+            std::string report;
+            for (int p = 0; p < c->world; ++p) {
+                if (p == c->rank || !bad[p]) continue;
+                unsigned long long first[8] = {0}, again[8] = {0};
+                char what[384], what2[384];
+                const bool got = hipMemcpy(first, v.mine + (size_t)p * WORDS, sizeof(first), hipMemcpyDeviceToHost) == hipSuccess
+                                 && hipMemcpy(again, v.peer[p] + (size_t)p * WORDS, sizeof(again), hipMemcpyDeviceToHost) == hipSuccess;
+                if (!got) { (void)hipGetLastError(); snprintf(what, sizeof(what), "(the words could not be read back)"); what2[0] = 0; }
+                else {
+                    comm_classify_page(first, nonce, c->world, p, what, sizeof(what));
+                    if (memcmp(first, again, sizeof(first)) == 0) snprintf(what2, sizeof(what2), "; a second read of the mapping returns the same words");
+                    else { char w2[384]; comm_classify_page(again, nonce, c->world, p, w2, sizeof(w2)); snprintf(what2, sizeof(what2), "; a second read of the mapping differs: %.300s", w2); }
+                }
+                char line[1024];
+                snprintf(line, sizeof(line), "%s rank %d's page: %u of %u words wrong — %s%s", report.empty() ? "" : " |", p, bad[p], WORDS, what, what2);
+                report += line;
+            }
+            if (!report.empty())
+                mine = sl_fail(SL_DEVICE_ERROR, "self-test of the ipc transport on rank %d of %d (rendezvous %s, job nonce %016llx, device %d):%s", c->rank, c->world,
+                               c->path.c_str(), nonce, c->device, report.c_str());
         } while (0);
         st = sl_comm_agree(c, mine);
     }
@@ -664,7 +723,16 @@ sl_status sl_comm_create(int rank, int world, const char *rendezvous, sl_comm **
                 // job's slots filled up by ranks of the new one: it will never confirm).  A live job's rank 0 removes the name
                 // and confirms microseconds later, so a name that changed hands is looked at once more before this block is given up
                 if (stat(c->path.c_str(), &cur) == 0 && cur.st_ino != ino) {
-                    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                    // ... for 2 ms — or, when every slot of this block is taken (it may well be the live job, its rank 0 descheduled between
+                    // unlink and confirm while another job republished the name: ADVICE r04), for up to 100 ms: leaving a barrier that has
+                    // already counted this rank would hang the others until the communicator's time limit
+                    bool all_in = true;
+                    for (int p = 0; p < world; ++p) all_in = all_in && ld_acq(&h->arrive[p]) != 0;
+                    const auto g0 = std::chrono::steady_clock::now();
+                    const double grace_ms = all_in ? 100.0 : 2.0;
+                    while (!(ld_acq(&h->confirmed) == gen && gen)
+                           && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g0).count() < grace_ms)
+                        std::this_thread::sleep_for(std::chrono::microseconds(200));
                     if (ld_acq(&h->confirmed) == gen && gen) { joined = true; break; }
                     stale = true;
                     break;

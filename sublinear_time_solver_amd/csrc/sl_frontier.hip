@@ -1359,9 +1359,11 @@ static sl_status wide_batch(sl_query_session *q, uint64_t count, const uint64_t 
         wd->slot.push_back(sub);
     }
     if (wd->h_io.size() < W) {
-        wd->h_io.resize(W); wd->h_aux.resize(W); wd->h_out.resize((size_t)W * SL_WIDE_OUT);
+        // device buffers first: were a later allocation to fail, the next call must come back here, not find the host vectors already
+        // sized and launch with a null io_dev / aux_dev / out_dev
         SL_TRY(wd->io_dev.alloc_owned(W * sizeof(sl_round_io))); SL_TRY(wd->aux_dev.alloc_owned(W * sizeof(sl_wide_aux)));
         SL_TRY(wd->out_dev.alloc_owned((size_t)W * SL_WIDE_OUT * 8));
+        wd->h_aux.resize(W); wd->h_out.resize((size_t)W * SL_WIDE_OUT); wd->h_io.resize(W);      // h_io last: its size is the "all of it is there" mark
     }
     static const int cfg_batch = [] { const char *e = getenv("SL_PUSH_BATCH"); const int v = e ? atoi(e) : 12; return v < 1 ? 1 : v; }();
     static const unsigned long long hit_div = [] { const char *e = getenv("SL_PUSH_HIT_DIV"); const unsigned long long v = e ? strtoull(e, nullptr, 10) : 64; return v ? v : 64ull; }();
@@ -1442,7 +1444,8 @@ static sl_status wide_batch(sl_query_session *q, uint64_t count, const uint64_t 
                 }
                 res->estimate = h[0]; res->residual_l1 = h[1];
                 res->rounds = o[0]; res->pushes = o[1]; res->rows_touched = o[2];
-                res->device_time_ms = ms; res->converged = o[4] == 0 ? 1 : 0;
+                res->device_time_ms = ms / (float)G;          // a group's launches serve its G queries at once: each carries its share (their sum = the device time spent)
+                res->converged = o[4] == 0 ? 1 : 0;
             } else {
                 // not finished inside the batch: clean the slot (everything the query touched is on its list), answer it the ordinary way
                 push_state &ps = wd->slot[j]->ps;

@@ -177,6 +177,7 @@ struct sl_ctx {
     // pinned staging of the control-plane transfers (sl_read_back / sl_upload): page-locked host memory of the library's own
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    bool pinned_failed = false;   // hipHostMalloc was refused once on this thread: pageable transfers, not a retry per call
     // side stream + fork / join events: the long-row kernel of a launch runs beside the slice kernel (sl_kernels.hip)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

@@ -1,0 +1,45 @@
+#!/bin/bash
+# First contact with a box that has N >= 2 GPUs: the first execution EVER of the library's RCCL transport with more
+# than one rank, and of the ipc transport across two physical devices.  Every stage has its own timeout and its own log under
+# gpurun_out/first_contact/; a stage that fails does not stop the later ones; the last line is a one-line verdict per stage.
+#   tools/first_contact.sh [N = number of visible GPUs] [rows per rank for the bench stage = 10000000]
+# Stages: (i) tests/c/dist_smoke.c (C99, one process per rank, every solution entry compared BIT FOR BIT with the one-GPU solve through the
+#             same ABI) at world N under SL_COMM_TRANSPORT=ipc, then rccl with SL_COMM_HALO=sendrecv (grouped ncclSend / ncclRecv) and
+#             =allreduce (one ncclAllReduce over the compact halo buffer: BASELINE north_star's wording), each on a neighbour-halo system,
+#             an all-over-the-matrix system (ncclAllGather) and an uneven three-way reach;
+#         (ii) python bench.py --gpus N (the line the driver's SCALE run asks for), once per transport.
+# One job at a time, N processes, nothing side by side.
+set -u
+cd "$(dirname "$0")/.."
+NDEV=$(python - <<'PY'
+import ctypes, sys
+sys.path.insert(0, ".")
+from sublinear_time_solver_amd import _lib
+n = ctypes.c_int(0); _lib.load().sl_device_count(ctypes.byref(n)); print(n.value)
+PY
+)
+N=${1:-$NDEV}; ROWS=${2:-10000000}
+O=gpurun_out/first_contact; mkdir -p $O; : > $O/verdict.txt
+echo "first contact: $NDEV devices visible, world $N" | tee -a $O/verdict.txt
+if [ "$NDEV" -lt 2 ] || [ "$N" -lt 2 ]; then echo "needs 2+ GPUs: nothing run" | tee -a $O/verdict.txt; exit 3; fi
+PKG=$PWD/sublinear_time_solver_amd
+gcc -std=c99 -pedantic -Wall -Iinclude tests/c/dist_smoke.c -o /tmp/dist_smoke_fc -L$PKG -lsublinear_hip -lm -Wl,-rpath,$PKG || { echo "dist_smoke did not build" | tee -a $O/verdict.txt; exit 1; }
+stage() {      # stage <name> <timeout> <command...>: log, exit status and the decisive lines into verdict.txt
+  local name=$1 tmo=$2; shift 2
+  timeout $tmo "$@" > $O/$name.log 2>&1; local rc=$?
+  printf '%-44s rc %3d  %s\n' "$name" $rc "$(grep -E 'dist_smoke ok|differ|"metric"' $O/$name.log | head -n 1 | cut -c1-220)" | tee -a $O/verdict.txt
+}
+for T in "ipc sendrecv" "rccl sendrecv" "rccl allreduce"; do
+  set -- $T; TR=$1; HALO=$2
+  export SL_LOG=1 SL_COMM_TRANSPORT=$TR SL_COMM_TIMEOUT_MS=60000
+  if [ "$HALO" = allreduce ]; then export SL_COMM_HALO=allreduce; else unset SL_COMM_HALO; fi
+  stage smoke_${TR}_${HALO}_halo      300 /tmp/dist_smoke_fc $N 400000 300
+  stage smoke_${TR}_${HALO}_allgather 300 /tmp/dist_smoke_fc $N 400000 1000000000
+  stage smoke_${TR}_${HALO}_uneven    300 /tmp/dist_smoke_fc $N 3000000 4096 uneven
+done
+unset SL_COMM_TRANSPORT SL_COMM_HALO SL_LOG
+for TR in ipc rccl; do
+  SL_BENCH_TRANSPORTS=$TR stage bench_${TR} 1500 python bench.py --gpus $N --rows $ROWS --steps 30 --warmup 5
+done
+echo "logs: $O/*.log"; cat $O/verdict.txt
+grep -c "rc   0" $O/verdict.txt
