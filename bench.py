@@ -684,7 +684,22 @@ def launcher(args, argv):
     return 1
 
 
+def refuse_emulator():
+    """bench.py measures an MI355X.  The SIMT emulator of tests/simt/ (the kernels as host fibers, test infrastructure for a container
+    without a GPU) exports `simt_counters`; a library that has it is not a device and nothing may be timed on it."""
+    path = os.environ.get("SUBLINEAR_HIP_LIB")
+    if not path:
+        return
+    try:
+        if hasattr(C.CDLL(path), "simt_counters"):
+            print(f"bench.py: {path} is the SIMT emulator (tests only): refusing to measure anything on it", file=sys.stderr, flush=True)
+            sys.exit(2)
+    except OSError:
+        pass
+
+
 def main():
+    refuse_emulator()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Build tests/simt/_build/libsublinear_hip_simt.so: the UNCHANGED sources of sublinear_time_solver_amd/csrc/*.hip compiled as host C++
+against the SIMT emulator (tests/simt/hip/hip_runtime.h + simt_rt.cpp).  TEST INFRASTRUCTURE — the product never loads this library.
+
+The sources are copied into the build directory with the handful of textual rewrites that a host compiler needs and that change no
+arithmetic and no control flow:
+  __builtin_amdgcn_X(...)                         -> simt_amdgcn_X(...)          (the emulator's versions of the gfx950 builtins)
+  __attribute__((address_space(N)))               -> removed                     (the casts of global_load_lds' pointer arguments)
+  extern __shared__ ... double NAME[];            -> double *NAME = the block's dynamic LDS window
+  asm volatile("s_waitcnt ..." ::: "memory")      -> a wave barrier              (where the wave waits for ITS memory operations on the hardware, the
+                                                                                  emulated lanes — which run one after the other — wait for each other: LDS written
+                                                                                  by one lane before the wait is read by another lane after it)
+  asm volatile("v_mov_b32 %0, 0" : "=v"(x))       -> x = 0
+  asm volatile("" : "+v"(a), ...)                 -> a compiler barrier          (scheduling hints for the real ISA)
+Compile flags carry -ffp-contract=off like the device build: a product is rounded before it is added."""
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+CSRC = ROOT / "sublinear_time_solver_amd" / "csrc"
+BUILD = HERE / "_build"
+CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g1", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing", "-pthread", "-Wno-unused-value",
+         "-Wno-unused-result", "-Wno-unknown-attributes", "-Wno-ignored-attributes", f"-I{HERE}", f"-I{BUILD}"]
+
+REWRITES = [
+    (re.compile(r"__builtin_amdgcn_"), "simt_amdgcn_"),
+    (re.compile(r"__attribute__\(\(address_space\(\d+\)\)\)\s*"), ""),
+    (re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s*)?(\w+)\s+(\w+)\[\];"), r"\1 *\2 = static_cast<\1 *>(::simt::block().dyn_lds);"),
+    (re.compile(r'asm volatile\("s_waitcnt[^"]*"\s*:::\s*"memory"\);'), 'simt_amdgcn_wave_barrier();'),
+    (re.compile(r'asm volatile\("v_mov_b32 %0, 0"\s*:\s*"=v"\((\w+)\)\);'), r"\1 = 0;"),
+    (re.compile(r'asm volatile\(""\s*:\s*"\+v"[^;]*\);'), 'asm volatile("" ::: "memory");'),
+]
+
+
+def rewrite(text: str) -> str:
+    for rx, rep in REWRITES:
+        text = rx.sub(rep, text)
+    return text
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def stale(out: Path) -> bool:
+    if not out.exists():
+        return True
+    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "sublinear_hip.h", HERE / "simt_rt.cpp", HERE / "hip" / "hip_runtime.h",
+                                                                    HERE / "rocprim" / "device" / "device_radix_sort.hpp", Path(__file__)]
+    return out.stat().st_mtime < max(d.stat().st_mtime for d in deps)
+
+
+def build(force: bool = False) -> Path:
+    out = BUILD / "libsublinear_hip_simt.so"
+    if not force and not stale(out):
+        return out
+    (BUILD / "csrc").mkdir(parents=True, exist_ok=True)
+    (BUILD / "include").mkdir(parents=True, exist_ok=True)
+    # mirror the tree so that "../../include/sublinear_hip.h" of sl_internal.hpp resolves: _build/pkg/csrc + _build/include
+    pkg = BUILD / "pkg" / "csrc"
+    pkg.mkdir(parents=True, exist_ok=True)
+    (BUILD / "include" / "sublinear_hip.h").write_text((ROOT / "include" / "sublinear_hip.h").read_text())
+    for f in list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")):
+        (pkg / f.name).write_text(rewrite(f.read_text()))
+    objs = []
+
+    def cc(src: Path):
+        obj = BUILD / (src.stem + ".o")
+        r = subprocess.run([CXX, *FLAGS, "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{src.name}:\n{r.stderr[-6000:]}")
+        return obj
+
+    todo = [pkg / s.name for s in sources()] + [HERE / "simt_rt.cpp"]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(cc, todo))
+    r = subprocess.run([CXX, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-o", str(out), *map(str, objs), "-ldl", "-lrt"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-4000:])
+    return out
+
+
+if __name__ == "__main__":
+    try:
+        print(build(force="--force" in sys.argv))
+    except RuntimeError as e:
+        print(e, file=sys.stderr)
+        sys.exit(1)
