@@ -22,8 +22,10 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
-CSRC = ROOT / "sublinear_time_solver_amd" / "csrc"
-BUILD = HERE / "_build"
+# SIMT_CSRC / SIMT_BUILD: another tree's kernels (e.g. `git worktree add /tmp/r03 <commit>`): does an older, hardware-verified version of a
+# kernel behave the same under the emulator?  — tells an emulator artefact from a regression
+CSRC = Path(os.environ["SIMT_CSRC"]) if os.environ.get("SIMT_CSRC") else ROOT / "sublinear_time_solver_amd" / "csrc"
+BUILD = Path(os.environ["SIMT_BUILD"]) if os.environ.get("SIMT_BUILD") else HERE / "_build"
 CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g1", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing", "-pthread", "-Wno-unused-value",
          "-Wno-unused-result", "-Wno-unknown-attributes", "-Wno-ignored-attributes", f"-I{HERE}", f"-I{BUILD}"]
@@ -38,9 +40,28 @@ REWRITES = [
 ]
 
 
-def rewrite(text: str) -> str:
+# Places where a kernel relies on the hardware's wave-synchronous execution WITHOUT any instruction the emulator can see: LDS written by
+# one lane and read by another lane of the same wave with nothing but program order in between ("LDS accesses of one wave execute in
+# issue order").  The emulated lanes run one after the other, so the order has to be made explicit there: a wave barrier is inserted
+# in the emulated copy (on the hardware it would be a no-op).  (file, anchor line that must exist exactly once, text inserted before it)
+SYNC_POINTS = [
+    ("sl_kernels.hip", "        for (uint32_t r = lane; r < SL_PANEL_TILE; r += 64) {\n            const uint64_t i = (uint64_t)tile * SL_PANEL_TILE + r;",
+     "        simt_amdgcn_wave_barrier();      // (emulator) the running sums of the last group are in LDS before any lane reads its rows' slots\n"),
+]
+
+
+def rewrite(text: str, name: str = "") -> str:
     for rx, rep in REWRITES:
         text = rx.sub(rep, text)
+    for fname, anchor, ins in SYNC_POINTS:
+        if fname == name:
+            if text.count(anchor) != 1:
+                raise RuntimeError(f"{name}: the anchor of an emulator sync point is gone or ambiguous:\n{anchor}")
+            text = text.replace(anchor, ins + anchor)
+    if os.environ.get("SIMT_PATCH"):        # debugging: a python file defining patch(name, text) -> text (printf probes in a scratch build)
+        ns = {}
+        exec(Path(os.environ["SIMT_PATCH"]).read_text(), ns)
+        text = ns["patch"](name, text)
     return text
 
 
@@ -51,7 +72,7 @@ def sources():
 def stale(out: Path) -> bool:
     if not out.exists():
         return True
-    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "sublinear_hip.h", HERE / "simt_rt.cpp", HERE / "hip" / "hip_runtime.h",
+    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [CSRC.parent.parent / "include" / "sublinear_hip.h", HERE / "simt_rt.cpp", HERE / "fake_rccl.cpp", HERE / "hip" / "hip_runtime.h",
                                                                     HERE / "rocprim" / "device" / "device_radix_sort.hpp", Path(__file__)]
     return out.stat().st_mtime < max(d.stat().st_mtime for d in deps)
 
@@ -65,9 +86,9 @@ def build(force: bool = False) -> Path:
     # mirror the tree so that "../../include/sublinear_hip.h" of sl_internal.hpp resolves: _build/pkg/csrc + _build/include
     pkg = BUILD / "pkg" / "csrc"
     pkg.mkdir(parents=True, exist_ok=True)
-    (BUILD / "include" / "sublinear_hip.h").write_text((ROOT / "include" / "sublinear_hip.h").read_text())
+    (BUILD / "include" / "sublinear_hip.h").write_text((CSRC.parent.parent / "include" / "sublinear_hip.h").read_text())
     for f in list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")):
-        (pkg / f.name).write_text(rewrite(f.read_text()))
+        (pkg / f.name).write_text(rewrite(f.read_text(), f.name))
     objs = []
 
     def cc(src: Path):
@@ -81,6 +102,11 @@ def build(force: bool = False) -> Path:
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, todo))
     r = subprocess.run([CXX, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-o", str(out), *map(str, objs), "-ldl", "-lrt"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-4000:])
+    # the stand-in the library's dlopen("librccl.so.1") finds when this directory leads LD_LIBRARY_PATH (multi-process tests only)
+    r = subprocess.run([CXX, "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-Wl,-soname,librccl.so.1", "-o", str(BUILD / "librccl.so.1"), str(HERE / "fake_rccl.cpp")],
+                       capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-4000:])
     return out

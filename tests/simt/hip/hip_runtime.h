@@ -150,40 +150,44 @@ template <class K, class... A> void launch_kernel(K k, dim3 grid, dim3 block, si
 using std::isfinite; using std::isnan; using std::isinf;
 
 // ---- device intrinsics -------------------------------------------------------------------------------------------------------------
+// A collective's identity is its SOURCE position (file, line, column of the call in the kernel), taken by defaulted arguments.  Not the return
+// address: the optimiser duplicates call sites (jump threading turns `p = c ? f(x) : 0; ballot(p != 0)` into two calls, one per arm of a
+// per-lane condition), and the lanes of one hardware instruction would then wait at two different addresses.
+#define SIMT_AT int _sl = __builtin_LINE(), int _sc = __builtin_COLUMN(), const char *_sf = __builtin_FILE()
+#define SIMT_SITE ((const void *)((uintptr_t)_sf * 1000003u + (uintptr_t)_sl * 4099u + (uintptr_t)_sc))
 namespace simt {
 template <class T> inline uint64_t to_bits(T v) { static_assert(sizeof(T) <= 8, "cross-lane values are at most 64 bits"); uint64_t b = 0; memcpy(&b, &v, sizeof(T)); return b; }
 template <class T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
-// the call sites of the wrappers below are inlined into the kernels: the return address inside collective() names the source site
-__attribute__((noinline)) uint64_t coll_site(int op, uint64_t value, uint64_t aux, uint64_t aux2);
+inline uint64_t coll_site(int op, uint64_t value, uint64_t aux, uint64_t aux2, const void *site) { return collective(op, value, aux, aux2, site); }
 }
-template <class T> __forceinline__ T __shfl(T v, int src, int width = 64)
+template <class T> __forceinline__ T __shfl(T v, int src, int width = 64, SIMT_AT)
 {
     const uint32_t l = ::simt::self().lane;
     const uint32_t j = (l & ~(uint32_t)(width - 1)) | ((uint32_t)src & (uint32_t)(width - 1));
-    return ::simt::from_bits<T>(::simt::coll_site(::simt::OP_SHFL, ::simt::to_bits(v), j, 0));
+    return ::simt::from_bits<T>(::simt::coll_site(::simt::OP_SHFL, ::simt::to_bits(v), j, 0, SIMT_SITE));
 }
-template <class T> __forceinline__ T __shfl_xor(T v, int mask, int width = 64)
+template <class T> __forceinline__ T __shfl_xor(T v, int mask, int width = 64, SIMT_AT)
 {
     const uint32_t l = ::simt::self().lane;
     uint32_t j = l ^ (uint32_t)mask;
     if ((j & ~(uint32_t)(width - 1)) != (l & ~(uint32_t)(width - 1))) j = l;
-    return ::simt::from_bits<T>(::simt::coll_site(::simt::OP_SHFL, ::simt::to_bits(v), j, 0));
+    return ::simt::from_bits<T>(::simt::coll_site(::simt::OP_SHFL, ::simt::to_bits(v), j, 0, SIMT_SITE));
 }
-template <class T> __forceinline__ T __shfl_up(T v, unsigned delta, int width = 64)
+template <class T> __forceinline__ T __shfl_up(T v, unsigned delta, int width = 64, SIMT_AT)
 {
     const uint32_t l = ::simt::self().lane;
     const uint32_t base = l & ~(uint32_t)(width - 1);
     const uint32_t j = (l - base) >= delta ? l - delta : l;
-    return ::simt::from_bits<T>(::simt::coll_site(::simt::OP_SHFL, ::simt::to_bits(v), j, 0));
+    return ::simt::from_bits<T>(::simt::coll_site(::simt::OP_SHFL, ::simt::to_bits(v), j, 0, SIMT_SITE));
 }
-template <class T> __forceinline__ T __shfl_down(T v, unsigned delta, int width = 64)
+template <class T> __forceinline__ T __shfl_down(T v, unsigned delta, int width = 64, SIMT_AT)
 {
     const uint32_t l = ::simt::self().lane;
     const uint32_t base = l & ~(uint32_t)(width - 1);
     const uint32_t j = (l - base) + delta < (uint32_t)width ? l + delta : l;
-    return ::simt::from_bits<T>(::simt::coll_site(::simt::OP_SHFL, ::simt::to_bits(v), j, 0));
+    return ::simt::from_bits<T>(::simt::coll_site(::simt::OP_SHFL, ::simt::to_bits(v), j, 0, SIMT_SITE));
 }
-__forceinline__ unsigned long long __ballot(int pred) { return ::simt::coll_site(::simt::OP_BALLOT, pred ? 1u : 0u, 0, 0); }
+__forceinline__ unsigned long long __ballot(int pred, SIMT_AT) { return ::simt::coll_site(::simt::OP_BALLOT, pred ? 1u : 0u, 0, 0, SIMT_SITE); }
 __forceinline__ void __syncthreads() { ::simt::barrier(); }
 int __syncthreads_or(int pred);
 int __syncthreads_count(int pred);
@@ -207,12 +211,12 @@ unsigned long long wall_clock64();          // 100 MHz, as on the device
 __forceinline__ unsigned long long clock64() { return wall_clock64(); }
 
 // amdgcn builtins the kernels call directly (clang only knows them for the amdgcn target): build.py rewrites `simt_amdgcn_` to `simt_amdgcn_`
-__forceinline__ int simt_amdgcn_readfirstlane(int v) { return (int)::simt::coll_site(::simt::OP_READFIRST, (uint32_t)v, 0, 0); }
-__forceinline__ int simt_amdgcn_readlane(int v, int l) { return (int)::simt::coll_site(::simt::OP_READLANE, (uint32_t)v, (uint32_t)l, 0); }
-__forceinline__ int simt_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+__forceinline__ int simt_amdgcn_readfirstlane(int v, SIMT_AT) { return (int)::simt::coll_site(::simt::OP_READFIRST, (uint32_t)v, 0, 0, SIMT_SITE); }
+__forceinline__ int simt_amdgcn_readlane(int v, int l, SIMT_AT) { return (int)::simt::coll_site(::simt::OP_READLANE, (uint32_t)v, (uint32_t)l, 0, SIMT_SITE); }
+__forceinline__ int simt_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl, SIMT_AT)
 {
     (void)row_mask; (void)bank_mask;      // every site passes 0xf, 0xf
-    return (int)::simt::coll_site(::simt::OP_DPP, (uint32_t)src, (uint32_t)ctrl | (bound_ctrl ? 0x10000u : 0u), (uint32_t)old);
+    return (int)::simt::coll_site(::simt::OP_DPP, (uint32_t)src, (uint32_t)ctrl | (bound_ctrl ? 0x10000u : 0u), (uint32_t)old, SIMT_SITE);
 }
 __forceinline__ bool simt_amdgcn_inverse_ballot_w64(unsigned long long m) { return (m >> ::simt::self().lane) & 1ull; }
 __forceinline__ uint32_t simt_amdgcn_mbcnt_lo(uint32_t m, uint32_t add)
@@ -225,7 +229,7 @@ __forceinline__ uint32_t simt_amdgcn_mbcnt_hi(uint32_t m, uint32_t add)
     const uint32_t l = ::simt::self().lane;
     return add + (l <= 32 ? 0u : (uint32_t)__builtin_popcount(m & ((1u << (l - 32)) - 1u)));
 }
-__forceinline__ void simt_amdgcn_wave_barrier() { (void)::simt::coll_site(::simt::OP_WAVE_BARRIER, 0, 0, 0); }
+__forceinline__ void simt_amdgcn_wave_barrier(SIMT_AT) { (void)::simt::coll_site(::simt::OP_WAVE_BARRIER, 0, 0, 0, SIMT_SITE); }
 __forceinline__ void simt_amdgcn_s_sleep(int) { ::simt::yield(); }
 #define simt_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 // buffer_load ... lds: every lane moves `size` bytes from ITS global address to LDS base + lane * size + offset (M0 = the wave-uniform base)

@@ -22,7 +22,9 @@
 #include <cstdio>
 #include <map>
 #include <mutex>
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -279,11 +281,6 @@ uint64_t collective(int op, uint64_t value, uint64_t aux, uint64_t aux2, const v
     to_scheduler(w);
     return me->result;
 }
-__attribute__((noinline)) uint64_t coll_site(int op, uint64_t value, uint64_t aux, uint64_t aux2)
-{
-    return collective(op, value, aux, aux2, __builtin_return_address(0));
-}
-
 void barrier()
 {
     worker *w = tl_worker;
@@ -406,7 +403,9 @@ struct simt_stream { int dummy; };
 struct simt_event { std::chrono::steady_clock::time_point t; };
 namespace {
 std::mutex g_mu;
-std::map<void *, size_t> g_alloc;
+struct alloc_info { size_t bytes, rounded; int fd; };
+std::map<void *, alloc_info> g_alloc;
+std::map<void *, size_t> g_ipc_open;
 size_t g_bytes = 0;
 }
 
@@ -422,27 +421,41 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
     p->totalGlobalMem = (size_t)16 << 30;
     p->sharedMemPerBlock = 64 * 1024; p->sharedMemPerBlockOptin = 160 * 1024; p->maxSharedMemoryPerMultiProcessor = 160 * 1024;
     const char *e = getenv("SIMT_CUS");
-    p->multiProcessorCount = e ? atoi(e) : 8;          // a small machine: persistent kernels launch one block per CU
+    p->multiProcessorCount = e ? atoi(e) : 256;        // as an MI355X: the layout decisions (which kernel a matrix gets) follow the CU count
     p->warpSize = 64; p->maxThreadsPerBlock = 1024; p->clockRate = 2400000; p->l2CacheSize = 4 << 20;
     return hipSuccess;
 }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : "error (simt emulator)"; }
+// SIMT_IPC=1: "device" allocations are memfd-backed shared mappings, so that hipIpcGetMemHandle / hipIpcOpenMemHandle work between the
+// processes of a multi-rank test exactly as the ipc transport uses them (one process per rank, peers' vectors mapped, pulled by copies).
+static bool ipc_on() { static const bool on = [] { const char *e = getenv("SIMT_IPC"); return e && *e == '1'; }(); return on; }
 hipError_t hipMalloc(void **p, size_t bytes)
 {
-    void *q = aligned_alloc(256, (bytes + 255) & ~(size_t)255);
-    if (!q) { *p = nullptr; return hipErrorOutOfMemory; }
+    const size_t rounded = (std::max<size_t>(bytes, 1) + 4095) & ~(size_t)4095;
+    void *q = nullptr;
+    int fd = -1;
+    if (ipc_on()) {
+        fd = memfd_create("simt_device_memory", 0);
+        if (fd < 0 || ftruncate(fd, (off_t)rounded) != 0) { if (fd >= 0) close(fd); *p = nullptr; return hipErrorOutOfMemory; }
+        q = mmap(nullptr, rounded, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (q == MAP_FAILED) { close(fd); *p = nullptr; return hipErrorOutOfMemory; }
+    } else {
+        q = aligned_alloc(256, (bytes + 255) & ~(size_t)255);
+        if (!q) { *p = nullptr; return hipErrorOutOfMemory; }
+    }
     memset(q, 0xCD, bytes);                               // fresh device memory is not zero either
-    { std::lock_guard<std::mutex> lk(g_mu); g_alloc[q] = bytes; g_bytes += bytes; }
+    { std::lock_guard<std::mutex> lk(g_mu); g_alloc[q] = alloc_info{bytes, rounded, fd}; g_bytes += bytes; }
     *p = q;
     return hipSuccess;
 }
 hipError_t hipFree(void *p)
 {
     if (!p) return hipSuccess;
-    { std::lock_guard<std::mutex> lk(g_mu); auto it = g_alloc.find(p); if (it == g_alloc.end()) return hipErrorInvalidValue; g_bytes -= it->second; g_alloc.erase(it); }
-    free(p);
+    alloc_info ai;
+    { std::lock_guard<std::mutex> lk(g_mu); auto it = g_alloc.find(p); if (it == g_alloc.end()) return hipErrorInvalidValue; ai = it->second; g_bytes -= ai.bytes; g_alloc.erase(it); }
+    if (ai.fd >= 0) { munmap(p, ai.rounded); close(ai.fd); } else free(p);
     return hipSuccess;
 }
 hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { *p = aligned_alloc(256, (bytes + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
@@ -466,11 +479,47 @@ hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
-// no inter-process device memory in the emulator: the ipc transport reports that it cannot export (one process per "GPU" only)
-hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *, void *) { return hipErrorNotSupported; }
-hipError_t hipIpcOpenMemHandle(void **, hipIpcMemHandle_t, unsigned) { return hipErrorNotSupported; }
-hipError_t hipIpcCloseMemHandle(void *) { return hipErrorNotSupported; }
+// inter-process device memory (SIMT_IPC=1): the handle names the exporter's memfd through /proc/<pid>/fd/<fd>; the opener maps the same pages
+struct simt_ipc_handle { char magic[8]; int pid, fd; unsigned long long bytes; };
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *h, void *p)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_alloc.find(p);                            // the base address of an allocation, as the real runtime demands
+    if (it == g_alloc.end() || it->second.fd < 0) return it == g_alloc.end() ? hipErrorInvalidValue : hipErrorNotSupported;
+    simt_ipc_handle sh;
+    memset(&sh, 0, sizeof(sh));
+    memcpy(sh.magic, "SIMTIPC1", 8);
+    sh.pid = (int)getpid(); sh.fd = it->second.fd; sh.bytes = it->second.rounded;
+    memset(h, 0, sizeof(*h));
+    memcpy(h->reserved, &sh, sizeof(sh));
+    return hipSuccess;
+}
+hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsigned)
+{
+    simt_ipc_handle sh;
+    memcpy(&sh, h.reserved, sizeof(sh));
+    if (memcmp(sh.magic, "SIMTIPC1", 8) != 0) return hipErrorInvalidValue;
+    char path[64];
+    snprintf(path, sizeof(path), "/proc/%d/fd/%d", sh.pid, sh.fd);
+    const int fd = open(path, O_RDWR);
+    if (fd < 0) return hipErrorInvalidValue;
+    void *q = mmap(nullptr, sh.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (q == MAP_FAILED) return hipErrorOutOfMemory;
+    { std::lock_guard<std::mutex> lk(g_mu); g_ipc_open[q] = sh.bytes; }
+    *p = q;
+    return hipSuccess;
+}
+hipError_t hipIpcCloseMemHandle(void *p)
+{
+    size_t bytes = 0;
+    { std::lock_guard<std::mutex> lk(g_mu); auto it = g_ipc_open.find(p); if (it == g_ipc_open.end()) return hipErrorInvalidValue; bytes = it->second; g_ipc_open.erase(it); }
+    munmap(p, bytes);
+    return hipSuccess;
+}
 
+// SIMT_REPORT=1: one line at exit — the tests assert on it that kernels really ran under the emulator (and not nothing at all)
+namespace { struct simt_report { ~simt_report() { if (getenv("SIMT_REPORT")) fprintf(stderr, "simt: %llu launches, %llu blocks executed as host fibers\n", simt::g_launches.load(), simt::g_blocks.load()); } } g_report; }
 // what the tests read to see that kernels really ran under the emulator
 void simt_counters(unsigned long long *launches, unsigned long long *blocks) { *launches = simt::g_launches.load(); *blocks = simt::g_blocks.load(); }
 }
