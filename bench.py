@@ -52,9 +52,19 @@ def recorded_traffic(n, k, w):
     try:
         rec = json.loads(tf.read_text())
         recs = rec.get("records", {"x": rec})
+        import hashlib
+        now = hashlib.sha256((ROOT / "sublinear_time_solver_amd" / "csrc" / "sl_kernels.hip").read_bytes()).hexdigest()[:16]
+        stale = None
         for r in recs.values():
             if r.get("n") == n and r.get("k") == k and r.get("bandwidth") == w:
-                return r.get("hbm_bytes_per_step", r.get("hbm_bytes_per_launch")), f"profiles/pmc_traffic.json [{r.get('tag')}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this configuration; not measured in this run)"
+                if r.get("kernel_source_sha16") != now:      # counters of another kernel are not this kernel's traffic ("stale by construction")
+                    stale = (f"profiles/pmc_traffic.json [{r.get('tag')}] was measured on sl_kernels.hip {r.get('kernel_source_sha16')} (commit {r.get('commit')}); the file is "
+                             f"{now} now: traffic not reported — re-profile with `bash tools/profile.sh <tag> --bandwidth {w}`")
+                    continue
+                return r.get("hbm_bytes_per_step", r.get("hbm_bytes_per_launch")), (f"profiles/pmc_traffic.json [{r.get('tag')}, commit {r.get('commit')}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                                                                   "passes of an earlier run of this configuration on this very kernel source; not measured in this run)")
+        if stale:
+            return None, stale
     except Exception:
         pass
     return None, None

@@ -65,3 +65,27 @@ def test_launcher_time_budget_leaves_every_transport_its_turn():
     src = (ROOT / "bench.py").read_text()
     assert '"SL_BENCH_ATTEMPT_TIMEOUT", "420"' in src and '"SL_BENCH_TOTAL_TIMEOUT", "1440"' in src
     assert 3 * 420 <= 1440 < 1500
+
+
+def test_recorded_traffic_is_reported_only_for_the_kernel_it_was_measured_on():
+    """roofline.traffic comes from committed rocprofv3 counter passes; a record names the sl_kernels.hip it was taken on and is withheld
+    (traffic = null, the reason in traffic_source) once that file has changed (the round-3 record was 'stale by construction')"""
+    import hashlib
+    import importlib.util
+    import json
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("bench_mod", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    now = hashlib.sha256((root / "sublinear_time_solver_amd" / "csrc" / "sl_kernels.hip").read_bytes()).hexdigest()[:16]
+    recs = json.loads((root / "profiles" / "pmc_traffic.json").read_text())["records"]
+    assert all("kernel_source_sha16" in r and "commit" in r for r in recs.values())
+    for r in recs.values():
+        got, why = bench.recorded_traffic(r["n"], r["k"], r["bandwidth"])
+        same_kernel = any(q["kernel_source_sha16"] == now for q in recs.values() if (q["n"], q["k"], q["bandwidth"]) == (r["n"], r["k"], r["bandwidth"]))
+        if same_kernel:
+            assert got and "this very kernel source" in why
+        else:
+            assert got is None and "re-profile" in why and now in why
+    assert bench.recorded_traffic(123, 4, 5) == (None, None)          # no record at all: nothing to say

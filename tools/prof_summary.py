@@ -108,10 +108,26 @@ def main():
             allrec["records"]["uniform" if w == 0 else f"w{w}"] = {
                 "tag": tag, "n": n, "k": kk, "bandwidth": w, "fetch_size_kib": rec.get("FETCH_SIZE"), "write_size_kib": rec.get("WRITE_SIZE"),
                 "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg,
-                "l2_hit_rate": (best_tcc[1] / (best_tcc[1] + best_tcc[2])) if best_tcc[0] else None}
+                "l2_hit_rate": (best_tcc[1] / (best_tcc[1] + best_tcc[2])) if best_tcc[0] else None,
+                # which kernel these counters belong to: bench.py reports a record only while sl_kernels.hip is still that file
+                "kernel_source_sha16": kernel_source_sha16(), "commit": head_commit()}
             tf.write_text(json.dumps(allrec, indent=1) + "\n")
     (out / f"{tag}_pmc.txt").write_text("\n".join(pm) + "\n")
     print("\n".join(pm))
+
+
+def kernel_source_sha16():
+    import hashlib
+    src = Path(__file__).resolve().parent.parent / "sublinear_time_solver_amd" / "csrc" / "sl_kernels.hip"
+    return hashlib.sha256(src.read_bytes()).hexdigest()[:16]
+
+
+def head_commit():
+    import subprocess
+    try:
+        return subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=Path(__file__).resolve().parent.parent, capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        return None          # (the GPU box has no .git: the hash of the source is what counts)
 
 
 if __name__ == "__main__":
