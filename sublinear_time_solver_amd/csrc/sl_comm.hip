@@ -211,6 +211,7 @@ sl_status sl_comm_agree(sl_comm *c, sl_status mine)
     const std::string msg = sl_context().last_error;
     const sl_status ex = sl_comm_allgather_blob(c, &v, sizeof(v), all.data());
     if (ex != SL_OK) { if (mine != SL_OK) { sl_context().last_error = msg; return mine; } return ex; }
+    if (mine != SL_OK) { sl_context().last_error = msg; return mine; }      // a rank that failed itself keeps ITS diagnosis, whoever else failed too
     for (int p = 0; p < c->world; ++p)
         if (all[p] != SL_OK) {
             if (p == c->rank) { sl_context().last_error = msg; return mine; }

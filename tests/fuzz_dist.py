@@ -24,11 +24,11 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def build(tmp):
+def build(tmp, simt_lib=None):
     exe = Path(tmp) / "dist_smoke"
-    pkg = ROOT / "sublinear_time_solver_amd"
+    pkg, name = (ROOT / "sublinear_time_solver_amd", "sublinear_hip") if not simt_lib else (Path(simt_lib).resolve().parent, "sublinear_hip_simt")
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c" / "dist_smoke.c"),
-                        "-o", str(exe), f"-L{pkg}", "-lsublinear_hip", "-lm", f"-Wl,-rpath,{pkg}"], capture_output=True, text=True)
+                        "-o", str(exe), f"-L{pkg}", f"-l{name}", "-lm", f"-Wl,-rpath,{pkg}"], capture_output=True, text=True)
     if r.returncode:
         raise SystemExit(r.stderr)
     return exe
@@ -41,13 +41,17 @@ def main():
     ap.add_argument("--min-world", type=int, default=1)
     ap.add_argument("--sizes", default="", help="comma-separated n to draw from instead of the default mix")
     ap.add_argument("--parallel", type=int, default=1, help="cases run side by side")
+    ap.add_argument("--transports", default="ipc", help="comma-separated, drawn per case: ipc, rccl (grouped send / receive, all-gather), rccl-allreduce (the compact halo buffer)")
+    ap.add_argument("--simt", default="", help="path of tests/simt/_build/libsublinear_hip_simt.so: the campaign on the SIMT emulator (no GPU; one process per rank over "
+                                               "memfd-backed IPC, RCCL = tests/simt's stand-in) instead of the device")
     args = ap.parse_args()
+    transports = [t for t in args.transports.split(",") if t in ("ipc", "rccl", "rccl-allreduce")] or ["ipc"]
     import threading
     lock = threading.Lock()
     failures, forms, repaired, by_staging = [], {}, [], {"pinned": 0, "pageable": 0}
     counter = [0]
     with tempfile.TemporaryDirectory() as tmp:
-        exe = build(tmp)
+        exe = build(tmp, args.simt or None)
         t_end = time.time() + args.seconds
 
         def worker(wid):
@@ -65,6 +69,14 @@ def main():
             cmd = [str(exe), str(world), str(n), str(w)] + (["uneven"] if uneven else [])
             staging = "pageable" if rng.random() < 0.5 else "pinned"
             env = dict(os.environ, SL_COMM_TIMEOUT_MS="60000", SL_DIST_OVERLAP=overlap, SL_LOG="1")
+            transport = str(rng.choice(transports))
+            env["SL_COMM_TRANSPORT"] = "rccl" if transport.startswith("rccl") else "ipc"
+            env.pop("SL_COMM_HALO", None)
+            if transport == "rccl-allreduce":
+                env["SL_COMM_HALO"] = "allreduce"
+            if args.simt:
+                d = str(Path(args.simt).resolve().parent)
+                env.update(SIMT_IPC="1", SIMT_THREADS=env.get("SIMT_THREADS", "1"), LD_LIBRARY_PATH=d + ":" + os.environ.get("LD_LIBRARY_PATH", ""), SL_COMM_TIMEOUT_MS="180000")
             if staging == "pageable":
                 env["SL_STAGING"] = "pageable"
             if n >= 400000 and rng.random() < 0.5:            # the paced layout with XCD-local spans forced on every rank (a pretended small device)
@@ -87,10 +99,10 @@ def main():
                 for ln in r.stderr.splitlines():
                     if "did not fit their slices" in ln or "IPC Attach" in ln or "succeeded on try" in ln:
                         repaired.append({"cmd": " ".join(cmd[1:]), "staging": staging, "line": ln[:700]})
-            key = f"world {world}: {form}"
+            key = f"world {world}, {transport}: {form}"
             forms[key] = forms.get(key, 0) + 1
             if not ok:
-                failures.append({"cmd": " ".join(cmd[1:]), "overlap": overlap, "staging": staging, "forced": {k: env[k] for k in ("SL_PW_CUS", "SL_PW_XCD") if k in env}, "tail": tail})
+                failures.append({"cmd": " ".join(cmd[1:]), "overlap": overlap, "staging": staging, "transport": transport, "forced": {k: env[k] for k in ("SL_PW_CUS", "SL_PW_XCD") if k in env}, "tail": tail})
                 print("FAIL", " ".join(cmd[1:]), "overlap", overlap, "staging", staging, "\n", tail, file=sys.stderr)
             lock.release()
 
@@ -100,7 +112,7 @@ def main():
         for t in threads:
             t.join()
     cases = counter[0]
-    print(json.dumps({"seed0": args.seed0, "cases": cases, "parallel": args.parallel, "cases_by_staging": by_staging, "forms_seen": dict(sorted(forms.items())), "failures": failures, "noticed_and_repaired": repaired}))
+    print(json.dumps({"seed0": args.seed0, "on": "simt emulator (tests/simt; no GPU)" if args.simt else "device", "transports": transports, "cases": cases, "parallel": args.parallel, "cases_by_staging": by_staging, "forms_seen": dict(sorted(forms.items())), "failures": failures, "noticed_and_repaired": repaired}))
     return 1 if failures else 0
 
 

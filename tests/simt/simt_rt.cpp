@@ -503,7 +503,11 @@ hipError_t hipIpcOpenMemHandle(void **p, hipIpcMemHandle_t h, unsigned)
     snprintf(path, sizeof(path), "/proc/%d/fd/%d", sh.pid, sh.fd);
     const int fd = open(path, O_RDWR);
     if (fd < 0) return hipErrorInvalidValue;
-    void *q = mmap(nullptr, sh.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    // SIMT_IPC_FAULT=zeros (tests of the library's own checks): the importer gets a private page of zeros instead of the exporter's memory —
+    // what a transport that does not deliver looks like; the ipc self-test must notice it on every rank and name it
+    static const bool fault_zeros = [] { const char *e = getenv("SIMT_IPC_FAULT"); return e && !strcmp(e, "zeros"); }();
+    void *q = fault_zeros ? mmap(nullptr, sh.bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0)
+                          : mmap(nullptr, sh.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (q == MAP_FAILED) return hipErrorOutOfMemory;
     { std::lock_guard<std::mutex> lk(g_mu); g_ipc_open[q] = sh.bytes; }

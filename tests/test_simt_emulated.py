@@ -83,8 +83,13 @@ GROUPS = {
 }
 
 
+FULL_ONLY = {"e)"}       # whole groups left to SIMT_FULL=1: the CPU suite stays within a few minutes
+
+
 @pytest.mark.parametrize("group", sorted(GROUPS))
 def test_gpu_parity_tests_pass_under_the_emulator(simt_lib, group):
+    if group[:2] in FULL_ONLY and os.environ.get("SIMT_FULL") != "1":
+        pytest.skip("runs with SIMT_FULL=1 (profiles/r05_simt_emulated_suite.txt holds this round's full run)")
     skip = NOT_HERE + ([] if os.environ.get("SIMT_FULL") == "1" else SLOW)
     cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--timeout", "900", *GROUPS[group]]
     for d in skip:
@@ -128,6 +133,19 @@ def test_boundary_first_overlap_under_the_emulator(simt_lib, dist_exe):
         r = subprocess.run([str(dist_exe), "2", "200000", "300"], capture_output=True, text=True, timeout=1200, env=env)
         assert r.returncode == 0 and "dist_smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
         assert ("runs its edge blocks first" in r.stderr) == expect, r.stderr[-2500:]
+
+
+def test_a_transport_that_does_not_deliver_is_named_by_the_ipc_self_test(simt_lib, dist_exe):
+    """SIMT_IPC_FAULT=zeros: every imported mapping is a page of zeros instead of the peer's memory.  The self-test at communicator
+    creation must fail on EVERY rank — no hang, no half-built communicator — and say what it saw: which peer's page, how many words,
+    'zeros ... ordering', the rendezvous name and the job nonce (the fault must name its cause in one line)."""
+    env = _env(simt_lib, SIMT_IPC="1", SIMT_THREADS="1", SIMT_IPC_FAULT="zeros", SL_COMM_TIMEOUT_MS="20000")
+    r = subprocess.run([str(dist_exe), "3", "20000", "300"], capture_output=True, text=True, timeout=600, env=env)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and "dist_smoke ok" not in r.stdout, out[-2000:]
+    assert "self-test of the ipc transport" in out and "512 of 512 words wrong" in out and "zeros" in out and "ordering" in out, out[-3000:]
+    assert "rendezvous /dev/shm/slcomm_" in out and "job nonce" in out and "a second read of the mapping returns the same words" in out, out[-3000:]
+    assert out.count("rank 1's page") >= 1 and out.count("rank 0's page") >= 1        # per peer, on the ranks that pulled from it
 
 
 def test_bench_refuses_the_emulator(simt_lib):
