@@ -5,7 +5,7 @@
 #   bash tools/r05_gpu_session.sh bench        the default bench line (parity_gate, roofline, cpu_baseline) -> gpurun_out/r05_bench_default.json
 #   bash tools/r05_gpu_session.sh profile      rocprofv3 stats + counters of the headline (tools/profile.sh) -> gpurun_out/prof_r05_uniform/
 #   bash tools/r05_gpu_session.sh optin        every opt-in path against its default, at size (CG fused dot, small rounds, wide batches, index-only stream)
-#   bash tools/r05_gpu_session.sh micro        tools/ldsdma_bench, tools/launch_floor
+#   bash tools/r05_gpu_session.sh micro        tools/split_bench (stream warmed by other CUs of the XCD?), tools/ldsdma_bench, tools/launch_floor
 #   bash tools/r05_gpu_session.sh optin_fuzz [s]   tests/fuzz_campaign.py with every opt-in path on
 # No many-process campaign here: at most 8 processes on the device, one job at a time (round 4 lost a box and the pool to 48).
 cd /root/repo
@@ -26,6 +26,7 @@ optin)
     for f in 0 1; do SL_PW_INDEX_ONLY=$f timeout 900 python tools/pagerank_query.py --thetas 1e-5 > $O/r05_pagerank_idx$f.json 2>$O/r05_pagerank_idx$f.err; head -c 900 $O/r05_pagerank_idx$f.json; echo; done
     for w in 8 16 32; do SL_QUERY_WIDE=$w timeout 600 python tools/pagerank_query.py --no-full-solve > $O/r05_pagerank_wide$w.json 2>$O/r05_pagerank_wide$w.err; tail -c 1500 $O/r05_pagerank_wide$w.json; echo; done ;;
 micro)
+    timeout 300 tools/split_bench 10 > $O/r05_split_bench.txt 2>&1; cat $O/r05_split_bench.txt
     timeout 200 tools/ldsdma_bench 20 > $O/r05_ldsdma_bench.txt 2>&1; cat $O/r05_ldsdma_bench.txt
     timeout 100 tools/launch_floor > $O/r05_launch_floor.txt 2>&1; cat $O/r05_launch_floor.txt ;;
 optin_fuzz)      # the random parity campaign with every opt-in path of the round switched on: whatever runs must still equal the oracle
