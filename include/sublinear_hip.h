@@ -34,7 +34,9 @@ extern "C" {
 /* 3 (round 5): + sl_spmv_add, sl_matrix_diagonal_dominance_factor, sl_matrix_spectral_radius_estimate, and the round-4 additions
  * (sl_neumann_state_current_term / _solution_rows, sl_backward_push_acl_with_source / _reachability, sl_acl_extrapolated_solution):
  * a library that lacks any of them answers 2 and is refused by the bindings before a symbol lookup can fail. */
-#define SL_ABI_VERSION 3
+/* 4 (round 5): + the element / iterator / norm side of trait Matrix — sl_matrix_get, sl_matrix_row, sl_matrix_col,
+ * sl_matrix_frobenius_norm, sl_matrix_sparsity_info (with the calls of version 3, `impl Matrix for HipMatrix` is complete). */
+#define SL_ABI_VERSION 4
 
 /* ---- status codes: 1:1 with SolverError variants (src/error.rs:16-140) ---------- */
 typedef enum {
@@ -148,6 +150,35 @@ sl_status sl_matrix_diagonal_dominance_factor(const sl_matrix *m, int *has_facto
 /* Matrix::spectral_radius_estimate (matrix/mod.rs:83-100): Gershgorin, max over rows of |a_ii| + sum_j |a_ij|; bit-exact.
  * With the two calls above it fills ConditioningInfo (matrix/mod.rs:548-556). */
 sl_status sl_matrix_spectral_radius_estimate(const sl_matrix *m, double *radius);
+/* Matrix::get (matrix/mod.rs:33, SparseMatrix::get :383-395 -> CSRStorage::get sparse.rs:142-155): *found = 0 is the reference's None
+ * — row or column out of bounds, or no stored entry (an exact zero is never stored: from_triplets drops it).  A row that holds the
+ * column more than once (duplicates are kept as separate entries, sparse.rs:80-132) answers with the entry the reference's
+ * `binary_search` of the row's column slice lands on (the halving search; the same rule NeumannState::new's diagonal lookup
+ * follows).  `row` counts from the first row of this matrix (a row slice: local row), `col` is the global column. */
+sl_status sl_matrix_get(const sl_matrix *m, uint64_t row, uint64_t col, int *found, double *value);
+/* Matrix::row_iter (matrix/mod.rs:37, CSRStorage::row_iter sparse.rs:158-176): the (column, value) pairs of one row in stored order
+ * = ascending column, duplicates in input order.  *count = the row's length (0 for a row out of bounds: the reference's empty
+ * iterator); the first min(*count, capacity) pairs are written (cols / values may be null when capacity is 0). */
+sl_status sl_matrix_row(const sl_matrix *m, uint64_t row, uint64_t capacity, uint32_t *cols, double *values, uint64_t *count);
+/* Matrix::col_iter (matrix/mod.rs:41, CSRColIter sparse.rs:273-298): row after row ascending, the pair (row, get(row, col)) of every
+ * row that holds the column — ONE pair per row even where the row holds it twice (the reference searches each row once).
+ * *count = the number of such rows; the first min(*count, capacity) pairs are written. */
+sl_status sl_matrix_col(const sl_matrix *m, uint64_t col, uint64_t capacity, uint32_t *rows, double *values, uint64_t *count);
+/* Matrix::frobenius_norm (matrix/mod.rs:74-82): sqrt of the sum of value^2 over the stored entries.  The reference adds the squares
+ * one after the other in row-major order; the device sums every row in stored order and the rows in a fixed tree — deterministic, and
+ * equal to the reference's value to rounding (tests: 1e-12 relative, like the device's other tree-reduced norms). */
+sl_status sl_matrix_frobenius_norm(const sl_matrix *m, double *norm);
+/* Matrix::sparsity_info (matrix/mod.rs:523-545; SparsityInfo, types.rs:114-129, ::new :344-369) */
+typedef struct {
+    uint64_t nnz, rows, cols;         /* dimensions = (rows, cols) */
+    double sparsity_ratio;            /* nnz / (rows * cols) as f64 / f64; 0 for an empty shape */
+    double avg_nnz_per_row;           /* nnz / rows; 0 without rows */
+    uint64_t max_nnz_per_row;
+    uint64_t bandwidth;               /* max |row - col| over the stored entries: always Some(..) in the reference (0 without entries) */
+    int32_t is_banded;                /* bandwidth < rows / 4 (integer division, matrix/mod.rs:542) */
+    int32_t reserved;
+} sl_sparsity_info;
+sl_status sl_matrix_sparsity_info(const sl_matrix *m, sl_sparsity_info *info);
 /* a7 (first half): D^-1 with the reference's rejection rules (neumann.rs:172-188):
  * missing diagonal or |d| < 1e-14 -> SL_INVALID_SPARSE_MATRIX.  dinv: n_rows doubles. */
 sl_status sl_matrix_diagonal_inverse(const sl_matrix *m, double *dinv, sl_mem where);

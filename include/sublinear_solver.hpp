@@ -128,9 +128,35 @@ public:
         return has ? std::optional<Precision>(f) : std::nullopt;
     }
     Precision spectral_radius_estimate() const { double r = 0.0; check(sl_matrix_spectral_radius_estimate(h_, &r)); return r; }
+    // Matrix::get (matrix/mod.rs:383-395 over CSRStorage::get, sparse.rs:142-155): nullopt out of bounds or where nothing is stored
+    std::optional<Precision> get(size_t row, size_t col) const
+    {
+        int found = 0; double v = 0.0;
+        check(sl_matrix_get(h_, row, col, &found, &v));
+        return found ? std::optional<Precision>(v) : std::nullopt;
+    }
+    // Matrix::row_iter (sparse.rs:158-176) / col_iter (CSRColIter sparse.rs:273-298: one pair per row): (index, value) pairs
+    std::vector<std::pair<IndexType, Precision>> row_iter(size_t row) const { return pairs(row, false); }
+    std::vector<std::pair<IndexType, Precision>> col_iter(size_t col) const { return pairs(col, true); }
+    // Matrix::frobenius_norm (matrix/mod.rs:74-82; tree-reduced on the device: the reference's value to rounding)
+    Precision frobenius_norm() const { double r = 0.0; check(sl_matrix_frobenius_norm(h_, &r)); return r; }
+    // Matrix::sparsity_info (matrix/mod.rs:523-545; the fields of SparsityInfo, types.rs:114-129)
+    sl_sparsity_info sparsity_info() const { sl_sparsity_info i; check(sl_matrix_sparsity_info(h_, &i)); return i; }
+    const char *format_name() const { return "CSR"; }
     const sl_matrix *handle() const { return h_; }
 
 private:
+    std::vector<std::pair<IndexType, Precision>> pairs(size_t index, bool by_column) const
+    {
+        uint64_t n = 0;
+        check(by_column ? sl_matrix_col(h_, index, 0, nullptr, nullptr, &n) : sl_matrix_row(h_, index, 0, nullptr, nullptr, &n));
+        std::vector<uint32_t> idx(n ? n : 1);
+        std::vector<double> val(n ? n : 1);
+        check(by_column ? sl_matrix_col(h_, index, n, idx.data(), val.data(), &n) : sl_matrix_row(h_, index, n, idx.data(), val.data(), &n));
+        std::vector<std::pair<IndexType, Precision>> out;
+        for (uint64_t k = 0; k < n; ++k) out.emplace_back(idx[k], val[k]);
+        return out;
+    }
     SparseMatrix(sl_matrix *h, size_t r, size_t c) : h_(h), rows_(r), cols_(c) {}
     sl_matrix *h_;
     size_t rows_, cols_;

@@ -52,6 +52,18 @@ static int one_system(uint64_t n, uint64_t seed, int hubs)
     orc_spmv_add_csr_sequential(n, rp, ci, va, x, z);                      /* z = y + A x, the seeded chain */
     { double f = -1.0; int has = orc_diagonal_dominance_factor(n, rp, ci, va, &f); CHECK(!has || f >= 1.0); }
     CHECK(orc_spectral_radius_estimate(n, rp, ci, va) >= 0.0 && orc_powi(0.5, 3) == 0.125);
+    {   /* the element / iterator / norm side of trait Matrix: rows and columns at both ends and out of bounds, zero capacity */
+        uint32_t idx[8]; double val[8]; uint64_t ou[3]; double of[2];
+        for (uint64_t q = 0; q < 3; ++q) {
+            const uint64_t at = q == 0 ? 0 : q == 1 ? (n ? n - 1 : 0) : n + 3;
+            (void)orc_matrix_get(n, n, rp, ci, va, at, at, &d);
+            CHECK(orc_csr_row(n, rp, ci, va, at, 8, idx, val) <= nnz && orc_csr_row(n, rp, ci, va, at, 0, idx, val) <= nnz);
+            CHECK(orc_csr_col(n, rp, ci, va, at, 8, idx, val) <= n && orc_csr_col(n, rp, ci, va, at, 0, idx, val) <= n);
+        }
+        CHECK(orc_frobenius_norm(n, rp, va) >= 0.0);
+        orc_sparsity_info(n, n, rp, ci, ou, of);
+        CHECK(ou[0] <= nnz && (n == 0 || ou[1] < n) && of[0] >= 0.0 && of[1] >= 0.0);
+    }
     (void)orc_dot_simd4(n, x, y); (void)orc_dot_sequential(n, x, y); orc_axpy(n, 0.5, x, y);
     (void)orc_l2_norm(n, y); (void)orc_l1_norm(n, y); (void)orc_linf_norm(n, y);
 

@@ -79,6 +79,9 @@ def lib(fast: bool = False) -> C.CDLL:
         l.orc_linf_norm.restype = f64
         l.orc_spectral_radius_estimate.restype = f64
         l.orc_powi.restype = f64
+        l.orc_frobenius_norm.restype = f64
+        l.orc_csr_row.restype = u64
+        l.orc_csr_col.restype = u64
         _libs[key] = l
     return _libs[key]
 
@@ -194,6 +197,51 @@ def diagonal_dominance_factor(rp, ci, va):
 def spectral_radius_estimate(rp, ci, va):
     rp, ci, va = _u32(rp), _u32(ci), _f(va)
     return lib().orc_spectral_radius_estimate(u64(rp.size - 1), _p(rp), _p(ci), _p(va))
+
+
+def matrix_get(rp, ci, va, r, c, cols=None):
+    """SparseMatrix::get (matrix/mod.rs:383-395): None out of bounds or where nothing is stored"""
+    rp, ci, va = _u32(rp), _u32(ci), _f(va)
+    rows = rp.size - 1
+    out = f64(0)
+    ok = lib().orc_matrix_get(u64(rows), u64(rows if cols is None else cols), _p(rp), _p(ci), _p(va), u64(r), u64(c), C.byref(out))
+    return out.value if ok else None
+
+
+def csr_row(rp, ci, va, r):
+    """CSRStorage::row_iter (sparse.rs:158-176): (columns, values) of one row in stored order; empty out of bounds"""
+    rp, ci, va = _u32(rp), _u32(ci), _f(va)
+    rows = rp.size - 1
+    cap = int(rp[r + 1] - rp[r]) if r < rows else 0
+    co, vo = np.zeros(max(cap, 1), dtype=np.uint32), np.zeros(max(cap, 1))
+    n = lib().orc_csr_row(u64(rows), _p(rp), _p(ci), _p(va), u64(r), u64(cap), _p(co), _p(vo))
+    return co[:n].copy(), vo[:n].copy()
+
+
+def csr_col(rp, ci, va, c):
+    """CSRColIter (sparse.rs:273-298): (rows, values), one pair per row that holds the column"""
+    rp, ci, va = _u32(rp), _u32(ci), _f(va)
+    rows = rp.size - 1
+    ro, vo = np.zeros(max(rows, 1), dtype=np.uint32), np.zeros(max(rows, 1))
+    n = lib().orc_csr_col(u64(rows), _p(rp), _p(ci), _p(va), u64(c), u64(rows), _p(ro), _p(vo))
+    return ro[:n].copy(), vo[:n].copy()
+
+
+def frobenius_norm(rp, va):
+    """Matrix::frobenius_norm (matrix/mod.rs:74-82), the squares added one after the other in row-major order"""
+    rp, va = _u32(rp), _f(va)
+    return lib().orc_frobenius_norm(u64(rp.size - 1), _p(rp), _p(va))
+
+
+def sparsity_info(rp, ci, cols=None):
+    """Matrix::sparsity_info (matrix/mod.rs:523-545): the fields of SparsityInfo as a dict"""
+    rp, ci = _u32(rp), _u32(ci)
+    rows = rp.size - 1
+    cols = rows if cols is None else cols
+    ou, of = (u64 * 3)(), (f64 * 2)()
+    lib().orc_sparsity_info(u64(rows), u64(cols), _p(rp), _p(ci), ou, of)
+    return {"nnz": int(rp[rows]) if rows else 0, "dimensions": (rows, cols), "sparsity_ratio": of[0], "avg_nnz_per_row": of[1],
+            "max_nnz_per_row": int(ou[0]), "bandwidth": int(ou[1]), "is_banded": bool(ou[2])}
 
 
 def powi(a, b):

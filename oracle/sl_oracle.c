@@ -343,6 +343,76 @@ double orc_spectral_radius_estimate(uint64_t rows, const uint32_t *row_ptr, cons
     return max_radius;
 }
 
+/* ---- the element / iterator / norm side of trait Matrix (matrix/mod.rs:33-41, 74-82, 523-545) ---- */
+
+/* SparseMatrix::get (matrix/mod.rs:383-395): out of bounds -> None, else CSRStorage::get (orc_csr_get above) */
+int orc_matrix_get(uint64_t rows, uint64_t cols, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values,
+                   uint64_t r, uint64_t c, double *out)
+{
+    if (r >= rows || c >= cols) return 0;
+    return orc_csr_get(row_ptr, col_idx, values, rows, r, c, out);
+}
+
+/* CSRStorage::row_iter (sparse.rs:158-176): a row out of bounds is an empty iterator; otherwise the row's pairs in stored order.
+ * Returns the row's length; writes the first min(length, cap) pairs. */
+uint64_t orc_csr_row(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, uint64_t r,
+                     uint64_t cap, uint32_t *cols_out, double *vals_out)
+{
+    if (r >= rows) return 0;
+    const uint64_t start = row_ptr[r], end = row_ptr[r + 1];
+    for (uint64_t k = start; k < end && k - start < cap; ++k) { cols_out[k - start] = col_idx[k]; vals_out[k - start] = values[k]; }
+    return end - start;
+}
+
+/* CSRColIter::next (sparse.rs:279-297): `while self.row < rows { if let Ok(pos) = col_indices[start..end].binary_search(&col)
+ * { yield (row, values[start + pos]) } row += 1 }` — one search per row, so a row that holds the column twice yields ONE pair,
+ * the one the search lands on.  Returns the number of pairs; writes the first min(count, cap). */
+uint64_t orc_csr_col(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, uint64_t c,
+                     uint64_t cap, uint32_t *rows_out, double *vals_out)
+{
+    uint64_t n = 0;
+    for (uint64_t r = 0; r < rows; ++r) {
+        double v;
+        if (c > 0xffffffffull) break;                       /* `col as IndexType` (sparse.rs:181) would wrap; the callers stay in u32 */
+        if (!orc_csr_get(row_ptr, col_idx, values, rows, r, c, &v)) continue;
+        if (n < cap) { rows_out[n] = (uint32_t)r; vals_out[n] = v; }
+        ++n;
+    }
+    return n;
+}
+
+/* Matrix::frobenius_norm (matrix/mod.rs:74-82): `norm_sq += value * value` over row_iter(row), rows ascending; sqrt. */
+double orc_frobenius_norm(uint64_t rows, const uint32_t *row_ptr, const double *values)
+{
+    double norm_sq = 0.0;
+    for (uint64_t r = 0; r < rows; ++r)
+        for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+            double sq = values[k] * values[k];
+            norm_sq = norm_sq + sq;
+        }
+    return sqrt(norm_sq);
+}
+
+/* Matrix::sparsity_info (matrix/mod.rs:523-545) over SparsityInfo::new (types.rs:344-369):
+ * out_u[0] = max_nnz_per_row, out_u[1] = bandwidth (always Some: 0 without entries), out_u[2] = is_banded (bandwidth < rows / 4);
+ * out_f[0] = sparsity_ratio (nnz / (rows * cols), 0 for an empty shape), out_f[1] = avg_nnz_per_row (0 without rows) */
+void orc_sparsity_info(uint64_t rows, uint64_t cols, const uint32_t *row_ptr, const uint32_t *col_idx, uint64_t out_u[3], double out_f[2])
+{
+    const uint64_t nnz = rows ? row_ptr[rows] : 0, total = rows * cols;
+    out_f[0] = total > 0 ? (double)nnz / (double)total : 0.0;
+    out_f[1] = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    uint64_t max_row = 0, max_bw = 0;
+    for (uint64_t r = 0; r < rows; ++r) {
+        const uint64_t len = row_ptr[r + 1] - row_ptr[r];
+        if (len > max_row) max_row = len;
+        for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) {
+            const uint64_t c = col_idx[k], bw = r > c ? r - c : c - r;
+            if (bw > max_bw) max_bw = bw;
+        }
+    }
+    out_u[0] = max_row; out_u[1] = max_bw; out_u[2] = max_bw < rows / 4 ? 1 : 0;
+}
+
 /* f64::powi (neumann.rs:336): rustc lowers it to llvm.powi.f64, which for a run-time exponent calls compiler-rt's
  * __powidf2 — square and multiply, NOT libm pow (third-party arithmetic outside /root/reference: LLVM compiler-rt
  * lib/builtins/powidf2.c, unchanged across the LLVM versions rustc 1.7x ships; restated from its published algorithm). */

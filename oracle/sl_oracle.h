@@ -107,6 +107,16 @@ int orc_diagonal_dominance_factor(uint64_t rows, const uint32_t *row_ptr, const 
                                   const double *values, double *factor);
 /* Matrix::spectral_radius_estimate (matrix/mod.rs:83-100) */
 double orc_spectral_radius_estimate(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values);
+/* the element / iterator / norm side of trait Matrix: get (matrix/mod.rs:383-395), row_iter (sparse.rs:158-176), col_iter
+ * (CSRColIter sparse.rs:273-298), frobenius_norm (matrix/mod.rs:74-82), sparsity_info (matrix/mod.rs:523-545, types.rs:344-369) */
+int orc_matrix_get(uint64_t rows, uint64_t cols, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values,
+                   uint64_t r, uint64_t c, double *out);
+uint64_t orc_csr_row(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, uint64_t r,
+                     uint64_t cap, uint32_t *cols_out, double *vals_out);
+uint64_t orc_csr_col(uint64_t rows, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, uint64_t c,
+                     uint64_t cap, uint32_t *rows_out, double *vals_out);
+double orc_frobenius_norm(uint64_t rows, const uint32_t *row_ptr, const double *values);
+void orc_sparsity_info(uint64_t rows, uint64_t cols, const uint32_t *row_ptr, const uint32_t *col_idx, uint64_t out_u[3], double out_f[2]);
 /* f64::powi as rustc emits it (compiler-rt __powidf2: square and multiply) */
 double orc_powi(double a, int b);
 /* NeumannState::estimate_error_bounds (neumann.rs:321-347): 1 + *bound for Some, 0 for None */

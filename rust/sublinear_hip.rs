@@ -5,8 +5,8 @@
 //! `#[repr(C)]` struct below agrees with include/sublinear_hip.h — names, argument counts, pointer / scalar kinds and widths, field
 //! order — so the shim cannot drift from the ABI it binds.
 //!
-//! Interfaces it implements: `trait SolverAlgorithm` / `trait SolverState` (src/solver/mod.rs:223-351) over `&dyn Matrix`
-//! (src/matrix/mod.rs:25-104); `ForwardPushSolver` / `BackwardPushSolver` over `PushGraph` (src/solver/forward_push.rs:52-301,
+//! Interfaces it implements: `trait Matrix` (src/matrix/mod.rs:25-104) for the device-resident `HipMatrix`; `trait SolverAlgorithm` /
+//! `trait SolverState` (src/solver/mod.rs:223-351) over `&dyn Matrix`; `ForwardPushSolver` / `BackwardPushSolver` over `PushGraph` (src/solver/forward_push.rs:52-301,
 //! src/solver/backward_push.rs:60-311, src/graph/adjacency.rs:199-277).
 //! build.rs: `println!("cargo:rustc-link-lib=dylib=sublinear_hip")` + a `rustc-link-search` for the directory holding the `.so`.
 
@@ -34,6 +34,9 @@ pub struct SlNeumannResult {
 }
 
 #[repr(C)] pub struct SlNeumannState { _private: [u8; 0] }
+#[repr(C)] #[derive(Default)]
+pub struct SlSparsityInfo { nnz: u64, rows: u64, cols: u64, sparsity_ratio: f64, avg_nnz_per_row: f64, max_nnz_per_row: u64, bandwidth: u64,
+                            is_banded: i32, reserved: i32 }
 
 #[link(name = "sublinear_hip")]
 extern "C" {
@@ -47,6 +50,11 @@ extern "C" {
     fn sl_matrix_is_diagonally_dominant(m: *const SlMatrix, is_dd: *mut c_int) -> c_int;
     fn sl_matrix_diagonal_dominance_factor(m: *const SlMatrix, has_factor: *mut c_int, factor: *mut f64) -> c_int;
     fn sl_matrix_spectral_radius_estimate(m: *const SlMatrix, radius: *mut f64) -> c_int;
+    fn sl_matrix_get(m: *const SlMatrix, row: u64, col: u64, found: *mut c_int, value: *mut f64) -> c_int;
+    fn sl_matrix_row(m: *const SlMatrix, row: u64, capacity: u64, cols: *mut u32, values: *mut f64, count: *mut u64) -> c_int;
+    fn sl_matrix_col(m: *const SlMatrix, col: u64, capacity: u64, rows: *mut u32, values: *mut f64, count: *mut u64) -> c_int;
+    fn sl_matrix_frobenius_norm(m: *const SlMatrix, norm: *mut f64) -> c_int;
+    fn sl_matrix_sparsity_info(m: *const SlMatrix, info: *mut SlSparsityInfo) -> c_int;
     fn sl_neumann_options_default(o: *mut SlNeumannOptions);
     fn sl_neumann_solve(m: *const SlMatrix, b: *const f64, initial_guess: *const f64,
                         opts: *const SlNeumannOptions, x_out: *mut f64, term_norms: *mut f64,
@@ -94,43 +102,78 @@ impl HipMatrix {
         Ok(Self { handle: h, key: Self::key_of(matrix) })
     }
 }
-/// The methods of `trait Matrix` (matrix/mod.rs:25-104) that are arithmetic over the stored entries, served from the device copy with the
-/// reference's rounding: multiply_vector (:415-439), multiply_vector_add (:441-465, running sums seeded with `result`, sparse.rs:192-203),
-/// is_diagonally_dominant (:467-485), diagonal_dominance_factor (:487-514), spectral_radius_estimate (:83-100), conditioning_info (:548-556).
-/// (`get` / `row_iter` / `col_iter` stay with the host matrix the device copy was made from.)
+/// `trait Matrix` (matrix/mod.rs:25-104), every method served from the device copy with the reference's rules: multiply_vector
+/// (:415-439), multiply_vector_add (:441-465, running sums seeded with `result`, sparse.rs:192-203), is_diagonally_dominant (:467-485),
+/// diagonal_dominance_factor (:487-514), spectral_radius_estimate (:83-100), conditioning_info (:548-556); get (:383-395 — the entry
+/// CSRStorage::get's binary search lands on, sparse.rs:142-155), row_iter (sparse.rs:158-176), col_iter (CSRColIter sparse.rs:273-298: one
+/// pair per row), frobenius_norm (:74-82, tree-reduced: equal to rounding), sparsity_info (:523-545).  A `HipMatrix` can therefore be
+/// handed to anything that takes `&dyn Matrix` — `NeumannSolver::solve` included — without a host copy of the entries beside it.
 impl HipMatrix {
     fn dims(&self) -> (usize, usize) { (self.key.1, self.key.2) }
-    pub fn multiply_vector(&self, x: &[Precision], result: &mut [Precision]) -> Result<()> {
+    fn pairs(&self, index: usize, by_column: bool) -> Vec<(crate::types::IndexType, Precision)> {
+        let mut n: u64 = 0;
+        let call = |cap: u64, i: *mut u32, v: *mut f64, n: &mut u64| unsafe {
+            if by_column { sl_matrix_col(self.handle, index as u64, cap, i, v, n) } else { sl_matrix_row(self.handle, index as u64, cap, i, v, n) } };
+        if call(0, core::ptr::null_mut(), core::ptr::null_mut(), &mut n) != 0 || n == 0 { return Vec::new(); }
+        let (mut idx, mut val) = (vec![0u32; n as usize], vec![0.0f64; n as usize]);
+        if call(n, idx.as_mut_ptr(), val.as_mut_ptr(), &mut n) != 0 { return Vec::new(); }
+        idx.into_iter().zip(val).collect()
+    }
+}
+impl Matrix for HipMatrix {
+    fn rows(&self) -> usize { self.key.1 }
+    fn cols(&self) -> usize { self.key.2 }
+    fn nnz(&self) -> usize { self.key.3 }
+    fn format_name(&self) -> &'static str { "CSR" }
+    fn get(&self, row: usize, col: usize) -> Option<Precision> {
+        let (mut found, mut v): (c_int, f64) = (0, 0.0);
+        if unsafe { sl_matrix_get(self.handle, row as u64, col as u64, &mut found, &mut v) } == 0 && found != 0 { Some(v) } else { None }
+    }
+    fn row_iter(&self, row: usize) -> Box<dyn Iterator<Item = (crate::types::IndexType, Precision)> + '_> { Box::new(self.pairs(row, false).into_iter()) }
+    fn col_iter(&self, col: usize) -> Box<dyn Iterator<Item = (crate::types::IndexType, Precision)> + '_> { Box::new(self.pairs(col, true).into_iter()) }
+    fn multiply_vector(&self, x: &[Precision], result: &mut [Precision]) -> Result<()> {
         let (rows, cols) = self.dims();
         if x.len() != cols { return Err(SolverError::DimensionMismatch { expected: cols, actual: x.len(), operation: "matrix_vector_multiply".into() }); }
         if result.len() != rows { return Err(SolverError::DimensionMismatch { expected: rows, actual: result.len(), operation: "matrix_vector_multiply".into() }); }
         let st = unsafe { sl_spmv(self.handle, x.as_ptr(), result.as_mut_ptr(), 0 /* SL_ORDER_CSR_SEQUENTIAL */, 0 /* SL_MEM_HOST */) };
         if st != 0 { Err(to_error(st, 0, f64::INFINITY, 0.0)) } else { Ok(()) }
     }
-    pub fn multiply_vector_add(&self, x: &[Precision], result: &mut [Precision]) -> Result<()> {
+    fn multiply_vector_add(&self, x: &[Precision], result: &mut [Precision]) -> Result<()> {
         let (rows, cols) = self.dims();
         if x.len() != cols { return Err(SolverError::DimensionMismatch { expected: cols, actual: x.len(), operation: "matrix_vector_multiply_add".into() }); }
         if result.len() != rows { return Err(SolverError::DimensionMismatch { expected: rows, actual: result.len(), operation: "matrix_vector_multiply_add".into() }); }
         let st = unsafe { sl_spmv_add(self.handle, x.as_ptr(), result.as_mut_ptr(), 0 /* SL_ORDER_CSR_SEQUENTIAL */, 0 /* SL_MEM_HOST */) };
         if st != 0 { Err(to_error(st, 0, f64::INFINITY, 0.0)) } else { Ok(()) }
     }
-    pub fn is_diagonally_dominant(&self) -> bool {
+    fn is_diagonally_dominant(&self) -> bool {
         let mut f: c_int = 0;
         unsafe { sl_matrix_is_diagonally_dominant(self.handle, &mut f) == 0 && f != 0 }
     }
-    pub fn diagonal_dominance_factor(&self) -> Option<Precision> {
+    fn diagonal_dominance_factor(&self) -> Option<Precision> {
         let (mut has, mut f): (c_int, f64) = (0, 0.0);
         if unsafe { sl_matrix_diagonal_dominance_factor(self.handle, &mut has, &mut f) } == 0 && has != 0 { Some(f) } else { None }
     }
-    pub fn spectral_radius_estimate(&self) -> Precision {
+    fn spectral_radius_estimate(&self) -> Precision {
         let mut r = 0.0;
         unsafe { sl_matrix_spectral_radius_estimate(self.handle, &mut r) };
         r
     }
-    pub fn conditioning_info(&self) -> crate::matrix::ConditioningInfo {
-        crate::matrix::ConditioningInfo { condition_number: None, is_diagonally_dominant: self.is_diagonally_dominant(),
-                                          diagonal_dominance_factor: self.diagonal_dominance_factor(),
-                                          spectral_radius: Some(self.spectral_radius_estimate()), is_positive_definite: None }
+    fn frobenius_norm(&self) -> Precision {
+        let mut r = 0.0;
+        unsafe { sl_matrix_frobenius_norm(self.handle, &mut r) };
+        r
+    }
+    fn sparsity_info(&self) -> crate::types::SparsityInfo {
+        let mut i = SlSparsityInfo::default();
+        unsafe { sl_matrix_sparsity_info(self.handle, &mut i) };
+        crate::types::SparsityInfo { nnz: i.nnz as usize, dimensions: (i.rows as usize, i.cols as usize), sparsity_ratio: i.sparsity_ratio,
+                                     avg_nnz_per_row: i.avg_nnz_per_row, max_nnz_per_row: i.max_nnz_per_row as usize,
+                                     bandwidth: Some(i.bandwidth as usize), is_banded: i.is_banded != 0 }
+    }
+    fn conditioning_info(&self) -> crate::types::ConditioningInfo {
+        crate::types::ConditioningInfo { condition_number: None, is_diagonally_dominant: self.is_diagonally_dominant(),
+                                         diagonal_dominance_factor: self.diagonal_dominance_factor(),
+                                         spectral_radius: Some(self.spectral_radius_estimate()), is_positive_definite: None }
     }
 }
 impl Drop for HipMatrix { fn drop(&mut self) { unsafe { sl_matrix_destroy(self.handle) } } }

@@ -36,6 +36,11 @@ class MatrixInfo(C.Structure):
                 ("column_panels", u32), ("reserved", u32)]
 
 
+class SparsityInfo(C.Structure):      # sl_sparsity_info (SparsityInfo, types.rs:114-129)
+    _fields_ = [("nnz", u64), ("rows", u64), ("cols", u64), ("sparsity_ratio", f64), ("avg_nnz_per_row", f64),
+                ("max_nnz_per_row", u64), ("bandwidth", u64), ("is_banded", C.c_int32), ("reserved", C.c_int32)]
+
+
 class NeumannOptions(C.Structure):
     _fields_ = [("tolerance", f64), ("max_iterations", u64), ("max_terms", u64), ("series_tolerance", f64),
                 ("order", i32), ("start", i32), ("residual", i32), ("mem", i32), ("collect_stats", i32),
@@ -97,7 +102,7 @@ class CgResult(C.Structure):
                 ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
 
 
-ABI_VERSION = 3      # SL_ABI_VERSION of include/sublinear_hip.h
+ABI_VERSION = 4      # SL_ABI_VERSION of include/sublinear_hip.h
 
 # every symbol include/sublinear_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -118,6 +123,11 @@ SIGNATURES = {
     "sl_matrix_diagonal_inverse": (C.c_int, [vp, vp, C.c_int]),
     "sl_matrix_diagonal_dominance_factor": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(f64)]),
     "sl_matrix_spectral_radius_estimate": (C.c_int, [vp, C.POINTER(f64)]),
+    "sl_matrix_get": (C.c_int, [vp, u64, u64, C.POINTER(C.c_int), C.POINTER(f64)]),
+    "sl_matrix_row": (C.c_int, [vp, u64, u64, vp, vp, C.POINTER(u64)]),
+    "sl_matrix_col": (C.c_int, [vp, u64, u64, vp, vp, C.POINTER(u64)]),
+    "sl_matrix_frobenius_norm": (C.c_int, [vp, C.POINTER(f64)]),
+    "sl_matrix_sparsity_info": (C.c_int, [vp, C.POINTER(SparsityInfo)]),
     "sl_spmv": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
     "sl_spmv_add": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
     "sl_dot": (C.c_int, [u64, vp, vp, C.POINTER(f64), C.c_int]),

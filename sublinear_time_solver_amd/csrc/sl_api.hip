@@ -518,6 +518,56 @@ sl_status sl_matrix_spectral_radius_estimate(const sl_matrix *m, double *radius)
     return SL_OK;
 }
 
+// ---- trait Matrix: get / row_iter / col_iter / frobenius_norm / sparsity_info (matrix/mod.rs:33-41, 74-82, 523-545) ----
+sl_status sl_matrix_get(const sl_matrix *m, uint64_t row, uint64_t col, int *found, double *value)
+{
+    if (!m || !found || !value) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_ABI_BEGIN
+    return sl_matrix_get_entry(m, row, col, found, value);
+    SL_ABI_END
+}
+
+sl_status sl_matrix_row(const sl_matrix *m, uint64_t row, uint64_t capacity, uint32_t *cols, double *values, uint64_t *count)
+{
+    if (!m || !count || (capacity && (!cols || !values))) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_ABI_BEGIN
+    return sl_matrix_fetch_row(m, row, capacity, cols, values, count);
+    SL_ABI_END
+}
+
+sl_status sl_matrix_col(const sl_matrix *m, uint64_t col, uint64_t capacity, uint32_t *rows, double *values, uint64_t *count)
+{
+    if (!m || !count || (capacity && (!rows || !values))) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_ABI_BEGIN
+    return sl_matrix_fetch_col(m, col, capacity, rows, values, count);
+    SL_ABI_END
+}
+
+sl_status sl_matrix_frobenius_norm(const sl_matrix *m, double *norm)
+{
+    if (!m || !norm) return sl_fail(SL_INVALID_INPUT, "null argument");
+    double sq = 0.0;
+    SL_TRY(sl_matrix_frobenius_sq(m, &sq));
+    *norm = std::sqrt(sq);
+    return SL_OK;
+}
+
+sl_status sl_matrix_sparsity_info(const sl_matrix *m, sl_sparsity_info *info)
+{
+    if (!m || !info) return sl_fail(SL_INVALID_INPUT, "null argument");
+    info->nnz = m->nnz; info->rows = m->n_rows; info->cols = m->n_cols;
+    const uint64_t total = m->n_rows * m->n_cols;                                          // SparsityInfo::new, types.rs:346-358
+    info->sparsity_ratio = total > 0 ? (double)m->nnz / (double)total : 0.0;
+    info->avg_nnz_per_row = m->n_rows > 0 ? (double)m->nnz / (double)m->n_rows : 0.0;
+    info->max_nnz_per_row = m->max_row_nnz;
+    uint64_t bw = 0;
+    SL_TRY(sl_matrix_entry_bandwidth(m, &bw));                                             // Some(max |r - c|) over ALL entries, matrix/mod.rs:535-541
+    info->bandwidth = bw;
+    info->is_banded = bw < m->n_rows / 4 ? 1 : 0;                                          // :542
+    info->reserved = 0;
+    return SL_OK;
+}
+
 sl_status sl_matrix_diagonal_inverse(const sl_matrix *m, double *dinv, sl_mem where)
 {
     if (!m || !dinv) return sl_fail(SL_INVALID_INPUT, "null argument");

@@ -407,6 +407,12 @@ sl_status sl_matrix_diag_pass(const sl_matrix *m, double *d_dinv, unsigned long 
 // ConditioningInfo's row statistics (matrix/mod.rs:487-514, 83-100): h_out[0] = min |a_ii| / sum |a_ij| over rows with off-diagonal
 // weight (+inf when there is none), h_out[1] = max |a_ii| + sum |a_ij|
 sl_status sl_matrix_cond_pass(const sl_matrix *m, double h_out[2]);
+// element / iterator / norm side of trait Matrix (sl_matrix.hip): get, row_iter, col_iter, the sum under frobenius_norm
+sl_status sl_matrix_get_entry(const sl_matrix *m, uint64_t row, uint64_t col, int *found, double *value);
+sl_status sl_matrix_fetch_row(const sl_matrix *m, uint64_t row, uint64_t capacity, uint32_t *cols, double *values, uint64_t *count);
+sl_status sl_matrix_fetch_col(const sl_matrix *m, uint64_t col, uint64_t capacity, uint32_t *rows, double *values, uint64_t *count);
+sl_status sl_matrix_frobenius_sq(const sl_matrix *m, double *sum_sq);
+sl_status sl_matrix_entry_bandwidth(const sl_matrix *m, uint64_t *bandwidth);   // max |row - col| over ALL stored entries (hub rows included)
 // same rules over a plain CSR operator (used for A^T, which has no row-slice layout)
 sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx, const double *val, double *d_dinv,
                            unsigned long long h_status[4]);

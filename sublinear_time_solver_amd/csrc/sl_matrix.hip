@@ -2,6 +2,7 @@
 // diagonal-dominance check, D^-1 extraction, column structure (pattern of A^T).
 // One-off work per matrix (not in the per-iteration metric).
 #include "sl_internal.hpp"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -1211,6 +1212,238 @@ void sl_matrix_row_dominance(const sl_matrix *m, uint64_t row, double out[2])
     hipLaunchKernelGGL(sl_row_dominance_kernel, dim3(1), dim3(1), 0, st, row, m->row_offset, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, buf.as<double>());
     if (hipMemcpyAsync(out, buf.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
         out[0] = out[1] = __builtin_nan("");
+}
+
+// ---- the element / iterator / norm side of trait Matrix (matrix/mod.rs:33-41, 74-82), served from the layouts the matrix already
+// carries: rows of the slice layout by their slots, hub rows by their raw CSR entries.  Nothing here is on a hot path; it is what a
+// caller holding a `&dyn Matrix` may ask of the device-resident matrix without keeping a host copy beside it.
+struct sl_rows_view {
+    uint64_t n_rows;
+    const uint32_t *slice_ptr, *row_len, *cols;
+    const double *vals;
+    const uint32_t *row_ptr, *col_idx;      // raw CSR: only the hub rows (row_len == SL_LONG_SENTINEL) are read from it
+    const double *values;
+};
+static sl_rows_view rows_view(const sl_matrix *m)
+{
+    return sl_rows_view{m->n_rows, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, m->d_row_ptr, m->d_col_idx, m->d_values};
+}
+// CSRStorage::get (sparse.rs:142-155): `col_indices[start..end].binary_search(&col)` — the halving search over the row's column
+// slice; with duplicate columns the entry IT lands on (the same walk as sl_bsearch_diag / orc_csr_get; positions relative to the
+// row's first entry, so the slice layout and the raw CSR entries of a hub row take the same steps)
+__device__ __forceinline__ bool sl_view_get(const sl_rows_view &v, uint64_t i, uint32_t col, double *out)
+{
+    const uint32_t len = v.row_len[i];
+    if (len == SL_LONG_SENTINEL) {
+        uint32_t lo = v.row_ptr[i], hi = v.row_ptr[i + 1];
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2, c = v.col_idx[mid];
+            if (c == col) { *out = v.values[mid]; return true; }
+            if (c < col) lo = mid + 1; else hi = mid;
+        }
+        return false;
+    }
+    const uint64_t s = i >> 6;
+    const uint32_t lane = (uint32_t)(i & 63u), q0 = v.slice_ptr[s], q1 = v.slice_ptr[s + 1];
+    uint32_t lo = 0, hi = len;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2, c = v.cols[sl_col_slot(q0, q1, mid, lane)];
+        if (c == col) { *out = v.vals[sl_val_slot(q0, mid, lane)]; return true; }
+        if (c < col) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+__global__ void sl_get_kernel(sl_rows_view v, uint64_t i, uint32_t col, double *out)      // out[0] = found (1.0 / 0.0), out[1] = value
+{
+    double val = 0.0;
+    const bool f = sl_view_get(v, i, col, &val);
+    out[0] = f ? 1.0 : 0.0; out[1] = val;
+}
+// CSRStorage::row_iter (sparse.rs:158-176): the row's (column, value) pairs in stored order; count[0] = the row's length
+__global__ __launch_bounds__(64) void sl_row_fetch_kernel(sl_rows_view v, uint64_t i, uint32_t cap, uint32_t *cols_out, double *vals_out, uint32_t *count)
+{
+    const uint32_t len = v.row_len[i];
+    if (len == SL_LONG_SENTINEL) {
+        const uint32_t k0 = v.row_ptr[i], n = v.row_ptr[i + 1] - k0;
+        for (uint32_t k = threadIdx.x; k < n && k < cap; k += 64) { cols_out[k] = v.col_idx[k0 + k]; vals_out[k] = v.values[k0 + k]; }
+        if (threadIdx.x == 0) count[0] = n;
+        return;
+    }
+    const uint64_t s = i >> 6;
+    const uint32_t lane = (uint32_t)(i & 63u), q0 = v.slice_ptr[s], q1 = v.slice_ptr[s + 1];
+    for (uint32_t k = threadIdx.x; k < len && k < cap; k += 64) { cols_out[k] = v.cols[sl_col_slot(q0, q1, k, lane)]; vals_out[k] = v.vals[sl_val_slot(q0, k, lane)]; }
+    if (threadIdx.x == 0) count[0] = len;
+}
+// CSRColIter (sparse.rs:273-298): row after row, the entry get(row, col) lands on — at most ONE pair per row even where a row holds
+// the column twice.  Matches are appended in arrival order (the host sorts the pairs by row: rows are unique); count[0] = all matches
+__global__ __launch_bounds__(256) void sl_col_fetch_kernel(sl_rows_view v, uint32_t col, uint32_t cap, uint32_t *rows_out, double *vals_out, uint32_t *count)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < v.n_rows; i += stride) {
+        double val;
+        if (!sl_view_get(v, i, col, &val)) continue;
+        const uint32_t at = atomicAdd(count, 1u);
+        if (at < cap) { rows_out[at] = (uint32_t)i; vals_out[at] = val; }
+    }
+}
+// Matrix::frobenius_norm (matrix/mod.rs:74-82): sum of value * value over all stored entries.  The reference adds them one after the
+// other in row-major order; here every row is summed in its stored order, the rows of a block in a fixed tree, the blocks by
+// sl_frob_final_kernel in a fixed order — deterministic, and equal to the reference's sum to rounding (tests: 1e-12 relative)
+__global__ __launch_bounds__(256) void sl_frob_kernel(sl_rows_view v, uint64_t n_slices, double *partials)
+{
+    __shared__ double red[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + wave;
+    double sum = 0.0;
+    if (s < n_slices) {
+        const uint64_t i = s * 64 + lane;
+        const uint32_t len = i < v.n_rows ? v.row_len[i] : 0u;
+        if (len && len != SL_LONG_SENTINEL) {
+            const uint32_t q0 = v.slice_ptr[s];
+            for (uint32_t k = 0; k < len; ++k) { const double x = v.vals[sl_val_slot(q0, k, lane)]; sum = __dadd_rn(sum, __dmul_rn(x, x)); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum = __dadd_rn(sum, __shfl_xor(sum, o));
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = __dadd_rn(__dadd_rn(red[0], red[1]), __dadd_rn(red[2], red[3]));
+}
+__global__ void sl_long_frob_kernel(uint32_t n_long, const uint32_t *long_rows, const uint32_t *row_ptr, const double *values, double *partials)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_long) return;
+    const uint32_t i = long_rows[t];
+    double sum = 0.0;
+    for (uint32_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) sum = __dadd_rn(sum, __dmul_rn(values[k], values[k]));
+    partials[t] = sum;
+}
+__global__ __launch_bounds__(256) void sl_frob_final_kernel(uint64_t n, const double *partials, double *out)
+{
+    __shared__ double red[256];
+    double sum = 0.0;
+    for (uint64_t k = threadIdx.x; k < n; k += 256) sum = __dadd_rn(sum, partials[k]);
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = __dadd_rn(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// SparsityInfo::bandwidth (matrix/mod.rs:535-541): max |r - c| over ALL stored entries.  sl_matrix::bandwidth is the layout's own figure
+// (slice rows only — the hub rows never enter the band kernel — and "none" for a row range reaching past the last column), so this
+// one is measured on request: integer max, exact in any order
+__global__ __launch_bounds__(256) void sl_bandw_kernel(sl_rows_view v, uint64_t n_slices, uint64_t row_offset, unsigned long long *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const uint64_t i = s * 64 + lane;
+    if (i >= v.n_rows) return;
+    const uint32_t len = v.row_len[i];
+    const uint64_t gi = row_offset + i;
+    uint64_t bw = 0;
+    if (len == SL_LONG_SENTINEL) {
+        for (uint32_t k = v.row_ptr[i]; k < v.row_ptr[i + 1]; ++k) { const uint64_t c = v.col_idx[k], d = gi > c ? gi - c : c - gi; bw = d > bw ? d : bw; }
+    } else {
+        const uint32_t q0 = v.slice_ptr[s], q1 = v.slice_ptr[s + 1];
+        for (uint32_t k = 0; k < len; ++k) { const uint64_t c = v.cols[sl_col_slot(q0, q1, k, lane)], d = gi > c ? gi - c : c - gi; bw = d > bw ? d : bw; }
+    }
+    if (bw) atomicMax(out, (unsigned long long)bw);
+}
+sl_status sl_matrix_entry_bandwidth(const sl_matrix *m, uint64_t *bandwidth)
+{
+    *bandwidth = 0;
+    if (!m->n_slices) return SL_OK;
+    hipStream_t st = sl_context().stream;
+    DevBuf buf;
+    SL_TRY(buf.alloc(sizeof(unsigned long long)));
+    SL_HIP(hipMemsetAsync(buf.p, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(sl_bandw_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, rows_view(m), m->n_slices, m->row_offset, buf.as<unsigned long long>());
+    SL_HIP(hipGetLastError());
+    unsigned long long h = 0;
+    SL_TRY(sl_read_back(&h, buf.p, sizeof(h), st));
+    *bandwidth = h;
+    return SL_OK;
+}
+
+sl_status sl_matrix_get_entry(const sl_matrix *m, uint64_t row, uint64_t col, int *found, double *value)
+{
+    *found = 0; *value = 0.0;
+    if (row >= m->n_rows || col >= m->n_cols || !m->n_slices) return SL_OK;               // SparseMatrix::get, matrix/mod.rs:383-386
+    hipStream_t st = sl_context().stream;
+    DevBuf buf;
+    SL_TRY(buf.alloc(2 * sizeof(double)));
+    hipLaunchKernelGGL(sl_get_kernel, dim3(1), dim3(1), 0, st, rows_view(m), row, (uint32_t)col, buf.as<double>());
+    SL_HIP(hipGetLastError());
+    double h[2];
+    SL_TRY(sl_read_back(h, buf.p, sizeof(h), st));
+    *found = h[0] != 0.0; *value = h[1];
+    return SL_OK;
+}
+
+sl_status sl_matrix_fetch_row(const sl_matrix *m, uint64_t row, uint64_t capacity, uint32_t *cols, double *values, uint64_t *count)
+{
+    *count = 0;
+    if (row >= m->n_rows || !m->n_slices) return SL_OK;                                     // CSRStorage::row_iter: an empty iterator
+    hipStream_t st = sl_context().stream;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(capacity, m->max_row_nnz);
+    DevBuf dc, dv, dn;
+    SL_TRY(dc.alloc((size_t)cap * sizeof(uint32_t))); SL_TRY(dv.alloc((size_t)cap * sizeof(double))); SL_TRY(dn.alloc(sizeof(uint32_t)));
+    hipLaunchKernelGGL(sl_row_fetch_kernel, dim3(1), dim3(64), 0, st, rows_view(m), row, cap, dc.as<uint32_t>(), dv.as<double>(), dn.as<uint32_t>());
+    SL_HIP(hipGetLastError());
+    uint32_t n = 0;
+    SL_TRY(sl_read_back(&n, dn.p, sizeof(n), st));
+    const uint32_t take = std::min(n, cap);
+    if (take) { SL_TRY(sl_read_back(cols, dc.p, (size_t)take * sizeof(uint32_t), st)); SL_TRY(sl_read_back(values, dv.p, (size_t)take * sizeof(double), st)); }
+    *count = n;
+    return SL_OK;
+}
+
+sl_status sl_matrix_fetch_col(const sl_matrix *m, uint64_t col, uint64_t capacity, uint32_t *rows, double *values, uint64_t *count)
+{
+    *count = 0;
+    if (col >= m->n_cols || !m->n_slices || !m->n_rows) return SL_OK;
+    hipStream_t st = sl_context().stream;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((m->n_rows + 255) / 256, 4096);
+    uint32_t cap = (uint32_t)std::min<uint64_t>(capacity, m->n_rows), n = 0;
+    std::vector<uint32_t> hr;
+    std::vector<double> hv;
+    for (int pass = 0; pass < 2; ++pass) {      // a second pass only when the column holds more entries than the caller's buffers: the FIRST `capacity` rows are wanted
+        DevBuf dr, dv, dn;
+        SL_TRY(dr.alloc((size_t)cap * sizeof(uint32_t))); SL_TRY(dv.alloc((size_t)cap * sizeof(double))); SL_TRY(dn.alloc(sizeof(uint32_t)));
+        SL_HIP(hipMemsetAsync(dn.p, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(sl_col_fetch_kernel, dim3(grid), dim3(256), 0, st, rows_view(m), (uint32_t)col, cap, dr.as<uint32_t>(), dv.as<double>(), dn.as<uint32_t>());
+        SL_HIP(hipGetLastError());
+        SL_TRY(sl_read_back(&n, dn.p, sizeof(n), st));
+        if (n > cap) { cap = n; continue; }
+        hr.resize(n); hv.resize(n);
+        if (n) { SL_TRY(sl_read_back(hr.data(), dr.p, (size_t)n * sizeof(uint32_t), st)); SL_TRY(sl_read_back(hv.data(), dv.p, (size_t)n * sizeof(double), st)); }
+        break;
+    }
+    std::vector<uint32_t> order(hr.size());
+    for (uint32_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hr[a] < hr[b]; });          // rows are unique: a total order
+    const uint64_t take = std::min<uint64_t>(capacity, order.size());
+    for (uint64_t k = 0; k < take; ++k) { rows[k] = hr[order[k]]; values[k] = hv[order[k]]; }
+    *count = n;
+    return SL_OK;
+}
+
+sl_status sl_matrix_frobenius_sq(const sl_matrix *m, double *sum_sq)
+{
+    *sum_sq = 0.0;
+    if (!m->n_slices) return SL_OK;
+    hipStream_t st = sl_context().stream;
+    const uint64_t nb = (m->n_slices + 3) / 4, np = nb + m->n_long;
+    DevBuf part, out;
+    SL_TRY(part.alloc(np * sizeof(double))); SL_TRY(out.alloc(sizeof(double)));
+    hipLaunchKernelGGL(sl_frob_kernel, dim3((uint32_t)nb), dim3(256), 0, st, rows_view(m), m->n_slices, part.as<double>());
+    if (m->n_long)
+        hipLaunchKernelGGL(sl_long_frob_kernel, dim3((uint32_t)((m->n_long + 63) / 64)), dim3(64), 0, st, (uint32_t)m->n_long, m->d_long_rows, m->d_row_ptr,
+                           m->d_values, part.as<double>() + nb);
+    hipLaunchKernelGGL(sl_frob_final_kernel, dim3(1), dim3(256), 0, st, np, part.as<double>(), out.as<double>());
+    SL_HIP(hipGetLastError());
+    return sl_read_back(sum_sq, out.p, sizeof(double), st);
 }
 
 // diag of a CSR operator (A^T has the same diagonal as A; used when only CSR arrays exist)

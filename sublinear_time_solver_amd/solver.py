@@ -188,6 +188,54 @@ class SparseMatrix:
                 "diagonal_dominance_factor": self.diagonal_dominance_factor(), "spectral_radius": self.spectral_radius_estimate(),
                 "is_positive_definite": None}
 
+    def get(self, row: int, col: int) -> Optional[float]:
+        """Matrix::get, matrix/mod.rs:33 / :383-395 -> CSRStorage::get sparse.rs:142-155: None out of bounds or where nothing is stored;
+        a row holding the column twice answers with the entry the reference's binary search lands on"""
+        if row < 0 or col < 0:
+            return None
+        found, v = C.c_int(0), C.c_double(0.0)
+        L.check(L.load().sl_matrix_get(self._h, row, col, C.byref(found), C.byref(v)))
+        return v.value if found.value else None
+
+    def row_iter(self, row: int):
+        """Matrix::row_iter, matrix/mod.rs:37 (CSRStorage::row_iter sparse.rs:158-176): (column, value) pairs in stored order; a row out
+        of bounds is empty"""
+        if row < 0:
+            return iter(())
+        lib, n = L.load(), C.c_uint64(0)
+        cap = max(1, int(self.info().max_row_nnz))
+        co, va = np.empty(cap, dtype=np.uint32), np.empty(cap, dtype=np.float64)
+        L.check(lib.sl_matrix_row(self._h, row, cap, L.ptr(co), L.ptr(va), C.byref(n)))
+        return iter(list(zip(co[: n.value].tolist(), va[: n.value].tolist())))
+
+    def col_iter(self, col: int):
+        """Matrix::col_iter, matrix/mod.rs:41 (CSRColIter sparse.rs:273-298): (row, value) pairs, rows ascending, one pair per row"""
+        if col < 0:
+            return iter(())
+        lib, n = L.load(), C.c_uint64(0)
+        L.check(lib.sl_matrix_col(self._h, col, 0, None, None, C.byref(n)))
+        cap = max(1, n.value)
+        ro, va = np.empty(cap, dtype=np.uint32), np.empty(cap, dtype=np.float64)
+        L.check(lib.sl_matrix_col(self._h, col, cap, L.ptr(ro), L.ptr(va), C.byref(n)))
+        return iter(list(zip(ro[: n.value].tolist(), va[: n.value].tolist())))
+
+    def frobenius_norm(self) -> float:
+        """Matrix::frobenius_norm, matrix/mod.rs:74-82 (tree-reduced on the device: equal to the reference's sequential sum to rounding)"""
+        r = C.c_double(0.0)
+        L.check(L.load().sl_matrix_frobenius_norm(self._h, C.byref(r)))
+        return r.value
+
+    def sparsity_info(self) -> dict:
+        """Matrix::sparsity_info, matrix/mod.rs:523-545: the fields of SparsityInfo (types.rs:114-129)"""
+        i = L.SparsityInfo()
+        L.check(L.load().sl_matrix_sparsity_info(self._h, C.byref(i)))
+        return {"nnz": int(i.nnz), "dimensions": (int(i.rows), int(i.cols)), "sparsity_ratio": i.sparsity_ratio, "avg_nnz_per_row": i.avg_nnz_per_row,
+                "max_nnz_per_row": int(i.max_nnz_per_row), "bandwidth": int(i.bandwidth), "is_banded": bool(i.is_banded)}
+
+    def format_name(self) -> str:
+        """Matrix::format_name, matrix/mod.rs:558-565: the storage this matrix was adopted from and keeps the order of"""
+        return "CSR"
+
     def to_csr(self):
         i = self.info()
         rp = np.empty(i.n_rows + 1, dtype=np.uint32)

@@ -25,6 +25,16 @@ int main()
     EXPECT(m.diagonal_dominance_factor().has_value() && *m.diagonal_dominance_factor() == 2.0 && m.spectral_radius_estimate() == 4.0);
     EXPECT(!SparseMatrix::from_triplets({{0, 0, 2.0}, {1, 1, 3.0}}, 2, 2).diagonal_dominance_factor().has_value());     // no off-diagonal weight: None
 
+    {   // get / row_iter / col_iter / frobenius_norm / sparsity_info; KAT sparse.rs:910-920 (test_csr_creation)
+        auto c = SparseMatrix::from_triplets({{0, 0, 1.0}, {0, 2, 2.0}, {1, 1, 3.0}, {2, 0, 4.0}, {2, 2, 5.0}}, 3, 3);
+        EXPECT(c.nnz() == 5 && *c.get(0, 0) == 1.0 && *c.get(0, 2) == 2.0 && *c.get(1, 1) == 3.0 && !c.get(0, 1).has_value() && !c.get(3, 0).has_value());
+        auto row2 = c.row_iter(2), col0 = c.col_iter(0);
+        EXPECT(row2.size() == 2 && row2[0].first == 0 && row2[0].second == 4.0 && row2[1].first == 2 && row2[1].second == 5.0 && c.row_iter(9).empty());
+        EXPECT(col0.size() == 2 && col0[0].first == 0 && col0[0].second == 1.0 && col0[1].first == 2 && col0[1].second == 4.0);
+        EXPECT(c.frobenius_norm() == std::sqrt(55.0) && std::string(c.format_name()) == "CSR");
+        auto si = c.sparsity_info();
+        EXPECT(si.nnz == 5 && si.rows == 3 && si.cols == 3 && si.max_nnz_per_row == 2 && si.bandwidth == 2 && !si.is_banded && si.sparsity_ratio == 5.0 / 9.0);
+    }
     // neumann.rs:572-590 (test_neumann_solver_simple): diagonally dominant 2x2
     auto a = SparseMatrix::from_triplets({{0, 0, 4.0}, {0, 1, 1.0}, {1, 0, 1.0}, {1, 1, 3.0}}, 2, 2, true);
     auto r = NeumannSolver(20, 1e-8).solve(a, {5.0, 4.0}, SolverOptions());

@@ -3,6 +3,12 @@
   Matrix::diagonal_dominance_factor  matrix/mod.rs:487-514                                                           (bit-exact)
   Matrix::spectral_radius_estimate   matrix/mod.rs:83-100                                                            (bit-exact)
   NeumannState::estimate_error_bounds neumann.rs:321-347   (<= 1e-12 relative: the device's norms are tree-reduced; None / Some(0.0) cases exact)
+and (ABI version 4) the element / iterator / norm side of the trait, from the layouts the device keeps — no host copy of the matrix:
+  Matrix::get             matrix/mod.rs:33, :383-395 over CSRStorage::get sparse.rs:142-155 (binary search; duplicates: the entry it lands on)   (exact)
+  Matrix::row_iter        matrix/mod.rs:37 over sparse.rs:158-176                                                                            (exact)
+  Matrix::col_iter        matrix/mod.rs:41 over CSRColIter sparse.rs:273-298 (one pair per row)                                             (exact)
+  Matrix::frobenius_norm  matrix/mod.rs:74-82                                                     (<= 1e-12 relative: tree-reduced)
+  Matrix::sparsity_info   matrix/mod.rs:523-545 over SparsityInfo::new types.rs:344-369                                                    (exact)
 Nothing here reads /root/reference."""
 import numpy as np
 import pytest
@@ -139,3 +145,98 @@ def test_error_bound_on_sdd_systems(gpu, n, k, seed):
     # and it IS a bound on what the truncation left out: ||x - x_inf||_2 for the exact series limit, here taken from a much longer series
     long = O.neumann_solve(rp, ci, va, b, tolerance=1e-30, series_tolerance=1e-300, max_terms=200, max_iterations=200, raise_on_error=False)
     assert np.linalg.norm(o["x"] - long["x"]) <= o["error_bound"]
+
+
+def _with_duplicates(n=700, seed=5):
+    """rows that hold some columns two to five times (from_triplets keeps duplicates as entries of their own, sparse.rs:80-132), the
+    diagonal among them; values all different, so that WHICH duplicate a lookup returns is visible"""
+    rng = np.random.default_rng(seed)
+    tr, tc, tv = [], [], []
+    for i in range(n):
+        cols = rng.choice(n, size=int(rng.integers(1, 12)), replace=False).tolist() + [i]
+        for c in cols:
+            for _ in range(int(rng.integers(1, 6)) if rng.random() < 0.3 else 1):
+                tr.append(i); tc.append(c); tv.append(float(rng.standard_normal()))
+    return O.csr_from_triplets(tr, tc, tv, n, n)
+
+
+ELEMENT_SYSTEMS = dict(SYSTEMS, duplicates=_with_duplicates)
+
+
+def test_get_known_answers_of_the_reference(gpu):
+    # sparse.rs:910-920 (test_csr_creation): hits, a miss inside a row; out of bounds is None (matrix/mod.rs:384-386)
+    m = S.SparseMatrix.from_triplets([(0, 0, 1.0), (0, 2, 2.0), (1, 1, 3.0), (2, 0, 4.0), (2, 2, 5.0)], 3, 3)
+    assert m.nnz() == 5 and m.get(0, 0) == 1.0 and m.get(0, 2) == 2.0 and m.get(1, 1) == 3.0 and m.get(0, 1) is None
+    assert m.get(3, 0) is None and m.get(0, 3) is None and m.get(-1, 0) is None
+    assert list(m.row_iter(2)) == [(0, 4.0), (2, 5.0)] and list(m.row_iter(3)) == [] and list(m.row_iter(1)) == [(1, 3.0)]
+    assert list(m.col_iter(0)) == [(0, 1.0), (2, 4.0)] and list(m.col_iter(1)) == [(1, 3.0)] and list(m.col_iter(7)) == []
+    assert m.frobenius_norm() == np.sqrt(55.0) and m.format_name() == "CSR" and m.is_square()
+    assert m.sparsity_info() == {"nnz": 5, "dimensions": (3, 3), "sparsity_ratio": 5.0 / 9.0, "avg_nnz_per_row": 5.0 / 3.0, "max_nnz_per_row": 2,
+                                 "bandwidth": 2, "is_banded": False}
+    e = S.SparseMatrix.from_triplets([], 4, 6)
+    assert e.get(0, 0) is None and list(e.row_iter(0)) == [] and list(e.col_iter(0)) == [] and e.frobenius_norm() == 0.0
+    assert e.sparsity_info() == {"nnz": 0, "dimensions": (4, 6), "sparsity_ratio": 0.0, "avg_nnz_per_row": 0.0, "max_nnz_per_row": 0, "bandwidth": 0,
+                                 "is_banded": True}           # 0 < 4 / 4
+
+
+@pytest.mark.parametrize("name", sorted(ELEMENT_SYSTEMS))
+def test_get_and_the_iterators_against_the_oracle(gpu, name):
+    rp, ci, va = ELEMENT_SYSTEMS[name]()
+    n = rp.size - 1
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+    rng = np.random.default_rng(23)
+    lens = np.diff(rp.astype(np.int64))
+    rows = sorted(set(rng.integers(0, n, size=24).tolist() + [0, n - 1, int(np.argmax(lens)), int(np.argmin(lens))]))
+    for r in rows:
+        co, vo = O.csr_row(rp, ci, va, r)
+        got = list(m.row_iter(r))
+        assert [c for c, _ in got] == co.tolist() and (bits([v for _, v in got]) == bits(vo)).all(), f"row {r}"
+        # every stored column of the row (duplicates: the one the search lands on), and a few that are not stored
+        for c in sorted(set(co.tolist()))[:40] + rng.integers(0, n, size=4).tolist():
+            want, have = O.matrix_get(rp, ci, va, r, c), m.get(r, c)
+            assert (want is None) == (have is None) and (want is None or bits([want])[0] == bits([have])[0]), f"get({r}, {c}): {have} vs {want}"
+    cols = sorted(set(rng.integers(0, n, size=6).tolist() + [0, n - 1, int(np.bincount(ci, minlength=n).argmax())]))
+    for c in cols:
+        ro, vo = O.csr_col(rp, ci, va, c)
+        got = list(m.col_iter(c))
+        assert [r for r, _ in got] == ro.tolist() and (bits([v for _, v in got]) == bits(vo)).all(), f"column {c}"
+    if name == "duplicates":            # the case that tells the search rule from "first" or "last": at least one lookup must differ from both
+        k = 0
+        for r in range(n):
+            seg = ci[rp[r]:rp[r + 1]]
+            for c in np.unique(seg[np.nonzero(np.diff(seg) == 0)[0]]):
+                idx = np.nonzero(seg == c)[0]
+                if idx.size >= 3 and O.matrix_get(rp, ci, va, r, int(c)) not in (va[rp[r] + idx[0]], va[rp[r] + idx[-1]]):
+                    assert bits([m.get(r, int(c))])[0] == bits([O.matrix_get(rp, ci, va, r, int(c))])[0]
+                    k += 1
+        assert k > 0
+
+
+@pytest.mark.parametrize("name", sorted(ELEMENT_SYSTEMS))
+def test_frobenius_norm_and_sparsity_info(gpu, name):
+    rp, ci, va = ELEMENT_SYSTEMS[name]()
+    n = rp.size - 1
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+    want = O.frobenius_norm(rp, va)
+    assert abs(m.frobenius_norm() - want) <= 1e-12 * want
+    assert m.frobenius_norm() == m.frobenius_norm()                     # deterministic: a fixed tree, no atomics
+    assert m.sparsity_info() == O.sparsity_info(rp, ci)
+
+
+def test_col_iter_with_fewer_slots_than_entries_returns_the_first_rows(gpu):
+    """the C call's capacity contract: *count = all matching rows, the first `capacity` of them (ascending) are written"""
+    import ctypes as C
+    rp, ci, va = _hub_system(n=3000, seed=7)
+    n = rp.size - 1
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+    c = int(np.bincount(ci, minlength=n).argmax())
+    ro, vo = O.csr_col(rp, ci, va, c)
+    assert ro.size > 8
+    lib, cnt = L.load(), C.c_uint64(0)
+    r5, v5 = np.zeros(5, dtype=np.uint32), np.zeros(5)
+    L.check(lib.sl_matrix_col(m._h, c, 5, L.ptr(r5), L.ptr(v5), C.byref(cnt)))
+    assert cnt.value == ro.size and r5.tolist() == ro[:5].tolist() and (bits(v5) == bits(vo[:5])).all()
+    hub = int(np.argmax(np.diff(rp.astype(np.int64))))                  # a hub row: served from the raw CSR entries, not the slice layout
+    c3, w3 = np.zeros(3, dtype=np.uint32), np.zeros(3)
+    L.check(lib.sl_matrix_row(m._h, hub, 3, L.ptr(c3), L.ptr(w3), C.byref(cnt)))
+    assert cnt.value == rp[hub + 1] - rp[hub] and c3.tolist() == ci[rp[hub]:rp[hub] + 3].tolist()

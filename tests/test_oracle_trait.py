@@ -105,3 +105,46 @@ def test_error_bound_analytic_case_and_the_none_and_zero_cases():
     assert O.neumann_error_bound([0.0, 0.0], [0.0, 0.0], 3, True) is None             # 0 / 0 = NaN estimate: `NaN < 1.0` is false => None
     assert O.neumann_error_bound([3.0, 4.0], [3.0, 4.0], 2, True) is None             # estimate 1.0: not < 1.0 => None
     assert O.neumann_error_bound([1.0], [2.0], 0, True) is None and O.neumann_error_bound([1.0], [2.0], 5, False) is None
+
+
+# ---- the element / iterator / norm side of trait Matrix (ABI version 4): the oracle twins the GPU tests compare against ----
+
+def test_get_row_col_known_answers_of_the_reference():
+    """sparse.rs:910-920 (test_csr_creation) + the bounds rule of SparseMatrix::get (matrix/mod.rs:384-386)"""
+    rp, ci, va = O.csr_from_triplets([0, 0, 1, 2, 2], [0, 2, 1, 0, 2], [1.0, 2.0, 3.0, 4.0, 5.0], 3, 3)
+    assert O.matrix_get(rp, ci, va, 0, 0) == 1.0 and O.matrix_get(rp, ci, va, 0, 2) == 2.0 and O.matrix_get(rp, ci, va, 1, 1) == 3.0
+    assert O.matrix_get(rp, ci, va, 0, 1) is None and O.matrix_get(rp, ci, va, 3, 0) is None and O.matrix_get(rp, ci, va, 0, 3) is None
+    co, vo = O.csr_row(rp, ci, va, 2)
+    assert co.tolist() == [0, 2] and vo.tolist() == [4.0, 5.0] and O.csr_row(rp, ci, va, 3)[0].size == 0
+    ro, wo = O.csr_col(rp, ci, va, 0)
+    assert ro.tolist() == [0, 2] and wo.tolist() == [1.0, 4.0] and O.csr_col(rp, ci, va, 1)[0].tolist() == [1]
+    assert O.frobenius_norm(rp, va) == np.sqrt(55.0)
+    assert O.sparsity_info(rp, ci) == {"nnz": 5, "dimensions": (3, 3), "sparsity_ratio": 5.0 / 9.0, "avg_nnz_per_row": 5.0 / 3.0,
+                                       "max_nnz_per_row": 2, "bandwidth": 2, "is_banded": False}
+
+
+def test_a_duplicated_column_answers_with_the_entry_the_halving_search_lands_on():
+    """from_triplets keeps duplicates as entries of their own (sparse.rs:80-132, stable sort); get is
+    `col_indices[start..end].binary_search(&col)` (sparse.rs:150): mid = lo + (hi - lo) / 2 until the column is met"""
+    # row 0: columns [1, 3, 3, 3, 3, 7] with values 10..15: lo = 0, hi = 6 -> mid 3 (column 3) -> the THIRD of the four, value 13
+    rp, ci, va = O.csr_from_triplets([0] * 6, [1, 3, 3, 3, 3, 7], [10.0, 11.0, 12.0, 13.0, 14.0, 15.0], 1, 8)
+    assert ci.tolist() == [1, 3, 3, 3, 3, 7] and va.tolist() == [10.0, 11.0, 12.0, 13.0, 14.0, 15.0]
+    assert O.matrix_get(rp, ci, va, 0, 3, cols=8) == 13.0
+    # col_iter searches each row once: ONE pair for the row, the same entry (CSRColIter::next, sparse.rs:282-296)
+    ro, wo = O.csr_col(rp, ci, va, 3)
+    assert ro.tolist() == [0] and wo.tolist() == [13.0]
+    # row_iter yields all of them, in input order
+    assert O.csr_row(rp, ci, va, 0)[1].tolist() == va.tolist()
+    # the Frobenius norm counts every stored entry, duplicates included
+    assert O.frobenius_norm(rp, va) == np.sqrt(sum(v * v for v in va))
+
+
+def test_sparsity_info_edge_cases():
+    rp, ci, _ = O.csr_from_triplets([], [], [], 4, 6)
+    assert O.sparsity_info(rp, ci, cols=6) == {"nnz": 0, "dimensions": (4, 6), "sparsity_ratio": 0.0, "avg_nnz_per_row": 0.0, "max_nnz_per_row": 0,
+                                               "bandwidth": 0, "is_banded": True}          # 0 < 4 / 4 (matrix/mod.rs:542, integer division)
+    rp, ci, _ = O.csr_from_triplets([0, 7], [0, 6], [1.0, 1.0], 8, 8)
+    i = O.sparsity_info(rp, ci)
+    assert i["bandwidth"] == 1 and i["is_banded"] and i["avg_nnz_per_row"] == 0.25 and i["sparsity_ratio"] == 2.0 / 64.0
+    rp, ci, _ = O.csr_from_triplets([0], [2], [1.0], 8, 8)
+    assert O.sparsity_info(rp, ci)["bandwidth"] == 2 and not O.sparsity_info(rp, ci)["is_banded"]      # 2 < 8 / 4 is false

@@ -110,6 +110,24 @@ def dist_exe(simt_lib, tmp_path_factory):
     return exe
 
 
+def test_c_and_cpp_programs_over_the_abi_under_the_emulator(simt_lib, tmp_path):
+    """the strict-C99 program (tests/c/abi_smoke.c, `gpu` mode: a 3 x 3 solve through the ABI) and the C++ host mirror's own test
+    (tests/cpp/test_host_mirror.cpp: the reference's unit-test values through include/sublinear_solver.hpp, the whole trait Matrix
+    surface included) linked against the emulator library — what test_gpu_cli / test_gpu_parity run against the real one"""
+    link = [f"-L{simt_lib.parent}", "-lsublinear_hip_simt", f"-Wl,-rpath,{simt_lib.parent}"]
+    c_exe, cpp_exe = tmp_path / "abi_smoke", tmp_path / "host_mirror"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c" / "abi_smoke.c"), "-o", str(c_exe), *link, "-lm"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(c_exe), "gpu"], capture_output=True, text=True, timeout=600, env=_env(simt_lib))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    r = subprocess.run(["g++", "-std=c++17", "-O1", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "cpp" / "test_host_mirror.cpp"), "-o", str(cpp_exe), *link],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(cpp_exe)], capture_output=True, text=True, timeout=900, env=_env(simt_lib))
+    assert r.returncode == 0 and "cpp host mirror ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 @pytest.mark.parametrize("transport,halo", [("ipc", ""), ("rccl", ""), ("rccl", "allreduce")])
 @pytest.mark.parametrize("case", ["2 20000 300", "3 50000 700 uneven", "2 30000 1000000000", "4 40000 15000 uneven"])
 def test_one_process_per_rank_under_the_emulator(simt_lib, dist_exe, transport, halo, case):
