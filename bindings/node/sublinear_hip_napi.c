@@ -389,6 +389,37 @@ static napi_value EstimateEntryRandomWalk(napi_env env, napi_callback_info info)
     return o;
 }
 
+/* solveRandomWalk (core/solver.ts:278-357): randomWalkSolve(matrix, b, epsilon, seed) -> { solution, iterations, residualNorm,
+ * converged, totalVariance, numWalks, deviceBytes }; a residual that misses epsilon is reported, the JS class throws as the reference does */
+static napi_value RandomWalkSolve(napi_env env, napi_callback_info info)
+{
+    napi_value argv[4], o, sol;
+    sl_matrix *m;
+    const double *b;
+    size_t nb = 0;
+    double eps, seed, *x;
+    sl_random_walk_result r;
+    sl_matrix_info mi;
+    sl_status st;
+    if (!get_args(env, info, 4, argv)) return NULL;
+    if (!(m = matrix_of(env, argv[0])) || !f64_view(env, argv[1], &b, &nb)) return NULL;
+    if (sl_matrix_get_info(m, &mi) != SL_OK || nb != mi.n_rows) { napi_throw_range_error(env, NULL, "vector length does not match the matrix"); return NULL; }
+    NAPI_OK(napi_get_value_double(env, argv[2], &eps));
+    NAPI_OK(napi_get_value_double(env, argv[3], &seed));
+    if (!(sol = new_f64(env, nb, &x))) return NULL;
+    st = sl_solve_random_walk(m, b, SL_MEM_HOST, eps, (uint32_t)seed, 0, x, NULL, &r);
+    if (st != SL_OK && st != SL_CONVERGENCE_FAILURE) return throw_status(env, st);
+    NAPI_OK(napi_create_object(env, &o));
+    napi_set_named_property(env, o, "solution", sol);
+    set_num(env, o, "iterations", (double)r.iterations);
+    set_num(env, o, "residualNorm", r.residual);
+    set_bool(env, o, "converged", r.converged);
+    set_num(env, o, "totalVariance", r.total_variance);
+    set_num(env, o, "numWalks", (double)r.num_walks);
+    set_num(env, o, "deviceBytes", (double)mi.device_bytes);
+    return o;
+}
+
 static napi_value CgSolve(napi_env env, napi_callback_info info)
 {
     napi_value argv[3], o, sol;
@@ -440,6 +471,7 @@ static napi_value Init(napi_env env, napi_value exports)
         {"forwardPushSouthwell", NULL, ForwardPushSouthwell, NULL, NULL, NULL, napi_default, NULL},
         {"estimateEntry", NULL, EstimateEntry, NULL, NULL, NULL, napi_default, NULL},
         {"estimateEntryRandomWalk", NULL, EstimateEntryRandomWalk, NULL, NULL, NULL, napi_default, NULL},
+        {"randomWalkSolve", NULL, RandomWalkSolve, NULL, NULL, NULL, napi_default, NULL},
         {"cgSolve", NULL, CgSolve, NULL, NULL, NULL, napi_default, NULL},
         {"deviceCount", NULL, DeviceCount, NULL, NULL, NULL, napi_default, NULL},
     };

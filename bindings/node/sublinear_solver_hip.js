@@ -164,13 +164,21 @@ class SublinearSolver {
     if (!analysis.isDiagonallyDominant) throw new SolverError('Matrix is not diagonally dominant', ErrorCodes.NOT_DIAGONALLY_DOMINANT, { analysis });
     const t0 = process.hrtime.bigint();
     const method = this.config.method;
-    if (method === 'random-walk') {
-      throw new SolverError('random-walk full solve is not part of the GPU path; use estimateEntry({method: "random-walk"})', ErrorCodes.INVALID_PARAMETERS);
-    }
     // Neumann needs ROW dominance (neumann.rs:139-170); a column-dominant system goes through the push, which does not
     const push = method !== 'neumann' || analysis.dominanceType !== 'row';
     const b = Float64Array.from(vector);
-    const out = withDeviceMatrix(matrix, push, (h) => {
+    const out = withDeviceMatrix(matrix, push || method === 'random-walk', (h) => {
+      if (method === 'random-walk') {
+        // solveRandomWalk (solver.ts:278-357): max(100, ceil(1 / eps^2)) walks per coordinate, a stream per walk from config.seed
+        // (the reference seeds ONE stream with `seed || Date.now()`); a residual that misses epsilon throws, as there (:335-341)
+        const seed = (this.config.seed !== undefined ? this.config.seed : Date.now()) >>> 0;
+        const w = native.randomWalkSolve(h, b, this.config.epsilon, seed);
+        if (!w.converged) {
+          throw new SolverError('Random walk sampling failed to achieve desired accuracy', ErrorCodes.CONVERGENCE_FAILED,
+                                { finalResidual: w.residualNorm, variance: Math.sqrt(w.totalVariance) });
+        }
+        return { solution: Array.from(w.solution), iterations: w.iterations, residual: w.residualNorm, converged: true, memoryUsed: w.deviceBytes };
+      }
       if (!push) {
         const r = native.neumannSolve(h, b, { tolerance: this.config.epsilon, maxIterations: this.config.maxIterations,
                                               maxTerms: this.config.maxIterations, seriesTolerance: this.config.epsilon });

@@ -35,7 +35,8 @@ extern "C" {
  * (sl_neumann_state_current_term / _solution_rows, sl_backward_push_acl_with_source / _reachability, sl_acl_extrapolated_solution):
  * a library that lacks any of them answers 2 and is refused by the bindings before a symbol lookup can fail. */
 /* 4 (round 5): + the element / iterator / norm side of trait Matrix — sl_matrix_get, sl_matrix_row, sl_matrix_col,
- * sl_matrix_frobenius_norm, sl_matrix_sparsity_info (with the calls of version 3, `impl Matrix for HipMatrix` is complete). */
+ * sl_matrix_frobenius_norm, sl_matrix_sparsity_info (with the calls of version 3, `impl Matrix for HipMatrix` is complete) — and
+ * sl_solve_random_walk, the `random-walk` method of the TS solve(). */
 #define SL_ABI_VERSION 4
 
 /* ---- status codes: 1:1 with SolverError variants (src/error.rs:16-140) ---------- */
@@ -517,8 +518,9 @@ sl_status sl_matrix_transpose(const sl_matrix *m, uint32_t flags, sl_matrix **ou
 
 /* ---- Monte-Carlo branch of estimateEntry ---------------------------------------------
  * TS estimateEntry with method 'random-walk' (src/core/solver.ts:585-601,630-648; walk rule :390-432):
- * numSamples = max(100, ceil(1/epsilon^2)) absorbing walks from `row`, one lane per walk, walk s drawing from
- * its own TS LCG stream createSeededRandom(seed + s) (core/utils.ts:161-168).  num_samples = 0 derives the
+ * numSamples = max(100, ceil(1/epsilon^2)) absorbing walks from `row`, one lane per walk.  All walks draw from the reference's ONE
+ * stream createSeededRandom(seed) (core/utils.ts:161-168), cut into blocks: walk s reads it from position 2048 s (the generator's
+ * own jump-ahead; a walk uses at most 2000 draws), so walk 0 is the reference's first walk draw for draw.  num_samples = 0 derives the
  * count from epsilon.  walk_values (may be NULL) receives the per-walk estimates.  Needs the raw CSR
  * (SL_MATRIX_KEEP_CSR or SL_MATRIX_WITH_TRANSPOSE). */
 typedef struct {
@@ -529,6 +531,26 @@ typedef struct {
 } sl_walk_result;
 sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double epsilon,
                                         uint32_t seed, uint64_t num_samples, double *walk_values, sl_walk_result *result);
+
+/* The `random-walk` METHOD of SublinearSolver.solve — solveRandomWalk, src/core/solver.ts:278-357: every coordinate i estimated by
+ * numWalks = max(100, ceil(1/epsilon^2)) absorbing walks from i (num_walks = 0 derives it; the walk rule of performRandomWalk
+ * :390-432 as above), x[i] = their mean, total_variance = the sum over coordinates of the sample variances (N - 1); then
+ * residual = ||A x - b||_2 and converged = residual < epsilon.  The reference THROWS when it is not (CONVERGENCE_FAILED,
+ * :335-341): SL_CONVERGENCE_FAILURE, with x, variances and *res filled all the same.  Streams: walk w of coordinate i is walk number
+ * i * numWalks + w of the solve and reads createSeededRandom(seed) from that number's block of 2048 draws, as in
+ * sl_estimate_entry_random_walk (the reference walks the stream serially; both forms are in the oracle).  variances (n doubles)
+ * may be NULL.  Needs the raw CSR. */
+typedef struct {
+    uint64_t iterations;      /* coordinates estimated = n (what the reference reports as `iterations`, solver.ts:321, 349) */
+    uint64_t num_walks;       /* per coordinate */
+    double residual;
+    double total_variance;
+    double device_time_ms;
+    int32_t converged;
+    int32_t reserved;
+} sl_random_walk_result;
+sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, sl_mem where, double epsilon, uint32_t seed, uint64_t num_walks,
+                               double *x, double *variances, sl_random_walk_result *res);
 
 /* ---- conjugate gradient behind the same SpMV ------------------------------------------
  * OptimizedConjugateGradientSolver::solve (src/optimized_solver.rs:182-295) == FastConjugateGradient::solve

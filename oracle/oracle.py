@@ -406,6 +406,13 @@ def ts_lcg(seed, count):
     return out
 
 
+def ts_lcg_jump(state, k):
+    """createSeededRandom's state after k draws from `state` (jump-ahead by squaring)"""
+    f = lib().orc_ts_lcg_jump
+    f.restype = u32
+    return int(f(u32(state & 0xFFFFFFFF), u64(k)))
+
+
 def ts_random_walk_estimate(rp, ci, va, b, row, epsilon, seed):
     rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
     n = rp.size - 1
@@ -436,6 +443,19 @@ def cg_solve(rp, ci, va, b, tolerance=1e-6, max_iterations=1000, order=ORDER_SEQ
     if st:
         raise OracleError(st)
     return {"x": x, "iterations": it.value, "residual_norm": res.value, "converged": bool(conv.value), "matvec_count": mv.value}
+
+
+def ts_random_walk_solve(rp, ci, va, b, epsilon, seed, num_walks=0, per_walk_streams=False):
+    """solveRandomWalk (solver.ts:278-357): the reference's one shared stream, or a stream per walk (what the device computes)"""
+    rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
+    n = rp.size - 1
+    x, var = np.zeros(n), np.zeros(n)
+    res, tv = f64(0), f64(0)
+    st = lib().orc_ts_random_walk_solve(u64(n), _p(rp), _p(ci), _p(va), _p(b), f64(epsilon), u32(seed), u64(num_walks), C.c_int(int(per_walk_streams)),
+                                        _p(x), _p(var), C.byref(res), C.byref(tv))
+    if st not in (0, 3):
+        raise OracleError(st)
+    return {"status": st, "x": x, "variances": var, "residual": res.value, "total_variance": tv.value, "converged": st == 0}
 
 
 def ts_random_walk_streams(rp, ci, va, b, row, num_samples, seed):

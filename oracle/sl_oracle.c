@@ -933,6 +933,20 @@ static inline double lcg_next(uint64_t *state)
     *state = (*state * 1664525ull + 1013904223ull) % 0x100000000ull;
     return (double)*state / 4294967296.0;
 }
+/* the generator's state after k draws from `state`: x -> 1664525 x + 1013904223 (mod 2^32) composed k times by squaring.  The
+ * device cuts the reference's ONE stream into blocks of ORC_WALK_STRIDE draws, one block per walk (a walk of at most 1000 steps
+ * uses at most 2000 draws): walk number s starts at orc_ts_lcg_jump(seed, s * ORC_WALK_STRIDE). */
+#define ORC_WALK_STRIDE 2048ull
+uint32_t orc_ts_lcg_jump(uint32_t state, uint64_t k)
+{
+    uint32_t cur_a = 1664525u, cur_c = 1013904223u, acc_a = 1u, acc_c = 0u;
+    for (; k; k >>= 1) {
+        if (k & 1ull) { acc_a = acc_a * cur_a; acc_c = acc_c * cur_a + cur_c; }
+        cur_c = (cur_a + 1u) * cur_c;
+        cur_a = cur_a * cur_a;
+    }
+    return acc_a * state + acc_c;
+}
 void orc_ts_lcg(uint32_t seed, uint64_t count, double *out)
 {
     uint64_t s = seed;
@@ -1034,10 +1048,82 @@ int orc_cg_solve(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, c
 
 /* ---------------------------------------------- (f-3) per-walk-stream MC -- */
 
+/* ---- solveRandomWalk: the `random-walk` method of SublinearSolver.solve (solver.ts:278-357) ----
+ * for i in 0..n: numWalks = max(100, ceil(1 / eps^2)) walks of performRandomWalk (:390-432) from i; solution[i] = their mean,
+ * totalVariance += their sample variance (N - 1); then residual = ||A solution - b||_2 (multiplyMatrixVector, norm2) and
+ * converged = residual < eps — otherwise the reference throws CONVERGENCE_FAILED (ORC_CONVERGENCE_FAILURE; x stays filled).
+ * one_walk: performRandomWalk over the CSR row (see orc_ts_random_walk_estimate for the cumulative-scan argument). */
+static double one_walk(const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, const double *diag, const double *b,
+                       uint64_t start, uint64_t *state)
+{
+    uint64_t cur = start; double value = 0.0;
+    for (int step = 0; step < 1000; ++step) {
+        const double absorb = 1.0 / diag[cur];
+        if (lcg_next(state) < fabs(absorb)) { value = value + b[cur] * absorb; break; }
+        double sum = 0.0;
+        for (uint64_t k = row_ptr[cur]; k < row_ptr[cur + 1]; ++k)
+            if (col_idx[k] != cur) sum = sum + fabs(-values[k] / diag[cur]);
+        if (sum == 0.0) { value = value + b[cur] * absorb; break; }
+        const double rnd = lcg_next(state) * sum;
+        if (rnd <= 0.0) { cur = 0; continue; }
+        double cum = 0.0;
+        const uint64_t row = cur;
+        for (uint64_t k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
+            if (col_idx[k] == row) continue;
+            cum = cum + fabs(-values[k] / diag[row]);
+            if (rnd <= cum) { cur = col_idx[k]; break; }
+        }
+    }
+    return value;
+}
+/* per_walk_streams = 0: the reference as written — ONE stream createSeededRandom(seed) shared by every walk of every coordinate
+ * (serial by construction: where a walk starts in the stream depends on the length of all walks before it).
+ * per_walk_streams = 1: what the device computes — walk w of coordinate i is walk number i * num_walks + w and reads the SAME stream
+ * from position number * ORC_WALK_STRIDE (orc_ts_lcg_jump): the rule of orc_ts_random_walk_streams coordinate after coordinate.
+ * Walk 0 of coordinate 0 is the reference's first walk draw for draw; same estimator, same walk rule, same generator. */
+int orc_ts_random_walk_solve(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, const double *b,
+                             double epsilon, uint32_t seed, uint64_t num_walks, int per_walk_streams,
+                             double *x, double *variances /* [n] or NULL */, double *residual, double *total_variance)
+{
+    double *diag = (double *)malloc((n ? n : 1) * sizeof(double));
+    for (uint64_t i = 0; i < n; ++i) {
+        double d = 0.0;
+        for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) if (col_idx[k] == i) d = values[k];     /* the dense table's a_ii: the last one stored */
+        if (fabs(d) < 1e-15) { free(diag); return ORC_NUMERICAL_INSTABILITY; }                          /* solver.ts:368-371 */
+        diag[i] = d;
+    }
+    if (num_walks == 0) { const double ns = ceil(1.0 / (epsilon * epsilon)); num_walks = ns > 100.0 ? (uint64_t)ns : 100; }
+    double *est = (double *)malloc(num_walks * sizeof(double));
+    uint64_t state = seed;
+    double tv = 0.0;
+    for (uint64_t i = 0; i < n; ++i) {
+        for (uint64_t w = 0; w < num_walks; ++w) {
+            if (per_walk_streams) state = orc_ts_lcg_jump(seed, (i * num_walks + w) * ORC_WALK_STRIDE);
+            est[w] = one_walk(row_ptr, col_idx, values, diag, b, i, &state);
+        }
+        double m = 0.0;
+        for (uint64_t w = 0; w < num_walks; ++w) m = m + est[w];
+        m = m / (double)num_walks;
+        double var = 0.0;
+        for (uint64_t w = 0; w < num_walks; ++w) { const double q = est[w] - m; var = var + q * q; }
+        var = var / (double)(num_walks - 1);
+        x[i] = m; tv = tv + var;
+        if (variances) variances[i] = var;
+    }
+    double *ax = (double *)malloc((n ? n : 1) * sizeof(double));
+    orc_spmv_csr_sequential(n, row_ptr, col_idx, values, x, ax);
+    for (uint64_t i = 0; i < n; ++i) ax[i] = ax[i] - b[i];
+    *residual = orc_l2_norm(n, ax);
+    *total_variance = tv;
+    free(diag); free(est); free(ax);
+    return *residual < epsilon ? ORC_OK : ORC_CONVERGENCE_FAILURE;
+}
+
 /* The data-parallel form of estimateEntry's random-walk branch (src/core/solver.ts:585-601,630-648 over
- * performRandomWalk :390-432): identical walk rule and estimator, but walk s draws from its OWN TS LCG
- * stream createSeededRandom(seed + s) (core/utils.ts:161-168) instead of one stream shared by all walks —
- * a shared stream makes walk s+1 depend on how many numbers walk s consumed, i.e. is inherently serial.
+ * performRandomWalk :390-432): identical walk rule and estimator and the SAME TS LCG stream createSeededRandom(seed)
+ * (core/utils.ts:161-168), cut into blocks: walk s reads it from position s * ORC_WALK_STRIDE (orc_ts_lcg_jump) instead of
+ * where walk s - 1 happened to stop — a position that depends on how many numbers every earlier walk consumed, i.e. is
+ * inherently serial.  Walk 0 is the reference's first walk.
  * values[] (num_samples) receives the per-walk estimates; mean / variance as in the reference (:630-634). */
 int orc_ts_random_walk_streams(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values_a,
                                const double *b, uint64_t start_row, uint64_t num_samples, uint32_t seed,
@@ -1049,7 +1135,7 @@ int orc_ts_random_walk_streams(uint64_t n, const uint32_t *row_ptr, const uint32
         if (fabs(d) < 1e-15) return ORC_NUMERICAL_INSTABILITY;
     }
     for (uint64_t s = 0; s < num_samples; ++s) {
-        uint64_t state = (uint32_t)(seed + (uint32_t)s);
+        uint64_t state = orc_ts_lcg_jump(seed, s * ORC_WALK_STRIDE);
         uint64_t cur = start_row; double value = 0.0;
         for (int step = 0; step < 1000; ++step) {
             double d = 0.0;

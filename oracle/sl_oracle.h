@@ -221,10 +221,16 @@ int orc_ts_forward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *col
 
 /* ---- a15: TS LCG + random-walk estimateEntry (core/utils.ts:161-168, solver.ts:359-432,585-648) ---- */
 void orc_ts_lcg(uint32_t seed, uint64_t count, double *out);
+uint32_t orc_ts_lcg_jump(uint32_t state, uint64_t k);      /* the state k draws further on (the per-walk blocks of the one stream) */
 int orc_ts_random_walk_estimate(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx,
                                 const double *values, const double *b, uint64_t start_row,
                                 double epsilon, uint32_t seed, double *mean, double *variance,
                                 uint64_t *num_samples);
+
+/* solveRandomWalk (solver.ts:278-357): per_walk_streams = 0 the reference's ONE shared stream, 1 = a stream per walk (the device's form) */
+int orc_ts_random_walk_solve(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values, const double *b,
+                             double epsilon, uint32_t seed, uint64_t num_walks, int per_walk_streams,
+                             double *x, double *variances, double *residual, double *total_variance);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,10 @@ pub struct SlNeumannResult {
 
 #[repr(C)] pub struct SlNeumannState { _private: [u8; 0] }
 #[repr(C)] #[derive(Default)]
+pub struct SlMatrixInfo { n_rows: u64, n_cols: u64, nnz: u64, row_offset: u64, padded_nnz: u64, n_slices: u64, device_bytes: u64, bandwidth: u64,
+                          max_row_nnz: u32, min_row_nnz: u32, uniform_width: u32, has_transpose: u32, long_row_threshold: u32, n_long_rows: u32,
+                          column_panels: u32, reserved: u32 }
+#[repr(C)] #[derive(Default)]
 pub struct SlSparsityInfo { nnz: u64, rows: u64, cols: u64, sparsity_ratio: f64, avg_nnz_per_row: f64, max_nnz_per_row: u64, bandwidth: u64,
                             is_banded: i32, reserved: i32 }
 
@@ -50,6 +54,7 @@ extern "C" {
     fn sl_matrix_is_diagonally_dominant(m: *const SlMatrix, is_dd: *mut c_int) -> c_int;
     fn sl_matrix_diagonal_dominance_factor(m: *const SlMatrix, has_factor: *mut c_int, factor: *mut f64) -> c_int;
     fn sl_matrix_spectral_radius_estimate(m: *const SlMatrix, radius: *mut f64) -> c_int;
+    fn sl_matrix_get_info(m: *const SlMatrix, info: *mut SlMatrixInfo) -> c_int;
     fn sl_matrix_get(m: *const SlMatrix, row: u64, col: u64, found: *mut c_int, value: *mut f64) -> c_int;
     fn sl_matrix_row(m: *const SlMatrix, row: u64, capacity: u64, cols: *mut u32, values: *mut f64, count: *mut u64) -> c_int;
     fn sl_matrix_col(m: *const SlMatrix, col: u64, capacity: u64, rows: *mut u32, values: *mut f64, count: *mut u64) -> c_int;
@@ -212,7 +217,16 @@ impl SolverState for HipState {
     fn error_bounds(&self) -> Option<ErrorBounds> {
         if self.last.error_bound >= 0.0 { Some(ErrorBounds::upper_bound_only(self.last.error_bound, crate::types::ErrorBoundMethod::NeumannTruncation)) } else { None }
     }
-    fn memory_usage(&self) -> MemoryInfo { MemoryInfo::default() }
+    /// neumann.rs:219-227 counts its five n-vectors; the device state holds six (b, dinv, rhs, x, two term buffers) and the matrix's
+    /// layouts in HBM are known exactly (`sl_matrix_info.device_bytes`), where the reference leaves `matrix_memory_bytes` a TODO
+    fn memory_usage(&self) -> MemoryInfo {
+        let mut i = SlMatrixInfo::default();
+        unsafe { sl_matrix_get_info(self._matrix.handle, &mut i) };
+        let vectors = self.n * 8 * 6;
+        MemoryInfo { current_usage_bytes: vectors + i.device_bytes as usize, peak_usage_bytes: vectors + i.device_bytes as usize,
+                     matrix_memory_bytes: i.device_bytes as usize, vector_memory_bytes: vectors, workspace_memory_bytes: 0,
+                     allocation_count: 6, deallocation_count: 0 }
+    }
     fn reset(&mut self) { unsafe { sl_neumann_state_reset(self.raw) }; self.last = SlNeumannResult::default(); }     // neumann.rs:367-378
 }
 

@@ -80,6 +80,11 @@ class WalkResult(C.Structure):
     _fields_ = [("estimate", f64), ("variance", f64), ("num_samples", u64), ("device_time_ms", f64)]
 
 
+class RandomWalkResult(C.Structure):     # sl_random_walk_result
+    _fields_ = [("iterations", u64), ("num_walks", u64), ("residual", f64), ("total_variance", f64), ("device_time_ms", f64),
+                ("converged", i32), ("reserved", i32)]
+
+
 class CommInfo(C.Structure):
     _fields_ = [("rank", i32), ("world", i32), ("device", i32), ("transport", i32), ("halo_allreduce", i32), ("ranks_joined", i32),
                 ("failed", i32), ("reserved", i32)]
@@ -179,6 +184,7 @@ SIGNATURES = {
     "sl_estimate_entry": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
     "sl_synth_sdd_device": (C.c_int, [u64, u32, u64, u64, u64, u64, vp, vp, vp, vp]),
     "sl_estimate_entry_random_walk": (C.c_int, [vp, vp, C.c_int, u64, f64, u32, u64, vp, C.POINTER(WalkResult)]),
+    "sl_solve_random_walk": (C.c_int, [vp, vp, C.c_int, f64, u32, u64, vp, vp, C.POINTER(RandomWalkResult)]),
     "sl_cg_options_default": (None, [C.POINTER(CgOptions)]),
     "sl_cg_solve": (C.c_int, [vp, vp, C.POINTER(CgOptions), vp, C.POINTER(CgResult)]),
     "sl_estimate_entry_transposed": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),

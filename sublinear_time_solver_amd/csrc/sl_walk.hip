@@ -3,9 +3,14 @@
 // (:390-432) and createTransitionMatrix (:359-385): absorb[i] = 1/a_ii, T[i][j] = -a_ij/a_ii; a walk from
 // `row` absorbs with probability |absorb[cur]| (value += b[cur] * absorb[cur]) or moves to the first j whose
 // cumulative |T[cur][.]| reaches rand; at most 1000 steps; numSamples = max(100, ceil(1/eps^2)).
-// The reference draws every walk from ONE LCG stream (serial by construction); here walk s owns the stream
-// createSeededRandom(seed + s) (src/core/utils.ts:161-168) — one lane per walk, CSR rows instead of the
-// dense n x n transition table.  Per-walk values are bit-identical to the CPU restatement of the same rule
+// The reference draws every walk from ONE LCG stream createSeededRandom(seed) (src/core/utils.ts:161-168), serial by construction:
+// where a walk starts in the stream depends on the length of every walk before it.  Here the SAME stream is cut into blocks: walk s
+// reads it from position s * SL_WALK_STRIDE (2048 draws: a walk of at most 1000 steps uses at most 2000), reached by the generator's
+// own jump-ahead (an affine map composed by squaring, 32 steps).  Walk 0 is the reference's first walk draw for draw; the others
+// read draws the reference would have reached later or skipped — the same generator, no second source of randomness.  (Round 3's
+// rule, a stream createSeededRandom(seed + s) per walk, put the FIRST draws of consecutive walks 1664525 / 2^32 = 3.9e-4 apart: the
+// first draws of 400 walks covered 15 % of [0, 1) — found by comparing against the serial form, tests/test_gpu_walk.py.)  One lane
+// per walk, CSR rows instead of the dense n x n transition table.  Per-walk values are bit-identical to the CPU restatement of the same rule
 // (tests/test_gpu_walk.py); mean / variance are tree reductions (1e-12 relative).
 // (The estimator is mirrored as behaviour; SURVEY.md Appendix A10 explains why it is not unbiased in general.)
 #include "sl_internal.hpp"
@@ -14,19 +19,35 @@
 #include <cstring>
 #include <vector>
 
+#define SL_WALK_STRIDE 2048ull
+// state after k draws of createSeededRandom from `state`: x -> A x + C (mod 2^32) composed k times by squaring
+__host__ __device__ inline uint32_t walk_lcg_jump(uint32_t state, uint64_t k)
+{
+    uint32_t cur_a = 1664525u, cur_c = 1013904223u, acc_a = 1u, acc_c = 0u;
+    for (; k; k >>= 1) {
+        if (k & 1ull) { acc_a = acc_a * cur_a; acc_c = acc_c * cur_a + cur_c; }
+        cur_c = (cur_a + 1u) * cur_c;
+        cur_a = cur_a * cur_a;
+    }
+    return acc_a * state + acc_c;
+}
 __device__ __forceinline__ double walk_lcg(uint64_t &state)
 {
     state = (state * 1664525ull + 1013904223ull) & 0xffffffffull;
     return __dmul_rn((double)state, 2.3283064365386963e-10);          // / 2^32
 }
 
-__global__ __launch_bounds__(256) void sl_walk_kernel(uint64_t n_walks, uint32_t seed, uint32_t start_row, const uint32_t *row_ptr,
+// per_row = 0: all walks start at start_row, walk s reads the stream from position s * SL_WALK_STRIDE (estimateEntry).
+// per_row = W > 0 (solveRandomWalk, solver.ts:300-326): walk s of this launch belongs to coordinate start_row + s / W and is that
+// coordinate's walk s % W = walk number coordinate * W + s % W of the solve, whatever batch of coordinates the launch holds
+__global__ __launch_bounds__(256) void sl_walk_kernel(uint64_t n_walks, uint32_t seed, uint32_t start_row, uint64_t per_row, const uint32_t *row_ptr,
                                                       const uint32_t *col_idx, const double *val, const double *b, double *values)
 {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n_walks) return;
-    uint64_t state = (uint32_t)(seed + (uint32_t)s);
-    uint32_t cur = start_row;
+    const uint64_t coord = per_row ? start_row + s / per_row : start_row;
+    uint64_t state = walk_lcg_jump(seed, (per_row ? coord * per_row + s % per_row : s) * SL_WALK_STRIDE);
+    uint32_t cur = (uint32_t)coord;
     double value = 0.0;
     for (int step = 0; step < 1000; ++step) {
         const uint32_t k0 = row_ptr[cur], k1 = row_ptr[cur + 1];
@@ -111,7 +132,7 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
     double *d_vals = vbuf.as<double>();
     sl_timer timer;
     SL_TRY(timer.start(s));
-    hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((num_samples + 255) / 256)), dim3(256), 0, s, num_samples, seed, (uint32_t)row,
+    hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((num_samples + 255) / 256)), dim3(256), 0, s, num_samples, seed, (uint32_t)row, (uint64_t)0,
                        m->d_row_ptr, m->d_col_idx, m->d_values, db, d_vals);
     double *scr = static_cast<double *>(sl_scratch(4096 * sizeof(double)));
     sl_status st = SL_OK;
@@ -142,5 +163,97 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
     hipError_t le = hipGetLastError();
     if (st == SL_OK && le != hipSuccess) st = sl_fail(SL_DEVICE_ERROR, "random-walk kernels failed: %s", hipGetErrorString(le));
     return st;
+    SL_ABI_END
+}
+
+
+// ---- solveRandomWalk: the `random-walk` method of SublinearSolver.solve (src/core/solver.ts:278-357) ----------------------------
+// for every coordinate i: numWalks = max(100, ceil(1 / eps^2)) walks from i (the kernel above), solution[i] = their mean,
+// totalVariance += their sample variance (N - 1 denominator); then residual = ||A solution - b||_2, converged = residual < eps, and
+// the reference THROWS when it is not (CONVERGENCE_FAILED, :335-341) — here SL_CONVERGENCE_FAILURE with x and the result filled.
+// Streams: the reference draws all walks of all coordinates from ONE LCG stream (serial by construction); as in estimateEntry above
+// walk w of coordinate i is walk number i * numWalks + w of the solve and reads the stream from that number's block (the CPU checker
+// of the tests restates both this form and the reference's serial walk of the stream).
+// one block per coordinate: mean and sample variance of its W walk values, fixed strided order + fixed tree = deterministic
+__global__ __launch_bounds__(256) void sl_walk_rows_kernel(uint64_t W, const double *values, double *x, double *var)
+{
+    __shared__ double red[256];
+    const double *v = values + (uint64_t)blockIdx.x * W;
+    double acc = 0.0;
+    for (uint64_t k = threadIdx.x; k < W; k += 256) acc = __dadd_rn(acc, v[k]);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = __dadd_rn(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    const double mean = red[0] / (double)W;
+    __syncthreads();
+    acc = 0.0;
+    for (uint64_t k = threadIdx.x; k < W; k += 256) { const double q = __dadd_rn(v[k], -mean); acc = __dadd_rn(acc, __dmul_rn(q, q)); }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = __dadd_rn(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) { x[blockIdx.x] = mean; var[blockIdx.x] = red[0] / (double)(W - 1); }
+}
+
+extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, sl_mem where, double epsilon, uint32_t seed, uint64_t num_walks,
+                                          double *x, double *variances, sl_random_walk_result *res)
+{
+    SL_ABI_BEGIN
+    if (!m || !b || !x || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
+    memset(res, 0, sizeof(*res));
+    if (m->n_rows != m->n_cols || m->row_offset != 0) return sl_fail(SL_INVALID_INPUT, "Matrix must be square");
+    if (!(epsilon > 0.0)) return sl_fail(SL_INVALID_INPUT, "epsilon must be positive");
+    if (!m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "random-walk solve needs the raw CSR (create with SL_MATRIX_KEEP_CSR)");
+    const uint64_t n = m->n_rows;
+    hipStream_t s = sl_context().stream;
+    unsigned long long hs[4];
+    SL_HIP(hipGetLastError());
+    SL_TRY(sl_matrix_diag_pass(m, nullptr, hs));
+    if (hs[0] & 6ull) return sl_fail(SL_NUMERICAL_INSTABILITY, "Zero diagonal at position %llu", (hs[0] & 2ull) ? hs[2] : hs[3]);     // solver.ts:368-371
+    if (num_walks == 0) {
+        const double ns = std::ceil(1.0 / (epsilon * epsilon));             // solver.ts:303
+        num_walks = ns > 100.0 ? (uint64_t)ns : 100;
+    }
+    if (num_walks < 2) return sl_fail(SL_INVALID_INPUT, "at least two walks per coordinate (the sample variance divides by N - 1)");
+    if (num_walks > (1ull << 26)) return sl_fail(SL_INVALID_INPUT, "%llu walks per coordinate (epsilon %g): more than 2^26", (unsigned long long)num_walks, epsilon);
+    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(n, (1ull << 26) / num_walks));      // at most 512 MB of walk values at a time
+    DevBuf bbuf, vbuf, xbuf, varbuf, ybuf;
+    const double *db = b;
+    if (where == SL_MEM_HOST) {
+        SL_TRY(bbuf.alloc(n * 8));
+        SL_HIP(hipMemcpyAsync(bbuf.p, b, n * 8, hipMemcpyHostToDevice, s));
+        db = bbuf.as<double>();
+    }
+    SL_TRY(vbuf.alloc(batch * num_walks * 8)); SL_TRY(xbuf.alloc(n * 8)); SL_TRY(varbuf.alloc(n * 8)); SL_TRY(ybuf.alloc(n * 8));
+    sl_timer timer;
+    SL_TRY(timer.start(s));
+    for (uint64_t i0 = 0; i0 < n; i0 += batch) {
+        const uint64_t rows = std::min(batch, n - i0), walks = rows * num_walks;
+        hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((walks + 255) / 256)), dim3(256), 0, s, walks, seed, (uint32_t)i0, num_walks,
+                           m->d_row_ptr, m->d_col_idx, m->d_values, db, vbuf.as<double>());
+        hipLaunchKernelGGL(sl_walk_rows_kernel, dim3((uint32_t)rows), dim3(256), 0, s, num_walks, vbuf.as<double>(), xbuf.as<double>() + i0, varbuf.as<double>() + i0);
+    }
+    SL_HIP(hipGetLastError());
+    // residual = ||A x - b||_2 (solver.ts:328-333) through the library's own primitives, device-resident
+    SL_TRY(sl_spmv(m, xbuf.as<double>(), ybuf.as<double>(), SL_ORDER_CSR_SEQUENTIAL, SL_MEM_DEVICE));
+    SL_TRY(sl_axpy(n, -1.0, db, ybuf.as<double>(), SL_MEM_DEVICE));
+    double resn = 0.0, tv = 0.0;
+    SL_TRY(sl_l2_norm(n, ybuf.as<double>(), &resn, SL_MEM_DEVICE));
+    {   // totalVariance: the coordinates' variances added in coordinate order, as the reference adds them (:319)
+        std::vector<double> hv(n);
+        if (n) SL_TRY(sl_read_back(hv.data(), varbuf.p, n * 8, s));
+        for (uint64_t i = 0; i < n; ++i) tv += hv[i];
+        if (variances && where == SL_MEM_HOST) memcpy(variances, hv.data(), n * 8);
+    }
+    res->device_time_ms = timer.stop();
+    if (n) {
+        SL_HIP(hipMemcpyAsync(x, xbuf.p, n * 8, where == SL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+        if (variances && where != SL_MEM_HOST) SL_HIP(hipMemcpyAsync(variances, varbuf.p, n * 8, hipMemcpyDeviceToDevice, s));
+        SL_HIP(hipStreamSynchronize(s));
+    }
+    res->iterations = n; res->num_walks = num_walks; res->residual = resn; res->total_variance = tv;
+    res->converged = resn < epsilon ? 1 : 0;
+    if (!res->converged)
+        return sl_fail(SL_CONVERGENCE_FAILURE, "Random walk sampling failed to achieve desired accuracy (final residual %.6g, variance %.6g)", resn, std::sqrt(tv));
+    return SL_OK;
     SL_ABI_END
 }

@@ -580,6 +580,22 @@ def estimate_entry(matrix: SparseMatrix, b, row: int, theta: float = 1e-8, max_r
     return res
 
 
+def random_walk_solve(matrix: SparseMatrix, b, epsilon: float, seed: int, num_walks: int = 0) -> dict:
+    """solveRandomWalk, core/solver.ts:278-357 (the `random-walk` method of SublinearSolver.solve): every coordinate from
+    max(100, ceil(1 / eps^2)) absorbing walks, mean and sample variance per coordinate, residual ||A x - b||_2, converged = residual < eps.
+    Never raises on a missed epsilon (the TS-shaped caller does); the matrix needs its raw CSR (keep_csr / with_transpose)."""
+    b = _f64(b)
+    n = matrix.rows()
+    if b.size != n:
+        raise SolverError(5, f"Vector length {b.size} does not match matrix rows {n}")
+    x, var, res = np.empty(n), np.empty(n), L.RandomWalkResult()
+    st = L.load().sl_solve_random_walk(matrix._h, L.ptr(b), L.SL_MEM_HOST, float(epsilon), seed & 0xFFFFFFFF, int(num_walks), L.ptr(x), L.ptr(var), C.byref(res))
+    if st not in (0, 3):
+        L.check(st)
+    return {"solution": x, "variances": var, "iterations": int(res.iterations), "num_walks": int(res.num_walks), "residual": res.residual,
+            "total_variance": res.total_variance, "converged": bool(res.converged), "device_ms": res.device_time_ms}
+
+
 class QuerySession:
     """Many single-entry queries against one system (ForwardPushSolver::new + query_single_entry,
     forward_push.rs:52-66, 224-231): setup once, then every query costs only the rows its push touches
@@ -683,13 +699,20 @@ class SublinearSolver:
         import time
         t0 = time.perf_counter()
         push = self.method in ("forward-push", "backward-push", "bidirectional")
-        m = _matrix_from_json(matrix, with_transpose=push)
+        m = _matrix_from_json(matrix, with_transpose=push, keep_csr=self.method == "random-walk")
         b = _f64(vector)
         if b.size != m.rows():
             raise SolverError(5, f"Vector length {b.size} does not match matrix rows {m.rows()}")
         if self.method == "random-walk":
-            raise SolverError(10, "random-walk full solve is out of scope for the GPU path (DESIGN.md §8)")
-        if not push:
+            # solveRandomWalk (solver.ts:278-357): max(100, ceil(1 / eps^2)) walks per coordinate; a stream per walk from the seed (the
+            # reference seeds ONE stream with `seed || Date.now()`); a residual that misses epsilon raises as the reference throws (:335-341)
+            import time as _t
+            seed = (self.seed if self.seed is not None else int(_t.time() * 1e3)) & 0xFFFFFFFF
+            rw = random_walk_solve(m, b, self.epsilon, seed)
+            if not rw["converged"]:
+                raise SolverError(3, "Random walk sampling failed to achieve desired accuracy")
+            sol, it, res, conv = rw["solution"], rw["iterations"], rw["residual"], True
+        elif not push:
             ns = NeumannSolver(max_terms=self.max_iterations, series_tolerance=self.epsilon)
             r = ns.solve(m, b, SolverOptions(tolerance=self.epsilon, max_iterations=self.max_iterations))
             sol, it, res, conv = r.solution, r.iterations, r.residual_norm, r.converged

@@ -64,7 +64,7 @@ async function rejects(p, code, re) {
   await rejects(s.solve(notDD, [1, 1]), ErrorCodes.NOT_DIAGONALLY_DOMINANT, /not diagonally dominant/);
   await rejects(s.solve(dense, [1, 2]), ErrorCodes.INVALID_DIMENSIONS, /does not match matrix columns/);
   await rejects(s.estimateEntry(dense, [1, 2, 3], { row: 7, column: 0, epsilon: 1e-6, confidence: 0.95, method: 'neumann' }), ErrorCodes.INVALID_PARAMETERS, /Row index 7 out of bounds/);
-  for (const f of ['createMatrix', 'neumannSolve', 'pushSolve', 'estimateEntry', 'estimateEntryRandomWalk', 'cgSolve']) assert.strictEqual(typeof native[f], 'function');
+  for (const f of ['createMatrix', 'neumannSolve', 'pushSolve', 'estimateEntry', 'estimateEntryRandomWalk', 'randomWalkSolve', 'cgSolve']) assert.strictEqual(typeof native[f], 'function');
 
   if (!onGpu) {
     if (native.deviceCount() === 0) {                       // no CPU fallback: the call must fail loudly
@@ -115,6 +115,15 @@ async function rejects(p, code, re) {
   for (let i = 0; i < 10; i++) for (const [j, v] of [[i - 1, -1], [i, 10], [i + 1, -1]]) if (j >= 0 && j < 10) { tri.rowIndices.push(i); tri.colIndices.push(j); tri.values.push(v); }
   const wt = await seeded.estimateEntry(tri, new Array(10).fill(1), { row: 0, column: 0, epsilon: 0.05, confidence: 0.95, method: 'random-walk' });
   assert(wt.numSamples === 400 && Math.abs(wt.estimate - 0.1) < 1e-9 && wt.confidence === 0.95, JSON.stringify(wt));
+  {   // the `random-walk` METHOD of solve() (solveRandomWalk, solver.ts:278-357): exact where every walk is (a diagonal system: each walk
+      // returns b_i / a_ii), CONVERGENCE_FAILED where the residual misses epsilon (:335-341) — tridiag(-1, 10, -1), b = 1: x = 0.1, ||A x - b|| = 0.57
+    const diag = { rows: 3, cols: 3, format: 'dense', data: [[4, 0, 0], [0, -5, 0], [0, 0, 8]] };
+    const rw = await new SublinearSolver({ method: 'random-walk', epsilon: 0.1, maxIterations: 10, seed: 3 }).solve(diag, [1, 2, 3]);
+    assert(rw.converged && rw.method === 'random-walk' && rw.iterations === 3 && rw.residual < 1e-14, JSON.stringify(rw));
+    [0.25, -0.4, 0.375].forEach((v, i) => assert(Math.abs(rw.solution[i] - v) < 1e-15));
+    await rejects(new SublinearSolver({ method: 'random-walk', epsilon: 0.05, maxIterations: 10, seed: 3 }).solve(tri, new Array(10).fill(1)),
+                  ErrorCodes.CONVERGENCE_FAILED, /Random walk sampling failed to achieve desired accuracy/);
+  }
   {   // G6 (tests/mcp/mcp-tool-tests.js:27-52): 10 x 10 tridiag(-1, 10, -1), b = e0 + e9, epsilon 1e-3 -> 12 pushes, ||r|| = 5.2915e-4
     const t = { rows: 10, cols: 10, format: 'coo', values: [], rowIndices: [], colIndices: [] };
     for (let i = 0; i < 10; i++) for (const [j, v] of [[i - 1, -1], [i, 10], [i + 1, -1]]) if (j >= 0 && j < 10) { t.rowIndices.push(i); t.colIndices.push(j); t.values.push(v); }

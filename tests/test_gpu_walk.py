@@ -1,5 +1,6 @@
-"""Monte-Carlo estimateEntry branch: GPU walks vs the oracle restatement of the same
-per-walk-stream rule — per-walk values bit-identical, mean / variance to 1e-12."""
+"""Monte-Carlo estimateEntry branch and the `random-walk` method of solve(): GPU walks vs the oracle restatement of the
+same rule — the reference's ONE LCG stream cut into a block of 2048 draws per walk — per-walk values bit-identical, mean / variance to
+1e-12; and against the reference as written (the stream walked serially) within Monte-Carlo error."""
 import ctypes as C
 
 import numpy as np
@@ -24,13 +25,15 @@ def _walk(m, b, row, n_samples, seed, eps=0.1):
 
 @pytest.mark.parametrize("n,k,w,seed", [(2000, 8, 0, 42), (5000, 16, 50, 1), (300, 5, 0, 12345)])
 def test_walk_values_bitwise_vs_oracle(gpu, n, k, w, seed):
-    rp, ci, va, b = G.sdd_rows(n, k, seed=3, half_bandwidth=w)
+    rp, ci, va, _ = G.sdd_rows(n, k, seed=3, half_bandwidth=w)
+    b = np.random.default_rng(n).standard_normal(n) * 2.0        # (the generator's own b has b_i / a_ii = 0.1 for every i: every walk would return 0.1)
     m = S.SparseMatrix.from_csr(rp, ci, va, n, n, keep_csr=True)
     N = 20000
     for row in (0, n // 2):
         gv, res = _walk(m, b, row, N, seed)
         ov, om, ovar = O.ts_random_walk_streams(rp, ci, va, b, row, N, seed)
         assert (gv.view(np.uint64) == ov.view(np.uint64)).all(), "per-walk values must be bit-identical"
+        assert np.unique(ov).size > 50
         assert res.num_samples == N
         assert abs(res.estimate - om) <= 1e-12 * max(1.0, abs(om))
         assert abs(res.variance - ovar) <= 1e-12 * max(ovar, om * om)      # both are sums of (v - mean)^2: compare on the scale of mean^2
@@ -54,3 +57,51 @@ def test_walk_sample_count_rule_and_ts_surface(gpu):
     with pytest.raises(S.SolverError) as e:
         _walk(bad, np.ones(2), 0, 10, 1)
     assert e.value.kind == "NumericalInstability"                     # Zero diagonal (solver.ts:368-371)
+
+
+def test_random_walk_solve_against_the_oracle(gpu):
+    """solveRandomWalk (core/solver.ts:278-357), the `random-walk` METHOD of solve(): every coordinate from its own walks.  Against the
+    oracle's per-walk-stream restatement: means / variances / residual to 1e-12 (tree-reduced sums), the verdict and the walk count equal;
+    against the reference AS WRITTEN (one shared stream, oracle per_walk_streams = 0): within Monte-Carlo error, coordinate by coordinate."""
+    n, eps, seed = 60, 0.05, 9
+    rp, ci, va, _ = G.sdd_rows(n, 6, seed=5)
+    b = np.random.default_rng(1).standard_normal(n) * 3.0            # (the generator's own b has b_i / a_ii = 0.1 for every i: all walks equal)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, keep_csr=True)
+    r = S.random_walk_solve(m, b, eps, seed)
+    o = O.ts_random_walk_solve(rp, ci, va, b, eps, seed, per_walk_streams=True)
+    W = 400
+    assert r["num_walks"] == W == max(100, int(np.ceil(1 / eps ** 2))) and r["iterations"] == n
+    assert np.abs(r["solution"] - o["x"]).max() <= 1e-12 * np.abs(o["x"]).max()
+    assert np.abs(r["variances"] - o["variances"]).max() <= 1e-12 * o["variances"].max() and o["variances"].min() > 0
+    assert abs(r["residual"] - o["residual"]) <= 1e-10 * o["residual"] and abs(r["total_variance"] - o["total_variance"]) <= 1e-12 * o["total_variance"]
+    assert r["converged"] == o["converged"]
+    # each coordinate IS the single-entry estimate (sl_estimate_entry_random_walk) seeded where that coordinate's walks begin in the stream
+    for i in (0, 17, n - 1):
+        at = O.ts_lcg_jump(seed, i * W * 2048)
+        gv, res = _walk(m, b, i, W, at)
+        assert abs(res.estimate - r["solution"][i]) <= 1e-12 * abs(res.estimate) and (gv.view(np.uint64) == O.ts_random_walk_streams(rp, ci, va, b, i, W, at)[0].view(np.uint64)).all()
+    # the reference's own single stream: a different sample of the same estimator
+    s = O.ts_random_walk_solve(rp, ci, va, b, eps, seed, per_walk_streams=False)
+    z = np.abs(r["solution"] - s["x"]) / np.sqrt((r["variances"] + s["variances"]) / W)
+    assert z.max() < 6.0 and np.mean(z < 2.0) > 0.8, (z.max(), np.mean(z < 2.0))
+    # reproducible, and the seed matters
+    again = S.random_walk_solve(m, b, eps, seed)
+    assert (again["solution"].view(np.uint64) == r["solution"].view(np.uint64)).all()
+    assert (S.random_walk_solve(m, b, eps, seed + 1)["solution"] != r["solution"]).any()
+
+
+def test_random_walk_method_of_the_ts_surface(gpu):
+    """SublinearSolver({method: 'random-walk'}).solve: converges where the walks are exact (a diagonal system: every walk ends at its
+    start with b_i / a_ii), throws CONVERGENCE_FAILED where the residual misses epsilon (solver.ts:335-341), as the reference does"""
+    d = [4.0, -5.0, 8.0]
+    A = {"rows": 3, "cols": 3, "format": "dense", "data": [[d[0], 0, 0], [0, d[1], 0], [0, 0, d[2]]]}
+    out = S.SublinearSolver(method="random-walk", epsilon=0.1, seed=3).solve(A, [1.0, 2.0, 3.0])
+    assert out["converged"] and out["method"] == "random-walk" and out["iterations"] == 3 and out["residual"] < 1e-15
+    assert np.allclose(out["solution"], [0.25, -0.4, 0.375], rtol=0, atol=1e-16)
+    B = {"rows": 2, "cols": 2, "format": "coo", "values": [4.0, 1.0, 1.0, 3.0], "rowIndices": [0, 0, 1, 1], "colIndices": [0, 1, 0, 1]}
+    with pytest.raises(S.SolverError) as e:
+        S.SublinearSolver(method="random-walk", epsilon=0.05, seed=3).solve(B, [5.0, 4.0])
+    assert e.value.status == 3 and "Random walk sampling failed" in str(e.value)
+    with pytest.raises(S.SolverError) as e:                             # createTransitionMatrix: "Zero diagonal at position 1" (solver.ts:368-371)
+        S.random_walk_solve(S.SparseMatrix.from_triplets([(0, 0, 1.0), (0, 1, 1.0), (1, 0, 1.0)], 2, 2, keep_csr=True), [1.0, 1.0], 0.1, 1)
+    assert e.value.status == 2 and "Zero diagonal at position 1" in str(e.value)

@@ -110,7 +110,7 @@ def dist_exe(simt_lib, tmp_path_factory):
     return exe
 
 
-def test_c_and_cpp_programs_over_the_abi_under_the_emulator(simt_lib, tmp_path):
+def test_c_cpp_and_javascript_programs_over_the_abi_under_the_emulator(simt_lib, tmp_path):
     """the strict-C99 program (tests/c/abi_smoke.c, `gpu` mode: a 3 x 3 solve through the ABI) and the C++ host mirror's own test
     (tests/cpp/test_host_mirror.cpp: the reference's unit-test values through include/sublinear_solver.hpp, the whole trait Matrix
     surface included) linked against the emulator library — what test_gpu_cli / test_gpu_parity run against the real one"""
@@ -126,6 +126,19 @@ def test_c_and_cpp_programs_over_the_abi_under_the_emulator(simt_lib, tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(cpp_exe)], capture_output=True, text=True, timeout=900, env=_env(simt_lib))
     assert r.returncode == 0 and "cpp host mirror ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    # the reference's shipped surface in its own language: the N-API addon + SublinearSolver class (bindings/node), tests/js/surface_test.js
+    # `gpu` mode — every method of solve() (random-walk included), estimateEntry, computePageRank.  The addon asks the loader for
+    # libsublinear_hip.so: the emulator library stands under that name in a directory of its own, found first through LD_LIBRARY_PATH
+    addon = ROOT / "bindings" / "node" / "sublinear_hip.node"
+    if addon.exists():
+        import shutil
+        d = tmp_path / "as_product"
+        d.mkdir()
+        shutil.copy(simt_lib, d / "libsublinear_hip.so")
+        env = _env(simt_lib, LD_LIBRARY_PATH=f"{d}:{os.environ.get('LD_LIBRARY_PATH', '')}")
+        r = subprocess.run(["node", str(ROOT / "tests" / "js" / "surface_test.js"), "gpu"], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "gpu surface ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+        assert _launches(r.stderr)[0] > 0, "the JavaScript surface did not reach the emulator"
 
 
 @pytest.mark.parametrize("transport,halo", [("ipc", ""), ("rccl", ""), ("rccl", "allreduce")])
