@@ -379,6 +379,14 @@ def acl_extrapolated_solution(alpha, estimate, residual):
     return out[: e.size]
 
 
+def acl_combine_with_forward(alpha, b_est, b_res, f_est, f_res):
+    """BackwardPushSolver::combine_with_forward (backward_push.rs:314-333), the reference's order of additions"""
+    be, br, fe, fr = _f(b_est), _f(b_res), _f(f_est), _f(f_res)
+    f = lib().orc_acl_combine_with_forward
+    f.restype = f64
+    return f(u64(be.size), u64(fe.size), f64(alpha), _p(be), _p(br), _p(fe), _p(fr))
+
+
 def csr_transpose(rp, ci, va, ncols=None):
     rp, ci, va = _u32(rp), _u32(ci), _f(va)
     nrows = rp.size - 1

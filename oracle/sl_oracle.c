@@ -924,6 +924,24 @@ int orc_ts_forward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *col
     return st;
 }
 
+/* BackwardPushSolver::combine_with_forward (backward_push.rs:314-333): over i in 0..min(|backward estimate|, |forward estimate|)
+ * three adds per node, one after the other.  (`a * b * alpha` is (a * b) * alpha.) */
+double orc_acl_combine_with_forward(uint64_t n_backward, uint64_t n_forward, double alpha, const double *b_est, const double *b_res,
+                                    const double *f_est, const double *f_res)
+{
+    double total = 0.0;
+    const uint64_t k = n_backward < n_forward ? n_backward : n_forward;
+    for (uint64_t i = 0; i < k; ++i) {
+        double t = b_est[i] * f_est[i];
+        total = total + t;
+        t = b_res[i] * f_est[i]; t = t * alpha;
+        total = total + t;
+        t = b_est[i] * f_res[i]; t = t * alpha;
+        total = total + t;
+    }
+    return total;
+}
+
 /* ------------------------------------------------------------------ a15 -- */
 
 /* createSeededRandom, src/core/utils.ts:161-168.  state*1664525 < 2^53, so the JS

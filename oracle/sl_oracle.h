@@ -219,6 +219,10 @@ int orc_ts_forward_push(uint64_t n, const uint32_t *row_ptr, const uint32_t *col
                         const double *values, const double *b, double epsilon, uint64_t max_iterations,
                         double *x, double *r, orc_ts_push_result *res);
 
+/* BackwardPushSolver::combine_with_forward (backward_push.rs:314-333) */
+double orc_acl_combine_with_forward(uint64_t n_backward, uint64_t n_forward, double alpha, const double *b_est, const double *b_res,
+                                    const double *f_est, const double *f_res);
+
 /* ---- a15: TS LCG + random-walk estimateEntry (core/utils.ts:161-168, solver.ts:359-432,585-648) ---- */
 void orc_ts_lcg(uint32_t seed, uint64_t count, double *out);
 uint32_t orc_ts_lcg_jump(uint32_t state, uint64_t k);      /* the state k draws further on (the per-walk blocks of the one stream) */

@@ -6,7 +6,7 @@
 //! order — so the shim cannot drift from the ABI it binds.
 //!
 //! Interfaces it implements: `trait Matrix` (src/matrix/mod.rs:25-104) for the device-resident `HipMatrix`; `trait SolverAlgorithm` /
-//! `trait SolverState` (src/solver/mod.rs:223-351) over `&dyn Matrix`; `ForwardPushSolver` / `BackwardPushSolver` over `PushGraph` (src/solver/forward_push.rs:52-301,
+//! `trait SolverState` (src/solver/mod.rs:223-351) over `&dyn Matrix`; `OptimizedConjugateGradientSolver` (src/optimized_solver.rs:167-350); `ForwardPushSolver` / `BackwardPushSolver` over `PushGraph` (src/solver/forward_push.rs:52-301,
 //! src/solver/backward_push.rs:60-311, src/graph/adjacency.rs:199-277).
 //! build.rs: `println!("cargo:rustc-link-lib=dylib=sublinear_hip")` + a `rustc-link-search` for the directory holding the `.so`.
 
@@ -357,9 +357,9 @@ fn acl_options(alpha: f64, epsilon: f64, queue_threshold: f64, max_pushes: usize
 }
 
 /// ForwardPushSolver over PushGraph (src/solver/forward_push.rs:52-301, src/graph/adjacency.rs:199-277).  The graph lives on the device;
-/// `solve_single_source` is the data-parallel push on the system sl_push_graph_system assembles (SL_SYSTEM_FORWARD, WITH_TRANSPOSE),
-/// with the spec's skip rule as per-row thresholds theta_u = alpha * epsilon * max(deg_u, 1); `solve_single_source_exact` and
-/// `solve_with_target` run the spec's OWN visiting order (WorkQueue pops) — push_count / nodes_visited / bits as the reference's loop.
+/// `solve_single_source` / `solve_multi_source` / `solve_with_target` / `query_single_entry` run the spec's OWN visiting order (WorkQueue
+/// pops) — push_count / nodes_visited / bits as the reference's loop; the system sl_push_graph_system assembles (SL_SYSTEM_FORWARD,
+/// WITH_TRANSPOSE) is what the data-parallel push and the local single-entry query (`HipForwardPush` above) run on.
 pub struct HipForwardPushSolver { graph: *mut SlPushGraph, system: *mut SlMatrix, config: ForwardPushConfig, n: usize }
 impl HipForwardPushSolver {
     pub fn new(graph: &PushGraph, config: ForwardPushConfig) -> Result<Self> {
@@ -390,6 +390,13 @@ impl HipForwardPushSolver {
         ForwardPushResult { estimate: est, residual: res, push_count: r.push_count as usize, nodes_visited: r.nodes_visited as usize, residual_norm: r.residual_norm }
     }
     pub fn solve_single_source_exact(&self, source: usize) -> ForwardPushResult { self.solve_multi_source_exact(&[source]) }
+    /// the reference's own names (forward_push.rs:67, :125, :224): the spec's visiting order, i.e. its bits
+    pub fn solve_single_source(&self, source: usize) -> ForwardPushResult { self.solve_multi_source_exact(&[source]) }
+    pub fn solve_multi_source(&self, sources: &[usize]) -> ForwardPushResult { self.solve_multi_source_exact(sources) }
+    pub fn query_single_entry(&self, source: usize, target: usize) -> f64 {                                            // :224-231
+        let r = self.solve_single_source(source);
+        if target < r.estimate.len() { r.estimate[target] } else { 0.0 }
+    }
     pub fn extrapolated_solution(&self, result: &ForwardPushResult) -> Vec<f64> {                                        // forward_push.rs:292-301
         let mut x = vec![0.0; result.estimate.len()];
         unsafe { sl_acl_extrapolated_solution(x.len() as u64, self.config.alpha, result.estimate.as_ptr(), result.residual.as_ptr(), x.as_mut_ptr(), 0) };
@@ -447,7 +454,141 @@ impl HipBackwardPushSolver {
         x
     }
 }
+impl HipBackwardPushSolver {
+    /// :314-333 — three adds per node in the reference's order; a left-to-right fold over the callers' host slices stays on the host
+    pub fn combine_with_forward(&self, backward_result: &BackwardPushResult, forward_estimate: &[f64], forward_residual: &[f64]) -> f64 {
+        let alpha = self.config.alpha;
+        (0..backward_result.estimate.len().min(forward_estimate.len())).fold(0.0, |t, i| {
+            let t = t + backward_result.estimate[i] * forward_estimate[i];
+            let t = t + backward_result.residual[i] * forward_estimate[i] * alpha;
+            t + backward_result.estimate[i] * forward_residual[i] * alpha })
+    }
+}
 impl Drop for HipBackwardPushSolver { fn drop(&mut self) { unsafe { sl_push_graph_destroy(self.graph) } } }
+
+/// BidirectionalPushSolver (src/solver/backward_push.rs:337-410) over the two device-resident solvers above: built once, not per query
+/// as the reference rebuilds them (`self.graph.clone()` per call, :360-367); the degrees of the heuristic come from the host PushGraph.
+pub struct HipBidirectionalPushSolver { graph: PushGraph, forward: HipForwardPushSolver, backward: HipBackwardPushSolver }
+impl HipBidirectionalPushSolver {
+    pub fn new(graph: PushGraph, forward_config: ForwardPushConfig, backward_config: BackwardPushConfig) -> Result<Self> {   // :346-357
+        let (forward, backward) = (HipForwardPushSolver::new(&graph, forward_config)?, HipBackwardPushSolver::new(&graph, backward_config)?);
+        Ok(Self { graph, forward, backward })
+    }
+    pub fn solve_bidirectional(&self, source: usize, target: usize) -> f64 {                                           // :359-377
+        let (f, b) = (self.forward.solve_single_source(source), self.backward.solve_single_target(target));
+        self.backward.combine_with_forward(&b, &f.estimate, &f.residual)
+    }
+    pub fn adaptive_solve(&self, source: usize, target: usize) -> f64 {                                                // :380-410
+        let n = self.graph.num_nodes();
+        if source >= n || target >= n { return 0.0; }
+        let (out_s, in_t) = (self.graph.out_degree(source), self.graph.in_degree(target));
+        if out_s > in_t * 2.0 { self.backward.query_transition_probability(source, target) }
+        else if in_t > out_s * 2.0 { self.forward.query_single_entry(source, target) }
+        else { self.solve_bidirectional(source, target) }
+    }
+}
+
+// ---- conjugate gradient behind the same SpMV: OptimizedConjugateGradientSolver (src/optimized_solver.rs:167-350) ----------------------
+#[repr(C)] #[derive(Default)]
+pub struct SlCgOptions { tolerance: f64, max_iterations: u64, order: i32, mem: i32 }
+#[repr(C)] #[derive(Default)]
+pub struct SlCgResult { iterations: u64, matvec_count: u64, residual_norm: f64, total_time_ms: f64, device_time_ms: f64, converged: i32, reserved: i32 }
+#[link(name = "sublinear_hip")]
+extern "C" {
+    fn sl_matrix_create_csr(n_rows: u64, n_cols: u64, nnz: u64, row_ptr: *const u32, col_idx: *const u32, values: *const f64, mem: c_int,
+                            row_offset: u64, flags: u32, out: *mut *mut SlMatrix) -> c_int;
+    fn sl_cg_options_default(o: *mut SlCgOptions);
+    fn sl_cg_solve(m: *const SlMatrix, b: *const f64, opts: *const SlCgOptions, x_out: *mut f64, result: *mut SlCgResult) -> c_int;
+}
+use crate::matrix::sparse::CSRStorage;
+use crate::optimized_solver::{OptimizedSolverConfig, OptimizedSolverResult, OptimizedSolverStats, OptimizedSparseMatrix};
+
+/// Same constructor, `solve`, `get_last_iteration_count` and `solve_with_callback` as the reference's solver (:174-350); the CSR arrays of
+/// the matrix are adopted as they are (`sl_matrix_create_csr`), the loop — x0 = 0, r = p = b, stop at r.r <= tol^2, break at |p.Ap| < 1e-16
+/// (:209-263) — runs on the device with the SpMV in the reference's summation order.  `OptimizedSparseMatrix` keeps its `CSRStorage`
+/// private (:17-21): the one line the crate gains is `pub(crate) fn storage(&self) -> &CSRStorage { &self.storage }` next to `nnz()` (:64).
+pub struct HipConjugateGradientSolver { config: OptimizedSolverConfig, stats: OptimizedSolverStats }
+impl HipConjugateGradientSolver {
+    pub fn new(config: OptimizedSolverConfig) -> Self { Self { config, stats: OptimizedSolverStats::default() } }                 // :174-179
+    pub fn solve(&mut self, matrix: &OptimizedSparseMatrix, b: &[Precision]) -> core::result::Result<OptimizedSolverResult, String> {   // :182-295
+        let (rows, cols) = matrix.dimensions();
+        self.solve_csr(matrix.storage(), rows, cols, b)
+    }
+    pub fn solve_csr(&mut self, a: &CSRStorage, rows: usize, cols: usize, b: &[Precision]) -> core::result::Result<OptimizedSolverResult, String> {
+        if rows != cols { return Err("Matrix must be square".to_string()); }                                                        // :187-190
+        if b.len() != rows { return Err("Right-hand side vector length must match matrix size".to_string()); }                      // :191-193
+        self.stats = OptimizedSolverStats::default();
+        let mut h: *mut SlMatrix = core::ptr::null_mut();
+        let st = unsafe { sl_matrix_create_csr(rows as u64, cols as u64, a.values.len() as u64, a.row_ptr.as_ptr(), a.col_indices.as_ptr(),
+                                               a.values.as_ptr(), 0 /* SL_MEM_HOST */, 0, 0, &mut h) };
+        if st != 0 { return Err(unsafe { std::ffi::CStr::from_ptr(sl_last_error_message()) }.to_string_lossy().into_owned()); }
+        let mut o = SlCgOptions::default();
+        unsafe { sl_cg_options_default(&mut o) };
+        o.tolerance = self.config.tolerance; o.max_iterations = self.config.max_iterations as u64;
+        let (mut x, mut r) = (vec![0.0; rows], SlCgResult::default());
+        let st = unsafe { sl_cg_solve(h, b.as_ptr(), &o, x.as_mut_ptr(), &mut r) };
+        unsafe { sl_matrix_destroy(h) };
+        if st != 0 && st != 3 /* CONVERGENCE_FAILURE: the reference returns Ok(converged = false), :286-293 */ {
+            return Err(unsafe { std::ffi::CStr::from_ptr(sl_last_error_message()) }.to_string_lossy().into_owned());
+        }
+        self.stats.matvec_count = r.matvec_count as usize;                     // dot_product_count / axpy_count stay 0 there too: the loop inlines them
+        self.stats.total_flops = self.stats.matvec_count * a.values.len() * 2 + r.iterations as usize * rows * 6;                  // :276-277
+        if r.total_time_ms > 0.0 {                                                                                                  // :279-283
+            self.stats.average_bandwidth_gbs = (self.stats.total_flops * 8) as f64 / 1e9 / (r.total_time_ms / 1000.0);
+            self.stats.average_gflops = self.stats.total_flops as f64 / (r.total_time_ms * 1e6);
+        }
+        Ok(OptimizedSolverResult { solution: x, residual_norm: r.residual_norm, iterations: r.iterations as usize, converged: r.converged != 0,
+                                   computation_time_ms: r.total_time_ms, performance_stats: self.stats.clone() })
+    }
+    pub fn get_last_iteration_count(&self) -> usize { self.stats.matvec_count }                                                    // :331-333
+    pub fn solve_with_callback<F: FnMut(&OptimizedSolverStats)>(&mut self, matrix: &OptimizedSparseMatrix, b: &[Precision], _chunk_size: usize,
+                                                                 mut callback: F) -> core::result::Result<OptimizedSolverResult, String> {   // :336-350
+        let r = self.solve(matrix, b)?;
+        callback(&r.performance_stats);                                        // (the reference never calls it; once, at the end, here)
+        Ok(r)
+    }
+}
+
+// ---- the crate's public free functions of src/simd_ops.rs (re-exported from lib.rs:83-87), same signatures, on the device ----------
+#[link(name = "sublinear_hip")]
+extern "C" {
+    fn sl_dot(n: u64, x: *const f64, y: *const f64, out: *mut f64, mem: c_int) -> c_int;
+    fn sl_axpy(n: u64, alpha: f64, x: *const f64, y: *mut f64, mem: c_int) -> c_int;
+}
+/// simd_ops::matrix_vector_multiply_simd (:20-88): rows of >= 8 entries in the 4-lane order, shorter ones sequentially (SL_ORDER_SIMD4 = 1).
+/// A one-shot call pays the upload and the layout build; callers that multiply by the same matrix again keep a `HipMatrix`.
+pub fn matrix_vector_multiply_simd(values: &[Precision], col_indices: &[u32], row_ptr: &[u32], x: &[Precision], y: &mut [Precision]) {
+    spmv_once(values, col_indices, row_ptr, x, y, 1 /* SL_ORDER_SIMD4 */)
+}
+/// simd_ops::parallel_matrix_vector_multiply (:201-239): row chunks over threads, each row summed sequentially (SL_ORDER_CSR_SEQUENTIAL = 0);
+/// `num_threads` has no meaning on the device
+pub fn parallel_matrix_vector_multiply(values: &[Precision], col_indices: &[u32], row_ptr: &[u32], x: &[Precision], y: &mut [Precision], _num_threads: Option<usize>) {
+    spmv_once(values, col_indices, row_ptr, x, y, 0 /* SL_ORDER_CSR_SEQUENTIAL */)
+}
+fn spmv_once(values: &[Precision], col_indices: &[u32], row_ptr: &[u32], x: &[Precision], y: &mut [Precision], order: c_int) {
+    let rows = row_ptr.len().saturating_sub(1);
+    assert_eq!(y.len(), rows);
+    let mut h: *mut SlMatrix = core::ptr::null_mut();
+    let st = unsafe { sl_matrix_create_csr(rows as u64, x.len() as u64, values.len() as u64, row_ptr.as_ptr(), col_indices.as_ptr(), values.as_ptr(),
+                                           0 /* SL_MEM_HOST */, 0, 0, &mut h) };
+    assert_eq!(st, 0, "sl_matrix_create_csr failed");                    // the reference indexes out of bounds (a panic) on the same inputs
+    let st = unsafe { sl_spmv(h, x.as_ptr(), y.as_mut_ptr(), order, 0) };
+    unsafe { sl_matrix_destroy(h) };
+    assert_eq!(st, 0, "sl_spmv failed");
+}
+/// simd_ops::dot_product_simd (:116-147) / axpy_simd (:158-189); the device's dot is a fixed tree (the reference's 4-lane sum to rounding)
+pub fn dot_product_simd(x: &[Precision], y: &[Precision]) -> Precision {
+    assert_eq!(x.len(), y.len());
+    let mut out = 0.0;
+    let st = unsafe { sl_dot(x.len() as u64, x.as_ptr(), y.as_ptr(), &mut out, 0) };
+    assert_eq!(st, 0, "sl_dot failed");
+    out
+}
+pub fn axpy_simd(alpha: Precision, x: &[Precision], y: &mut [Precision]) {
+    assert_eq!(x.len(), y.len());
+    let st = unsafe { sl_axpy(x.len() as u64, alpha, x.as_ptr(), y.as_mut_ptr(), 0) };
+    assert_eq!(st, 0, "sl_axpy failed");
+}
 
 // ---- one process per GPU: the communicator and the partitioned NeumannState (src/simd_ops.rs:201-239 is the crate's precedent: row
 // chunks behind one call).  A host that starts N processes drives N GPUs through these alone. -------------------------------------------

@@ -8,6 +8,7 @@
   BackwardPushSolver::{solve_single_target, solve_multi_target, solve_with_source,
       query_transition_probability, reachability_probabilities,
       extrapolated_solution, combine_with_forward}                                      BackwardPushSolver src/solver/backward_push.rs:67-334
+  BidirectionalPushSolver::{solve_bidirectional, adaptive_solve}  BidirectionalPushSolver backward_push.rs:337-410
 
 The reference pushes one node at a time from a priority queue (inherently sequential).  The device runs the
 synchronous form of the same push: personalised PageRank pi_s = alpha e_s^T (I - (1-alpha) P)^-1 is the solution
@@ -106,6 +107,29 @@ class PushGraph:
 
     def in_degree(self, node: int) -> float:
         return float(self.reverse_degrees[node]) if 0 <= node < self.n else 0.0
+
+    def forward_neighbors(self, node: int):
+        """PushGraph::forward_neighbors, adjacency.rs:251-253: (target, weight) pairs of the node's out-edges in stored order"""
+        if not (0 <= node < self.n):
+            return iter(())
+        k0, k1 = int(self.row_ptr[node]), int(self.row_ptr[node + 1])
+        return iter(list(zip(self.col_idx[k0:k1].tolist(), self.weights[k0:k1].tolist())))
+
+    def backward_neighbors(self, node: int):
+        """PushGraph::backward_neighbors, adjacency.rs:256-258: (source, weight) pairs of the node's in-edges — a row of the transposed
+        adjacency (CompressedSparseRow::transpose, graph/mod.rs:92-130: sources ascending, parallel edges in stored order), read from
+        host arrays the graph was given (the device keeps its own transpose for the pushes)"""
+        if not (0 <= node < self.n):
+            return iter(())
+        if "_rev" not in self._cache:                                    # built once on the host from the arrays the graph was given
+            order = np.argsort(self.col_idx, kind="stable")              # stable: sources ascending, parallel edges in stored order
+            src = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(self.row_ptr.astype(np.int64)))
+            ptr = np.zeros(self.n + 1, dtype=np.int64)
+            np.add.at(ptr, self.col_idx.astype(np.int64) + 1, 1)
+            self._cache["_rev"] = (np.cumsum(ptr), src[order], self.weights[order])
+        ptr, src, w = self._cache["_rev"]
+        k0, k1 = int(ptr[node]), int(ptr[node + 1])
+        return iter(list(zip(src[k0:k1].tolist(), w[k0:k1].tolist())))
 
     def system(self, alpha: float, backward: bool, flags: int = L.SL_MATRIX_WITH_TRANSPOSE, dangling_identity: bool = False) -> SparseMatrix:
         """forward: A = I - (1-alpha) P^T ; backward: A = I - (1-alpha) P  (P_uv = w_uv / deg_u; dangling u: P_uu = 1, or — dangling_identity,
@@ -251,9 +275,52 @@ class BackwardPushSolver(_PushBase):
         return float(r.estimate[source]) if 0 <= source < r.estimate.size else 0.0
 
     def combine_with_forward(self, backward_result: PushResult, forward_estimate, forward_residual) -> float:
-        """backward_push.rs:314-333"""
-        a = self.config.alpha
-        k = min(backward_result.estimate.size, len(forward_estimate))
-        be, br = backward_result.estimate[:k], backward_result.residual[:k]
-        fe, fr = np.asarray(forward_estimate)[:k], np.asarray(forward_residual)[:k]
-        return float(np.sum(be * fe + br * fe * a + be * fr * a))
+        """backward_push.rs:314-333: for i in 0..min(len): total += be_i * fe_i; total += br_i * fe_i * alpha; total += be_i * fr_i * alpha —
+        three adds per node, one after the other, and so here: the 3 k terms interleaved in that order and folded left to right
+        (np.add.accumulate is the sequential running sum), not a pairwise np.sum — the reference's bits"""
+        return combine_with_forward(self.config.alpha, backward_result.estimate, backward_result.residual, forward_estimate, forward_residual)
+
+
+def combine_with_forward(alpha: float, backward_estimate, backward_residual, forward_estimate, forward_residual) -> float:
+    """BackwardPushSolver::combine_with_forward, backward_push.rs:314-333, in the reference's order of operations (host-side: the four
+    vectors are the callers' host arrays, and a left-to-right fold has no parallel form that keeps its bits)"""
+    be, br = np.asarray(backward_estimate, dtype=np.float64), np.asarray(backward_residual, dtype=np.float64)
+    fe, fr = np.asarray(forward_estimate, dtype=np.float64), np.asarray(forward_residual, dtype=np.float64)
+    k = min(be.size, fe.size)                                              # `.min(forward_estimate.len())`; the residuals are indexed alike
+    if k == 0:
+        return 0.0
+    terms = np.empty(3 * k)
+    terms[0::3] = be[:k] * fe[:k]
+    terms[1::3] = (br[:k] * fe[:k]) * alpha
+    terms[2::3] = (be[:k] * fr[:k]) * alpha
+    return float(np.add.accumulate(terms)[-1] + 0.0)                       # 0.0 + t0 = t0 exactly (-0.0 + 0.0 = +0.0, as `0.0 + t0` gives)
+
+
+class BidirectionalPushSolver:
+    """BidirectionalPushSolver, backward_push.rs:337-410: a forward solve from the source and a backward solve from the target combined
+    (solve_bidirectional), or whichever single direction starts from the node of much higher degree (adaptive_solve).
+    order="reference" runs both pushes in the spec's visiting order (the bits of the reference's own loop), "synchronous" (default) the
+    data-parallel pushes."""
+
+    def __init__(self, graph: PushGraph, forward_config: ForwardPushConfig | None = None, backward_config: ForwardPushConfig | None = None,
+                 order: str = "synchronous"):
+        self.graph, self.order = graph, order
+        self.forward_config, self.backward_config = forward_config or ForwardPushConfig(), backward_config or BackwardPushConfig()
+
+    def solve_bidirectional(self, source: int, target: int) -> float:                                                  # :359-377
+        f = ForwardPushSolver(self.graph, self.forward_config).solve_single_source(source, order=self.order)
+        bs = BackwardPushSolver(self.graph, self.backward_config)
+        b = bs.solve_single_target(target, order=self.order)
+        return bs.combine_with_forward(b, f.estimate, f.residual)
+
+    def adaptive_solve(self, source: int, target: int) -> float:                                                       # :380-410
+        n = self.graph.num_nodes()
+        if not (0 <= source < n) or not (0 <= target < n):
+            return 0.0
+        out_s, in_t = self.graph.out_degree(source), self.graph.in_degree(target)
+        if out_s > in_t * 2.0:                                             # start from the target (backward push)
+            r = BackwardPushSolver(self.graph, self.backward_config).solve_single_target(target, order=self.order)
+            return float(r.estimate[source])                               # query_transition_probability, :228-235
+        if in_t > out_s * 2.0:                                             # start from the source (forward push)
+            return float(ForwardPushSolver(self.graph, self.forward_config).solve_single_source(source, order=self.order).estimate[target])   # query_single_entry, :224-231
+        return self.solve_bidirectional(source, target)

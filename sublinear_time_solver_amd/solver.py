@@ -730,6 +730,32 @@ class SublinearSolver:
         return {"solution": sol, "iterations": it, "residual": res, "converged": conv, "method": self.method,
                 "computeTime": elapsed_ms, "memoryUsed": int(m.info().device_bytes)}
 
+    def compute_pagerank(self, adjacency, damping: float = 0.85, epsilon: float = 1e-6, max_iterations: int = 1000, personalized=None) -> np.ndarray:
+        """computePageRank(adjacency, {damping, epsilon, maxIterations, personalized?}) — core/solver.ts:664-722: the system
+        (I - d P^T) x = (1 - d) / n (or `personalized`), P_ji = adj[j][i] / out_j for out_j > 0 (a dangling node's column stays zero, as there),
+        solved by THIS solver's method with the call's epsilon / maxIterations; returns the solution vector.  The system is assembled in
+        CSR (the reference builds a dense n x n table)."""
+        from . import io, generators as G
+        if not (0.0 <= damping <= 1.0):                                  # ValidationUtils.validateRange, core/utils.ts
+            raise SolverError(4, "damping must be between 0 and 1")
+        if not (epsilon > 0):
+            raise SolverError(4, "epsilon must be a positive number")
+        r, c, v, rows, cols = io.matrix_to_triplets(adjacency)
+        if rows != cols:
+            raise SolverError(5, "Adjacency matrix must be square")
+        import scipy.sparse as sp
+        A = sp.csr_matrix((np.asarray(v, dtype=np.float64), (np.asarray(r, dtype=np.int64), np.asarray(c, dtype=np.int64))), shape=(rows, cols))
+        A.sum_duplicates()
+        A.sort_indices()
+        rp, ci, va, b = G.pagerank_system(rows, A.indptr.astype(np.uint32), A.indices.astype(np.uint32), A.data, damping)
+        if personalized is not None:
+            b = _f64(personalized)
+            if b.size != rows:
+                raise SolverError(5, f"Vector length {b.size} does not match matrix rows {rows}")
+        m = SparseMatrix.from_csr(rp, ci, va, rows, rows, with_transpose=True, keep_csr=True)
+        inner = SublinearSolver(method=self.method, epsilon=epsilon, max_iterations=max_iterations, timeout=self.timeout, seed=self.seed, push_order=self.push_order)
+        return inner.solve(m, b)["solution"]
+
     def estimate_entry(self, matrix, vector, row: int, column: int = 0, epsilon: Optional[float] = None,
                        confidence: float = 0.95, method: str = "neumann") -> dict:
         """estimateEntry(matrix, vector, {row, column, epsilon, confidence, method}) -> {estimate,

@@ -143,6 +143,31 @@ def test_g9_gpu_pagerank_matches_the_reference_power_iteration(gpu):
         assert abs(e.estimate - ref[top]) <= 1e-12
 
 
+def test_compute_pagerank_of_the_ts_surface(gpu):
+    """SublinearSolver.compute_pagerank = computePageRank (core/solver.ts:664-722): adjacency in the TS wire format, the system assembled
+    in CSR, solved by the solver's own method; against the same goldens, plus the reference's argument checks"""
+    from pathlib import Path
+    z = np.load(Path(__file__).resolve().parent / "golden" / "reference_pagerank.npz")
+    key = str(z["__cases"][0])
+    n, d = int(z[f"{key}__n"][0]), float(z[f"{key}__damping"][0])
+    adj = {"rows": n, "cols": n, "format": "coo", "values": z[f"{key}__vals"].tolist(), "rowIndices": z[f"{key}__rows"].astype(int).tolist(),
+           "colIndices": z[f"{key}__cols"].astype(int).tolist()}
+    ref = z[f"{key}__pagerank"]
+    for method in ("forward-push", "bidirectional"):          # (I - d P^T is COLUMN dominant: the Neumann path wants row dominance, neumann.rs:139-170)
+        x = S.SublinearSolver(method=method, epsilon=1e-14, max_iterations=100000, push_order="synchronous").compute_pagerank(adj, damping=d, epsilon=1e-14, max_iterations=100000)
+        assert np.abs(x - ref).max() <= 1e-11, (method, np.abs(x - ref).max())
+    # personalised right-hand side: linear in it
+    e0 = np.zeros(n); e0[0] = 1.0
+    s = S.SublinearSolver(method="forward-push", push_order="synchronous")
+    x0 = s.compute_pagerank(adj, damping=d, epsilon=1e-14, max_iterations=100000, personalized=e0)
+    x2 = s.compute_pagerank(adj, damping=d, epsilon=1e-14, max_iterations=100000, personalized=2.0 * e0)
+    assert np.abs(x2 - 2.0 * x0).max() <= 1e-12 and x0[0] > 0
+    with pytest.raises(S.SolverError, match="damping must be between 0 and 1"):
+        s.compute_pagerank(adj, damping=1.5)
+    with pytest.raises(S.SolverError, match="Adjacency matrix must be square"):
+        s.compute_pagerank({"rows": 2, "cols": 3, "format": "dense", "data": [[0, 1, 0], [1, 0, 0]]})
+
+
 def test_index_only_stream_of_column_constant_operators_keeps_the_bits(gpu):
     """SL_PW_INDEX_ONLY=1: for I - (1 - alpha) P^T of an UNWEIGHTED graph every off-diagonal entry of column u is -(1 - alpha) / deg_u and
     the diagonal is exactly 1; the dense push rounds then run the paced kernel on the index words of its stream alone and gather the
