@@ -513,6 +513,47 @@ public:
         x.resize(r.estimate.size());
         return x;
     }
+    // :314-333 — three additions per node, one after the other, in the reference's order (a left-to-right fold over host vectors)
+    Precision combine_with_forward(const BackwardPushResult &backward_result, const std::vector<Precision> &forward_estimate,
+                                   const std::vector<Precision> &forward_residual) const
+    {
+        Precision total = 0.0;
+        const size_t k = std::min(backward_result.estimate.size(), forward_estimate.size());
+        for (size_t i = 0; i < k; ++i) {
+            total += backward_result.estimate[i] * forward_estimate[i];
+            total += backward_result.residual[i] * forward_estimate[i] * config_.alpha;
+            total += backward_result.estimate[i] * forward_residual[i] * config_.alpha;
+        }
+        return total;
+    }
+};
+
+// BidirectionalPushSolver (backward_push.rs:337-410): forward from the source, backward from the target, combined — or the single
+// direction that starts from the node of much higher degree
+class BidirectionalPushSolver {
+public:
+    BidirectionalPushSolver(const PushGraph &graph, ForwardPushConfig forward_config = {}, BackwardPushConfig backward_config = {})
+        : graph_(graph), forward_(graph, forward_config), backward_(graph, backward_config) {}
+    Precision solve_bidirectional(size_t source, size_t target) const                                                                       // :359-377
+    {
+        const ForwardPushResult f = forward_.solve_single_source(source);
+        const BackwardPushResult b = backward_.solve_single_target(target);
+        return backward_.combine_with_forward(b, f.estimate, f.residual);
+    }
+    Precision adaptive_solve(size_t source, size_t target) const                                                                            // :380-410
+    {
+        const size_t n = graph_.num_nodes();
+        if (source >= n || target >= n) return 0.0;
+        const Precision out_s = graph_.out_degree(source), in_t = graph_.in_degree(target);
+        if (out_s > in_t * 2.0) return backward_.query_transition_probability(source, target);
+        if (in_t > out_s * 2.0) return forward_.query_single_entry(source, target);
+        return solve_bidirectional(source, target);
+    }
+
+private:
+    const PushGraph &graph_;
+    ForwardPushSolver forward_;
+    BackwardPushSolver backward_;
 };
 
 // Many single-entry queries against one system: ForwardPushSolver::new(graph, config) once, query_single_entry per
@@ -553,6 +594,36 @@ public:
 private:
     sl_query_session *q_ = nullptr;
 };
+
+// The crate's public free functions of src/simd_ops.rs (re-exported from lib.rs:83-87), the reference's argument order, on the device.
+// A one-shot product pays the upload and the layout build; multiply by the same matrix again through SparseMatrix.
+inline void spmv_once(const std::vector<Precision> &values, const std::vector<IndexType> &col_indices, const std::vector<IndexType> &row_ptr,
+                      const std::vector<Precision> &x, std::vector<Precision> &y, sl_order order)
+{
+    const size_t rows = row_ptr.empty() ? 0 : row_ptr.size() - 1;
+    if (y.size() != rows) throw SolverError(SL_DIMENSION_MISMATCH, "matrix_vector_multiply: y");
+    SparseMatrix::from_csr(row_ptr, col_indices, values, rows, x.size()).multiply_vector(x, y, order);
+}
+// simd_ops::matrix_vector_multiply_simd (:20-88): rows of >= 8 entries in the 4-lane order, shorter ones sequentially
+inline void matrix_vector_multiply_simd(const std::vector<Precision> &values, const std::vector<IndexType> &col_indices, const std::vector<IndexType> &row_ptr,
+                                        const std::vector<Precision> &x, std::vector<Precision> &y) { spmv_once(values, col_indices, row_ptr, x, y, SL_ORDER_SIMD4); }
+// simd_ops::parallel_matrix_vector_multiply (:201-239): row chunks, every row summed sequentially; the thread count has no meaning here
+inline void parallel_matrix_vector_multiply(const std::vector<Precision> &values, const std::vector<IndexType> &col_indices, const std::vector<IndexType> &row_ptr,
+                                            const std::vector<Precision> &x, std::vector<Precision> &y, std::optional<size_t> = std::nullopt)
+{ spmv_once(values, col_indices, row_ptr, x, y, SL_ORDER_CSR_SEQUENTIAL); }
+// simd_ops::dot_product_simd (:116-147; the device's sum is a fixed tree: the 4-lane sum to rounding) / axpy_simd (:158-189)
+inline Precision dot_product_simd(const std::vector<Precision> &x, const std::vector<Precision> &y)
+{
+    if (x.size() != y.size()) throw SolverError(SL_DIMENSION_MISMATCH, "dot_product: lengths differ");
+    double out = 0.0;
+    check(sl_dot(x.size(), x.data(), y.data(), &out, SL_MEM_HOST));
+    return out;
+}
+inline void axpy_simd(Precision alpha, const std::vector<Precision> &x, std::vector<Precision> &y)
+{
+    if (x.size() != y.size()) throw SolverError(SL_DIMENSION_MISMATCH, "axpy: lengths differ");
+    check(sl_axpy(x.size(), alpha, x.data(), y.data(), SL_MEM_HOST));
+}
 
 // OptimizedConjugateGradientSolver (optimized_solver.rs:167-295; config defaults :119-127) / FastConjugateGradient
 // (fast_solver.rs:110-178) over sl_cg_solve

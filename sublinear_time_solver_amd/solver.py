@@ -695,7 +695,9 @@ class SublinearSolver:
             raise SolverError(4, "epsilon must be positive")
         self.method, self.epsilon, self.max_iterations, self.timeout, self.seed = method, epsilon, max_iterations, timeout, seed
 
-    def solve(self, matrix, vector) -> dict:
+    def solve(self, matrix, vector, progress_callback=None) -> dict:
+        """solve(matrix, vector, progressCallback?) — core/solver.ts:58-111; the callback gets one report {iteration, residual, elapsed} when the
+        device loop has ended (the loop runs on the device: there is no per-iteration host turn to report from)"""
         import time
         t0 = time.perf_counter()
         push = self.method in ("forward-push", "backward-push", "bidirectional")
@@ -727,6 +729,8 @@ class SublinearSolver:
         elapsed_ms = (time.perf_counter() - t0) * 1e3
         if self.timeout and elapsed_ms > self.timeout:               # TimeoutController.checkTimeout, core/utils.ts:319-325 (measured per solve)
             raise SolverError(3, f"Operation timed out after {self.timeout}ms")
+        if progress_callback is not None:
+            progress_callback({"iteration": it, "residual": res, "elapsed": elapsed_ms})
         return {"solution": sol, "iterations": it, "residual": res, "converged": conv, "method": self.method,
                 "computeTime": elapsed_ms, "memoryUsed": int(m.info().device_bytes)}
 

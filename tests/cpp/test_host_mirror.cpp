@@ -35,6 +35,17 @@ int main()
         auto si = c.sparsity_info();
         EXPECT(si.nnz == 5 && si.rows == 3 && si.cols == 3 && si.max_nnz_per_row == 2 && si.bandwidth == 2 && !si.is_banded && si.sparsity_ratio == 5.0 / 9.0);
     }
+    {   // simd_ops free functions (lib.rs:83-87) with the reference's own unit-test values: simd_ops.rs:259-286
+        std::vector<double> yy(2);
+        matrix_vector_multiply_simd({2.0, 1.0, 1.0, 3.0}, {0, 1, 0, 1}, {0, 2, 4}, {1.0, 2.0}, yy);
+        EXPECT(yy[0] == 4.0 && yy[1] == 7.0);
+        parallel_matrix_vector_multiply({2.0, 1.0, 1.0, 3.0}, {0, 1, 0, 1}, {0, 2, 4}, {1.0, 2.0}, yy);
+        EXPECT(yy[0] == 4.0 && yy[1] == 7.0);
+        EXPECT(dot_product_simd({1.0, 2.0, 3.0, 4.0}, {5.0, 6.0, 7.0, 8.0}) == 70.0);
+        std::vector<double> ay = {1.0, 1.0, 1.0, 1.0};
+        axpy_simd(2.0, {1.0, 2.0, 3.0, 4.0}, ay);
+        EXPECT(ay[0] == 3.0 && ay[1] == 5.0 && ay[2] == 7.0 && ay[3] == 9.0);
+    }
     // neumann.rs:572-590 (test_neumann_solver_simple): diagonally dominant 2x2
     auto a = SparseMatrix::from_triplets({{0, 0, 4.0}, {0, 1, 1.0}, {1, 0, 1.0}, {1, 1, 3.0}}, 2, 2, true);
     auto r = NeumannSolver(20, 1e-8).solve(a, {5.0, 4.0}, SolverOptions());
@@ -106,6 +117,13 @@ int main()
         const std::vector<double> reach = bps.reachability_probabilities(3), extra = bps.extrapolated_solution(bfull);
         for (int i = 0; i < 4; ++i) EXPECT(reach[i] == extra[i] && reach[i] == bfull.estimate[i] + 0.15 * bfull.residual[i]);
         EXPECT(bps.solve_multi_target({3, 1}).push_count > 0);
+        {   // combine_with_forward / BidirectionalPushSolver (backward_push.rs:314-410): the CPU checker's value for source 0, target 3 of the
+            // fixture (200 forward + 305 backward pushes, the reference's order of additions); no degree dominates there: adaptive = bidirectional
+            const ForwardPushResult f0 = fps.solve_single_source(0);
+            EXPECT(f0.push_count == 200 && bps.combine_with_forward(bfull, f0.estimate, f0.residual) == 0.13230768829166403);
+            BidirectionalPushSolver bi(g);
+            EXPECT(bi.solve_bidirectional(0, 3) == 0.13230768829166403 && bi.adaptive_solve(0, 3) == 0.13230768829166403 && bi.adaptive_solve(0, 9) == 0.0);
+        }
         auto e = PushGraph::from_edges(5, {{0, 1, 1.0}, {1, 2, 1.0}, {2, 3, 1.0}, {7, 1, 1.0}});     // the invalid edge is skipped
         EXPECT(e.num_edges() == 3 && ForwardPushSolver(e).solve_single_source(0).estimate[4] == 0.0);
     }

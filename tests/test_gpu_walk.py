@@ -95,7 +95,9 @@ def test_random_walk_method_of_the_ts_surface(gpu):
     start with b_i / a_ii), throws CONVERGENCE_FAILED where the residual misses epsilon (solver.ts:335-341), as the reference does"""
     d = [4.0, -5.0, 8.0]
     A = {"rows": 3, "cols": 3, "format": "dense", "data": [[d[0], 0, 0], [0, d[1], 0], [0, 0, d[2]]]}
-    out = S.SublinearSolver(method="random-walk", epsilon=0.1, seed=3).solve(A, [1.0, 2.0, 3.0])
+    seen = []
+    out = S.SublinearSolver(method="random-walk", epsilon=0.1, seed=3).solve(A, [1.0, 2.0, 3.0], progress_callback=seen.append)
+    assert len(seen) == 1 and seen[0]["iteration"] == 3 and seen[0]["residual"] == out["residual"]
     assert out["converged"] and out["method"] == "random-walk" and out["iterations"] == 3 and out["residual"] < 1e-15
     assert np.allclose(out["solution"], [0.25, -0.4, 0.375], rtol=0, atol=1e-16)
     B = {"rows": 2, "cols": 2, "format": "coo", "values": [4.0, 1.0, 1.0, 3.0], "rowIndices": [0, 0, 1, 1], "colIndices": [0, 1, 0, 1]}
