@@ -92,6 +92,26 @@ public:
                                              with_transpose ? SL_MATRIX_WITH_TRANSPOSE : SL_MATRIX_DEFAULT, &h));
         return SparseMatrix(h, rows, cols);
     }
+    // SparseMatrix::from_dense (matrix/mod.rs:204-223: row-major data, zeros not stored), identity (:226-229), diagonal (:232-239)
+    static SparseMatrix from_dense(const std::vector<Precision> &data, size_t rows, size_t cols)
+    {
+        if (data.size() != rows * cols) throw SolverError(SL_DIMENSION_MISMATCH, "dense_to_sparse_conversion");
+        std::vector<Triplet> t;
+        for (size_t i = 0; i < data.size(); ++i) if (data[i] != 0.0) t.emplace_back(i / cols, i % cols, data[i]);
+        return from_triplets(t, rows, cols);
+    }
+    static SparseMatrix identity(size_t size)
+    {
+        std::vector<Triplet> t;
+        for (size_t i = 0; i < size; ++i) t.emplace_back(i, i, 1.0);
+        return from_triplets(t, size, size);
+    }
+    static SparseMatrix diagonal(const std::vector<Precision> &diag)
+    {
+        std::vector<Triplet> t;
+        for (size_t i = 0; i < diag.size(); ++i) if (diag[i] != 0.0) t.emplace_back(i, i, diag[i]);
+        return from_triplets(t, diag.size(), diag.size());
+    }
     // adopt CSRStorage arrays (sparse.rs:16-23)
     static SparseMatrix from_csr(const std::vector<IndexType> &row_ptr, const std::vector<IndexType> &col_indices,
                                  const std::vector<Precision> &values, size_t rows, size_t cols, bool with_transpose = false)

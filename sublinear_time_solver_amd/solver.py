@@ -115,6 +115,17 @@ class SparseMatrix:
         return cls.from_triplets(zip(rr.tolist(), cc.tolist(), a[rr, cc].tolist()), rows, cols, **kw)
 
     @classmethod
+    def identity(cls, size: int, **kw):
+        """SparseMatrix::identity, matrix/mod.rs:226-229"""
+        return cls.from_triplets(((i, i, 1.0) for i in range(size)), size, size, **kw)
+
+    @classmethod
+    def diagonal(cls, diag, **kw):
+        """SparseMatrix::diagonal, matrix/mod.rs:232-239: zero entries of `diag` are not stored"""
+        d = _f64(diag)
+        return cls.from_triplets(((i, i, float(v)) for i, v in enumerate(d) if v != 0.0), d.size, d.size, **kw)
+
+    @classmethod
     def from_scipy(cls, A, **kw):
         A = A.tocsr()
         A.sort_indices()

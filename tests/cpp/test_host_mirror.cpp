@@ -35,6 +35,16 @@ int main()
         auto si = c.sparsity_info();
         EXPECT(si.nnz == 5 && si.rows == 3 && si.cols == 3 && si.max_nnz_per_row == 2 && si.bandwidth == 2 && !si.is_banded && si.sparsity_ratio == 5.0 / 9.0);
     }
+    {   // from_dense / identity / diagonal (matrix/mod.rs:204-239)
+        auto dn = SparseMatrix::from_dense({2.0, 0.0, 1.0, 3.0}, 2, 2);
+        EXPECT(dn.nnz() == 3 && *dn.get(1, 0) == 1.0 && !dn.get(0, 1).has_value());
+        auto id = SparseMatrix::identity(3);
+        auto dg = SparseMatrix::diagonal({2.0, 0.0, -4.0});
+        EXPECT(id.nnz() == 3 && *id.get(2, 2) == 1.0 && dg.nnz() == 2 && *dg.get(2, 2) == -4.0 && !dg.get(1, 1).has_value());
+        bool threw = false;
+        try { SparseMatrix::from_dense({1.0, 2.0, 3.0}, 2, 2); } catch (const SolverError &) { threw = true; }
+        EXPECT(threw);
+    }
     {   // simd_ops free functions (lib.rs:83-87) with the reference's own unit-test values: simd_ops.rs:259-286
         std::vector<double> yy(2);
         matrix_vector_multiply_simd({2.0, 1.0, 1.0, 3.0}, {0, 1, 0, 1}, {0, 2, 4}, {1.0, 2.0}, yy);

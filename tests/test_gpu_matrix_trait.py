@@ -173,6 +173,8 @@ def test_get_known_answers_of_the_reference(gpu):
     assert m.frobenius_norm() == np.sqrt(55.0) and m.format_name() == "CSR" and m.is_square()
     assert m.sparsity_info() == {"nnz": 5, "dimensions": (3, 3), "sparsity_ratio": 5.0 / 9.0, "avg_nnz_per_row": 5.0 / 3.0, "max_nnz_per_row": 2,
                                  "bandwidth": 2, "is_banded": False}
+    i3, dg = S.SparseMatrix.identity(3), S.SparseMatrix.diagonal([2.0, 0.0, -4.0])       # matrix/mod.rs:226-239
+    assert i3.nnz() == 3 and i3.get(1, 1) == 1.0 and dg.nnz() == 2 and dg.get(2, 2) == -4.0 and dg.get(1, 1) is None
     e = S.SparseMatrix.from_triplets([], 4, 6)
     assert e.get(0, 0) is None and list(e.row_iter(0)) == [] and list(e.col_iter(0)) == [] and e.frobenius_norm() == 0.0
     assert e.sparsity_info() == {"nnz": 0, "dimensions": (4, 6), "sparsity_ratio": 0.0, "avg_nnz_per_row": 0.0, "max_nnz_per_row": 0, "bandwidth": 0,
