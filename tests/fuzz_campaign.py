@@ -3,7 +3,7 @@
 tests guard against regressions, this looks for what they do not cover.  Every case is checked bit for bit against the oracle (counts
 and lists included); the first line of a failure carries everything needed to replay it (`--replay "<kind> <seed>"`).
 
-usage: python tests/fuzz_campaign.py --seconds 300 [--kinds general,paced,orderany,acl,southwell,cg,wideband,session] [--seed0 S]
+usage: python tests/fuzz_campaign.py --seconds 300 [--kinds general,paced,orderany,acl,southwell,cg,wideband,session,trait,walk] [--seed0 S]
 Prints one JSON line: cases per kind, failures (each with kind + seed).  Exit status 1 when anything failed."""
 import argparse
 import json
@@ -248,7 +248,63 @@ def case_session(seed):
             assert (a.rounds, a.pushes, a.rows_touched, a.converged) == (g.rounds, g.pushes, g.rows_touched, g.converged), "batch counts"
 
 
-KINDS = {"general": case_general, "paced": case_paced, "orderany": case_orderany, "acl": case_acl, "southwell": case_southwell, "cg": case_cg,
+def case_trait(seed):
+    """the element / iterator / norm side of trait Matrix on random structures with duplicated columns and hub rows: get (incl. misses and
+    out of bounds), row_iter, col_iter, frobenius_norm, sparsity_info, spmv_add — exact except the norm"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 63, 64, 65, 130, 900, 2500]))
+    long_rows = bool(rng.random() < 0.5) and n >= 700
+    rp, ci, va = F._random_system(rng, n, 0, int(rng.integers(1, 40)), long_rows)
+    if rng.random() < 0.6 and n > 2:                           # duplicate some entries (from_triplets keeps them, sparse.rs:80-132)
+        tr = np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))
+        pick = rng.random(tr.size) < 0.15
+        reps = rng.integers(1, 4, size=int(pick.sum()))
+        tr2 = np.concatenate([tr, np.repeat(tr[pick], reps)]); tc2 = np.concatenate([ci, np.repeat(ci[pick], reps)])
+        tv2 = np.concatenate([va, rng.standard_normal(int(reps.sum()))])
+        rp, ci, va = O.csr_from_triplets(tr2, tc2, tv2, n, n)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+    seen("trait", m)
+    for r in set(int(v) for v in rng.integers(0, n, size=6)) | {0, n - 1, int(np.argmax(np.diff(rp.astype(np.int64))))}:
+        co, vo = O.csr_row(rp, ci, va, r)
+        got = list(m.row_iter(r))
+        assert [c for c, _ in got] == co.tolist() and bits_equal([v for _, v in got], vo), ("row_iter", r)
+        for c in list(dict.fromkeys(co.tolist()))[:12] + [int(v) for v in rng.integers(0, n, size=2)] + [n]:
+            want, have = O.matrix_get(rp, ci, va, r, c), m.get(r, c)
+            assert (want is None) == (have is None) and (want is None or bits_equal([want], [have])), ("get", r, c)
+    for c in set(int(v) for v in rng.integers(0, n, size=3)) | {int(np.bincount(ci, minlength=n).argmax()) if ci.size else 0}:
+        ro, vo = O.csr_col(rp, ci, va, c)
+        got = list(m.col_iter(c))
+        assert [r for r, _ in got] == ro.tolist() and bits_equal([v for _, v in got], vo), ("col_iter", c)
+    want = O.frobenius_norm(rp, va)
+    assert abs(m.frobenius_norm() - want) <= 1e-12 * max(want, 1e-300), "frobenius"
+    assert m.sparsity_info() == O.sparsity_info(rp, ci), "sparsity_info"
+    x, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    y = y0.copy()
+    m.multiply_vector_add(x, y)
+    assert bits_equal(y, O.spmv_add(rp, ci, va, x, y0)), "spmv_add"
+
+
+def case_walk(seed):
+    """solveRandomWalk and the single-entry walks: per-coordinate means / variances against the CPU checker's block form, per-walk values bit for bit"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([3, 40, 150]))
+    rp, ci, va = F._random_system(rng, n, 0, int(rng.integers(2, 9)), False)
+    b = rng.standard_normal(n)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, keep_csr=True)
+    W, sd = int(rng.choice([100, 257, 1000])), int(rng.integers(0, 2 ** 32))
+    r = S.random_walk_solve(m, b, 0.1, sd, num_walks=W)
+    o = O.ts_random_walk_solve(rp, ci, va, b, 0.1, sd, num_walks=W, per_walk_streams=True)
+    scale = max(np.abs(o["x"]).max(), 1e-300)
+    assert np.abs(r["solution"] - o["x"]).max() <= 1e-12 * scale and r["converged"] == o["converged"] and r["num_walks"] == W, "walk solve"
+    assert np.abs(r["variances"] - o["variances"]).max() <= 1e-11 * max(o["variances"].max(), scale * scale), "walk variances"
+    row = int(rng.integers(0, n))
+    import ctypes as C
+    vals, res = np.zeros(W), L.WalkResult()
+    L.check(L.load().sl_estimate_entry_random_walk(m._h, L.ptr(b), 0, row, 0.1, sd, W, L.ptr(vals), C.byref(res)))
+    assert bits_equal(vals, O.ts_random_walk_streams(rp, ci, va, b, row, W, sd)[0]), "walk values"
+
+
+KINDS = {"trait": case_trait, "walk": case_walk, "general": case_general, "paced": case_paced, "orderany": case_orderany, "acl": case_acl, "southwell": case_southwell, "cg": case_cg,
          "wideband": case_wideband, "session": case_session}
 
 

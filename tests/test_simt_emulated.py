@@ -166,6 +166,34 @@ def test_boundary_first_overlap_under_the_emulator(simt_lib, dist_exe):
         assert ("runs its edge blocks first" in r.stderr) == expect, r.stderr[-2500:]
 
 
+@pytest.mark.parametrize("world,n,w,overlap,expect", [(3, 600000, 5000, "1", True),       # band kernel with a wide window, unequal ranges
+                                                      (4, 40000, 15000, "1", False),      # reach beyond the neighbour: no interior to hide behind
+                                                      (1, 300000, 2000, "2", True)])      # forced on at world size 1 (same stream topology, no peers)
+def test_boundary_first_step_cases_of_the_gpu_suite_under_the_emulator(simt_lib, dist_exe, world, n, w, overlap, expect):
+    """tests/test_gpu_dist_abi.py::test_boundary_first_step_gives_the_same_bits, its remaining cases, against the emulator library"""
+    env = _env(simt_lib, SIMT_IPC="1", SIMT_THREADS="2", SL_LOG="1", SL_DIST_OVERLAP=overlap)
+    r = subprocess.run([str(dist_exe), str(world), str(n), str(w)] + (["uneven"] if world == 3 else []), capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "dist_smoke ok" in r.stdout and "bit-identical to one GPU" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert ("runs its edge blocks first" in r.stderr) == expect, r.stderr[-2500:]
+
+
+@pytest.mark.parametrize("world,n,w,expect", [(2, 1_200_000, 30_000, True),        # pretended 8-CU device with 4 L2 groups: 4 rounds, the first one = the edge
+                                              (3, 2_000_000, 25_000, False)])      # unequal ranges: one rank has a single round, so nobody splits
+def test_paced_layout_edge_rounds_first_under_the_emulator(simt_lib, dist_exe, world, n, w, expect):
+    """tests/test_gpu_dist_abi.py::test_paced_layout_runs_its_edge_rounds_first (its forced cases): the paced layout with XCD-local spans on
+    every rank, the edge rounds launched first and the exchange beside the rest — same bits with the split and without it.  Minutes as
+    fibers: SIMT_FULL=1 only."""
+    if os.environ.get("SIMT_FULL") != "1":
+        pytest.skip("runs with SIMT_FULL=1 (profiles/r05_simt_emulated_suite.txt holds this round's full run)")
+    for overlap in ("1", "0"):
+        env = _env(simt_lib, SIMT_IPC="1", SIMT_THREADS="4", SL_LOG="1", SL_DIST_OVERLAP=overlap, SL_COLUMN_PANELS="1", SL_PW_FORCE="1", SL_PW_CUS="8", SL_PW_XCD="4",
+                   SL_COMM_TIMEOUT_MS="600000")
+        r = subprocess.run([str(dist_exe), str(world), str(n), str(w)] + (["uneven"] if world == 3 else []), capture_output=True, text=True, timeout=1500, env=env)
+        assert r.returncode == 0 and "dist_smoke ok" in r.stdout and "bit-identical to one GPU" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+        assert "paced column panels" in r.stderr
+        assert ("runs its edge rounds first" in r.stderr) == (expect and overlap == "1"), r.stderr[-3000:]
+
+
 def test_a_transport_that_does_not_deliver_is_named_by_the_ipc_self_test(simt_lib, dist_exe):
     """SIMT_IPC_FAULT=zeros: every imported mapping is a page of zeros instead of the peer's memory.  The self-test at communicator
     creation must fail on EVERY rank — no hang, no half-built communicator — and say what it saw: which peer's page, how many words,
