@@ -565,7 +565,7 @@ def main_abi(args, world, rank, local_rank, attempt=0):
                                           "nnz_iter_per_s": sweep[bk]["nnz_iter_per_s"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(n_global, k, args.seed, w_head)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(dry_run_line(out) if DRY_RUN else out), flush=True)
     finally:
         comm.close()
 
@@ -702,10 +702,42 @@ def refuse_emulator():
         return
     try:
         if hasattr(C.CDLL(path), "simt_counters"):
+            if os.environ.get("SL_BENCH_DRY_RUN") == "1":
+                # a REHEARSAL of this file's code path in the CPU suite (tests/test_simt_emulated.py): torch's device buffers are stood in
+                # for by host arrays (tests/simt/fake_torch.py — the emulator's "device memory" is host memory); the line printed carries
+                # "dry_run" and NO value, roofline figure or time — see dry_run_line()
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("torch", str(ROOT / "tests" / "simt" / "fake_torch.py"))
+                sys.modules["torch"] = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(sys.modules["torch"])
+                global DRY_RUN
+                DRY_RUN = True
+                return
             print(f"bench.py: {path} is the SIMT emulator (tests only): refusing to measure anything on it", file=sys.stderr, flush=True)
             sys.exit(2)
     except OSError:
         pass
+
+
+DRY_RUN = False
+
+
+def dry_run_line(out):
+    """what a rehearsal under the emulator may print: the structure of the line, every number that would be a measurement removed"""
+    def scrub(o):
+        if isinstance(o, dict):
+            return {k: (None if k in TIMED_KEYS and not isinstance(v, (dict, list)) else scrub(v)) for k, v in o.items()}
+        if isinstance(o, list):
+            return [scrub(v) for v in o]
+        return o
+    out = scrub(out)
+    out["dry_run"] = "rehearsal of bench.py's code path under the SIMT emulator (tests/simt): host fibers, not an MI355X — no figure of this line is a measurement"
+    return out
+
+
+TIMED_KEYS = {"value", "ms_per_step", "achieved", "frac", "launch_ms", "timed_region_device_ms_per_step", "algorithmic_over_copy_ceiling_6290", "rows_iter_per_s",
+              "achieved_GBps", "roofline_frac", "nnz_iter_per_s", "floor_ms", "single_thread_simd4", "all_threads_rowchunk", "n1_ms_per_step", "slice_ms_per_step",
+              "device_ms_per_step_slowest_rank", "roofline_frac_per_gpu", "spmv_s_per_step", "vector_passes_s_per_step"}
 
 
 def main():

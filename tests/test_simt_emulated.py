@@ -207,6 +207,34 @@ def test_a_transport_that_does_not_deliver_is_named_by_the_ipc_self_test(simt_li
     assert out.count("rank 1's page") >= 1 and out.count("rank 0's page") >= 1        # per peer, on the ranks that pulled from it
 
 
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_py_rehearsed_end_to_end_under_the_emulator(simt_lib, gpus):
+    """bench.py changed after the last GPU access of this repository and the driver runs it unattended: SL_BENCH_DRY_RUN=1 lets the WHOLE
+    file execute against the emulator (torch's device buffers stood in for by host arrays, tests/simt/fake_torch.py) — synthesis through
+    the ABI, layout build, the parity gate with its CPU child, warm-up and timed steps, exchange verification, the column-structure sweep /
+    the variants of the N > 1 line, rank 0's scaling reference, the cpu_baseline child, the launcher that starts its own ranks — and
+    prints the line's STRUCTURE with every figure that would be a measurement removed.  A rehearsal, never a number."""
+    env = _env(simt_lib, SL_BENCH_DRY_RUN="1", SIMT_IPC="1", SIMT_THREADS="4" if gpus == 1 else "2", SL_COMM_TIMEOUT_MS="300000",
+               LD_LIBRARY_PATH=f"{simt_lib.parent}:{os.environ.get('LD_LIBRARY_PATH', '')}")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--n", "30000", "--steps", "2", "--warmup", "1"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    import json
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "dry_run" in line and line["value"] is None and line["ms_per_step"] is None and line["roofline"]["frac"] is None and line["roofline"]["achieved"] is None
+    assert line["metric"] == "push_iterations_x_nnz_per_sec" and line["n_ranks"] == gpus and line["steps"] == 2 and line["dtype"] == "f64"
+    gate = line["parity_gate"]
+    assert gate["bitwise_equal"] and gate["ranks_equal"] == gpus and gate["rows_checked"] == 3 * 4096 * gpus
+    if gpus == 1:
+        assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] is None and "roofline_banded" in line
+        assert set(line["config"]["other_column_structures"]) >= {"w4096", "w512"}
+    else:
+        assert line["config"]["n_ranks_joined"] == 2 and line["config"]["exchange_verified"] is True
+        for v in ("uniform_variant", "halo_variant"):
+            assert line[v]["exchange_verified"] is True and line[v]["parity_gate"]["bitwise_equal"] and line[v]["value"] is None
+        assert "error" not in line["scaling_reference"], line["scaling_reference"]
+
+
 def test_bench_refuses_the_emulator(simt_lib):
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1"], cwd=ROOT, capture_output=True, text=True, timeout=120, env=_env(simt_lib))
     assert r.returncode == 2 and "refusing to measure" in r.stderr
