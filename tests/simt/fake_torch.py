@@ -14,6 +14,18 @@ class Tensor(np.ndarray):
     def data_ptr(self):
         return self.ctypes.data
 
+    def abs(self):
+        return np.abs(self).view(Tensor)
+
+    def item(self):
+        return np.asarray(self).item()
+
+    def numel(self):
+        return int(self.size)
+
+    def element_size(self):
+        return int(self.itemsize)
+
     def clone(self):
         return self.copy().view(Tensor)
 
@@ -41,6 +53,14 @@ def empty(*shape, dtype=float64, device=None):
 
 def zeros(*shape, dtype=float64, device=None):
     return _t(np.zeros(shape[0] if len(shape) == 1 else shape, dtype=dtype))
+
+
+def ones(*shape, dtype=float64, device=None):
+    return _t(np.ones(shape[0] if len(shape) == 1 else shape, dtype=dtype))
+
+
+def full(shape, value, dtype=float64, device=None):
+    return _t(np.full(shape, value, dtype=dtype))
 
 
 def empty_like(a):

@@ -235,6 +235,26 @@ def test_bench_py_rehearsed_end_to_end_under_the_emulator(simt_lib, gpus):
         assert "error" not in line["scaling_reference"], line["scaling_reference"]
 
 
+SESSION_TOOLS = [("tools/cg_bench.py", ["--m", "20"], {}, "nnz_iter_per_s", False),
+                 ("tests/full_solve_report.py", ["--n", "20000", "--k", "8"], {}, "solution_bits_equal_cpu", False),
+                 ("tools/cg_bench.py", ["--m", "20"], {"SL_CG_FUSED_DOT": "1"}, "nnz_iter_per_s", True),
+                 ("tools/walk_bench.py", ["--rows", "20000"], {}, "walks_per_s", True),
+                 ("tools/pagerank_query.py", ["--n", "5000", "--thetas", "1e-5"], {}, "query_batches", True),
+                 ("tools/pagerank_query.py", ["--n", "5000", "--thetas", "1e-5"], {"SL_PUSH_SMALL": "1"}, "query_batches", True),
+                 ("tools/pagerank_query.py", ["--n", "5000", "--thetas", "1e-5"], {"SL_QUERY_WIDE": "8"}, "query_batches", True),
+                 ("tools/pagerank_query.py", ["--n", "5000", "--thetas", "1e-5"], {"SL_PW_INDEX_ONLY": "1"}, "query_batches", True)]
+
+
+@pytest.mark.parametrize("script,argv,extra,expect,full_only", SESSION_TOOLS, ids=[f"{s.split('/')[-1]}{'+' + '+'.join(e) if e else ''}" for s, _, e, _, _ in SESSION_TOOLS])
+def test_gpu_session_tools_rehearsed_under_the_emulator(simt_lib, script, argv, extra, expect, full_only):
+    """every command tools/r05_gpu_session.sh will spend a GPU call on, run once at a small size against the emulator (tests/simt/rehearse.py:
+    torch stood in for by host arrays) — so that the first minutes on a device are not lost to a typo in a tool.  What they print is not a measurement."""
+    if full_only and os.environ.get("SIMT_FULL") != "1":
+        pytest.skip("runs with SIMT_FULL=1")
+    r = subprocess.run([sys.executable, str(SIMT / "rehearse.py"), str(ROOT / script), *argv], cwd=ROOT, capture_output=True, text=True, timeout=1500, env=_env(simt_lib, **extra))
+    assert r.returncode == 0 and expect in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_bench_refuses_the_emulator(simt_lib):
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1"], cwd=ROOT, capture_output=True, text=True, timeout=120, env=_env(simt_lib))
     assert r.returncode == 2 and "refusing to measure" in r.stderr
