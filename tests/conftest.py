@@ -10,6 +10,15 @@ if str(ROOT) not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+# Under the SIMT emulator (tests/test_simt_emulated.py sets SUBLINEAR_HIP_LIB to it) the tests that hand torch.cuda tensors to the ABI get
+# tests/simt/fake_torch.py instead: host arrays whose address is a valid "device" address there.  Never in effect on a GPU box.
+if "simt" in Path(os.environ.get("SUBLINEAR_HIP_LIB", "")).name and os.environ.get("SIMT_FAKE_TORCH") == "1":
+    import importlib.util
+    _spec = importlib.util.spec_from_file_location("torch", str(ROOT / "tests" / "simt" / "fake_torch.py"))
+    sys.modules["torch"] = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(sys.modules["torch"])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 
