@@ -68,7 +68,8 @@ SLOW = [T + "panels.py::test_seven_million_short_rows_many_thin_panels", T + "pa
         T + "pagerank.py::test_index_only_stream_of_column_constant_operators_keeps_the_bits", T + "session.py::test_batch_of_queries_on_lanes_equals_one_at_a_time",
         T + "session.py::test_wide_batch_answers_equal_single_queries", T + "optin_oracle.py::test_index_only_stream_against_the_oracle",
         T + "mpass.py::test_the_same_checks_through_the_wide_band_panel_layout", T + "mpass.py::test_the_same_checks_through_the_multi_pass_kernel",
-        T + "parity.py::test_c2_full_solve_1m", T + "push_graph.py::test_bidirectional_solver_in_the_specs_order_bit_for_bit"]
+        T + "parity.py::test_c2_full_solve_1m", T + "push_graph.py::test_bidirectional_solver_in_the_specs_order_bit_for_bit",
+        T + "pagerank.py::test_spr_generator_and_transposed_query"]
 GROUPS = {
     "a) matrix trait + error bound (round 5), state object, degenerate inputs": [T + "matrix_trait.py", T + "state.py", T + "degenerate.py"],
     "b) config 1, golden fixtures, S-DD parity, push frontiers, estimateEntry": [T + "parity.py"],
