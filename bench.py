@@ -703,13 +703,14 @@ def refuse_emulator():
     try:
         if hasattr(C.CDLL(path), "simt_counters"):
             if os.environ.get("SL_BENCH_DRY_RUN") == "1":
-                # a REHEARSAL of this file's code path in the CPU suite (tests/test_simt_emulated.py): torch's device buffers are stood in
-                # for by host arrays (tests/simt/fake_torch.py — the emulator's "device memory" is host memory); the line printed carries
+                # a REHEARSAL of this file's code path in the CPU suite (tests/test_simt_emulated.py): torch hands out HOST tensors where this
+                # file asks for device ones (tests/simt/torch_on_host.py — the emulator's "device memory" is host memory); the line printed carries
                 # "dry_run" and NO value, roofline figure or time — see dry_run_line()
                 import importlib.util
-                spec = importlib.util.spec_from_file_location("torch", str(ROOT / "tests" / "simt" / "fake_torch.py"))
-                sys.modules["torch"] = importlib.util.module_from_spec(spec)
-                spec.loader.exec_module(sys.modules["torch"])
+                spec = importlib.util.spec_from_file_location("torch_on_host", str(ROOT / "tests" / "simt" / "torch_on_host.py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                mod.install()
                 global DRY_RUN
                 DRY_RUN = True
                 return
@@ -1014,7 +1015,7 @@ def main_torch(args, world, rank, local_rank):
                                           "nnz_iter_per_s": sweep[bk]["nnz_iter_per_s"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(n_global, k, args.seed, w)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(dry_run_line(out) if DRY_RUN else out), flush=True)
     for hh in handles:
         lib.sl_matrix_destroy(hh)
     if world > 1 or force_dist:

@@ -236,6 +236,29 @@ def test_bench_py_rehearsed_end_to_end_under_the_emulator(simt_lib, gpus):
         assert "error" not in line["scaling_reference"], line["scaling_reference"]
 
 
+@pytest.mark.parametrize("exchange", ["abi", "p2p", "allreduce"])
+def test_bench_py_rehearsed_as_the_driver_launches_it(simt_lib, exchange):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` — the form the driver's scaling run takes — against the
+    emulator: the ABI path with the ranks' gloo agreement on every attempt, and the exchange above the ABI over torch.distributed
+    (--exchange p2p / allreduce; gloo here, RCCL on a node).  Real torch on host tensors (tests/simt/torch_on_host.py); every measured figure nulled."""
+    import json
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = _env(simt_lib, SL_BENCH_DRY_RUN="1", SL_BENCH_BACKEND="gloo", SIMT_IPC="1", SIMT_THREADS="2", SL_COMM_TIMEOUT_MS="300000",
+               LD_LIBRARY_PATH=f"{simt_lib.parent}:{os.environ.get('LD_LIBRARY_PATH', '')}")
+    env.pop("SIMT_FAKE_TORCH", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        str(ROOT / "bench.py"), "--gpus", "2", "--rows", "30000", "--steps", "2", "--warmup", "1", "--exchange", exchange],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "dry_run" in line and line["value"] is None and line["ms_per_step"] is None and line["n_ranks"] == 2
+    assert line["parity_gate"]["bitwise_equal"] is True, line["parity_gate"]
+    assert ("torch.distributed" in line["config"]["transport"]) == (exchange != "abi")
+
+
 SESSION_TOOLS = [("tools/cg_bench.py", ["--m", "20"], {}, "nnz_iter_per_s", False),
                  ("tests/full_solve_report.py", ["--n", "20000", "--k", "8"], {}, "solution_bits_equal_cpu", False),
                  ("tools/cg_bench.py", ["--m", "20"], {"SL_CG_FUSED_DOT": "1"}, "nnz_iter_per_s", True),
