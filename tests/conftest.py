@@ -12,11 +12,17 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # Under the SIMT emulator (tests/test_simt_emulated.py sets SUBLINEAR_HIP_LIB to it) the tests that hand torch.cuda tensors to the ABI get
 # tests/simt/fake_torch.py instead: host arrays whose address is a valid "device" address there.  Never in effect on a GPU box.
-if "simt" in Path(os.environ.get("SUBLINEAR_HIP_LIB", "")).name and os.environ.get("SIMT_FAKE_TORCH") == "1":
+if "simt" in Path(os.environ.get("SUBLINEAR_HIP_LIB", "")).name and os.environ.get("SIMT_FAKE_TORCH") in ("1", "2"):
     import importlib.util
-    _spec = importlib.util.spec_from_file_location("torch", str(ROOT / "tests" / "simt" / "fake_torch.py"))
-    sys.modules["torch"] = importlib.util.module_from_spec(_spec)
-    _spec.loader.exec_module(sys.modules["torch"])
+    if os.environ["SIMT_FAKE_TORCH"] == "2":      # the real torch, host tensors where a test asks for device ones (tests/simt/torch_on_host.py)
+        _spec = importlib.util.spec_from_file_location("torch_on_host", str(ROOT / "tests" / "simt" / "torch_on_host.py"))
+        _mod = importlib.util.module_from_spec(_spec)
+        _spec.loader.exec_module(_mod)
+        _mod.install()
+    else:
+        _spec = importlib.util.spec_from_file_location("torch", str(ROOT / "tests" / "simt" / "fake_torch.py"))
+        sys.modules["torch"] = importlib.util.module_from_spec(_spec)
+        _spec.loader.exec_module(sys.modules["torch"])
 
 
 def pytest_configure(config):

@@ -35,7 +35,7 @@ def simt_lib():
 
 def _env(lib, **extra):
     env = dict(os.environ, SUBLINEAR_HIP_LIB=str(lib), SIMT_THREADS=str(max(1, min(8, os.cpu_count() or 1))), SIMT_REPORT="1", SL_COMM_TIMEOUT_MS="120000",
-               SIMT_FAKE_TORCH="1")      # (tests/conftest.py: the few tests that hand torch.cuda tensors to the ABI get host arrays instead)
+               SIMT_FAKE_TORCH="2")      # (tests/conftest.py: tests that hand torch.cuda tensors to the ABI get torch's HOST tensors, tests/simt/torch_on_host.py)
     for k in ("SL_COMM_TRANSPORT", "SL_COMM_HALO", "SL_PUSH_SMALL", "SL_QUERY_WIDE", "SL_PW_INDEX_ONLY", "SL_CG_FUSED_DOT"):
         env.pop(k, None)
     env.update(extra)
@@ -81,6 +81,7 @@ GROUPS = {
     "h) wide bands, multi-pass windows, order-free stream": [T + "mpass.py", T + "order_any.py"],
     "i) PageRank systems, band kernel variants, CG": [T + "pagerank.py", T + "cg.py"],
     "j) Gauss-Southwell, random walks, push graph, CLI front end": [T + "southwell.py", T + "walk.py", T + "push_graph.py", T + "cli.py"],
+    "k) the partitioned solver above the ABI (distributed.py over torch.distributed) at world 1, step partials in pieces": [T + "partitioned.py"],
 }
 
 
