@@ -15,9 +15,12 @@ ROOT = Path(__file__).resolve().parent.parent
 @pytest.fixture(scope="module")
 def dist_exe(tmp_path_factory):
     exe = tmp_path_factory.mktemp("dist") / "dist_smoke"
-    pkg = ROOT / "sublinear_time_solver_amd"
+    pkg, name = ROOT / "sublinear_time_solver_amd", "sublinear_hip"
+    simt = Path(os.environ.get("SUBLINEAR_HIP_LIB", ""))
+    if "simt" in simt.name:                 # tests/test_simt_emulated.py: the same program against the emulator library (no GPU in the container)
+        pkg, name = simt.parent, simt.name[3:].split(".")[0]
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "c" / "dist_smoke.c"),
-                        "-o", str(exe), f"-L{pkg}", "-lsublinear_hip", "-lm", f"-Wl,-rpath,{pkg}"], capture_output=True, text=True)
+                        "-o", str(exe), f"-L{pkg}", f"-l{name}", "-lm", f"-Wl,-rpath,{pkg}"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
 

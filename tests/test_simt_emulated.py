@@ -63,7 +63,9 @@ NOT_HERE = [T + "parity.py::test_c3_full_size_properties", T + "parity.py::test_
             T + "pagerank.py::test_c4_full_size_pagerank_queries", T + "order_any.py::test_order_any_headline_instance_sampled",
             T + "cli.py::test_c_program_solves_through_the_abi", T + "cli.py::test_javascript_surface_on_gpu",
             T + "degenerate.py::test_slice_pointers_that_do_not_match_the_row_lengths_are_noticed_and_rebuilt",
-            T + "fuzz.py::test_nothing_relies_on_fresh_device_memory_being_zero"]
+            T + "fuzz.py::test_nothing_relies_on_fresh_device_memory_being_zero",
+            T + "dist_abi.py::test_paced_layout_runs_its_edge_rounds_first[2-20000000-2500000-False-True]",        # config 5's own size per rank
+            T + "dist_abi.py::test_two_ranks_on_one_device_are_refused_by_the_rccl_transport_collectively"]         # (a refusal of the REAL librccl)
 SLOW = [T + "panels.py::test_seven_million_short_rows_many_thin_panels", T + "panels.py::test_paced_uniform_columns_all_epilogues",
         T + "pagerank.py::test_index_only_stream_of_column_constant_operators_keeps_the_bits", T + "session.py::test_batch_of_queries_on_lanes_equals_one_at_a_time",
         T + "session.py::test_wide_batch_answers_equal_single_queries", T + "optin_oracle.py::test_index_only_stream_against_the_oracle",
@@ -82,10 +84,12 @@ GROUPS = {
     "i) PageRank systems, band kernel variants, CG": [T + "pagerank.py", T + "cg.py"],
     "j) Gauss-Southwell, random walks, push graph, CLI front end": [T + "southwell.py", T + "walk.py", T + "push_graph.py", T + "cli.py"],
     "k) the partitioned solver above the ABI (distributed.py over torch.distributed) at world 1, step partials in pieces": [T + "partitioned.py"],
+    "l) one process per rank through the C ABI (dist_smoke.c linked against the emulator): halos, boundary-first, paced edge rounds, rccl at world 1, a rank that never arrives": [T + "dist_abi.py"],
 }
+GROUP_ENV = {"l)": {"SIMT_IPC": "1", "SIMT_THREADS": "2"}}      # (memfd-backed "device" memory so that IPC handles open across processes)
 
 
-FULL_ONLY = {"e)"}       # whole groups left to SIMT_FULL=1: the CPU suite stays within a few minutes
+FULL_ONLY = {"e)", "l)"}       # whole groups left to SIMT_FULL=1: the CPU suite stays within a few minutes
 
 
 @pytest.mark.parametrize("group", sorted(GROUPS))
@@ -96,10 +100,11 @@ def test_gpu_parity_tests_pass_under_the_emulator(simt_lib, group):
     cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--timeout", "900", *GROUPS[group]]
     for d in skip:
         cmd += ["--deselect", d]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=3000, env=_env(simt_lib))
+    extra = dict(GROUP_ENV.get(group[:2], {}), LD_LIBRARY_PATH=f"{simt_lib.parent}:{os.environ.get('LD_LIBRARY_PATH', '')}")
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=3000, env=_env(simt_lib, **extra))
     tail = r.stdout[-2500:] + r.stderr[-1500:]
     assert r.returncode == 0 and " passed" in r.stdout and " failed" not in r.stdout and " error" not in r.stdout, tail
-    if not group.startswith("g)"):        # (g's tests run their kernels in children of their own, whose report they keep)
+    if group[:2] not in ("g)", "l)"):     # (g's and l's tests run their kernels in children of their own, whose report they keep)
         assert _launches(r.stderr)[0] > 0, "no kernel ran under the emulator"
 
 
