@@ -89,7 +89,7 @@ GROUPS = {
 GROUP_ENV = {"l)": {"SIMT_IPC": "1", "SIMT_THREADS": "2"}}      # (memfd-backed "device" memory so that IPC handles open across processes)
 
 
-FULL_ONLY = {"e)", "l)"}       # whole groups left to SIMT_FULL=1: the CPU suite stays within a few minutes
+FULL_ONLY = {"c)", "e)", "g)", "h)", "i)", "l)"}       # whole groups left to SIMT_FULL=1: the CPU suite stays within a few minutes
 
 
 @pytest.mark.parametrize("group", sorted(GROUPS))
@@ -221,6 +221,8 @@ def test_bench_py_rehearsed_end_to_end_under_the_emulator(simt_lib, gpus):
     the ABI, layout build, the parity gate with its CPU child, warm-up and timed steps, exchange verification, the column-structure sweep /
     the variants of the N > 1 line, rank 0's scaling reference, the cpu_baseline child, the launcher that starts its own ranks — and
     prints the line's STRUCTURE with every figure that would be a measurement removed.  A rehearsal, never a number."""
+    if gpus == 1 and os.environ.get("SIMT_FULL") != "1":
+        pytest.skip("runs with SIMT_FULL=1 (its cpu_baseline child takes its 12 s; the N = 2 case below covers the launcher and the line in the CPU suite)")
     env = _env(simt_lib, SL_BENCH_DRY_RUN="1", SIMT_IPC="1", SIMT_THREADS="4" if gpus == 1 else "2", SL_COMM_TIMEOUT_MS="300000",
                LD_LIBRARY_PATH=f"{simt_lib.parent}:{os.environ.get('LD_LIBRARY_PATH', '')}")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--n", "30000", "--steps", "2", "--warmup", "1"], cwd=ROOT, capture_output=True,
@@ -247,6 +249,8 @@ def test_bench_py_rehearsed_as_the_driver_launches_it(simt_lib, exchange):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` — the form the driver's scaling run takes — against the
     emulator: the ABI path with the ranks' gloo agreement on every attempt, and the exchange above the ABI over torch.distributed
     (--exchange p2p / allreduce; gloo here, RCCL on a node).  Real torch on host tensors (tests/simt/torch_on_host.py); every measured figure nulled."""
+    if exchange != "abi" and os.environ.get("SIMT_FULL") != "1":
+        pytest.skip("runs with SIMT_FULL=1")
     import json
     import socket
     with socket.socket() as so:
