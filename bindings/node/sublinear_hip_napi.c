@@ -368,19 +368,20 @@ static napi_value EstimateEntry(napi_env env, napi_callback_info info)
 
 static napi_value EstimateEntryRandomWalk(napi_env env, napi_callback_info info)
 {
-    napi_value argv[5], o;
+    napi_value argv[6], o;
     sl_matrix *m;
     const double *b;
     size_t nb = 0;
-    double row, eps, seed;
+    double row, eps, seed, stream;
     sl_walk_result r;
     sl_status st;
-    if (!get_args(env, info, 5, argv)) return NULL;
+    if (!get_args(env, info, 6, argv)) return NULL;
     if (!(m = matrix_of(env, argv[0])) || !f64_view(env, argv[1], &b, &nb)) return NULL;
     NAPI_OK(napi_get_value_double(env, argv[2], &row));
     NAPI_OK(napi_get_value_double(env, argv[3], &eps));
     NAPI_OK(napi_get_value_double(env, argv[4], &seed));
-    st = sl_estimate_entry_random_walk(m, b, SL_MEM_HOST, (uint64_t)row, eps, (uint32_t)seed, 0, NULL, &r);
+    NAPI_OK(napi_get_value_double(env, argv[5], &stream));      /* sl_walk_stream: 0 blocks, 1 the reference's serial stream */
+    st = sl_estimate_entry_random_walk(m, b, SL_MEM_HOST, (uint64_t)row, eps, (uint32_t)seed, (sl_walk_stream)(int)stream, 0, NULL, &r);
     if (st != SL_OK) return throw_status(env, st);
     NAPI_OK(napi_create_object(env, &o));
     set_num(env, o, "estimate", r.estimate);
@@ -389,25 +390,26 @@ static napi_value EstimateEntryRandomWalk(napi_env env, napi_callback_info info)
     return o;
 }
 
-/* solveRandomWalk (core/solver.ts:278-357): randomWalkSolve(matrix, b, epsilon, seed) -> { solution, iterations, residualNorm,
+/* solveRandomWalk (core/solver.ts:278-357): randomWalkSolve(matrix, b, epsilon, seed, stream) -> { solution, iterations, residualNorm,
  * converged, totalVariance, numWalks, deviceBytes }; a residual that misses epsilon is reported, the JS class throws as the reference does */
 static napi_value RandomWalkSolve(napi_env env, napi_callback_info info)
 {
-    napi_value argv[4], o, sol;
+    napi_value argv[5], o, sol;
     sl_matrix *m;
     const double *b;
     size_t nb = 0;
-    double eps, seed, *x;
+    double eps, seed, stream, *x;
     sl_random_walk_result r;
     sl_matrix_info mi;
     sl_status st;
-    if (!get_args(env, info, 4, argv)) return NULL;
+    if (!get_args(env, info, 5, argv)) return NULL;
     if (!(m = matrix_of(env, argv[0])) || !f64_view(env, argv[1], &b, &nb)) return NULL;
     if (sl_matrix_get_info(m, &mi) != SL_OK || nb != mi.n_rows) { napi_throw_range_error(env, NULL, "vector length does not match the matrix"); return NULL; }
     NAPI_OK(napi_get_value_double(env, argv[2], &eps));
     NAPI_OK(napi_get_value_double(env, argv[3], &seed));
+    NAPI_OK(napi_get_value_double(env, argv[4], &stream));
     if (!(sol = new_f64(env, nb, &x))) return NULL;
-    st = sl_solve_random_walk(m, b, SL_MEM_HOST, eps, (uint32_t)seed, 0, x, NULL, &r);
+    st = sl_solve_random_walk(m, b, SL_MEM_HOST, eps, (uint32_t)seed, (sl_walk_stream)(int)stream, 0, x, NULL, &r);
     if (st != SL_OK && st != SL_CONVERGENCE_FAILURE) return throw_status(env, st);
     NAPI_OK(napi_create_object(env, &o));
     napi_set_named_property(env, o, "solution", sol);

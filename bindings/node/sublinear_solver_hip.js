@@ -140,10 +140,13 @@ function withDeviceMatrix(matrix, withTranspose, fn) {
   try { return fn(h); } catch (e) { return rethrow(e); } finally { native.destroyMatrix(h); }
 }
 
+const WALK_STREAMS = { blocks: 0, reference: 1, serial: 1 };
 const METHODS = ['neumann', 'random-walk', 'forward-push', 'backward-push', 'bidirectional'];
 
 class SublinearSolver {
-  /** core/solver.ts:36-56: { method, epsilon, maxIterations, timeout?, enableProgress?, seed? } */
+  /** core/solver.ts:36-56: { method, epsilon, maxIterations, timeout?, enableProgress?, seed? }
+   *  + stream?: 'blocks' (default: one lane per walk, every walk its own block of the seed's stream) | 'reference' (the reference's ONE
+   *  serial stream: random-walk results bit-identical to solver.ts for the same seed; include/sublinear_hip.h, sl_walk_stream) */
   constructor(config) {
     if (!config || METHODS.indexOf(config.method) < 0) throw new SolverError(`Unknown method: ${config && config.method}`, ErrorCodes.INVALID_PARAMETERS);
     validatePositiveNumber(config.epsilon, 'epsilon');
@@ -151,7 +154,11 @@ class SublinearSolver {
       throw new SolverError('maxIterations must be an integer between 1 and 1000000', ErrorCodes.INVALID_PARAMETERS);
     }
     if (config.timeout) validatePositiveNumber(config.timeout, 'timeout');
+    if (config.stream !== undefined && WALK_STREAMS[config.stream] === undefined) {
+      throw new SolverError(`Unknown random-walk stream: ${config.stream}`, ErrorCodes.INVALID_PARAMETERS);
+    }
     this.config = Object.assign({}, config);
+    this.walkStream = WALK_STREAMS[config.stream === undefined ? 'blocks' : config.stream];
   }
 
   /** core/solver.ts:58-111 -> { solution, iterations, residual, converged, method, computeTime, memoryUsed } */
@@ -172,7 +179,7 @@ class SublinearSolver {
         // solveRandomWalk (solver.ts:278-357): max(100, ceil(1 / eps^2)) walks per coordinate, a stream per walk from config.seed
         // (the reference seeds ONE stream with `seed || Date.now()`); a residual that misses epsilon throws, as there (:335-341)
         const seed = (this.config.seed !== undefined ? this.config.seed : Date.now()) >>> 0;
-        const w = native.randomWalkSolve(h, b, this.config.epsilon, seed);
+        const w = native.randomWalkSolve(h, b, this.config.epsilon, seed, this.walkStream);
         if (!w.converged) {
           throw new SolverError('Random walk sampling failed to achieve desired accuracy', ErrorCodes.CONVERGENCE_FAILED,
                                 { finalResidual: w.residualNorm, variance: Math.sqrt(w.totalVariance) });
@@ -219,7 +226,7 @@ class SublinearSolver {
     return withDeviceMatrix(matrix, true, (h) => {
       if (config.method === 'random-walk' || config.method === 'monte-carlo') {        // solver.ts:585-601, 630-648
         const seed = (this.config.seed !== undefined ? this.config.seed : 0) >>> 0;
-        const r = native.estimateEntryRandomWalk(h, b, config.row, eps, seed);
+        const r = native.estimateEntryRandomWalk(h, b, config.row, eps, seed, this.walkStream);
         return { estimate: r.estimate, variance: r.variance, confidence: config.confidence, numSamples: r.numSamples };
       }
       const r = native.estimateEntry(h, b, config.row, eps * 1e-2, this.config.maxIterations * 100);

@@ -37,7 +37,10 @@ extern "C" {
 /* 4 (round 5): + the element / iterator / norm side of trait Matrix — sl_matrix_get, sl_matrix_row, sl_matrix_col,
  * sl_matrix_frobenius_norm, sl_matrix_sparsity_info (with the calls of version 3, `impl Matrix for HipMatrix` is complete) — and
  * sl_solve_random_walk, the `random-walk` method of the TS solve(). */
-#define SL_ABI_VERSION 4
+/* 5 (round 6): + sl_device_name; the in-place mutators sl_matrix_scale / sl_matrix_add_diagonal; sl_l1_norm / sl_linf_norm /
+ * sl_compute_norm / sl_compute_residual / sl_check_convergence (solver::utils); sl_neumann_options_streaming; and a `stream` argument
+ * on sl_estimate_entry_random_walk / sl_solve_random_walk (SL_WALK_STREAM_SERIAL = the reference's one serial stream, bit for bit). */
+#define SL_ABI_VERSION 5
 
 /* ---- status codes: 1:1 with SolverError variants (src/error.rs:16-140) ---------- */
 typedef enum {
@@ -88,6 +91,8 @@ typedef struct sl_matrix sl_matrix; /* opaque, device resident */
 #define SL_MATRIX_KEEP_CSR 2u       /* keep the raw CSR arrays on the device next to the slice layout */
 #define SL_MATRIX_COLUMN_PANELS 4u  /* build the column-panel layout whatever the size (by default: only where it pays) */
 #define SL_MATRIX_NO_COLUMN_PANELS 8u /* never build it (saves 14 B per entry of HBM) */
+#define SL_MATRIX_ROW_SLICE 32u     /* the rows are a row range of a SQUARE system of n_cols rows (what row_offset > 0 implies; this flag says it
+                                       for the range that starts at row 0): sl_matrix_add_diagonal accepts such a matrix */
 #define SL_MATRIX_ORDER_ANY 16u     /* where column panels pay, build the ORDER-FREE column stream (12 B per entry) instead of the ordered
                                        one: what SL_ORDER_ANY solves run on; exact orders on such a matrix take the row-slice kernels */
 
@@ -96,6 +101,9 @@ int sl_abi_version(void);
 const char *sl_last_error_message(void);
 const char *sl_status_string(sl_status s);
 sl_status sl_device_count(int *count);
+/* hipDeviceProp_t::gcnArchName of `device` ("gfx950:sramecc+:xnack-" on an MI355X), NUL-terminated and cut to `capacity` bytes:
+ * what a caller (and the test suite's first line) prints to show WHICH device the library runs on. */
+sl_status sl_device_name(int device, char *name, uint64_t capacity);
 sl_status sl_set_device(int device);
 /* all launches of the calling thread go to `hip_stream` (a hipStream_t); NULL = default stream */
 sl_status sl_set_stream(void *hip_stream);
@@ -139,6 +147,19 @@ typedef struct {
     uint32_t reserved;
 } sl_matrix_info;
 sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info);
+/* In-place mutators — SparseMatrix::scale / add_diagonal (matrix/mod.rs:346-372) over CSRStorage::scale / add_diagonal
+ * (matrix/sparse.rs:229-248).  They are the two `&mut self` methods of the matrix: the caller must hold the matrix exclusively (no
+ * solve running on it); Neumann states / query sessions created before the call keep the D^-1 they computed and must be re-created.
+ *   sl_matrix_scale         every stored value *= factor (one rounded product per entry, in every layout copy the matrix carries).
+ *   sl_matrix_add_diagonal  A += alpha I: in every row the entry `binary_search` finds at the row's own column gets += alpha; a row
+ *                           WITHOUT a stored diagonal entry is silently skipped (sparse.rs:236-248: "we'd need to restructure the
+ *                           matrix"), a row that stores its diagonal twice changes only the entry the halving search lands on.
+ *                           Non-square matrix: SL_INVALID_INPUT (matrix/mod.rs:356-361) — except a row slice of a square system
+ *                           (row_offset > 0 or SL_MATRIX_ROW_SLICE), whose "own column" is row_offset + row.
+ * Both keep every device layout consistent (row slices, raw CSR, transpose in place; the sorted column streams of a matrix that
+ * carries column panels are rebuilt from the updated rows). */
+sl_status sl_matrix_scale(sl_matrix *m, double factor);
+sl_status sl_matrix_add_diagonal(sl_matrix *m, double alpha);
 /* download the CSR arrays back to the host (needs SL_MATRIX_KEEP_CSR); for tests / ingest */
 sl_status sl_matrix_download_csr(const sl_matrix *m, uint32_t *row_ptr, uint32_t *col_idx, double *values);
 
@@ -198,6 +219,26 @@ sl_status sl_spmv_add(const sl_matrix *m, const double *x, double *y, sl_order o
 sl_status sl_dot(uint64_t n, const double *x, const double *y, double *out, sl_mem where);
 sl_status sl_axpy(uint64_t n, double alpha, const double *x, double *y, sl_mem where);
 sl_status sl_l2_norm(uint64_t n, const double *x, double *out, sl_mem where);
+/* solver::utils::l1_norm / linf_norm (solver/mod.rs:374-381): sum of |x_i| (fixed tree, equal to the sequential sum to rounding);
+ * max of |x_i| folded from 0.0 with f64::max — exact in any order; a NaN entry is ignored exactly as f64::max ignores it. */
+sl_status sl_l1_norm(uint64_t n, const double *x, double *out, sl_mem where);
+sl_status sl_linf_norm(uint64_t n, const double *x, double *out, sl_mem where);
+/* solver::utils::compute_norm (solver/mod.rs:384-391) over NormType (types.rs): Weighted falls back to L2 as in the reference. */
+typedef enum { SL_NORM_L1 = 0, SL_NORM_L2 = 1, SL_NORM_LINF = 2, SL_NORM_WEIGHTED = 3 } sl_norm_type;
+sl_status sl_compute_norm(uint64_t n, const double *x, sl_norm_type norm_type, double *out, sl_mem where);
+/* solver::utils::compute_residual (solver/mod.rs:394-405): residual = A x, then residual_i -= b_i (per row bit-identical to the
+ * reference: the row sum in `order`, then one subtraction).  x: n_cols, b / residual: n_rows. */
+sl_status sl_compute_residual(const sl_matrix *m, const double *x, const double *b, double *residual, sl_order order, sl_mem where);
+/* solver::utils::check_convergence (solver/mod.rs:408-461) over ConvergenceMode (types.rs:30-41): ResidualNorm: residual_norm <=
+ * tolerance; RelativeResidual: residual_norm / b_norm <= tolerance (b_norm > 0, else the absolute test); SolutionChange:
+ * ||current - prev||_2 <= tolerance; RelativeSolutionChange: ||current - prev||_2 / ||prev||_2 <= tolerance (||prev|| > 0, else the
+ * absolute test) — both false without a previous solution (prev_solution == NULL); Combined: residual_norm <= tolerance and
+ * (b_norm == 0 or residual_norm / b_norm <= tolerance).  The two vector modes reduce their sums of squares on the device (fixed tree:
+ * the reference's sequential sums to rounding; n entries each in `where`); the other modes are host arithmetic on the caller's numbers. */
+typedef enum { SL_CONV_RESIDUAL_NORM = 0, SL_CONV_RELATIVE_RESIDUAL = 1, SL_CONV_SOLUTION_CHANGE = 2, SL_CONV_RELATIVE_SOLUTION_CHANGE = 3,
+               SL_CONV_COMBINED = 4 } sl_convergence_mode;
+sl_status sl_check_convergence(double residual_norm, double tolerance, sl_convergence_mode mode, double b_norm, uint64_t n,
+                               const double *prev_solution, const double *current_solution, sl_mem where, int *converged);
 
 /* ---- a8 / a9: the fused Neumann step (device pointers only) -------------------------
  * One pass of NeumannState::apply_iteration_matrix (neumann.rs:280-299) +
@@ -242,6 +283,11 @@ typedef struct {
     int32_t compute_error_bounds; /* SolverOptions.compute_error_bounds (neumann.rs:321-347) */
 } sl_neumann_options;
 void sl_neumann_options_default(sl_neumann_options *o);
+/* SolverOptions::streaming(interval) (solver/mod.rs:101-116): tolerance 1e-4, max_iterations 1000, collect_stats on, no error
+ * bounds; everything else as sl_neumann_options_default.  (streaming_interval itself paces the reference's PartialSolution
+ * callbacks, solver/mod.rs:197-214 — a host-side concern of the caller's loop over sl_neumann_state_run_steps; it is not a field
+ * of the device options.) */
+void sl_neumann_options_streaming(sl_neumann_options *o);
 
 typedef struct {
     uint64_t iterations;     /* SolverResult.iterations */
@@ -258,6 +304,9 @@ typedef struct {
     int32_t converged;       /* SolverResult.converged */
     int32_t series_converged;
 } sl_neumann_result;
+
+/* SolverResult::meets_quality_criteria (solver/mod.rs:192-195): converged && residual_norm <= tolerance; 1 / 0 */
+int sl_neumann_result_meets_quality_criteria(const sl_neumann_result *r, double tolerance);
 
 /* x_out (n_rows) is always written, also on SL_CONVERGENCE_FAILURE (the reference drops
  * it, neumann.rs:523-530).  term_norms may be NULL, else receives one l2 norm per term
@@ -518,11 +567,23 @@ sl_status sl_matrix_transpose(const sl_matrix *m, uint32_t flags, sl_matrix **ou
 
 /* ---- Monte-Carlo branch of estimateEntry ---------------------------------------------
  * TS estimateEntry with method 'random-walk' (src/core/solver.ts:585-601,630-648; walk rule :390-432):
- * numSamples = max(100, ceil(1/epsilon^2)) absorbing walks from `row`, one lane per walk.  All walks draw from the reference's ONE
- * stream createSeededRandom(seed) (core/utils.ts:161-168), cut into blocks: walk s reads it from position 2048 s (the generator's
- * own jump-ahead; a walk uses at most 2000 draws), so walk 0 is the reference's first walk draw for draw.  num_samples = 0 derives the
+ * numSamples = max(100, ceil(1/epsilon^2)) absorbing walks from `row`.  All walks draw from the reference's ONE stream
+ * createSeededRandom(seed) (core/utils.ts:161-168), in the order `stream` selects (sl_walk_stream below).  num_samples = 0 derives the
  * count from epsilon.  walk_values (may be NULL) receives the per-walk estimates.  Needs the raw CSR
  * (SL_MATRIX_KEEP_CSR or SL_MATRIX_WITH_TRANSPOSE). */
+/* Which draws a walk reads.  Both forms draw from the reference's ONE generator createSeededRandom(seed) (core/utils.ts:161-168).
+ *   SL_WALK_STREAM_BLOCKS (default, the throughput form): the stream is cut into blocks, walk number s reads it from position
+ *     s * stride, one lane per walk.  stride = 2048 draws (a walk uses at most 2000) while all walks of the call fit the generator's
+ *     period, total_walks * 2048 <= 2^32; beyond that the largest power of two <= 2^32 / total_walks (so that no two walks of a call
+ *     START at the same position; walks longer than the stride read into their successor's block), and more than 2^28 walks in one
+ *     call are refused (SL_INVALID_INPUT: the stride would fall below 16 draws).  Walk 0 equals the reference's first walk draw for
+ *     draw; the estimate agrees with the reference's statistically, not bit for bit.
+ *   SL_WALK_STREAM_SERIAL (the reference as written): ONE stream walked serially — walk s starts where walk s - 1 stopped
+ *     (solver.ts:585-601, 300-326), the sums of mean and variance are added in walk order.  Every per-walk value, `estimate` and
+ *     `variance` (solve: every x_i, variance_i, total_variance) are bit-identical to the reference's for the same
+ *     (matrix, b, row, epsilon, seed).  One lane does all the work: N = max(100, ceil(1 / epsilon^2)) walks per coordinate take
+ *     microseconds each — the parity form, not the fast one. */
+typedef enum { SL_WALK_STREAM_BLOCKS = 0, SL_WALK_STREAM_SERIAL = 1 } sl_walk_stream;
 typedef struct {
     double estimate;         /* mean of the walk values            (solver.ts:630)  */
     double variance;         /* sample variance, N - 1 denominator (solver.ts:631-633) */
@@ -530,15 +591,16 @@ typedef struct {
     double device_time_ms;
 } sl_walk_result;
 sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double epsilon,
-                                        uint32_t seed, uint64_t num_samples, double *walk_values, sl_walk_result *result);
+                                        uint32_t seed, sl_walk_stream stream, uint64_t num_samples, double *walk_values,
+                                        sl_walk_result *result);
 
 /* The `random-walk` METHOD of SublinearSolver.solve — solveRandomWalk, src/core/solver.ts:278-357: every coordinate i estimated by
  * numWalks = max(100, ceil(1/epsilon^2)) absorbing walks from i (num_walks = 0 derives it; the walk rule of performRandomWalk
  * :390-432 as above), x[i] = their mean, total_variance = the sum over coordinates of the sample variances (N - 1); then
  * residual = ||A x - b||_2 and converged = residual < epsilon.  The reference THROWS when it is not (CONVERGENCE_FAILED,
  * :335-341): SL_CONVERGENCE_FAILURE, with x, variances and *res filled all the same.  Streams: walk w of coordinate i is walk number
- * i * numWalks + w of the solve and reads createSeededRandom(seed) from that number's block of 2048 draws, as in
- * sl_estimate_entry_random_walk (the reference walks the stream serially; both forms are in the oracle).  variances (n doubles)
+ * i * numWalks + w of the solve (total_walks = n * numWalks); SL_WALK_STREAM_BLOCKS reads createSeededRandom(seed) from that number's
+ * block, SL_WALK_STREAM_SERIAL walks the one stream serially as the reference does (sl_walk_stream above).  variances (n doubles)
  * may be NULL.  Needs the raw CSR. */
 typedef struct {
     uint64_t iterations;      /* coordinates estimated = n (what the reference reports as `iterations`, solver.ts:321, 349) */
@@ -549,8 +611,8 @@ typedef struct {
     int32_t converged;
     int32_t reserved;
 } sl_random_walk_result;
-sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, sl_mem where, double epsilon, uint32_t seed, uint64_t num_walks,
-                               double *x, double *variances, sl_random_walk_result *res);
+sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, sl_mem where, double epsilon, uint32_t seed, sl_walk_stream stream,
+                               uint64_t num_walks, double *x, double *variances, sl_random_walk_result *res);
 
 /* ---- conjugate gradient behind the same SpMV ------------------------------------------
  * OptimizedConjugateGradientSolver::solve (src/optimized_solver.rs:182-295) == FastConjugateGradient::solve

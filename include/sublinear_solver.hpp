@@ -57,6 +57,9 @@ struct SolverOptions {                       // solver/mod.rs:20-62
     bool compute_error_bounds = false;
     static SolverOptions high_precision() { SolverOptions o; o.tolerance = 1e-12; o.max_iterations = 5000; o.collect_stats = true; o.compute_error_bounds = true; return o; }
     static SolverOptions fast() { SolverOptions o; o.tolerance = 1e-3; o.max_iterations = 100; return o; }
+    // SolverOptions::streaming (solver/mod.rs:101-116); the interval paces the caller's loop over NeumannState::run_steps
+    size_t streaming_interval = 0;
+    static SolverOptions streaming(size_t interval) { SolverOptions o; o.tolerance = 1e-4; o.max_iterations = 1000; o.collect_stats = true; o.streaming_interval = interval; return o; }
 };
 
 struct SolverStats {                         // types.rs:88-109 (fields the path fills) + device additions
@@ -72,6 +75,8 @@ struct SolverResult {                        // solver/mod.rs:118-195
     bool converged = false;
     std::optional<Precision> error_bound;
     std::optional<SolverStats> stats;
+    // SolverResult::meets_quality_criteria (solver/mod.rs:192-195)
+    bool meets_quality_criteria(Precision tolerance) const { return converged && residual_norm <= tolerance; }
 };
 
 class SparseMatrix {
@@ -162,6 +167,11 @@ public:
     Precision frobenius_norm() const { double r = 0.0; check(sl_matrix_frobenius_norm(h_, &r)); return r; }
     // Matrix::sparsity_info (matrix/mod.rs:523-545; the fields of SparsityInfo, types.rs:114-129)
     sl_sparsity_info sparsity_info() const { sl_sparsity_info i; check(sl_matrix_sparsity_info(h_, &i)); return i; }
+    // SparseMatrix::scale / add_diagonal (matrix/mod.rs:346-372 over sparse.rs:229-248): in place on the device, every layout copy;
+    // non-const like the reference's `&mut self` (no solve may be running on the matrix; re-create states / sessions afterwards).
+    // add_diagonal skips rows without a stored diagonal entry; SL_INVALID_INPUT for a non-square matrix
+    void scale(Precision factor) { check(sl_matrix_scale(h_, factor)); }
+    void add_diagonal(Precision alpha) { check(sl_matrix_add_diagonal(h_, alpha)); }
     const char *format_name() const { return "CSR"; }
     const sl_matrix *handle() const { return h_; }
 
@@ -183,6 +193,35 @@ private:
 };
 
 enum class StepResult { Continue, Converged, Failed };        // solver/mod.rs:197-221
+
+// solver::utils (solver/mod.rs:363-461): vectors reduced on the device (sums: fixed tree, the reference's sequential sum to rounding)
+namespace utils {
+enum class NormType { L1 = SL_NORM_L1, L2 = SL_NORM_L2, LInfinity = SL_NORM_LINF, Weighted = SL_NORM_WEIGHTED };                  // types.rs:46-55
+enum class ConvergenceMode { ResidualNorm = SL_CONV_RESIDUAL_NORM, RelativeResidual = SL_CONV_RELATIVE_RESIDUAL, SolutionChange = SL_CONV_SOLUTION_CHANGE,
+                             RelativeSolutionChange = SL_CONV_RELATIVE_SOLUTION_CHANGE, Combined = SL_CONV_COMBINED };             // types.rs:30-41
+inline Precision l2_norm(const std::vector<Precision> &v) { double r = 0; check(sl_l2_norm(v.size(), v.data(), &r, SL_MEM_HOST)); return r; }
+inline Precision l1_norm(const std::vector<Precision> &v) { double r = 0; check(sl_l1_norm(v.size(), v.data(), &r, SL_MEM_HOST)); return r; }
+inline Precision linf_norm(const std::vector<Precision> &v) { double r = 0; check(sl_linf_norm(v.size(), v.data(), &r, SL_MEM_HOST)); return r; }
+inline Precision compute_norm(const std::vector<Precision> &v, NormType t)
+{
+    double r = 0;
+    check(sl_compute_norm(v.size(), v.data(), static_cast<sl_norm_type>(t), &r, SL_MEM_HOST));
+    return r;
+}
+inline void compute_residual(const SparseMatrix &m, const std::vector<Precision> &x, const std::vector<Precision> &b, std::vector<Precision> &residual)
+{
+    residual.resize(m.rows());
+    check(sl_compute_residual(m.handle(), x.data(), b.data(), residual.data(), SL_ORDER_CSR_SEQUENTIAL, SL_MEM_HOST));
+}
+inline bool check_convergence(Precision residual_norm, Precision tolerance, ConvergenceMode mode, Precision b_norm,
+                              const std::vector<Precision> *prev_solution, const std::vector<Precision> &current_solution)
+{
+    int out = 0;
+    check(sl_check_convergence(residual_norm, tolerance, static_cast<sl_convergence_mode>(mode), b_norm, current_solution.size(),
+                               prev_solution ? prev_solution->data() : nullptr, current_solution.data(), SL_MEM_HOST, &out));
+    return out != 0;
+}
+} // namespace utils
 
 // sl_comm: one process per GPU of one node (include/sublinear_hip.h, multi-GPU); every rank passes the same name
 class Communicator {

@@ -82,6 +82,8 @@ def lib(fast: bool = False) -> C.CDLL:
         l.orc_frobenius_norm.restype = f64
         l.orc_csr_row.restype = u64
         l.orc_csr_col.restype = u64
+        l.orc_walk_stride.restype = u64
+        l.orc_csr_add_diagonal.restype = u64
         _libs[key] = l
     return _libs[key]
 
@@ -464,6 +466,37 @@ def ts_random_walk_solve(rp, ci, va, b, epsilon, seed, num_walks=0, per_walk_str
     if st not in (0, 3):
         raise OracleError(st)
     return {"status": st, "x": x, "variances": var, "residual": res.value, "total_variance": tv.value, "converged": st == 0}
+
+
+def walk_stride(total_walks):
+    """draws between the starting points of consecutive walks of a call (include/sublinear_hip.h, sl_walk_stream)"""
+    return int(lib().orc_walk_stride(u64(total_walks)))
+
+
+def ts_random_walk_serial(rp, ci, va, b, row, num_samples, seed):
+    """estimateEntry's random-walk branch as written (solver.ts:585-601, 630-634): ONE serial stream; per-walk values, mean, variance"""
+    rp, ci, va, b = _u32(rp), _u32(ci), _f(va), _f(b)
+    n = rp.size - 1
+    vals = np.zeros(num_samples)
+    mean, var = f64(0), f64(0)
+    st = lib().orc_ts_random_walk_serial(u64(n), _p(rp), _p(ci), _p(va), _p(b), u64(row), u64(num_samples), u32(seed), _p(vals), C.byref(mean), C.byref(var))
+    if st:
+        raise OracleError(st)
+    return vals, mean.value, var.value
+
+
+def csr_scale(va, factor):
+    """CSRStorage::scale (sparse.rs:229-233) on a copy of the values"""
+    out = _f(va).copy()
+    lib().orc_csr_scale(u64(out.size), _p(out), f64(factor))
+    return out
+
+
+def csr_add_diagonal(rp, ci, va, alpha, row_offset=0):
+    """CSRStorage::add_diagonal (sparse.rs:236-248) on a copy of the values; returns (values, rows changed)"""
+    rp, ci, out = _u32(rp), _u32(ci), _f(va).copy()
+    changed = lib().orc_csr_add_diagonal(u64(rp.size - 1), u64(row_offset), _p(rp), _p(ci), _p(out), f64(alpha))
+    return out, int(changed)
 
 
 def ts_random_walk_streams(rp, ci, va, b, row, num_samples, seed):

@@ -87,6 +87,31 @@ int orc_csr_get(const uint32_t *row_ptr, const uint32_t *col_idx, const double *
     return 0;
 }
 
+/* CSRStorage::scale (sparse.rs:229-233): `for value in &mut self.values { *value *= factor; }` */
+void orc_csr_scale(uint64_t nnz, double *values, double factor)
+{
+    for (uint64_t k = 0; k < nnz; ++k) values[k] = values[k] * factor;
+}
+
+/* CSRStorage::add_diagonal (sparse.rs:236-248): per row `col_indices[start..end].binary_search(&row)` (the halving search of
+ * orc_csr_get: with the diagonal stored twice, the entry IT lands on) and `values[start + pos] += alpha`; a row without a stored
+ * diagonal entry is skipped.  row_offset: the rows are rows [row_offset, row_offset + rows) of a larger square system (their own
+ * column is row_offset + row; 0 for a whole matrix).  Returns the number of rows changed. */
+uint64_t orc_csr_add_diagonal(uint64_t rows, uint64_t row_offset, const uint32_t *row_ptr, const uint32_t *col_idx, double *values, double alpha)
+{
+    uint64_t changed = 0;
+    for (uint64_t r = 0; r < rows; ++r) {
+        const uint64_t c = row_offset + r;
+        uint64_t lo = row_ptr[r], hi = row_ptr[r + 1];
+        while (lo < hi) {
+            uint64_t mid = lo + (hi - lo) / 2;
+            if (col_idx[mid] == c) { values[mid] = values[mid] + alpha; ++changed; break; }
+            if (col_idx[mid] < c) lo = mid + 1; else hi = mid;
+        }
+    }
+    return changed;
+}
+
 /* ------------------------------------------------------------- a2/a3/a4 -- */
 
 /* CSRStorage::multiply_vector (sparse.rs:187-203): result.fill(0.0) then
@@ -955,6 +980,15 @@ static inline double lcg_next(uint64_t *state)
  * device cuts the reference's ONE stream into blocks of ORC_WALK_STRIDE draws, one block per walk (a walk of at most 1000 steps
  * uses at most 2000 draws): walk number s starts at orc_ts_lcg_jump(seed, s * ORC_WALK_STRIDE). */
 #define ORC_WALK_STRIDE 2048ull
+/* draws between the starting points of consecutive walks of a call with `total` walks: 2048 while total * 2048 fits the generator's
+ * period of 2^32 draws (2^21 walks), then the largest power of two <= 2^32 / total, never below 16 (the device refuses more than 2^28
+ * walks in one call) — so that no two walks of a call start at the same position of the stream */
+uint64_t orc_walk_stride(uint64_t total)
+{
+    uint64_t stride = ORC_WALK_STRIDE;
+    while (stride > 16 && total * stride > (1ull << 32)) stride >>= 1;
+    return stride;
+}
 uint32_t orc_ts_lcg_jump(uint32_t state, uint64_t k)
 {
     uint32_t cur_a = 1664525u, cur_c = 1013904223u, acc_a = 1u, acc_c = 0u;
@@ -1019,6 +1053,51 @@ int orc_ts_random_walk_estimate(uint64_t n, const uint32_t *row_ptr, const uint3
     if (N > 1) { for (uint64_t s = 0; s < N; ++s) { double d = est[s] - m; var = var + d * d; } var = var / (double)(N - 1); }
     *mean = m; *variance = var; *num_samples = N;
     free(absorb); free(diag); free(est);
+    return ORC_OK;
+}
+
+/* The same branch with the walk count given and every walk's value returned: the reference as written — ONE stream, walk s starts
+ * where walk s - 1 stopped (solver.ts:589-592) — for SL_WALK_STREAM_SERIAL, which must equal it bit for bit: values[] (num_samples),
+ * mean and variance added in walk order as Array.reduce adds them (:630-633).  Diagonal = the last a_ii stored in the row (the dense
+ * table of createTransitionMatrix, as orc_ts_random_walk_solve reads it). */
+int orc_ts_random_walk_serial(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values_a, const double *b,
+                              uint64_t start_row, uint64_t num_samples, uint32_t seed, double *values, double *mean, double *variance)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        double d = 0.0;
+        for (uint64_t k = row_ptr[i]; k < row_ptr[i + 1]; ++k) if (col_idx[k] == i) d = values_a[k];
+        if (fabs(d) < 1e-15) return ORC_NUMERICAL_INSTABILITY;
+    }
+    uint64_t state = seed;
+    for (uint64_t s = 0; s < num_samples; ++s) {
+        uint64_t cur = start_row; double value = 0.0;
+        for (int step = 0; step < 1000; ++step) {
+            double d = 0.0;
+            for (uint64_t k = row_ptr[cur]; k < row_ptr[cur + 1]; ++k) if (col_idx[k] == cur) d = values_a[k];
+            const double absorb = 1.0 / d;
+            if (lcg_next(&state) < fabs(absorb)) { value = value + b[cur] * absorb; break; }
+            double sum = 0.0;
+            for (uint64_t k = row_ptr[cur]; k < row_ptr[cur + 1]; ++k)
+                if (col_idx[k] != cur) sum = sum + fabs(-values_a[k] / d);
+            if (sum == 0.0) { value = value + b[cur] * absorb; break; }
+            const double rnd = lcg_next(&state) * sum;
+            if (rnd <= 0.0) { cur = 0; continue; }
+            double cum = 0.0;
+            const uint64_t row = cur;
+            for (uint64_t k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {
+                if (col_idx[k] == row) continue;
+                cum = cum + fabs(-values_a[k] / d);
+                if (rnd <= cum) { cur = col_idx[k]; break; }
+            }
+        }
+        values[s] = value;
+    }
+    double m = 0.0;
+    for (uint64_t s = 0; s < num_samples; ++s) m = m + values[s];
+    m = m / (double)num_samples;
+    double var = 0.0;
+    if (num_samples > 1) { for (uint64_t s = 0; s < num_samples; ++s) { double q = values[s] - m; var = var + q * q; } var = var / (double)(num_samples - 1); }
+    *mean = m; *variance = var;
     return ORC_OK;
 }
 
@@ -1114,9 +1193,10 @@ int orc_ts_random_walk_solve(uint64_t n, const uint32_t *row_ptr, const uint32_t
     double *est = (double *)malloc(num_walks * sizeof(double));
     uint64_t state = seed;
     double tv = 0.0;
+    const uint64_t stride = orc_walk_stride(n * num_walks);
     for (uint64_t i = 0; i < n; ++i) {
         for (uint64_t w = 0; w < num_walks; ++w) {
-            if (per_walk_streams) state = orc_ts_lcg_jump(seed, (i * num_walks + w) * ORC_WALK_STRIDE);
+            if (per_walk_streams) state = orc_ts_lcg_jump(seed, (i * num_walks + w) * stride);
             est[w] = one_walk(row_ptr, col_idx, values, diag, b, i, &state);
         }
         double m = 0.0;
@@ -1152,8 +1232,9 @@ int orc_ts_random_walk_streams(uint64_t n, const uint32_t *row_ptr, const uint32
         orc_csr_get(row_ptr, col_idx, values_a, n, i, i, &d);
         if (fabs(d) < 1e-15) return ORC_NUMERICAL_INSTABILITY;
     }
+    const uint64_t stride = orc_walk_stride(num_samples);
     for (uint64_t s = 0; s < num_samples; ++s) {
-        uint64_t state = orc_ts_lcg_jump(seed, s * ORC_WALK_STRIDE);
+        uint64_t state = orc_ts_lcg_jump(seed, s * stride);
         uint64_t cur = start_row; double value = 0.0;
         for (int step = 0; step < 1000; ++step) {
             double d = 0.0;

@@ -225,6 +225,12 @@ double orc_acl_combine_with_forward(uint64_t n_backward, uint64_t n_forward, dou
 
 /* ---- a15: TS LCG + random-walk estimateEntry (core/utils.ts:161-168, solver.ts:359-432,585-648) ---- */
 void orc_ts_lcg(uint32_t seed, uint64_t count, double *out);
+uint64_t orc_walk_stride(uint64_t total_walks);            /* draws between the starting points of consecutive walks of a call */
+int orc_ts_random_walk_serial(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values_a, const double *b,
+                              uint64_t start_row, uint64_t num_samples, uint32_t seed, double *values, double *mean, double *variance);
+void orc_csr_scale(uint64_t nnz, double *values, double factor);                                   /* sparse.rs:229-233 */
+uint64_t orc_csr_add_diagonal(uint64_t rows, uint64_t row_offset, const uint32_t *row_ptr, const uint32_t *col_idx, double *values,
+                              double alpha);                                                         /* sparse.rs:236-248 */
 uint32_t orc_ts_lcg_jump(uint32_t state, uint64_t k);      /* the state k draws further on (the per-walk blocks of the one stream) */
 int orc_ts_random_walk_estimate(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx,
                                 const double *values, const double *b, uint64_t start_row,

@@ -60,6 +60,19 @@ extern "C" {
     fn sl_matrix_col(m: *const SlMatrix, col: u64, capacity: u64, rows: *mut u32, values: *mut f64, count: *mut u64) -> c_int;
     fn sl_matrix_frobenius_norm(m: *const SlMatrix, norm: *mut f64) -> c_int;
     fn sl_matrix_sparsity_info(m: *const SlMatrix, info: *mut SlSparsityInfo) -> c_int;
+    // the two `&mut self` methods of SparseMatrix (matrix/mod.rs:346-372)
+    fn sl_matrix_scale(m: *mut SlMatrix, factor: f64) -> c_int;
+    fn sl_matrix_add_diagonal(m: *mut SlMatrix, alpha: f64) -> c_int;
+    // solver::utils (solver/mod.rs:363-461)
+    fn sl_l2_norm(n: u64, x: *const f64, out: *mut f64, mem: c_int) -> c_int;
+    fn sl_l1_norm(n: u64, x: *const f64, out: *mut f64, mem: c_int) -> c_int;
+    fn sl_linf_norm(n: u64, x: *const f64, out: *mut f64, mem: c_int) -> c_int;
+    fn sl_compute_norm(n: u64, x: *const f64, norm_type: c_int, out: *mut f64, mem: c_int) -> c_int;
+    fn sl_compute_residual(m: *const SlMatrix, x: *const f64, b: *const f64, residual: *mut f64, order: c_int, mem: c_int) -> c_int;
+    fn sl_check_convergence(residual_norm: f64, tolerance: f64, mode: c_int, b_norm: f64, n: u64, prev_solution: *const f64,
+                            current_solution: *const f64, mem: c_int, converged: *mut c_int) -> c_int;
+    fn sl_neumann_options_streaming(o: *mut SlNeumannOptions);
+    fn sl_neumann_result_meets_quality_criteria(r: *const SlNeumannResult, tolerance: f64) -> c_int;
     fn sl_neumann_options_default(o: *mut SlNeumannOptions);
     fn sl_neumann_solve(m: *const SlMatrix, b: *const f64, initial_guess: *const f64,
                         opts: *const SlNeumannOptions, x_out: *mut f64, term_norms: *mut f64,
@@ -182,6 +195,57 @@ impl Matrix for HipMatrix {
     }
 }
 impl Drop for HipMatrix { fn drop(&mut self) { unsafe { sl_matrix_destroy(self.handle) } } }
+/// SparseMatrix::scale / add_diagonal (matrix/mod.rs:346-372 over CSRStorage::scale / add_diagonal, sparse.rs:229-248), in place on the
+/// device: `&mut self` is exactly the exclusivity the ABI asks for (no solve running on the matrix).  add_diagonal skips rows without a
+/// stored diagonal entry as the reference does; InvalidInput for a non-square matrix.
+impl HipMatrix {
+    pub fn scale(&mut self, factor: Precision) { unsafe { sl_matrix_scale(self.handle, factor) }; }
+    pub fn add_diagonal(&mut self, alpha: Precision) -> Result<()> {
+        let st = unsafe { sl_matrix_add_diagonal(self.handle, alpha) };
+        if st != 0 { Err(to_error(st, 0, f64::INFINITY, 0.0)) } else { Ok(()) }
+    }
+}
+
+/// solver::utils (solver/mod.rs:363-461) with the vectors reduced on the device: same names, same argument meaning.  Sums are tree
+/// reductions (equal to the reference's sequential sums to rounding); linf_norm and every comparison are exact.
+pub mod hip_utils {
+    use super::*;
+    use crate::types::{ConvergenceMode, NormType};
+    fn norm(f: unsafe extern "C" fn(u64, *const f64, *mut f64, c_int) -> c_int, v: &[Precision]) -> Precision {
+        let mut out = 0.0;
+        unsafe { f(v.len() as u64, v.as_ptr(), &mut out, 0 /* SL_MEM_HOST */) };
+        out
+    }
+    pub fn l2_norm(v: &[Precision]) -> Precision { norm(sl_l2_norm, v) }
+    pub fn l1_norm(v: &[Precision]) -> Precision { norm(sl_l1_norm, v) }
+    pub fn linf_norm(v: &[Precision]) -> Precision { norm(sl_linf_norm, v) }
+    pub fn compute_norm(v: &[Precision], norm_type: NormType) -> Precision {
+        let t = match norm_type { NormType::L1 => 0, NormType::L2 => 1, NormType::LInfinity => 2, NormType::Weighted => 3 };
+        let mut out = 0.0;
+        unsafe { sl_compute_norm(v.len() as u64, v.as_ptr(), t, &mut out, 0) };
+        out
+    }
+    pub fn compute_residual(matrix: &HipMatrix, x: &[Precision], b: &[Precision], residual: &mut [Precision]) -> Result<()> {
+        if x.len() != matrix.cols() { return Err(SolverError::DimensionMismatch { expected: matrix.cols(), actual: x.len(), operation: "matrix_vector_multiply".into() }); }
+        if residual.len() != matrix.rows() || b.len() != matrix.rows() {
+            return Err(SolverError::DimensionMismatch { expected: matrix.rows(), actual: residual.len().min(b.len()), operation: "matrix_vector_multiply".into() });
+        }
+        let st = unsafe { sl_compute_residual(matrix.handle, x.as_ptr(), b.as_ptr(), residual.as_mut_ptr(), 0, 0) };
+        if st != 0 { Err(to_error(st, 0, f64::INFINITY, 0.0)) } else { Ok(()) }
+    }
+    pub fn check_convergence(residual_norm: Precision, tolerance: Precision, mode: ConvergenceMode, b_norm: Precision,
+                             prev_solution: Option<&[Precision]>, current_solution: &[Precision]) -> bool {
+        let m = match mode { ConvergenceMode::ResidualNorm => 0, ConvergenceMode::RelativeResidual => 1, ConvergenceMode::SolutionChange => 2,
+                             ConvergenceMode::RelativeSolutionChange => 3, ConvergenceMode::Combined => 4 };
+        let mut out: c_int = 0;
+        let prev = prev_solution.map(|p| p.as_ptr()).unwrap_or(core::ptr::null());
+        unsafe { sl_check_convergence(residual_norm, tolerance, m, b_norm, current_solution.len() as u64, prev, current_solution.as_ptr(), 0, &mut out) };
+        out != 0
+    }
+    /// SolverOptions::streaming (solver/mod.rs:101-116) as the device options; SolverResult::meets_quality_criteria (:192-195)
+    pub fn streaming_options() -> SlNeumannOptions { let mut o = SlNeumannOptions::default(); unsafe { sl_neumann_options_streaming(&mut o) }; o }
+    pub fn meets_quality_criteria(r: &SlNeumannResult, tolerance: Precision) -> bool { unsafe { sl_neumann_result_meets_quality_criteria(r, tolerance) != 0 } }
+}
 
 /// Same constructor surface as NeumannSolver (neumann.rs:48-92).  The solver caches the device matrix of the last system it saw.
 pub struct HipNeumannSolver { pub max_terms: usize, pub series_tolerance: Precision, cache: std::sync::Mutex<Option<std::sync::Arc<HipMatrix>>> }

@@ -6,7 +6,7 @@ C ABI (include/sublinear_hip.h, csrc/), plus this host-side mirror of the refere
 from ._lib import SolverError, load  # noqa: F401
 from .solver import (Communicator, ConjugateGradientSolver, GaussSouthwellSolver, NeumannSolver, NeumannState, PushSolver, QuerySession, SolverOptions, SolverResult,  # noqa: F401
                      SparseMatrix, SublinearSolver, estimate_entry, random_walk_solve)
-from . import generators  # noqa: F401
+from . import generators, utils  # noqa: F401
 
 __all__ = ["SolverError", "load", "Communicator", "ConjugateGradientSolver", "GaussSouthwellSolver", "NeumannSolver", "NeumannState", "PushSolver", "QuerySession", "SolverOptions", "SolverResult", "SparseMatrix",
-           "SublinearSolver", "estimate_entry", "random_walk_solve", "generators"]
+           "SublinearSolver", "estimate_entry", "random_walk_solve", "generators", "utils"]

@@ -24,6 +24,10 @@ SL_START_ZERO, SL_START_REFERENCE_DEFAULT, SL_START_INITIAL_GUESS = 0, 1, 2
 SL_RESIDUAL_TRUE, SL_RESIDUAL_REFERENCE_SCALED = 0, 1
 SL_SYSTEM_FORWARD, SL_SYSTEM_BACKWARD, SL_SYSTEM_DANGLING_IDENTITY = 0, 1, 2
 SL_MATRIX_WITH_TRANSPOSE, SL_MATRIX_KEEP_CSR, SL_MATRIX_COLUMN_PANELS, SL_MATRIX_NO_COLUMN_PANELS, SL_MATRIX_ORDER_ANY = 1, 2, 4, 8, 16
+SL_MATRIX_ROW_SLICE = 32
+SL_WALK_STREAM_BLOCKS, SL_WALK_STREAM_SERIAL = 0, 1
+SL_NORM_L1, SL_NORM_L2, SL_NORM_LINF, SL_NORM_WEIGHTED = 0, 1, 2, 3
+SL_CONV_RESIDUAL_NORM, SL_CONV_RELATIVE_RESIDUAL, SL_CONV_SOLUTION_CHANGE, SL_CONV_RELATIVE_SOLUTION_CHANGE, SL_CONV_COMBINED = 0, 1, 2, 3, 4
 
 u64, u32, i32, f64 = C.c_uint64, C.c_uint32, C.c_int32, C.c_double
 vp = C.c_void_p
@@ -107,7 +111,7 @@ class CgResult(C.Structure):
                 ("device_time_ms", f64), ("converged", i32), ("reserved", i32)]
 
 
-ABI_VERSION = 4      # SL_ABI_VERSION of include/sublinear_hip.h
+ABI_VERSION = 5      # SL_ABI_VERSION of include/sublinear_hip.h
 
 # every symbol include/sublinear_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -115,6 +119,7 @@ SIGNATURES = {
     "sl_last_error_message": (C.c_char_p, []),
     "sl_status_string": (C.c_char_p, [C.c_int]),
     "sl_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sl_device_name": (C.c_int, [C.c_int, C.c_char_p, u64]),
     "sl_set_device": (C.c_int, [C.c_int]),
     "sl_set_stream": (C.c_int, [vp]),
     "sl_synchronize": (C.c_int, []),
@@ -123,6 +128,8 @@ SIGNATURES = {
     "sl_matrix_create_csr": (C.c_int, [u64, u64, u64, vp, vp, vp, C.c_int, u64, u32, C.POINTER(vp)]),
     "sl_matrix_destroy": (None, [vp]),
     "sl_matrix_get_info": (C.c_int, [vp, C.POINTER(MatrixInfo)]),
+    "sl_matrix_scale": (C.c_int, [vp, f64]),
+    "sl_matrix_add_diagonal": (C.c_int, [vp, f64]),
     "sl_matrix_download_csr": (C.c_int, [vp, vp, vp, vp]),
     "sl_matrix_is_diagonally_dominant": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "sl_matrix_diagonal_inverse": (C.c_int, [vp, vp, C.c_int]),
@@ -138,6 +145,11 @@ SIGNATURES = {
     "sl_dot": (C.c_int, [u64, vp, vp, C.POINTER(f64), C.c_int]),
     "sl_axpy": (C.c_int, [u64, f64, vp, vp, C.c_int]),
     "sl_l2_norm": (C.c_int, [u64, vp, C.POINTER(f64), C.c_int]),
+    "sl_l1_norm": (C.c_int, [u64, vp, C.POINTER(f64), C.c_int]),
+    "sl_linf_norm": (C.c_int, [u64, vp, C.POINTER(f64), C.c_int]),
+    "sl_compute_norm": (C.c_int, [u64, vp, C.c_int, C.POINTER(f64), C.c_int]),
+    "sl_compute_residual": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int]),
+    "sl_check_convergence": (C.c_int, [f64, f64, C.c_int, f64, u64, vp, vp, C.c_int, C.POINTER(C.c_int)]),
     "sl_neumann_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int]),
     "sl_matrix_partials_capacity": (C.c_int, [vp, C.POINTER(u64)]),
     "sl_neumann_step_partials": (C.c_int, [vp, vp, vp, vp, vp, vp, C.POINTER(C.c_uint32), C.c_int]),
@@ -145,6 +157,8 @@ SIGNATURES = {
     "sl_residual_norm2": (C.c_int, [vp, vp, vp, vp, vp, C.c_int]),
     "sl_neumann_run_steps": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, u64, C.POINTER(C.c_float)]),
     "sl_neumann_options_default": (None, [C.POINTER(NeumannOptions)]),
+    "sl_neumann_options_streaming": (None, [C.POINTER(NeumannOptions)]),
+    "sl_neumann_result_meets_quality_criteria": (C.c_int, [C.POINTER(NeumannResult), f64]),
     "sl_neumann_solve": (C.c_int, [vp, vp, vp, C.POINTER(NeumannOptions), vp, vp, C.POINTER(NeumannResult)]),
     "sl_neumann_state_create": (C.c_int, [vp, vp, vp, C.POINTER(NeumannOptions), C.POINTER(vp)]),
     "sl_neumann_state_destroy": (None, [vp]),
@@ -183,8 +197,8 @@ SIGNATURES = {
     "sl_forward_push_southwell": (C.c_int, [vp, vp, C.POINTER(SouthwellOptions), vp, vp, vp, u64, C.POINTER(SouthwellResult)]),
     "sl_estimate_entry": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),
     "sl_synth_sdd_device": (C.c_int, [u64, u32, u64, u64, u64, u64, vp, vp, vp, vp]),
-    "sl_estimate_entry_random_walk": (C.c_int, [vp, vp, C.c_int, u64, f64, u32, u64, vp, C.POINTER(WalkResult)]),
-    "sl_solve_random_walk": (C.c_int, [vp, vp, C.c_int, f64, u32, u64, vp, vp, C.POINTER(RandomWalkResult)]),
+    "sl_estimate_entry_random_walk": (C.c_int, [vp, vp, C.c_int, u64, f64, u32, C.c_int, u64, vp, C.POINTER(WalkResult)]),
+    "sl_solve_random_walk": (C.c_int, [vp, vp, C.c_int, f64, u32, C.c_int, u64, vp, vp, C.POINTER(RandomWalkResult)]),
     "sl_cg_options_default": (None, [C.POINTER(CgOptions)]),
     "sl_cg_solve": (C.c_int, [vp, vp, C.POINTER(CgOptions), vp, C.POINTER(CgResult)]),
     "sl_estimate_entry_transposed": (C.c_int, [vp, vp, C.c_int, u64, f64, u64, C.POINTER(EstimateResult)]),

@@ -339,6 +339,16 @@ sl_status sl_device_count(int *count)
     *count = (e == hipSuccess) ? n : 0;
     return SL_OK;
 }
+sl_status sl_device_name(int device, char *name, uint64_t capacity)
+{
+    if (!name || !capacity) return sl_fail(SL_INVALID_INPUT, "null argument");
+    name[0] = 0;
+    SL_TRY(require_device());
+    hipDeviceProp_t prop;
+    SL_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(name, (size_t)capacity, "%s", prop.gcnArchName);
+    return SL_OK;
+}
 sl_status sl_set_device(int device)
 {
     SL_TRY(require_device());
@@ -502,20 +512,24 @@ sl_status sl_matrix_is_diagonally_dominant(const sl_matrix *m, int *is_dd)
 sl_status sl_matrix_diagonal_dominance_factor(const sl_matrix *m, int *has_factor, double *factor)
 {
     if (!m || !has_factor || !factor) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_ABI_BEGIN
     double h[2];
     SL_TRY(sl_matrix_cond_pass(m, h));
     *has_factor = std::isfinite(h[0]) ? 1 : 0;                          // matrix/mod.rs:508-512: Some(min) only when finite
     *factor = *has_factor ? h[0] : 0.0;
     return SL_OK;
+    SL_ABI_END
 }
 
 sl_status sl_matrix_spectral_radius_estimate(const sl_matrix *m, double *radius)
 {
     if (!m || !radius) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_ABI_BEGIN
     double h[2];
     SL_TRY(sl_matrix_cond_pass(m, h));
     *radius = h[1];
     return SL_OK;
+    SL_ABI_END
 }
 
 // ---- trait Matrix: get / row_iter / col_iter / frobenius_norm / sparsity_info (matrix/mod.rs:33-41, 74-82, 523-545) ----
@@ -546,15 +560,18 @@ sl_status sl_matrix_col(const sl_matrix *m, uint64_t col, uint64_t capacity, uin
 sl_status sl_matrix_frobenius_norm(const sl_matrix *m, double *norm)
 {
     if (!m || !norm) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_ABI_BEGIN
     double sq = 0.0;
     SL_TRY(sl_matrix_frobenius_sq(m, &sq));
     *norm = std::sqrt(sq);
     return SL_OK;
+    SL_ABI_END
 }
 
 sl_status sl_matrix_sparsity_info(const sl_matrix *m, sl_sparsity_info *info)
 {
     if (!m || !info) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_ABI_BEGIN
     info->nnz = m->nnz; info->rows = m->n_rows; info->cols = m->n_cols;
     const uint64_t total = m->n_rows * m->n_cols;                                          // SparsityInfo::new, types.rs:346-358
     info->sparsity_ratio = total > 0 ? (double)m->nnz / (double)total : 0.0;
@@ -566,6 +583,29 @@ sl_status sl_matrix_sparsity_info(const sl_matrix *m, sl_sparsity_info *info)
     info->is_banded = bw < m->n_rows / 4 ? 1 : 0;                                          // :542
     info->reserved = 0;
     return SL_OK;
+    SL_ABI_END
+}
+
+// ---- the `&mut self` methods of SparseMatrix: scale / add_diagonal (matrix/mod.rs:346-372) ----
+sl_status sl_matrix_scale(sl_matrix *m, double factor)
+{
+    if (!m) return sl_fail(SL_INVALID_INPUT, "null matrix");
+    SL_ABI_BEGIN
+    SL_TRY(require_device());
+    return sl_matrix_scale_values(m, factor);
+    SL_ABI_END
+}
+
+sl_status sl_matrix_add_diagonal(sl_matrix *m, double alpha)
+{
+    if (!m) return sl_fail(SL_INVALID_INPUT, "null matrix");
+    SL_ABI_BEGIN
+    // matrix/mod.rs:356-361: only square matrices — a row slice of a square system (global column ids) counts as part of one
+    const bool row_slice = (m->row_offset > 0 || (m->flags & SL_MATRIX_ROW_SLICE)) && m->row_offset + m->n_rows <= m->n_cols;
+    if (m->n_rows != m->n_cols && !row_slice) return sl_fail(SL_INVALID_INPUT, "Cannot add diagonal to non-square matrix");
+    SL_TRY(require_device());
+    return sl_matrix_shift_diagonal(m, alpha);
+    SL_ABI_END
 }
 
 sl_status sl_matrix_diagonal_inverse(const sl_matrix *m, double *dinv, sl_mem where)
@@ -611,6 +651,7 @@ sl_status sl_spmv_add(const sl_matrix *m, const double *x, double *y, sl_order o
     if (order == SL_ORDER_SIMD4)
         return sl_fail(SL_INVALID_INPUT, "multiply_vector_add exists in the CSR order only (sparse.rs:192-203); simd_ops.rs has no accumulating form");
     if (x == y) return sl_fail(SL_INVALID_INPUT, "x and y must not alias");
+    SL_ABI_BEGIN
     hipStream_t s = sl_context().stream;
     DevBuf xin, yio;
     const double *dx;
@@ -627,27 +668,86 @@ sl_status sl_spmv_add(const sl_matrix *m, const double *x, double *y, sl_order o
     if (where == SL_MEM_HOST && m->n_rows) SL_HIP(hipMemcpyAsync(y, dy, m->n_rows * sizeof(double), hipMemcpyDeviceToHost, s));
     SL_HIP(hipStreamSynchronize(s));
     return SL_OK;
+    SL_ABI_END
 }
 
 static sl_status reduce_common(int mode, uint64_t n, const double *x, const double *y, double *out, sl_mem where)
 {
-    if (!x || !out || (mode == 1 && !y)) return sl_fail(SL_INVALID_INPUT, "null argument");
+    if (!x || !out || ((mode == 1 || mode == 4) && !y)) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_ABI_BEGIN
     SL_TRY(require_device());
     hipStream_t s = sl_context().stream;
     DevBuf xin, yin;
     const double *dx, *dy = nullptr;
     SL_TRY(stage_in(x, n, where, xin, &dx));
-    if (mode == 1) SL_TRY(stage_in(y, n, where, yin, &dy));
+    if (mode == 1 || mode == 4) SL_TRY(stage_in(y, n, where, yin, &dy));
     double *scr = static_cast<double *>(sl_scratch(4096 * sizeof(double)));
     if (!scr) return sl_fail(SL_ALLOCATION, "scratch allocation failed");
     double *res = scr + 4000;
     if (mode == 0) SL_TRY(sl_launch_sumsq(n, dx, scr, res, s));
     else if (mode == 1) SL_TRY(sl_launch_dot(n, dx, dy, scr, res, s));
+    else if (mode == 3) SL_TRY(sl_launch_abs_max(n, dx, scr, res, s));
+    else if (mode == 4) SL_TRY(sl_launch_diff_sumsq(n, dx, dy, scr, res, s));
     else SL_TRY(sl_launch_abs_sum(n, dx, scr, res, s));
     double h;
     SL_TRY(read_scalars(res, &h, 1));
     *out = (mode == 0) ? std::sqrt(h) : h;
     return SL_OK;
+    SL_ABI_END
+}
+// solver::utils (solver/mod.rs:374-461): l1_norm, linf_norm, compute_norm, compute_residual, check_convergence
+sl_status sl_l1_norm(uint64_t n, const double *x, double *out, sl_mem where) { return reduce_common(2, n, x, nullptr, out, where); }
+sl_status sl_linf_norm(uint64_t n, const double *x, double *out, sl_mem where) { return reduce_common(3, n, x, nullptr, out, where); }
+sl_status sl_compute_norm(uint64_t n, const double *x, sl_norm_type norm_type, double *out, sl_mem where)
+{
+    switch (norm_type) {
+    case SL_NORM_L1: return sl_l1_norm(n, x, out, where);
+    case SL_NORM_LINF: return sl_linf_norm(n, x, out, where);
+    case SL_NORM_L2: case SL_NORM_WEIGHTED: return sl_l2_norm(n, x, out, where);      // "Default to L2 for weighted", solver/mod.rs:389
+    }
+    return sl_fail(SL_INVALID_INPUT, "unknown sl_norm_type %d", (int)norm_type);
+}
+sl_status sl_compute_residual(const sl_matrix *m, const double *x, const double *b, double *residual, sl_order order, sl_mem where)
+{
+    if (!m || !x || !b || !residual) return sl_fail(SL_INVALID_INPUT, "null argument");
+    SL_ABI_BEGIN
+    hipStream_t s = sl_context().stream;
+    DevBuf xin, bin, rout;
+    const double *dx, *db;
+    SL_TRY(stage_in(x, m->n_cols, where, xin, &dx));
+    SL_TRY(stage_in(b, m->n_rows, where, bin, &db));
+    double *dr = residual;
+    if (where == SL_MEM_HOST) { SL_TRY(rout.alloc((m->n_rows ? m->n_rows : 1) * sizeof(double))); dr = rout.as<double>(); }
+    sl_row_args a = row_args(m);
+    a.gather = dx; a.out = dr;
+    SL_TRY(sl_launch_rows(a, order, SL_EPI_SPMV, s));                       // matrix.multiply_vector(x, residual)
+    if (m->n_rows) SL_TRY(sl_launch_sub(m->n_rows, dr, db, dr, s));         // *r -= b_val
+    if (where == SL_MEM_HOST && m->n_rows) SL_HIP(hipMemcpyAsync(residual, dr, m->n_rows * sizeof(double), hipMemcpyDeviceToHost, s));
+    SL_HIP(hipStreamSynchronize(s));
+    return SL_OK;
+    SL_ABI_END
+}
+sl_status sl_check_convergence(double residual_norm, double tolerance, sl_convergence_mode mode, double b_norm, uint64_t n,
+                               const double *prev_solution, const double *current_solution, sl_mem where, int *converged)
+{
+    if (!converged) return sl_fail(SL_INVALID_INPUT, "null argument");
+    *converged = 0;
+    switch (mode) {
+    case SL_CONV_RESIDUAL_NORM: *converged = residual_norm <= tolerance; return SL_OK;
+    case SL_CONV_RELATIVE_RESIDUAL: *converged = b_norm > 0.0 ? (residual_norm / b_norm) <= tolerance : residual_norm <= tolerance; return SL_OK;
+    case SL_CONV_COMBINED: *converged = residual_norm <= tolerance && (b_norm == 0.0 || (residual_norm / b_norm) <= tolerance); return SL_OK;
+    case SL_CONV_SOLUTION_CHANGE: case SL_CONV_RELATIVE_SOLUTION_CHANGE: {
+        if (!prev_solution) return SL_OK;                                    // None => false
+        if (!current_solution) return sl_fail(SL_INVALID_INPUT, "null current_solution");
+        double change = 0.0, prev = 0.0;
+        SL_TRY(reduce_common(4, n, current_solution, prev_solution, &change, where));
+        if (mode == SL_CONV_SOLUTION_CHANGE) { *converged = std::sqrt(change) <= tolerance; return SL_OK; }
+        SL_TRY(reduce_common(0, n, prev_solution, nullptr, &prev, where));   // sqrt(sum prev^2)
+        *converged = prev > 0.0 ? (std::sqrt(change) / prev) <= tolerance : std::sqrt(change) <= tolerance;
+        return SL_OK;
+    }
+    }
+    return sl_fail(SL_INVALID_INPUT, "unknown sl_convergence_mode %d", (int)mode);
 }
 sl_status sl_dot(uint64_t n, const double *x, const double *y, double *out, sl_mem where) { return reduce_common(1, n, x, y, out, where); }
 sl_status sl_l2_norm(uint64_t n, const double *x, double *out, sl_mem where) { return reduce_common(0, n, x, nullptr, out, where); }
@@ -733,6 +833,16 @@ sl_status sl_neumann_run_steps(const sl_matrix *m, const double *dinv, double *t
 }
 
 // ---- NeumannSolver::solve ---------------------------------------------------------------------------
+void sl_neumann_options_default(sl_neumann_options *o);
+void sl_neumann_options_streaming(sl_neumann_options *o)      // SolverOptions::streaming, solver/mod.rs:101-116
+{
+    sl_neumann_options_default(o);
+    o->tolerance = 1e-4; o->max_iterations = 1000; o->collect_stats = 1; o->compute_error_bounds = 0;
+}
+int sl_neumann_result_meets_quality_criteria(const sl_neumann_result *r, double tolerance)      // SolverResult::meets_quality_criteria, solver/mod.rs:192-195
+{
+    return r && r->converged && r->residual_norm <= tolerance;
+}
 void sl_neumann_options_default(sl_neumann_options *o)
 {
     memset(o, 0, sizeof(*o));

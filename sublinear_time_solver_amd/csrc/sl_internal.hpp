@@ -128,6 +128,9 @@ struct sl_matrix {
     // column u is that one rounded product, so the row sums keep their bits (sl_pw_kernel<.., IDX>).
     double *d_colval = nullptr;
     uint64_t device_bytes = 0;
+    // what the slice fill counted (selects the column streams; kept so that the in-place mutators can rebuild them): entries far from
+    // their row, entries in the slice layout, entries continuing a diagonal; stream_bytes = the share of device_bytes the streams hold
+    uint64_t far_entries = 0, slice_entries = 0, diagonal_entries = 0, stream_bytes = 0;
     bool caller_device_arrays = false;  // sl_matrix_create_csr was handed device pointers (diagnostics of the layout build)
 };
 #ifndef SL_PANEL_TILE
@@ -396,6 +399,8 @@ sl_status sl_launch_axpy(uint64_t n, double alpha, const double *x, double *y, h
 sl_status sl_launch_scale_rows(uint64_t n, const double *a, const double *b, double *out, hipStream_t s); // out = a*b
 sl_status sl_launch_sub(uint64_t n, const double *a, const double *b, double *out, hipStream_t s);        // out = a-b
 sl_status sl_launch_abs_sum(uint64_t n, const double *x, double *partials, double *result, hipStream_t s);
+sl_status sl_launch_abs_max(uint64_t n, const double *x, double *partials, double *result, hipStream_t s);                    // max |x_i|, NaN entries skipped
+sl_status sl_launch_diff_sumsq(uint64_t n, const double *x, const double *y, double *partials, double *result, hipStream_t s); // sum (x_i - y_i)^2
 
 // matrix build (sl_matrix.hip)
 sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx,
@@ -413,6 +418,9 @@ sl_status sl_matrix_fetch_row(const sl_matrix *m, uint64_t row, uint64_t capacit
 sl_status sl_matrix_fetch_col(const sl_matrix *m, uint64_t col, uint64_t capacity, uint32_t *rows, double *values, uint64_t *count);
 sl_status sl_matrix_frobenius_sq(const sl_matrix *m, double *sum_sq);
 sl_status sl_matrix_entry_bandwidth(const sl_matrix *m, uint64_t *bandwidth);   // max |row - col| over ALL stored entries (hub rows included)
+// the `&mut self` methods (matrix/mod.rs:346-372 over sparse.rs:229-248): every layout copy updated (sl_matrix.hip)
+sl_status sl_matrix_scale_values(sl_matrix *m, double factor);
+sl_status sl_matrix_shift_diagonal(sl_matrix *m, double alpha);
 // same rules over a plain CSR operator (used for A^T, which has no row-slice layout)
 sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx, const double *val, double *d_dinv,
                            unsigned long long h_status[4]);

@@ -1765,7 +1765,7 @@ sl_status sl_launch_final_reduce(const double *partials, uint32_t n, double *res
 // ---- vector primitives (a5) -----------------------------------------------------------------
 #define SL_VEC_BLOCKS 2048
 
-template <int MODE> // 0: sum x^2, 1: sum x*y, 2: sum |x|
+template <int MODE> // 0: sum x^2, 1: sum x*y, 2: sum |x|, 3: sum (x - y)^2
 __global__ __launch_bounds__(256) void sl_reduce_kernel(uint64_t n, const double *__restrict__ x,
                                                         const double *__restrict__ y, double *partials)
 {
@@ -1775,6 +1775,7 @@ __global__ __launch_bounds__(256) void sl_reduce_kernel(uint64_t n, const double
         const double v = x[i];
         if (MODE == 0) acc = DADD(acc, DMUL(v, v));
         else if (MODE == 1) acc = DADD(acc, DMUL(v, y[i]));
+        else if (MODE == 3) { const double d = DSUB(v, y[i]); acc = DADD(acc, DMUL(d, d)); }
         else acc = DADD(acc, fabs(v));
     }
     acc = wave_sum(acc);
@@ -1821,6 +1822,47 @@ sl_status sl_launch_abs_sum(uint64_t n, const double *x, double *partials, doubl
     const uint32_t g = vec_grid(n);
     hipLaunchKernelGGL((sl_reduce_kernel<2>), dim3(g), dim3(256), 0, s, n, x, x, partials);
     hipLaunchKernelGGL(sl_final_reduce_kernel, dim3(1), dim3(1024), 0, s, partials, g, result, 1);
+    SL_HIP(hipGetLastError());
+    return SL_OK;
+}
+
+sl_status sl_launch_diff_sumsq(uint64_t n, const double *x, const double *y, double *partials, double *result, hipStream_t s)
+{
+    const uint32_t g = vec_grid(n);
+    hipLaunchKernelGGL((sl_reduce_kernel<3>), dim3(g), dim3(256), 0, s, n, x, y, partials);
+    hipLaunchKernelGGL(sl_final_reduce_kernel, dim3(1), dim3(1024), 0, s, partials, g, result, 1);
+    SL_HIP(hipGetLastError());
+    return SL_OK;
+}
+// solver::utils::linf_norm (solver/mod.rs:379-381): v.iter().map(|x| x.abs()).fold(0.0, f64::max) — f64::max returns the other
+// operand when one is NaN, so NaN entries never enter; fmax has the same rule, and a maximum is exact in any order
+__global__ __launch_bounds__(256) void sl_absmax_kernel(uint64_t n, const double *__restrict__ x, double *partials)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) acc = fmax(acc, fabs(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc = fmax(acc, __shfl_xor(acc, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void sl_absmax_final_kernel(uint32_t n, const double *partials, double *result)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) acc = fmax(acc, partials[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc = fmax(acc, __shfl_xor(acc, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) result[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+sl_status sl_launch_abs_max(uint64_t n, const double *x, double *partials, double *result, hipStream_t s)
+{
+    const uint32_t g = vec_grid(n);
+    hipLaunchKernelGGL(sl_absmax_kernel, dim3(g), dim3(256), 0, s, n, x, partials);
+    hipLaunchKernelGGL(sl_absmax_final_kernel, dim3(1), dim3(256), 0, s, g, partials, result);
     SL_HIP(hipGetLastError());
     return SL_OK;
 }

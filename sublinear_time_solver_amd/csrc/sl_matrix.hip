@@ -868,6 +868,78 @@ static sl_status sl_detect_column_constant(sl_matrix *m, const uint32_t *d_row_p
     return SL_OK;
 }
 
+// 2b / 2c of the build, as a step of its own: the sorted column streams (dynamic column panels, paced panels, order-free stream) and
+// the column-constant table, chosen from the statistics the slice fill left in the matrix.  The in-place mutators re-run it on the
+// updated rows (sl_matrix_rebuild_column_streams) — the same choices, the same geometry, new values.
+static sl_status sl_build_column_streams(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx, const double *d_values, hipStream_t st)
+{
+    const uint64_t n = m->n_rows, nnz = m->nnz;
+    const uint64_t far_entries = m->far_entries, slice_entries = m->slice_entries, diagonal_entries = m->diagonal_entries;
+    const uint64_t bytes_before = m->device_bytes;
+    struct account { sl_matrix *m; uint64_t before; ~account() { m->stream_bytes = m->device_bytes - before; } } account_{m, bytes_before};
+    // 2b. column panels: where neither the LDS window (bandwidth) nor the L2 (vector of a few MB) can serve the gathers
+    {
+        static const int env_panels = [] { const char *e = getenv("SL_COLUMN_PANELS"); return e && *e ? atoi(e) : -1; }();   // 0 never, 1 always
+        const bool forced = (m->flags & SL_MATRIX_COLUMN_PANELS) || env_panels == 1 || env_panels == 3;
+        const bool refused = (m->flags & SL_MATRIX_NO_COLUMN_PANELS) || env_panels == 0;
+        // pays where most entries sit megabytes of vector away from their row (uniformly random columns) and the vector is far larger
+        // than the L2 — measured at n = 10^7 x 16: 2.73 -> 1.71 ms; band structures, however wide, are served better by the general
+        // kernel (their gathers hit L2; here the entries of a row would crowd one panel and their sums serialise): w = 10^6: 1.86 vs 2.47 ms
+        // Round 2 (tools/ab_c2.sh, paced layout against the general kernel, ms per step): n = 10^6 x 8 0.087 / 0.087, 10^6 x 16
+        // 0.108 / 0.146, 2 * 10^6 x 8 0.135 / 0.223, 3 * 10^6 x 16 0.290 / 0.660 — the paced layout pays from a vector of ~8 MB on;
+        // the DYNAMIC tiles (fallback for unbalanced matrices) only from ~24 MB on (10^6 x 8: 0.168, worse than no panels).
+        // of the off-diagonal entries of the rows the count covers (the diagonal is never far; the long rows' entries are not counted:
+        // a graph whose hubs hold most of the entries — PageRank's out-link side — is judged by its other rows)
+        const bool spread = 2 * far_entries > slice_entries - std::min<uint64_t>(n, slice_entries);
+        const bool pays = m->n_cols >= (3ull << 20) && spread;
+        // (tools/ab_small_paced.sh after the accumulation moved to the VALU, paced / general: 7 * 10^5 x 8 0.058 / 0.048, 7 * 10^5 x 16
+        // 0.074 / 0.088, 10^6 x 8 0.070 / 0.086, 10^6 x 16 0.099 / 0.145, 1.5 * 10^6 x 8 0.094 / 0.151: from 9 * 10^5 columns on)
+        const bool pays_paced = m->n_cols >= 900000ull && spread;
+        const uint64_t n_tiles = (n + SL_PANEL_TILE - 1) / SL_PANEL_TILE;
+        const uint64_t n_panels = (m->n_cols + (1ull << SL_PANEL_COL_BITS) - 1) >> SL_PANEL_COL_BITS;
+        // wide bands (experiment knob SL_PW_BAND = log2 of the panel width): the paced layout with block-local rows and narrow panels
+        // Wide bands — a measured bandwidth beyond the LDS window of the band kernel (w > ~9 500), gathers that the general kernel
+        // serves from the L2 one request each: the paced layout with block-local rows and narrow panels makes them L1 hits
+        // (w = 12 000 .. 100 000: 0.60-0.74 -> 0.47-0.59 ms at n = 10^7 x 16; from w ~ 3 * 10^5 on the band is too thin for that and
+        // the general kernel — beyond ~10^6 the uniform-column layout above — keeps it).  SL_PW_BAND: 0 off, n = force panels of 2^n.
+        static const int env_band = [] { const char *e = getenv("SL_PW_BAND"); return e && *e ? atoi(e) : -1; }();
+        // Not for stencils: where most entries continue a diagonal from the row above, neighbouring lanes of the general kernel gather
+        // from the same lines already (7-point stencil on 215^3, w = 46 225: 0.234 ms there, 0.364 ms on this layout).
+        const bool band_wide = m->bandwidth != ~0ull && m->bandwidth >= 9500 && !spread && !m->n_long && nnz && nnz < 0x7fffffffull
+                               && m->row_offset + n <= m->n_cols;
+        const bool band_pays = n >= 1500000ull                       // n = 2^20 x 16, w = 32 768: 0.090 against 0.077 ms; 1.5 * 10^6: 0.092 / 0.098
+                               && 2 * diagonal_entries < slice_entries;
+        // SL_MATRIX_ORDER_ANY: where column panels pay, the order-free column stream takes their place (SL_ORDER_ANY solves run on it; exact
+        // orders on such a matrix take the row-slice kernels).  Hub rows need no separate kernel there: LDS atomics do not care how many
+        // entries of a row arrive at once.
+        if ((m->flags & SL_MATRIX_ORDER_ANY) && !refused && (forced || pays_paced) && nnz && nnz < 0x7fffffffull) {
+            const sl_status ps = sl_build_order_free_stream(m, d_row_ptr, d_col_idx, d_values, st);
+            if (ps != SL_OK) return ps;
+        }
+        if (m->d_pwr_idx) {
+        } else
+        if (env_band != 0 && !refused && band_wide && (env_band > 0 || band_pays)) {
+            sl_status ps = sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st, env_band > 0 ? (uint32_t)env_band : SL_PW_BAND_AUTO);
+            if (ps != SL_OK) return ps;
+        } else
+        if (!refused && (forced || pays || pays_paced) && nnz && nnz < 0x7fffffffull && n_tiles * n_panels < 0xfffffff0ull) {
+            // balanced matrices of some size: persistent paced blocks (SL_COLUMN_PANELS=3 forces the dynamic tiles instead)
+            sl_status ps = env_panels == 3 ? SL_OK : sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st);
+            if (ps == SL_OK && !m->d_pw_idx && (forced || pays)) ps = sl_build_column_panels(m, d_row_ptr, d_col_idx, d_values, n_tiles, (uint32_t)n_panels, st);
+            if (ps != SL_OK) return ps;
+        }
+    }
+
+    // 2c. column-constant operators with a unit diagonal (PageRank / PPR systems of unweighted graphs) on the uniform-column paced layout:
+    //     opt-in for now (SL_PW_INDEX_ONLY=1, read when the matrix is built and when a push runs on it)
+    {
+        static const bool idx_only = [] { const char *e = getenv("SL_PW_INDEX_ONLY"); return e && *e == '1'; }();
+        if (idx_only && m->d_pw_idx && !m->pw_band) SL_TRY(sl_detect_column_constant(m, d_row_ptr, d_col_idx, d_values, st));
+    }
+
+    return SL_OK;
+}
+
 sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, const uint32_t *d_col_idx,
                                    const double *d_values, bool keep_csr_copy)
 {
@@ -1026,65 +1098,8 @@ sl_status sl_build_from_device_csr(sl_matrix *m, const uint32_t *d_row_ptr, cons
     }
     m->device_bytes = (m->n_slices + 1 + padded_rows) * sizeof(uint32_t) + m->padded_nnz * 12 + (m->d_cols16 ? m->padded_nnz * 2 : 0);
 
-    // 2b. column panels: where neither the LDS window (bandwidth) nor the L2 (vector of a few MB) can serve the gathers
-    {
-        static const int env_panels = [] { const char *e = getenv("SL_COLUMN_PANELS"); return e && *e ? atoi(e) : -1; }();   // 0 never, 1 always
-        const bool forced = (m->flags & SL_MATRIX_COLUMN_PANELS) || env_panels == 1 || env_panels == 3;
-        const bool refused = (m->flags & SL_MATRIX_NO_COLUMN_PANELS) || env_panels == 0;
-        // pays where most entries sit megabytes of vector away from their row (uniformly random columns) and the vector is far larger
-        // than the L2 — measured at n = 10^7 x 16: 2.73 -> 1.71 ms; band structures, however wide, are served better by the general
-        // kernel (their gathers hit L2; here the entries of a row would crowd one panel and their sums serialise): w = 10^6: 1.86 vs 2.47 ms
-        // Round 2 (tools/ab_c2.sh, paced layout against the general kernel, ms per step): n = 10^6 x 8 0.087 / 0.087, 10^6 x 16
-        // 0.108 / 0.146, 2 * 10^6 x 8 0.135 / 0.223, 3 * 10^6 x 16 0.290 / 0.660 — the paced layout pays from a vector of ~8 MB on;
-        // the DYNAMIC tiles (fallback for unbalanced matrices) only from ~24 MB on (10^6 x 8: 0.168, worse than no panels).
-        // of the off-diagonal entries of the rows the count covers (the diagonal is never far; the long rows' entries are not counted:
-        // a graph whose hubs hold most of the entries — PageRank's out-link side — is judged by its other rows)
-        const bool spread = 2 * far_entries > slice_entries - std::min<uint64_t>(n, slice_entries);
-        const bool pays = m->n_cols >= (3ull << 20) && spread;
-        // (tools/ab_small_paced.sh after the accumulation moved to the VALU, paced / general: 7 * 10^5 x 8 0.058 / 0.048, 7 * 10^5 x 16
-        // 0.074 / 0.088, 10^6 x 8 0.070 / 0.086, 10^6 x 16 0.099 / 0.145, 1.5 * 10^6 x 8 0.094 / 0.151: from 9 * 10^5 columns on)
-        const bool pays_paced = m->n_cols >= 900000ull && spread;
-        const uint64_t n_tiles = (n + SL_PANEL_TILE - 1) / SL_PANEL_TILE;
-        const uint64_t n_panels = (m->n_cols + (1ull << SL_PANEL_COL_BITS) - 1) >> SL_PANEL_COL_BITS;
-        // wide bands (experiment knob SL_PW_BAND = log2 of the panel width): the paced layout with block-local rows and narrow panels
-        // Wide bands — a measured bandwidth beyond the LDS window of the band kernel (w > ~9 500), gathers that the general kernel
-        // serves from the L2 one request each: the paced layout with block-local rows and narrow panels makes them L1 hits
-        // (w = 12 000 .. 100 000: 0.60-0.74 -> 0.47-0.59 ms at n = 10^7 x 16; from w ~ 3 * 10^5 on the band is too thin for that and
-        // the general kernel — beyond ~10^6 the uniform-column layout above — keeps it).  SL_PW_BAND: 0 off, n = force panels of 2^n.
-        static const int env_band = [] { const char *e = getenv("SL_PW_BAND"); return e && *e ? atoi(e) : -1; }();
-        // Not for stencils: where most entries continue a diagonal from the row above, neighbouring lanes of the general kernel gather
-        // from the same lines already (7-point stencil on 215^3, w = 46 225: 0.234 ms there, 0.364 ms on this layout).
-        const bool band_wide = m->bandwidth != ~0ull && m->bandwidth >= 9500 && !spread && !m->n_long && nnz && nnz < 0x7fffffffull
-                               && m->row_offset + n <= m->n_cols;
-        const bool band_pays = n >= 1500000ull                       // n = 2^20 x 16, w = 32 768: 0.090 against 0.077 ms; 1.5 * 10^6: 0.092 / 0.098
-                               && 2 * diagonal_entries < slice_entries;
-        // SL_MATRIX_ORDER_ANY: where column panels pay, the order-free column stream takes their place (SL_ORDER_ANY solves run on it; exact
-        // orders on such a matrix take the row-slice kernels).  Hub rows need no separate kernel there: LDS atomics do not care how many
-        // entries of a row arrive at once.
-        if ((m->flags & SL_MATRIX_ORDER_ANY) && !refused && (forced || pays_paced) && nnz && nnz < 0x7fffffffull) {
-            const sl_status ps = sl_build_order_free_stream(m, d_row_ptr, d_col_idx, d_values, st);
-            if (ps != SL_OK) return ps;
-        }
-        if (m->d_pwr_idx) {
-        } else
-        if (env_band != 0 && !refused && band_wide && (env_band > 0 || band_pays)) {
-            sl_status ps = sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st, env_band > 0 ? (uint32_t)env_band : SL_PW_BAND_AUTO);
-            if (ps != SL_OK) return ps;
-        } else
-        if (!refused && (forced || pays || pays_paced) && nnz && nnz < 0x7fffffffull && n_tiles * n_panels < 0xfffffff0ull) {
-            // balanced matrices of some size: persistent paced blocks (SL_COLUMN_PANELS=3 forces the dynamic tiles instead)
-            sl_status ps = env_panels == 3 ? SL_OK : sl_build_paced_panels(m, d_row_ptr, d_col_idx, d_values, st);
-            if (ps == SL_OK && !m->d_pw_idx && (forced || pays)) ps = sl_build_column_panels(m, d_row_ptr, d_col_idx, d_values, n_tiles, (uint32_t)n_panels, st);
-            if (ps != SL_OK) return ps;
-        }
-    }
-
-    // 2c. column-constant operators with a unit diagonal (PageRank / PPR systems of unweighted graphs) on the uniform-column paced layout:
-    //     opt-in for now (SL_PW_INDEX_ONLY=1, read when the matrix is built and when a push runs on it)
-    {
-        static const bool idx_only = [] { const char *e = getenv("SL_PW_INDEX_ONLY"); return e && *e == '1'; }();
-        if (idx_only && m->d_pw_idx && !m->pw_band) SL_TRY(sl_detect_column_constant(m, d_row_ptr, d_col_idx, d_values, st));
-    }
+    m->far_entries = far_entries; m->slice_entries = slice_entries; m->diagonal_entries = diagonal_entries;
+    SL_TRY(sl_build_column_streams(m, d_row_ptr, d_col_idx, d_values, st));
 
     // 3. transpose
     if (m->flags & SL_MATRIX_WITH_TRANSPOSE) {
@@ -1473,6 +1488,165 @@ sl_status sl_csr_diag_pass(uint64_t n, const uint32_t *ptr, const uint32_t *idx,
     SL_HIP(hipMemcpyAsync(d_status, init, sizeof(init), hipMemcpyHostToDevice, st));
     if (n) hipLaunchKernelGGL(sl_csr_dinv_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, ptr, idx, val, d_dinv, d_status);
     SL_HIP(hipMemcpyAsync(h_status, d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    SL_HIP(hipStreamSynchronize(st));
+    return SL_OK;
+}
+
+
+// ---- in-place mutators: SparseMatrix::scale / add_diagonal (matrix/mod.rs:346-372) over CSRStorage::scale / add_diagonal
+// (sparse.rs:229-248).  Every value array the matrix carries is brought up to date: the row slices entry by entry (padding slots stay
+// untouched), the raw CSR and the transpose in place; the sorted column streams either in place (scale by a finite factor: one
+// rounded product per stored value, padding 0 stays 0) or rebuilt from the updated rows.
+__global__ __launch_bounds__(256) void sl_scale_slices_kernel(uint64_t n_rows, uint64_t n_slices, const uint32_t *slice_ptr, const uint32_t *row_len,
+                                                              double *vals, double factor)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_slices) return;
+    const uint64_t i = s * 64 + lane;
+    const uint32_t len = i < n_rows ? row_len[i] : 0u;
+    if (!len || len == SL_LONG_SENTINEL) return;
+    const uint32_t q0 = slice_ptr[s];
+    for (uint32_t k = 0; k < len; ++k) { double *p = vals + sl_val_slot(q0, k, lane); *p = __dmul_rn(*p, factor); }
+}
+__global__ __launch_bounds__(256) void sl_scale_array_kernel(uint64_t n, double *p, double factor)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (uint64_t)gridDim.x * 256) p[k] = __dmul_rn(p[k], factor);
+}
+// CSRStorage::add_diagonal (sparse.rs:236-248): `col_indices[start..end].binary_search(&row)` — the halving search of sl_view_get —
+// and `values[start + pos] += alpha`; rows where it finds nothing are skipped.  One thread per row updates the row's slot in the slice
+// layout, the same entry of the raw CSR (csr_* null: not kept) and of the transpose (t* null: none; tent = the CSR entry behind every
+// transposed entry, so the ONE duplicate the search landed on is the one that changes there too).
+__global__ __launch_bounds__(256) void sl_add_diag_kernel(uint64_t n_rows, uint64_t row_offset, uint64_t n_cols, const uint32_t *slice_ptr,
+                                                          const uint32_t *row_len, const uint32_t *cols, double *vals, const uint32_t *csr_ptr,
+                                                          const uint32_t *csr_idx, double *csr_val, const uint32_t *tptr, const uint32_t *tent,
+                                                          double *tval, double alpha)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint64_t gi = row_offset + i;
+    if (gi >= n_cols) return;                                   // (rows below the last column of a tall slice have no own column)
+    const uint32_t col = (uint32_t)gi, len = row_len[i];
+    uint32_t pos = 0xffffffffu;                                 // CSR entry index of the diagonal entry
+    if (len == SL_LONG_SENTINEL) {
+        uint32_t lo = csr_ptr[i], hi = csr_ptr[i + 1];
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2, c = csr_idx[mid];
+            if (c == col) { pos = mid; break; }
+            if (c < col) lo = mid + 1; else hi = mid;
+        }
+        if (pos == 0xffffffffu) return;
+        csr_val[pos] = __dadd_rn(csr_val[pos], alpha);
+    } else {
+        const uint64_t s = i >> 6;
+        const uint32_t lane = (uint32_t)(i & 63u), q0 = slice_ptr[s], q1 = slice_ptr[s + 1];
+        uint32_t lo = 0, hi = len, at = 0xffffffffu;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2, c = cols[sl_col_slot(q0, q1, mid, lane)];
+            if (c == col) { at = mid; break; }
+            if (c < col) lo = mid + 1; else hi = mid;
+        }
+        if (at == 0xffffffffu) return;
+        double *p = vals + sl_val_slot(q0, at, lane);
+        *p = __dadd_rn(*p, alpha);
+        if (csr_ptr) { pos = csr_ptr[i] + at; csr_val[pos] = __dadd_rn(csr_val[pos], alpha); }
+    }
+    if (tptr && pos != 0xffffffffu)
+        for (uint32_t e = tptr[col]; e < tptr[col + 1]; ++e)
+            if (tent[e] == pos) { tval[e] = __dadd_rn(tval[e], alpha); break; }
+}
+// the rows of the slice layout back as a plain CSR (a matrix built without SL_MATRIX_KEEP_CSR holds no other copy of its rows, and
+// has no hub rows: those make the build keep the raw arrays)
+__global__ __launch_bounds__(256) void sl_slices_to_csr_kernel(uint64_t n_rows, const uint32_t *slice_ptr, const uint32_t *row_len, const uint32_t *cols,
+                                                               const double *vals, const uint32_t *row_ptr, uint32_t *col_idx, double *values)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint64_t s = i >> 6;
+    const uint32_t lane = (uint32_t)(i & 63u), q0 = slice_ptr[s], q1 = slice_ptr[s + 1], len = row_len[i], k0 = row_ptr[i];
+    for (uint32_t k = 0; k < len; ++k) { col_idx[k0 + k] = cols[sl_col_slot(q0, q1, k, lane)]; values[k0 + k] = vals[sl_val_slot(q0, k, lane)]; }
+}
+
+static void free_column_streams(sl_matrix *m)
+{
+    hipFree(m->d_pan_tile_ptr); hipFree(m->d_pan_row); hipFree(m->d_pan_col); hipFree(m->d_pan_val);
+    hipFree(m->d_pw_idx); hipFree(m->d_pw_val); hipFree(m->d_pw_tile_ptr); hipFree(m->d_pw_span_tab);
+    hipFree(m->d_pwr_idx); hipFree(m->d_pwr_val); hipFree(m->d_pwr_base); hipFree(m->d_pwr_tile_ptr); hipFree(m->d_pwr_diag);
+    hipFree(m->d_colval);
+    m->d_pan_tile_ptr = nullptr; m->d_pan_row = nullptr; m->d_pan_col = nullptr; m->d_pan_val = nullptr;
+    m->d_pw_idx = nullptr; m->d_pw_val = nullptr; m->d_pw_tile_ptr = nullptr; m->d_pw_span_tab = nullptr;
+    m->d_pwr_idx = nullptr; m->d_pwr_val = nullptr; m->d_pwr_base = nullptr; m->d_pwr_tile_ptr = nullptr; m->d_pwr_diag = nullptr;
+    m->d_colval = nullptr;
+    m->n_pan_tiles = m->pan_entries = 0; m->pan_balanced = false;
+    m->n_pw_tiles = m->pw_chunks = 0; m->pw_rpw = m->pw_blocks = 0; m->pw_deal = 0; m->pw_pbits = 16; m->pw_xcd = 0; m->pw_edge_rounds = 0;
+    m->pw_edge_rows = 0; m->pw_band = false; m->pw_slack = 4;
+    m->n_pwr_tiles = m->pwr_chunks = 0; m->pwr_rpb = m->pwr_blocks = 0;
+    m->device_bytes -= m->stream_bytes; m->stream_bytes = 0;
+}
+static bool has_column_streams(const sl_matrix *m) { return m->d_pan_tile_ptr || m->d_pw_idx || m->d_pwr_idx || m->d_colval; }
+
+// the sorted column streams again, from the rows as they are now (the raw CSR where the matrix keeps it, else the slices written back)
+static sl_status sl_matrix_rebuild_column_streams(sl_matrix *m)
+{
+    hipStream_t st = sl_context().stream;
+    free_column_streams(m);
+    if (m->d_row_ptr) return sl_build_column_streams(m, m->d_row_ptr, m->d_col_idx, m->d_values, st);
+    const uint64_t n = m->n_rows;
+    std::vector<uint32_t> len(n), rp(n + 1, 0);
+    if (n) SL_TRY(sl_read_back(len.data(), m->d_row_len, n * sizeof(uint32_t), st));
+    for (uint64_t i = 0; i < n; ++i) rp[i + 1] = rp[i] + len[i];
+    DevBuf d_rp, d_ci, d_va;
+    SL_TRY(d_rp.alloc_owned((n + 1) * sizeof(uint32_t))); SL_TRY(d_ci.alloc_owned((m->nnz ? m->nnz : 1) * sizeof(uint32_t)));
+    SL_TRY(d_va.alloc_owned((m->nnz ? m->nnz : 1) * sizeof(double)));
+    SL_TRY(sl_upload(d_rp.p, rp.data(), (n + 1) * sizeof(uint32_t), st));
+    if (n) hipLaunchKernelGGL(sl_slices_to_csr_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals,
+                              d_rp.as<uint32_t>(), d_ci.as<uint32_t>(), d_va.as<double>());
+    SL_HIP(hipGetLastError());
+    const sl_status r = sl_build_column_streams(m, d_rp.as<uint32_t>(), d_ci.as<uint32_t>(), d_va.as<double>(), st);
+    SL_HIP(hipStreamSynchronize(st));
+    return r;
+}
+
+sl_status sl_matrix_scale_values(sl_matrix *m, double factor)
+{
+    hipStream_t st = sl_context().stream;
+    sl_range trace_range("matrix scale");
+    auto scale = [&](double *p, uint64_t count) {
+        if (p && count) hipLaunchKernelGGL(sl_scale_array_kernel, dim3((uint32_t)std::min<uint64_t>((count + 255) / 256, 8192)), dim3(256), 0, st, count, p, factor);
+    };
+    if (m->n_slices)
+        hipLaunchKernelGGL(sl_scale_slices_kernel, dim3((uint32_t)((m->n_slices + 3) / 4)), dim3(256), 0, st, m->n_rows, m->n_slices, m->d_slice_ptr, m->d_row_len,
+                           m->d_vals, factor);
+    scale(m->d_values, m->nnz);
+    scale(m->d_tval, m->nnz);
+    SL_HIP(hipGetLastError());
+    if (has_column_streams(m)) {
+        // the column-constant table (unit diagonal by definition) does not survive a scale; the streams take the product in place when
+        // the factor is finite (their padding entries hold 0, and 0 * finite = 0), else they are rebuilt (0 * inf would poison sums)
+        const bool in_place = std::isfinite(factor) && !m->d_colval;
+        if (in_place) {
+            scale(m->d_pan_val, m->pan_entries);
+            scale(m->d_pw_val, m->pw_chunks * 256);
+            scale(m->d_pwr_val, m->pwr_chunks * SL_PWR_CHUNK);
+            scale(m->d_pwr_diag, m->d_pwr_diag ? m->n_rows : 0);
+            SL_HIP(hipGetLastError());
+        } else {
+            SL_TRY(sl_matrix_rebuild_column_streams(m));
+        }
+    }
+    SL_HIP(hipStreamSynchronize(st));
+    return SL_OK;
+}
+
+sl_status sl_matrix_shift_diagonal(sl_matrix *m, double alpha)
+{
+    hipStream_t st = sl_context().stream;
+    sl_range trace_range("matrix add_diagonal");
+    if (m->n_rows)
+        hipLaunchKernelGGL(sl_add_diag_kernel, dim3((uint32_t)((m->n_rows + 255) / 256)), dim3(256), 0, st, m->n_rows, m->row_offset, m->n_cols, m->d_slice_ptr,
+                           m->d_row_len, m->d_cols, m->d_vals, m->d_row_ptr, m->d_col_idx, m->d_values, m->d_tptr, m->d_tent, m->d_tval, alpha);
+    SL_HIP(hipGetLastError());
+    if (has_column_streams(m)) SL_TRY(sl_matrix_rebuild_column_streams(m));
     SL_HIP(hipStreamSynchronize(st));
     return SL_OK;
 }

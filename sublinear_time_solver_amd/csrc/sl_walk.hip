@@ -13,6 +13,10 @@
 // per walk, CSR rows instead of the dense n x n transition table.  Per-walk values are bit-identical to the CPU restatement of the same rule
 // (tests/test_gpu_walk.py); mean / variance are tree reductions (1e-12 relative).
 // (The estimator is mirrored as behaviour; SURVEY.md Appendix A10 explains why it is not unbiased in general.)
+// The block stride follows the number of walks of the call (walk_stride below): the generator's period is 2^32 draws, so 2048-draw
+// blocks give 2^21 distinct starting points; a call with more walks takes narrower blocks instead of reading the same block twice.
+// SL_WALK_STREAM_SERIAL is the reference as written: sl_walk_serial_kernel, ONE lane walking the one stream walk after walk and
+// adding mean and variance in walk order — every number bit-identical to solver.ts for the same seed (the parity form).
 #include "sl_internal.hpp"
 #include <algorithm>
 #include <cmath>
@@ -20,6 +24,14 @@
 #include <vector>
 
 #define SL_WALK_STRIDE 2048ull
+#define SL_WALK_MAX_TOTAL (1ull << 28)      // block form: more walks than this in one call would need blocks of fewer than 16 draws
+// draws between the starting points of consecutive walks of a call with `total` walks (include/sublinear_hip.h, sl_walk_stream)
+static inline uint64_t walk_stride(uint64_t total)
+{
+    uint64_t stride = SL_WALK_STRIDE;
+    while (stride > 16 && total * stride > (1ull << 32)) stride >>= 1;
+    return stride;
+}
 // state after k draws of createSeededRandom from `state`: x -> A x + C (mod 2^32) composed k times by squaring
 __host__ __device__ inline uint32_t walk_lcg_jump(uint32_t state, uint64_t k)
 {
@@ -40,14 +52,11 @@ __device__ __forceinline__ double walk_lcg(uint64_t &state)
 // per_row = 0: all walks start at start_row, walk s reads the stream from position s * SL_WALK_STRIDE (estimateEntry).
 // per_row = W > 0 (solveRandomWalk, solver.ts:300-326): walk s of this launch belongs to coordinate start_row + s / W and is that
 // coordinate's walk s % W = walk number coordinate * W + s % W of the solve, whatever batch of coordinates the launch holds
-__global__ __launch_bounds__(256) void sl_walk_kernel(uint64_t n_walks, uint32_t seed, uint32_t start_row, uint64_t per_row, const uint32_t *row_ptr,
-                                                      const uint32_t *col_idx, const double *val, const double *b, double *values)
+// performRandomWalk (solver.ts:390-432) over the CSR row of the current state; `state` is the generator's state, advanced in place
+__device__ __forceinline__ double walk_one(uint32_t start, uint64_t &state, const uint32_t *row_ptr, const uint32_t *col_idx, const double *val,
+                                           const double *b)
 {
-    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_walks) return;
-    const uint64_t coord = per_row ? start_row + s / per_row : start_row;
-    uint64_t state = walk_lcg_jump(seed, (per_row ? coord * per_row + s % per_row : s) * SL_WALK_STRIDE);
-    uint32_t cur = (uint32_t)coord;
+    uint32_t cur = start;
     double value = 0.0;
     for (int step = 0; step < 1000; ++step) {
         const uint32_t k0 = row_ptr[cur], k1 = row_ptr[cur + 1];
@@ -68,7 +77,37 @@ __global__ __launch_bounds__(256) void sl_walk_kernel(uint64_t n_walks, uint32_t
             if (rnd <= cum) { cur = col_idx[k]; break; }
         }
     }
-    values[s] = value;
+    return value;
+}
+__global__ __launch_bounds__(256) void sl_walk_kernel(uint64_t n_walks, uint32_t seed, uint32_t start_row, uint64_t per_row, uint64_t stride,
+                                                      const uint32_t *row_ptr, const uint32_t *col_idx, const double *val, const double *b, double *values)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_walks) return;
+    const uint64_t coord = per_row ? start_row + s / per_row : start_row;
+    uint64_t state = walk_lcg_jump(seed, (per_row ? coord * per_row + s % per_row : s) * stride);
+    values[s] = walk_one((uint32_t)coord, state, row_ptr, col_idx, val, b);
+}
+// SL_WALK_STREAM_SERIAL — the reference as written (solver.ts:585-601 for one row, :300-326 coordinate after coordinate): ONE lane, ONE
+// stream; walk s starts where walk s - 1 stopped.  n_coords coordinates from start_row, W walks each; the walk values of coordinate c
+// go to values + (keep_all ? c * W : 0) (a solve reuses one buffer of W), its mean and sample variance — added in walk order as
+// Array.reduce adds them (:630-633, :313-316) — to x[c] / var[c].
+__global__ void sl_walk_serial_kernel(uint64_t n_coords, uint64_t W, uint32_t seed, uint32_t start_row, int keep_all, const uint32_t *row_ptr,
+                                      const uint32_t *col_idx, const double *val, const double *b, double *values, double *x, double *var)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t state = seed;
+    for (uint64_t c = 0; c < n_coords; ++c) {
+        double *v = values + (keep_all ? c * W : 0);
+        for (uint64_t w = 0; w < W; ++w) v[w] = walk_one((uint32_t)(start_row + c), state, row_ptr, col_idx, val, b);
+        double m = 0.0;
+        for (uint64_t w = 0; w < W; ++w) m = __dadd_rn(m, v[w]);
+        m = m / (double)W;
+        double q2 = 0.0;
+        for (uint64_t w = 0; w < W; ++w) { const double q = __dadd_rn(v[w], -m); q2 = __dadd_rn(q2, __dmul_rn(q, q)); }
+        x[c] = m;
+        var[c] = W > 1 ? q2 / (double)(W - 1) : 0.0;
+    }
 }
 
 // sum of (v - mean)^2 partials
@@ -99,7 +138,8 @@ __global__ __launch_bounds__(256) void sl_walk_sum_kernel(uint64_t n, const doub
 }
 
 extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const double *b, sl_mem where, uint64_t row, double epsilon,
-                                                   uint32_t seed, uint64_t num_samples, double *walk_values, sl_walk_result *res)
+                                                   uint32_t seed, sl_walk_stream stream, uint64_t num_samples, double *walk_values,
+                                                   sl_walk_result *res)
 {
     SL_ABI_BEGIN
     if (!m || !b || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
@@ -108,6 +148,7 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
     if (row >= m->n_rows) return sl_fail(SL_INVALID_INPUT, "Row index %llu out of bounds. Matrix has %llu rows", (unsigned long long)row, (unsigned long long)m->n_rows);
     if (!(epsilon > 0.0) && num_samples == 0) return sl_fail(SL_INVALID_INPUT, "epsilon must be positive");
     if (!m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "random-walk estimation needs the raw CSR (create with SL_MATRIX_KEEP_CSR)");
+    if (stream != SL_WALK_STREAM_BLOCKS && stream != SL_WALK_STREAM_SERIAL) return sl_fail(SL_INVALID_INPUT, "unknown sl_walk_stream %d", (int)stream);
     const uint64_t n = m->n_rows;
     hipStream_t s = sl_context().stream;
     unsigned long long hs[4];
@@ -121,6 +162,9 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
         const double ns = std::ceil(1.0 / (epsilon * epsilon));             // solver.ts:586
         num_samples = ns > 100.0 ? (uint64_t)ns : 100;
     }
+    if (stream == SL_WALK_STREAM_BLOCKS && num_samples > SL_WALK_MAX_TOTAL)
+        return sl_fail(SL_INVALID_INPUT, "%llu walks in one call: the generator's period (2^32 draws) leaves blocks of fewer than 16 draws beyond 2^28 walks",
+                       (unsigned long long)num_samples);
     DevBuf bbuf, vbuf;
     const double *db = b;
     if (where == SL_MEM_HOST) {
@@ -132,13 +176,20 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
     double *d_vals = vbuf.as<double>();
     sl_timer timer;
     SL_TRY(timer.start(s));
-    hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((num_samples + 255) / 256)), dim3(256), 0, s, num_samples, seed, (uint32_t)row, (uint64_t)0,
-                       m->d_row_ptr, m->d_col_idx, m->d_values, db, d_vals);
     double *scr = static_cast<double *>(sl_scratch(4096 * sizeof(double)));
     sl_status st = SL_OK;
     double h_sum = 0.0, h_var = 0.0;
     if (!scr) st = sl_fail(SL_ALLOCATION, "scratch");
-    if (st == SL_OK) {
+    if (st == SL_OK && stream == SL_WALK_STREAM_SERIAL) {
+        hipLaunchKernelGGL(sl_walk_serial_kernel, dim3(1), dim3(1), 0, s, (uint64_t)1, num_samples, seed, (uint32_t)row, 1, m->d_row_ptr, m->d_col_idx,
+                           m->d_values, db, d_vals, scr, scr + 1);
+        double h[2] = {0.0, 0.0};
+        hipMemcpyAsync(h, scr, sizeof(h), hipMemcpyDeviceToHost, s);
+        hipStreamSynchronize(s);
+        res->estimate = h[0]; res->variance = h[1]; res->num_samples = num_samples;
+    } else if (st == SL_OK) {
+        hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((num_samples + 255) / 256)), dim3(256), 0, s, num_samples, seed, (uint32_t)row, (uint64_t)0,
+                           walk_stride(num_samples), m->d_row_ptr, m->d_col_idx, m->d_values, db, d_vals);
         const uint32_t g = (uint32_t)std::min<uint64_t>((num_samples + 255) / 256, 2048);
         hipLaunchKernelGGL(sl_walk_sum_kernel, dim3(g), dim3(256), 0, s, num_samples, d_vals, scr);
         std::vector<double> part(g);
@@ -194,8 +245,8 @@ __global__ __launch_bounds__(256) void sl_walk_rows_kernel(uint64_t W, const dou
     if (threadIdx.x == 0) { x[blockIdx.x] = mean; var[blockIdx.x] = red[0] / (double)(W - 1); }
 }
 
-extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, sl_mem where, double epsilon, uint32_t seed, uint64_t num_walks,
-                                          double *x, double *variances, sl_random_walk_result *res)
+extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, sl_mem where, double epsilon, uint32_t seed, sl_walk_stream stream,
+                                          uint64_t num_walks, double *x, double *variances, sl_random_walk_result *res)
 {
     SL_ABI_BEGIN
     if (!m || !b || !x || !res) return sl_fail(SL_INVALID_INPUT, "null argument");
@@ -203,6 +254,7 @@ extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, s
     if (m->n_rows != m->n_cols || m->row_offset != 0) return sl_fail(SL_INVALID_INPUT, "Matrix must be square");
     if (!(epsilon > 0.0)) return sl_fail(SL_INVALID_INPUT, "epsilon must be positive");
     if (!m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "random-walk solve needs the raw CSR (create with SL_MATRIX_KEEP_CSR)");
+    if (stream != SL_WALK_STREAM_BLOCKS && stream != SL_WALK_STREAM_SERIAL) return sl_fail(SL_INVALID_INPUT, "unknown sl_walk_stream %d", (int)stream);
     const uint64_t n = m->n_rows;
     hipStream_t s = sl_context().stream;
     unsigned long long hs[4];
@@ -215,7 +267,12 @@ extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, s
     }
     if (num_walks < 2) return sl_fail(SL_INVALID_INPUT, "at least two walks per coordinate (the sample variance divides by N - 1)");
     if (num_walks > (1ull << 26)) return sl_fail(SL_INVALID_INPUT, "%llu walks per coordinate (epsilon %g): more than 2^26", (unsigned long long)num_walks, epsilon);
-    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(n, (1ull << 26) / num_walks));      // at most 512 MB of walk values at a time
+    const bool serial = stream == SL_WALK_STREAM_SERIAL;
+    if (!serial && n * num_walks > SL_WALK_MAX_TOTAL)
+        return sl_fail(SL_INVALID_INPUT, "%llu coordinates x %llu walks: the generator's period (2^32 draws) leaves blocks of fewer than 16 draws beyond 2^28 walks",
+                       (unsigned long long)n, (unsigned long long)num_walks);
+    const uint64_t stride = walk_stride(n * num_walks);
+    const uint64_t batch = serial ? 1 : std::max<uint64_t>(1, std::min<uint64_t>(n, (1ull << 26) / num_walks));      // at most 512 MB of walk values at a time
     DevBuf bbuf, vbuf, xbuf, varbuf, ybuf;
     const double *db = b;
     if (where == SL_MEM_HOST) {
@@ -226,9 +283,12 @@ extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, s
     SL_TRY(vbuf.alloc(batch * num_walks * 8)); SL_TRY(xbuf.alloc(n * 8)); SL_TRY(varbuf.alloc(n * 8)); SL_TRY(ybuf.alloc(n * 8));
     sl_timer timer;
     SL_TRY(timer.start(s));
-    for (uint64_t i0 = 0; i0 < n; i0 += batch) {
+    if (serial && n)       // the reference as written: one lane, one stream, coordinate after coordinate
+        hipLaunchKernelGGL(sl_walk_serial_kernel, dim3(1), dim3(1), 0, s, n, num_walks, seed, 0u, 0, m->d_row_ptr, m->d_col_idx, m->d_values, db,
+                           vbuf.as<double>(), xbuf.as<double>(), varbuf.as<double>());
+    for (uint64_t i0 = 0; i0 < n && !serial; i0 += batch) {
         const uint64_t rows = std::min(batch, n - i0), walks = rows * num_walks;
-        hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((walks + 255) / 256)), dim3(256), 0, s, walks, seed, (uint32_t)i0, num_walks,
+        hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((walks + 255) / 256)), dim3(256), 0, s, walks, seed, (uint32_t)i0, num_walks, stride,
                            m->d_row_ptr, m->d_col_idx, m->d_values, db, vbuf.as<double>());
         hipLaunchKernelGGL(sl_walk_rows_kernel, dim3((uint32_t)rows), dim3(256), 0, s, num_walks, vbuf.as<double>(), xbuf.as<double>() + i0, varbuf.as<double>() + i0);
     }

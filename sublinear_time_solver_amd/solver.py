@@ -44,6 +44,12 @@ class SolverOptions:
     def fast() -> "SolverOptions":             # solver/mod.rs:79-89
         return SolverOptions(tolerance=1e-3, max_iterations=100)
 
+    @staticmethod
+    def streaming(interval: int) -> "SolverOptions":   # solver/mod.rs:101-116 (sl_neumann_options_streaming)
+        o = SolverOptions(tolerance=1e-4, max_iterations=1000, collect_stats=True, compute_error_bounds=False)
+        o.streaming_interval = interval          # paces the caller's loop over NeumannState.run_steps (PartialSolution, solver/mod.rs:197-214)
+        return o
+
 
 @dataclass
 class SolverResult:
@@ -55,6 +61,10 @@ class SolverResult:
     error_bounds: Optional[float] = None
     stats: Optional[dict] = None
     term_norms: Optional[np.ndarray] = None
+
+    def meets_quality_criteria(self, tolerance: float) -> bool:
+        """SolverResult::meets_quality_criteria, solver/mod.rs:192-195"""
+        return bool(self.converged and self.residual_norm <= tolerance)
 
 
 class SparseMatrix:
@@ -229,6 +239,17 @@ class SparseMatrix:
         ro, va = np.empty(cap, dtype=np.uint32), np.empty(cap, dtype=np.float64)
         L.check(lib.sl_matrix_col(self._h, col, cap, L.ptr(ro), L.ptr(va), C.byref(n)))
         return iter(list(zip(ro[: n.value].tolist(), va[: n.value].tolist())))
+
+    def scale(self, factor: float) -> None:
+        """SparseMatrix::scale, matrix/mod.rs:346-354 over CSRStorage::scale, sparse.rs:229-233: every stored value *= factor, in place on
+        the device (every layout copy).  A `&mut self` method: no solve may be running on the matrix; states / sessions created before
+        keep their old D^-1 and must be re-created."""
+        L.check(L.load().sl_matrix_scale(self._h, float(factor)))
+
+    def add_diagonal(self, alpha: float) -> None:
+        """SparseMatrix::add_diagonal, matrix/mod.rs:356-372 over CSRStorage::add_diagonal, sparse.rs:236-248: A += alpha I in place; a row
+        without a stored diagonal entry is silently skipped as in the reference; non-square: InvalidInput."""
+        L.check(L.load().sl_matrix_add_diagonal(self._h, float(alpha)))
 
     def frobenius_norm(self) -> float:
         """Matrix::frobenius_norm, matrix/mod.rs:74-82 (tree-reduced on the device: equal to the reference's sequential sum to rounding)"""
@@ -591,16 +612,89 @@ def estimate_entry(matrix: SparseMatrix, b, row: int, theta: float = 1e-8, max_r
     return res
 
 
-def random_walk_solve(matrix: SparseMatrix, b, epsilon: float, seed: int, num_walks: int = 0) -> dict:
+# ---- solver::utils (solver/mod.rs:363-461) on device-reduced vectors -----------------------------------------------------------------
+NORM_TYPES = {"l1": L.SL_NORM_L1, "l2": L.SL_NORM_L2, "linf": L.SL_NORM_LINF, "weighted": L.SL_NORM_WEIGHTED}
+CONVERGENCE_MODES = {"residual_norm": L.SL_CONV_RESIDUAL_NORM, "relative_residual": L.SL_CONV_RELATIVE_RESIDUAL,
+                     "solution_change": L.SL_CONV_SOLUTION_CHANGE, "relative_solution_change": L.SL_CONV_RELATIVE_SOLUTION_CHANGE,
+                     "combined": L.SL_CONV_COMBINED}
+
+
+def _norm(fn_name: str, v) -> float:
+    v = _f64(v)
+    out = C.c_double(0.0)
+    L.check(getattr(L.load(), fn_name)(v.size, L.ptr(v), C.byref(out), L.SL_MEM_HOST))
+    return out.value
+
+
+def l2_norm(v) -> float:
+    """utils::l2_norm, solver/mod.rs:369-371"""
+    return _norm("sl_l2_norm", v)
+
+
+def l1_norm(v) -> float:
+    """utils::l1_norm, solver/mod.rs:374-376"""
+    return _norm("sl_l1_norm", v)
+
+
+def linf_norm(v) -> float:
+    """utils::linf_norm, solver/mod.rs:379-381 (NaN entries are ignored as f64::max ignores them)"""
+    return _norm("sl_linf_norm", v)
+
+
+def compute_norm(v, norm_type: str = "l2") -> float:
+    """utils::compute_norm, solver/mod.rs:384-391 (weighted falls back to l2 there)"""
+    if norm_type not in NORM_TYPES:
+        raise SolverError(4, f"Unknown norm type: {norm_type}")
+    v = _f64(v)
+    out = C.c_double(0.0)
+    L.check(L.load().sl_compute_norm(v.size, L.ptr(v), NORM_TYPES[norm_type], C.byref(out), L.SL_MEM_HOST))
+    return out.value
+
+
+def compute_residual(matrix: "SparseMatrix", x, b, order: int = L.SL_ORDER_CSR_SEQUENTIAL) -> np.ndarray:
+    """utils::compute_residual, solver/mod.rs:394-405: r = A x - b"""
+    x, b = _f64(x), _f64(b)
+    if x.size != matrix.cols() or b.size != matrix.rows():
+        raise SolverError(5, f"Dimension mismatch: x {x.size} / b {b.size} against a {matrix.rows()} x {matrix.cols()} matrix")
+    r = np.empty(matrix.rows())
+    L.check(L.load().sl_compute_residual(matrix._h, L.ptr(x), L.ptr(b), L.ptr(r), order, L.SL_MEM_HOST))
+    return r
+
+
+def check_convergence(residual_norm: float, tolerance: float, mode: str, b_norm: float, prev_solution, current_solution) -> bool:
+    """utils::check_convergence, solver/mod.rs:408-461"""
+    if mode not in CONVERGENCE_MODES:
+        raise SolverError(4, f"Unknown convergence mode: {mode}")
+    cur = _f64(current_solution)
+    prev = None if prev_solution is None else _f64(prev_solution)
+    out = C.c_int(0)
+    L.check(L.load().sl_check_convergence(float(residual_norm), float(tolerance), CONVERGENCE_MODES[mode], float(b_norm), cur.size,
+                                          L.ptr(prev), L.ptr(cur), L.SL_MEM_HOST, C.byref(out)))
+    return bool(out.value)
+
+
+WALK_STREAMS = {"blocks": L.SL_WALK_STREAM_BLOCKS, "reference": L.SL_WALK_STREAM_SERIAL, "serial": L.SL_WALK_STREAM_SERIAL}
+
+
+def _walk_stream(stream: str) -> int:
+    if stream not in WALK_STREAMS:
+        raise SolverError(4, f"Unknown random-walk stream: {stream} (blocks | reference)")
+    return WALK_STREAMS[stream]
+
+
+def random_walk_solve(matrix: SparseMatrix, b, epsilon: float, seed: int, num_walks: int = 0, stream: str = "blocks") -> dict:
     """solveRandomWalk, core/solver.ts:278-357 (the `random-walk` method of SublinearSolver.solve): every coordinate from
     max(100, ceil(1 / eps^2)) absorbing walks, mean and sample variance per coordinate, residual ||A x - b||_2, converged = residual < eps.
+    stream = "blocks": one lane per walk, each reading its own block of the seed's stream (throughput); "reference": the ONE stream walked
+    serially as the reference does — every x_i and variance bit-identical to solver.ts for the same seed (include/sublinear_hip.h, sl_walk_stream).
     Never raises on a missed epsilon (the TS-shaped caller does); the matrix needs its raw CSR (keep_csr / with_transpose)."""
     b = _f64(b)
     n = matrix.rows()
     if b.size != n:
         raise SolverError(5, f"Vector length {b.size} does not match matrix rows {n}")
     x, var, res = np.empty(n), np.empty(n), L.RandomWalkResult()
-    st = L.load().sl_solve_random_walk(matrix._h, L.ptr(b), L.SL_MEM_HOST, float(epsilon), seed & 0xFFFFFFFF, int(num_walks), L.ptr(x), L.ptr(var), C.byref(res))
+    st = L.load().sl_solve_random_walk(matrix._h, L.ptr(b), L.SL_MEM_HOST, float(epsilon), seed & 0xFFFFFFFF, _walk_stream(stream), int(num_walks),
+                                       L.ptr(x), L.ptr(var), C.byref(res))
     if st not in (0, 3):
         L.check(st)
     return {"solution": x, "variances": var, "iterations": int(res.iterations), "num_walks": int(res.num_walks), "residual": res.residual,
@@ -689,6 +783,9 @@ def _matrix_from_json(matrix, **kw) -> SparseMatrix:
 class SublinearSolver:
     """new SublinearSolver({method, epsilon, maxIterations, timeout?, seed?}) — core/solver.ts:36-58.
 
+    `stream` (random-walk method and the random-walk branch of estimate_entry): "blocks" = one lane per walk, every walk its own block of
+    the seed's stream; "reference" = the reference's ONE serial stream — results bit-identical to solver.ts for the same seed.
+
     `neumann` runs the exact series (the TS sign bug of solver.ts:157-163 is NOT reproduced,
     SURVEY.md §0.3); `forward-push` / `backward-push` / `bidirectional` (aliases in the reference,
     solver.ts:527-545) run the push: `push_order="reference"` = solveForwardPush's own order, one Gauss-Southwell push per
@@ -696,10 +793,12 @@ class SublinearSolver:
     thresholded push with theta = epsilon (`iterations` = rounds), `"auto"` (default) = reference order up to 4096 rows."""
 
     def __init__(self, method: str = "neumann", epsilon: float = 1e-6, max_iterations: int = 1000,
-                 timeout: Optional[float] = None, seed: Optional[int] = None, push_order: str = "auto"):
+                 timeout: Optional[float] = None, seed: Optional[int] = None, push_order: str = "auto", stream: str = "blocks"):
         if push_order not in ("auto", "reference", "synchronous"):
             raise SolverError(4, f"Unknown push_order: {push_order}")
         self.push_order = push_order
+        _walk_stream(stream)
+        self.stream = stream
         if method not in ("neumann", "random-walk", "forward-push", "backward-push", "bidirectional"):
             raise SolverError(4, f"Unknown method: {method}")
         if not (epsilon > 0):
@@ -721,7 +820,7 @@ class SublinearSolver:
             # reference seeds ONE stream with `seed || Date.now()`); a residual that misses epsilon raises as the reference throws (:335-341)
             import time as _t
             seed = (self.seed if self.seed is not None else int(_t.time() * 1e3)) & 0xFFFFFFFF
-            rw = random_walk_solve(m, b, self.epsilon, seed)
+            rw = random_walk_solve(m, b, self.epsilon, seed, stream=self.stream)
             if not rw["converged"]:
                 raise SolverError(3, "Random walk sampling failed to achieve desired accuracy")
             sol, it, res, conv = rw["solution"], rw["iterations"], rw["residual"], True
@@ -768,7 +867,8 @@ class SublinearSolver:
             if b.size != rows:
                 raise SolverError(5, f"Vector length {b.size} does not match matrix rows {rows}")
         m = SparseMatrix.from_csr(rp, ci, va, rows, rows, with_transpose=True, keep_csr=True)
-        inner = SublinearSolver(method=self.method, epsilon=epsilon, max_iterations=max_iterations, timeout=self.timeout, seed=self.seed, push_order=self.push_order)
+        inner = SublinearSolver(method=self.method, epsilon=epsilon, max_iterations=max_iterations, timeout=self.timeout, seed=self.seed, push_order=self.push_order,
+                                stream=self.stream)
         return inner.solve(m, b)["solution"]
 
     def estimate_entry(self, matrix, vector, row: int, column: int = 0, epsilon: Optional[float] = None,
@@ -787,7 +887,7 @@ class SublinearSolver:
         if method == "random-walk":                                      # solver.ts:585-601, 630-648
             res = L.WalkResult()
             seed = (self.seed if self.seed is not None else 0) & 0xFFFFFFFF
-            L.check(L.load().sl_estimate_entry_random_walk(m._h, L.ptr(b), L.SL_MEM_HOST, row, eps, seed, 0, None, C.byref(res)))
+            L.check(L.load().sl_estimate_entry_random_walk(m._h, L.ptr(b), L.SL_MEM_HOST, row, eps, seed, _walk_stream(self.stream), 0, None, C.byref(res)))
             return {"estimate": res.estimate, "variance": res.variance, "confidence": confidence, "numSamples": int(res.num_samples)}
         r = estimate_entry(m, b, row, theta=eps * 1e-2, max_rounds=self.max_iterations * 100)
         return {"estimate": r.estimate, "variance": 0.0, "confidence": 1.0 if r.converged else 0.5,

@@ -40,22 +40,77 @@ def pytest_sessionstart(session):
         subprocess.run(["make", "-C", str(ROOT / "oracle"), "liboracle.so", "liboracle_fast.so"], check=True, capture_output=True)
 
 
+# The driver runs `pytest tests -x -q -m gpu`: the first failure ends the run, so the files come in the order of what they prove — core
+# parity of the hot path first, the other kernels next, single-process surfaces, and only then everything that starts
+# processes (partitioned / dist_abi / multi_device) with the bench subprocesses last.  tests/test_collection_order_host.py pins this list.
+GPU_FILE_ORDER = [
+    "test_gpu_parity", "test_gpu_state", "test_gpu_matrix_trait", "test_gpu_matrix_mutate", "test_gpu_panels", "test_gpu_fullsize", "test_gpu_longrows",
+    "test_gpu_mpass", "test_gpu_order_any", "test_gpu_degenerate", "test_gpu_pagerank", "test_gpu_southwell", "test_gpu_walk", "test_gpu_acl",
+    "test_gpu_push_graph", "test_gpu_cg", "test_gpu_session", "test_gpu_optin_oracle", "test_gpu_fuzz", "test_gpu_cli", "test_gpu_partitioned",
+    "test_gpu_dist_abi", "test_gpu_multi_device", "test_gpu_bench",
+]
+
+
+def gpu_file_rank(path_stem: str) -> int:
+    """position of a test file in the run: listed GPU files in GPU_FILE_ORDER's order, unlisted files after the single-process ones and
+    before the multi-process ones (a new file never runs behind test_gpu_bench by accident)"""
+    if path_stem in GPU_FILE_ORDER:
+        return GPU_FILE_ORDER.index(path_stem) * 2
+    return GPU_FILE_ORDER.index("test_gpu_partitioned") * 2 - 1
+
+
+def pytest_collection_modifyitems(session, config, items):
+    items.sort(key=lambda it: gpu_file_rank(Path(str(it.fspath)).stem))      # list.sort is stable: the order inside a file stays
+
+
+def loaded_library_report() -> str:
+    """'device: <gcnArchName>, library: <path>' of the library the tests run on — and a refusal to run on the SIMT emulator unawares:
+    tests/simt's library answers sl_device_count like a GPU does, so a stray SUBLINEAR_HIP_LIB could turn a GPU run green without a GPU.
+    The emulated children of tests/test_simt_emulated.py set SIMT_ALLOW=1; nothing else may."""
+    import ctypes
+    from sublinear_time_solver_amd import _lib
+    lib = _lib.load()
+    path = os.environ.get("SUBLINEAR_HIP_LIB", str(_lib.LIB_PATH))
+    emulator = hasattr(lib, "simt_counters")
+    if emulator and os.environ.get("SIMT_ALLOW") != "1":
+        raise RuntimeError(f"the loaded library {path} is the SIMT emulator (it exports simt_counters), not the HIP build: unset SUBLINEAR_HIP_LIB "
+                           "(only the emulated children of tests/test_simt_emulated.py set SIMT_ALLOW=1)")
+    n = ctypes.c_int(0)
+    lib.sl_device_count(ctypes.byref(n))
+    name = ctypes.create_string_buffer(256)
+    if n.value > 0:
+        lib.sl_device_name(0, name, 256)
+    return f"device: {name.value.decode() or 'none'} ({n.value} visible){' [SIMT EMULATOR]' if emulator else ''}, library: {path}"
+
+
 def _has_gpu() -> bool:
-    try:
-        import ctypes
-        from sublinear_time_solver_amd import _lib
-        n = ctypes.c_int(0)
-        _lib.load().sl_device_count(ctypes.byref(n))
-        return n.value > 0
-    except Exception:
-        return False
+    import ctypes
+    from sublinear_time_solver_amd import _lib
+    n = ctypes.c_int(0)
+    _lib.load().sl_device_count(ctypes.byref(n))
+    return n.value > 0
 
 
 @pytest.fixture(scope="session")
 def gpu():
+    try:
+        report = loaded_library_report()
+    except Exception as e:      # noqa: BLE001 — whatever keeps the library from loading ends the GPU run with its message
+        pytest.fail(f"GPU tests have no fallback: {e}")
+    sys.stderr.write("\n[sublinear_hip] " + report + "\n")
     if not _has_gpu():
         pytest.fail("no HIP device or libsublinear_hip.so missing: GPU tests have no fallback")
     return True
+
+
+def pytest_report_header(config):
+    """first lines of the run: which device and which library (a `-m gpu` run's tail must show gfx950 and the in-tree .so)"""
+    if "gpu" not in (config.getoption("-m") or "") or "not gpu" in (config.getoption("-m") or ""):
+        return None
+    try:
+        return "[sublinear_hip] " + loaded_library_report()
+    except Exception as e:      # noqa: BLE001
+        return f"[sublinear_hip] library not usable: {e}"
 
 
 @pytest.fixture

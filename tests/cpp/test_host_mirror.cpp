@@ -35,6 +35,40 @@ int main()
         auto si = c.sparsity_info();
         EXPECT(si.nnz == 5 && si.rows == 3 && si.cols == 3 && si.max_nnz_per_row == 2 && si.bandwidth == 2 && !si.is_banded && si.sparsity_ratio == 5.0 / 9.0);
     }
+    {   // the `&mut self` methods: scale / add_diagonal (matrix/mod.rs:346-372 over sparse.rs:229-248) — in place on the device
+        auto c = SparseMatrix::from_triplets({{0, 0, 1.0}, {0, 2, 2.0}, {1, 0, 3.0}, {2, 0, 4.0}, {2, 2, 5.0}}, 3, 3);      // row 1 stores no diagonal
+        c.scale(-2.0);
+        EXPECT(*c.get(0, 0) == -2.0 && *c.get(0, 2) == -4.0 && *c.get(1, 0) == -6.0 && *c.get(2, 2) == -10.0 && c.nnz() == 5);
+        c.add_diagonal(0.5);
+        EXPECT(*c.get(0, 0) == -1.5 && *c.get(2, 2) == -9.5 && !c.get(1, 1).has_value() && *c.get(1, 0) == -6.0);         // row 1 silently skipped
+        std::vector<double> y(3);
+        c.multiply_vector({1.0, 1.0, 1.0}, y);
+        EXPECT(y[0] == -5.5 && y[1] == -6.0 && y[2] == -17.5);
+        bool threw = false;
+        try { SparseMatrix::from_triplets({{0, 0, 1.0}, {1, 2, 1.0}}, 2, 3).add_diagonal(1.0); } catch (const SolverError &e) { threw = e.kind == SL_INVALID_INPUT; }
+        EXPECT(threw);                                                                                                     // matrix/mod.rs:356-361
+    }
+    {   // solver::utils (solver/mod.rs:363-461), SolverOptions::streaming (:101-116), meets_quality_criteria (:192-195)
+        const std::vector<double> v = {3.0, -4.0, 0.5};
+        EXPECT(utils::l1_norm(v) == 7.5 && utils::linf_norm(v) == 4.0 && utils::l2_norm(v) == std::sqrt(25.25));
+        EXPECT(utils::compute_norm(v, utils::NormType::L1) == 7.5 && utils::compute_norm(v, utils::NormType::LInfinity) == 4.0
+               && utils::compute_norm(v, utils::NormType::Weighted) == utils::l2_norm(v));
+        auto a = SparseMatrix::from_triplets({{0, 0, 2.0}, {0, 1, 1.0}, {1, 0, 1.0}, {1, 1, 3.0}}, 2, 2);
+        std::vector<double> r;
+        utils::compute_residual(a, {1.0, 2.0}, {1.0, 1.0}, r);
+        EXPECT(r.size() == 2 && r[0] == 3.0 && r[1] == 6.0);
+        const std::vector<double> cur = {1.0, 2.0}, prev = {1.0, 2.5};
+        EXPECT(utils::check_convergence(1e-7, 1e-6, utils::ConvergenceMode::ResidualNorm, 0.0, nullptr, cur));
+        EXPECT(!utils::check_convergence(1e-3, 1e-6, utils::ConvergenceMode::RelativeResidual, 10.0, nullptr, cur));
+        EXPECT(!utils::check_convergence(0.0, 1.0, utils::ConvergenceMode::SolutionChange, 1.0, nullptr, cur));            // no previous solution
+        EXPECT(utils::check_convergence(0.0, 0.5, utils::ConvergenceMode::SolutionChange, 1.0, &prev, cur) && !utils::check_convergence(0.0, 0.49, utils::ConvergenceMode::SolutionChange, 1.0, &prev, cur));
+        EXPECT(utils::check_convergence(0.0, 0.2, utils::ConvergenceMode::RelativeSolutionChange, 1.0, &prev, cur) && !utils::check_convergence(0.0, 0.18, utils::ConvergenceMode::RelativeSolutionChange, 1.0, &prev, cur));
+        EXPECT(utils::check_convergence(1e-7, 1e-6, utils::ConvergenceMode::Combined, 0.0, nullptr, cur) && !utils::check_convergence(1e-7, 1e-6, utils::ConvergenceMode::Combined, 1e-3, nullptr, cur));
+        auto so = SolverOptions::streaming(10);
+        EXPECT(so.tolerance == 1e-4 && so.max_iterations == 1000 && so.collect_stats && !so.compute_error_bounds && so.streaming_interval == 10);
+        SolverResult sr; sr.converged = true; sr.residual_norm = 1e-5;
+        EXPECT(sr.meets_quality_criteria(1e-4) && !sr.meets_quality_criteria(1e-6));
+    }
     {   // from_dense / identity / diagonal (matrix/mod.rs:204-239)
         auto dn = SparseMatrix::from_dense({2.0, 0.0, 1.0, 3.0}, 2, 2);
         EXPECT(dn.nnz() == 3 && *dn.get(1, 0) == 1.0 && !dn.get(0, 1).has_value());

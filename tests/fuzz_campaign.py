@@ -300,7 +300,7 @@ def case_walk(seed):
     row = int(rng.integers(0, n))
     import ctypes as C
     vals, res = np.zeros(W), L.WalkResult()
-    L.check(L.load().sl_estimate_entry_random_walk(m._h, L.ptr(b), 0, row, 0.1, sd, W, L.ptr(vals), C.byref(res)))
+    L.check(L.load().sl_estimate_entry_random_walk(m._h, L.ptr(b), 0, row, 0.1, sd, 0, W, L.ptr(vals), C.byref(res)))
     assert bits_equal(vals, O.ts_random_walk_streams(rp, ci, va, b, row, W, sd)[0]), "walk values"
 
 

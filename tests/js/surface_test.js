@@ -124,6 +124,29 @@ async function rejects(p, code, re) {
     await rejects(new SublinearSolver({ method: 'random-walk', epsilon: 0.05, maxIterations: 10, seed: 3 }).solve(tri, new Array(10).fill(1)),
                   ErrorCodes.CONVERGENCE_FAILED, /Random walk sampling failed to achieve desired accuracy/);
   }
+  {   // { stream: 'reference' }: the reference's ONE serial LCG stream — estimate / variance (estimateEntry) and solution (solve) bit for
+      // bit what the reference's own TypeScript printed for these inputs (tests/golden/reference_walk_js.json, make_golden_walk.py: G9 / G10)
+    const golden = JSON.parse(require('fs').readFileSync(require('path').join(__dirname, '..', 'golden', 'reference_walk_js.json'), 'utf8'));
+    assert(golden.length === 2);
+    for (const g of golden) {
+      const gm = { rows: g.n, cols: g.n, format: 'coo', values: g.values, rowIndices: g.rows, colIndices: g.cols };
+      const rs = new SublinearSolver({ method: 'random-walk', epsilon: g.epsilon, maxIterations: 10, seed: g.seed, stream: 'reference' });
+      if (g.kind === 'estimate') {
+        const e = await rs.estimateEntry(gm, g.b, { row: g.row, column: 0, epsilon: g.epsilon, confidence: 0.9, method: 'random-walk' });
+        assert.strictEqual(e.estimate, g.expect.mean);
+        assert.strictEqual(e.variance, g.expect.variance);
+        const eb = await new SublinearSolver({ method: 'random-walk', epsilon: g.epsilon, maxIterations: 10, seed: g.seed })
+          .estimateEntry(gm, g.b, { row: g.row, column: 0, epsilon: g.epsilon, confidence: 0.9, method: 'random-walk' });
+        assert(eb.estimate !== e.estimate && eb.numSamples === e.numSamples);       // the block form: another sample of the same estimator
+      } else {
+        let err = null;
+        try { await rs.solve(gm, g.b); } catch (x) { err = x; }                     // this system misses epsilon: the reference throws there too
+        assert(err && err.code === ErrorCodes.CONVERGENCE_FAILED && Math.abs(err.details.finalResidual - g.expect.residual) < 1e-12 * g.expect.residual, String(err));
+        assert.strictEqual(err.details.variance, Math.sqrt(g.expect.totalVariance));
+      }
+    }
+    assert.throws(() => new SublinearSolver({ method: 'random-walk', epsilon: 0.1, maxIterations: 10, stream: 'nonsense' }), /Unknown random-walk stream/);
+  }
   {   // G6 (tests/mcp/mcp-tool-tests.js:27-52): 10 x 10 tridiag(-1, 10, -1), b = e0 + e9, epsilon 1e-3 -> 12 pushes, ||r|| = 5.2915e-4
     const t = { rows: 10, cols: 10, format: 'coo', values: [], rowIndices: [], colIndices: [] };
     for (let i = 0; i < 10; i++) for (const [j, v] of [[i - 1, -1], [i, 10], [i + 1, -1]]) if (j >= 0 && j < 10) { t.rowIndices.push(i); t.colIndices.push(j); t.values.push(v); }

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in sublinear_hip.h but not exported"
         assert n in L.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.sl_abi_version() == 4
+    assert lib.sl_abi_version() == 5
     assert lib.sl_status_string(3) == b"ConvergenceFailure"
 
 

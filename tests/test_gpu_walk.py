@@ -14,11 +14,11 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _walk(m, b, row, n_samples, seed, eps=0.1):
+def _walk(m, b, row, n_samples, seed, eps=0.1, stream=L.SL_WALK_STREAM_BLOCKS):
     lib = L.load()
     vals = np.zeros(max(n_samples, 1))
     res = L.WalkResult()
-    L.check(lib.sl_estimate_entry_random_walk(m._h, L.ptr(np.ascontiguousarray(b, dtype=np.float64)), 0, row, eps, seed, n_samples,
+    L.check(lib.sl_estimate_entry_random_walk(m._h, L.ptr(np.ascontiguousarray(b, dtype=np.float64)), 0, row, eps, seed, stream, n_samples,
                                               L.ptr(vals) if n_samples else None, C.byref(res)))
     return vals, res
 
@@ -107,3 +107,74 @@ def test_random_walk_method_of_the_ts_surface(gpu):
     with pytest.raises(S.SolverError) as e:                             # createTransitionMatrix: "Zero diagonal at position 1" (solver.ts:368-371)
         S.random_walk_solve(S.SparseMatrix.from_triplets([(0, 0, 1.0), (0, 1, 1.0), (1, 0, 1.0)], 2, 2, keep_csr=True), [1.0, 1.0], 0.1, 1)
     assert e.value.status == 2 and "Zero diagonal at position 1" in str(e.value)
+
+
+# ---- SL_WALK_STREAM_SERIAL: the reference AS WRITTEN (one stream walked serially) — bit for bit ------------------------------------------
+def test_serial_stream_equals_the_executed_reference(gpu):
+    """tests/golden/reference_walk.npz holds what the reference's own TypeScript walk code printed for these inputs
+    (tests/golden/make_golden_walk.py): every per-walk value, estimate and variance of estimateEntry, every x_i / variance_i /
+    totalVariance of solveRandomWalk must come back from the device with the same bits under stream = serial"""
+    from tests.test_oracle_walk import golden_walk_cases
+    kinds = set()
+    for k, g, c in golden_walk_cases():
+        m = S.SparseMatrix.from_csr(c["rp"], c["ci"], c["va"], c["n"], c["n"], keep_csr=True)
+        if k + "/estimates" in g:
+            want = g[k + "/estimates"]
+            vals, res = _walk(m, c["b"], c["row"], 0, c["seed"], eps=c["eps"], stream=L.SL_WALK_STREAM_SERIAL)      # the count from epsilon, as the reference derives it
+            assert res.num_samples == want.size, k
+            vals, res = _walk(m, c["b"], c["row"], want.size, c["seed"], eps=c["eps"], stream=L.SL_WALK_STREAM_SERIAL)
+            assert (vals.view(np.uint64) == want.view(np.uint64)).all(), k
+            assert (res.estimate, res.variance) == tuple(g[k + "/mean_variance"]), k
+            kinds.add("estimate")
+        else:
+            r = S.random_walk_solve(m, c["b"], c["eps"], c["seed"], stream="reference")
+            assert (r["solution"].view(np.uint64) == g[k + "/solution"].view(np.uint64)).all(), k
+            assert (r["variances"].view(np.uint64) == g[k + "/variances"].view(np.uint64)).all(), k
+            tv, res = g[k + "/total_variance_residual"]
+            assert r["total_variance"] == tv, k
+            assert abs(r["residual"] - res) <= 1e-12 * res, k                       # (the norm of the residual is a tree reduction on the device)
+            assert not r["converged"]                                               # these systems miss epsilon: the reference throws there
+            kinds.add("solve")
+    assert kinds == {"estimate", "solve"}
+
+
+def test_serial_stream_against_the_oracle_on_larger_systems(gpu):
+    n, seed = 3000, 77
+    rp, ci, va, _ = G.sdd_rows(n, 8, seed=3, half_bandwidth=60)
+    b = np.random.default_rng(4).standard_normal(n)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, keep_csr=True)
+    for row, N in ((0, 2500), (n - 1, 400)):
+        gv, res = _walk(m, b, row, N, seed, stream=L.SL_WALK_STREAM_SERIAL)
+        ov, om, ovar = O.ts_random_walk_serial(rp, ci, va, b, row, N, seed)
+        assert (gv.view(np.uint64) == ov.view(np.uint64)).all() and (res.estimate, res.variance) == (om, ovar)
+        bv, _ = _walk(m, b, row, N, seed)                                           # the block form: walk 0 is the same walk, the rest differ
+        assert bv[0] == gv[0] and (bv != gv).any()
+    # the TS surface takes {stream: 'reference'}
+    tri = {"rows": 3, "cols": 3, "format": "coo", "values": [4.0, -1.0, -1.0, 5.0, -2.0, -1.0, 6.0], "rowIndices": [0, 0, 1, 1, 1, 2, 2],
+           "colIndices": [0, 1, 0, 1, 2, 1, 2]}
+    trp, tci, tva = O.csr_from_triplets(tri["rowIndices"], tri["colIndices"], tri["values"], 3, 3)
+    out = S.SublinearSolver(method="random-walk", epsilon=0.1, seed=11, stream="reference").estimate_entry(tri, [1.0, 2.0, 3.0], row=1, method="random-walk")
+    om, ovar, ns = O.ts_random_walk_estimate(trp, tci, tva, [1.0, 2.0, 3.0], 1, 0.1, 11)
+    assert (out["estimate"], out["variance"], out["numSamples"]) == (om, ovar, ns)
+    with pytest.raises(S.SolverError):
+        S.SublinearSolver(method="random-walk", stream="nonsense")
+
+
+def test_block_stride_shrinks_beyond_the_generators_period(gpu):
+    """more than 2^21 walks in one call: blocks of 1024 draws instead of a second pass over the same 2048-draw blocks — the
+    per-walk values still equal the oracle's block form, and walk s no longer equals walk s + 2^21"""
+    n = 64
+    rp, ci, va, _ = G.sdd_rows(n, 4, seed=2)
+    b = np.random.default_rng(6).standard_normal(n)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, keep_csr=True)
+    N = (1 << 21) + 4096
+    gv, res = _walk(m, b, 5, N, 9)
+    assert res.num_samples == N and O.walk_stride(N) == 1024
+    head = np.arange(0, 4096)
+    for s in (0, 1, 4095):                                                         # spot values against the block rule at THIS call's stride
+        one, _, _ = O.ts_random_walk_streams(rp, ci, va, b, 5, 1, O.ts_lcg_jump(9, s * 1024))
+        assert gv[s] == one[0]
+    assert (gv[head] != gv[head + (1 << 21)]).any()
+    with pytest.raises(S.SolverError) as e:
+        _walk(m, b, 5, (1 << 28) + 1, 9)
+    assert e.value.kind == "InvalidInput"

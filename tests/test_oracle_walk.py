@@ -63,3 +63,54 @@ def test_a_diagonal_system_is_solved_exactly_by_every_walk():
     r = O.ts_random_walk_solve(rp, ci, va, [1.0, 2.0, 3.0, 4.0], 0.1, 1, per_walk_streams=True)
     want = np.array([1.0, 2.0, 3.0, 4.0]) * (1.0 / d)                  # b[cur] * absorptionProbs[cur], absorptionProbs = 1 / a_ii
     assert r["status"] == 0 and r["converged"] and np.abs(r["x"] - want).max() <= 4e-16 * np.abs(want).max() and r["residual"] < 1e-14 and r["total_variance"] < 1e-28
+
+
+# ---- G9 / G10: the reference's own TypeScript walk code executed on these inputs (tests/golden/make_golden_walk.py) -----------------------
+GOLDEN_WALK = Path(__file__).resolve().parent / "golden" / "reference_walk.npz"
+
+
+def golden_walk_cases():
+    g = np.load(GOLDEN_WALK)
+    for k in (str(x) for x in g["names"]):
+        n, row, seed = (int(v) for v in g[k + "/params"])
+        rp, ci, va = O.csr_from_triplets(g[k + "/rows"], g[k + "/cols"], g[k + "/values"], n, n)
+        yield k, g, dict(n=n, row=row, seed=seed, eps=float(g[k + "/epsilon"][0]), rp=rp, ci=ci, va=va, b=g[k + "/b"])
+
+
+def test_serial_forms_equal_the_executed_reference_bit_for_bit():
+    """the oracle's serial forms — what SL_WALK_STREAM_SERIAL must equal — against the numbers the reference's createSeededRandom /
+    createTransitionMatrix / performRandomWalk and its own reduce() calls produced: every walk value, mean, variance, x_i, totalVariance"""
+    seen = set()
+    for k, g, c in golden_walk_cases():
+        if k + "/estimates" in g:
+            want = g[k + "/estimates"]
+            vals, mean, var = O.ts_random_walk_serial(c["rp"], c["ci"], c["va"], c["b"], c["row"], want.size, c["seed"])
+            assert (vals.view(np.uint64) == want.view(np.uint64)).all(), k
+            assert np.unique(want).size > 10, "a fixture whose walks all agree pins nothing"
+            assert (mean, var) == tuple(g[k + "/mean_variance"]), k
+            assert O.ts_random_walk_estimate(c["rp"], c["ci"], c["va"], c["b"], c["row"], c["eps"], c["seed"]) == (mean, var, want.size), k   # the count rule too
+            seen.add("estimate")
+        else:
+            r = O.ts_random_walk_solve(c["rp"], c["ci"], c["va"], c["b"], c["eps"], c["seed"], per_walk_streams=False)
+            assert (r["x"].view(np.uint64) == g[k + "/solution"].view(np.uint64)).all(), k
+            assert (r["variances"].view(np.uint64) == g[k + "/variances"].view(np.uint64)).all(), k
+            assert (r["total_variance"], r["residual"]) == tuple(g[k + "/total_variance_residual"]), k
+            seen.add("solve")
+    assert seen == {"estimate", "solve"}
+
+
+def test_block_stride_follows_the_number_of_walks_of_a_call():
+    """2048-draw blocks give 2^21 starting points in a generator of period 2^32: a call with more walks takes narrower blocks, so that walk
+    s and walk s + 2^21 never read the same draws (with a fixed stride they were bit-identical copies)"""
+    assert O.walk_stride(1) == O.walk_stride(1 << 21) == 2048
+    assert O.walk_stride((1 << 21) + 1) == 1024 and O.walk_stride(1 << 22) == 1024 and O.walk_stride(10 ** 7) == 256
+    assert O.walk_stride(1 << 28) == 16 and O.walk_stride(1 << 40) == 16          # (the device refuses more than 2^28 walks per call)
+    for total in (1 << 21, (1 << 21) + 1, 5 * 10 ** 6, 1 << 26, 1 << 28):
+        assert total * O.walk_stride(total) <= 1 << 32                            # every walk of the call starts at its own position
+    # the failure the fixed stride had: the states of walk s and walk s + 2^21 coincide at stride 2048, and no longer at the call's stride
+    seed, s = 42, 12345
+    assert O.ts_lcg_jump(seed, s * 2048) == O.ts_lcg_jump(seed, (s + (1 << 21)) * 2048)
+    st = O.walk_stride(1 << 22)
+    assert O.ts_lcg_jump(seed, s * st) != O.ts_lcg_jump(seed, (s + (1 << 21)) * st)
+    starts = {O.ts_lcg_jump(seed, w * st) for w in range(0, 1 << 22, 4099)}
+    assert len(starts) == len(range(0, 1 << 22, 4099))

@@ -39,7 +39,7 @@ def main():
             best = None
             for _ in range(3):
                 r = L.WalkResult()
-                L.check(lib.sl_estimate_entry_random_walk(h, C.c_void_p(b.data_ptr()), L.SL_MEM_DEVICE, row, eps, 42, 0, None, C.byref(r)))
+                L.check(lib.sl_estimate_entry_random_walk(h, C.c_void_p(b.data_ptr()), L.SL_MEM_DEVICE, row, eps, 42, 0, 0, None, C.byref(r)))
                 if best is None or r.device_time_ms < best.device_time_ms:
                     best = r
             out["queries"].append({"row": row, "epsilon": eps, "walks": int(best.num_samples), "device_ms": best.device_time_ms,
