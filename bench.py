@@ -427,8 +427,10 @@ def _abi_measure(args, lib, L, torch, dev, comm, world, rank, w, verify=True):
     return out
 
 
-def main_abi(args, world, rank, local_rank, attempt=0):
-    """Every N (1 included) through the C ABI alone: sl_comm + partitioned NeumannState; torch only provides the device buffers the
+def main_abi(args, world, rank, local_rank, attempt=0, emit=True):
+    """Returns rank 0's line (None on the other ranks); prints it when `emit` (a caller that measures several exchange variants in one
+    job merges them first: exchange_variants below).
+    Every N (1 included) through the C ABI alone: sl_comm + partitioned NeumannState; torch only provides the device buffers the
     generator writes into and the device synchronisation.  Barrier = sl_comm_barrier (drains the stream, then all ranks meet), MAX
     over ranks through sl_comm_allgather.  The transport of the vectors and sums is the library's (SL_COMM_TRANSPORT: ipc | rccl)."""
     import torch
@@ -462,12 +464,15 @@ def main_abi(args, world, rank, local_rank, attempt=0):
         if "gate" in m and "skipped" not in m["gate"] and not m["gate"]["bitwise_equal"]:
             # a fast kernel whose results differ is not measured: the line carries the gate and NO value (every rank sees the same verdict;
             # not a transport failure, so no fallback is tried)
-            if rank == 0:
-                print(json.dumps({"metric": "push_iterations_x_nnz_per_sec", "value": None, "unit": "nnz*iter/s", "n_gpus": len(set(devices)), "n_ranks": world,
-                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
-                                  "vs_baseline": None, "dtype": "f64", "data": "synthetic", "error": "parity gate failed: the step's results differ from the CPU checker's; nothing was timed",
-                                  "parity_gate": m["gate"], "config": {"workload": f"S-DD(n={n_local} rows/rank, nnz/row={k}, seed={args.seed}, half-bandwidth {w_head})"}}), flush=True)
-            return
+            if rank != 0:
+                return None
+            failed_line = {"metric": "push_iterations_x_nnz_per_sec", "value": None, "unit": "nnz*iter/s", "n_gpus": len(set(devices)), "n_ranks": world,
+                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "error": "parity gate failed: the step's results differ from the CPU checker's; nothing was timed",
+                           "parity_gate": m["gate"], "config": {"workload": f"S-DD(n={n_local} rows/rank, nnz/row={k}, seed={args.seed}, half-bandwidth {w_head})", "transport": transport}}
+            if emit:
+                print(json.dumps(failed_line), flush=True)
+            return failed_line
         variants = []
         if not args.no_sweep and world > 1:                                        # the other column structures of the recipe in the same job
             for w_other in (0, w_c5, BANDED_BANDWIDTH):
@@ -495,7 +500,7 @@ def main_abi(args, world, rank, local_rank, attempt=0):
                     ref = {"error": str(e)}
             comm.barrier()
         if rank != 0:
-            return
+            return None
         nnz_total = n_global * k
         per_launch_bytes = algorithmic_bytes(n_local, n_local * k)
         launch_ms = m.get("kern_ms", m["dev_ms"] / args.steps)
@@ -565,9 +570,73 @@ def main_abi(args, world, rank, local_rank, attempt=0):
                                           "nnz_iter_per_s": sweep[bk]["nnz_iter_per_s"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(n_global, k, args.seed, w_head)
-        print(json.dumps(dry_run_line(out) if DRY_RUN else out), flush=True)
+        if emit:
+            print(json.dumps(dry_run_line(out) if DRY_RUN else out), flush=True)
+        return out
     finally:
         comm.close()
+
+
+# ---- N > 1 on one GPU per rank: the SAME line under both exchanges the library has ---------------------------------------------------------
+# BASELINE's north_star words the exchange as "RCCL all-reduce over xGMI on the halo residual vector only"; the library's default
+# transport pulls the halo strips out of IPC-mapped peer memory instead (same bytes, no collective).  Which is faster is a property of
+# the node, so the N > 1 line measures the headline structure under BOTH — `ipc`, and `rccl` with SL_COMM_HALO=allreduce (ONE ncclAllReduce
+# over the compact halo buffer) — reports both in `exchange_variants`, and takes the faster for `value`.  n_ranks_joined of the rccl variant
+# comes from ncclCommCount (sl_comm_info): the line itself says whether RCCL saw N ranks.
+EXCHANGE_VARIANTS = (("ipc", {"SL_COMM_TRANSPORT": "ipc", "SL_COMM_HALO": None}),
+                     ("rccl_allreduce", {"SL_COMM_TRANSPORT": "rccl", "SL_COMM_HALO": "allreduce"}))
+
+
+def apply_variant_env(env_spec, env=None):
+    env = os.environ if env is None else env
+    for key, val in env_spec.items():
+        if val is None:
+            env.pop(key, None)
+        else:
+            env[key] = val
+
+
+def _measured(line):
+    """a line that carries a measurement (or, in a rehearsal under the emulator, would carry one: its figures are removed, not absent)"""
+    return bool(line) and not line.get("error") and (line.get("value") is not None or "dry_run" in line)
+
+
+def variant_summary(line):
+    """what exchange_variants holds of one variant's line"""
+    cfg = line.get("config", {})
+    rl = line.get("roofline", {})
+    return {"ok": _measured(line), "value": line.get("value"), "unit": line.get("unit"), "ms_per_step": line.get("ms_per_step"),
+            "device_ms_per_step_slowest_rank": rl.get("launch_ms"), "roofline_frac_per_gpu": rl.get("frac"), "transport": cfg.get("transport"),
+            "n_ranks_joined": cfg.get("n_ranks_joined"), "exchange": cfg.get("exchange"), "exchange_verified": cfg.get("exchange_verified"),
+            "bytes_received_per_rank_per_step": cfg.get("bytes_received_per_rank_per_step"),
+            "parity_gate_bitwise_equal": (line.get("parity_gate") or {}).get("bitwise_equal"), "error": line.get("error")}
+
+
+def merge_exchange_variants(lines, failures):
+    """lines: {variant: rank 0's line}; failures: {variant: why}.  The headline is the faster measured variant (its whole line, the secondary
+    measurements of the first variant carried over), both are stated in exchange_variants."""
+    measured = {k: v for k, v in lines.items() if _measured(v)}
+    if not measured:
+        head = next((v for v in lines.values() if v), None)
+        if head is None:
+            return None
+    else:
+        best = max(measured, key=lambda k: measured[k]["value"] or 0.0)
+        head = dict(measured[best])
+        full = next((v for v in lines.values() if v and any(key in v for key in ("uniform_variant", "halo_variant", "locality_variant", "scaling_reference"))), None)
+        if full is not None and full is not measured[best]:      # the light variant won: the other column structures and the one-GPU reference were measured once, under the first
+            for key in ("uniform_variant", "halo_variant", "locality_variant", "scaling_reference"):
+                if key in full:
+                    head[key] = dict(full[key], measured_under=full.get("config", {}).get("transport")) if isinstance(full[key], dict) else full[key]
+        head.setdefault("config", {})["exchange_headline"] = best
+    ev = {k: variant_summary(v) for k, v in lines.items() if v}
+    for k, why in failures.items():
+        ev[k] = {"ok": False, "error": why}
+    ev["note"] = ("the headline structure measured under each exchange the library has, same job, same ranks: ipc = halo strips pulled out of IPC-mapped peer memory; "
+                  "rccl_allreduce = SL_COMM_TRANSPORT=rccl + SL_COMM_HALO=allreduce, ONE ncclAllReduce over the compact halo buffer (BASELINE north_star's wording); "
+                  "value / ms_per_step of the line = the faster variant (config.exchange_headline)")
+    head["exchange_variants"] = ev
+    return head
 
 
 def run_cpu_baseline(n_global, k, seed, w):
@@ -617,13 +686,14 @@ def launcher(args, argv):
         order = [t for t in order if t == "ipc"] or ["ipc"]
     attempts = []
     t_launch = time.time()
-    for att, transport in enumerate(order):
+
+    def run_attempt(att, transport, later, extra_env=None):
+        """one job of n ranks under `transport`; returns rank 0's line (dict) or None; appends its record to `attempts`"""
         left = args.total_timeout - (time.time() - t_launch)
         if left < 60 and att:      # the whole job stays inside the driver's limit: what is left would not run an attempt
             attempts.append({"transport": transport, "ok": False, "seconds": 0.0, "why": f"not started: {left:.0f} s of the total budget of {args.total_timeout:.0f} s left"})
-            continue
+            return None
         # a later transport always gets its turn: an attempt may take its own limit, and never more than its share of what is left
-        later = len(order) - att - 1
         limit = max(30.0, min(args.attempt_timeout, left - 90.0 * later))
         port = _free_port()
         job = f"{os.getpid()}_{att}"
@@ -633,12 +703,12 @@ def launcher(args, argv):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                        SL_BENCH_CHILD="1", SL_BENCH_TRANSPORT=transport, SL_BENCH_JOB=job, SL_BENCH_ATTEMPT=str(att))
             env.pop("TORCHELASTIC_RUN_ID", None)
+            env.update(extra_env or {})
             err = tempfile.TemporaryFile(mode="w+")
             logs.append(err)
             procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py")] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                           stderr=err, text=True, start_new_session=True, cwd=str(ROOT)))
         deadline, failed, why = t0 + limit, False, ""
-        out0 = ""
         import threading
         buf = []
         th = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
@@ -679,14 +749,40 @@ def launcher(args, argv):
                 tails.append(f"--- rank {r} stderr tail ---\n{txt[-1500:]}")
             elif r == 0 and txt.strip():
                 sys.stderr.write(txt[-4000:])
-        rec = {"transport": transport, "ok": (not failed) and bool(lines), "seconds": round(time.time() - t0, 1)}
+        rec = {"transport": transport + ("+halo-allreduce" if (extra_env or {}).get("SL_BENCH_HALO") == "allreduce" else ""), "ok": (not failed) and bool(lines),
+               "seconds": round(time.time() - t0, 1)}
         if failed or not lines:
             rec["why"] = why or "rank 0 printed no line"
             attempts.append(rec)
-            print(f"[bench launcher] attempt {att} (transport {transport}) failed: {rec['why']}\n" + "\n".join(tails), file=sys.stderr, flush=True)
-            continue
+            print(f"[bench launcher] attempt {att} (transport {rec['transport']}) failed: {rec['why']}\n" + "\n".join(tails), file=sys.stderr, flush=True)
+            return None
         attempts.append(rec)
-        line = json.loads(lines[-1])
+        return json.loads(lines[-1])
+
+    # one GPU per rank and no transport forced: the headline structure under BOTH exchanges of the library, one line (EXCHANGE_VARIANTS)
+    if ndev >= n and "SL_BENCH_TRANSPORTS" not in os.environ and os.environ.get("SL_BENCH_ONE_EXCHANGE") != "1" and not os.environ.get("SL_COMM_TRANSPORT"):
+        lines, failures = {}, {}
+        first = run_attempt(0, "ipc", 2)
+        if first is not None:
+            lines["ipc"] = first
+        else:
+            failures["ipc"] = attempts[-1].get("why", "failed")
+        second = run_attempt(1, "rccl", 1, {"SL_BENCH_HALO": "allreduce", **({"SL_BENCH_LIGHT": "1"} if first is not None else {})})
+        if second is not None:
+            lines["rccl_allreduce"] = second
+        else:
+            failures["rccl_allreduce"] = attempts[-1].get("why", "failed")
+        merged = merge_exchange_variants(lines, failures) if lines else None
+        if merged is not None:
+            merged.setdefault("config", {})["launcher"] = {"self_launched_ranks": n, "attempts": attempts}
+            print(json.dumps(merged), flush=True)
+            return 0
+        order = [t for t in order if t == "torch"]
+    base = len(attempts)
+    for i, transport in enumerate(order):
+        line = run_attempt(base + i, transport, len(order) - i - 1)
+        if line is None:
+            continue
         line.setdefault("config", {})["launcher"] = {"self_launched_ranks": n, "attempts": attempts}
         print(json.dumps(line), flush=True)
         return 0
@@ -794,7 +890,12 @@ def main():
             raise SystemExit("SL_BENCH_FAIL_ATTEMPT: this rank leaves before the rendezvous (test of the launcher's fallback)")
         if transport in ("ipc", "rccl"):
             os.environ["SL_COMM_TRANSPORT"] = transport
-            return main_abi(args, world, rank, local_rank, int(os.environ.get("SL_BENCH_ATTEMPT", "0")))
+            if os.environ.get("SL_BENCH_HALO") == "allreduce":      # the rccl_allreduce variant of the parent's two-exchange measurement
+                os.environ["SL_COMM_HALO"] = "allreduce"
+            if os.environ.get("SL_BENCH_LIGHT") == "1":             # second variant: the headline structure only
+                args.no_sweep, args.no_scaling_reference, args.no_cpu_baseline = True, True, True
+            main_abi(args, world, rank, local_rank, int(os.environ.get("SL_BENCH_ATTEMPT", "0")))
+            return
         args.exchange = "p2p"
     elif use_abi and world == 1:
         return main_abi(args, world, rank, local_rank)
@@ -804,8 +905,42 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("cpu:gloo,cuda:nccl" if os.environ.get("SL_BENCH_BACKEND", "nccl") == "nccl" else "gloo", rank=rank, world_size=world)
         import torch
+        one_gpu_per_rank = max(1, torch.cuda.device_count()) >= world
+        if one_gpu_per_rank and not os.environ.get("SL_COMM_TRANSPORT") and os.environ.get("SL_BENCH_ONE_EXCHANGE") != "1":
+            # both exchanges, one line (EXCHANGE_VARIANTS above): the first variant that measures carries the secondary measurements, the other runs light
+            import copy
+            lines, failures, have_full = {}, {}, False
+            for att, (vname, env_spec) in enumerate(EXCHANGE_VARIANTS):
+                apply_variant_env(env_spec)
+                a = copy.copy(args)
+                if have_full:
+                    a.no_sweep, a.no_scaling_reference, a.no_cpu_baseline = True, True, True
+                ok, err, line = 1, None, None
+                try:
+                    line = main_abi(a, world, rank, local_rank, att, emit=False)
+                except Exception as e:                      # every wait in the communicator is bounded: all ranks get here
+                    ok, err = 0, e
+                flag = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag[0]) == 1:
+                    have_full = True
+                    if rank == 0:
+                        lines[vname] = line
+                else:
+                    failures[vname] = f"failed on {'rank ' + str(rank) + ': ' + repr(err) if err else 'another rank'}"
+                    print(f"[bench rank {rank}] exchange variant {vname}: {failures[vname]}", file=sys.stderr, flush=True)
+            apply_variant_env({"SL_COMM_TRANSPORT": None, "SL_COMM_HALO": None})
+            if have_full:
+                if rank == 0:
+                    merged = merge_exchange_variants(lines, failures)
+                    print(json.dumps(dry_run_line(merged) if DRY_RUN else merged), flush=True)
+                dist.destroy_process_group()
+                return
+            print(f"[bench rank {rank}] falling back to the exchange over torch.distributed / RCCL", file=sys.stderr, flush=True)
+            args.exchange = "p2p"
+            return main_torch(args, world, rank, local_rank)
         transports = [os.environ["SL_COMM_TRANSPORT"]] if os.environ.get("SL_COMM_TRANSPORT") else ["ipc", "rccl"]
-        if max(1, torch.cuda.device_count()) < world:
+        if not one_gpu_per_rank:
             transports = [t for t in transports if t == "ipc"] or ["ipc"]
         for att, transport in enumerate(transports):
             os.environ["SL_COMM_TRANSPORT"] = transport

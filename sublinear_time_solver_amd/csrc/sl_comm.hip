@@ -110,10 +110,12 @@ const rccl_api &rccl()
 {
     static const rccl_api api = [] {
         rccl_api a;
-        // the soname first: a host process that already holds an RCCL (PyTorch bundles one) shares that copy instead of loading a second
+        // SL_RCCL_LIB = the path of the RCCL build to use (a node with several ROCm trees; the test suite's stand-in); otherwise the
+        // soname first: a host process that already holds an RCCL (PyTorch bundles one) shares that copy instead of loading a second
+        if (const char *e = getenv("SL_RCCL_LIB")) if (*e) a.lib = dlopen(e, RTLD_NOW | RTLD_LOCAL);
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (a.lib) break;
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!a.lib) return a;
         bool all = true;

@@ -410,9 +410,12 @@ size_t g_bytes = 0;
 }
 
 extern "C" {
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+// SIMT_DEVICES=N: pretend N devices (all of them this host) — what lets a rehearsal take the "one GPU per rank" branches of bench.py
+static int simt_device_count() { static const int n = [] { const char *e = getenv("SIMT_DEVICES"); const int v = e && *e ? atoi(e) : 1; return v > 0 ? v : 1; }(); return n; }
+static thread_local int simt_current_device = 0;
+hipError_t hipGetDeviceCount(int *n) { *n = simt_device_count(); return hipSuccess; }
+hipError_t hipGetDevice(int *d) { *d = simt_current_device; return hipSuccess; }
+hipError_t hipSetDevice(int d) { if (d < 0 || d >= simt_device_count()) return hipErrorInvalidValue; simt_current_device = d; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
 {
     memset(p, 0, sizeof(*p));

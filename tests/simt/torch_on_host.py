@@ -36,7 +36,8 @@ def install():
 
     c = torch.cuda
     c.is_available = lambda: True
-    c.device_count = lambda: 1
+    import os
+    c.device_count = lambda: max(1, int(os.environ.get("SIMT_DEVICES", "1") or 1))
     c.set_device = lambda d: None
     c.synchronize = lambda d=None: None
     c.empty_cache = lambda: None

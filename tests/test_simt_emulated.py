@@ -35,7 +35,8 @@ def simt_lib():
 
 def _env(lib, **extra):
     env = dict(os.environ, SUBLINEAR_HIP_LIB=str(lib), SIMT_THREADS=str(max(1, min(8, os.cpu_count() or 1))), SIMT_REPORT="1", SL_COMM_TIMEOUT_MS="120000",
-               SIMT_FAKE_TORCH="2", SIMT_ALLOW="1")      # (tests/conftest.py: tests that hand torch.cuda tensors to the ABI get torch's HOST tensors, tests/simt/torch_on_host.py)
+               SIMT_FAKE_TORCH="2", SIMT_ALLOW="1",
+               SL_RCCL_LIB=str(Path(lib).parent / "librccl.so.1"))      # (the stand-in RCCL by path: a process that imports the real torch already holds the real librccl.so.1)      # (tests/conftest.py: tests that hand torch.cuda tensors to the ABI get torch's HOST tensors, tests/simt/torch_on_host.py)
     for k in ("SL_COMM_TRANSPORT", "SL_COMM_HALO", "SL_PUSH_SMALL", "SL_QUERY_WIDE", "SL_PW_INDEX_ONLY", "SL_CG_FUSED_DOT"):
         env.pop(k, None)
     env.update(extra)
@@ -224,8 +225,8 @@ def test_bench_py_rehearsed_end_to_end_under_the_emulator(simt_lib, gpus):
     prints the line's STRUCTURE with every figure that would be a measurement removed.  A rehearsal, never a number."""
     if gpus == 1 and os.environ.get("SIMT_FULL") != "1":
         pytest.skip("runs with SIMT_FULL=1 (its cpu_baseline child takes its 12 s; the N = 2 case below covers the launcher and the line in the CPU suite)")
-    env = _env(simt_lib, SL_BENCH_DRY_RUN="1", SIMT_IPC="1", SIMT_THREADS="4" if gpus == 1 else "2", SL_COMM_TIMEOUT_MS="300000",
-               LD_LIBRARY_PATH=f"{simt_lib.parent}:{os.environ.get('LD_LIBRARY_PATH', '')}")
+    env = _env(simt_lib, SL_BENCH_DRY_RUN="1", SIMT_IPC="1", SIMT_THREADS="4" if gpus == 1 else "2", SL_COMM_TIMEOUT_MS="300000", SIMT_DEVICES=str(gpus),
+               LD_LIBRARY_PATH=f"{simt_lib.parent}:{os.environ.get('LD_LIBRARY_PATH', '')}")      # (SIMT_DEVICES = N: "one GPU per rank", so both exchanges are measured)
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--n", "30000", "--steps", "2", "--warmup", "1"], cwd=ROOT, capture_output=True,
                        text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
@@ -243,6 +244,17 @@ def test_bench_py_rehearsed_end_to_end_under_the_emulator(simt_lib, gpus):
         for v in ("uniform_variant", "halo_variant"):
             assert line[v]["exchange_verified"] is True and line[v]["parity_gate"]["bitwise_equal"] and line[v]["value"] is None
         assert "error" not in line["scaling_reference"], line["scaling_reference"]
+        _check_exchange_variants(line)
+
+
+def _check_exchange_variants(line):
+    """the N > 1 line on one GPU per rank: the headline structure under ipc AND under rccl + one all-reduce over the halo"""
+    ev = line["exchange_variants"]
+    assert set(ev) >= {"ipc", "rccl_allreduce", "note"}, ev
+    assert ev["ipc"]["ok"] and ev["ipc"]["transport"] == "ipc" and ev["ipc"]["n_ranks_joined"] == 2 and ev["ipc"]["exchange_verified"] is True, ev["ipc"]
+    ra = ev["rccl_allreduce"]
+    assert ra["ok"] and ra["transport"] == "rccl+halo-allreduce" and ra["n_ranks_joined"] == 2 and ra["exchange_verified"] is True and ra["parity_gate_bitwise_equal"], ra
+    assert line["config"]["exchange_headline"] in ("ipc", "rccl_allreduce")
 
 
 @pytest.mark.parametrize("exchange", ["abi", "p2p", "allreduce"])
@@ -257,7 +269,7 @@ def test_bench_py_rehearsed_as_the_driver_launches_it(simt_lib, exchange):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    env = _env(simt_lib, SL_BENCH_DRY_RUN="1", SL_BENCH_BACKEND="gloo", SIMT_IPC="1", SIMT_THREADS="2", SL_COMM_TIMEOUT_MS="300000",
+    env = _env(simt_lib, SL_BENCH_DRY_RUN="1", SL_BENCH_BACKEND="gloo", SIMT_IPC="1", SIMT_THREADS="2", SL_COMM_TIMEOUT_MS="300000", SIMT_DEVICES="2",
                LD_LIBRARY_PATH=f"{simt_lib.parent}:{os.environ.get('LD_LIBRARY_PATH', '')}")
     env.pop("SIMT_FAKE_TORCH", None)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
@@ -268,6 +280,8 @@ def test_bench_py_rehearsed_as_the_driver_launches_it(simt_lib, exchange):
     assert "dry_run" in line and line["value"] is None and line["ms_per_step"] is None and line["n_ranks"] == 2
     assert line["parity_gate"]["bitwise_equal"] is True, line["parity_gate"]
     assert ("torch.distributed" in line["config"]["transport"]) == (exchange != "abi")
+    if exchange == "abi":
+        _check_exchange_variants(line)
 
 
 SESSION_TOOLS = [("tools/cg_bench.py", ["--m", "20"], {}, "nnz_iter_per_s", False),

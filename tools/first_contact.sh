@@ -9,6 +9,22 @@
 #             an all-over-the-matrix system (ncclAllGather) and an uneven three-way reach;
 #         (ii) python bench.py --gpus N (the line the driver's SCALE run asks for), once per transport.
 # One job at a time, N processes, nothing side by side.
+#
+# WHAT TO LOOK AT FIRST.  Until this script runs, the library's RCCL calls have met more than one rank only against the test suite's
+# stand-in (tests/simt/fake_rccl.cpp), which implements what the code ASSUMES of RCCL.  Three assumptions a real librccl may not share —
+# if a `rccl` stage fails while its `ipc` twin passes, read its log with these in mind (SL_LOG=1 names the call that returned the error):
+#   1. IN-PLACE ncclAllGather: sl_comm.hip passes sendbuff = recvbuff + rank * count (the rank's own rows inside the gathered vector).
+#      NCCL documents exactly this aliasing as the in-place form; the stand-in accepts any overlap.  A real "invalid argument" here means
+#      the offset arithmetic (rows per rank must be equal: `equal_ranges`) is off by something the stand-in does not check.
+#   2. ZERO-LENGTH members of a group: the halo exchange is ONE ncclGroupStart / End around a Send and a Recv per peer, and a peer whose
+#      strip is empty (uneven reach, stage *_uneven) is SKIPPED on both sides by the same rule (give / need lists built from the same
+#      all-gathered reaches).  The stand-in matches sends to receives by (peer, order); real RCCL hangs — it does not fail — when one
+#      side posts a member the other skipped: a stage that ends in SL_COMM_TIMEOUT_MS with "ncclGroupEnd" last in the log is this.
+#   3. STREAM ORDER against the side stream of the boundary-first step: the collective is enqueued on the exchange stream after an event
+#      recorded behind the edge blocks on the launch stream; the stand-in runs every call synchronously, so ordering bugs cannot show
+#      there.  Symptom on hardware: `differ` in dist_smoke (a stale halo), only with SL_DIST_OVERLAP unset, gone with SL_DIST_OVERLAP=0.
+#   Also: ncclAllReduce (SL_COMM_HALO=allreduce) sums a buffer that holds -0.0 wherever a rank exports nothing, so that x + (-0.0) keeps
+#   every bit of x; a reduction that flushes -0.0 or reorders into a tree changes nothing here (each slot has exactly one non-zero term).
 set -u
 cd "$(dirname "$0")/.."
 NDEV=$(python - <<'PY'
