@@ -72,7 +72,7 @@ def sources():
 def stale(out: Path) -> bool:
     if not out.exists():
         return True
-    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [CSRC.parent.parent / "include" / "sublinear_hip.h", HERE / "simt_rt.cpp", HERE / "fake_rccl.cpp", HERE / "hip" / "hip_runtime.h",
+    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [CSRC.parent.parent / "include" / "sublinear_hip.h", HERE / "simt_rt.cpp", HERE / "simt_debug.cpp", HERE / "fake_rccl.cpp", HERE / "hip" / "hip_runtime.h",
                                                                     HERE / "rocprim" / "device" / "device_radix_sort.hpp", Path(__file__)]
     return out.stat().st_mtime < max(d.stat().st_mtime for d in deps)
 
@@ -98,7 +98,7 @@ def build(force: bool = False) -> Path:
             raise RuntimeError(f"{src.name}:\n{r.stderr[-6000:]}")
         return obj
 
-    todo = [pkg / s.name for s in sources()] + [HERE / "simt_rt.cpp"]
+    todo = [pkg / s.name for s in sources()] + [HERE / "simt_rt.cpp", HERE / "simt_debug.cpp"]
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, todo))
     r = subprocess.run([CXX, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-o", str(out), *map(str, objs), "-ldl", "-lrt"], capture_output=True, text=True)

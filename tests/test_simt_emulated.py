@@ -88,6 +88,20 @@ GROUPS = {
     "k) the partitioned solver above the ABI (distributed.py over torch.distributed) at world 1, step partials in pieces": [T + "partitioned.py"],
     "l) one process per rank through the C ABI (dist_smoke.c linked against the emulator): halos, boundary-first, paced edge rounds, rccl at world 1, a rank that never arrives": [T + "dist_abi.py"],
 }
+# one or two FAST tests of every group that otherwise waits for SIMT_FULL=1: a regression in long rows, the fuzzed paced
+# layouts, the opt-in paths, wide bands / the order-free stream, PageRank / band variants / CG is noticed by the default CPU suite
+# (durations under the emulator on 8 cores, profiles/r06_simt_durations.txt: each of these well under 6 s)
+GROUPS["m) a fast sample of the groups left to SIMT_FULL=1 (c, e, g, h, i)"] = [
+    T + "longrows.py::test_long_rows_spmv_neumann_both_orders", T + "longrows.py::test_hub_columns_and_batched_sparse_rounds_bitwise",
+    T + "longrows.py::test_duplicate_entries_in_hit_driven_sparse_rounds", T + "longrows.py::test_long_rows_push_bitwise[0.0625]",
+    T + "fuzz.py::test_random_systems_bitwise[2049-300-17-False]", T + "fuzz.py::test_random_systems_bitwise[700-699-60-True]",
+    T + "fuzz.py::test_paced_panels_random_structures_bitwise[4097-4097-cluster-12-True-2]", T + "fuzz.py::test_paced_panels_with_spans_dealt_inside_one_l2_bitwise[30000-5-500-8-8-0-30000]",
+    T + "optin_oracle.py::test_small_rounds_kernel_against_the_oracle", T + "optin_oracle.py::test_every_switch_on_at_once_leaves_the_default_solves_alone",
+    T + "mpass.py::test_wide_bands_uniform_rows[70000-12-10000]", T + "mpass.py::test_row_slice_of_a_wide_band", T + "mpass.py::test_ragged_rows_in_a_wide_band",
+    T + "order_any.py::test_order_any_on_uniform_columns[50003-16-3]", T + "order_any.py::test_push_on_an_order_any_matrix_stays_bit_exact",
+    T + "pagerank.py::test_band_kernel_variants_bitwise", T + "pagerank.py::test_compute_pagerank_of_the_ts_surface",
+    T + "cg.py::test_cg_matches_oracle", T + "cg.py::test_cg_kat_from_reference_test", T + "cg.py::test_cg_on_sdd_system_agrees_with_neumann",
+]
 GROUP_ENV = {"l)": {"SIMT_IPC": "1", "SIMT_THREADS": "2"}}      # (memfd-backed "device" memory so that IPC handles open across processes)
 
 
