@@ -174,9 +174,15 @@ sl_status sl_matrix_diagonal_dominance_factor(const sl_matrix *m, int *has_facto
 sl_status sl_matrix_spectral_radius_estimate(const sl_matrix *m, double *radius);
 /* Matrix::get (matrix/mod.rs:33, SparseMatrix::get :383-395 -> CSRStorage::get sparse.rs:142-155): *found = 0 is the reference's None
  * — row or column out of bounds, or no stored entry (an exact zero is never stored: from_triplets drops it).  A row that holds the
- * column more than once (duplicates are kept as separate entries, sparse.rs:80-132) answers with the entry the reference's
- * `binary_search` of the row's column slice lands on (the halving search; the same rule NeumannState::new's diagonal lookup
- * follows).  `row` counts from the first row of this matrix (a row slice: local row), `col` is the global column. */
+ * column more than once (duplicates are kept as separate entries, sparse.rs:80-132): Rust's slice::binary_search promises only that
+ * "any one of the matches could be returned", and WHICH one depends on the standard library the reference is built with.  This
+ * library (and its CPU checker) mirrors the classical halving search — lo = 0, hi = len; mid = lo + (hi - lo) / 2; return at the
+ * first mid whose key is equal, else lo = mid + 1 / hi = mid — which is what std's binary_search_by did up to Rust 1.81; std >= 1.82
+ * runs a branchless search without the early return and may land on another of the equal keys.  So: without duplicates in a row
+ * (every fixture and generator of the reference) the answer is THE entry; with duplicates it is one of the stored values, the one
+ * named above — bit-exact against a reference built with Rust <= 1.81, "a" match against newer ones (the same holds for the
+ * diagonal lookups of NeumannState::new, sl_matrix_col and sl_matrix_add_diagonal, which use the same search).
+ * `row` counts from the first row of this matrix (a row slice: local row), `col` is the global column. */
 sl_status sl_matrix_get(const sl_matrix *m, uint64_t row, uint64_t col, int *found, double *value);
 /* Matrix::row_iter (matrix/mod.rs:37, CSRStorage::row_iter sparse.rs:158-176): the (column, value) pairs of one row in stored order
  * = ascending column, duplicates in input order.  *count = the row's length (0 for a row out of bounds: the reference's empty

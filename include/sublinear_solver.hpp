@@ -84,7 +84,7 @@ public:
     using Triplet = std::tuple<size_t, size_t, Precision>;
     SparseMatrix(const SparseMatrix &) = delete;
     SparseMatrix &operator=(const SparseMatrix &) = delete;
-    SparseMatrix(SparseMatrix &&o) noexcept : h_(o.h_), rows_(o.rows_), cols_(o.cols_) { o.h_ = nullptr; }
+    SparseMatrix(SparseMatrix &&o) noexcept : h_(o.h_), rows_(o.rows_), cols_(o.cols_), format_(o.format_) { o.h_ = nullptr; }
     ~SparseMatrix() { if (h_) sl_matrix_destroy(h_); }
 
     static SparseMatrix from_triplets(const std::vector<Triplet> &t, size_t rows, size_t cols, bool with_transpose = false)
@@ -172,7 +172,21 @@ public:
     // add_diagonal skips rows without a stored diagonal entry; SL_INVALID_INPUT for a non-square matrix
     void scale(Precision factor) { check(sl_matrix_scale(h_, factor)); }
     void add_diagonal(Precision alpha) { check(sl_matrix_add_diagonal(h_, alpha)); }
-    const char *format_name() const { return "CSR"; }
+    // Matrix::format_name (matrix/mod.rs:557-564) / SparseMatrix::convert_to_format (:244-296).  No device work: every storage the
+    // reference converts a SparseMatrix into is filled from to_triplets() of the one before, so its multiply loop adds a row's products
+    // in the CSR loop's own sequence — the same bits (tests/test_oracle_formats.py); only the name changes.  GraphAdjacency of a
+    // non-square matrix is refused (GraphStorage::from_triplets drops entries whose column is >= rows, sparse.rs:655-690)
+    const char *format_name() const { return format_; }
+    void convert_to_format(const std::string &new_format)
+    {
+        for (const char *f : {"CSR", "CSC", "COO", "GraphAdjacency"})
+            if (new_format == f) {
+                if (new_format == "GraphAdjacency" && rows_ != cols_) throw SolverError(SL_UNSUPPORTED_FORMAT, "GraphAdjacency of a non-square matrix");
+                format_ = f;
+                return;
+            }
+        throw SolverError(SL_UNSUPPORTED_FORMAT, "Unsupported matrix format: " + new_format);
+    }
     const sl_matrix *handle() const { return h_; }
 
 private:
@@ -190,6 +204,7 @@ private:
     SparseMatrix(sl_matrix *h, size_t r, size_t c) : h_(h), rows_(r), cols_(c) {}
     sl_matrix *h_;
     size_t rows_, cols_;
+    const char *format_ = "CSR";
 };
 
 enum class StepResult { Continue, Converged, Failed };        // solver/mod.rs:197-221

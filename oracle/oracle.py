@@ -468,6 +468,38 @@ def ts_random_walk_solve(rp, ci, va, b, epsilon, seed, num_walks=0, per_walk_str
     return {"status": st, "x": x, "variances": var, "residual": res.value, "total_variance": tv.value, "converged": st == 0}
 
 
+def spmv_coo(rows, row_idx, col_idx, va, x):
+    """COOStorage::multiply_vector (sparse.rs:584-597) over entries in the order given"""
+    r, c, va, x = _u32(row_idx), _u32(col_idx), _f(va), _f(x)
+    y = np.zeros(rows)
+    lib().orc_spmv_coo(u64(rows), u64(va.size), _p(r), _p(c), _p(va), _p(x), _p(y))
+    return y
+
+
+def coo_to_csc(cols, row_idx, col_idx, va):
+    """CSCStorage::from_coo (sparse.rs:303-356): stable sort by (column, row) -> (col_ptr, row_idx, values)"""
+    r, c, va = _u32(row_idx), _u32(col_idx), _f(va)
+    cp, ro, vo = np.zeros(cols + 1, dtype=np.uint32), np.zeros(max(va.size, 1), dtype=np.uint32), np.zeros(max(va.size, 1))
+    lib().orc_coo_to_csc(u64(cols), u64(va.size), _p(r), _p(c), _p(va), _p(cp), _p(ro), _p(vo))
+    return cp, ro[: va.size], vo[: va.size]
+
+
+def spmv_csc(rows, col_ptr, row_idx, va, x):
+    """CSCStorage::multiply_vector (sparse.rs:409-430)"""
+    cp, r, va, x = _u32(col_ptr), _u32(row_idx), _f(va), _f(x)
+    y = np.zeros(rows)
+    lib().orc_spmv_csc(u64(rows), u64(cp.size - 1), _p(cp), _p(r), _p(va), _p(x), _p(y))
+    return y
+
+
+def spmv_graph(nodes, row_idx, col_idx, va, x):
+    """GraphStorage::from_triplets + multiply_vector (sparse.rs:655-690, 763-773) over triplets in the order given"""
+    r, c, va, x = _u32(row_idx), _u32(col_idx), _f(va), _f(x)
+    y = np.zeros(nodes)
+    lib().orc_spmv_graph(u64(nodes), u64(va.size), _p(r), _p(c), _p(va), u64(x.size), _p(x), _p(y))
+    return y
+
+
 def walk_stride(total_walks):
     """draws between the starting points of consecutive walks of a call (include/sublinear_hip.h, sl_walk_stream)"""
     return int(lib().orc_walk_stride(u64(total_walks)))

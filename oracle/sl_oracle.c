@@ -73,7 +73,11 @@ int orc_csr_from_triplets(uint64_t ntrip, const uint64_t *tr, const uint64_t *tc
 
 /* CSRStorage::get, sparse.rs:142-155 — binary search of the row's column slice.
  * (With duplicate columns the reference returns whichever entry the search
- * lands on; so does this.) */
+ * lands on; so does this.)  PINNED ALGORITHM: the classical halving search with an early return on Equal — core's
+ * binary_search_by up to Rust 1.81.  slice::binary_search documents "if there are multiple matches, then any one of the matches
+ * could be returned", and std >= 1.82 (a branchless loop without the early return) can pick another of the equal keys: with
+ * duplicates in a row this restatement is bit-exact against a reference built with Rust <= 1.81 and returns one of the stored
+ * matches otherwise; without duplicates there is nothing to choose. */
 int orc_csr_get(const uint32_t *row_ptr, const uint32_t *col_idx, const double *values,
                 uint64_t rows, uint64_t r, uint64_t c, double *out)
 {
@@ -310,6 +314,73 @@ double orc_linf_norm(uint64_t n, const double *v)
     double m = 0.0;                      /* fold(0.0, f64::max): max ignores NaN, as fmax does */
     for (uint64_t i = 0; i < n; ++i) m = fmax(m, fabs(v[i]));
     return m;
+}
+
+/* ---- the other storages' multiply loops (matrix/sparse.rs) ------------------------------------------------------------
+ * SparseMatrix::from_triplets always builds CSR (matrix/mod.rs:160-199); COO / CSC / Graph storage exist only as
+ * convert_to_format() of it (matrix/mod.rs:244-296), filled from to_triplets() of the storage before.  These restate the
+ * three other multiply loops over entries in THEIR storage order, so that a test can show what the device relies on: every
+ * storage reachable through SparseMatrix adds a row's products in the same sequence as the CSR loop (ascending column,
+ * duplicates in insertion order), i.e. the same bits.
+ * COOStorage::multiply_vector (sparse.rs:584-597): result.fill(0), then entry after entry result[row] += value * x[col]. */
+void orc_spmv_coo(uint64_t rows, uint64_t nnz, const uint32_t *row_idx, const uint32_t *col_idx, const double *values, const double *x, double *y)
+{
+    for (uint64_t i = 0; i < rows; ++i) y[i] = 0.0;
+    for (uint64_t k = 0; k < nnz; ++k) { const double p = values[k] * x[col_idx[k]]; y[row_idx[k]] = y[row_idx[k]] + p; }
+}
+/* CSCStorage::multiply_vector (sparse.rs:409-430): column after column, a column whose x is exactly 0.0 is skipped. */
+void orc_spmv_csc(uint64_t rows, uint64_t cols, const uint32_t *col_ptr, const uint32_t *row_idx, const double *values, const double *x, double *y)
+{
+    for (uint64_t i = 0; i < rows; ++i) y[i] = 0.0;
+    for (uint64_t c = 0; c < cols; ++c) {
+        const double xc = x[c];
+        if (xc == 0.0) continue;
+        for (uint64_t k = col_ptr[c]; k < col_ptr[c + 1]; ++k) { const double p = values[k] * xc; y[row_idx[k]] = y[row_idx[k]] + p; }
+    }
+}
+/* CSCStorage::from_coo (sparse.rs:303-356): stable sort by (column, row).  In: COO entries in any order; out: col_ptr[cols + 1], row_idx, values. */
+void orc_coo_to_csc(uint64_t cols, uint64_t nnz, const uint32_t *row_in, const uint32_t *col_in, const double *val_in, uint32_t *col_ptr, uint32_t *row_out, double *val_out)
+{
+    uint64_t *perm = (uint64_t *)malloc((nnz ? nnz : 1) * sizeof(uint64_t));
+    for (uint64_t k = 0; k < nnz; ++k) perm[k] = k;
+    /* insertion-stable merge sort by (col, row) */
+    uint64_t *tmp = (uint64_t *)malloc((nnz ? nnz : 1) * sizeof(uint64_t));
+    for (uint64_t width = 1; width < nnz; width *= 2)
+        for (uint64_t lo = 0; lo < nnz; lo += 2 * width) {
+            uint64_t mid = lo + width < nnz ? lo + width : nnz, hi = lo + 2 * width < nnz ? lo + 2 * width : nnz, a = lo, b = mid, o = lo;
+            while (a < mid && b < hi) {
+                const uint64_t pa = perm[a], pb = perm[b];
+                const int b_less = col_in[pb] < col_in[pa] || (col_in[pb] == col_in[pa] && row_in[pb] < row_in[pa]);
+                tmp[o++] = b_less ? perm[b++] : perm[a++];
+            }
+            while (a < mid) tmp[o++] = perm[a++];
+            while (b < hi) tmp[o++] = perm[b++];
+            for (uint64_t q = lo; q < hi; ++q) perm[q] = tmp[q];
+        }
+    for (uint64_t c = 0; c <= cols; ++c) col_ptr[c] = 0;
+    for (uint64_t k = 0; k < nnz; ++k) { col_ptr[col_in[k] + 1] += 1; row_out[k] = row_in[perm[k]]; val_out[k] = val_in[perm[k]]; }
+    for (uint64_t c = 0; c < cols; ++c) col_ptr[c + 1] += col_ptr[c];
+    free(perm); free(tmp);
+}
+/* GraphStorage::from_triplets + multiply_vector (sparse.rs:655-690, 763-773): out_edges[row] in triplet order (entries with weight 0
+ * or an index >= nodes are dropped), then row after row, edge after edge result[row] += weight * x[target] (targets >= len(x) skipped). */
+void orc_spmv_graph(uint64_t nodes, uint64_t nnz, const uint32_t *row_idx, const uint32_t *col_idx, const double *values, uint64_t x_len, const double *x, double *y)
+{
+    /* a row's edges in triplet order = the triplets of that row in the order given: walk the triplets once per row block */
+    for (uint64_t i = 0; i < nodes; ++i) y[i] = 0.0;
+    uint64_t *count = (uint64_t *)calloc(nodes + 1, sizeof(uint64_t));
+    for (uint64_t k = 0; k < nnz; ++k) if (values[k] != 0.0 && row_idx[k] < nodes && col_idx[k] < nodes) count[row_idx[k] + 1] += 1;
+    for (uint64_t i = 0; i < nodes; ++i) count[i + 1] += count[i];
+    uint64_t *at = (uint64_t *)malloc((nodes ? nodes : 1) * sizeof(uint64_t));
+    uint64_t *edge = (uint64_t *)malloc((nnz ? nnz : 1) * sizeof(uint64_t));
+    for (uint64_t i = 0; i < nodes; ++i) at[i] = count[i];
+    for (uint64_t k = 0; k < nnz; ++k) if (values[k] != 0.0 && row_idx[k] < nodes && col_idx[k] < nodes) edge[at[row_idx[k]]++] = k;
+    for (uint64_t i = 0; i < nodes; ++i)
+        for (uint64_t e = count[i]; e < count[i + 1]; ++e) {
+            const uint64_t k = edge[e];
+            if (col_idx[k] < x_len) { const double p = values[k] * x[col_idx[k]]; y[i] = y[i] + p; }
+        }
+    free(count); free(at); free(edge);
 }
 
 /* ------------------------------------------------------------------ a6 -- */

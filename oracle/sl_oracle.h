@@ -228,6 +228,11 @@ void orc_ts_lcg(uint32_t seed, uint64_t count, double *out);
 uint64_t orc_walk_stride(uint64_t total_walks);            /* draws between the starting points of consecutive walks of a call */
 int orc_ts_random_walk_serial(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *values_a, const double *b,
                               uint64_t start_row, uint64_t num_samples, uint32_t seed, double *values, double *mean, double *variance);
+/* the multiply loops of the storages convert_to_format() can produce (sparse.rs:409-430, 584-597, 763-773), entries in THEIR order */
+void orc_spmv_coo(uint64_t rows, uint64_t nnz, const uint32_t *row_idx, const uint32_t *col_idx, const double *values, const double *x, double *y);
+void orc_spmv_csc(uint64_t rows, uint64_t cols, const uint32_t *col_ptr, const uint32_t *row_idx, const double *values, const double *x, double *y);
+void orc_coo_to_csc(uint64_t cols, uint64_t nnz, const uint32_t *row_in, const uint32_t *col_in, const double *val_in, uint32_t *col_ptr, uint32_t *row_out, double *val_out);
+void orc_spmv_graph(uint64_t nodes, uint64_t nnz, const uint32_t *row_idx, const uint32_t *col_idx, const double *values, uint64_t x_len, const double *x, double *y);
 void orc_csr_scale(uint64_t nnz, double *values, double factor);                                   /* sparse.rs:229-233 */
 uint64_t orc_csr_add_diagonal(uint64_t rows, uint64_t row_offset, const uint32_t *row_ptr, const uint32_t *col_idx, double *values,
                               double alpha);                                                         /* sparse.rs:236-248 */

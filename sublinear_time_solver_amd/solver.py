@@ -264,9 +264,23 @@ class SparseMatrix:
         return {"nnz": int(i.nnz), "dimensions": (int(i.rows), int(i.cols)), "sparsity_ratio": i.sparsity_ratio, "avg_nnz_per_row": i.avg_nnz_per_row,
                 "max_nnz_per_row": int(i.max_nnz_per_row), "bandwidth": int(i.bandwidth), "is_banded": bool(i.is_banded)}
 
+    FORMATS = ("CSR", "CSC", "COO", "GraphAdjacency")        # SparseFormat, matrix/mod.rs:106-116
+
     def format_name(self) -> str:
-        """Matrix::format_name, matrix/mod.rs:558-565: the storage this matrix was adopted from and keeps the order of"""
-        return "CSR"
+        """Matrix::format_name, matrix/mod.rs:557-564"""
+        return getattr(self, "_format", "CSR")
+
+    def convert_to_format(self, new_format: str) -> None:
+        """SparseMatrix::convert_to_format, matrix/mod.rs:244-296.  No device work: every storage the reference can convert a SparseMatrix
+        into is filled from to_triplets() of the one before, so its multiply loop adds a row's products in the CSR loop's own sequence —
+        the same bits (tests/test_oracle_formats.py shows it on restatements of all four loops, duplicates and every conversion path
+        included).  The device copy keeps its layouts; only the name changes.  GraphAdjacency of a non-square matrix is refused: the
+        reference's GraphStorage::from_triplets silently DROPS entries whose column is >= rows (sparse.rs:655-690)."""
+        if new_format not in self.FORMATS:
+            raise SolverError(6, f"Unsupported matrix format: {new_format}")
+        if new_format == "GraphAdjacency" and self._rows != self._cols:
+            raise SolverError(6, "GraphAdjacency of a non-square matrix: the reference drops the entries beyond column `rows`; not mirrored")
+        self._format = new_format
 
     def to_csr(self):
         i = self.info()

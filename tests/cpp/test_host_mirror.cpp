@@ -32,6 +32,11 @@ int main()
         EXPECT(row2.size() == 2 && row2[0].first == 0 && row2[0].second == 4.0 && row2[1].first == 2 && row2[1].second == 5.0 && c.row_iter(9).empty());
         EXPECT(col0.size() == 2 && col0[0].first == 0 && col0[0].second == 1.0 && col0[1].first == 2 && col0[1].second == 4.0);
         EXPECT(c.frobenius_norm() == std::sqrt(55.0) && std::string(c.format_name()) == "CSR");
+        c.convert_to_format("COO");                                                    // matrix/mod.rs:244-296: the name changes, the products' bits do not
+        EXPECT(std::string(c.format_name()) == "COO" && *c.get(2, 2) == 5.0);
+        bool bad_format = false;
+        try { c.convert_to_format("ELL"); } catch (const SolverError &e) { bad_format = e.kind == SL_UNSUPPORTED_FORMAT; }
+        EXPECT(bad_format);
         auto si = c.sparsity_info();
         EXPECT(si.nnz == 5 && si.rows == 3 && si.cols == 3 && si.max_nnz_per_row == 2 && si.bandwidth == 2 && !si.is_banded && si.sparsity_ratio == 5.0 / 9.0);
     }
