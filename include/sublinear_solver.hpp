@@ -174,7 +174,7 @@ public:
     void add_diagonal(Precision alpha) { check(sl_matrix_add_diagonal(h_, alpha)); }
     // Matrix::format_name (matrix/mod.rs:557-564) / SparseMatrix::convert_to_format (:244-296).  No device work: every storage the
     // reference converts a SparseMatrix into is filled from to_triplets() of the one before, so its multiply loop adds a row's products
-    // in the CSR loop's own sequence — the same bits (tests/test_oracle_formats.py); only the name changes.  GraphAdjacency of a
+    // in the CSR loop's own sequence — the same bits (tests/test_storage_formats_host.py); only the name changes.  GraphAdjacency of a
     // non-square matrix is refused (GraphStorage::from_triplets drops entries whose column is >= rows, sparse.rs:655-690)
     const char *format_name() const { return format_; }
     void convert_to_format(const std::string &new_format)

@@ -143,7 +143,7 @@ impl Matrix for HipMatrix {
     fn cols(&self) -> usize { self.key.2 }
     fn nnz(&self) -> usize { self.key.3 }
     /// The device copy is built from `to_triplets()` of whatever storage the borrowed matrix holds; every storage the crate can convert a
-    /// SparseMatrix into (matrix/mod.rs:244-296) multiplies to the CSR loop's bits (tests/test_oracle_formats.py), so one layout serves all
+    /// SparseMatrix into (matrix/mod.rs:244-296) multiplies to the CSR loop's bits (tests/test_storage_formats_host.py), so one layout serves all
     fn format_name(&self) -> &'static str { "CSR" }
     fn get(&self, row: usize, col: usize) -> Option<Precision> {
         let (mut found, mut v): (c_int, f64) = (0, 0.0);

@@ -273,7 +273,7 @@ class SparseMatrix:
     def convert_to_format(self, new_format: str) -> None:
         """SparseMatrix::convert_to_format, matrix/mod.rs:244-296.  No device work: every storage the reference can convert a SparseMatrix
         into is filled from to_triplets() of the one before, so its multiply loop adds a row's products in the CSR loop's own sequence —
-        the same bits (tests/test_oracle_formats.py shows it on restatements of all four loops, duplicates and every conversion path
+        the same bits (tests/test_storage_formats_host.py shows it on restatements of all four loops, duplicates and every conversion path
         included).  The device copy keeps its layouts; only the name changes.  GraphAdjacency of a non-square matrix is refused: the
         reference's GraphStorage::from_triplets silently DROPS entries whose column is >= rows (sparse.rs:655-690)."""
         if new_format not in self.FORMATS:

@@ -1,7 +1,7 @@
 """Golden vectors of the reference's random-walk code AS WRITTEN (one serial LCG stream): tests/golden/reference_walk.npz.
 
-  G9   TS estimateEntry, method 'random-walk' (src/core/solver.ts:585-601, 630-634): per-walk estimates, mean, variance
-  G10  TS solveRandomWalk (src/core/solver.ts:278-333): solution, per-coordinate variances, totalVariance, residual
+  G10  TS estimateEntry, method 'random-walk' (src/core/solver.ts:585-601, 630-634): per-walk estimates, mean, variance
+  G11  TS solveRandomWalk (src/core/solver.ts:278-333): solution, per-coordinate variances, totalVariance, residual
 
 Runs ONLY in the build container (needs /root/reference and node).  The reference's shipped source for this path is TypeScript and the
 image has no tsc, so the functions on the path — createSeededRandom (core/utils.ts:161-168), MatrixOperations.getEntry / getDiagonal

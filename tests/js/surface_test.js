@@ -125,7 +125,7 @@ async function rejects(p, code, re) {
                   ErrorCodes.CONVERGENCE_FAILED, /Random walk sampling failed to achieve desired accuracy/);
   }
   {   // { stream: 'reference' }: the reference's ONE serial LCG stream — estimate / variance (estimateEntry) and solution (solve) bit for
-      // bit what the reference's own TypeScript printed for these inputs (tests/golden/reference_walk_js.json, make_golden_walk.py: G9 / G10)
+      // bit what the reference's own TypeScript printed for these inputs (tests/golden/reference_walk_js.json, make_golden_walk.py: G10 / G11)
     const golden = JSON.parse(require('fs').readFileSync(require('path').join(__dirname, '..', 'golden', 'reference_walk_js.json'), 'utf8'));
     assert(golden.length === 2);
     for (const g of golden) {

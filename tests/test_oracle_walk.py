@@ -65,7 +65,7 @@ def test_a_diagonal_system_is_solved_exactly_by_every_walk():
     assert r["status"] == 0 and r["converged"] and np.abs(r["x"] - want).max() <= 4e-16 * np.abs(want).max() and r["residual"] < 1e-14 and r["total_variance"] < 1e-28
 
 
-# ---- G9 / G10: the reference's own TypeScript walk code executed on these inputs (tests/golden/make_golden_walk.py) -----------------------
+# ---- G10 / G11: the reference's own TypeScript walk code executed on these inputs (tests/golden/make_golden_walk.py) -----------------------
 GOLDEN_WALK = Path(__file__).resolve().parent / "golden" / "reference_walk.npz"
 
 

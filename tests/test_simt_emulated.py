@@ -310,7 +310,7 @@ SESSION_TOOLS = [("tools/cg_bench.py", ["--m", "20"], {}, "nnz_iter_per_s", Fals
 
 @pytest.mark.parametrize("script,argv,extra,expect,full_only", SESSION_TOOLS, ids=[f"{s.split('/')[-1]}{'+' + '+'.join(e) if e else ''}" for s, _, e, _, _ in SESSION_TOOLS])
 def test_gpu_session_tools_rehearsed_under_the_emulator(simt_lib, script, argv, extra, expect, full_only):
-    """every command tools/r05_gpu_session.sh will spend a GPU call on, run once at a small size against the emulator (tests/simt/rehearse.py:
+    """every command tools/r06_gpu_session.sh will spend a GPU call on, run once at a small size against the emulator (tests/simt/rehearse.py:
     torch stood in for by host arrays) — so that the first minutes on a device are not lost to a typo in a tool.  What they print is not a measurement."""
     if full_only and os.environ.get("SIMT_FULL") != "1":
         pytest.skip("runs with SIMT_FULL=1")
