@@ -25,10 +25,22 @@ ROOT = HERE.parent.parent
 # SIMT_CSRC / SIMT_BUILD: another tree's kernels (e.g. `git worktree add /tmp/r03 <commit>`): does an older, hardware-verified version of a
 # kernel behave the same under the emulator?  — tells an emulator artefact from a regression
 CSRC = Path(os.environ["SIMT_CSRC"]) if os.environ.get("SIMT_CSRC") else ROOT / "sublinear_time_solver_amd" / "csrc"
-BUILD = Path(os.environ["SIMT_BUILD"]) if os.environ.get("SIMT_BUILD") else HERE / "_build"
+# SIMT_SANITIZE=1: the same library under AddressSanitizer (its own build directory): "device" allocations get their exact size, so a kernel
+# that reads or writes past a device buffer — harmless-looking on hardware, where allocations are padded to pages — is reported with the
+# kernel's source line.  Run with LD_PRELOAD=<libclang_rt.asan-x86_64.so> (tests/test_simt_asan.py does).
+SANITIZE = os.environ.get("SIMT_SANITIZE") == "1"
+BUILD = Path(os.environ["SIMT_BUILD"]) if os.environ.get("SIMT_BUILD") else HERE / ("_build_asan" if SANITIZE else "_build")
 CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g1", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing", "-pthread", "-Wno-unused-value",
          "-Wno-unused-result", "-Wno-unknown-attributes", "-Wno-ignored-attributes", f"-I{HERE}", f"-I{BUILD}"]
+if SANITIZE:
+    FLAGS += ["-fsanitize=address", "-fno-omit-frame-pointer", "-DSIMT_EXACT_ALLOC", "-shared-libasan"]
+
+
+def asan_runtime() -> str:
+    """path of the shared ASAN runtime of the compiler that builds the emulator (to LD_PRELOAD into the python that loads the library)"""
+    r = subprocess.run([CXX, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    return r.stdout.strip()
 
 REWRITES = [
     (re.compile(r"__builtin_amdgcn_"), "simt_amdgcn_"),
@@ -101,7 +113,8 @@ def build(force: bool = False) -> Path:
     todo = [pkg / s.name for s in sources()] + [HERE / "simt_rt.cpp", HERE / "simt_debug.cpp"]
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, todo))
-    r = subprocess.run([CXX, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-o", str(out), *map(str, objs), "-ldl", "-lrt"], capture_output=True, text=True)
+    r = subprocess.run([CXX, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", *(["-fsanitize=address", "-shared-libasan"] if SANITIZE else []), "-o", str(out), *map(str, objs),
+                        "-ldl", "-lrt"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-4000:])
     # the stand-in the library's dlopen("librccl.so.1") finds when this directory leads LD_LIBRARY_PATH (multi-process tests only)

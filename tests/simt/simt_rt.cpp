@@ -445,7 +445,11 @@ hipError_t hipMalloc(void **p, size_t bytes)
         q = mmap(nullptr, rounded, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         if (q == MAP_FAILED) { close(fd); *p = nullptr; return hipErrorOutOfMemory; }
     } else {
+#ifdef SIMT_EXACT_ALLOC      // the AddressSanitizer build: the allocation ends where the request ends, so the first byte past a device buffer is poisoned
+        if (posix_memalign(&q, 256, std::max<size_t>(bytes, 1)) != 0) q = nullptr;
+#else
         q = aligned_alloc(256, (bytes + 255) & ~(size_t)255);
+#endif
         if (!q) { *p = nullptr; return hipErrorOutOfMemory; }
     }
     memset(q, 0xCD, bytes);                               // fresh device memory is not zero either
