@@ -94,7 +94,8 @@ class SparseMatrix:
 
     @classmethod
     def from_csr(cls, row_ptr, col_idx, values, rows: int, cols: int, row_offset: int = 0,
-                 with_transpose: bool = False, keep_csr: bool = False, device: bool = False, column_panels=None, order_any: bool = False):
+                 with_transpose: bool = False, keep_csr: bool = False, device: bool = False, column_panels=None, order_any: bool = False,
+                 row_slice: bool = False):
         """Adopt CSRStorage arrays (matrix/sparse.rs:16-23); device=True: torch CUDA tensors.
         column_panels: None = the library decides (large systems with columns all over the vector), True / False = force / forbid
         the second, panel-ordered copy of the entries."""
@@ -110,6 +111,8 @@ class SparseMatrix:
         flags = (L.SL_MATRIX_WITH_TRANSPOSE if with_transpose else 0) | (L.SL_MATRIX_KEEP_CSR if keep_csr else 0)
         if column_panels is not None:
             flags |= L.SL_MATRIX_COLUMN_PANELS if column_panels else L.SL_MATRIX_NO_COLUMN_PANELS
+        if row_slice:      # rows [row_offset, row_offset + rows) of a SQUARE system of `cols` rows — said explicitly for the range that starts at row 0 (add_diagonal)
+            flags |= L.SL_MATRIX_ROW_SLICE
         if order_any:      # the order-free column stream: what SolverOptions(order=SL_ORDER_ANY) solves run on (results to rounding, not bit for bit)
             flags |= L.SL_MATRIX_ORDER_ANY
         L.check(lib.sl_matrix_create_csr(rows, cols, nnz, L.ptr(row_ptr), L.ptr(col_idx), L.ptr(values),

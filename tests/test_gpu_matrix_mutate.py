@@ -171,6 +171,15 @@ def test_add_diagonal_refuses_non_square_and_accepts_row_slices(gpu):
     assert changed == hi - lo
     _, _, got = _download(m, hi - lo, sl_va.size)
     assert (_bits(got) == _bits(want)).all()
+    # the range that starts at row 0 looks like a wide matrix: SL_MATRIX_ROW_SLICE says what it is
+    first = S.SparseMatrix.from_csr(rp[:lo + 1], ci[:rp[lo]], va[:rp[lo]], lo, n, keep_csr=True)
+    with pytest.raises(S.SolverError):
+        first.add_diagonal(0.5)
+    first = S.SparseMatrix.from_csr(rp[:lo + 1], ci[:rp[lo]], va[:rp[lo]], lo, n, keep_csr=True, row_slice=True)
+    first.add_diagonal(0.5)
+    want0, changed0 = O.csr_add_diagonal(rp[:lo + 1], ci[:rp[lo]], va[:rp[lo]], 0.5)
+    _, _, got0 = _download(first, lo, int(rp[lo]))
+    assert changed0 == lo and (_bits(got0) == _bits(want0)).all()
 
 
 def test_solver_utils_norms_residual_convergence(gpu):
