@@ -3,7 +3,7 @@
 tests guard against regressions, this looks for what they do not cover.  Every case is checked bit for bit against the oracle (counts
 and lists included); the first line of a failure carries everything needed to replay it (`--replay "<kind> <seed>"`).
 
-usage: python tests/fuzz_campaign.py --seconds 300 [--kinds general,paced,orderany,acl,southwell,cg,wideband,session,trait,walk] [--seed0 S]
+usage: python tests/fuzz_campaign.py --seconds 300 [--kinds general,paced,orderany,acl,southwell,cg,wideband,session,trait,walk,mutate,walkserial] [--seed0 S]
 Prints one JSON line: cases per kind, failures (each with kind + seed).  Exit status 1 when anything failed."""
 import argparse
 import json
@@ -304,7 +304,86 @@ def case_walk(seed):
     assert bits_equal(vals, O.ts_random_walk_streams(rp, ci, va, b, row, W, sd)[0]), "walk values"
 
 
-KINDS = {"trait": case_trait, "walk": case_walk, "general": case_general, "paced": case_paced, "orderany": case_orderany, "acl": case_acl, "southwell": case_southwell, "cg": case_cg,
+def case_mutate(seed):
+    """the in-place mutators on random structures (duplicated columns, hub rows, rows without a diagonal, with and without raw CSR /
+    transpose, forced paced panels now and then): a random sequence of scale / add_diagonal, then every layout copy against the CPU
+    checker applied to the plain CSR — SpMV in both orders, row_iter, the transpose, a full solve where the result is still dominant"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 2, 63, 65, 130, 900, 2500, 6000]))
+    long_rows = bool(rng.random() < 0.4) and n >= 700
+    rp, ci, va = F._random_system(rng, n, int(rng.choice([0, 0, 40])) if n > 100 else 0, int(rng.integers(1, 30)), long_rows)
+    tr = np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))
+    keep = np.ones(tr.size, dtype=bool)
+    if rng.random() < 0.5 and n > 4:                               # some rows lose their diagonal entry: add_diagonal must skip them
+        keep &= ~((tr == ci) & (rng.random(tr.size) < 0.2))
+    tr2, tc2, tv2 = tr[keep], ci[keep], va[keep]
+    if rng.random() < 0.5 and n > 2:                               # some diagonals stored twice: ONE of them changes
+        d = np.flatnonzero(tr2 == tc2)
+        d = d[rng.random(d.size) < 0.2]
+        tr2, tc2, tv2 = np.concatenate([tr2, tr2[d]]), np.concatenate([tc2, tc2[d]]), np.concatenate([tv2, rng.standard_normal(d.size)])
+    rp, ci, va = O.csr_from_triplets(tr2, tc2, tv2, n, n)
+    mode = int(rng.integers(0, 3))
+    forced = n >= 2000 and rng.random() < 0.4
+    if forced:
+        os.environ["SL_PW_FORCE"], os.environ["SL_PW_CUS"] = "1", "2"
+    try:
+        m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=mode == 2, keep_csr=mode >= 1, column_panels=True if forced else None)
+    finally:
+        os.environ.pop("SL_PW_FORCE", None); os.environ.pop("SL_PW_CUS", None)
+    seen("mutate", m)
+    want = va.copy()
+    for _ in range(int(rng.integers(1, 5))):
+        if rng.random() < 0.5:
+            f = float(rng.choice([2.0, -0.5, 1.0 / 3.0, 1e-3, 7.25]))
+            os.environ.update({"SL_PW_FORCE": "1", "SL_PW_CUS": "2"}) if forced else None
+            try:
+                m.scale(f)
+            finally:
+                os.environ.pop("SL_PW_FORCE", None); os.environ.pop("SL_PW_CUS", None)
+            want = O.csr_scale(want, f)
+        else:
+            a = float(rng.choice([0.5, -0.125, 3.0, 1e-9]))
+            os.environ.update({"SL_PW_FORCE": "1", "SL_PW_CUS": "2"}) if forced else None
+            try:
+                m.add_diagonal(a)
+            finally:
+                os.environ.pop("SL_PW_FORCE", None); os.environ.pop("SL_PW_CUS", None)
+            want, _ = O.csr_add_diagonal(rp, ci, want, a)
+    x = rng.standard_normal(n)
+    for order in (0, 1):
+        assert bits_equal(m.multiply_vector(x, order), O.spmv(rp, ci, want, x, order)), ("spmv after mutation", order)
+    for r in set(int(v) for v in rng.integers(0, n, size=4)) | {0, n - 1}:
+        got = list(m.row_iter(r))
+        co, vo = O.csr_row(rp, ci, want, r)
+        assert [c for c, _ in got] == co.tolist() and bits_equal([v for _, v in got], vo), ("row_iter after mutation", r)
+    if mode == 2 and n > 1:
+        mt = m.transpose(keep_csr=True)
+        _, tci, tva = O.csr_transpose(rp, ci, want, n)
+        y = rng.standard_normal(n)
+        trp = O.csr_transpose(rp, ci, want, n)[0]
+        assert bits_equal(mt.multiply_vector(y), O.spmv(trp, tci, tva, y)), "transpose after mutation"
+
+
+def case_walkserial(seed):
+    """SL_WALK_STREAM_SERIAL against the CPU checker's serial form (= the reference as written): per-walk values, mean, variance, and the
+    solve's x / variances / total variance — bit for bit"""
+    import ctypes as C
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([3, 40, 150]))
+    rp, ci, va = F._random_system(rng, n, 0, int(rng.integers(2, 9)), False)
+    b = rng.standard_normal(n)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, keep_csr=True)
+    W, sd, row = int(rng.choice([100, 257, 700])), int(rng.integers(0, 2 ** 32)), int(rng.integers(0, n))
+    vals, res = np.zeros(W), L.WalkResult()
+    L.check(L.load().sl_estimate_entry_random_walk(m._h, L.ptr(b), 0, row, 0.1, sd, L.SL_WALK_STREAM_SERIAL, W, L.ptr(vals), C.byref(res)))
+    ov, om, ovar = O.ts_random_walk_serial(rp, ci, va, b, row, W, sd)
+    assert bits_equal(vals, ov) and (res.estimate, res.variance) == (om, ovar), "serial walk values"
+    r = S.random_walk_solve(m, b, 0.1, sd, num_walks=W, stream="reference")
+    o = O.ts_random_walk_solve(rp, ci, va, b, 0.1, sd, num_walks=W, per_walk_streams=False)
+    assert bits_equal(r["solution"], o["x"]) and bits_equal(r["variances"], o["variances"]) and r["total_variance"] == o["total_variance"], "serial walk solve"
+
+
+KINDS = {"mutate": case_mutate, "walkserial": case_walkserial, "trait": case_trait, "walk": case_walk, "general": case_general, "paced": case_paced, "orderany": case_orderany, "acl": case_acl, "southwell": case_southwell, "cg": case_cg,
          "wideband": case_wideband, "session": case_session}
 
 
