@@ -581,7 +581,7 @@ def main_abi(args, world, rank, local_rank, attempt=0, emit=True):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(n_global, k, args.seed, w_head)
         if emit:
-            print(json.dumps(dry_run_line(out) if DRY_RUN else out), flush=True)
+            emit_line(out)
         return out
     finally:
         comm.close()
@@ -802,23 +802,23 @@ def launcher(args, argv):
 
 def refuse_emulator():
     """bench.py measures an MI355X.  The SIMT emulator of tests/simt/ (the kernels as host fibers, test infrastructure for a container
-    without a GPU) exports `simt_counters`; a library that has it is not a device and nothing may be timed on it."""
+    without a GPU) exports `simt_counters`; a library that has it is not a device and nothing may be timed on it.  The one exception is a
+    REHEARSAL of this file's code path in the CPU suite (SL_BENCH_DRY_RUN=1, tests/test_simt_emulated.py): its plumbing lives with the
+    emulator (tests/simt/bench_rehearsal.py: host tensors where this file asks for device ones, and a line with every measured figure
+    removed) and is loaded from there only then — nothing of it is part of a measuring run."""
     path = os.environ.get("SUBLINEAR_HIP_LIB")
     if not path:
         return
     try:
         if hasattr(C.CDLL(path), "simt_counters"):
             if os.environ.get("SL_BENCH_DRY_RUN") == "1":
-                # a REHEARSAL of this file's code path in the CPU suite (tests/test_simt_emulated.py): torch hands out HOST tensors where this
-                # file asks for device ones (tests/simt/torch_on_host.py — the emulator's "device memory" is host memory); the line printed carries
-                # "dry_run" and NO value, roofline figure or time — see dry_run_line()
                 import importlib.util
-                spec = importlib.util.spec_from_file_location("torch_on_host", str(ROOT / "tests" / "simt" / "torch_on_host.py"))
+                spec = importlib.util.spec_from_file_location("bench_rehearsal", str(ROOT / "tests" / "simt" / "bench_rehearsal.py"))
                 mod = importlib.util.module_from_spec(spec)
                 spec.loader.exec_module(mod)
                 mod.install()
-                global DRY_RUN
-                DRY_RUN = True
+                global REHEARSAL
+                REHEARSAL = mod
                 return
             print(f"bench.py: {path} is the SIMT emulator (tests only): refusing to measure anything on it", file=sys.stderr, flush=True)
             sys.exit(2)
@@ -826,25 +826,12 @@ def refuse_emulator():
         pass
 
 
-DRY_RUN = False
+REHEARSAL = None      # tests/simt/bench_rehearsal.py under SL_BENCH_DRY_RUN=1 + the emulator library; None in every measuring run
 
 
-def dry_run_line(out):
-    """what a rehearsal under the emulator may print: the structure of the line, every number that would be a measurement removed"""
-    def scrub(o):
-        if isinstance(o, dict):
-            return {k: (None if k in TIMED_KEYS and not isinstance(v, (dict, list)) else scrub(v)) for k, v in o.items()}
-        if isinstance(o, list):
-            return [scrub(v) for v in o]
-        return o
-    out = scrub(out)
-    out["dry_run"] = "rehearsal of bench.py's code path under the SIMT emulator (tests/simt): host fibers, not an MI355X — no figure of this line is a measurement"
-    return out
-
-
-TIMED_KEYS = {"value", "ms_per_step", "achieved", "frac", "launch_ms", "timed_region_device_ms_per_step", "algorithmic_over_copy_ceiling_6290", "rows_iter_per_s",
-              "achieved_GBps", "roofline_frac", "nnz_iter_per_s", "floor_ms", "single_thread_simd4", "all_threads_rowchunk", "n1_ms_per_step", "slice_ms_per_step",
-              "device_ms_per_step_slowest_rank", "roofline_frac_per_gpu", "spmv_s_per_step", "vector_passes_s_per_step"}      # (floor_ms and the ceiling derived from it are constants of the model, not measurements — floor_ms is scrubbed with the rest for simplicity)
+def emit_line(line):
+    """rank 0's ONE JSON line (a rehearsal prints its structure with every measured figure removed)"""
+    print(json.dumps(REHEARSAL.dry_run_line(line) if REHEARSAL else line), flush=True)
 
 
 def main():
@@ -943,7 +930,7 @@ def main():
             if have_full:
                 if rank == 0:
                     merged = merge_exchange_variants(lines, failures)
-                    print(json.dumps(dry_run_line(merged) if DRY_RUN else merged), flush=True)
+                    emit_line(merged)
                 dist.destroy_process_group()
                 return
             print(f"[bench rank {rank}] falling back to the exchange over torch.distributed / RCCL", file=sys.stderr, flush=True)
@@ -1160,7 +1147,7 @@ def main_torch(args, world, rank, local_rank):
                                           "nnz_iter_per_s": sweep[bk]["nnz_iter_per_s"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(n_global, k, args.seed, w)
-        print(json.dumps(dry_run_line(out) if DRY_RUN else out), flush=True)
+        emit_line(out)
     for hh in handles:
         lib.sl_matrix_destroy(hh)
     if world > 1 or force_dist:

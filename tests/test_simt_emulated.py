@@ -237,8 +237,8 @@ def test_bench_py_rehearsed_end_to_end_under_the_emulator(simt_lib, gpus):
     the ABI, layout build, the parity gate with its CPU child, warm-up and timed steps, exchange verification, the column-structure sweep /
     the variants of the N > 1 line, rank 0's scaling reference, the cpu_baseline child, the launcher that starts its own ranks — and
     prints the line's STRUCTURE with every figure that would be a measurement removed.  A rehearsal, never a number."""
-    if gpus == 1 and os.environ.get("SIMT_FULL") != "1":
-        pytest.skip("runs with SIMT_FULL=1 (its cpu_baseline child takes its 12 s; the N = 2 case below covers the launcher and the line in the CPU suite)")
+    # (N = 1 is the command the driver's bench step runs: always rehearsed — 18 s with its cpu_baseline child — since round 6, when an edit of
+    # the line's last statement would otherwise have reached the GPU box untested)
     env = _env(simt_lib, SL_BENCH_DRY_RUN="1", SIMT_IPC="1", SIMT_THREADS="4" if gpus == 1 else "2", SL_COMM_TIMEOUT_MS="300000", SIMT_DEVICES=str(gpus),
                LD_LIBRARY_PATH=f"{simt_lib.parent}:{os.environ.get('LD_LIBRARY_PATH', '')}")      # (SIMT_DEVICES = N: "one GPU per rank", so both exchanges are measured)
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), "--n", "30000", "--steps", "2", "--warmup", "1"], cwd=ROOT, capture_output=True,
