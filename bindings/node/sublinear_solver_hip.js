@@ -241,23 +241,30 @@ class SublinearSolver {
     validatePositiveNumber(config.epsilon, 'epsilon');
     if (adjacency.rows !== adjacency.cols) throw new SolverError('Adjacency matrix must be square', ErrorCodes.INVALID_DIMENSIONS);
     const n = adjacency.rows;
+    // The reference's own arithmetic (solver.ts:679-698), so that the system carries its bits (golden G13): out_j = the row's entries added
+    // left to right in column order; S[i][j] = [i == j] - damping * (adj[j][i] / out_j) for out_j > 0; MatrixOperations.getEntry reads the
+    // FIRST stored match of a duplicated COO entry (matrix.ts:105-112), so later duplicates are dropped, a stored 0 included.
     const { r, c, v } = MatrixOperations.toTriplets(adjacency);
+    const order = Array.from(v.keys()).sort((a, b) => (r[a] - r[b]) || (c[a] - c[b]) || (a - b));
+    const er = [], ec = [], ev = [];
+    for (let q = 0; q < order.length; q++) {
+      const k = order[q];
+      if (q > 0 && r[order[q - 1]] === r[k] && c[order[q - 1]] === c[k]) continue;     // a later duplicate
+      if (v[k] !== 0) { er.push(r[k]); ec.push(c[k]); ev.push(v[k]); }
+    }
     const out = new Float64Array(n);
-    for (let k = 0; k < v.length; k++) out[r[k]] += v[k];
-    const rowIndices = [], colIndices = [], values = [];
-    for (let i = 0; i < n; i++) { rowIndices.push(i); colIndices.push(i); values.push(1); }
-    for (let k = 0; k < v.length; k++) {                       // S[i][j] -= damping * adj[j][i] / out[j]
-      const j = r[k], i = c[k];
-      if (out[j] > 0 && v[k] !== 0) { rowIndices.push(i); colIndices.push(j); values.push(-config.damping * v[k] / out[j]); }
-    }
-    const merged = new Map();                                   // an edge i -> i lands on the diagonal entry: merge duplicates
-    for (let k = 0; k < values.length; k++) {
-      const key = rowIndices[k] * n + colIndices[k];
-      merged.set(key, (merged.get(key) || 0) + values[k]);
-    }
+    for (let k = 0; k < ev.length; k++) out[er[k]] += ev[k];
+    const diag = new Float64Array(n).fill(1);
     const sys = { rows: n, cols: n, format: 'coo', values: [], rowIndices: [], colIndices: [] };
-    for (const [key, val] of merged) { const i = Math.floor(key / n); sys.rowIndices.push(i); sys.colIndices.push(key - i * n); sys.values.push(val); }
-    const rhs = config.personalized || new Array(n).fill((1 - config.damping) / n);
+    for (let k = 0; k < ev.length; k++) {
+      const j = er[k], i = ec[k];
+      if (!(out[j] > 0)) continue;                                                     // a dangling node's column stays the identity's
+      const prob = ev[k] / out[j];
+      if (i === j) diag[i] = 1 - config.damping * prob;
+      else { sys.rowIndices.push(i); sys.colIndices.push(j); sys.values.push(-(config.damping * prob)); }
+    }
+    for (let i = 0; i < n; i++) if (diag[i] !== 0) { sys.rowIndices.push(i); sys.colIndices.push(i); sys.values.push(diag[i]); }
+    const rhs = config.personalized || new Array(n).fill(1 * ((1 - config.damping) / n));
     const solver = new SublinearSolver({ method: this.config.method, epsilon: config.epsilon, maxIterations: config.maxIterations, timeout: this.config.timeout });
     return (await solver.solve(sys, rhs)).solution;
   }

@@ -72,11 +72,8 @@ def _pagerank(a):
     r, c, v, rows, cols = io.matrix_to_triplets(adj)
     if rows != cols:
         raise SystemExit("adjacency matrix must be square")
-    import scipy.sparse as sp
-    A = sp.csr_matrix((v, (r, c)), shape=(rows, cols))
-    A.sum_duplicates()
-    A.sort_indices()
-    rp, ci, va, b = G.pagerank_system(rows, A.indptr.astype(np.uint32), A.indices.astype(np.uint32), A.data, a.damping)
+    arp, aci, ava = G.adjacency_csr_first_match(r, c, v, rows)
+    rp, ci, va, b = G.pagerank_system(rows, arp, aci, ava, a.damping)
     m = solver.SparseMatrix.from_csr(rp, ci, va, rows, rows, with_transpose=True)
     res = solver.PushSolver(theta=a.epsilon / rows, max_rounds=a.max_iterations).solve(m, b)
     x = res["solution"]

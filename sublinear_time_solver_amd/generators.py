@@ -159,17 +159,53 @@ def pagerank_graph(n: int, seed: int, mean_degree: int = 16, zipf_s: float = 2.1
     return rp2.astype(np.uint32), tgt.astype(np.uint32), np.ones(tgt.size, dtype=np.float64)
 
 
-def pagerank_system(n: int, adj_rp, adj_ci, adj_w, damping: float = 0.85):
-    """A = I - d * P^T in CSR with P_ij = w_ij / out_i (computePageRank, src/core/solver.ts:664-722:
-    S[i][j] -= d * adj[j][i] / out[j]; dangling columns stay identity), rhs = (1-d)/n."""
-    import scipy.sparse as sp
+def adjacency_csr_first_match(r, c, v, n: int):
+    """Triplets of an adjacency -> CSR (ascending columns) the way the reference READS a COO matrix: MatrixOperations.getEntry
+    (src/core/matrix.ts:95-116) returns the FIRST stored match of (row, col) — later duplicates never enter its arithmetic, and a stored 0
+    hides them too — so the first occurrence is kept, then exact zeros are dropped (a zero weight changes nothing in computePageRank)."""
+    r = np.ascontiguousarray(r, dtype=np.int64)
+    c = np.ascontiguousarray(c, dtype=np.int64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    key = r * n + c
+    _, first = np.unique(key, return_index=True)                 # sorted by key = (row, column); index of the first occurrence
+    first = first[v[first] != 0.0]
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rp, r[first] + 1, 1)
+    return np.cumsum(rp).astype(np.uint32), c[first].astype(np.uint32), v[first]
 
-    A = sp.csr_matrix((adj_w, adj_ci.astype(np.int64), adj_rp.astype(np.int64)), shape=(n, n))
-    out = np.asarray(A.sum(axis=1)).ravel()
-    inv = np.where(out > 0, 1.0 / np.where(out > 0, out, 1.0), 0.0)
-    P = sp.diags(inv) @ A
-    S = (sp.identity(n, format="csr") - damping * P.T).tocsr()
-    S.sort_indices()
-    S.eliminate_zeros()
-    return (S.indptr.astype(np.uint32), S.indices.astype(np.uint32), S.data.astype(np.float64),
-            np.full(n, (1.0 - damping) / n))
+
+def pagerank_system(n: int, adj_rp, adj_ci, adj_w, damping: float = 0.85):
+    """The system computePageRank assembles (src/core/solver.ts:664-722), in CSR, with the reference's OWN arithmetic — so that the values
+    carry its bits (golden G13: the reference's TypeScript executed on the same adjacency):
+        out_j      = adj[j][0] + adj[j][1] + ... left to right over the row            (:679-684)
+        S[i][j]    = (i == j ? 1 : 0) - damping * (adj[j][i] / out_j)   for out_j > 0   (:689-698; a dangling node's column stays the identity's)
+        rhs_i      = 1 * ((1 - damping) / n)                                            (:708)
+    The adjacency is CSR with ascending, duplicate-free columns (the reference's getEntry reads the FIRST stored match of a COO entry:
+    coalesce duplicates before calling).  Exact zeros are not stored (SparseMatrix::from_dense filters them)."""
+    rp = np.ascontiguousarray(adj_rp, dtype=np.int64)
+    ci = np.ascontiguousarray(adj_ci, dtype=np.int64)
+    w = np.ascontiguousarray(adj_w, dtype=np.float64)
+    lens = np.diff(rp)
+    out = np.zeros(n)
+    for k in range(int(lens.max()) if n and lens.size else 0):          # the k-th entry of every row that has one: a left-to-right sum per row
+        rows = np.flatnonzero(lens > k)
+        out[rows] = out[rows] + w[rp[rows] + k]
+    src = np.repeat(np.arange(n, dtype=np.int64), lens)                 # edge src -> ci with weight w
+    live = out[src] > 0
+    src, dst, a = src[live], ci[live], w[live]
+    prob = a / out[src]
+    val = -(damping * prob)                                             # 0 - damping * prob
+    loop = src == dst
+    diag = np.ones(n)
+    diag[dst[loop]] = 1.0 - damping * prob[loop]                         # 1 - damping * prob on a self loop
+    rows_s = np.concatenate([dst[~loop], np.arange(n, dtype=np.int64)])
+    cols_s = np.concatenate([src[~loop], np.arange(n, dtype=np.int64)])
+    vals_s = np.concatenate([val[~loop], diag])
+    keep = vals_s != 0.0
+    rows_s, cols_s, vals_s = rows_s[keep], cols_s[keep], vals_s[keep]
+    order = np.lexsort((cols_s, rows_s))
+    rows_s, cols_s, vals_s = rows_s[order], cols_s[order], vals_s[order]
+    s_rp = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(s_rp, rows_s + 1, 1)
+    s_rp = np.cumsum(s_rp)
+    return (s_rp.astype(np.uint32), cols_s.astype(np.uint32), vals_s.astype(np.float64), np.full(n, 1.0 * ((1.0 - damping) / n)))

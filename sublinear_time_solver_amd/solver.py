@@ -874,11 +874,10 @@ class SublinearSolver:
         r, c, v, rows, cols = io.matrix_to_triplets(adjacency)
         if rows != cols:
             raise SolverError(5, "Adjacency matrix must be square")
-        import scipy.sparse as sp
-        A = sp.csr_matrix((np.asarray(v, dtype=np.float64), (np.asarray(r, dtype=np.int64), np.asarray(c, dtype=np.int64))), shape=(rows, cols))
-        A.sum_duplicates()
-        A.sort_indices()
-        rp, ci, va, b = G.pagerank_system(rows, A.indptr.astype(np.uint32), A.indices.astype(np.uint32), A.data, damping)
+        # the reference's own arithmetic and its own reading of the adjacency (first stored match of a duplicated entry): the system carries
+        # its bits (golden G13, tests/golden/make_golden_ts_pagerank.py)
+        arp, aci, ava = G.adjacency_csr_first_match(r, c, v, rows)
+        rp, ci, va, b = G.pagerank_system(rows, arp, aci, ava, damping)
         if personalized is not None:
             b = _f64(personalized)
             if b.size != rows:

@@ -209,3 +209,16 @@ print("RESULT " + json.dumps(out))
     assert res["0"] == res["1"], {k: (res["0"][k], res["1"][k]) for k in res["0"] if res["0"][k] != res["1"][k]}
     assert res["1"]["unit layout"] == 2 and res["1"]["unit 1e-09"][2] > 3                       # paced layout, several dense rounds
     assert logs["1"].count("column-constant operator") == 1 and "column-constant operator" not in logs["0"]   # the unit graph only, and only when asked
+
+
+def test_g13_compute_pagerank_equals_the_references_own_typescript(gpu):
+    """SublinearSolver({method: 'forward-push'}).computePageRank on the device against what the reference's own TypeScript returned for the
+    same adjacency (tests/golden/reference_ts_pagerank.npz, make_golden_ts_pagerank.py): the solution bit for bit — assembly arithmetic,
+    dangling nodes, self loops, weights, a personalised right-hand side, and the push in the reference's visiting order"""
+    from tests.test_oracle_golden import golden_ts_pagerank_cases
+    for k, g, c in golden_ts_pagerank_cases():
+        n = c["n"]
+        adj = {"rows": n, "cols": n, "format": "coo", "values": g[k + "/adj_values"].tolist(), "rowIndices": g[k + "/adj_rows"].tolist(), "colIndices": g[k + "/adj_cols"].tolist()}
+        s = S.SublinearSolver(method="forward-push", epsilon=1e-6, max_iterations=10, push_order="reference")
+        x = s.compute_pagerank(adj, damping=c["damping"], epsilon=c["eps"], max_iterations=c["maxit"], personalized=g[k + "/rhs"] if c["personalized"] else None)
+        assert (np.ascontiguousarray(x).view(np.uint64) == g[k + "/solution"].view(np.uint64)).all(), k

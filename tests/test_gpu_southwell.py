@@ -153,3 +153,28 @@ def test_degree_scaled_rule_on_a_skewed_graph(gpu):
     bound = eps * deg.sum()
     assert np.abs(scaled.estimate - acl["estimate"]).max() <= bound
     assert (acl["residual"] < eps * deg + 1e-18).all()
+
+
+def test_g12_the_references_own_typescript_push_on_the_gpu(gpu):
+    """tests/golden/reference_ts_push.npz holds what the reference's solveForwardPush — its own TypeScript, executed on these inputs by
+    tests/golden/make_golden_ts_push.py — returned: the device's solution must carry the same bits after the same number of pushes (ties of
+    |r_i| on a PageRank-type system, an asymmetric tridiagonal, 10^3 pushes on a band, and the CONVERGENCE_FAILED exit after maxIterations)"""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "reference_ts_push.npz")
+    seen_failure = False
+    for k in map(str, g["names"]):
+        n, maxit, conv, its = (int(v) for v in g[k + "/params"])
+        eps, res = (float(v) for v in g[k + "/epsilon_residual"])
+        rp, ci, va = O.csr_from_triplets(g[k + "/rows"], g[k + "/cols"], g[k + "/values"], n, n)
+        m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
+        out = S.GaussSouthwellSolver(epsilon=eps, max_iterations=maxit).solve(m, g[k + "/b"], on_failure="return")
+        assert out["iterations"] == its and out["converged"] == bool(conv), (k, out["iterations"], its)
+        assert abs(out["residual"] - res) <= 1e-12 * res, (k, out["residual"], res)
+        if conv:
+            assert (bits(out["solution"]) == bits(g[k + "/solution"])).all(), k
+        else:
+            seen_failure = True
+            with pytest.raises(S.SolverError) as e:                     # the reference throws there; so does the default surface
+                S.GaussSouthwellSolver(epsilon=eps, max_iterations=maxit).solve(m, g[k + "/b"])
+            assert e.value.kind == "ConvergenceFailure"
+    assert seen_failure

@@ -325,3 +325,63 @@ def test_oracle_is_clean_under_asan_and_ubsan():
     from pathlib import Path
     r = subprocess.run(["make", "-C", str(Path(__file__).resolve().parent.parent / "oracle"), "asan"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "asan_check ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+# ---- G12: the reference's own TypeScript forward push, executed (tests/golden/make_golden_ts_push.py) -----------------------------------
+def test_g12_ts_forward_push_equals_the_executed_reference():
+    """solveForwardPush (src/core/solver.ts:437-522) as the reference's own code ran it on six seeded systems: iterations, solution bits,
+    the residual norm bit for bit (norm2's sequential reduce), and the CONVERGENCE_FAILED exit with the residual it reports"""
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "reference_ts_push.npz")
+    kinds = set()
+    for k in map(str, g["names"]):
+        n, maxit, conv, its = (int(v) for v in g[k + "/params"])
+        eps, res = (float(v) for v in g[k + "/epsilon_residual"])
+        rp, ci, va = O.csr_from_triplets(g[k + "/rows"], g[k + "/cols"], g[k + "/values"], n, n)
+        r = O.ts_forward_push(rp, ci, va, g[k + "/b"], eps, maxit)
+        assert r["iterations"] == its and r["converged"] == bool(conv) and r["residual"] == res, (k, r["iterations"], its, r["residual"], res)
+        assert r["status"] == (0 if conv else 3), k
+        if conv:
+            assert (r["x"].view(np.uint64) == g[k + "/solution"].view(np.uint64)).all(), k
+        kinds.add(bool(conv))
+    assert kinds == {True, False} and len(g["names"]) == 6
+
+
+# ---- G13: the reference's own TypeScript computePageRank, executed (tests/golden/make_golden_ts_pagerank.py) ----------------------------
+def golden_ts_pagerank_cases():
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "reference_ts_pagerank.npz")
+    for k in map(str, g["names"]):
+        n, maxit, its, pers = (int(v) for v in g[k + "/params"])
+        d, eps, res = (float(v) for v in g[k + "/damping_epsilon_residual"])
+        yield k, g, dict(n=n, maxit=maxit, its=its, personalized=bool(pers), damping=d, eps=eps, residual=res)
+
+
+def test_g13_pagerank_system_and_solve_equal_the_executed_reference():
+    """computePageRank (src/core/solver.ts:664-722, method forward-push) as the reference's own code ran it: the assembled system matrix —
+    out-degrees as left-to-right row sums, [i == j] - damping * (adj[j][i] / out_j), dangling columns untouched, self loops on the
+    diagonal — entry for entry and bit for bit, the right-hand side, and the solution / iteration count / residual of its own push"""
+    from sublinear_time_solver_amd import generators as G
+    n_cases = 0
+    for k, g, c in golden_ts_pagerank_cases():
+        n = c["n"]
+        arp, aci, ava = G.adjacency_csr_first_match(g[k + "/adj_rows"], g[k + "/adj_cols"], g[k + "/adj_values"], n)
+        rp, ci, va, b = G.pagerank_system(n, arp, aci, ava, c["damping"])
+        S = g[k + "/system"]
+        rr, cc = np.nonzero(S)
+        srp, sci, sva = O.csr_from_triplets(rr, cc, S[rr, cc], n, n)
+        assert (srp == rp).all() and (sci == ci).all() and (sva.view(np.uint64) == va.view(np.uint64)).all(), k
+        if not c["personalized"]:
+            assert (b.view(np.uint64) == g[k + "/rhs"].view(np.uint64)).all(), k
+        r = O.ts_forward_push(rp, ci, va, g[k + "/rhs"], c["eps"], c["maxit"])
+        assert r["iterations"] == c["its"] and r["residual"] == c["residual"] and (r["x"].view(np.uint64) == g[k + "/solution"].view(np.uint64)).all(), k
+        n_cases += 1
+    assert n_cases == 3
+
+
+def test_adjacency_is_read_the_way_the_reference_reads_a_coo_matrix():
+    """MatrixOperations.getEntry returns the FIRST stored match (matrix.ts:105-112): later duplicates never count, a stored 0 hides them"""
+    from sublinear_time_solver_amd import generators as G
+    r, c, v = [0, 0, 1, 0, 2, 2], [1, 1, 0, 2, 0, 0], [2.0, 5.0, 1.0, 3.0, 0.0, 7.0]
+    rp, ci, va = G.adjacency_csr_first_match(r, c, v, 3)
+    assert rp.tolist() == [0, 2, 3, 3] and ci.tolist() == [1, 2, 0] and va.tolist() == [2.0, 3.0, 1.0]
