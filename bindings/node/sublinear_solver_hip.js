@@ -89,41 +89,51 @@ const MatrixOperations = {
     return { r: Float64Array.from(rowIndices), c: Float64Array.from(colIndices), v: Float64Array.from(values) };
   },
 
-  /** core/matrix.ts:327-351 with checkDiagonalDominance (:211-258), isSymmetric (:263-296), calculateSparsity (:301-322) */
+  /** core/matrix.ts:327-351 with checkDiagonalDominance (:211-258), isSymmetric (:263-296), calculateSparsity (:301-322) — with the
+   *  reference's own reading of the matrix, so that every field (the bits of dominanceStrength included) is what its TypeScript returns
+   *  (golden G14, tests/golden/reference_ts_analyze.json): the diagonal and the symmetry test read entries through getEntry, i.e. the FIRST
+   *  stored match of a duplicated COO entry (:105-112); the off-diagonal row / column sums add |value| over ALL stored entries in storage
+   *  order (getRowSum / getColumnSum :143-206); the loop over the rows stops at the first zero diagonal (:228-234).  O(entries), where the
+   *  reference walks the whole array per row. */
   analyzeMatrix(matrix) {
     MatrixOperations.validateMatrix(matrix);
-    const { r, c, v } = MatrixOperations.toTriplets(matrix);
-    const n = matrix.rows, square = matrix.rows === matrix.cols;
-    let isRow = false, isCol = false, strength = 0, symmetric = square;
+    const n = matrix.rows, square = matrix.rows === matrix.cols, dense = matrix.format === 'dense';
+    let isRow = false, isCol = false, strength = 0, symmetric = false, stored = 0;
+    const first = new Map();                                   // (row, col) -> the value getEntry returns
+    const rowOff = new Float64Array(n), colOff = new Float64Array(square ? n : 0);
+    const visit = (i, j, val) => {
+      if (!square) return;
+      const key = i * n + j;
+      if (!first.has(key)) first.set(key, val);
+      if (i !== j) { rowOff[i] += Math.abs(val); colOff[j] += Math.abs(val); }
+    };
+    if (dense) {
+      for (let i = 0; i < matrix.rows; i++) for (let j = 0; j < matrix.cols; j++) { const val = matrix.data[i][j]; if (Math.abs(val) > 1e-15) stored++; if (val !== 0) visit(i, j, val); }
+    } else {
+      const { values, rowIndices, colIndices } = cooArrays(matrix);
+      stored = values.length;
+      for (let k = 0; k < values.length; k++) visit(rowIndices[k], colIndices[k], values[k]);
+    }
     if (square) {
-      const d = new Float64Array(n), rowOff = new Float64Array(n), colOff = new Float64Array(n);
-      const entries = new Map();
-      for (let k = 0; k < v.length; k++) {
-        if (r[k] === c[k]) d[r[k]] += v[k];
-        else { rowOff[r[k]] += Math.abs(v[k]); colOff[c[k]] += Math.abs(v[k]); }
-        const key = r[k] * n + c[k];
-        entries.set(key, (entries.get(key) || 0) + v[k]);
-      }
-      for (const [key, val] of entries) {
+      symmetric = true;
+      for (const [key, val] of first) {
         const i = Math.floor(key / n), j = key - i * n;
-        if (i !== j && Math.abs(val - (entries.get(j * n + i) || 0)) > 1e-10) { symmetric = false; break; }
+        if (i !== j && Math.abs(val - (first.has(j * n + i) ? first.get(j * n + i) : 0)) > 1e-10) { symmetric = false; break; }
       }
       let zeroDiag = false, minR = Infinity, minC = Infinity;
       isRow = true; isCol = true;
       for (let i = 0; i < n; i++) {
-        const a = Math.abs(d[i]);
+        const a = Math.abs(first.has(i * n + i) ? first.get(i * n + i) : 0);
         if (a === 0) { zeroDiag = true; break; }
         if (a - rowOff[i] < 0) isRow = false; else minR = Math.min(minR, (a - rowOff[i]) / a);
         if (a - colOff[i] < 0) isCol = false; else minC = Math.min(minC, (a - colOff[i]) / a);
       }
-      if (zeroDiag) { isRow = false; isCol = false; }
+      if (zeroDiag) { isRow = false; isCol = false; minR = 0; minC = 0; }
       strength = Math.max(isRow ? minR : 0, isCol ? minC : 0);
     }
-    let nonzero = v.length;
-    if (matrix.format === 'dense') { nonzero = 0; for (let k = 0; k < v.length; k++) if (Math.abs(v[k]) > 1e-15) nonzero++; }
     return {
       isDiagonallyDominant: isRow || isCol, dominanceType: isRow ? 'row' : (isCol ? 'column' : 'none'), dominanceStrength: strength,
-      isSymmetric: symmetric, sparsity: 1 - nonzero / (matrix.rows * matrix.cols), size: { rows: matrix.rows, cols: matrix.cols }
+      isSymmetric: symmetric, sparsity: 1 - stored / (matrix.rows * matrix.cols), size: { rows: matrix.rows, cols: matrix.cols }
     };
   }
 };

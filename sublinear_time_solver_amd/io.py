@@ -134,28 +134,53 @@ def matrix_to_device(matrix: Dict[str, Any], **kw):
 
 
 # ---- analyzeMatrix -------------------------------------------------------------------------------
+def _ordered_group_sums(group: np.ndarray, values: np.ndarray, n: int) -> np.ndarray:
+    """out[g] = the values of group g added one after the other IN THE ORDER GIVEN (a running sum per group, as a `sum +=` loop over the
+    stored entries forms it) — vectorised over the groups, sequential inside each"""
+    out = np.zeros(n)
+    if not values.size:
+        return out
+    order = np.argsort(group, kind="stable")
+    g, val = group[order], values[order]
+    start = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(start, g + 1, 1)
+    start = np.cumsum(start)
+    lens = np.diff(start)
+    for k in range(int(lens.max())):
+        rows = np.flatnonzero(lens > k)
+        out[rows] = out[rows] + val[start[rows] + k]
+    return out
+
+
 def analyze_matrix(matrix: Dict[str, Any]) -> Dict[str, Any]:
-    """MatrixOperations.analyzeMatrix (src/core/matrix.ts:327-351) with checkDiagonalDominance (:211-258),
-    isSymmetric (:263-296, tolerance 1e-10) and calculateSparsity (:301-322)."""
+    """MatrixOperations.analyzeMatrix (src/core/matrix.ts:327-351) with checkDiagonalDominance (:211-258), isSymmetric (:263-296,
+    tolerance 1e-10) and calculateSparsity (:301-322) — with the reference's own reading of the matrix, so that every field (the bits of
+    dominanceStrength included) is what its TypeScript returns (golden G14, tests/golden/make_golden_ts_analyze.py):
+    the DIAGONAL and the symmetry test read entries through getEntry, i.e. the FIRST stored match of a duplicated COO entry (:105-112); the
+    off-diagonal row / column sums add |value| over ALL stored entries in storage order (getRowSum / getColumnSum, :143-206); the loop over
+    the rows stops at the first zero diagonal with everything false and strength 0 (:228-234)."""
     import scipy.sparse as sp
 
     r, c, v, rows, cols = matrix_to_triplets(matrix)
-    A = sp.csr_matrix((v, (r, c)), shape=(rows, cols))          # duplicates are summed here (getEntry returns the first)
-    is_row, is_col, strength = False, False, 0.0
+    is_row, is_col, strength, symmetric = False, False, 0.0, False
     if rows == cols:
-        d = np.abs(A.diagonal())
-        absA = abs(A)
-        row_off = np.asarray(absA.sum(axis=1)).ravel() - d
-        col_off = np.asarray(absA.sum(axis=0)).ravel() - d
-        if (d == 0).any():
-            is_row = is_col = False
-        else:
+        n = rows
+        _, first = np.unique(r * n + c, return_index=True)               # the first stored match of every (row, col)
+        fr, fc, fv = r[first], c[first], v[first]
+        d = np.zeros(n)
+        on = fr == fc
+        d[fr[on]] = np.abs(fv[on])
+        off = r != c
+        row_off = _ordered_group_sums(r[off], np.abs(v[off]), n)
+        col_off = _ordered_group_sums(c[off], np.abs(v[off]), n)
+        if not (d == 0).any():
             rs, cs = d - row_off, d - col_off
             is_row, is_col = bool((rs >= 0).all()), bool((cs >= 0).all())
             min_r = float((rs[rs >= 0] / d[rs >= 0]).min()) if (rs >= 0).any() else float("inf")
             min_c = float((cs[cs >= 0] / d[cs >= 0]).min()) if (cs >= 0).any() else float("inf")
             strength = max(min_r if is_row else 0.0, min_c if is_col else 0.0)
-    symmetric = rows == cols and (abs(A - A.T) > 1e-10).nnz == 0
+        F = sp.csr_matrix((fv, (fr, fc)), shape=(n, n))                  # the matrix getEntry sees
+        symmetric = (abs(F - F.T) > 1e-10).nnz == 0
     if matrix.get("format") == "dense":
         sparsity = 1.0 - float((np.abs(v) > 1e-15).sum()) / (rows * cols)
     else:

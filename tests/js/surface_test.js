@@ -60,6 +60,12 @@ async function rejects(p, code, re) {
   assert(Math.abs(a.sparsity - 2 / 9) < 1e-15 && Math.abs(a.dominanceStrength - (5 - 3) / 5) < 1e-15);
   const notDD = { rows: 2, cols: 2, format: 'dense', data: [[1, 3], [2, 1]] };
   assert.strictEqual(MatrixOperations.analyzeMatrix(notDD).isDiagonallyDominant, false);
+  {   // G14: analyzeMatrix field by field (the bits of dominanceStrength included) against what the reference's own TypeScript returned for
+      // these matrices (tests/golden/reference_ts_analyze.json, make_golden_ts_analyze.py): duplicated COO entries, storage order, zero diagonals
+    const golden = JSON.parse(require('fs').readFileSync(path.join(__dirname, '..', 'golden', 'reference_ts_analyze.json'), 'utf8'));
+    assert(golden.length >= 14);
+    for (const g of golden) assert.deepStrictEqual(MatrixOperations.analyzeMatrix(g.matrix), g.analysis, g.name);
+  }
   const s = new SublinearSolver({ method: 'neumann', epsilon: 1e-10, maxIterations: 1000 });
   await rejects(s.solve(notDD, [1, 1]), ErrorCodes.NOT_DIAGONALLY_DOMINANT, /not diagonally dominant/);
   await rejects(s.solve(dense, [1, 2]), ErrorCodes.INVALID_DIMENSIONS, /does not match matrix columns/);

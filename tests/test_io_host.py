@@ -90,3 +90,17 @@ def test_generate_and_vectors(tmp_path):
     (tmp_path / "b.json").write_text("[1, 2, 3]")
     (tmp_path / "b.txt").write_text("1\n2\n3\n")
     assert io.load_vector(tmp_path / "b.json").tolist() == io.load_vector(tmp_path / "b.txt").tolist() == [1.0, 2.0, 3.0]
+
+
+def test_g14_analyze_matrix_equals_the_references_own_typescript():
+    """MatrixOperations.analyzeMatrix (core/matrix.ts:327-351) as the reference's own code evaluated it on 13 matrices
+    (tests/golden/make_golden_ts_analyze.py): every field equal — the bits of dominanceStrength, the diagonal read by FIRST stored match,
+    row / column sums over all duplicates in storage order, the stop at the first zero diagonal, symmetry through getEntry"""
+    import json
+    from pathlib import Path
+    from sublinear_time_solver_amd import io
+    cases = json.loads((Path(__file__).resolve().parent / "golden" / "reference_ts_analyze.json").read_text())
+    assert len(cases) >= 14
+    for c in cases:
+        assert io.analyze_matrix(c["matrix"]) == c["analysis"], c["name"]
+    assert {c["analysis"]["dominanceType"] for c in cases} >= {"row", "column", "none"} and any(c["analysis"]["isSymmetric"] for c in cases)
