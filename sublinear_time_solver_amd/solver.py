@@ -828,6 +828,17 @@ class SublinearSolver:
         import time
         t0 = time.perf_counter()
         push = self.method in ("forward-push", "backward-push", "bidirectional")
+        if isinstance(matrix, dict):
+            # the reference's gate, in its order (solver.ts:59-78): validateMatrix, vector length against the COLUMNS, then analyzeMatrix —
+            # "Matrix is not diagonally dominant" (row or column dominance, read the way its getEntry / getRowSum read the matrix: golden G14)
+            from . import io
+            analysis = io.analyze_matrix(matrix)                           # (validates first)
+            if len(vector) != int(matrix["cols"]):
+                raise SolverError(5, f"Vector length {len(vector)} does not match matrix columns {int(matrix['cols'])}")
+            if not analysis["isDiagonallyDominant"]:
+                raise SolverError(1, "Matrix is not diagonally dominant")
+            if not push and self.method == "neumann" and analysis["dominanceType"] != "row":
+                push = True      # Neumann needs ROW dominance (neumann.rs:139-170); a column-dominant system goes through the push, which does not
         m = _matrix_from_json(matrix, with_transpose=push, keep_csr=self.method == "random-walk")
         b = _f64(vector)
         if b.size != m.rows():

@@ -448,3 +448,23 @@ def test_cpp_host_mirror(gpu, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "cpp host mirror ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_ts_surface_gate_is_the_references(gpu):
+    """SublinearSolver.solve's checks in the reference's order (solver.ts:59-78): validateMatrix, vector length against the COLUMNS,
+    analyzeMatrix -> 'Matrix is not diagonally dominant'; a column-dominant system passes the gate (the reference accepts row OR column
+    dominance) and — Neumann needing row dominance — is solved by the push"""
+    not_dd = {"rows": 2, "cols": 2, "format": "dense", "data": [[1.0, 3.0], [2.0, 1.0]]}
+    for method in ("neumann", "forward-push", "random-walk"):
+        with pytest.raises(S.SolverError) as e:
+            S.SublinearSolver(method=method, epsilon=1e-6).solve(not_dd, [1.0, 1.0])
+        assert e.value.kind == "MatrixNotDiagonallyDominant" and "Matrix is not diagonally dominant" in str(e.value)
+    with pytest.raises(S.SolverError) as e:                            # the length is checked before the analysis
+        S.SublinearSolver().solve(not_dd, [1.0, 1.0, 1.0])
+    assert e.value.kind == "DimensionMismatch" and "matrix columns 2" in str(e.value)
+    col_dd = {"rows": 2, "cols": 2, "format": "dense", "data": [[4.0, 3.5], [1.0, 4.0]]}      # rows: 4 > 3.5, 4 > 1 — row dominant too; make it column-only:
+    col_dd["data"] = [[4.0, 5.0], [1.0, 6.0]]                                                 # row 0: 4 < 5 (not row dominant); columns: 4 > 1, 6 > 5
+    from sublinear_time_solver_amd import io
+    assert io.analyze_matrix(col_dd)["dominanceType"] == "column"
+    r = S.SublinearSolver(method="neumann", epsilon=1e-10, max_iterations=10000).solve(col_dd, [1.0, 2.0])
+    assert r["converged"] and np.allclose(np.array(col_dd["data"]) @ r["solution"], [1.0, 2.0], atol=1e-8)
