@@ -385,3 +385,26 @@ def test_adjacency_is_read_the_way_the_reference_reads_a_coo_matrix():
     r, c, v = [0, 0, 1, 0, 2, 2], [1, 1, 0, 2, 0, 0], [2.0, 5.0, 1.0, 3.0, 0.0, 7.0]
     rp, ci, va = G.adjacency_csr_first_match(r, c, v, 3)
     assert rp.tolist() == [0, 2, 3, 3] and ci.tolist() == [1, 2, 0] and va.tolist() == [2.0, 3.0, 1.0]
+
+
+# ---- G15: the reference's own `generate -t diagonally-dominant`, executed with its seeded generator (tests/golden/make_golden_ts_generate.py) ----
+def test_g15_config0_generator_equals_the_executed_reference():
+    """generators.gen1000_dense against MatrixTools.generateDiagonallyDominantMatrix (src/mcp/tools/matrix.ts:297-322) run by node with
+    Math.random = createSeededRandom(seed): every entry at size 150, and BASELINE config 0 itself (size 1000, strength 2, seed 42) by entry
+    count, exact sums and the SHA-256 of the dense table"""
+    import hashlib
+    import math
+    from pathlib import Path
+    from sublinear_time_solver_amd import generators as G
+    g = np.load(Path(__file__).resolve().parent / "golden" / "reference_ts_generate.npz")
+    assert [str(k) for k in g["names"]][-1] == "dd1000_strength2_seed42"
+    for k in map(str, g["names"]):
+        size, seed, nnz = (int(v) for v in g[k + "/params"])
+        rp, ci, va, b = G.gen1000_dense(size, float(g[k + "/strength"][0]), seed)
+        a = np.zeros((size, size))
+        a[np.repeat(np.arange(size), np.diff(rp.astype(np.int64))), ci] = va
+        assert int((a != 0).sum()) == nnz and hashlib.sha256(a.tobytes()).digest() == bytes(g[k + "/sha256"]), k
+        assert (math.fsum(np.diag(a).tolist()), math.fsum(a.ravel().tolist())) == tuple(g[k + "/sums"]), k
+        if k + "/values" in g:
+            rr, cc = np.nonzero(a)
+            assert (rr == g[k + "/rows"]).all() and (cc == g[k + "/cols"]).all() and (a[rr, cc].view(np.uint64) == g[k + "/values"].view(np.uint64)).all(), k
