@@ -60,3 +60,16 @@ def test_the_gpu_fixture_and_smoke_refuse_the_emulator_without_the_flag(tmp_path
     assert r.returncode == 0 and "[SIMT EMULATOR]" in r.stdout and "library:" in r.stdout, r.stdout + r.stderr[-800:]
     # the box's snapshot leaves the emulator build behind
     assert "tests/simt/_build/" in (ROOT / ".gpurunignore").read_text().split()
+
+
+def test_gpu_suite_keeps_its_own_clock(tmp_path):
+    """with the budget spent, waiting GPU tests are skipped with a reason instead of running into the driver's step limit"""
+    import os
+    t = tmp_path / "test_budget_probe.py"
+    t.write_text("import pytest, time\npytestmark = pytest.mark.gpu\n"
+                 "def test_first():\n    time.sleep(1.2)\n"
+                 "def test_second():\n    raise AssertionError('must have been skipped')\n")
+    (tmp_path / "conftest.py").write_text((ROOT / "tests" / "conftest.py").read_text().replace("ROOT = Path(__file__).resolve().parent.parent", f"ROOT = Path({str(ROOT)!r})"))
+    env = dict(os.environ, SL_GPU_SUITE_BUDGET_S="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(t), "-m", "gpu", "-q", "-rs", "-p", "no:cacheprovider"], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "1 passed, 1 skipped" in r.stdout and "GPU suite budget" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
