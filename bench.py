@@ -913,12 +913,33 @@ def main():
                 if have_full:
                     a.no_sweep, a.no_scaling_reference, a.no_cpu_baseline = True, True, True
                 ok, err, line = 1, None, None
+                # A measured variant is never lost to the one after it: ncclCommInitRank and the collectives of a first contact with RCCL have
+                # no time limit of their own, and a rank that hangs there would take the whole job — and the line already measured — into the
+                # driver's kill.  Once a variant is in hand, the next one runs under a watchdog on EVERY rank (same limit everywhere): when it
+                # fires, rank 0 prints the line with that variant marked as timed out, and every rank leaves with status 0.
+                dog = None
+                if have_full:
+                    import threading
+                    def fire(vname=vname):
+                        if rank == 0:
+                            f = dict(failures)
+                            f[vname] = f"no result within {args.attempt_timeout:.0f} s (watchdog): the variant measured before it stands"
+                            emit_line(merge_exchange_variants(lines, f))
+                        sys.stdout.flush(); sys.stderr.flush()
+                        os._exit(0)
+                    dog = threading.Timer(args.attempt_timeout, fire)
+                    dog.daemon = True
+                    dog.start()
                 try:
+                    if os.environ.get("SL_BENCH_HANG_VARIANT") == vname and rank == world - 1:      # test of the watchdog: this rank never comes back
+                        time.sleep(10 ** 6)
                     line = main_abi(a, world, rank, local_rank, att, emit=False)
                 except Exception as e:                      # every wait in the communicator is bounded: all ranks get here
                     ok, err = 0, e
                 flag = torch.tensor([ok], dtype=torch.int32)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # (still under the watchdog: the ranks that finished wait here for the one that hangs)
+                if dog is not None:
+                    dog.cancel()
                 if int(flag[0]) == 1:
                     have_full = True
                     if rank == 0:

@@ -298,6 +298,27 @@ def test_bench_py_rehearsed_as_the_driver_launches_it(simt_lib, exchange):
         _check_exchange_variants(line)
 
 
+def test_a_hanging_second_exchange_variant_does_not_lose_the_first(simt_lib):
+    """under torch.distributed.run, the last rank never returns from the rccl_allreduce variant (SL_BENCH_HANG_VARIANT): the watchdog
+    fires on every rank, rank 0 prints the line with the ipc variant measured and the other marked as timed out, the job exits 0"""
+    import json
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = _env(simt_lib, SL_BENCH_DRY_RUN="1", SL_BENCH_BACKEND="gloo", SIMT_IPC="1", SIMT_THREADS="2", SL_COMM_TIMEOUT_MS="300000", SIMT_DEVICES="2",
+               SL_BENCH_HANG_VARIANT="rccl_allreduce", LD_LIBRARY_PATH=f"{simt_lib.parent}:{os.environ.get('LD_LIBRARY_PATH', '')}")
+    env.pop("SIMT_FAKE_TORCH", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        str(ROOT / "bench.py"), "--gpus", "2", "--rows", "30000", "--steps", "2", "--warmup", "1", "--no-sweep", "--no-scaling-reference", "--attempt-timeout", "25"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ev = line["exchange_variants"]
+    assert ev["ipc"]["ok"] and not ev["rccl_allreduce"]["ok"] and "watchdog" in ev["rccl_allreduce"]["error"], ev
+    assert line["config"]["exchange_headline"] == "ipc" and line["parity_gate"]["bitwise_equal"] is True
+
+
 SESSION_TOOLS = [("tools/cg_bench.py", ["--m", "20"], {}, "nnz_iter_per_s", False),
                  ("tests/full_solve_report.py", ["--n", "20000", "--k", "8"], {}, "solution_bits_equal_cpu", False),
                  ("tools/cg_bench.py", ["--m", "20"], {"SL_CG_FUSED_DOT": "1"}, "nnz_iter_per_s", True),
