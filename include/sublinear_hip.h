@@ -160,7 +160,8 @@ sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info);
  * carries column panels are rebuilt from the updated rows). */
 sl_status sl_matrix_scale(sl_matrix *m, double factor);
 sl_status sl_matrix_add_diagonal(sl_matrix *m, double alpha);
-/* download the CSR arrays back to the host (needs SL_MATRIX_KEEP_CSR); for tests / ingest */
+/* SparseMatrix::as_csr / to_triplets (matrix/mod.rs:298-321): the CSR arrays back on the host — row_ptr (n_rows + 1), col_idx / values (nnz);
+ * the raw copy where the matrix keeps one (SL_MATRIX_KEEP_CSR), otherwise written back from the row-slice layout (same arrays, same order) */
 sl_status sl_matrix_download_csr(const sl_matrix *m, uint32_t *row_ptr, uint32_t *col_idx, double *values);
 
 /* a6: SparseMatrix::is_diagonally_dominant (matrix/mod.rs:467-485), weak ROW dominance */

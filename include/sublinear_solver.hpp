@@ -170,6 +170,20 @@ public:
     // SparseMatrix::scale / add_diagonal (matrix/mod.rs:346-372 over sparse.rs:229-248): in place on the device, every layout copy;
     // non-const like the reference's `&mut self` (no solve may be running on the matrix; re-create states / sessions afterwards).
     // add_diagonal skips rows without a stored diagonal entry; SL_INVALID_INPUT for a non-square matrix
+    // SparseMatrix::to_triplets (matrix/mod.rs:298-305): (row, col, value) in stored order; the raw CSR where the matrix keeps one, else
+    // written back from the row slices
+    std::vector<Triplet> to_triplets() const
+    {
+        sl_matrix_info i;
+        check(sl_matrix_get_info(h_, &i));
+        std::vector<uint32_t> rp(i.n_rows + 1), ci(i.nnz ? i.nnz : 1);
+        std::vector<double> va(i.nnz ? i.nnz : 1);
+        check(sl_matrix_download_csr(h_, rp.data(), ci.data(), va.data()));
+        std::vector<Triplet> out;
+        out.reserve(i.nnz);
+        for (uint64_t r = 0; r < i.n_rows; ++r) for (uint32_t k = rp[r]; k < rp[r + 1]; ++k) out.emplace_back(r, ci[k], va[k]);
+        return out;
+    }
     void scale(Precision factor) { check(sl_matrix_scale(h_, factor)); }
     void add_diagonal(Precision alpha) { check(sl_matrix_add_diagonal(h_, alpha)); }
     // Matrix::format_name (matrix/mod.rs:557-564) / SparseMatrix::convert_to_format (:244-296).  No device work: every storage the

@@ -489,8 +489,21 @@ sl_status sl_matrix_get_info(const sl_matrix *m, sl_matrix_info *info)
 sl_status sl_matrix_download_csr(const sl_matrix *m, uint32_t *row_ptr, uint32_t *col_idx, double *values)
 {
     if (!m) return sl_fail(SL_INVALID_INPUT, "null matrix");
-    if (!m->d_row_ptr) return sl_fail(SL_UNSUPPORTED_FORMAT, "matrix was created without SL_MATRIX_KEEP_CSR");
     hipStream_t s = sl_context().stream;
+    if (!m->d_row_ptr) {      // no raw copy kept: the rows are written back from the slice layout (SparseMatrix::as_csr / to_triplets always work)
+        SL_ABI_BEGIN
+        DevBuf rp, ci, va;
+        SL_TRY(rp.alloc((m->n_rows + 1) * sizeof(uint32_t))); SL_TRY(ci.alloc((m->nnz ? m->nnz : 1) * sizeof(uint32_t))); SL_TRY(va.alloc((m->nnz ? m->nnz : 1) * sizeof(double)));
+        SL_TRY(sl_matrix_slices_to_csr(m, rp.as<uint32_t>(), ci.as<uint32_t>(), va.as<double>()));
+        SL_HIP(hipMemcpyAsync(row_ptr, rp.p, (m->n_rows + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (m->nnz) {
+            SL_HIP(hipMemcpyAsync(col_idx, ci.p, m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            SL_HIP(hipMemcpyAsync(values, va.p, m->nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
+        SL_HIP(hipStreamSynchronize(s));
+        return SL_OK;
+        SL_ABI_END
+    }
     SL_HIP(hipMemcpyAsync(row_ptr, m->d_row_ptr, (m->n_rows + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (m->nnz) {
         SL_HIP(hipMemcpyAsync(col_idx, m->d_col_idx, m->nnz * sizeof(uint32_t), hipMemcpyDeviceToHost, s));

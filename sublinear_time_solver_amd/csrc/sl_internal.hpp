@@ -419,6 +419,7 @@ sl_status sl_matrix_fetch_col(const sl_matrix *m, uint64_t col, uint64_t capacit
 sl_status sl_matrix_frobenius_sq(const sl_matrix *m, double *sum_sq);
 sl_status sl_matrix_entry_bandwidth(const sl_matrix *m, uint64_t *bandwidth);   // max |row - col| over ALL stored entries (hub rows included)
 // the `&mut self` methods (matrix/mod.rs:346-372 over sparse.rs:229-248): every layout copy updated (sl_matrix.hip)
+sl_status sl_matrix_slices_to_csr(const sl_matrix *m, uint32_t *d_rp, uint32_t *d_ci, double *d_va);   // a matrix without raw CSR: its rows from the slice layout
 sl_status sl_matrix_scale_values(sl_matrix *m, double factor);
 sl_status sl_matrix_shift_diagonal(sl_matrix *m, double alpha);
 // same rules over a plain CSR operator (used for A^T, which has no row-slice layout)

@@ -1585,23 +1585,34 @@ static void free_column_streams(sl_matrix *m)
 }
 static bool has_column_streams(const sl_matrix *m) { return m->d_pan_tile_ptr || m->d_pw_idx || m->d_pwr_idx || m->d_colval; }
 
+// the rows of a matrix that keeps no raw CSR, written back from the slice layout into device arrays of the caller's (row_ptr: n + 1,
+// col_idx / values: nnz) — such a matrix has no hub rows (those make the build keep the raw arrays)
+sl_status sl_matrix_slices_to_csr(const sl_matrix *m, uint32_t *d_rp, uint32_t *d_ci, double *d_va)
+{
+    hipStream_t st = sl_context().stream;
+    const uint64_t n = m->n_rows;
+    std::vector<uint32_t> len(n), rp(n + 1, 0);
+    if (n) SL_TRY(sl_read_back(len.data(), m->d_row_len, n * sizeof(uint32_t), st));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (len[i] == SL_LONG_SENTINEL) return sl_fail(SL_ALGORITHM_ERROR, "internal: a hub row in a matrix without raw CSR arrays");
+        rp[i + 1] = rp[i] + len[i];
+    }
+    SL_TRY(sl_upload(d_rp, rp.data(), (n + 1) * sizeof(uint32_t), st));
+    if (n) hipLaunchKernelGGL(sl_slices_to_csr_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals, d_rp, d_ci, d_va);
+    SL_HIP(hipGetLastError());
+    return SL_OK;
+}
+
 // the sorted column streams again, from the rows as they are now (the raw CSR where the matrix keeps it, else the slices written back)
 static sl_status sl_matrix_rebuild_column_streams(sl_matrix *m)
 {
     hipStream_t st = sl_context().stream;
     free_column_streams(m);
     if (m->d_row_ptr) return sl_build_column_streams(m, m->d_row_ptr, m->d_col_idx, m->d_values, st);
-    const uint64_t n = m->n_rows;
-    std::vector<uint32_t> len(n), rp(n + 1, 0);
-    if (n) SL_TRY(sl_read_back(len.data(), m->d_row_len, n * sizeof(uint32_t), st));
-    for (uint64_t i = 0; i < n; ++i) rp[i + 1] = rp[i] + len[i];
     DevBuf d_rp, d_ci, d_va;
-    SL_TRY(d_rp.alloc_owned((n + 1) * sizeof(uint32_t))); SL_TRY(d_ci.alloc_owned((m->nnz ? m->nnz : 1) * sizeof(uint32_t)));
+    SL_TRY(d_rp.alloc_owned((m->n_rows + 1) * sizeof(uint32_t))); SL_TRY(d_ci.alloc_owned((m->nnz ? m->nnz : 1) * sizeof(uint32_t)));
     SL_TRY(d_va.alloc_owned((m->nnz ? m->nnz : 1) * sizeof(double)));
-    SL_TRY(sl_upload(d_rp.p, rp.data(), (n + 1) * sizeof(uint32_t), st));
-    if (n) hipLaunchKernelGGL(sl_slices_to_csr_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, n, m->d_slice_ptr, m->d_row_len, m->d_cols, m->d_vals,
-                              d_rp.as<uint32_t>(), d_ci.as<uint32_t>(), d_va.as<double>());
-    SL_HIP(hipGetLastError());
+    SL_TRY(sl_matrix_slices_to_csr(m, d_rp.as<uint32_t>(), d_ci.as<uint32_t>(), d_va.as<double>()));
     const sl_status r = sl_build_column_streams(m, d_rp.as<uint32_t>(), d_ci.as<uint32_t>(), d_va.as<double>(), st);
     SL_HIP(hipStreamSynchronize(st));
     return r;

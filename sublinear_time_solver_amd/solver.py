@@ -285,7 +285,14 @@ class SparseMatrix:
             raise SolverError(6, "GraphAdjacency of a non-square matrix: the reference drops the entries beyond column `rows`; not mirrored")
         self._format = new_format
 
+    def to_triplets(self):
+        """SparseMatrix::to_triplets, matrix/mod.rs:298-305 (CSRStorage::to_triplets, sparse.rs:211-226): (row, col, value) in stored order"""
+        rp, ci, va = self.to_csr()
+        rows = np.repeat(np.arange(rp.size - 1), np.diff(rp.astype(np.int64)))
+        return list(zip(rows.tolist(), ci.tolist(), va.tolist()))
+
     def to_csr(self):
+        """SparseMatrix::as_csr, matrix/mod.rs:315-321: the raw arrays where the matrix keeps them, else written back from the row slices"""
         i = self.info()
         rp = np.empty(i.n_rows + 1, dtype=np.uint32)
         ci = np.empty(i.nnz, dtype=np.uint32)

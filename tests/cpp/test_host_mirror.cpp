@@ -45,6 +45,8 @@ int main()
         c.scale(-2.0);
         EXPECT(*c.get(0, 0) == -2.0 && *c.get(0, 2) == -4.0 && *c.get(1, 0) == -6.0 && *c.get(2, 2) == -10.0 && c.nnz() == 5);
         c.add_diagonal(0.5);
+        auto tr = c.to_triplets();                                                       // matrix/mod.rs:298-305, from the row slices (no raw copy kept)
+        EXPECT(tr.size() == 5 && std::get<0>(tr[2]) == 1 && std::get<1>(tr[2]) == 0 && std::get<2>(tr[2]) == -6.0 && std::get<2>(tr[4]) == -9.5);
         EXPECT(*c.get(0, 0) == -1.5 && *c.get(2, 2) == -9.5 && !c.get(1, 1).has_value() && *c.get(1, 0) == -6.0);         // row 1 silently skipped
         std::vector<double> y(3);
         c.multiply_vector({1.0, 1.0, 1.0}, y);

@@ -115,6 +115,9 @@ def test_mutators_on_a_matrix_that_keeps_only_its_row_slices(gpu):
     x = np.random.default_rng(3).standard_normal(n)
     assert (_bits(m.multiply_vector(x)) == _bits(O.spmv(rp, ci, want, x))).all()
     assert (_bits(m.multiply_vector(x, order=L.SL_ORDER_SIMD4)) == _bits(O.spmv(rp, ci, want, x, order=O.ORDER_SIMD4))).all()
+    grp, gci, gva = m.to_csr()                                           # no raw copy kept: as_csr writes the rows back from the slices
+    assert (grp == rp).all() and (gci == ci).all() and (_bits(gva) == _bits(want)).all()
+    assert m.to_triplets()[:3] == [(0, int(ci[0]), float(want[0])), (0, int(ci[1]), float(want[1])), (0, int(ci[2]), float(want[2]))]
     # a shifted system solves like the re-uploaded one, bit for bit (what the mutators are for)
     g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-10))
     o = O.neumann_solve(rp, ci, want, b, tolerance=1e-10)
