@@ -150,6 +150,36 @@ function withDeviceMatrix(matrix, withTranspose, fn) {
   try { return fn(h); } catch (e) { return rethrow(e); } finally { native.destroyMatrix(h); }
 }
 
+/** The system computePageRank assembles (core/solver.ts:679-698), sparse, with the reference's own arithmetic so that it carries its bits
+ *  (golden G13): out_j = the row's entries added left to right in column order; S[i][j] = [i == j] - damping * (adj[j][i] / out_j) for
+ *  out_j > 0 (a dangling node's column stays the identity's); MatrixOperations.getEntry reads the FIRST stored match of a duplicated COO
+ *  entry (matrix.ts:105-112), so later duplicates are dropped, a stored 0 included.  Returns a COO matrix, entries by column then diagonal. */
+function pageRankSystem(adjacency, damping) {
+  const config = { damping };
+  const n = adjacency.rows;
+  const { r, c, v } = MatrixOperations.toTriplets(adjacency);
+  const order = Array.from(v.keys()).sort((a, b) => (r[a] - r[b]) || (c[a] - c[b]) || (a - b));
+  const er = [], ec = [], ev = [];
+  for (let q = 0; q < order.length; q++) {
+    const k = order[q];
+    if (q > 0 && r[order[q - 1]] === r[k] && c[order[q - 1]] === c[k]) continue;     // a later duplicate
+    if (v[k] !== 0) { er.push(r[k]); ec.push(c[k]); ev.push(v[k]); }
+  }
+  const out = new Float64Array(n);
+  for (let k = 0; k < ev.length; k++) out[er[k]] += ev[k];
+  const diag = new Float64Array(n).fill(1);
+  const sys = { rows: n, cols: n, format: 'coo', values: [], rowIndices: [], colIndices: [] };
+  for (let k = 0; k < ev.length; k++) {
+    const j = er[k], i = ec[k];
+    if (!(out[j] > 0)) continue;                                                     // a dangling node's column stays the identity's
+    const prob = ev[k] / out[j];
+    if (i === j) diag[i] = 1 - config.damping * prob;
+    else { sys.rowIndices.push(i); sys.colIndices.push(j); sys.values.push(-(config.damping * prob)); }
+  }
+  for (let i = 0; i < n; i++) if (diag[i] !== 0) { sys.rowIndices.push(i); sys.colIndices.push(i); sys.values.push(diag[i]); }
+  return sys;
+}
+
 const WALK_STREAMS = { blocks: 0, reference: 1, serial: 1 };
 const METHODS = ['neumann', 'random-walk', 'forward-push', 'backward-push', 'bidirectional'];
 
@@ -251,33 +281,11 @@ class SublinearSolver {
     validatePositiveNumber(config.epsilon, 'epsilon');
     if (adjacency.rows !== adjacency.cols) throw new SolverError('Adjacency matrix must be square', ErrorCodes.INVALID_DIMENSIONS);
     const n = adjacency.rows;
-    // The reference's own arithmetic (solver.ts:679-698), so that the system carries its bits (golden G13): out_j = the row's entries added
-    // left to right in column order; S[i][j] = [i == j] - damping * (adj[j][i] / out_j) for out_j > 0; MatrixOperations.getEntry reads the
-    // FIRST stored match of a duplicated COO entry (matrix.ts:105-112), so later duplicates are dropped, a stored 0 included.
-    const { r, c, v } = MatrixOperations.toTriplets(adjacency);
-    const order = Array.from(v.keys()).sort((a, b) => (r[a] - r[b]) || (c[a] - c[b]) || (a - b));
-    const er = [], ec = [], ev = [];
-    for (let q = 0; q < order.length; q++) {
-      const k = order[q];
-      if (q > 0 && r[order[q - 1]] === r[k] && c[order[q - 1]] === c[k]) continue;     // a later duplicate
-      if (v[k] !== 0) { er.push(r[k]); ec.push(c[k]); ev.push(v[k]); }
-    }
-    const out = new Float64Array(n);
-    for (let k = 0; k < ev.length; k++) out[er[k]] += ev[k];
-    const diag = new Float64Array(n).fill(1);
-    const sys = { rows: n, cols: n, format: 'coo', values: [], rowIndices: [], colIndices: [] };
-    for (let k = 0; k < ev.length; k++) {
-      const j = er[k], i = ec[k];
-      if (!(out[j] > 0)) continue;                                                     // a dangling node's column stays the identity's
-      const prob = ev[k] / out[j];
-      if (i === j) diag[i] = 1 - config.damping * prob;
-      else { sys.rowIndices.push(i); sys.colIndices.push(j); sys.values.push(-(config.damping * prob)); }
-    }
-    for (let i = 0; i < n; i++) if (diag[i] !== 0) { sys.rowIndices.push(i); sys.colIndices.push(i); sys.values.push(diag[i]); }
+    const sys = pageRankSystem(adjacency, config.damping);
     const rhs = config.personalized || new Array(n).fill(1 * ((1 - config.damping) / n));
     const solver = new SublinearSolver({ method: this.config.method, epsilon: config.epsilon, maxIterations: config.maxIterations, timeout: this.config.timeout });
     return (await solver.solve(sys, rhs)).solution;
   }
 }
 
-module.exports = { SublinearSolver, SolverError, ErrorCodes, MatrixOperations, native };
+module.exports = { SublinearSolver, SolverError, ErrorCodes, MatrixOperations, pageRankSystem, native };

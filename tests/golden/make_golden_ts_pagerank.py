@@ -120,6 +120,15 @@ def main():
         out[k + "/system"] = np.array(r["system"], dtype=np.float64)               # the dense n x n table the reference assembled
         out[k + "/rhs"] = np.array(r["rhs"], dtype=np.float64)
         out[k + "/solution"] = np.array(r["solution"], dtype=np.float64)
+    # the same cases as JSON for the JavaScript surface test (node reads no .npz): the system as sorted (row, col, value) triplets
+    js = []
+    for c, r in zip(cases, res):
+        S = np.array(r["system"], dtype=np.float64)
+        rr, cc = np.nonzero(S)
+        js.append({"name": c["name"], "adjacency": {"rows": c["n"], "cols": c["n"], "format": "coo", "values": c["values"], "rowIndices": c["rows"], "colIndices": c["cols"]},
+                   "damping": c["damping"], "epsilon": c["epsilon"], "maxIterations": c["maxIterations"], "personalized": c.get("personalized"),
+                   "system": {"rows": rr.tolist(), "cols": cc.tolist(), "values": S[rr, cc].tolist()}, "rhs": r["rhs"], "solution": r["solution"], "iterations": r["iterations"]})
+    (ROOT / "tests" / "golden" / "reference_ts_pagerank_js.json").write_text(json.dumps(js))
     path = ROOT / "tests" / "golden" / "reference_ts_pagerank.npz"
     np.savez_compressed(path, **out)
     print(path, {str(k): int(out[str(k) + "/params"][2]) for k in out["names"]})

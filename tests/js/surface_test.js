@@ -3,7 +3,7 @@
  * Without `gpu`: host logic only (config / matrix validation, analyzeMatrix, the loud DeviceError).  With `gpu`: solves. */
 const assert = require('assert');
 const path = require('path');
-const { SublinearSolver, SolverError, ErrorCodes, MatrixOperations, native } = require(path.join(__dirname, '..', '..', 'bindings', 'node'));
+const { SublinearSolver, SolverError, ErrorCodes, MatrixOperations, pageRankSystem, native } = require(path.join(__dirname, '..', '..', 'bindings', 'node'));
 
 const onGpu = process.argv[2] === 'gpu';
 
@@ -60,6 +60,18 @@ async function rejects(p, code, re) {
   assert(Math.abs(a.sparsity - 2 / 9) < 1e-15 && Math.abs(a.dominanceStrength - (5 - 3) / 5) < 1e-15);
   const notDD = { rows: 2, cols: 2, format: 'dense', data: [[1, 3], [2, 1]] };
   assert.strictEqual(MatrixOperations.analyzeMatrix(notDD).isDiagonallyDominant, false);
+  const goldenPageRank = JSON.parse(require('fs').readFileSync(path.join(__dirname, '..', 'golden', 'reference_ts_pagerank_js.json'), 'utf8'));
+  {   // G13: the system computePageRank assembles, entry for entry and bit for bit what the reference's own TypeScript assembled
+      // (tests/golden/make_golden_ts_pagerank.py): weights, self loops on the diagonal, dangling nodes, left-to-right out-degrees
+    assert(goldenPageRank.length === 3);
+    for (const g of goldenPageRank) {
+      const sys = pageRankSystem(g.adjacency, g.damping);
+      const order = Array.from(sys.values.keys()).sort((a, b) => (sys.rowIndices[a] - sys.rowIndices[b]) || (sys.colIndices[a] - sys.colIndices[b]));
+      assert.deepStrictEqual(order.map(k => sys.rowIndices[k]), g.system.rows, g.name);
+      assert.deepStrictEqual(order.map(k => sys.colIndices[k]), g.system.cols, g.name);
+      assert.deepStrictEqual(order.map(k => sys.values[k]), g.system.values, g.name);
+    }
+  }
   {   // G14: analyzeMatrix field by field (the bits of dominanceStrength included) against what the reference's own TypeScript returned for
       // these matrices (tests/golden/reference_ts_analyze.json, make_golden_ts_analyze.py): duplicated COO entries, storage order, zero diagonals
     const golden = JSON.parse(require('fs').readFileSync(path.join(__dirname, '..', 'golden', 'reference_ts_analyze.json'), 'utf8'));
@@ -152,6 +164,12 @@ async function rejects(p, code, re) {
       }
     }
     assert.throws(() => new SublinearSolver({ method: 'random-walk', epsilon: 0.1, maxIterations: 10, stream: 'nonsense' }), /Unknown random-walk stream/);
+  }
+  for (const g of goldenPageRank) {   // G13 on the device: computePageRank with method forward-push returns the reference's solution, bit for bit
+    const pr = new SublinearSolver({ method: 'forward-push', epsilon: 1e-6, maxIterations: 10 });
+    const cfg = { damping: g.damping, epsilon: g.epsilon, maxIterations: g.maxIterations };
+    if (g.personalized) cfg.personalized = g.personalized;
+    assert.deepStrictEqual(Array.from(await pr.computePageRank(g.adjacency, cfg)), g.solution, g.name);
   }
   {   // G6 (tests/mcp/mcp-tool-tests.js:27-52): 10 x 10 tridiag(-1, 10, -1), b = e0 + e9, epsilon 1e-3 -> 12 pushes, ||r|| = 5.2915e-4
     const t = { rows: 10, cols: 10, format: 'coo', values: [], rowIndices: [], colIndices: [] };
