@@ -127,6 +127,11 @@ def main():
         out[k + "/epsilon_residual"] = np.array([c["epsilon"], r["residual"] if r["converged"] else r["finalResidual"]], dtype=np.float64)
         if r["converged"]:
             out[k + "/solution"] = np.array(r["solution"], dtype=np.float64)
+    # the small cases as JSON for the JavaScript surface test
+    js = [{"name": c["name"], "matrix": {"rows": c["n"], "cols": c["n"], "format": "coo", "values": c["values"], "rowIndices": c["rows"], "colIndices": c["cols"]},
+           "b": c["b"], "epsilon": c["epsilon"], "maxIterations": c["maxIterations"], "solution": r["solution"], "iterations": r["iterations"], "residual": r["residual"]}
+          for c, r in zip(cases, res) if c["n"] <= 60 and r["converged"]]
+    (ROOT / "tests" / "golden" / "reference_ts_push_js.json").write_text(json.dumps(js))
     path = ROOT / "tests" / "golden" / "reference_ts_push.npz"
     np.savez_compressed(path, **out)
     print(path, {str(k): (int(out[str(k) + "/params"][3]), int(out[str(k) + "/params"][2])) for k in out["names"]})

@@ -165,6 +165,17 @@ async function rejects(p, code, re) {
     }
     assert.throws(() => new SublinearSolver({ method: 'random-walk', epsilon: 0.1, maxIterations: 10, stream: 'nonsense' }), /Unknown random-walk stream/);
   }
+  {   // G12 on the device: solve() with method forward-push against the reference's own solveForwardPush (executed: make_golden_ts_push.py) —
+      // pushes counted as iterations, the solution bit for bit
+    const goldenPush = JSON.parse(require('fs').readFileSync(path.join(__dirname, '..', 'golden', 'reference_ts_push_js.json'), 'utf8'));
+    assert(goldenPush.length >= 3);
+    for (const g of goldenPush) {
+      const r = await new SublinearSolver({ method: 'forward-push', epsilon: g.epsilon, maxIterations: g.maxIterations }).solve(g.matrix, g.b);
+      assert.strictEqual(r.iterations, g.iterations, g.name);
+      assert.deepStrictEqual(r.solution, g.solution, g.name);
+      assert(Math.abs(r.residual - g.residual) <= 1e-12 * g.residual, g.name);
+    }
+  }
   for (const g of goldenPageRank) {   // G13 on the device: computePageRank with method forward-push returns the reference's solution, bit for bit
     const pr = new SublinearSolver({ method: 'forward-push', epsilon: 1e-6, maxIterations: 10 });
     const cfg = { damping: g.damping, epsilon: g.epsilon, maxIterations: g.maxIterations };
