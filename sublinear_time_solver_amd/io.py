@@ -115,12 +115,11 @@ def matrix_to_triplets(matrix: Dict[str, Any]) -> Tuple[np.ndarray, np.ndarray, 
         r = np.asarray(r, dtype=np.int64)
         c = np.asarray(c, dtype=np.int64)
         v = np.asarray(v, dtype=np.float64)
-        bad = np.nonzero((r < 0) | (r >= rows))[0]
+        bad_r, bad_c = (r < 0) | (r >= rows), (c < 0) | (c >= cols)      # entry after entry, the row before the column (matrix.ts:44-51)
+        bad = np.nonzero(bad_r | bad_c)[0]
         if bad.size:
-            raise SolverError(8, f"Invalid row index {int(r[bad[0]])}")
-        bad = np.nonzero((c < 0) | (c >= cols))[0]
-        if bad.size:
-            raise SolverError(8, f"Invalid column index {int(c[bad[0]])}")
+            k = int(bad[0])
+            raise SolverError(8, f"Invalid row index {int(r[k])}" if bad_r[k] else f"Invalid column index {int(c[k])}")
         return r, c, v, rows, cols
     raise SolverError(6, f"Unsupported matrix format: {fmt}")
 

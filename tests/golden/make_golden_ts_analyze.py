@@ -42,7 +42,8 @@ class MatrixOperations {
 }
 const analyzeMatrix = (m) => MatrixOperations.analyzeMatrix(m);
 const cases = require('./cases.json');
-const out = cases.map(c => { const a = analyzeMatrix(c.matrix); if (a.dominanceStrength === Infinity) a.dominanceStrength = 'Infinity'; return { name: c.name, analysis: a }; });
+const out = cases.map(c => { if (c.invalid) { try { analyzeMatrix(c.matrix); return { name: c.name, error: null }; } catch (e) { return { name: c.name, error: { message: e.message, code: e.code } }; } }
+  const a = analyzeMatrix(c.matrix); if (a.dominanceStrength === Infinity) a.dominanceStrength = 'Infinity'; return { name: c.name, analysis: a }; });
 process.stdout.write(JSON.stringify(out));
 """
 
@@ -89,6 +90,17 @@ def cases():
     rr, cc = np.nonzero(A)
     srp, sci, sva, _ = G.pagerank_system(n, arp, cc.astype(np.uint32), A[rr, cc], 0.85)
     coo("pagerank20_column_dominant_only", n, np.repeat(np.arange(n), np.diff(srp.astype(np.int64))), sci, sva)
+    # validateMatrix (core/matrix.ts:11-55): which error a malformed matrix draws, message and code — checked entry after entry, row before column
+    def invalid(name, matrix):
+        out.append({"name": name, "invalid": True, "matrix": matrix})
+    invalid("invalid_zero_rows", {"rows": 0, "cols": 3, "format": "dense", "data": []})
+    invalid("invalid_dense_row_count", {"rows": 2, "cols": 2, "format": "dense", "data": [[1.0, 0.0]]})
+    invalid("invalid_dense_row_length", {"rows": 2, "cols": 2, "format": "dense", "data": [[1.0, 0.0], [1.0]]})
+    invalid("invalid_coo_lengths", {"rows": 2, "cols": 2, "format": "coo", "values": [1.0, 2.0], "rowIndices": [0], "colIndices": [0, 1]})
+    invalid("invalid_coo_missing_array", {"rows": 2, "cols": 2, "format": "coo", "values": [1.0], "rowIndices": [0]})
+    invalid("invalid_column_in_entry_0_row_in_entry_2", {"rows": 2, "cols": 2, "format": "coo", "values": [1.0, 1.0, 1.0], "rowIndices": [0, 1, 5], "colIndices": [7, 1, 0]})
+    invalid("invalid_row_and_column_in_one_entry", {"rows": 2, "cols": 2, "format": "coo", "values": [1.0], "rowIndices": [-1], "colIndices": [9]})
+    invalid("invalid_format", {"rows": 2, "cols": 2, "format": "csr", "data": []})
     return out
 
 
@@ -102,10 +114,16 @@ def main():
         assert p.returncode == 0, p.stderr[-3000:]
         res = json.loads(p.stdout)
     for c, r in zip(cs, res):
-        c["analysis"] = r["analysis"]
+        if c.get("invalid"):
+            c["error"] = r["error"]
+        else:
+            c["analysis"] = r["analysis"]
     path = ROOT / "tests" / "golden" / "reference_ts_analyze.json"
     path.write_text(json.dumps(cs))
     for c in cs:
+        if c.get("invalid"):
+            print(f"{c['name']:44s} {c['error']}")
+            continue
         a = c["analysis"]
         print(f"{c['name']:44s} dd {a['isDiagonallyDominant']!s:5s} {a['dominanceType']:6s} strength {a['dominanceStrength']!r:24} sym {a['isSymmetric']!s:5s} sparsity {a['sparsity']}")
 

@@ -75,8 +75,14 @@ async function rejects(p, code, re) {
   {   // G14: analyzeMatrix field by field (the bits of dominanceStrength included) against what the reference's own TypeScript returned for
       // these matrices (tests/golden/reference_ts_analyze.json, make_golden_ts_analyze.py): duplicated COO entries, storage order, zero diagonals
     const golden = JSON.parse(require('fs').readFileSync(path.join(__dirname, '..', 'golden', 'reference_ts_analyze.json'), 'utf8'));
-    assert(golden.length >= 14);
-    for (const g of golden) assert.deepStrictEqual(MatrixOperations.analyzeMatrix(g.matrix), g.analysis, g.name);
+    assert(golden.length >= 22);
+    const codeOf = { INVALID_MATRIX: ErrorCodes.INVALID_MATRIX, INVALID_DIMENSIONS: ErrorCodes.INVALID_DIMENSIONS };
+    for (const g of golden) {
+      if (!g.invalid) { assert.deepStrictEqual(MatrixOperations.analyzeMatrix(g.matrix), g.analysis, g.name); continue; }
+      let err = null;                                             // validateMatrix (core/matrix.ts:11-55): the reference's message and code
+      try { MatrixOperations.analyzeMatrix(g.matrix); } catch (e) { err = e; }
+      assert(err instanceof SolverError && err.message === g.error.message && err.code === codeOf[g.error.code], `${g.name}: ${err && err.message} / ${err && err.code}`);
+    }
   }
   const s = new SublinearSolver({ method: 'neumann', epsilon: 1e-10, maxIterations: 1000 });
   await rejects(s.solve(notDD, [1, 1]), ErrorCodes.NOT_DIAGONALLY_DOMINANT, /not diagonally dominant/);

@@ -101,6 +101,15 @@ def test_g14_analyze_matrix_equals_the_references_own_typescript():
     from sublinear_time_solver_amd import io
     cases = json.loads((Path(__file__).resolve().parent / "golden" / "reference_ts_analyze.json").read_text())
     assert len(cases) >= 14
-    for c in cases:
+    from sublinear_time_solver_amd import SolverError
+    valid = [c for c in cases if not c.get("invalid")]
+    for c in valid:
         assert io.analyze_matrix(c["matrix"]) == c["analysis"], c["name"]
-    assert {c["analysis"]["dominanceType"] for c in cases} >= {"row", "column", "none"} and any(c["analysis"]["isSymmetric"] for c in cases)
+    assert {c["analysis"]["dominanceType"] for c in valid} >= {"row", "column", "none"} and any(c["analysis"]["isSymmetric"] for c in valid)
+    # validateMatrix (core/matrix.ts:11-55): the same message for the same malformed matrix — entry after entry, the row before the column
+    bad = [c for c in cases if c.get("invalid")]
+    assert len(bad) >= 8
+    for c in bad:
+        with pytest.raises(SolverError) as e:
+            io.analyze_matrix(c["matrix"])
+        assert c["error"]["message"] in str(e.value), (c["name"], str(e.value))
