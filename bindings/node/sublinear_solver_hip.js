@@ -262,9 +262,16 @@ class SublinearSolver {
     }
     if (vector.length !== matrix.rows) throw new SolverError(`Vector length ${vector.length} does not match matrix rows ${matrix.rows}`, ErrorCodes.INVALID_DIMENSIONS);
     const eps = config.epsilon !== undefined ? config.epsilon : this.config.epsilon;
+    // config.entryOf = 'solution' (default): x_row = (A^-1 vector)_row, what the reference's random-walk branch estimates; 'inverse':
+    // (A^-1)[row][column] with `vector` ignored — what the reference's non-random-walk branch computes (A x = e_column, x[row]: solver.ts:603-620)
+    if (config.entryOf !== undefined && config.entryOf !== 'solution' && config.entryOf !== 'inverse') {
+      throw new SolverError(`Unknown entryOf: ${config.entryOf}`, ErrorCodes.INVALID_PARAMETERS);
+    }
+    const walk = config.method === 'random-walk' || config.method === 'monte-carlo';
     const b = Float64Array.from(vector);
+    if (config.entryOf === 'inverse' && !walk) { b.fill(0); b[config.column] = 1; }
     return withDeviceMatrix(matrix, true, (h) => {
-      if (config.method === 'random-walk' || config.method === 'monte-carlo') {        // solver.ts:585-601, 630-648
+      if (walk) {        // solver.ts:585-601, 630-648
         const seed = (this.config.seed !== undefined ? this.config.seed : 0) >>> 0;
         const r = native.estimateEntryRandomWalk(h, b, config.row, eps, seed, this.walkStream);
         return { estimate: r.estimate, variance: r.variance, confidence: config.confidence, numSamples: r.numSamples };

@@ -906,9 +906,14 @@ class SublinearSolver:
         return inner.solve(m, b)["solution"]
 
     def estimate_entry(self, matrix, vector, row: int, column: int = 0, epsilon: Optional[float] = None,
-                       confidence: float = 0.95, method: str = "neumann") -> dict:
+                       confidence: float = 0.95, method: str = "neumann", entry_of: str = "solution") -> dict:
         """estimateEntry(matrix, vector, {row, column, epsilon, confidence, method}) -> {estimate,
-        variance, confidence} (solver.ts:550-554).  Returns x_row = (A^-1 vector)_row."""
+        variance, confidence} (solver.ts:550-554).  entry_of = "solution" (default): x_row = (A^-1 vector)_row — what the reference's
+        random-walk branch estimates and what the name says.  entry_of = "inverse": (A^-1)[row][column], `vector` IGNORED — what the
+        reference's non-random-walk branch computes (it solves A x = e_column and reads x[row], solver.ts:603-620; listed as a defect in
+        SURVEY §8, offered for callers that relied on it; by the same local push: e_row^T A^-1 e_column)."""
+        if entry_of not in ("solution", "inverse"):
+            raise SolverError(4, f"Unknown entry_of: {entry_of}")
         m = _matrix_from_json(matrix, with_transpose=True)
         if not (0 <= row < m.rows()):
             raise SolverError(4, f"Row index {row} out of bounds. Matrix has {m.rows()} rows (valid range: 0-{m.rows() - 1})")
@@ -918,6 +923,9 @@ class SublinearSolver:
         if b.size != m.rows():
             raise SolverError(5, f"Vector length {b.size} does not match matrix rows {m.rows()}")
         eps = epsilon if epsilon is not None else self.epsilon
+        if entry_of == "inverse" and method != "random-walk":
+            b = np.zeros(m.rows())
+            b[column] = 1.0
         if method == "random-walk":                                      # solver.ts:585-601, 630-648
             res = L.WalkResult()
             seed = (self.seed if self.seed is not None else 0) & 0xFFFFFFFF

@@ -468,3 +468,21 @@ def test_ts_surface_gate_is_the_references(gpu):
     assert io.analyze_matrix(col_dd)["dominanceType"] == "column"
     r = S.SublinearSolver(method="neumann", epsilon=1e-10, max_iterations=10000).solve(col_dd, [1.0, 2.0])
     assert r["converged"] and np.allclose(np.array(col_dd["data"]) @ r["solution"], [1.0, 2.0], atol=1e-8)
+
+
+def test_estimate_entry_of_the_inverse_as_the_references_deterministic_branch_means_it(gpu):
+    """entry_of="inverse": (A^-1)[row][column], the vector ignored (solver.ts:603-620: A x = e_column, x[row]); the default estimates x_row"""
+    n = 60
+    rp, ci, va, b = G.sdd_rows(n, 6, seed=2)
+    A = np.zeros((n, n))
+    A[np.repeat(np.arange(n), np.diff(rp.astype(np.int64))), ci] = va
+    inv = np.linalg.inv(A)
+    m = {"rows": n, "cols": n, "format": "dense", "data": A.tolist()}
+    s = S.SublinearSolver(epsilon=1e-12, max_iterations=10000)
+    for row, col in ((0, 0), (7, 31), (59, 2)):
+        e = s.estimate_entry(m, b, row=row, column=col, entry_of="inverse")
+        assert abs(e["estimate"] - inv[row, col]) <= 1e-10 * max(abs(inv[row, col]), 1e-3), (row, col)
+        d = s.estimate_entry(m, b, row=row, column=col)
+        assert abs(d["estimate"] - (inv @ b)[row]) <= 1e-10 * abs((inv @ b)[row])
+    with pytest.raises(S.SolverError):
+        s.estimate_entry(m, b, row=0, column=0, entry_of="nonsense")
