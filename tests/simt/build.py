@@ -28,13 +28,18 @@ CSRC = Path(os.environ["SIMT_CSRC"]) if os.environ.get("SIMT_CSRC") else ROOT / 
 # SIMT_SANITIZE=1: the same library under AddressSanitizer (its own build directory): "device" allocations get their exact size, so a kernel
 # that reads or writes past a device buffer — harmless-looking on hardware, where allocations are padded to pages — is reported with the
 # kernel's source line.  Run with LD_PRELOAD=<libclang_rt.asan-x86_64.so> (tests/test_simt_asan.py does).
-SANITIZE = os.environ.get("SIMT_SANITIZE") == "1"
-BUILD = Path(os.environ["SIMT_BUILD"]) if os.environ.get("SIMT_BUILD") else HERE / ("_build_asan" if SANITIZE else "_build")
+# SIMT_SANITIZE=2: AddressSanitizer + UndefinedBehaviorSanitizer (shift counts, signed overflow, float -> integer conversions out of range,
+# static array bounds, null dereferences; not `alignment`: the hardware's vector loads need dword alignment only) in `_build_ubsan/`.
+SANITIZE = os.environ.get("SIMT_SANITIZE") in ("1", "2")
+UBSAN = os.environ.get("SIMT_SANITIZE") == "2"
+BUILD = Path(os.environ["SIMT_BUILD"]) if os.environ.get("SIMT_BUILD") else HERE / ("_build_ubsan" if UBSAN else "_build_asan" if SANITIZE else "_build")
 CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g1", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing", "-pthread", "-Wno-unused-value",
          "-Wno-unused-result", "-Wno-unknown-attributes", "-Wno-ignored-attributes", f"-I{HERE}", f"-I{BUILD}"]
 if SANITIZE:
     FLAGS += ["-fsanitize=address", "-fno-omit-frame-pointer", "-DSIMT_EXACT_ALLOC", "-shared-libasan"]
+if UBSAN:
+    FLAGS += ["-fsanitize=undefined,float-cast-overflow", "-fno-sanitize=alignment,vptr,function", "-fno-sanitize-recover=undefined"]
 
 
 def asan_runtime() -> str:
@@ -113,7 +118,7 @@ def build(force: bool = False) -> Path:
     todo = [pkg / s.name for s in sources()] + [HERE / "simt_rt.cpp", HERE / "simt_debug.cpp"]
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, todo))
-    r = subprocess.run([CXX, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", *(["-fsanitize=address", "-shared-libasan"] if SANITIZE else []), "-o", str(out), *map(str, objs),
+    r = subprocess.run([CXX, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", *(["-fsanitize=address", "-shared-libasan"] if SANITIZE else []), *(["-fsanitize=undefined", "-shared-libsan"] if UBSAN else []), "-o", str(out), *map(str, objs),
                         "-ldl", "-lrt"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stderr[-4000:])

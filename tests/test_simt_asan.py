@@ -69,6 +69,20 @@ def test_parity_tests_are_clean_under_address_sanitizer(asan_lib):
     assert r.returncode == 0 and " passed" in r.stdout and " failed" not in r.stdout and "AddressSanitizer" not in r.stdout + r.stderr, r.stdout[-2500:] + r.stderr[-2500:]
 
 
+def test_smoke_is_clean_under_undefined_behaviour_sanitizer():
+    """SIMT_SANITIZE=2: + UndefinedBehaviorSanitizer (shift counts, signed overflow, float -> integer conversions out of range, static array
+    bounds; not `alignment`).  SIMT_FULL=1 only (a second sanitized build: 50 s); the whole selection under it: profiles/r06_simt_ubsan.txt"""
+    if os.environ.get("SIMT_FULL") != "1":
+        pytest.skip("runs with SIMT_FULL=1 (profiles/r06_simt_ubsan.txt holds this round's sweep)")
+    env0 = dict(os.environ, SIMT_SANITIZE="2")
+    r = subprocess.run([sys.executable, str(SIMT / "build.py")], capture_output=True, text=True, timeout=1500, env=env0)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lib = Path(r.stdout.strip().splitlines()[-1])
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True, text=True, timeout=1500,
+                       env=_env(lib, UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"))
+    assert r.returncode == 0 and "smoke ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 def test_a_planted_off_by_one_is_reported(tmp_path):
     """teeth: sl_scale_array_kernel made to touch element n (one past the array) in a scratch build — ASAN names the kernel"""
     patch = tmp_path / "patch.py"
