@@ -160,6 +160,7 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
     }
     if (num_samples == 0) {
         const double ns = std::ceil(1.0 / (epsilon * epsilon));             // solver.ts:586
+        if (!(ns < 9.0e15)) return sl_fail(SL_INVALID_INPUT, "epsilon %g asks for %g walks", epsilon, ns);      // (beyond 2^53 the count is no integer any more; NaN lands here too)
         num_samples = ns > 100.0 ? (uint64_t)ns : 100;
     }
     if (stream == SL_WALK_STREAM_BLOCKS && num_samples > SL_WALK_MAX_TOTAL)
@@ -263,6 +264,7 @@ extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, s
     if (hs[0] & 6ull) return sl_fail(SL_NUMERICAL_INSTABILITY, "Zero diagonal at position %llu", (hs[0] & 2ull) ? hs[2] : hs[3]);     // solver.ts:368-371
     if (num_walks == 0) {
         const double ns = std::ceil(1.0 / (epsilon * epsilon));             // solver.ts:303
+        if (!(ns < 9.0e15)) return sl_fail(SL_INVALID_INPUT, "epsilon %g asks for %g walks per coordinate", epsilon, ns);
         num_walks = ns > 100.0 ? (uint64_t)ns : 100;
     }
     if (num_walks < 2) return sl_fail(SL_INVALID_INPUT, "at least two walks per coordinate (the sample variance divides by N - 1)");

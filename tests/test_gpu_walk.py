@@ -178,3 +178,6 @@ def test_block_stride_shrinks_beyond_the_generators_period(gpu):
     with pytest.raises(S.SolverError) as e:
         _walk(m, b, 5, (1 << 28) + 1, 9)
     assert e.value.kind == "InvalidInput"
+    with pytest.raises(S.SolverError) as e:                                         # an epsilon whose 1 / eps^2 is no integer any more: refused, not converted
+        _walk(m, b, 5, 0, 9, eps=1e-12)
+    assert e.value.kind == "InvalidInput" and "walks" in str(e.value)
