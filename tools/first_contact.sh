@@ -7,7 +7,8 @@
 #             same ABI) at world N under SL_COMM_TRANSPORT=ipc, then rccl with SL_COMM_HALO=sendrecv (grouped ncclSend / ncclRecv) and
 #             =allreduce (one ncclAllReduce over the compact halo buffer: BASELINE north_star's wording), each on a neighbour-halo system,
 #             an all-over-the-matrix system (ncclAllGather) and an uneven three-way reach;
-#         (ii) python bench.py --gpus N (the line the driver's SCALE run asks for), once per transport.
+#         (ii) python bench.py --gpus N (the line the driver's SCALE run asks for), once per transport;
+#         (iii) the same line with both exchanges measured in one job (exchange_variants), self-launched and under torch.distributed.run.
 # One job at a time, N processes, nothing side by side.
 #
 # WHAT TO LOOK AT FIRST.  Until this script runs, the library's RCCL calls have met more than one rank only against the test suite's
@@ -57,5 +58,9 @@ unset SL_COMM_TRANSPORT SL_COMM_HALO SL_LOG
 for TR in ipc rccl; do
   SL_BENCH_TRANSPORTS=$TR stage bench_${TR} 1500 python bench.py --gpus $N --rows $ROWS --steps 30 --warmup 5
 done
+# (iii) the line as the driver's scaling run gets it: both exchanges in one job (exchange_variants: ipc, and rccl + ONE all-reduce over the halo), once
+#       self-launched and once under torch.distributed.run
+stage bench_both_selflaunched 1700 python bench.py --gpus $N --rows $ROWS --steps 30 --warmup 5
+stage bench_both_torchrun 1700 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus $N --rows $ROWS --steps 30 --warmup 5
 echo "logs: $O/*.log"; cat $O/verdict.txt
 grep -c "rc   0" $O/verdict.txt
