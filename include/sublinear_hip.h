@@ -588,8 +588,12 @@ sl_status sl_matrix_transpose(const sl_matrix *m, uint32_t flags, sl_matrix **ou
  *   SL_WALK_STREAM_SERIAL (the reference as written): ONE stream walked serially — walk s starts where walk s - 1 stopped
  *     (solver.ts:585-601, 300-326), the sums of mean and variance are added in walk order.  Every per-walk value, `estimate` and
  *     `variance` (solve: every x_i, variance_i, total_variance) are bit-identical to the reference's for the same
- *     (matrix, b, row, epsilon, seed).  One lane does all the work: N = max(100, ceil(1 / epsilon^2)) walks per coordinate take
- *     microseconds each — the parity form, not the fast one. */
+ *     (matrix, b, row, epsilon, seed).  The serial dependency is only WHERE in the stream a walk starts; what a walk does from a
+ *     given position is independent of the others.  So the device simulates a walk from EVERY position of a window of the stream
+ *     (one lane per position, the state there by jump-ahead), records value and draws used, and then follows the reference's chain
+ *     position -> position + draws used through the window (per-4096-position tables in LDS, one short serial pass over the chunks):
+ *     the reference's walks, in its order, at a cost of (mean draws per walk) simulated walks per walk kept.
+ *     SL_WALK_SERIAL_PLAIN=1 (environment) runs the reference as written on ONE lane instead — the cross-check of the tests. */
 typedef enum { SL_WALK_STREAM_BLOCKS = 0, SL_WALK_STREAM_SERIAL = 1 } sl_walk_stream;
 typedef struct {
     double estimate;         /* mean of the walk values            (solver.ts:630)  */

@@ -43,8 +43,9 @@ __host__ __device__ inline uint32_t walk_lcg_jump(uint32_t state, uint64_t k)
     }
     return acc_a * state + acc_c;
 }
-__device__ __forceinline__ double walk_lcg(uint64_t &state)
+__device__ __forceinline__ double walk_lcg(uint64_t &state, uint32_t &draws)
 {
+    ++draws;
     state = (state * 1664525ull + 1013904223ull) & 0xffffffffull;
     return __dmul_rn((double)state, 2.3283064365386963e-10);          // / 2^32
 }
@@ -53,8 +54,9 @@ __device__ __forceinline__ double walk_lcg(uint64_t &state)
 // per_row = W > 0 (solveRandomWalk, solver.ts:300-326): walk s of this launch belongs to coordinate start_row + s / W and is that
 // coordinate's walk s % W = walk number coordinate * W + s % W of the solve, whatever batch of coordinates the launch holds
 // performRandomWalk (solver.ts:390-432) over the CSR row of the current state; `state` is the generator's state, advanced in place
+// `draws` counts the generator's draws the walk consumed (1 per absorption test, 1 per transition: at most 2000)
 __device__ __forceinline__ double walk_one(uint32_t start, uint64_t &state, const uint32_t *row_ptr, const uint32_t *col_idx, const double *val,
-                                           const double *b)
+                                           const double *b, uint32_t &draws)
 {
     uint32_t cur = start;
     double value = 0.0;
@@ -63,11 +65,11 @@ __device__ __forceinline__ double walk_one(uint32_t start, uint64_t &state, cons
         double d = 0.0;
         for (uint32_t k = k0; k < k1; ++k) if (col_idx[k] == cur) d = val[k];
         const double absorb = 1.0 / d;
-        if (walk_lcg(state) < fabs(absorb)) { value = __dadd_rn(value, __dmul_rn(b[cur], absorb)); break; }
+        if (walk_lcg(state, draws) < fabs(absorb)) { value = __dadd_rn(value, __dmul_rn(b[cur], absorb)); break; }
         double sum = 0.0;
         for (uint32_t k = k0; k < k1; ++k) if (col_idx[k] != cur) sum = __dadd_rn(sum, fabs(-val[k] / d));
         if (sum == 0.0) { value = __dadd_rn(value, __dmul_rn(b[cur], absorb)); break; }
-        const double rnd = __dmul_rn(walk_lcg(state), sum);
+        const double rnd = __dmul_rn(walk_lcg(state, draws), sum);
         if (rnd <= 0.0) { cur = 0; continue; }
         double cum = 0.0;
         const uint32_t row = cur;
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(256) void sl_walk_kernel(uint64_t n_walks, uint32_t
     if (s >= n_walks) return;
     const uint64_t coord = per_row ? start_row + s / per_row : start_row;
     uint64_t state = walk_lcg_jump(seed, (per_row ? coord * per_row + s % per_row : s) * stride);
-    values[s] = walk_one((uint32_t)coord, state, row_ptr, col_idx, val, b);
+    uint32_t draws = 0;
+    values[s] = walk_one((uint32_t)coord, state, row_ptr, col_idx, val, b, draws);
 }
 // SL_WALK_STREAM_SERIAL — the reference as written (solver.ts:585-601 for one row, :300-326 coordinate after coordinate): ONE lane, ONE
 // stream; walk s starts where walk s - 1 stopped.  n_coords coordinates from start_row, W walks each; the walk values of coordinate c
@@ -99,7 +102,8 @@ __global__ void sl_walk_serial_kernel(uint64_t n_coords, uint64_t W, uint32_t se
     uint64_t state = seed;
     for (uint64_t c = 0; c < n_coords; ++c) {
         double *v = values + (keep_all ? c * W : 0);
-        for (uint64_t w = 0; w < W; ++w) v[w] = walk_one((uint32_t)(start_row + c), state, row_ptr, col_idx, val, b);
+        uint32_t draws = 0;
+        for (uint64_t w = 0; w < W; ++w) v[w] = walk_one((uint32_t)(start_row + c), state, row_ptr, col_idx, val, b, draws);
         double m = 0.0;
         for (uint64_t w = 0; w < W; ++w) m = __dadd_rn(m, v[w]);
         m = m / (double)W;
@@ -109,6 +113,144 @@ __global__ void sl_walk_serial_kernel(uint64_t n_coords, uint64_t W, uint32_t se
         var[c] = W > 1 ? q2 / (double)(W - 1) : 0.0;
     }
 }
+
+// ---- SL_WALK_STREAM_SERIAL at speed: the serial stream, data-parallel ------------------------------------------------------------------
+// Where walk s starts in the ONE stream depends on how many draws walks 0 .. s - 1 used — a serial dependency.  But WHAT a walk does depends
+// only on the stream position it starts at (and its start row).  So, for a window of M consecutive stream positions:
+//   A  (sl_walk_spec_kernel)   one lane per POSITION p: the walk the reference would perform if one of its walks started at p (the state there by
+//                              the generator's jump-ahead) -> val[p], used[p] = draws it consumes (1 .. 2000).  All positions are simulated, most
+//                              for nothing: the price of the speculation is the mean number of draws per walk (tens).
+//   B1 (sl_walk_chunk_kernel)  the chain p -> p + used[p] is what the reference follows.  Per chunk of 4096 positions, back to front in LDS:
+//                              tab[p] = (walks started inside the chunk from p on) << 16 | (offset in the NEXT chunk where the chain leaves to);
+//                              a jump is at most 2000 < 4096 positions, so a chain never skips a chunk.
+//   B2 (sl_walk_chain_kernel)  one lane follows the chain chunk by chunk (M / 4096 steps): where it enters each chunk, how many walks came before.
+//   B3 (sl_walk_emit_kernel)   one lane per chunk follows the chain inside it and writes the walks' values IN WALK ORDER; the lane that writes the
+//                              last wanted walk also says where the stream stands after it.
+// The host repeats windows until the wanted number of walks is there (a window always yields walks), then sl_walk_seq_stats_kernel adds mean
+// and variance in walk order (64 values loaded at once, added one after the other): the same values, the same order, the same bits as the
+// one-lane kernel above (tests compare the two, and both with the reference's own TypeScript: G10 / G11).
+#define SL_WALK_SPEC_CHUNK 4096u
+struct sl_walk_meta { unsigned long long done, next_rel, active_chunks, pad; };
+__global__ __launch_bounds__(256) void sl_walk_spec_kernel(uint64_t M, uint32_t seed, uint64_t base, uint32_t row, const uint32_t *row_ptr, const uint32_t *col_idx,
+                                                           const double *val, const double *b, double *out_val, uint32_t *out_used)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    uint64_t state = walk_lcg_jump(seed, base + j);
+    uint32_t draws = 0;
+    out_val[j] = walk_one(row, state, row_ptr, col_idx, val, b, draws);
+    out_used[j] = draws;
+}
+__global__ __launch_bounds__(256) void sl_walk_chunk_kernel(uint64_t M, const uint32_t *used, uint32_t *tab)
+{
+    __shared__ uint32_t u[SL_WALK_SPEC_CHUNK], t[SL_WALK_SPEC_CHUNK];
+    const uint64_t c0 = (uint64_t)blockIdx.x * SL_WALK_SPEC_CHUNK;
+    const uint32_t len = (uint32_t)(M - c0 < SL_WALK_SPEC_CHUNK ? M - c0 : SL_WALK_SPEC_CHUNK);
+    for (uint32_t e = threadIdx.x; e < len; e += 256) u[e] = used[c0 + e];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (uint32_t e = len; e-- > 0;) {
+            const uint32_t to = e + u[e];
+            t[e] = to >= len ? (1u << 16) | (to - len) : ((t[to] >> 16) + 1u) << 16 | (t[to] & 0xffffu);
+        }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < len; e += 256) tab[c0 + e] = t[e];
+}
+__global__ void sl_walk_chain_kernel(uint64_t M, uint64_t need, const uint32_t *tab, uint32_t *chunk_entry, unsigned long long *chunk_base, sl_walk_meta *meta)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    const uint64_t nchunks = (M + SL_WALK_SPEC_CHUNK - 1) / SL_WALK_SPEC_CHUNK;
+    unsigned long long done = 0, next_rel = 0, active = 0;
+    uint32_t e = 0;
+    bool limited = false;
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        const uint64_t c0 = c * SL_WALK_SPEC_CHUNK;
+        const uint32_t len = (uint32_t)(M - c0 < SL_WALK_SPEC_CHUNK ? M - c0 : SL_WALK_SPEC_CHUNK);
+        if (e >= len) { next_rel = c0 + e; active = c; goto out; }      // (a short last chunk the chain jumps over)
+        const uint32_t tv = tab[c0 + e], cnt = tv >> 16;
+        chunk_entry[c] = e; chunk_base[c] = done;
+        active = c + 1;
+        if (done + cnt >= need) { done = need; limited = true; break; }   // the last wanted walk starts in this chunk: the emitting lane says where the stream stands then
+        done += cnt;
+        e = tv & 0xffffu;
+    }
+    if (!limited) next_rel = M + e;
+out:
+    meta->done = done; meta->active_chunks = active;
+    meta->next_rel = limited ? 0 : next_rel;          // (limited: the emitting lane of the last walk writes it)
+}
+__global__ __launch_bounds__(64) void sl_walk_emit_kernel(uint64_t M, uint64_t need, const sl_walk_meta *meta, const uint32_t *chunk_entry, const unsigned long long *chunk_base,
+                                                          const uint32_t *used, const double *val, double *values, sl_walk_meta *meta_out)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= meta->active_chunks) return;
+    const uint64_t c0 = c * SL_WALK_SPEC_CHUNK, c1 = c0 + SL_WALK_SPEC_CHUNK < M ? c0 + SL_WALK_SPEC_CHUNK : M;
+    uint64_t p = c0 + chunk_entry[c], k = chunk_base[c];
+    while (p < c1 && k < need) {
+        values[k] = val[p];
+        p += used[p];
+        if (++k == need) meta_out->next_rel = p;
+    }
+}
+// mean and sample variance added in walk order, as Array.reduce adds them (solver.ts:630-633, :313-316): one wave, 64 values loaded at a time,
+// every lane adding them one after the other (uniform: all lanes hold the same running sums)
+__global__ __launch_bounds__(64) void sl_walk_seq_stats_kernel(uint64_t W, const double *v, double *mean_out, double *var_out)
+{
+    const uint32_t lane = threadIdx.x;
+    double m = 0.0;
+    for (uint64_t b0 = 0; b0 < W; b0 += 64) {
+        const double x = b0 + lane < W ? v[b0 + lane] : 0.0;
+        const int cnt = (int)(W - b0 < 64 ? W - b0 : 64);
+        for (int j = 0; j < cnt; ++j) m = __dadd_rn(m, __shfl(x, j));
+    }
+    m = m / (double)W;
+    double q2 = 0.0;
+    for (uint64_t b0 = 0; b0 < W; b0 += 64) {
+        const double x = b0 + lane < W ? v[b0 + lane] : 0.0;
+        const int cnt = (int)(W - b0 < 64 ? W - b0 : 64);
+        for (int j = 0; j < cnt; ++j) { const double q = __dadd_rn(__shfl(x, j), -m); q2 = __dadd_rn(q2, __dmul_rn(q, q)); }
+    }
+    if (lane == 0) { mean_out[0] = m; var_out[0] = W > 1 ? q2 / (double)(W - 1) : 0.0; }
+}
+
+// Host side of the pipeline: `need` walks from `row`, the stream standing at absolute draw `*pos` (advanced to where it stands afterwards);
+// values[need] in walk order (device).  Buffers are the caller's (sized for max_m positions).
+struct sl_walk_spec_bufs { double *val; uint32_t *used, *tab, *chunk_entry; unsigned long long *chunk_base; sl_walk_meta *meta; uint64_t max_m; };
+static sl_status sl_walk_spec_run(const sl_matrix *m, const double *db, uint32_t seed, uint32_t row, uint64_t need, uint64_t *pos, double *d_values,
+                                  const sl_walk_spec_bufs &w, hipStream_t s)
+{
+    uint64_t done = 0;
+    while (done < need) {
+        uint64_t M = (need - done) * 64;
+        M = (M + SL_WALK_SPEC_CHUNK - 1) / SL_WALK_SPEC_CHUNK * SL_WALK_SPEC_CHUNK;
+        M = std::min<uint64_t>(std::max<uint64_t>(M, SL_WALK_SPEC_CHUNK), w.max_m);
+        const uint64_t nchunks = M / SL_WALK_SPEC_CHUNK;
+        hipLaunchKernelGGL(sl_walk_spec_kernel, dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, s, M, seed, *pos, row, m->d_row_ptr, m->d_col_idx, m->d_values, db, w.val, w.used);
+        hipLaunchKernelGGL(sl_walk_chunk_kernel, dim3((uint32_t)nchunks), dim3(256), 0, s, M, w.used, w.tab);
+        hipLaunchKernelGGL(sl_walk_chain_kernel, dim3(1), dim3(1), 0, s, M, need - done, w.tab, w.chunk_entry, w.chunk_base, w.meta);
+        hipLaunchKernelGGL(sl_walk_emit_kernel, dim3((uint32_t)((nchunks + 63) / 64)), dim3(64), 0, s, M, need - done, w.meta, w.chunk_entry, w.chunk_base, w.used, w.val,
+                           d_values + done, w.meta);
+        SL_HIP(hipGetLastError());
+        sl_walk_meta h;
+        SL_TRY(sl_read_back(&h, w.meta, sizeof(h), s));
+        if (!h.done || !h.next_rel) return sl_fail(SL_ALGORITHM_ERROR, "internal: a window of the serial-stream pipeline yielded no walk");
+        done += h.done;
+        *pos += h.next_rel;
+    }
+    return SL_OK;
+}
+static sl_status sl_walk_spec_alloc(uint64_t need, DevBuf &val, DevBuf &used, DevBuf &tab, DevBuf &ce, DevBuf &cb, DevBuf &meta, sl_walk_spec_bufs *w)
+{
+    uint64_t cap = 1ull << 22;                       // positions per window: 4 Mi (80 MB of scratch); SL_WALK_SPEC_WINDOW = a smaller one (tests: many windows on few walks)
+    if (const char *e = getenv("SL_WALK_SPEC_WINDOW")) { const uint64_t v = strtoull(e, nullptr, 10); if (v) cap = std::min<uint64_t>(cap, (v + SL_WALK_SPEC_CHUNK - 1) / SL_WALK_SPEC_CHUNK * SL_WALK_SPEC_CHUNK); }
+    uint64_t max_m = std::min<uint64_t>(std::max<uint64_t>((need * 64 + SL_WALK_SPEC_CHUNK - 1) / SL_WALK_SPEC_CHUNK * SL_WALK_SPEC_CHUNK, SL_WALK_SPEC_CHUNK), cap);
+    const uint64_t nchunks = max_m / SL_WALK_SPEC_CHUNK;
+    SL_TRY(val.alloc(max_m * 8)); SL_TRY(used.alloc(max_m * 4)); SL_TRY(tab.alloc(max_m * 4)); SL_TRY(ce.alloc(nchunks * 4)); SL_TRY(cb.alloc(nchunks * 8)); SL_TRY(meta.alloc(sizeof(sl_walk_meta)));
+    *w = sl_walk_spec_bufs{val.as<double>(), used.as<uint32_t>(), tab.as<uint32_t>(), ce.as<uint32_t>(), cb.as<unsigned long long>(), static_cast<sl_walk_meta *>(meta.p), max_m};
+    return SL_OK;
+}
+// SL_WALK_SERIAL_PLAIN=1: the one-lane kernel instead (the cross-check of the tests)
+static bool walk_serial_plain() { const char *e = getenv("SL_WALK_SERIAL_PLAIN"); return e && *e == '1'; }
 
 // sum of (v - mean)^2 partials
 __global__ __launch_bounds__(256) void sl_walk_var_kernel(uint64_t n, const double *v, double mean, double *partials)
@@ -182,8 +324,17 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
     double h_sum = 0.0, h_var = 0.0;
     if (!scr) st = sl_fail(SL_ALLOCATION, "scratch");
     if (st == SL_OK && stream == SL_WALK_STREAM_SERIAL) {
-        hipLaunchKernelGGL(sl_walk_serial_kernel, dim3(1), dim3(1), 0, s, (uint64_t)1, num_samples, seed, (uint32_t)row, 1, m->d_row_ptr, m->d_col_idx,
-                           m->d_values, db, d_vals, scr, scr + 1);
+        if (walk_serial_plain())
+            hipLaunchKernelGGL(sl_walk_serial_kernel, dim3(1), dim3(1), 0, s, (uint64_t)1, num_samples, seed, (uint32_t)row, 1, m->d_row_ptr, m->d_col_idx,
+                               m->d_values, db, d_vals, scr, scr + 1);
+        else {
+            DevBuf wv, wu, wt, wce, wcb, wm;
+            sl_walk_spec_bufs wb;
+            SL_TRY(sl_walk_spec_alloc(num_samples, wv, wu, wt, wce, wcb, wm, &wb));
+            uint64_t pos = 0;
+            SL_TRY(sl_walk_spec_run(m, db, seed, (uint32_t)row, num_samples, &pos, d_vals, wb, s));
+            hipLaunchKernelGGL(sl_walk_seq_stats_kernel, dim3(1), dim3(64), 0, s, num_samples, d_vals, scr, scr + 1);
+        }
         double h[2] = {0.0, 0.0};
         hipMemcpyAsync(h, scr, sizeof(h), hipMemcpyDeviceToHost, s);
         hipStreamSynchronize(s);
@@ -285,9 +436,19 @@ extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, s
     SL_TRY(vbuf.alloc(batch * num_walks * 8)); SL_TRY(xbuf.alloc(n * 8)); SL_TRY(varbuf.alloc(n * 8)); SL_TRY(ybuf.alloc(n * 8));
     sl_timer timer;
     SL_TRY(timer.start(s));
-    if (serial && n)       // the reference as written: one lane, one stream, coordinate after coordinate
+    if (serial && n && walk_serial_plain())       // the reference as written: one lane, one stream, coordinate after coordinate
         hipLaunchKernelGGL(sl_walk_serial_kernel, dim3(1), dim3(1), 0, s, n, num_walks, seed, 0u, 0, m->d_row_ptr, m->d_col_idx, m->d_values, db,
                            vbuf.as<double>(), xbuf.as<double>(), varbuf.as<double>());
+    else if (serial && n) {                       // the same stream, every position of it simulated in parallel, coordinate after coordinate (pipeline above)
+        DevBuf wv, wu, wt, wce, wcb, wm;
+        sl_walk_spec_bufs wb;
+        SL_TRY(sl_walk_spec_alloc(num_walks, wv, wu, wt, wce, wcb, wm, &wb));
+        uint64_t pos = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            SL_TRY(sl_walk_spec_run(m, db, seed, (uint32_t)i, num_walks, &pos, vbuf.as<double>(), wb, s));
+            hipLaunchKernelGGL(sl_walk_seq_stats_kernel, dim3(1), dim3(64), 0, s, num_walks, vbuf.as<double>(), xbuf.as<double>() + i, varbuf.as<double>() + i);
+        }
+    }
     for (uint64_t i0 = 0; i0 < n && !serial; i0 += batch) {
         const uint64_t rows = std::min(batch, n - i0), walks = rows * num_walks;
         hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((walks + 255) / 256)), dim3(256), 0, s, walks, seed, (uint32_t)i0, num_walks, stride,

@@ -160,6 +160,43 @@ def test_serial_stream_against_the_oracle_on_larger_systems(gpu):
         S.SublinearSolver(method="random-walk", stream="nonsense")
 
 
+def test_serial_stream_pipeline_equals_the_one_lane_kernel(gpu, monkeypatch):
+    """the default SERIAL form simulates a walk from EVERY stream position and then follows the reference's chain through them
+    (sl_walk.hip, "the serial stream, data-parallel"); SL_WALK_SERIAL_PLAIN=1 is the reference as written on one lane.  Same bits, and the
+    oracle's — on walks that run into the 1000-step cap (2000 draws: the longest jump a chunk's table must carry), on windows of one chunk
+    (every window boundary is a chunk boundary the chain crosses), on windows that yield fewer walks than asked for, across coordinates"""
+    n = 48
+    rows, cols, vals = [], [], []
+    for i in range(n):                                                  # a chain; a walk stops with probability 1 / a_ii per step (solver.ts:398-401): from rows
+        d = 3000.0 if i < 16 else 2.0 + 0.5 * (1 + i % 5)               # 0..15 it runs for hundreds of steps, many into the cap; the other rows absorb quickly
+        for j, v in ((i - 1, -1.0), (i, d), (i + 1, -1.0)):
+            if 0 <= j < n:
+                rows.append(i), cols.append(j), vals.append(v)
+    rp, ci, va = O.csr_from_triplets(rows, cols, vals, n, n)
+    b = np.random.default_rng(12).standard_normal(n)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, keep_csr=True)
+    for window, row, N, seed in (("", 3, 300, 5), ("4096", 3, 150, 6), ("4096", 30, 3000, 7), ("8192", 17, 900, 8), ("", 40, 5000, 9)):
+        ov, om, ovar = O.ts_random_walk_serial(rp, ci, va, b, row, N, seed)
+        assert row != 3 or (ov == 0.0).any()                            # (a walk cut off at 1000 steps contributes 0: such walks are in the sample)
+        got = {}
+        for plain in ("0", "1"):
+            monkeypatch.setenv("SL_WALK_SERIAL_PLAIN", plain)
+            monkeypatch.setenv("SL_WALK_SPEC_WINDOW", window) if window else monkeypatch.delenv("SL_WALK_SPEC_WINDOW", raising=False)
+            gv, res = _walk(m, b, row, N, seed, stream=L.SL_WALK_STREAM_SERIAL)
+            got[plain] = (gv.copy(), res.estimate, res.variance)
+            assert (gv.view(np.uint64) == ov.view(np.uint64)).all() and (res.estimate, res.variance) == (om, ovar), (window, row, plain)
+        assert (got["0"][0].view(np.uint64) == got["1"][0].view(np.uint64)).all() and got["0"][1:] == got["1"][1:]
+    sol = {}
+    for plain, window in (("1", ""), ("0", ""), ("0", "4096")):         # solveRandomWalk: one stream through all coordinates
+        monkeypatch.setenv("SL_WALK_SERIAL_PLAIN", plain)
+        monkeypatch.setenv("SL_WALK_SPEC_WINDOW", window) if window else monkeypatch.delenv("SL_WALK_SPEC_WINDOW", raising=False)
+        r = S.random_walk_solve(m, b, 0.2, 21, stream="reference")
+        sol[(plain, window)] = np.concatenate([r["solution"], r["variances"], [r["total_variance"]]]).view(np.uint64)
+    assert (sol[("1", "")] == sol[("0", "")]).all() and (sol[("1", "")] == sol[("0", "4096")]).all()
+    o = O.ts_random_walk_solve(rp, ci, va, b, 0.2, 21)                  # (the reference's one shared stream)
+    assert (sol[("0", "")] == np.concatenate([o["x"], o["variances"], [o["total_variance"]]]).view(np.uint64)).all()
+
+
 def test_block_stride_shrinks_beyond_the_generators_period(gpu):
     """more than 2^21 walks in one call: blocks of 1024 draws instead of a second pass over the same 2048-draw blocks — the
     per-walk values still equal the oracle's block form, and walk s no longer equals walk s + 2^21"""
