@@ -46,6 +46,15 @@ def main():
                                    "walks_per_s": best.num_samples / (best.device_time_ms * 1e-3), "estimate": best.estimate,
                                    "std_error": (best.variance / best.num_samples) ** 0.5, "local_push_estimate": pe.estimate,
                                    "local_push_device_ms": pe.device_time_ms})
+    # the reference's ONE serial stream, bit for bit: the data-parallel pipeline (default) against the one-lane kernel (SL_WALK_SERIAL_PLAIN=1)
+    out["serial_stream"] = []
+    for plain, walks in (("0", n // 100), ("0", n // 10), ("1", n // 100)):      # 10^5, 10^6, 10^5 walks at n = 10^7
+        os.environ["SL_WALK_SERIAL_PLAIN"] = plain
+        r = L.WalkResult()
+        L.check(lib.sl_estimate_entry_random_walk(h, C.c_void_p(b.data_ptr()), L.SL_MEM_DEVICE, n // 2, 1e-3, 42, L.SL_WALK_STREAM_SERIAL, walks, None, C.byref(r)))
+        out["serial_stream"].append({"form": "one lane" if plain == "1" else "pipeline", "walks": walks, "device_ms": r.device_time_ms,
+                                     "walks_per_s": walks / (r.device_time_ms * 1e-3), "estimate": r.estimate})
+    os.environ.pop("SL_WALK_SERIAL_PLAIN", None)
     lib.sl_matrix_destroy(h)
     print(json.dumps(out))
 
