@@ -247,32 +247,56 @@ struct sl_slice_regs {
     double e_d, e_x, e_aux;
 };
 
+// A wave-uniform pointer pinned to an SGPR pair and opaque to the optimiser.  Without it the compiler hoists `stream + lane * 16` out of
+// the slice loop as a 64-bit VGPR pair per stream and adds the slice's offset on the VALU — into registers that double as load
+// destinations, so that the next slice's loads wait (s_waitcnt vmcnt(0)) for the loads still in flight: one slice of loads per wave
+// instead of the two the pipeline is written for.  Through this the loads are `global_load vdst, v_lane16, s[base:base+1] offset:imm`.
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T *sl_scalar_ptr(const T *p)
+{
+    auto g = (const __attribute__((address_space(1))) T *)p;      // (global, not flat: the asm hides where the pointer came from)
+    asm volatile("" : "+s"(g));
+    return g;
+}
+
+// `s` must be wave-uniform (the callers derive it from the block's and the wave's number)
+template <typename T>
+__device__ __forceinline__ T sl_stream_load(const __attribute__((address_space(1))) T *base, uint32_t lane, int k)      // base[k * 64 + lane]
+{
+    return __builtin_nontemporal_load(&base[k * 64 + lane]);
+}
 template <int EPI, int UW, bool C16>
 __device__ __forceinline__ void sl_slice_load(const sl_row_args &a, uint64_t s, uint32_t lane, sl_slice_regs<UW, C16> &r)
 {
-    const f64x2 *__restrict__ vq = reinterpret_cast<const f64x2 *>(a.vals);
     constexpr int NQ = UW / 4;
-    const uint64_t qb = s * NQ;
+    const auto *vq = sl_scalar_ptr(reinterpret_cast<const f64x2 *>(a.vals) + s * (NQ * 2 * 64));
     if constexpr (C16) {
-        const u32x4 *__restrict__ c16 = reinterpret_cast<const u32x4 *>(a.cols16);
+        const auto *c16 = sl_scalar_ptr(reinterpret_cast<const u32x4 *>(a.cols16) + s * ((UW / 8) * 64));
 #pragma unroll
-        for (int o = 0; o < UW / 8; ++o) r.c[o] = __builtin_nontemporal_load(&c16[(s * (UW / 8) + o) * 64 + lane]);
+        for (int o = 0; o < UW / 8; ++o) r.c[o] = sl_stream_load(c16, lane, o);
     } else {
-        const u32x4 *__restrict__ cq = reinterpret_cast<const u32x4 *>(a.cols);
+        const auto *cq = sl_scalar_ptr(reinterpret_cast<const u32x4 *>(a.cols) + s * (NQ * 64));
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) r.c[q] = __builtin_nontemporal_load(&cq[(qb + q) * 64 + lane]);
+        for (int q = 0; q < NQ; ++q) r.c[q] = sl_stream_load(cq, lane, q);
     }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        r.va[q] = __builtin_nontemporal_load(&vq[((qb + q) * 2) * 64 + lane]);
-        r.vb[q] = __builtin_nontemporal_load(&vq[((qb + q) * 2 + 1) * 64 + lane]);
+    for (int q = 0; q < NQ; q += 2) {                                 // a scalar base per 4 KiB: the instruction's immediate offset reaches 4095
+        const auto *vh = q ? sl_scalar_ptr(vq + q * 2 * 64) : vq;
+#pragma unroll
+        for (int h = 0; h < 2 && q + h < NQ; ++h) {
+            r.va[q + h] = sl_stream_load(vh, lane, h * 2);
+            r.vb[q + h] = sl_stream_load(vh, lane, h * 2 + 1);
+        }
     }
-    const uint64_t i = s * SL_SLICE + lane;
+    // the row's epilogue operands, from EVERY lane: the lanes past the last row of the matrix's last slice read that row's (and never use
+    // them) — a load under a lane mask is a branch, and a branch around loads leaves the compiler without the count its waits need
+    const uint64_t rows_left = a.n_rows - s * SL_SLICE;                 // >= 1: s is a slice of the matrix
+    const uint32_t li = lane < rows_left ? lane : (uint32_t)rows_left - 1u;
     r.e_d = 0.0; r.e_x = 0.0; r.e_aux = 0.0;
-    if (i < a.n_rows) {
-        if constexpr (EPI == SL_EPI_NEUMANN) { r.e_d = a.dinv[i]; r.e_x = a.x[i]; }
-        else if constexpr (EPI == SL_EPI_RESIDUAL) { r.e_aux = a.aux[i]; }
-        else if constexpr (EPI == SL_EPI_PUSH) { r.e_aux = a.r[i]; r.e_d = a.dinv[i]; r.e_x = a.x[i]; }
+    if constexpr (EPI == SL_EPI_NEUMANN) { r.e_d = sl_scalar_ptr(a.dinv + s * SL_SLICE)[li]; r.e_x = sl_scalar_ptr(a.x + s * SL_SLICE)[li]; }
+    else if constexpr (EPI == SL_EPI_RESIDUAL) { r.e_aux = sl_scalar_ptr(a.aux + s * SL_SLICE)[li]; }
+    else if constexpr (EPI == SL_EPI_PUSH) {
+        r.e_aux = sl_scalar_ptr(a.r + s * SL_SLICE)[li]; r.e_d = sl_scalar_ptr(a.dinv + s * SL_SLICE)[li]; r.e_x = sl_scalar_ptr(a.x + s * SL_SLICE)[li];
     }
 }
 
@@ -475,7 +499,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_ro
     __shared__ double red[2 * NW];
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    // the wave's number as a SCALAR: slice numbers and every stream address derived from them then live in SGPRs (loads take the
+    // saddr + lane-offset form) instead of one 64-bit VGPR pair per stream — the 16-wave instantiation, held to 128 VGPRs, spilled
+    // such a pair and reloaded it from scratch in front of every prefetch (s_waitcnt vmcnt(0): the pipeline drained each slice)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
     if (a.blk_cnt) { if (lb >= a.blk_cnt) return; lb += a.blk_lo; }     // a range of the launch's blocks (block-uniform)
     const uint64_t R = (uint64_t)NW * spw * SL_SLICE;
@@ -519,16 +546,29 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 4 : 1) void sl_band_kernel(sl_ro
         const uint32_t base = (uint32_t)win_lo;
 
         if constexpr (UW > 0 && PIPE) {
-            for (uint32_t j = 0; j < spw; j += 2) {
-                const uint64_t sa = s0 + (uint64_t)j * NW, sb = sa + NW;
-                if (sa >= a.n_slices) break;
-                const bool has_b = (j + 1 < spw) && sb < a.n_slices;
-                if (has_b) sl_slice_load<EPI, UW, C16>(a, sb, lane, rb);
+            // ra holds the wave's first slice.  Steady state: both successors exist, so every load of the body is issued unconditionally
+            // and the compiler's wait counts are exact — slice j + 1's loads stay in flight while slice j is reduced, slice j + 2's are
+            // issued before slice j + 1's are waited for.  (With the loads under `if (next slice exists)` the waits were placed for the
+            // path that skips them: vmcnt(0) a few instructions into every reduction, the loads just issued included.)
+            uint32_t nsl = 0;                                           // this wave's slices: s0, s0 + NW, ... (scalar)
+            if (s0 < a.n_slices) { const uint64_t left = (a.n_slices - s0 + NW - 1) / NW; nsl = left < spw ? (uint32_t)left : spw; }
+            uint32_t j = 0;
+            for (; j + 2 < nsl; j += 2) {
+                const uint64_t sa = s0 + (uint64_t)j * NW, sb = sa + NW, sc = sb + NW;
+                sl_slice_load<EPI, UW, C16>(a, sb, lane, rb);
                 sl_slice_finish<EPI, UW, C16>(a, sa, lane, ra, lw, base, part0, part1);
-                if (!has_b) break;
-                const uint64_t sc = sb + NW;
-                if (j + 2 < spw && sc < a.n_slices) sl_slice_load<EPI, UW, C16>(a, sc, lane, ra);
+                sl_slice_load<EPI, UW, C16>(a, sc, lane, ra);
                 sl_slice_finish<EPI, UW, C16>(a, sb, lane, rb, lw, base, part0, part1);
+            }
+            if (j < nsl) {                                              // one or two slices left, the first of them in ra
+                const uint64_t sa = s0 + (uint64_t)j * NW;
+                if (j + 1 < nsl) {
+                    sl_slice_load<EPI, UW, C16>(a, sa + NW, lane, rb);
+                    sl_slice_finish<EPI, UW, C16>(a, sa, lane, ra, lw, base, part0, part1);
+                    sl_slice_finish<EPI, UW, C16>(a, sa + NW, lane, rb, lw, base, part0, part1);
+                } else {
+                    sl_slice_finish<EPI, UW, C16>(a, sa, lane, ra, lw, base, part0, part1);
+                }
             }
         } else if constexpr (UW > 0) {
             for (uint32_t j = 0; j < spw; ++j) {

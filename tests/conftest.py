@@ -44,7 +44,7 @@ def pytest_sessionstart(session):
 # parity of the hot path first, the other kernels next, single-process surfaces, and only then everything that starts
 # processes (partitioned / dist_abi / multi_device) with the bench subprocesses last.  tests/test_collection_order_host.py pins this list.
 GPU_FILE_ORDER = [
-    "test_gpu_parity", "test_gpu_state", "test_gpu_matrix_trait", "test_gpu_matrix_mutate", "test_gpu_panels", "test_gpu_fullsize", "test_gpu_longrows",
+    "test_gpu_parity", "test_gpu_state", "test_gpu_matrix_trait", "test_gpu_matrix_mutate", "test_gpu_band_geometry", "test_gpu_panels", "test_gpu_fullsize", "test_gpu_longrows",
     "test_gpu_mpass", "test_gpu_order_any", "test_gpu_degenerate", "test_gpu_pagerank", "test_gpu_southwell", "test_gpu_walk", "test_gpu_acl",
     "test_gpu_push_graph", "test_gpu_cg", "test_gpu_session", "test_gpu_optin_oracle", "test_gpu_fuzz", "test_gpu_cli", "test_gpu_partitioned",
     "test_gpu_dist_abi", "test_gpu_multi_device", "test_gpu_bench",

@@ -11,7 +11,7 @@ arithmetic and no control flow:
                                                                                   emulated lanes — which run one after the other — wait for each other: LDS written
                                                                                   by one lane before the wait is read by another lane after it)
   asm volatile("v_mov_b32 %0, 0" : "=v"(x))       -> x = 0
-  asm volatile("" : "+v"(a), ...)                 -> a compiler barrier          (scheduling hints for the real ISA)
+  asm volatile("" : "+v"(a), ...) / "+s"(p)       -> a compiler barrier          (scheduling / register-class hints for the real ISA)
 Compile flags carry -ffp-contract=off like the device build: a product is rounded before it is added."""
 import os
 import re
@@ -53,7 +53,7 @@ REWRITES = [
     (re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s*)?(\w+)\s+(\w+)\[\];"), r"\1 *\2 = static_cast<\1 *>(::simt::block().dyn_lds);"),
     (re.compile(r'asm volatile\("s_waitcnt[^"]*"\s*:::\s*"memory"\);'), 'simt_amdgcn_wave_barrier();'),
     (re.compile(r'asm volatile\("v_mov_b32 %0, 0"\s*:\s*"=v"\((\w+)\)\);'), r"\1 = 0;"),
-    (re.compile(r'asm volatile\(""\s*:\s*"\+v"[^;]*\);'), 'asm volatile("" ::: "memory");'),
+    (re.compile(r'asm volatile\(""\s*:\s*"\+[vs]"[^;]*\);'), 'asm volatile("" ::: "memory");'),
 ]
 
 

@@ -75,7 +75,7 @@ SLOW = [T + "panels.py::test_seven_million_short_rows_many_thin_panels", T + "pa
         T + "pagerank.py::test_spr_generator_and_transposed_query",
         T + "walk.py::test_block_stride_shrinks_beyond_the_generators_period"]       # (2^21 + 4096 walks: seconds on a GPU, many minutes as fibers)
 GROUPS = {
-    "a) matrix trait + error bound (round 5), state object, degenerate inputs": [T + "matrix_trait.py", T + "matrix_mutate.py", T + "state.py", T + "degenerate.py"],
+    "a) matrix trait + error bound (round 5), state object, degenerate inputs, band-kernel slice runs": [T + "matrix_trait.py", T + "matrix_mutate.py", T + "state.py", T + "degenerate.py", T + "band_geometry.py"],
     "b) config 1, golden fixtures, S-DD parity, push frontiers, estimateEntry": [T + "parity.py"],
     "c) long rows, hub columns, sparse launch train": [T + "longrows.py"],
     "d) column panels: dynamic tiles and the paced headline layout": [T + "panels.py"],
