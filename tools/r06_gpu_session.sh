@@ -22,7 +22,9 @@ tests_multi)
 tests)
     timeout 2400 python -m pytest tests -x -q -m gpu --timeout 900 -p no:cacheprovider --durations=40 2>&1 | tee $O/r06_pytest_gpu.txt | tail -60 ;;
 bench)
-    timeout 900 python bench.py > $O/r06_bench_default.json 2>$O/r06_bench_default.err; cut -c1-3000 $O/r06_bench_default.json; tail -n 5 $O/r06_bench_default.err ;;
+    timeout 900 python bench.py > $O/r06_bench_default.json 2>$O/r06_bench_default.err; cut -c1-3000 $O/r06_bench_default.json; tail -n 5 $O/r06_bench_default.err
+    # the band kernel's pipeline was rebuilt this round: the banded variant of the recipe (round 3: 0.326 ms = 0.90) and the 16-wave window (0.81)
+    for w in 4096 8192; do timeout 600 python bench.py --bandwidth $w --no-cpu-baseline --no-sweep > $O/r06_bench_w$w.json 2>$O/r06_bench_w$w.err; cut -c1-1200 $O/r06_bench_w$w.json; done ;;
 profile)
     bash tools/profile.sh r06_uniform --bandwidth 0 2>&1 | tail -12 ;;
 micro)
