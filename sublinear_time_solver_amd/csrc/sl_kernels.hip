@@ -183,7 +183,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32
     __shared__ double red[2 * SL_WAVES_PER_BLOCK];
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;           // speculative solve loop: the stop rule already fired
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // a scalar: slice numbers and stream bases in SGPRs
     // XCD-aware mapping: physical block b is dispatched to XCD b % 8; give every XCD a
     // contiguous range of row blocks so that its private L2 sees one band of the gathered
     // vector (speed only — correctness does not depend on placement).
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(SL_BLOCK) void sl_rows_kernel(sl_row_args a, uint32
 __global__ __launch_bounds__(SL_BLOCK) void sl_rows_add_kernel(sl_row_args a, uint32_t nb8)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // a scalar: slice numbers and stream bases in SGPRs
     const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);
     const uint64_t s = (uint64_t)lb * SL_WAVES_PER_BLOCK + wave;
     if (s >= a.n_slices) return;                                       // whole waves; no block barrier below
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(SL_MP_WAVES * 64, 2) void sl_mpass_kernel(sl_row_ar
     __shared__ double red[2 * SL_MP_WAVES];
     __shared__ unsigned long long occ;
     if (a.ctl && a.gate_it > a.ctl->stop_after) return;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lb = (blockIdx.x & 7u) * nb8 + (blockIdx.x >> 3);        // XCD-aware: an XCD's blocks own one contiguous row range
     constexpr uint64_t R = (uint64_t)SL_MP_WAVES * SPW * SL_SLICE;
     const uint64_t r0 = (uint64_t)lb * R;

@@ -17,10 +17,9 @@ spec = importlib.util.spec_from_file_location("isa_resources", ROOT / "tools" / 
 ISA = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(ISA)
 
-# kernels allowed to touch scratch, with the bytes they had when they were last measured on hardware (the 4-waves-per-SIMD launch bound
-# winning over two registers; not a default path of the headline configurations' hot loop).  The 16-wave band kernel was on this list
-# with 12 bytes until round 6 took its stream addresses out of the VGPRs (scalar wave number, SGPR bases).
-SCRATCH_ALLOWED = {"sl_mpass_kernel<3, 4, 4>": 20}
+# kernels allowed to touch scratch: none.  (Until round 6: the 16-wave band kernel with 12 bytes and the multi-pass push kernel with 20 —
+# both lost them when the wave's number became a scalar and the stream addresses left the VGPRs.)
+SCRATCH_ALLOWED = {}
 # files whose kernels carry the reference's arithmetic: a product is rounded before it is added (no contraction)
 PARITY_FILES = {"sl_kernels.hip", "sl_frontier.hip", "sl_acl.hip", "sl_southwell.hip", "sl_cg.hip", "sl_walk.hip", "sl_matrix.hip"}
 
