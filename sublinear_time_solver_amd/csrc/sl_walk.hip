@@ -55,19 +55,24 @@ __device__ __forceinline__ double walk_lcg(uint64_t &state, uint32_t &draws)
 // coordinate's walk s % W = walk number coordinate * W + s % W of the solve, whatever batch of coordinates the launch holds
 // performRandomWalk (solver.ts:390-432) over the CSR row of the current state; `state` is the generator's state, advanced in place
 // `draws` counts the generator's draws the walk consumed (1 per absorption test, 1 per transition: at most 2000)
+// rd / rs (both or neither): the call's per-row table (sl_walk_table_kernel below) — the row's diagonal and the sum of its transition
+// weights, the two of the three passes over a row that do not depend on the draw; the same operations in the same order, done once per
+// row of the matrix instead of once per visit
 __device__ __forceinline__ double walk_one(uint32_t start, uint64_t &state, const uint32_t *row_ptr, const uint32_t *col_idx, const double *val,
-                                           const double *b, uint32_t &draws)
+                                           const double *b, uint32_t &draws, const double *rd, const double *rs)
 {
     uint32_t cur = start;
     double value = 0.0;
     for (int step = 0; step < 1000; ++step) {
         const uint32_t k0 = row_ptr[cur], k1 = row_ptr[cur + 1];
         double d = 0.0;
-        for (uint32_t k = k0; k < k1; ++k) if (col_idx[k] == cur) d = val[k];
+        if (rd) d = rd[cur];
+        else for (uint32_t k = k0; k < k1; ++k) if (col_idx[k] == cur) d = val[k];
         const double absorb = 1.0 / d;
         if (walk_lcg(state, draws) < fabs(absorb)) { value = __dadd_rn(value, __dmul_rn(b[cur], absorb)); break; }
         double sum = 0.0;
-        for (uint32_t k = k0; k < k1; ++k) if (col_idx[k] != cur) sum = __dadd_rn(sum, fabs(-val[k] / d));
+        if (rs) sum = rs[cur];
+        else for (uint32_t k = k0; k < k1; ++k) if (col_idx[k] != cur) sum = __dadd_rn(sum, fabs(-val[k] / d));
         if (sum == 0.0) { value = __dadd_rn(value, __dmul_rn(b[cur], absorb)); break; }
         const double rnd = __dmul_rn(walk_lcg(state, draws), sum);
         if (rnd <= 0.0) { cur = 0; continue; }
@@ -81,15 +86,27 @@ __device__ __forceinline__ double walk_one(uint32_t start, uint64_t &state, cons
     }
     return value;
 }
+// the table: one lane per row, the scans of walk_one as written there (the LAST stored match is the diagonal; the weights added in storage order)
+__global__ __launch_bounds__(256) void sl_walk_table_kernel(uint64_t n, const uint32_t *row_ptr, const uint32_t *col_idx, const double *val, double *rd, double *rs)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k0 = row_ptr[i], k1 = row_ptr[i + 1];
+    double d = 0.0, sum = 0.0;
+    for (uint32_t k = k0; k < k1; ++k) if (col_idx[k] == (uint32_t)i) d = val[k];
+    for (uint32_t k = k0; k < k1; ++k) if (col_idx[k] != (uint32_t)i) sum = __dadd_rn(sum, fabs(-val[k] / d));
+    rd[i] = d; rs[i] = sum;
+}
 __global__ __launch_bounds__(256) void sl_walk_kernel(uint64_t n_walks, uint32_t seed, uint32_t start_row, uint64_t per_row, uint64_t stride,
-                                                      const uint32_t *row_ptr, const uint32_t *col_idx, const double *val, const double *b, double *values)
+                                                      const uint32_t *row_ptr, const uint32_t *col_idx, const double *val, const double *b, double *values,
+                                                      const double *rd, const double *rs)
 {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n_walks) return;
     const uint64_t coord = per_row ? start_row + s / per_row : start_row;
     uint64_t state = walk_lcg_jump(seed, (per_row ? coord * per_row + s % per_row : s) * stride);
     uint32_t draws = 0;
-    values[s] = walk_one((uint32_t)coord, state, row_ptr, col_idx, val, b, draws);
+    values[s] = walk_one((uint32_t)coord, state, row_ptr, col_idx, val, b, draws, rd, rs);
 }
 // SL_WALK_STREAM_SERIAL — the reference as written (solver.ts:585-601 for one row, :300-326 coordinate after coordinate): ONE lane, ONE
 // stream; walk s starts where walk s - 1 stopped.  n_coords coordinates from start_row, W walks each; the walk values of coordinate c
@@ -103,7 +120,7 @@ __global__ void sl_walk_serial_kernel(uint64_t n_coords, uint64_t W, uint32_t se
     for (uint64_t c = 0; c < n_coords; ++c) {
         double *v = values + (keep_all ? c * W : 0);
         uint32_t draws = 0;
-        for (uint64_t w = 0; w < W; ++w) v[w] = walk_one((uint32_t)(start_row + c), state, row_ptr, col_idx, val, b, draws);
+        for (uint64_t w = 0; w < W; ++w) v[w] = walk_one((uint32_t)(start_row + c), state, row_ptr, col_idx, val, b, draws, nullptr, nullptr);
         double m = 0.0;
         for (uint64_t w = 0; w < W; ++w) m = __dadd_rn(m, v[w]);
         m = m / (double)W;
@@ -132,13 +149,13 @@ __global__ void sl_walk_serial_kernel(uint64_t n_coords, uint64_t W, uint32_t se
 #define SL_WALK_SPEC_CHUNK 4096u
 struct sl_walk_meta { unsigned long long done, next_rel, active_chunks, pad; };
 __global__ __launch_bounds__(256) void sl_walk_spec_kernel(uint64_t M, uint32_t seed, uint64_t base, uint32_t row, const uint32_t *row_ptr, const uint32_t *col_idx,
-                                                           const double *val, const double *b, double *out_val, uint32_t *out_used)
+                                                           const double *val, const double *b, double *out_val, uint32_t *out_used, const double *rd, const double *rs)
 {
     const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= M) return;
     uint64_t state = walk_lcg_jump(seed, base + j);
     uint32_t draws = 0;
-    out_val[j] = walk_one(row, state, row_ptr, col_idx, val, b, draws);
+    out_val[j] = walk_one(row, state, row_ptr, col_idx, val, b, draws, rd, rs);
     out_used[j] = draws;
 }
 __global__ __launch_bounds__(256) void sl_walk_chunk_kernel(uint64_t M, const uint32_t *used, uint32_t *tab)
@@ -215,17 +232,21 @@ __global__ __launch_bounds__(64) void sl_walk_seq_stats_kernel(uint64_t W, const
 
 // Host side of the pipeline: `need` walks from `row`, the stream standing at absolute draw `*pos` (advanced to where it stands afterwards);
 // values[need] in walk order (device).  Buffers are the caller's (sized for max_m positions).
-struct sl_walk_spec_bufs { double *val; uint32_t *used, *tab, *chunk_entry; unsigned long long *chunk_base; sl_walk_meta *meta; uint64_t max_m; };
+struct sl_walk_spec_bufs { double *val; uint32_t *used, *tab, *chunk_entry; unsigned long long *chunk_base; sl_walk_meta *meta; uint64_t max_m; const double *rd, *rs; };
 static sl_status sl_walk_spec_run(const sl_matrix *m, const double *db, uint32_t seed, uint32_t row, uint64_t need, uint64_t *pos, double *d_values,
                                   const sl_walk_spec_bufs &w, hipStream_t s)
 {
-    uint64_t done = 0;
+    uint64_t done = 0, used = 0;                        // walks kept so far, draws they used: the next window is sized from their ratio
     while (done < need) {
-        uint64_t M = (need - done) * 64;
+        // positions the missing walks are expected to span (+ 1/8 and a chunk); before anything is known: 16 per walk (a walk of the
+        // S-DD recipe uses ~20 draws, one on a unit diagonal 1) — a window that falls short is followed by another, one that overshoots
+        // simulated positions for nothing
+        uint64_t M = done ? (uint64_t)((double)(need - done) * (double)used / (double)done) : (need - done) * 16;
+        M += M / 8 + SL_WALK_SPEC_CHUNK;
         M = (M + SL_WALK_SPEC_CHUNK - 1) / SL_WALK_SPEC_CHUNK * SL_WALK_SPEC_CHUNK;
         M = std::min<uint64_t>(std::max<uint64_t>(M, SL_WALK_SPEC_CHUNK), w.max_m);
         const uint64_t nchunks = M / SL_WALK_SPEC_CHUNK;
-        hipLaunchKernelGGL(sl_walk_spec_kernel, dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, s, M, seed, *pos, row, m->d_row_ptr, m->d_col_idx, m->d_values, db, w.val, w.used);
+        hipLaunchKernelGGL(sl_walk_spec_kernel, dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, s, M, seed, *pos, row, m->d_row_ptr, m->d_col_idx, m->d_values, db, w.val, w.used, w.rd, w.rs);
         hipLaunchKernelGGL(sl_walk_chunk_kernel, dim3((uint32_t)nchunks), dim3(256), 0, s, M, w.used, w.tab);
         hipLaunchKernelGGL(sl_walk_chain_kernel, dim3(1), dim3(1), 0, s, M, need - done, w.tab, w.chunk_entry, w.chunk_base, w.meta);
         hipLaunchKernelGGL(sl_walk_emit_kernel, dim3((uint32_t)((nchunks + 63) / 64)), dim3(64), 0, s, M, need - done, w.meta, w.chunk_entry, w.chunk_base, w.used, w.val,
@@ -235,6 +256,7 @@ static sl_status sl_walk_spec_run(const sl_matrix *m, const double *db, uint32_t
         SL_TRY(sl_read_back(&h, w.meta, sizeof(h), s));
         if (!h.done || !h.next_rel) return sl_fail(SL_ALGORITHM_ERROR, "internal: a window of the serial-stream pipeline yielded no walk");
         done += h.done;
+        used += h.next_rel;
         *pos += h.next_rel;
     }
     return SL_OK;
@@ -246,7 +268,21 @@ static sl_status sl_walk_spec_alloc(uint64_t need, DevBuf &val, DevBuf &used, De
     uint64_t max_m = std::min<uint64_t>(std::max<uint64_t>((need * 64 + SL_WALK_SPEC_CHUNK - 1) / SL_WALK_SPEC_CHUNK * SL_WALK_SPEC_CHUNK, SL_WALK_SPEC_CHUNK), cap);
     const uint64_t nchunks = max_m / SL_WALK_SPEC_CHUNK;
     SL_TRY(val.alloc(max_m * 8)); SL_TRY(used.alloc(max_m * 4)); SL_TRY(tab.alloc(max_m * 4)); SL_TRY(ce.alloc(nchunks * 4)); SL_TRY(cb.alloc(nchunks * 8)); SL_TRY(meta.alloc(sizeof(sl_walk_meta)));
-    *w = sl_walk_spec_bufs{val.as<double>(), used.as<uint32_t>(), tab.as<uint32_t>(), ce.as<uint32_t>(), cb.as<unsigned long long>(), static_cast<sl_walk_meta *>(meta.p), max_m};
+    *w = sl_walk_spec_bufs{val.as<double>(), used.as<uint32_t>(), tab.as<uint32_t>(), ce.as<uint32_t>(), cb.as<unsigned long long>(), static_cast<sl_walk_meta *>(meta.p), max_m, nullptr, nullptr};
+    return SL_OK;
+}
+// The per-row table of a call (rd, rs: n doubles each) when the walks are expected to visit at least as many rows as the matrix has —
+// expected_visits = walks (or simulated stream positions) x a few steps; SL_WALK_TABLE=0 / 1 forces it off / on (tests: same bits).
+static sl_status walk_table(const sl_matrix *m, uint64_t expected_visits, DevBuf &rd, DevBuf &rs, const double **prd, const double **prs, hipStream_t s)
+{
+    *prd = *prs = nullptr;
+    const char *e = getenv("SL_WALK_TABLE");
+    const bool on = e && (*e == '0' || *e == '1') ? *e == '1' : expected_visits >= m->n_rows;
+    if (!on || !m->n_rows) return SL_OK;
+    SL_TRY(rd.alloc(m->n_rows * 8)); SL_TRY(rs.alloc(m->n_rows * 8));
+    hipLaunchKernelGGL(sl_walk_table_kernel, dim3((uint32_t)((m->n_rows + 255) / 256)), dim3(256), 0, s, m->n_rows, m->d_row_ptr, m->d_col_idx, m->d_values,
+                       rd.as<double>(), rs.as<double>());
+    *prd = rd.as<double>(); *prs = rs.as<double>();
     return SL_OK;
 }
 // SL_WALK_SERIAL_PLAIN=1: the one-lane kernel instead (the cross-check of the tests)
@@ -320,6 +356,10 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
     sl_timer timer;
     SL_TRY(timer.start(s));
     double *scr = static_cast<double *>(sl_scratch(4096 * sizeof(double)));
+    DevBuf rdbuf, rsbuf;
+    const double *rd = nullptr, *rs = nullptr;
+    if (!(stream == SL_WALK_STREAM_SERIAL && walk_serial_plain()))       // (serial pipeline: 16+ simulated positions per walk kept)
+        SL_TRY(walk_table(m, num_samples * (stream == SL_WALK_STREAM_SERIAL ? 64 : 4), rdbuf, rsbuf, &rd, &rs, s));
     sl_status st = SL_OK;
     double h_sum = 0.0, h_var = 0.0;
     if (!scr) st = sl_fail(SL_ALLOCATION, "scratch");
@@ -331,6 +371,7 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
             DevBuf wv, wu, wt, wce, wcb, wm;
             sl_walk_spec_bufs wb;
             SL_TRY(sl_walk_spec_alloc(num_samples, wv, wu, wt, wce, wcb, wm, &wb));
+            wb.rd = rd; wb.rs = rs;
             uint64_t pos = 0;
             SL_TRY(sl_walk_spec_run(m, db, seed, (uint32_t)row, num_samples, &pos, d_vals, wb, s));
             hipLaunchKernelGGL(sl_walk_seq_stats_kernel, dim3(1), dim3(64), 0, s, num_samples, d_vals, scr, scr + 1);
@@ -341,7 +382,7 @@ extern "C" sl_status sl_estimate_entry_random_walk(const sl_matrix *m, const dou
         res->estimate = h[0]; res->variance = h[1]; res->num_samples = num_samples;
     } else if (st == SL_OK) {
         hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((num_samples + 255) / 256)), dim3(256), 0, s, num_samples, seed, (uint32_t)row, (uint64_t)0,
-                           walk_stride(num_samples), m->d_row_ptr, m->d_col_idx, m->d_values, db, d_vals);
+                           walk_stride(num_samples), m->d_row_ptr, m->d_col_idx, m->d_values, db, d_vals, rd, rs);
         const uint32_t g = (uint32_t)std::min<uint64_t>((num_samples + 255) / 256, 2048);
         hipLaunchKernelGGL(sl_walk_sum_kernel, dim3(g), dim3(256), 0, s, num_samples, d_vals, scr);
         std::vector<double> part(g);
@@ -436,6 +477,9 @@ extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, s
     SL_TRY(vbuf.alloc(batch * num_walks * 8)); SL_TRY(xbuf.alloc(n * 8)); SL_TRY(varbuf.alloc(n * 8)); SL_TRY(ybuf.alloc(n * 8));
     sl_timer timer;
     SL_TRY(timer.start(s));
+    DevBuf rdbuf, rsbuf;
+    const double *rd = nullptr, *rs = nullptr;
+    if (!(serial && walk_serial_plain())) SL_TRY(walk_table(m, n * num_walks, rdbuf, rsbuf, &rd, &rs, s));      // (every row starts >= 100 walks)
     if (serial && n && walk_serial_plain())       // the reference as written: one lane, one stream, coordinate after coordinate
         hipLaunchKernelGGL(sl_walk_serial_kernel, dim3(1), dim3(1), 0, s, n, num_walks, seed, 0u, 0, m->d_row_ptr, m->d_col_idx, m->d_values, db,
                            vbuf.as<double>(), xbuf.as<double>(), varbuf.as<double>());
@@ -443,6 +487,7 @@ extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, s
         DevBuf wv, wu, wt, wce, wcb, wm;
         sl_walk_spec_bufs wb;
         SL_TRY(sl_walk_spec_alloc(num_walks, wv, wu, wt, wce, wcb, wm, &wb));
+        wb.rd = rd; wb.rs = rs;
         uint64_t pos = 0;
         for (uint64_t i = 0; i < n; ++i) {
             SL_TRY(sl_walk_spec_run(m, db, seed, (uint32_t)i, num_walks, &pos, vbuf.as<double>(), wb, s));
@@ -452,7 +497,7 @@ extern "C" sl_status sl_solve_random_walk(const sl_matrix *m, const double *b, s
     for (uint64_t i0 = 0; i0 < n && !serial; i0 += batch) {
         const uint64_t rows = std::min(batch, n - i0), walks = rows * num_walks;
         hipLaunchKernelGGL(sl_walk_kernel, dim3((uint32_t)((walks + 255) / 256)), dim3(256), 0, s, walks, seed, (uint32_t)i0, num_walks, stride,
-                           m->d_row_ptr, m->d_col_idx, m->d_values, db, vbuf.as<double>());
+                           m->d_row_ptr, m->d_col_idx, m->d_values, db, vbuf.as<double>(), rd, rs);
         hipLaunchKernelGGL(sl_walk_rows_kernel, dim3((uint32_t)rows), dim3(256), 0, s, num_walks, vbuf.as<double>(), xbuf.as<double>() + i0, varbuf.as<double>() + i0);
     }
     SL_HIP(hipGetLastError());

@@ -197,6 +197,35 @@ def test_serial_stream_pipeline_equals_the_one_lane_kernel(gpu, monkeypatch):
     assert (sol[("0", "")] == np.concatenate([o["x"], o["variances"], [o["total_variance"]]]).view(np.uint64)).all()
 
 
+def test_row_table_changes_no_bit(gpu, monkeypatch):
+    """a call that expects its walks to visit at least as many rows as the matrix has first tabulates every row's diagonal and the sum of
+    its transition weights (sl_walk_table_kernel) — two of walk_one's three passes over a row, done once per row instead of once per
+    visit.  Same operations in the same order: SL_WALK_TABLE=0 / 1 (forced off / on) must agree bit for bit on per-walk values,
+    estimates, variances, in both stream forms and in the solve, duplicate diagonal entries included (the LAST stored match is the
+    diagonal, as the scan finds it)"""
+    n = 300
+    rp, ci, va, _ = G.sdd_rows(n, 8, seed=5, half_bandwidth=40)
+    rp, ci, va = np.array(rp), np.array(ci), np.array(va)
+    k = int(rp[7])                                                      # row 7: a second stored entry at the diagonal's column
+    ci[k] = 7 if ci[k] != 7 else ci[k]
+    b = np.random.default_rng(8).standard_normal(n)
+    m = S.SparseMatrix.from_csr(rp, ci, va, n, n, keep_csr=True)
+    got = {}
+    for tab in ("0", "1"):
+        monkeypatch.setenv("SL_WALK_TABLE", tab)
+        bv, br = _walk(m, b, 7, 700, 3)
+        sv, sr = _walk(m, b, 7, 700, 3, stream=L.SL_WALK_STREAM_SERIAL)
+        r1 = S.random_walk_solve(m, b, 0.1, 4)
+        r2 = S.random_walk_solve(m, b, 0.1, 4, stream="reference")
+        got[tab] = np.concatenate([bv, [br.estimate, br.variance], sv, [sr.estimate, sr.variance], r1["solution"], r1["variances"], r2["solution"],
+                                   r2["variances"], [r1["total_variance"], r2["total_variance"]]]).view(np.uint64)
+    assert (got["0"] == got["1"]).all()
+    monkeypatch.delenv("SL_WALK_TABLE")
+    ov, om, ovar = O.ts_random_walk_serial(rp, ci, va, b, 7, 700, 3)
+    sv, sr = _walk(m, b, 7, 700, 3, stream=L.SL_WALK_STREAM_SERIAL)     # (the rule's own choice: 700 x 64 >= 300 rows -> table)
+    assert (sv.view(np.uint64) == ov.view(np.uint64)).all() and (sr.estimate, sr.variance) == (om, ovar)
+
+
 def test_block_stride_shrinks_beyond_the_generators_period(gpu):
     """more than 2^21 walks in one call: blocks of 1024 draws instead of a second pass over the same 2048-draw blocks — the
     per-walk values still equal the oracle's block form, and walk s no longer equals walk s + 2^21"""
