@@ -5,6 +5,7 @@ metadata.  profiles/isa_resources.json is the committed record (regenerate: `pyt
 profiles/isa_resources.json`).  A blind edit that spills, loses an occupancy tier, grows a static LDS array or lets an FMA
 contraction into a parity kernel fails HERE instead of on the driver's GPU box."""
 import importlib.util
+import re
 import json
 from pathlib import Path
 
@@ -75,6 +76,13 @@ def test_hot_kernels_keep_their_occupancy_and_lds_geometry(isa):
             assert k["vgpr"] <= 128, (name, k["vgpr"])
         if name.startswith("sl_band_kernel"):                                     # stream addresses live in SGPRs: no spill anywhere in the family
             assert k["scratch_bytes"] == 0 and k["vgpr_spills"] == 0, (name, k)
+    # no pipelined uniform-width band kernel has a loop that issues loads and waits for all of them (tools/isa_resources.py, drained_loops);
+    # the ragged-row batches still do (their loads sit under wave-uniform branches: DESIGN 5.5) — listed, not hidden
+    for name, k in isa.items():
+        if name.startswith("sl_band_kernel") and re.search(r"<\d, [012], (8|16), true,", name):     # (SpMV, Neumann step, residual; the push epilogue reads
+            assert k["drained_loops"] == 0, name                                                   #  its optional per-row threshold / column value and waits)
+        if name.startswith("sl_band_kernel") and re.search(r"<\d, \d, 0, true,", name):
+            assert k["drained_loops"] == 1, name
     # the pipelined uniform-width band kernels (the 0.90 kernel and its 16-wave form): two slices of matrix bytes in registers and room to spare
     for nw in (4, 8, 16):
         assert isa[f"sl_band_kernel<0, 1, 16, true, true, {nw}>"]["vgpr"] <= 116, nw

@@ -72,6 +72,29 @@ def kernel_bodies(asm: str):
     return out
 
 
+def drained_loops(body: str):
+    """loops that issue at least four vector memory loads AND wait for `vmcnt(0)`: a software pipeline that drains — every load in flight
+    is waited for inside the loop that is meant to keep some ahead.  Loop membership is the compiler's own block annotation
+    (`; =>This Inner Loop Header` / `;   in Loop: Header=BBn_m`, innermost loop of a block).  [(header, loads, waits)].  A loop that waits by
+    design (a staging loop in front of a barrier) shows up too: read the kernel before believing the number."""
+    cur, stat = None, {}
+    for ln in body.split("\n"):
+        m = re.match(r"^\.LBB(\d+_\d+):(.*)$", ln)
+        if m:
+            rest = m.group(2)
+            h = re.search(r"in Loop: Header=BB(\d+_\d+)", rest)
+            cur = m.group(1) if "Loop Header" in rest else (h.group(1) if h else None)
+            continue
+        if cur is None or not ln.startswith("\t"):
+            continue
+        st = stat.setdefault(cur, [0, 0])
+        if re.search(r"\b(global|buffer|flat)_load_", ln) and "lds" not in ln:
+            st[0] += 1
+        if re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", ln):
+            st[1] += 1
+    return [(h, l, w) for h, (l, w) in sorted(stat.items()) if l >= 4 and w]
+
+
 def parse_asm(path: Path):
     asm = path.read_text()
     md = re.search(r"^\s*\.amdgpu_metadata\n(.*?)^\s*\.end_amdgpu_metadata", asm, flags=re.M | re.S)
@@ -101,6 +124,7 @@ def parse_asm(path: Path):
             "v_fma_f64": sum(1 for i in ins if i.startswith("v_fma_f64") or i.startswith("v_fmac_f64")),
             "f64_divisions": sum(1 for i in ins if i.startswith("v_div_fixup_f64")),      # each IEEE division expands to 5 v_fma_f64 of its own
             "scratch_ops": sum(1 for i in ins if i.startswith("scratch_") or i.startswith("buffer_store") and "offen" in i),
+            "drained_loops": len(drained_loops(body)),
             "lds_dma_loads": sum(1 for ln in body.split("\n") if re.search(r"\b(global|buffer)_load_(lds_)?dword.*\blds\b|global_load_lds", ln)),
         }
     return res
