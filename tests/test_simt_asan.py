@@ -46,11 +46,14 @@ def test_smoke_is_clean_under_address_sanitizer(asan_lib):
 
 
 # the default CPU suite runs the fast half (about a minute); SIMT_FULL=1 adds the rest; tools/simt_asan_full.sh runs every `-m gpu` file
-FAST = [T + "matrix_mutate.py", T + "matrix_trait.py", T + "walk.py::test_serial_stream_equals_the_executed_reference",
-        T + "panels.py::test_paced_thin_panels_and_empty_super_panels", T + "panels.py::test_paced_runs_longer_than_four_ending_a_panel_followed_by_the_same_row",
-        T + "longrows.py::test_long_rows_spmv_neumann_both_orders", T + "longrows.py::test_hub_columns_and_batched_sparse_rounds_bitwise",
-        T + "fuzz.py::test_random_systems_bitwise[2049-300-17-False]", T + "order_any.py::test_order_any_on_uniform_columns[20000-8-5]", T + "cg.py::test_cg_kat_from_reference_test"]
-REST = [T + "state.py", T + "walk.py::test_walk_values_bitwise_vs_oracle", T + "panels.py::test_paced_ragged_rows_hubs_duplicates",
+FAST = [T + "matrix_mutate.py", T + "walk.py::test_serial_stream_pipeline_equals_the_one_lane_kernel", T + "walk.py::test_row_table_changes_no_bit",
+        T + "band_geometry.py::test_band_kernel_every_slice_run_shape[default]", T + "band_geometry.py::test_band_kernel_every_slice_run_shape[SL_BAND_SPW=1]",
+        T + "panels.py::test_paced_thin_panels_and_empty_super_panels", T + "longrows.py::test_hub_columns_and_batched_sparse_rounds_bitwise",
+        T + "cg.py::test_cg_kat_from_reference_test"]
+REST = [T + "matrix_trait.py", T + "walk.py::test_serial_stream_equals_the_executed_reference",
+        T + "panels.py::test_paced_runs_longer_than_four_ending_a_panel_followed_by_the_same_row", T + "longrows.py::test_long_rows_spmv_neumann_both_orders",
+        T + "fuzz.py::test_random_systems_bitwise[2049-300-17-False]", T + "order_any.py::test_order_any_on_uniform_columns[20000-8-5]",
+        T + "band_geometry.py", T + "state.py", T + "walk.py::test_walk_values_bitwise_vs_oracle", T + "panels.py::test_paced_ragged_rows_hubs_duplicates",
         T + "panels.py::test_ragged_rows_hubs_duplicates_and_dense_push_rounds", T + "fuzz.py::test_paced_panels_random_structures_bitwise[4097-4097-cluster-12-True-2]",
         T + "mpass.py::test_row_slice_of_a_wide_band", T + "cg.py::test_cg_matches_oracle", T + "southwell.py",
         T + "session.py::test_session_survives_flooding_and_round_limit", T + "session.py::test_small_rounds_in_one_workgroup_give_the_same_answers"]
