@@ -15,8 +15,11 @@
 // (The estimator is mirrored as behaviour; SURVEY.md Appendix A10 explains why it is not unbiased in general.)
 // The block stride follows the number of walks of the call (walk_stride below): the generator's period is 2^32 draws, so 2048-draw
 // blocks give 2^21 distinct starting points; a call with more walks takes narrower blocks instead of reading the same block twice.
-// SL_WALK_STREAM_SERIAL is the reference as written: sl_walk_serial_kernel, ONE lane walking the one stream walk after walk and
-// adding mean and variance in walk order — every number bit-identical to solver.ts for the same seed (the parity form).
+// SL_WALK_STREAM_SERIAL is the reference's ONE stream in the reference's order, every number bit-identical to solver.ts for the same seed:
+// by default as a data-parallel pipeline (a walk simulated from every position of a window of the stream, the chain position ->
+// position + draws followed through them: "the serial stream, data-parallel" below), with SL_WALK_SERIAL_PLAIN=1 as written — ONE lane
+// walking the stream walk after walk (sl_walk_serial_kernel, the tests' cross-check).  Mean and variance are added in walk order.
+// Calls that expect to visit at least as many rows as the matrix has tabulate the rows' diagonals and weight sums first (walk_table).
 #include "sl_internal.hpp"
 #include <algorithm>
 #include <cmath>
