@@ -116,6 +116,25 @@ __device__ __forceinline__ double sl_row_walk(const sl_row_args &a, uint64_t s, 
 
 // Epilogue of a live row.  e_t / e_d / e_x were fetched before the row walk; dself = the gathered
 // vector's own entry (PUSH only).
+// SL_EPI_PUSH (dense round of the thresholded push): x_i += delta_i (the frontier being consumed); r -= A delta; next
+// frontier value delta'_i = r_i * dinv_i where |.| >= theta, else 0.  thr = the row's threshold, zc = the column's constant value
+// (column-constant operators: a.zout) — fetched by the caller's functions WHERE THEY ARE USED: the one-slice-per-wave kernels load them
+// there (no register held across the row walk), the pipelined band kernel hands over what it had in flight with the row's other vectors
+template <class THR, class ZC>
+__device__ __forceinline__ void sl_push_epilogue(const sl_row_args &a, uint64_t i, double sum, double e_t, double e_d, double e_x, double dself,
+                                                 THR thr, ZC zc, double &part0, double &part1)
+{
+    if (dself != 0.0) a.x[i] = DADD(e_x, dself);
+    const double rn = DSUB(e_t, sum);
+    a.r[i] = rn;
+    const double p = DMUL(rn, e_d);
+    const bool f = fabs(p) >= thr();
+    const double dn = f ? p : 0.0;
+    a.out[i] = dn;
+    if (a.zout) a.zout[i] = DMUL(zc(), dn);       // column-constant operator: the one product every entry of column i will contribute next round
+    part0 = DADD(part0, DMUL(rn, rn));
+    part1 += f ? 1.0 : 0.0;
+}
 template <int EPI>
 __device__ __forceinline__ void sl_row_epilogue(const sl_row_args &a, uint64_t i, double sum, double e_t, double e_d,
                                                 double e_x, double dself, double &part0, double &part1)
@@ -140,19 +159,8 @@ __device__ __forceinline__ void sl_row_epilogue(const sl_row_args &a, uint64_t i
         const double rr = DSUB(sum, e_t);
         if (a.out) a.out[i] = rr;
         part0 = DADD(part0, DMUL(rr, rr));
-    } else { // SL_EPI_PUSH (dense round of the thresholded push):
-        // x_i += delta_i (the frontier being consumed); r -= A delta; next frontier value
-        // delta'_i = r_i * dinv_i where |.| >= theta, else 0.
-        if (dself != 0.0) a.x[i] = DADD(e_x, dself);
-        const double rn = DSUB(e_t, sum);
-        a.r[i] = rn;
-        const double p = DMUL(rn, e_d);
-        const bool f = fabs(p) >= (a.theta_rows ? a.theta_rows[i] : a.theta);
-        const double dn = f ? p : 0.0;
-        a.out[i] = dn;
-        if (a.zout) a.zout[i] = DMUL(a.zcol[i], dn);       // column-constant operator: the one product every entry of column i will contribute next round
-        part0 = DADD(part0, DMUL(rn, rn));
-        part1 += f ? 1.0 : 0.0;
+    } else { // SL_EPI_PUSH
+        sl_push_epilogue(a, i, sum, e_t, e_d, e_x, dself, [&] { return a.theta_rows ? a.theta_rows[i] : a.theta; }, [&] { return a.zcol[i]; }, part0, part1);
     }
 }
 
@@ -245,6 +253,7 @@ struct sl_slice_regs {
     u32x4 c[UW > 0 ? (C16 ? UW / 8 : UW / 4) : 1];
     f64x2 va[UW > 0 ? UW / 4 : 1], vb[UW > 0 ? UW / 4 : 1];
     double e_d, e_x, e_aux;
+    double e_th, e_z;          // push epilogue: the row's threshold and column value (where the launch has them)
 };
 
 // A wave-uniform pointer pinned to an SGPR pair and opaque to the optimiser.  Without it the compiler hoists `stream + lane * 16` out of
@@ -297,6 +306,10 @@ __device__ __forceinline__ void sl_slice_load(const sl_row_args &a, uint64_t s, 
     else if constexpr (EPI == SL_EPI_RESIDUAL) { r.e_aux = sl_scalar_ptr(a.aux + s * SL_SLICE)[li]; }
     else if constexpr (EPI == SL_EPI_PUSH) {
         r.e_aux = sl_scalar_ptr(a.r + s * SL_SLICE)[li]; r.e_d = sl_scalar_ptr(a.dinv + s * SL_SLICE)[li]; r.e_x = sl_scalar_ptr(a.x + s * SL_SLICE)[li];
+        // the optional per-row threshold / column value: always a load (of dinv again — the same line, a hit — where the launch has none), never
+        // a load under a branch
+        r.e_th = sl_scalar_ptr((a.theta_rows ? a.theta_rows : a.dinv) + s * SL_SLICE)[li];
+        r.e_z = sl_scalar_ptr((a.zout ? a.zcol : a.dinv) + s * SL_SLICE)[li];
     }
 }
 
@@ -343,7 +356,7 @@ __device__ __forceinline__ void sl_slice_finish(const sl_row_args &a, uint64_t s
     if (i < a.n_rows) {
         const double own = lw[rowpos];                                   // the gathered vector's own entry
         if constexpr (EPI == SL_EPI_NEUMANN) sl_row_epilogue<EPI>(a, i, sum, own, r.e_d, r.e_x, 0.0, part0, part1);
-        else if constexpr (EPI == SL_EPI_PUSH) sl_row_epilogue<EPI>(a, i, sum, r.e_aux, r.e_d, r.e_x, own, part0, part1);
+        else if constexpr (EPI == SL_EPI_PUSH) sl_push_epilogue(a, i, sum, r.e_aux, r.e_d, r.e_x, own, [&] { return a.theta_rows ? r.e_th : a.theta; }, [&] { return r.e_z; }, part0, part1);
         else sl_row_epilogue<EPI>(a, i, sum, r.e_aux, 0.0, 0.0, 0.0, part0, part1);
     }
 }

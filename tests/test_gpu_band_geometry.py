@@ -5,7 +5,7 @@ the current slice exist) and a tail of one or two slices.  How many slices a wav
 block, slices per wave) and from where the matrix ends — so the geometry knobs (read once per process: a child process per setting)
 are swept over matrices whose last block is cut at every position: one slice, two, odd counts, a last slice with fewer than 64
 rows, a matrix smaller than one block.  Every result must have the bits of the sequential reference loop (sparse.rs:187-203 through the
-fused Neumann step, neumann.rs:252-299)."""
+fused Neumann step, neumann.rs:252-299, and the dense push round)."""
 import os
 import subprocess
 import sys
@@ -40,12 +40,24 @@ for k in (8, 16):
                 continue
             rp, ci, va, b = banded(n, k, hb, n + k + hb)
             x = np.cos(np.arange(n) * 0.37)
-            m = S.SparseMatrix.from_csr(rp, ci, va, n, n)
+            m = S.SparseMatrix.from_csr(rp, ci, va, n, n, with_transpose=True)
             assert m.info().bandwidth <= hb
             assert (m.multiply_vector(x).view(np.uint64) == O.spmv(rp, ci, va, x).view(np.uint64)).all(), (k, hb, n)
             g = S.NeumannSolver().solve(m, b, S.SolverOptions(tolerance=1e-9, max_iterations=100))
             o = O.neumann_solve(rp, ci, va, b, tolerance=1e-9, max_iterations=100)
             assert g.iterations == o["iterations"] and (g.solution.view(np.uint64) == o["x"].view(np.uint64)).all(), (k, hb, n)
+            # the thresholded push with every round dense (dense_switch below any frontier): the same kernel with the push epilogue, whose
+            # threshold / column operands travel with the slice's other vectors
+            if n <= 1000 or (k == 8 and hb == 30):
+                g = S.PushSolver(theta=1e-7, dense_switch=1e-9).solve(m, b)
+                o = O.push_sync_solve(rp, ci, va, b, theta=1e-7)
+                assert g["rounds"] == o["rounds"] and g["pushes"] == o["pushes"] and g["dense_rounds"] > 0, (k, hb, n)
+                assert (g["solution"].view(np.uint64) == o["x"].view(np.uint64)).all() and (g["residual"].view(np.uint64) == o["r"].view(np.uint64)).all(), (k, hb, n)
+                thr = 1e-7 * (1.0 + (np.arange(n) % 5))                   # per-row thresholds (the degree-scaled rule's operand)
+                g = S.PushSolver(theta=1e-7, dense_switch=1e-9, theta_rows=thr).solve(m, b)
+                o = O.push_sync_solve(rp, ci, va, b, theta=1e-7, theta_rows=thr)
+                assert g["rounds"] == o["rounds"] and g["pushes"] == o["pushes"], (k, hb, n, "theta_rows")
+                assert (g["solution"].view(np.uint64) == o["x"].view(np.uint64)).all() and (g["residual"].view(np.uint64) == o["r"].view(np.uint64)).all(), (k, hb, n)
             cases += 1
 print("band geometry ok", cases)
 """
