@@ -83,6 +83,11 @@ def test_hot_kernels_keep_their_occupancy_and_lds_geometry(isa):
             assert k["drained_loops"] == 0, name                                                   #  column value travel with the slice's other vectors)
         if name.startswith("sl_band_kernel") and re.search(r"<\d, \d, 0, true,", name):
             assert k["drained_loops"] == 1, name
+    # the paced headline kernel: the only loop that waits for everything in flight is the ROUND (tile pointers, span, one wait in front of the
+    # epilogue): the chunk pipeline never did, and since round 6 the per-row epilogue loop does not either (4 rows' vectors in flight together)
+    for name, k in isa.items():
+        if name.startswith("sl_pw_kernel"):
+            assert k["drained_loops"] == 1, (name, k["drained_loops"])
     # the pipelined uniform-width band kernels (the 0.90 kernel and its 16-wave form): two slices of matrix bytes in registers and room to spare
     for nw in (4, 8, 16):
         assert isa[f"sl_band_kernel<0, 1, 16, true, true, {nw}>"]["vgpr"] <= 116, nw
