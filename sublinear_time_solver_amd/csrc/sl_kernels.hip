@@ -882,6 +882,64 @@ __device__ __forceinline__ void sl_ordered_accumulate(double *acc, uint32_t lane
     }
 }
 
+
+// The epilogue of a tile whose rows' running sums sit in LDS (acc[slot], slots < nslots): a lane owns slots lane, lane + 64, ...; row_of(slot)
+// = the slot's local row, or ~0 for none.  The vectors of SL_PW_EPI_ROWS of a lane's rows are in flight together and every load is
+// unconditional (a slot without a row reads row 0's operands and uses none; the push epilogue's optional threshold / column value are read
+// from dinv's line again where the launch has none).  As one row per trip — loads, wait, arithmetic, stores, and `s_waitcnt vmcnt(0)` at
+// the head of the next trip (the compiler's wait for values loaded before the loop, which then also waits for the trip's own stores) — a
+// paced round's ~20 trips were 20 serialised memory round trips per wave at the very moment the block's 16 paced waves all stop
+// streaming: round 3 measured 0.875 ms without the epilogue vectors against 0.944 with them, for 17 % of the bytes.  The rows are finished in
+// slot order: the partial sums add the same terms in the same sequence as the one-row loop.
+#ifndef SL_PW_EPI_ROWS
+#define SL_PW_EPI_ROWS 4          // (a paced round has rpw / 64 ~ 20 slots per lane, a dynamic tile 32)
+#endif
+template <int EPI, bool NO_VECTORS, class ROWOF>
+__device__ __forceinline__ void sl_tile_epilogue(const sl_row_args &a, const double *__restrict__ g, const double *acc, uint32_t lane, uint32_t nslots, ROWOF row_of,
+                                                 double &part0, double &part1)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // once per tile, not once per trip
+    for (uint32_t r0 = lane; r0 < nslots; r0 += 64u * SL_PW_EPI_ROWS) {
+        bool ok[SL_PW_EPI_ROWS];
+        uint64_t ri[SL_PW_EPI_ROWS];
+        double e_t[SL_PW_EPI_ROWS], e_d[SL_PW_EPI_ROWS], e_x[SL_PW_EPI_ROWS], dself[SL_PW_EPI_ROWS];
+        [[maybe_unused]] double e_th[SL_PW_EPI_ROWS], e_z[SL_PW_EPI_ROWS];      // push: the row's threshold / column value where the launch has them
+        [[maybe_unused]] const double *thp = a.theta_rows ? a.theta_rows : a.dinv, *zp = a.zout ? a.zcol : a.dinv;     // (else dinv's line again: never a load under a branch)
+#pragma unroll
+        for (int u = 0; u < SL_PW_EPI_ROWS; ++u) {
+            const uint32_t r = r0 + 64u * (uint32_t)u;
+            const uint64_t i = r < nslots ? row_of(r) : ~0ull;
+            ok[u] = i < a.n_rows;
+            ri[u] = ok[u] ? i : 0;
+            e_t[u] = 0.0; e_d[u] = 0.0; e_x[u] = 0.0; dself[u] = 0.0;
+            if constexpr (!NO_VECTORS) {
+                if constexpr (EPI == SL_EPI_NEUMANN) { e_t[u] = g[a.row_offset + ri[u]]; e_d[u] = a.dinv[ri[u]]; e_x[u] = a.x[ri[u]]; }
+                else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t[u] = a.aux[ri[u]]; }
+                else if constexpr (EPI == SL_EPI_PUSH) {
+                    e_t[u] = a.r[ri[u]]; e_d[u] = a.dinv[ri[u]]; e_x[u] = a.x[ri[u]]; dself[u] = g[a.row_offset + ri[u]];
+                    e_th[u] = thp[ri[u]]; e_z[u] = zp[ri[u]];
+                }
+            }
+        }
+        if (a.n_long) {                                           // hub rows belong to the long-row kernel
+            uint32_t rl[SL_PW_EPI_ROWS];
+#pragma unroll
+            for (int u = 0; u < SL_PW_EPI_ROWS; ++u) rl[u] = a.row_len[ri[u]];
+#pragma unroll
+            for (int u = 0; u < SL_PW_EPI_ROWS; ++u) ok[u] = ok[u] && rl[u] != SL_LONG_SENTINEL;
+        }
+#pragma unroll
+        for (int u = 0; u < SL_PW_EPI_ROWS; ++u) {
+            if (!ok[u]) continue;
+            const uint32_t r = r0 + 64u * (uint32_t)u;
+            if constexpr (NO_VECTORS) part0 += acc[r];
+            else if constexpr (EPI == SL_EPI_PUSH)
+                sl_push_epilogue(a, ri[u], acc[r], e_t[u], e_d[u], e_x[u], dself[u], [&] { return a.theta_rows ? e_th[u] : a.theta; }, [&] { return e_z[u]; }, part0, part1);
+            else sl_row_epilogue<EPI>(a, ri[u], acc[r], e_t[u], e_d[u], e_x[u], dself[u], part0, part1);
+        }
+    }
+}
+
 // ---- column-panel kernel: gathers served by the L2 -----------------------------------------------------
 // For matrices whose columns are spread over a vector far larger than the L2 (uniformly random columns — the reference
 // generators' recipe): every gather of the general kernel misses L2, and misses are served at 58 G/s whatever the table size
@@ -927,15 +985,7 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
                 sl_ordered_accumulate<12>(acc, lane, row, prod, cl[u] >> SL_PANEL_COL_BITS);
             }
         }
-        for (uint32_t r = lane; r < SL_PANEL_TILE; r += 64) {
-            const uint64_t i = (uint64_t)tile * SL_PANEL_TILE + r;
-            if (i >= a.n_rows || (a.n_long && a.row_len[i] == SL_LONG_SENTINEL)) continue;
-            double e_t = 0.0, e_d = 0.0, e_x = 0.0, dself = 0.0;
-            if constexpr (EPI == SL_EPI_NEUMANN) { e_t = g[a.row_offset + i]; e_d = a.dinv[i]; e_x = a.x[i]; }
-            else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t = a.aux[i]; }
-            else if constexpr (EPI == SL_EPI_PUSH) { e_t = a.r[i]; e_d = a.dinv[i]; e_x = a.x[i]; dself = g[a.row_offset + i]; }
-            sl_row_epilogue<EPI>(a, i, acc[r], e_t, e_d, e_x, dself, part0, part1);
-        }
+        sl_tile_epilogue<EPI, false>(a, g, acc, lane, SL_PANEL_TILE, [&](uint32_t r) -> uint64_t { return (uint64_t)tile * SL_PANEL_TILE + r; }, part0, part1);
     }
     sl_block_partials<EPI, SL_PANEL_WAVES>(a, red, lane, wave, lb, a.part_stride, part0, part1);
 }
@@ -958,9 +1008,6 @@ __global__ __launch_bounds__(SL_PANEL_WAVES * 64) void sl_panel_kernel(sl_row_ar
 // Two forms of the layout share the kernel (launch parameters pw_deal / pw_pbits): uniform columns — panels of 2^16 columns, row
 // groups dealt among ALL tiles, gathers served by the L2 as described; wide bands — panels of 2^9..2^10 columns, row groups dealt
 // among the 16 tiles of ONE block, so that the CU's waves gather from the same few KB of vector: hits in its own L1.
-#ifndef SL_PW_EPI_ROWS
-#define SL_PW_EPI_ROWS 4          // rows of a lane whose epilogue vectors are in flight together (a round has rpw / 64 ~ 20 per lane)
-#endif
 #ifndef SL_PW_SLEEP
 #define SL_PW_SLEEP 4            // s_sleep argument of a paced wave that waits (x 64 cycles)
 #endif
@@ -1091,50 +1138,11 @@ __global__ __launch_bounds__(SL_PW_WAVES * 64) void sl_pw_kernel(sl_row_args a)
         }
         if (lane == 0) prog_st(wave, (round + 1u) << 20);            // as far along as the round's end while the vectors are written
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // The round's epilogue: slot r = group r / 16 of the tile, row r % 16 of the group; a lane owns slots lane, lane + 64, ...  The vectors
-        // of SL_PW_EPI_ROWS of a lane's rows are in flight together and every load is unconditional (a slot without a row reads row 0's operands
-        // and uses none).  As one row per trip — loads, wait, arithmetic, stores, and `s_waitcnt vmcnt(0)` at the head of the next trip (the
-        // compiler's wait for values loaded before the loop, which then also waits for the trip's own stores) — a round's ~20 trips were 20
-        // serialised memory round trips per wave at the very moment the block's 16 paced waves all stop streaming: round 3 measured 0.875 ms
-        // without the epilogue vectors against 0.944 with them, for 17 % of the bytes.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // once per round, not once per trip
-        for (uint32_t r0 = lane; r0 < rpw; r0 += 64u * SL_PW_EPI_ROWS) {
-            bool ok[SL_PW_EPI_ROWS];
-            uint64_t ri[SL_PW_EPI_ROWS];
-            double e_t[SL_PW_EPI_ROWS], e_d[SL_PW_EPI_ROWS], e_x[SL_PW_EPI_ROWS], dself[SL_PW_EPI_ROWS];
-            [[maybe_unused]] double e_th[SL_PW_EPI_ROWS], e_z[SL_PW_EPI_ROWS];      // push: the row's threshold / column value where the launch has them
-            [[maybe_unused]] const double *thp = a.theta_rows ? a.theta_rows : a.dinv, *zp = a.zout ? a.zcol : a.dinv;     // (else dinv's line again: never a load under a branch)
-#pragma unroll
-            for (int u = 0; u < SL_PW_EPI_ROWS; ++u) {
-                const uint32_t r = r0 + 64u * (uint32_t)u;
-                const uint32_t gl = (r / SL_PW_GROUP) * deal + tdeal;
-                const uint64_t i = (g0 + gl) * SL_PW_GROUP + (r % SL_PW_GROUP);
-                ok[u] = r < rpw && gl < gcnt && i < a.n_rows;           // (gl >= gcnt: a span shorter than its tiles' slots)
-                ri[u] = ok[u] ? i : 0;
-                e_t[u] = 0.0; e_d[u] = 0.0; e_x[u] = 0.0; dself[u] = 0.0;
-                if constexpr (!(PWV & 8)) {
-                    if constexpr (EPI == SL_EPI_NEUMANN) { e_t[u] = g[a.row_offset + ri[u]]; e_d[u] = a.dinv[ri[u]]; e_x[u] = a.x[ri[u]]; }
-                    else if constexpr (EPI == SL_EPI_RESIDUAL) { e_t[u] = a.aux[ri[u]]; }
-                    else if constexpr (EPI == SL_EPI_PUSH) {
-                        e_t[u] = a.r[ri[u]]; e_d[u] = a.dinv[ri[u]]; e_x[u] = a.x[ri[u]]; dself[u] = g[a.row_offset + ri[u]];
-                        e_th[u] = thp[ri[u]]; e_z[u] = zp[ri[u]];
-                    }
-                }
-            }
-            if (a.n_long) {                                           // hub rows belong to the long-row kernel
-#pragma unroll
-                for (int u = 0; u < SL_PW_EPI_ROWS; ++u) if (ok[u] && a.row_len[ri[u]] == SL_LONG_SENTINEL) ok[u] = false;
-            }
-#pragma unroll
-            for (int u = 0; u < SL_PW_EPI_ROWS; ++u) {
-                if (!ok[u]) continue;
-                const uint32_t r = r0 + 64u * (uint32_t)u;
-                if constexpr (PWV & 8) part0 += acc[r];
-                else if constexpr (EPI == SL_EPI_PUSH)
-                    sl_push_epilogue(a, ri[u], acc[r], e_t[u], e_d[u], e_x[u], dself[u], [&] { return a.theta_rows ? e_th[u] : a.theta; }, [&] { return e_z[u]; }, part0, part1);
-                else sl_row_epilogue<EPI>(a, ri[u], acc[r], e_t[u], e_d[u], e_x[u], dself[u], part0, part1);
-            }
-        }
+        // the round's epilogue: slot r = group r / 16 of the tile, row r % 16 of the group
+        sl_tile_epilogue<EPI, (PWV & 8) != 0>(a, g, acc, lane, rpw, [&](uint32_t r) -> uint64_t {
+            const uint32_t gl = (r / SL_PW_GROUP) * deal + tdeal;
+            return gl < gcnt ? (g0 + gl) * SL_PW_GROUP + (r % SL_PW_GROUP) : ~0ull;          // (gl >= gcnt: a span shorter than its tiles' slots)
+        }, part0, part1);
     }
     // (a range of rounds that does not start at round 0 = the second of two launches: its own set of partial sums behind the first's)
     sl_block_partials<EPI, SL_PW_WAVES>(a, red, lane, wave, blockIdx.x + (round_lo ? nblocks : 0u), a.part_stride, part0, part1);

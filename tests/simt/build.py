@@ -62,8 +62,8 @@ REWRITES = [
 # issue order").  The emulated lanes run one after the other, so the order has to be made explicit there: a wave barrier is inserted
 # in the emulated copy (on the hardware it would be a no-op).  (file, anchor line that must exist exactly once, text inserted before it)
 SYNC_POINTS = [
-    ("sl_kernels.hip", "        for (uint32_t r = lane; r < SL_PANEL_TILE; r += 64) {\n            const uint64_t i = (uint64_t)tile * SL_PANEL_TILE + r;",
-     "        simt_amdgcn_wave_barrier();      // (emulator) the running sums of the last group are in LDS before any lane reads its rows' slots\n"),
+    # (none at present.  Until round 6 the dynamic-tile panel kernel read its rows' slots right behind the last group's LDS updates; its epilogue
+    #  — sl_tile_epilogue — now opens with `s_waitcnt vmcnt(0)`, which the rewrite above turns into the wave barrier this list used to insert.)
 ]
 
 
