@@ -4,6 +4,8 @@
     python tools/isa_resources.py                     # compile csrc/*.hip with the Makefile's flags, print a table
     python tools/isa_resources.py --json out.json     # ... and write {kernel: {vgpr, agpr, sgpr, scratch, lds, spills, waves_per_simd, ...}}
     python tools/isa_resources.py --asm-dir DIR       # reuse DIR/<file>.s where newer than the source
+    python tools/isa_resources.py --skeleton 'sl_pw_kernel<1'   # loop headers, vector loads / stores and s_waitcnt of a kernel, in order:
+                                                      # how many loads a software pipeline really keeps in flight
 
 What a blind edit can break without failing a CPU test — a spill to scratch, an occupancy tier lost to a few registers, an LDS
 array that no longer leaves room for a second block — shows up here; tests/test_isa_host.py pins the hot kernels against
@@ -154,14 +156,30 @@ def main():
     ap.add_argument("--json")
     ap.add_argument("--asm-dir")
     ap.add_argument("--match", default="", help="only kernels whose name contains this")
+    ap.add_argument("--skeleton", default="", help="print the memory skeleton (loop headers, vector loads / stores, s_waitcnt) of the kernels whose name contains this")
     ap.add_argument("sources", nargs="*")
     a = ap.parse_args()
     res = collect(a.sources or None, a.asm_dir)
     rows = sorted(res.items())
-    print(f"{'kernel':78s} {'vgpr':>4s} {'agpr':>4s} {'sgpr':>4s} {'scr':>5s} {'lds':>6s} {'w/simd':>6s} {'instr':>6s}")
+    if not a.skeleton:
+        print(f"{'kernel':78s} {'vgpr':>4s} {'agpr':>4s} {'sgpr':>4s} {'scr':>5s} {'lds':>6s} {'w/simd':>6s} {'instr':>6s}")
     for name, r in rows:
-        if a.match in name:
+        if a.match in name and not a.skeleton:
             print(f"{name[:78]:78s} {r['vgpr']:4d} {r['agpr']:4d} {r['sgpr']:4d} {r['scratch_bytes']:5d} {r['lds_static_bytes']:6d} {r['waves_per_simd']:6d} {r['instructions']:6d}")
+    if a.skeleton:
+        import tempfile
+        tmp = Path(a.asm_dir) if a.asm_dir else None
+        if tmp is None:
+            tmp = Path(tempfile.mkdtemp(prefix="sl_isa_"))
+            collect(a.sources or None, tmp)
+        for path in sorted(tmp.glob("*.s")):
+            bodies = kernel_bodies(path.read_text())
+            for mangled, full in zip(bodies, demangle(list(bodies))):
+                if a.skeleton in full:
+                    print(f"== {short_name(full)}   drained loops: {drained_loops(bodies[mangled])}")
+                    for i, ln in enumerate(bodies[mangled].split("\n")):
+                        if re.search(r"Loop Header|\b(global|buffer|flat|scratch)_(load|store)|s_waitcnt|s_barrier", ln):
+                            print(f"{i:6d}  {ln.strip()[:110]}")
     if a.json:
         Path(a.json).write_text(json.dumps(dict(rows), indent=1, sort_keys=True) + "\n")
     return 0
