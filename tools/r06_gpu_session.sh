@@ -35,6 +35,7 @@ optin)
     for f in 0 1; do SL_CG_FUSED_DOT=$f timeout 300 python tools/cg_bench.py > $O/r06_cg_bench_fused$f.json 2>$O/r06_cg_fused$f.err; cat $O/r06_cg_bench_fused$f.json; done
     for f in 0 1; do SL_PUSH_SMALL=$f timeout 600 python tools/pagerank_query.py --no-full-solve > $O/r06_pagerank_small$f.json 2>$O/r06_pagerank_small$f.err; tail -c 2500 $O/r06_pagerank_small$f.json; echo; done
     for f in 0 1; do SL_PW_INDEX_ONLY=$f timeout 900 python tools/pagerank_query.py --thetas 1e-5 > $O/r06_pagerank_idx$f.json 2>$O/r06_pagerank_idx$f.err; head -c 900 $O/r06_pagerank_idx$f.json; echo; done
+    timeout 900 bash tools/ab_epi_rows.sh > $O/r06_ab_epi_rows.txt 2>&1; cat $O/r06_ab_epi_rows.txt
     timeout 600 python tools/walk_bench.py > $O/r06_walk_bench.json 2>$O/r06_walk_bench.err; tail -c 1200 $O/r06_walk_bench.json; echo
     for w in 8 16 32; do SL_QUERY_WIDE=$w timeout 600 python tools/pagerank_query.py --no-full-solve > $O/r06_pagerank_wide$w.json 2>$O/r06_pagerank_wide$w.err; tail -c 1500 $O/r06_pagerank_wide$w.json; echo; done ;;
 *)
